@@ -1,0 +1,115 @@
+# -*- coding:utf-8 -*-
+"""ctypes binding of libdt_hip.so (the C-ABI declared in include/dt_hip.h).
+
+This is the stub a DeepTables maintainer would add next to deeptables/models/layers.py to call
+the MI355X kernels.  `import torch` MUST come first: the library's
+NEEDED libamdhip64.so.7 then binds to the HIP runtime torch already loaded, so
+`tensor.data_ptr()` and `torch.cuda.current_stream().cuda_stream` are valid in our launches.
+
+There is no CPU fallback: `lib()` raises if the shared object is missing.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdt_hip.so')
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_f32 = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/dt_hip.h one to one
+SIGNATURES = {
+    'dt_version': (_c_int, []),
+    'dt_last_error': (ctypes.c_char_p, []),
+    'dt_build_arch': (ctypes.c_char_p, []),
+    'dt_embedding_fwd': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr,
+                                  _ptr, _ptr]),
+    'dt_embedding_bwd_dense': (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
+    'dt_fm_fwd': (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_fm_bwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_embed_fm_linear_fwd': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
+                                        _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'dt_embed_fm_linear_bwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _c_int,
+                                        _ptr, _ptr]),
+    'dt_bn_workspace_bytes': (_c_i64, [_c_int, _c_int]),
+    'dt_bn_train_fwd': (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr,
+                                 _ptr, _ptr, _ptr, _ptr]),
+    'dt_bn_infer_fwd': (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr, _c_f32, _ptr, _ptr, _ptr, _ptr]),
+    'dt_bn_train_bwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                 _ptr]),
+    'dt_cross_workspace_bytes': (_c_i64, [_c_int, _c_int, _c_int]),
+    'dt_cross_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_cross_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr,
+                              _ptr, _ptr]),
+    'dt_inner_product_fwd': (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_inner_product_bwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_outer_product_fwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_outer_product_bwd': (_c_int, [_ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr,
+                                      _ptr]),
+    'dt_cin_layer_fwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_i64, _c_i64, _ptr, _ptr]),
+    'dt_cin_layer_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
+                                 _ptr, _ptr, _ptr, _ptr]),
+    'dt_adam_dense_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32,
+                                    _ptr]),
+    'dt_adam_rows_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _c_int, _c_f32,
+                                   _c_f32, _c_f32, _c_f32, _ptr]),
+}
+
+DT_IDX_F32, DT_IDX_I32 = 0, 1
+DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
+DT_OP_KERNEL = {'mat': 0, 'vec': 1, 'num': 2}
+
+_lib = None
+
+
+class DtHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(hipcc --offload-arch=gfx950). deeptables_amd has no CPU fallback for the layers hot path.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().dt_last_error().decode('utf-8', 'replace')
+        raise DtHipError(f'{what} failed with code {rc}: {msg}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DtHipError('deeptables_amd kernels run on the GPU only (got a CPU tensor); '
+                             'there is deliberately no CPU fallback for the hot path.')

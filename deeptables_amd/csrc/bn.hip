@@ -1,0 +1,282 @@
+// bn.hip — Keras-semantics BatchNormalization over the rows of x[N,C].
+//
+// Replaces keras BatchNormalization(name='bn_concat_emb_dense') in
+// deeptables/models/deepmodel.py:359 (and the BatchNormalization at the end of
+// MultiheadAttention.call, deeptables/models/layers.py:152, with N = batch*fields):
+// biased batch variance, epsilon 1e-3 and momentum 0.99 by default (passed in), moving
+// statistics updated with the biased variance.
+//
+// HBM-bound column reduction: a block owns a chunk of rows and all C columns; threads are laid
+// out (row-lane, column) with the column index fastest so every wave reads contiguous row
+// segments.  Per column the block accumulates SHIFTED sums (shift = first row of the chunk) so
+// the M2 it reports does not suffer E[x^2]-E[x]^2 cancellation; chunk results are merged with
+// Chan's parallel formula in a one-thread-per-column finalize kernel.
+#include "common.h"
+
+namespace dt {
+
+constexpr int kBnThreads = 256;
+constexpr int kBnMaxChunks = 512;
+
+static int bn_chunks(int N) {
+    int c = ceil_div(N, 32);
+    if (c > kBnMaxChunks) c = kBnMaxChunks;
+    if (c < 1) c = 1;
+    return c;
+}
+static int bn_col_width(int C) {  // power of two in [1,256]
+    int w = 1;
+    while (w < C && w < kBnThreads) w <<= 1;
+    return w;
+}
+
+// partial[chunk][0..2][C] = {count, mean, M2}
+__global__ __launch_bounds__(kBnThreads) void k_bn_stats(const float* __restrict__ x, int N, int C,
+                                                         int CW, int rows_per_chunk,
+                                                         float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][RS][CW]
+    const int RS = kBnThreads / CW;
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    float* ps = lds;
+    float* pq = lds + RS * CW;
+    for (int c0 = 0; c0 < C; c0 += CW) {
+        const int col = c0 + tx;
+        float s = 0.f, q = 0.f, K = 0.f;
+        if (col < C && r0 < r1) {
+            K = x[(int64_t)r0 * C + col];
+            for (int r = r0 + ty; r < r1; r += RS) {
+                const float d = x[(int64_t)r * C + col] - K;
+                s += d;
+                q += d * d;
+            }
+        }
+        ps[ty * CW + tx] = s;
+        pq[ty * CW + tx] = q;
+        __syncthreads();
+        if (ty == 0 && col < C) {
+            for (int k = 1; k < RS; ++k) {
+                s += ps[k * CW + tx];
+                q += pq[k * CW + tx];
+            }
+            const float n = (float)max(r1 - r0, 0);
+            float mean = 0.f, m2 = 0.f;
+            if (n > 0.f) {
+                mean = K + s / n;
+                m2 = fmaxf(q - s * s / n, 0.f);
+            }
+            float* p = partial + (int64_t)blockIdx.x * 3 * C;
+            p[col] = n;
+            p[C + col] = mean;
+            p[2 * C + col] = m2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int chunks,
+                                                     int C, float eps, float momentum,
+                                                     float* __restrict__ moving_mean,
+                                                     float* __restrict__ moving_var,
+                                                     float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        const float* p = partial + (int64_t)k * 3 * C;
+        const float nb = p[col];
+        if (nb <= 0.f) continue;
+        const float mb = p[C + col], m2b = p[2 * C + col];
+        const float nt = n + nb;
+        const float delta = mb - mean;
+        mean += delta * (nb / nt);
+        m2 += m2b + delta * delta * (n * nb / nt);
+        n = nt;
+    }
+    const float var = n > 0.f ? m2 / n : 0.f;
+    save_mean[col] = mean;
+    save_rstd[col] = 1.0f / sqrtf(var + eps);
+    if (moving_mean) moving_mean[col] = moving_mean[col] * momentum + mean * (1.f - momentum);
+    if (moving_var) moving_var[col] = moving_var[col] * momentum + var * (1.f - momentum);
+}
+
+// y = (x-mean)*rstd*gamma+beta   (a = rstd*gamma, b = beta-mean*a evaluated per element to keep
+// the rounding sequence of the unfused formula)
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, int64_t total, int C,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta,
+                                                  const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd,
+                                                  float* __restrict__ y) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const float g = gamma ? gamma[c] : 1.f;
+        const float bb = beta ? beta[c] : 0.f;
+        y[t] = (x[t] - mean[c]) * rstd[c] * g + bb;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_infer(const float* __restrict__ x, int64_t total, int C,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta,
+                                                  const float* __restrict__ mmean,
+                                                  const float* __restrict__ mvar, float eps,
+                                                  float* __restrict__ y) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const float g = gamma ? gamma[c] : 1.f;
+        const float bb = beta ? beta[c] : 0.f;
+        y[t] = (x[t] - mmean[c]) * (1.0f / sqrtf(mvar[c] + eps)) * g + bb;
+    }
+}
+
+// backward partial sums: partial[chunk][0..1][C] = {sum g, sum g*xhat}
+__global__ __launch_bounds__(kBnThreads) void k_bn_bwd_stats(
+    const float* __restrict__ x, const float* __restrict__ gy, int N, int C, int CW,
+    int rows_per_chunk, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int RS = kBnThreads / CW;
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    float* ps = lds;
+    float* pq = lds + RS * CW;
+    for (int c0 = 0; c0 < C; c0 += CW) {
+        const int col = c0 + tx;
+        float s = 0.f, q = 0.f;
+        if (col < C) {
+            const float m = mean[col], rs = rstd[col];
+            for (int r = r0 + ty; r < r1; r += RS) {
+                const float g = gy[(int64_t)r * C + col];
+                s += g;
+                q += g * ((x[(int64_t)r * C + col] - m) * rs);
+            }
+        }
+        ps[ty * CW + tx] = s;
+        pq[ty * CW + tx] = q;
+        __syncthreads();
+        if (ty == 0 && col < C) {
+            for (int k = 1; k < RS; ++k) {
+                s += ps[k * CW + tx];
+                q += pq[k * CW + tx];
+            }
+            float* p = partial + (int64_t)blockIdx.x * 2 * C;
+            p[col] = s;
+            p[C + col] = q;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial,
+                                                         int chunks, int C,
+                                                         float* __restrict__ sum_g,
+                                                         float* __restrict__ sum_gx,
+                                                         float* __restrict__ grad_gamma,
+                                                         float* __restrict__ grad_beta) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        s += partial[(int64_t)k * 2 * C + col];
+        q += partial[(int64_t)k * 2 * C + C + col];
+    }
+    sum_g[col] = s;
+    sum_gx[col] = q;
+    if (grad_gamma) grad_gamma[col] = q;
+    if (grad_beta) grad_beta[col] = s;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(
+    const float* __restrict__ x, const float* __restrict__ gy, int64_t total, int C, float inv_n,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ gx) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const float xhat = (x[t] - mean[c]) * rstd[c];
+        const float g = gamma ? gamma[c] : 1.f;
+        gx[t] = g * rstd[c] * (gy[t] - sum_g[c] * inv_n - xhat * (sum_gx[c] * inv_n));
+    }
+}
+
+static int elementwise_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" int64_t dt_bn_workspace_bytes(int N, int C) {
+    if (N < 0 || C <= 0) return 0;
+    // stats partials (3 floats) dominate the backward partials (2 floats) + 2*C finalized sums
+    return (int64_t)sizeof(float) * ((int64_t)kBnMaxChunks * 3 * C + 2 * C);
+}
+
+extern "C" int dt_bn_train_fwd(const float* x, int N, int C, const float* gamma, const float* beta,
+                               float eps, float momentum, float* moving_mean, float* moving_var,
+                               float* y, float* save_mean, float* save_rstd, void* ws,
+                               void* stream) {
+    DT_REQUIRE(N > 0 && C > 0, "dt_bn_train_fwd: bad sizes N=%d C=%d", N, C);
+    DT_REQUIRE(x && y && save_mean && save_rstd && ws, "dt_bn_train_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int chunks = bn_chunks(N);
+    const int rpc = ceil_div(N, chunks);
+    const int CW = bn_col_width(C);
+    const size_t lds = 2 * kBnThreads * sizeof(float);
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(k_bn_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, N, C, CW, rpc,
+                       partial);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, chunks, C,
+                       eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
+    const int64_t total = (int64_t)N * C;
+    hipLaunchKernelGGL(k_bn_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, total, C,
+                       gamma, beta, save_mean, save_rstd, y);
+    return launch_status("dt_bn_train_fwd");
+}
+
+extern "C" int dt_bn_infer_fwd(const float* x, int N, int C, const float* gamma, const float* beta,
+                               float eps, const float* moving_mean, const float* moving_var,
+                               float* y, void* stream) {
+    DT_REQUIRE(N >= 0 && C > 0, "dt_bn_infer_fwd: bad sizes");
+    if (N == 0) return DT_OK;
+    DT_REQUIRE(x && y && moving_mean && moving_var, "dt_bn_infer_fwd: null pointer");
+    const int64_t total = (int64_t)N * C;
+    hipLaunchKernelGGL(k_bn_infer, dim3(elementwise_blocks(total)), dim3(256), 0, as_stream(stream),
+                       x, total, C, gamma, beta, moving_mean, moving_var, eps, y);
+    return launch_status("dt_bn_infer_fwd");
+}
+
+extern "C" int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C,
+                               const float* gamma, const float* save_mean, const float* save_rstd,
+                               float* grad_x, float* grad_gamma, float* grad_beta, void* ws,
+                               void* stream) {
+    DT_REQUIRE(N > 0 && C > 0, "dt_bn_train_bwd: bad sizes");
+    DT_REQUIRE(x && grad_y && save_mean && save_rstd && grad_x && ws,
+               "dt_bn_train_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int chunks = bn_chunks(N);
+    const int rpc = ceil_div(N, chunks);
+    const int CW = bn_col_width(C);
+    const size_t lds = 2 * kBnThreads * sizeof(float);
+    float* partial = reinterpret_cast<float*>(ws);
+    float* sums = partial + (int64_t)kBnMaxChunks * 3 * C;
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, grad_y, N, C, CW,
+                       rpc, save_mean, save_rstd, partial);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, chunks,
+                       C, sums, sums + C, grad_gamma, grad_beta);
+    const int64_t total = (int64_t)N * C;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, grad_y,
+                       total, C, 1.0f / (float)N, gamma, save_mean, save_rstd, sums, sums + C,
+                       grad_x);
+    return launch_status("dt_bn_train_bwd");
+}

@@ -1,0 +1,467 @@
+// cin.hip — one Compressed-Interaction-Network layer on the matrix cores.
+//
+// Replaces the per-layer op chain of CIN.call, deeptables/models/layers.py:689-710:
+//   split x0 / x_k into D column tensors, tf.matmul(outer product) -> Z [B, D, F0*Hk],
+//   tf.nn.conv1d(Z, filters[1, F0*Hk, L]) (+bias), activation, transpose -> [B, L, D].
+// The reference materialises Z (354-872 MB per layer at the Criteo shape).  Here the layer is
+// the GEMM   Y[(b,d), l] = sum_{k=(i,j)} Z[(b,d), k] * W[k, l],   M = B*D, K = F0*Hk, N = L
+// with the A operand Z[(b,d),(i,j)] = x0[b,i,d] * xk[b,j,d] formed in registers (one multiply
+// per MFMA step) from LDS-resident x0/xk tiles — Z never exists in memory.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate): bitwise an f32 fmaf chain, so
+// the layer meets the reference's fp32 tolerance (1e-4) without a precision mode switch.
+// fp32-MFMA roof: 157.3 TFLOP/s.
+//
+// Three kernels (wave64, 4 waves per block, one 32-row MFMA tile per wave):
+//   fwd    block tile 128 rows (b,d) x 128 cols l; W streamed through LDS in 16-row K chunks.
+//   dgrad  T^T[(i,j), (b,d)] = sum_l W[(i,j), l] G[(b,d), l] per (i, 32 j's) chunk; the lane that
+//          owns column (b,d) contracts its 16 T values against xk / x0 in registers:
+//          grad_x0[b,i,d] += sum_j xk T,  grad_xk[b,j,d] += x0 T  — T is never stored either.
+//   wgrad  grad_W[(i,j), l] = sum_{(b,d)} Z G with Z regenerated; split over the batch, partial
+//          tiles added with float atomics.
+#include "common.h"
+
+namespace dt {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCinKC = 16;    // K rows of W per LDS chunk (fwd)
+constexpr int kCinTileM = 128;
+constexpr int kCinTileN = 128;
+
+__host__ __device__ inline int cin_slab(int F, int D) {  // floats per batch row in an LDS tile
+    int s = F * D;
+    if (D < 32) s += ((D - (s % 32)) % 32 + 32) % 32;  // s % 32 == D % 32: two b's never collide
+    return s;
+}
+__host__ __device__ inline int cin_nb(int D) {  // batch rows an m-tile of 128 (b,d) rows can touch
+    return (kCinTileM % D == 0) ? kCinTileM / D : kCinTileM / D + 2;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    return act == DT_ACT_RELU ? fmaxf(v, 0.f) : v;
+}
+
+// copy the [nb] batch rows starting at b_first of x[B, F, D] (b stride `bstride`) into LDS slabs
+__device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t bstride, int B, int F,
+                                           int D, int b_first, int nb, int slab, float* lds) {
+    const int FD = F * D;
+    for (int e = threadIdx.x; e < nb * FD; e += blockDim.x) {
+        const int bl = e / FD, r = e - bl * FD;
+        const int b = b_first + bl;
+        lds[bl * slab + r] = b < B ? x[(int64_t)b * bstride + r] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_cin_fwd(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const float* __restrict__ W, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
+    int D, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    const int S0 = cin_slab(F0, D), Sk = cin_slab(Hk, D), NB = cin_nb(D);
+    float* x0t = lds;
+    float* xkt = x0t + NB * S0;
+    float* wt = xkt + NB * Sk;  // [2][kCinKC][kCinTileN]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kCinTileM;
+    const int n0 = blockIdx.y * kCinTileN;
+    const int b_first = (int)(m0 / D);
+    stage_rows(x0, x0_bs, B, F0, D, b_first, NB, S0, x0t);
+    stage_rows(xk, xk_bs, B, Hk, D, b_first, NB, Sk, xkt);
+
+    // this lane's A-operand row
+    const int64_t m = m0 + wave * 32 + c;
+    const bool mvalid = m < M;
+    const int bl = (int)(m / D) - b_first, d = (int)(m % D);
+    const float* x0row = x0t + bl * S0 + d;
+    const float* xkrow = xkt + bl * Sk + d;
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int nchunks = (K + kCinKC - 1) / kCinKC;
+    // W chunk loader: 256 threads x 8 floats = 16 x 128
+    float wreg[8];
+    auto load_w = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = threadIdx.x + 256 * r;
+            const int kk = idx >> 7, n = idx & 127;
+            const int k = chunk * kCinKC + kk;
+            wreg[r] = (k < K && n0 + n < L) ? W[(int64_t)k * L + n0 + n] : 0.f;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) wt[buf * kCinKC * kCinTileN + threadIdx.x + 256 * r] = wreg[r];
+    };
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    int ki = s / Hk, kj = s % Hk;  // (i,j) of k = 2*step + s, advanced incrementally
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) load_w(chunk + 1);
+        const float* wb = wt + buf * kCinKC * kCinTileN;
+#pragma unroll
+        for (int kk2 = 0; kk2 < kCinKC / 2; ++kk2) {
+            const int k = chunk * kCinKC + 2 * kk2 + s;
+            float a = 0.f;
+            if (mvalid && k < K) a = x0row[ki * D] * xkrow[kj * D];
+            kj += 2;
+            while (kj >= Hk) { kj -= Hk; ++ki; }
+            const float* wrow = wb + (2 * kk2 + s) * kCinTileN + c;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (nb < nblocks_n)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[nb * 32], acc[nb], 0, 0, 0);
+        }
+        if (chunk + 1 < nchunks) store_w(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: row = (r&3) + 8*(r>>2) + 4*s  (4 consecutive rows per register quad), col = c
+    const bool vec_ok = (D % 4 == 0);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nblocks_n) continue;
+        const int n = n0 + nb * 32 + c;
+        if (n >= L) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t mr = m0 + wave * 32 + 8 * g + 4 * s;
+            if (mr >= M) continue;
+            const int64_t b = mr / D;
+            const int dd = (int)(mr % D);
+            float4 o;
+            o.x = act_apply(acc[nb][g * 4 + 0] + bv, act);
+            o.y = act_apply(acc[nb][g * 4 + 1] + bv, act);
+            o.z = act_apply(acc[nb][g * 4 + 2] + bv, act);
+            o.w = act_apply(acc[nb][g * 4 + 3] + bv, act);
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(y + (b * L + n) * D + dd) = o;
+            } else {
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t mm = mr + r;
+                    if (mm < M) y[((mm / D) * L + n) * D + (mm % D)] = ov[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad: grad_x0 (+=), grad_xk (=)
+// ------------------------------------------------------------------------------------------
+template <int LH /* ceil(L/2) upper bound: 64 or 128 */, int JB /* ceil(Hk/32) upper bound */>
+__global__ __launch_bounds__(256) void k_cin_dgrad(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const float* __restrict__ W, const float* __restrict__ y, const float* __restrict__ gy, int act,
+    int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int64_t M = (int64_t)B * D;
+    const int S0 = cin_slab(F0, D), Sk = cin_slab(Hk, D), NB = cin_nb(D);
+    const int LP = 2 * LH + 1;  // padded W row (lanes walk rows)
+    float* x0t = lds;
+    float* xkt = x0t + NB * S0;
+    float* wt = xkt + NB * Sk;  // [2][32][LP]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kCinTileM;
+    const int b_first = (int)(m0 / D);
+    stage_rows(x0, x0_bs, B, F0, D, b_first, NB, S0, x0t);
+    stage_rows(xk, xk_bs, B, Hk, D, b_first, NB, Sk, xkt);
+
+    const int64_t m = m0 + wave * 32 + c;  // the column of T^T this lane owns
+    const bool mvalid = m < M;
+    const int64_t b = mvalid ? m / D : 0;
+    const int d = mvalid ? (int)(m % D) : 0;
+    const int bl = (int)b - b_first;
+
+    // G[m][l] for l = 2*t + s, kept in registers for the whole tile
+    float G[LH];
+#pragma unroll
+    for (int t = 0; t < LH; ++t) {
+        const int l = 2 * t + s;
+        float g = 0.f;
+        if (mvalid && l < L) {
+            const int64_t o = (b * L + l) * D + d;
+            g = gy[o];
+            if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+        }
+        G[t] = g;
+    }
+    __syncthreads();
+    // xk values this lane needs: j = jb*32 + (r&3) + 8*(r>>2) + 4*s
+    float xkv[JB][16], gxk_acc[JB][16];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+            xkv[jb][r] = (mvalid && j < Hk) ? xkt[bl * Sk + j * D + d] : 0.f;
+            gxk_acc[jb][r] = 0.f;
+        }
+
+    const int njb = (Hk + 31) / 32;
+    const int nchunks = F0 * njb;
+    // W chunk (i, jb): rows k = i*Hk + jb*32 + r (r<32, j<Hk), cols l < L  -> wt[r][l]
+    auto stage_w = [&](int chunk, int buf) {
+        const int i = chunk / njb, jb = chunk - i * njb;
+        float* dst = wt + buf * 32 * LP;
+        for (int e = threadIdx.x; e < 32 * 2 * LH; e += 256) {
+            const int r = e / (2 * LH), l = e - r * (2 * LH);
+            const int j = jb * 32 + r;
+            dst[r * LP + l] = (j < Hk && l < L) ? W[((int64_t)i * Hk + j) * L + l] : 0.f;
+        }
+    };
+    stage_w(0, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const int i = chunk / njb, jb = chunk - i * njb;
+        if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
+        const float* wrow = wt + buf * 32 * LP + c * LP + s;
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < LH; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[2 * t], G[t], acc, 0, 0, 0);
+        // contract T^T[j, m] (16 j's in this lane) against xk and x0
+        const float x0v = mvalid ? x0t[bl * S0 + i * D + d] : 0.f;
+        float p = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+            if (jj == jb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p += xkv[jj][r] * acc[r];
+                    gxk_acc[jj][r] += x0v * acc[r];
+                }
+            }
+        p += __shfl_xor(p, 32, 64);
+        if (mvalid && s == 0) gx0[(b * F0 + i) * D + d] += p;  // unique owner of (b,i,d)
+        __syncthreads();
+    }
+    if (mvalid) {
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (j < Hk) gxk[(b * Hk + j) * D + d] = gxk_acc[jb][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: grad_W[k, l] += sum_m Z[m,k] G[m,l]
+// ------------------------------------------------------------------------------------------
+constexpr int kCinMC = 64;  // (b,d) rows per LDS chunk
+
+__global__ __launch_bounds__(256, 2) void k_cin_wgrad(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
+    int D, int64_t rows_per_split, float* __restrict__ gW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    const int F0P = F0 | 1, HkP = Hk | 1, LPAD = kCinTileN + 1;
+    float* x0T = lds;                 // [MC][F0P]
+    float* xkT = x0T + kCinMC * F0P;  // [MC][HkP]
+    float* gT = xkT + kCinMC * HkP;   // [MC][LPAD]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int k = blockIdx.x * 128 + wave * 32 + c;  // this lane's A row (i,j)
+    const bool kvalid = k < K;
+    const int ki = kvalid ? k / Hk : 0, kj = kvalid ? k % Hk : 0;
+    const int n0 = blockIdx.z * kCinTileN;
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(M, m_begin + rows_per_split);
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    for (int64_t mc = m_begin; mc < m_end; mc += kCinMC) {
+        __syncthreads();
+        // stage transposed tiles: rows mm = mc + r
+        for (int e = threadIdx.x; e < kCinMC * F0; e += 256) {
+            const int i = e / kCinMC, r = e - i * kCinMC;  // r fastest -> d fastest in global
+            const int64_t mm = mc + r;
+            x0T[r * F0P + i] = mm < m_end ? x0[(mm / D) * x0_bs + (int64_t)i * D + (mm % D)] : 0.f;
+        }
+        for (int e = threadIdx.x; e < kCinMC * Hk; e += 256) {
+            const int j = e / kCinMC, r = e - j * kCinMC;
+            const int64_t mm = mc + r;
+            xkT[r * HkP + j] = mm < m_end ? xk[(mm / D) * xk_bs + (int64_t)j * D + (mm % D)] : 0.f;
+        }
+        for (int e = threadIdx.x; e < kCinMC * kCinTileN; e += 256) {
+            const int l = e / kCinMC, r = e - l * kCinMC;
+            const int64_t mm = mc + r;
+            float g = 0.f;
+            if (mm < m_end && n0 + l < L) {
+                const int64_t o = ((mm / D) * L + n0 + l) * D + (mm % D);
+                g = gy[o];
+                if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+            }
+            gT[r * LPAD + l] = g;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < kCinMC / 2; ++t) {
+            const int r = 2 * t + s;
+            const float a = kvalid ? x0T[r * F0P + ki] * xkT[r * HkP + kj] : 0.f;
+            const float* grow = gT + r * LPAD + c;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (nb < nblocks_n)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, grow[nb * 32], acc[nb], 0, 0, 0);
+        }
+    }
+    // out: row = k_local = (r&3)+8*(r>>2)+4*s, col = l_local = c
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nblocks_n) continue;
+        const int l = n0 + nb * 32 + c;
+        if (l >= L) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+            if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[nb][r]);
+        }
+    }
+}
+
+// grad_bias[l] += sum_{b,d} G[b,l,d]
+__global__ __launch_bounds__(256) void k_cin_bias_grad(const float* __restrict__ y,
+                                                       const float* __restrict__ gy, int act, int B,
+                                                       int L, int D, float* __restrict__ gbias) {
+    const int l = blockIdx.x;
+    float sacc = 0.f;
+    const int64_t n = (int64_t)B * D;
+    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t b = e / D;
+        const int d = (int)(e % D);
+        const int64_t o = (b * L + l) * D + d;
+        float g = gy[o];
+        if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+        sacc += g;
+    }
+    sacc = wave_sum(sacc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&gbias[l], sacc);
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+static int cin_check(const char* who, int B, int F0, int Hk, int L, int D) {
+    DT_REQUIRE(B >= 0 && F0 > 0 && Hk > 0 && L > 0 && D > 0, "%s: bad sizes B=%d F0=%d Hk=%d L=%d D=%d",
+               who, B, F0, Hk, L, D);
+    DT_UNSUPPORTED(D > kCinTileM, "%s: D=%d > %d", who, D, kCinTileM);
+    return DT_OK;
+}
+
+extern "C" int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W, const float* bias,
+                                int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride,
+                                int64_t xk_bstride, float* y, void* stream) {
+    int rc = cin_check("dt_cin_layer_fwd", B, F0, Hk, L, D);
+    if (rc) return rc;
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x0 && xk && W && y, "dt_cin_layer_fwd: null pointer");
+    DT_REQUIRE(act == DT_ACT_LINEAR || act == DT_ACT_RELU, "dt_cin_layer_fwd: act %d", act);
+    const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
+                        2 * kCinKC * kCinTileN) * sizeof(float);
+    DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd: tiles need %zu B of LDS (> 160 KiB)", lds);
+    const int64_t M = (int64_t)B * D;
+    dim3 grid((unsigned)((M + kCinTileM - 1) / kCinTileM), (unsigned)ceil_div(L, kCinTileN));
+    hipFuncSetAttribute((const void*)k_cin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cin_fwd, grid, dim3(256), lds, as_stream(stream), x0, x0_bstride, xk,
+                       xk_bstride, W, bias, act, B, F0, Hk, L, D, y);
+    return launch_status("dt_cin_layer_fwd");
+}
+
+template <int LH, int JB>
+static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const float* W,
+                        const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D,
+                        float* gx0, float* gxk, hipStream_t st) {
+    const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
+                        2 * 32 * (2 * LH + 1)) * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("dt_cin_layer_bwd: tiles need %zu B of LDS (> 160 KiB)", lds);
+        return DT_ERR_UNSUPPORTED;
+    }
+    const int64_t M = (int64_t)B * D;
+    dim3 grid((unsigned)((M + kCinTileM - 1) / kCinTileM));
+    hipFuncSetAttribute((const void*)k_cin_dgrad<LH, JB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL((k_cin_dgrad<LH, JB>), grid, dim3(256), lds, st, x0, x0_bs, xk, xk_bs, W, y, gy,
+                       act, B, F0, Hk, L, D, gx0, gxk);
+    return launch_status("dt_cin_layer_bwd(dgrad)");
+}
+
+extern "C" int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const float* y,
+                                const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                                int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                                float* grad_W, float* grad_bias, void* stream) {
+    int rc = cin_check("dt_cin_layer_bwd", B, F0, Hk, L, D);
+    if (rc) return rc;
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x0 && xk && W && y && grad_y && grad_x0 && grad_xk && grad_W,
+               "dt_cin_layer_bwd: null pointer");
+    DT_UNSUPPORTED(L > 256, "dt_cin_layer_bwd: L=%d > 256 filters per layer", L);
+    DT_UNSUPPORTED(Hk > 128, "dt_cin_layer_bwd: Hk=%d > 128 hidden feature maps", Hk);
+    hipStream_t st = as_stream(stream);
+    const int jb = ceil_div(Hk, 32);
+#define DT_DGRAD(LHV, JBV)                                                                          \
+    rc = launch_dgrad<LHV, JBV>(x0, x0_bstride, xk, xk_bstride, W, y, grad_y, act, B, F0, Hk, L, D, \
+                                grad_x0, grad_xk, st)
+    if (L <= 128) {
+        if (jb <= 1) DT_DGRAD(64, 1);
+        else if (jb <= 2) DT_DGRAD(64, 2);
+        else DT_DGRAD(64, 4);
+    } else {
+        if (jb <= 1) DT_DGRAD(128, 1);
+        else if (jb <= 2) DT_DGRAD(128, 2);
+        else DT_DGRAD(128, 4);
+    }
+#undef DT_DGRAD
+    if (rc) return rc;
+
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    const int kblocks = ceil_div(K, 128), nblocks = ceil_div(L, kCinTileN);
+    int splits = (512 + kblocks * nblocks - 1) / (kblocks * nblocks);
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + kCinMC - 1) / kCinMC * kCinMC;
+    splits = (int)((M + rps - 1) / rps);
+    const size_t lds = (size_t)kCinMC * ((F0 | 1) + (Hk | 1) + kCinTileN + 1) * sizeof(float);
+    hipFuncSetAttribute((const void*)k_cin_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cin_wgrad, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride,
+                       xk, xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
+    if (grad_bias)
+        hipLaunchKernelGGL(k_cin_bias_grad, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D,
+                           grad_bias);
+    return launch_status("dt_cin_layer_bwd(wgrad)");
+}

@@ -1,0 +1,208 @@
+// cross.hip — depth-fused CrossNet.
+//
+// Replaces Cross.call, deeptables/models/layers.py:428-436:
+//     x_n = tf.matmul(x_f, tf.tensordot(x_n, kernels[i], axes=(1,0))) + x_n + bias[i]
+// i.e. per row  x_{l+1} = x_0 * (x_l . w_l) + x_l + b_l,  l = 0..L-1.
+// The reference runs >= 4 full passes over [B,C] per layer; here one wavefront keeps a whole
+// row (x_0 and x_l, C/64 floats per lane each) in registers across all L layers: one read and
+// one write of the row, one wave reduction per layer.  Only the L scalars s_l = x_l.w_l are
+// saved for the backward, which recomputes x_l from x_0 (exactly the forward's values).
+//
+// Backward (t_l = g_{l+1} . x_0):  g_l = g_{l+1} + w_l t_l ;  grad_w_l = sum_b x_l t_l ;
+// grad_b_l = sum_b g_{l+1} ;  grad_x = g_0 + sum_l g_{l+1} s_l.
+// grad_w/grad_b are accumulated per block in LDS, written as per-block partials into the
+// workspace and summed by a second kernel (no global float atomics).
+#include "common.h"
+
+namespace dt {
+
+constexpr int kCrossMaxBlocks = 512;
+
+template <int PER>
+__global__ __launch_bounds__(256) void k_cross_fwd(const float* __restrict__ x,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ bias, int B, int C,
+                                                   int L, float* __restrict__ out,
+                                                   float* __restrict__ save_s) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+        float x0[PER], xl[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            x0[k] = col < C ? x[(int64_t)b * C + col] : 0.f;
+            xl[k] = x0[k];
+        }
+        for (int l = 0; l < L; ++l) {
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int col = k * 64 + lane;
+                if (col < C) p += xl[k] * w[(int64_t)l * C + col];
+            }
+            const float s = wave_sum(p);
+            if (save_s && lane == 0) save_s[(int64_t)b * L + l] = s;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int col = k * 64 + lane;
+                if (col < C) xl[k] = x0[k] * s + xl[k] + bias[(int64_t)l * C + col];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            if (col < C) out[(int64_t)b * C + col] = xl[k];
+        }
+    }
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void k_cross_bwd(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ save_s, const float* __restrict__ gout, int B, int C, int L,
+    float* __restrict__ gx, float* __restrict__ partial /* [grid][2][L][C] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][L][C]
+    float* lgw = lds;
+    float* lgb = lds + (int64_t)L * C;
+    for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+        float x0[PER], g[PER], acc[PER], xl[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            x0[k] = col < C ? x[(int64_t)b * C + col] : 0.f;
+            g[k] = col < C ? gout[(int64_t)b * C + col] : 0.f;
+            acc[k] = 0.f;
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            // recompute x_l from x_0 with the saved scalars (same arithmetic as the forward)
+#pragma unroll
+            for (int k = 0; k < PER; ++k) xl[k] = x0[k];
+            for (int m = 0; m < l; ++m) {
+                const float sm = save_s[(int64_t)b * L + m];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int col = k * 64 + lane;
+                    if (col < C) xl[k] = x0[k] * sm + xl[k] + bias[(int64_t)m * C + col];
+                }
+            }
+            const float s = save_s[(int64_t)b * L + l];
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) p += g[k] * x0[k];
+            const float t = wave_sum(p);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int col = k * 64 + lane;
+                if (col < C) {
+                    atomicAdd(&lgw[(int64_t)l * C + col], xl[k] * t);
+                    atomicAdd(&lgb[(int64_t)l * C + col], g[k]);
+                    acc[k] += g[k] * s;
+                    g[k] += w[(int64_t)l * C + col] * t;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            if (col < C) gx[(int64_t)b * C + col] = g[k] + acc[k];
+        }
+    }
+    __syncthreads();
+    float* p = partial + (int64_t)blockIdx.x * 2 * L * C;
+    for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) p[i] = lds[i];
+}
+
+__global__ __launch_bounds__(256) void k_cross_bwd_reduce(const float* __restrict__ partial,
+                                                          int nblocks, int LC,
+                                                          float* __restrict__ grad_w,
+                                                          float* __restrict__ grad_b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * LC) return;
+    float s = 0.f;
+    for (int k = 0; k < nblocks; ++k) s += partial[(int64_t)k * 2 * LC + i];
+    if (i < LC) {
+        if (grad_w) grad_w[i] += s;
+    } else {
+        if (grad_b) grad_b[i - LC] += s;
+    }
+}
+
+static int cross_blocks(int B) {
+    int g = ceil_div(B, 4);
+    if (g > kCrossMaxBlocks) g = kCrossMaxBlocks;
+    return g < 1 ? 1 : g;
+}
+static int cross_per(int C) {
+    int per = 1;
+    while (per * 64 < C) per <<= 1;
+    return per;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" int64_t dt_cross_workspace_bytes(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    return (int64_t)sizeof(float) * cross_blocks(B) * 2 * L * C;
+}
+
+extern "C" int dt_cross_fwd(const float* x, const float* w, const float* b, int B, int C, int L,
+                            float* out, float* save_s, void* stream) {
+    DT_REQUIRE(B >= 0 && C > 0 && L >= 0, "dt_cross_fwd: bad sizes B=%d C=%d L=%d", B, C, L);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && out && (L == 0 || (w && b)), "dt_cross_fwd: null pointer");
+    const int per = cross_per(C);
+    DT_UNSUPPORTED(per > 32, "dt_cross_fwd: C=%d exceeds 2048 columns per row", C);
+    hipStream_t st = as_stream(stream);
+    int fwd_blocks = ceil_div(B, 4);
+    if (fwd_blocks > 2048) fwd_blocks = 2048;
+    dim3 grid(fwd_blocks), block(256);
+#define DT_CROSS_FWD(P)                                                                         \
+    case P:                                                                                     \
+        hipLaunchKernelGGL((k_cross_fwd<P>), grid, block, 0, st, x, w, b, B, C, L, out, save_s); \
+        break;
+    switch (per) {
+        DT_CROSS_FWD(1) DT_CROSS_FWD(2) DT_CROSS_FWD(4) DT_CROSS_FWD(8) DT_CROSS_FWD(16)
+        DT_CROSS_FWD(32)
+    }
+#undef DT_CROSS_FWD
+    return launch_status("dt_cross_fwd");
+}
+
+extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, const float* save_s,
+                            const float* grad_out, int B, int C, int L, float* grad_x,
+                            float* grad_w, float* grad_b, void* ws, void* stream) {
+    DT_REQUIRE(B >= 0 && C > 0 && L >= 0, "dt_cross_bwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && grad_out && grad_x && (L == 0 || (w && b && save_s && ws)),
+               "dt_cross_bwd: null pointer");
+    const int per = cross_per(C);
+    DT_UNSUPPORTED(per > 32, "dt_cross_bwd: C=%d exceeds 2048 columns per row", C);
+    const size_t lds = (size_t)2 * L * C * sizeof(float);
+    DT_UNSUPPORTED(lds > 64 * 1024, "dt_cross_bwd: L*C=%d exceeds the 8192-float LDS accumulator",
+                   L * C);
+    hipStream_t st = as_stream(stream);
+    const int nblocks = cross_blocks(B);
+    dim3 grid(nblocks), block(256);
+    float* partial = reinterpret_cast<float*>(ws);
+#define DT_CROSS_BWD(P)                                                                       \
+    case P:                                                                                   \
+        hipLaunchKernelGGL((k_cross_bwd<P>), grid, block, lds, st, x, w, b, save_s, grad_out, \
+                           B, C, L, grad_x, partial);                                         \
+        break;
+    switch (per) {
+        DT_CROSS_BWD(1) DT_CROSS_BWD(2) DT_CROSS_BWD(4) DT_CROSS_BWD(8) DT_CROSS_BWD(16)
+        DT_CROSS_BWD(32)
+    }
+#undef DT_CROSS_BWD
+    if (L > 0 && (grad_w || grad_b))
+        hipLaunchKernelGGL(k_cross_bwd_reduce, dim3(ceil_div(2 * L * C, 256)), dim3(256), 0, st,
+                           partial, nblocks, L * C, grad_w, grad_b);
+    return launch_status("dt_cross_bwd");
+}

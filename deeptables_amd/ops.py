@@ -1,0 +1,396 @@
+# -*- coding:utf-8 -*-
+"""torch.autograd.Function wrappers over the C-ABI kernels (include/dt_hip.h).
+
+Each Function is the forward+backward of one reference `Layer.call` in
+deeptables/models/layers.py; torch is only the carrier of device memory, streams and the
+autograd tape.  All functions require CUDA(HIP) tensors — no CPU fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, require_cuda, stream_ptr
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _idx_kind(idx):
+    if idx.dtype == torch.float32:
+        return _lib.DT_IDX_F32
+    if idx.dtype == torch.int32:
+        return _lib.DT_IDX_I32
+    raise TypeError(f'categorical ids must be float32 (reference contract) or int32, got {idx.dtype}')
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiColumnEmbedding.call — deeptables/models/layers.py:889-904
+# ------------------------------------------------------------------------------------------------
+class SparseRowGrad:
+    """The (indices, values) pair TF calls IndexedSlices: gradient of a packed embedding table."""
+
+    __slots__ = ('rows', 'values')
+
+    def __init__(self, rows, values):
+        self.rows = rows        # int64 [n]   packed row ids, -1 = out-of-range lookup
+        self.values = values    # float32 [n, D]
+
+
+class _EmbeddingLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, table, row_offset, vocab, holder, dense_grad, oob):
+        require_cuda(idx, table)
+        idx = idx.contiguous()
+        B, F = idx.shape
+        D = table.shape[1]
+        out = torch.empty((B, F, D), dtype=torch.float32, device=table.device)
+        rows = torch.empty((B, F), dtype=torch.int64, device=table.device)
+        check(lib().dt_embedding_fwd(ptr(idx), _idx_kind(idx), ptr(table), ptr(row_offset), ptr(vocab),
+                                     B, F, D, ptr(out), ptr(rows), ptr(oob), stream_ptr()),
+              'dt_embedding_fwd')
+        ctx.holder = holder
+        ctx.dense_grad = dense_grad
+        ctx.table_shape = table.shape
+        ctx.save_for_backward(rows)
+        ctx.mark_non_differentiable(rows)
+        return out, rows
+
+    @staticmethod
+    def backward(ctx, g_out, _g_rows):
+        (rows,) = ctx.saved_tensors
+        g_out = _f32c(g_out)
+        D = ctx.table_shape[1]
+        g_table = None
+        if ctx.dense_grad:
+            g_table = torch.zeros(ctx.table_shape, dtype=torch.float32, device=g_out.device)
+            check(lib().dt_embedding_bwd_dense(ptr(rows), ptr(g_out), rows.numel(), D, ptr(g_table),
+                                               stream_ptr()), 'dt_embedding_bwd_dense')
+        elif ctx.holder is not None:
+            ctx.holder.add_sparse_grad(SparseRowGrad(rows.reshape(-1), g_out.reshape(-1, D)))
+        return None, g_table, None, None, None, None, None
+
+
+def embedding_lookup(idx, table, row_offset, vocab, holder=None, dense_grad=False, oob=None):
+    """-> (emb [B,F,D], rows [B,F] int64).  With dense_grad=False the table gradient is handed to
+    `holder.add_sparse_grad(SparseRowGrad)` instead of being densified."""
+    # a dummy requires-grad path is needed so backward runs even though `table.grad` stays None
+    return _EmbeddingLookup.apply(idx, table, row_offset, vocab, holder, dense_grad, oob)
+
+
+# ------------------------------------------------------------------------------------------------
+# FM.call — deeptables/models/layers.py:53-62
+# ------------------------------------------------------------------------------------------------
+class _FM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        x = _f32c(x)
+        B, F, D = x.shape
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        check(lib().dt_fm_fwd(ptr(x), B, F, D, ptr(out), stream_ptr()), 'dt_fm_fwd')
+        ctx.save_for_backward(x)
+        return out.view(B, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, F, D = x.shape
+        g = _f32c(g).view(B)
+        gx = torch.empty_like(x)
+        check(lib().dt_fm_bwd(ptr(x), ptr(g), B, F, D, ptr(gx), stream_ptr()), 'dt_fm_bwd')
+        return gx
+
+
+def fm(x):
+    return _FM.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused: embedding gather + [flatten(emb), dense] concat + linear field-sum + FM
+# layers.py:889-904 + deepmodel.py:269-274,348-353 + deepnets.py:49-51 + layers.py:53-62
+# ------------------------------------------------------------------------------------------------
+class _EmbedFmLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, table, row_offset, vocab, dense, holder, dense_grad, oob, want_emb):
+        require_cuda(idx, table)
+        idx = idx.contiguous()
+        B, F = idx.shape
+        D = table.shape[1]
+        Nd = 0 if dense is None else dense.shape[1]
+        dev = table.device
+        dense_c = None if dense is None else _f32c(dense)
+        emb = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        concat = torch.empty((B, F * D + Nd), dtype=torch.float32, device=dev)
+        fsum = torch.empty((B, F), dtype=torch.float32, device=dev)
+        fmo = torch.empty((B,), dtype=torch.float32, device=dev)
+        rows = torch.empty((B, F), dtype=torch.int64, device=dev)
+        check(lib().dt_embed_fm_linear_fwd(ptr(idx), _idx_kind(idx), ptr(table), ptr(row_offset),
+                                           ptr(vocab), ptr(dense_c), B, F, D, Nd, ptr(emb), ptr(concat),
+                                           ptr(fsum), ptr(fmo), ptr(rows), ptr(oob), stream_ptr()),
+              'dt_embed_fm_linear_fwd')
+        ctx.holder, ctx.dense_grad, ctx.table_shape, ctx.Nd = holder, dense_grad, table.shape, Nd
+        ctx.save_for_backward(emb, rows)
+        ctx.mark_non_differentiable(rows)
+        return emb, concat, fsum, fmo.view(B, 1), rows
+
+    @staticmethod
+    def backward(ctx, g_emb, g_concat, g_fsum, g_fm, _g_rows):
+        emb, rows = ctx.saved_tensors
+        B, F, D = emb.shape
+        g_emb = None if g_emb is None else _f32c(g_emb)
+        g_concat = None if g_concat is None else _f32c(g_concat)
+        g_fsum = None if g_fsum is None else _f32c(g_fsum)
+        g_fm = None if g_fm is None else _f32c(g_fm).view(B)
+        grad_rows = torch.empty_like(emb)
+        check(lib().dt_embed_fm_linear_bwd(ptr(emb), ptr(g_emb), ptr(g_concat), F * D + ctx.Nd,
+                                           ptr(g_fsum), ptr(g_fm), B, F, D, ptr(grad_rows),
+                                           stream_ptr()), 'dt_embed_fm_linear_bwd')
+        g_table = None
+        if ctx.dense_grad:
+            g_table = torch.zeros(ctx.table_shape, dtype=torch.float32, device=emb.device)
+            check(lib().dt_embedding_bwd_dense(ptr(rows), ptr(grad_rows), rows.numel(), D,
+                                               ptr(g_table), stream_ptr()), 'dt_embedding_bwd_dense')
+        elif ctx.holder is not None:
+            ctx.holder.add_sparse_grad(SparseRowGrad(rows.reshape(-1), grad_rows.reshape(-1, D)))
+        g_dense = None
+        if ctx.Nd > 0 and g_concat is not None and ctx.needs_input_grad[4]:
+            g_dense = g_concat[:, F * D:].contiguous()
+        return None, g_table, None, None, g_dense, None, None, None, None
+
+
+def embed_fm_linear(idx, table, row_offset, vocab, dense=None, holder=None, dense_grad=False, oob=None):
+    """-> emb [B,F,D], concat [B,F*D+Nd], field_sum [B,F], fm [B,1], rows [B,F]"""
+    return _EmbedFmLinear.apply(idx, table, row_offset, vocab, dense, holder, dense_grad, oob, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# Keras BatchNormalization (deepmodel.py:359; layers.py:152)
+# ------------------------------------------------------------------------------------------------
+def _bn_ws(N, C, device):
+    nbytes = lib().dt_bn_workspace_bytes(N, C)
+    return torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=device)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum):
+        require_cuda(x)
+        x2 = _f32c(x).view(-1, x.shape[-1])
+        N, C = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _bn_ws(N, C, x.device)
+        check(lib().dt_bn_train_fwd(ptr(x2), N, C, ptr(gamma), ptr(beta), eps, momentum,
+                                    ptr(moving_mean), ptr(moving_var), ptr(y), ptr(mean), ptr(rstd),
+                                    ptr(ws), stream_ptr()), 'dt_bn_train_fwd')
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.has_affine = (gamma is not None, beta is not None)
+        ctx.x_shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        N, C = x2.shape
+        gy2 = _f32c(gy).view(N, C)
+        gx = torch.empty_like(x2)
+        ggamma = torch.empty((C,), dtype=torch.float32, device=x2.device)
+        gbeta = torch.empty((C,), dtype=torch.float32, device=x2.device)
+        ws = _bn_ws(N, C, x2.device)
+        check(lib().dt_bn_train_bwd(ptr(x2), ptr(gy2), N, C, ptr(gamma), ptr(mean), ptr(rstd), ptr(gx),
+                                    ptr(ggamma), ptr(gbeta), ptr(ws), stream_ptr()), 'dt_bn_train_bwd')
+        return (gx.view(ctx.x_shape), ggamma if ctx.has_affine[0] else None,
+                gbeta if ctx.has_affine[1] else None, None, None, None, None)
+
+
+def batchnorm_train(x, gamma, beta, moving_mean, moving_var, eps=1e-3, momentum=0.99):
+    return _BatchNormTrain.apply(x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum))
+
+
+def batchnorm_infer(x, gamma, beta, moving_mean, moving_var, eps=1e-3):
+    require_cuda(x)
+    x2 = _f32c(x).view(-1, x.shape[-1])
+    N, C = x2.shape
+    y = torch.empty_like(x2)
+    check(lib().dt_bn_infer_fwd(ptr(x2), N, C, ptr(gamma), ptr(beta), float(eps), ptr(moving_mean),
+                                ptr(moving_var), ptr(y), stream_ptr()), 'dt_bn_infer_fwd')
+    return y.view(x.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# Cross.call — deeptables/models/layers.py:428-436
+# ------------------------------------------------------------------------------------------------
+class _Cross(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_cuda(x, w, b)
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        B, C = x.shape
+        L = w.shape[0]
+        out = torch.empty_like(x)
+        save_s = torch.empty((B, max(L, 1)), dtype=torch.float32, device=x.device)
+        check(lib().dt_cross_fwd(ptr(x), ptr(w), ptr(b), B, C, L, ptr(out), ptr(save_s), stream_ptr()),
+              'dt_cross_fwd')
+        ctx.save_for_backward(x, w, b, save_s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, save_s = ctx.saved_tensors
+        B, C = x.shape
+        L = w.shape[0]
+        g = _f32c(g)
+        gx = torch.empty_like(x)
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(b)
+        nbytes = lib().dt_cross_workspace_bytes(B, C, L)
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+        check(lib().dt_cross_bwd(ptr(x), ptr(w), ptr(b), ptr(save_s), ptr(g), B, C, L, ptr(gx), ptr(gw),
+                                 ptr(gb), ptr(ws), stream_ptr()), 'dt_cross_bwd')
+        return gx, gw, gb
+
+
+def cross(x, w, b):
+    """x [B,C]; w,b [L,C] (Keras kernels_l/bias_l of shape (C,1), stacked and squeezed)."""
+    return _Cross.apply(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# InnerProduct.call / OuterProduct.call — deeptables/models/layers.py:473-487, 543-581
+# ------------------------------------------------------------------------------------------------
+class _InnerProduct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        x = _f32c(x)
+        B, F, D = x.shape
+        out = torch.empty((B, F * (F - 1) // 2), dtype=torch.float32, device=x.device)
+        check(lib().dt_inner_product_fwd(ptr(x), B, F, D, ptr(out), stream_ptr()), 'dt_inner_product_fwd')
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, F, D = x.shape
+        gx = torch.empty_like(x)
+        check(lib().dt_inner_product_bwd(ptr(x), ptr(_f32c(g)), B, F, D, ptr(gx), stream_ptr()),
+              'dt_inner_product_bwd')
+        return gx
+
+
+def inner_product(x):
+    return _InnerProduct.apply(x)
+
+
+class _OuterProduct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, kernel_type):
+        require_cuda(x, kernel)
+        x, kernel = _f32c(x), _f32c(kernel)
+        B, F, D = x.shape
+        out = torch.empty((B, F * (F - 1) // 2), dtype=torch.float32, device=x.device)
+        check(lib().dt_outer_product_fwd(ptr(x), ptr(kernel), kernel_type, B, F, D, ptr(out),
+                                         stream_ptr()), 'dt_outer_product_fwd')
+        ctx.save_for_backward(x, kernel)
+        ctx.kernel_type = kernel_type
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel = ctx.saved_tensors
+        B, F, D = x.shape
+        gx = torch.empty_like(x)
+        gk = torch.zeros_like(kernel)
+        check(lib().dt_outer_product_bwd(ptr(x), ptr(kernel), ctx.kernel_type, ptr(_f32c(g)), B, F, D,
+                                         ptr(gx), ptr(gk), stream_ptr()), 'dt_outer_product_bwd')
+        return gx, gk, None
+
+
+def outer_product(x, kernel, kernel_type='mat'):
+    return _OuterProduct.apply(x, kernel, _lib.DT_OP_KERNEL[kernel_type])
+
+
+# ------------------------------------------------------------------------------------------------
+# one CIN layer — deeptables/models/layers.py:689-710
+# ------------------------------------------------------------------------------------------------
+class _CinLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, xk, W, bias, act):
+        require_cuda(x0, xk, W)
+        x0, W = _f32c(x0), _f32c(W)
+        if xk.dtype != torch.float32:
+            xk = xk.float()
+        # xk may be a channel-slice view [:, :H] of the previous layer's output (direct=False)
+        if not (xk.stride(2) == 1 and xk.stride(1) == xk.shape[2]):
+            xk = xk.contiguous()
+        B, F0, D = x0.shape
+        Hk = xk.shape[1]
+        L = W.shape[1]
+        y = torch.empty((B, L, D), dtype=torch.float32, device=x0.device)
+        bias_c = None if bias is None else _f32c(bias)
+        check(lib().dt_cin_layer_fwd(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
+                                     F0 * D, xk.stride(0), ptr(y), stream_ptr()), 'dt_cin_layer_fwd')
+        ctx.save_for_backward(x0, xk, W, y)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, xk, W, y = ctx.saved_tensors
+        B, F0, D = x0.shape
+        Hk = xk.shape[1]
+        L = W.shape[1]
+        gy = _f32c(gy)
+        gx0 = torch.zeros_like(x0)
+        gxk = torch.zeros((B, Hk, D), dtype=torch.float32, device=x0.device)
+        gW = torch.zeros_like(W)
+        gb = torch.zeros((L,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
+        check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                     F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
+                                     stream_ptr()), 'dt_cin_layer_bwd')
+        return gx0, gxk, gW, gb, None
+
+
+def cin_layer(x0, xk, W, bias=None, activation='relu'):
+    """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias)."""
+    act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}.get(activation)
+    if act is None:
+        raise ValueError(f'CIN activation {activation!r} is not supported by the HIP kernel (relu/linear).')
+    return _CinLayer.apply(x0, xk, W, bias, act)
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiheadAttention core — deeptables/models/layers.py:129-145
+# ------------------------------------------------------------------------------------------------
+class _MhaCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, H):
+        require_cuda(q, k, v)
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        B, F, D = q.shape
+        out = torch.empty_like(q)
+        lse = torch.empty((B, H, F), dtype=torch.float32, device=q.device)
+        check(lib().dt_mha_core_fwd(ptr(q), ptr(k), ptr(v), B, F, D, H, ptr(out), ptr(lse), stream_ptr()),
+              'dt_mha_core_fwd')
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, F, D = q.shape
+        g = _f32c(g)
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(lib().dt_mha_core_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), B, F, D, ctx.H,
+                                    ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
+        return gq, gk, gv, None
+
+
+def mha_core(q, k, v, num_heads):
+    return _MhaCore.apply(q, k, v, int(num_heads))

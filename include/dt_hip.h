@@ -1,0 +1,198 @@
+/*
+ * dt_hip.h — C-ABI of libdt_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * DeepTables `deeptables.models.layers` hot path.
+ *
+ * The reference (DataCanvasIO/DeepTables) is 100 % Python on TensorFlow/Keras and has no FFI
+ * of its own; the "boundary" it exposes for this path is the Keras `Layer.call` of each class
+ * in deeptables/models/layers.py.  Every entry point below replaces the TF op sequence of one
+ * `call` (forward) and of its autodiff (backward); the citation next to each declaration is
+ * the reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types.  All pointers are DEVICE pointers (HBM) unless the name
+ *     ends in `_host`.  The caller owns every buffer (in the Python host these are
+ *     torch.Tensor storages); the library never allocates, frees or synchronises.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), stateless and re-entrant.  Launches are hipGraph-capturable.
+ *   - all tensors are dense, row-major, contiguous, fp32 unless stated; sizes are explicit.
+ *   - return value: DT_OK (0) or a negative DT_ERR_* code; dt_last_error() returns a
+ *     thread-local human readable message for the last failing call on this thread.
+ *   - "idx_kind": categorical ids arrive either as float32 (the reference's tf.data contract,
+ *     utils/dataset_generator.py:41-42; cast with truncation exactly like
+ *     keras.ops.cast(inputs,'int32'), models/layers.py:893-895) or as int32 (fast path).
+ *   - out-of-range ids read as a zero row (TF-GPU embedding_lookup behaviour) and are counted
+ *     into the optional `oob_count` device counter so the host can raise like TF-CPU does.
+ */
+#ifndef DT_HIP_H
+#define DT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DT_OK 0
+#define DT_ERR_INVALID_ARG (-1)   /* bad size / null pointer / unsupported combination   */
+#define DT_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels are specialised for   */
+#define DT_ERR_LAUNCH (-3)        /* hipGetLastError() != hipSuccess after a launch       */
+
+#define DT_IDX_F32 0
+#define DT_IDX_I32 1
+
+#define DT_ACT_LINEAR 0
+#define DT_ACT_RELU 1
+
+#define DT_OP_KERNEL_MAT 0
+#define DT_OP_KERNEL_VEC 1
+#define DT_OP_KERNEL_NUM 2
+
+/* ---- library --------------------------------------------------------------------------- */
+int dt_version(void);                 /* ABI version, currently 1 */
+const char* dt_last_error(void);      /* thread-local message of the last failing call */
+const char* dt_build_arch(void);      /* "gfx950" */
+
+/* ---- a2  MultiColumnEmbedding.call  (models/layers.py:889-904) -------------------------- *
+ * All F columns live in ONE packed table [sum_f vocab_f, D]; column f starts at row
+ * row_offset[f] and has vocab[f] rows (same D for every column; per-column D is handled by
+ * the host with one call per D-group).
+ *   idx        [B,F]  float32 or int32 (idx_kind)
+ *   out        [B,F,D]           out[b,f,:] = table[row_offset[f] + int(idx[b,f]), :]
+ *   rows_out   [B,F] int64 or NULL: the resolved packed row per lookup (the `indices` half
+ *              of TF's IndexedSlices gradient); -1 for an out-of-range id.
+ * The gather is a bit-exact copy.                                                           */
+int dt_embedding_fwd(const void* idx, int idx_kind, const float* table,
+                     const int64_t* row_offset, const int32_t* vocab,
+                     int B, int F, int D, float* out, int64_t* rows_out,
+                     int* oob_count, void* stream);
+
+/* Backward of the gather into a DENSE gradient table (TF densifies IndexedSlices for
+ * optimizers without a sparse path): grad_table[rows[b,f],:] += grad_out[b,f,:].
+ * grad_table must be zeroed by the caller.  Rows < 0 are skipped.                           */
+int dt_embedding_bwd_dense(const int64_t* rows, const float* grad_out, int n_lookups, int D,
+                           float* grad_table, void* stream);
+
+/* ---- a4  FM.call  (models/layers.py:53-62) ----------------------------------------------- *
+ *   x [B,F,D] -> out [B]  = 0.5 * sum_d[(sum_f x)^2 - sum_f x^2]
+ *   backward: grad_x[b,f,d] = grad_out[b] * (S[b,d] - x[b,f,d]),  S = sum_f x               */
+int dt_fm_fwd(const float* x, int B, int F, int D, float* out, void* stream);
+int dt_fm_bwd(const float* x, const float* grad_out, int B, int F, int D, float* grad_x,
+              void* stream);
+
+/* ---- a2+a3+a4 fused: embedding gather + linear field-sum + FM --------------------------- *
+ * (models/layers.py:889-904 + models/deepnets.py:43-66 `linear` + models/layers.py:53-62)
+ *   emb_out   [B,F,D]  gathered rows (bit-exact)                       (may be NULL)
+ *   concat_out[B, F*D+Nd] = [flatten(emb), dense]  (deepmodel.py:269-274,348-353; may be NULL)
+ *   field_sum [B,F]    s[b,f] = sum_d emb[b,f,d]   (deepnets.py:51)    (may be NULL)
+ *   fm_out    [B]      FM second-order term                            (may be NULL)
+ *   dense     [B,Nd]   continuous inputs (only read when concat_out != NULL; Nd may be 0)   */
+int dt_embed_fm_linear_fwd(const void* idx, int idx_kind, const float* table,
+                           const int64_t* row_offset, const int32_t* vocab,
+                           const float* dense, int B, int F, int D, int Nd,
+                           float* emb_out, float* concat_out, float* field_sum, float* fm_out,
+                           int64_t* rows_out, int* oob_count, void* stream);
+
+/* Fused backward of the three consumers of the embedding block.  Any grad input may be NULL.
+ *   grad_rows[b,f,d] = g_concat[b, f*D+d] + g_field_sum[b,f] + g_fm[b]*(S[b,d]-emb[b,f,d])
+ *                      (+ g_emb[b,f,d])
+ * `emb` is the saved forward activation [B,F,D] (or the re-gathered rows).
+ * g_concat has row stride concat_stride (= F*D+Nd) floats.                                  */
+int dt_embed_fm_linear_bwd(const float* emb, const float* g_emb, const float* g_concat,
+                           int concat_stride, const float* g_field_sum, const float* g_fm,
+                           int B, int F, int D, float* grad_rows, void* stream);
+
+/* ---- a5  BatchNormalization on concat_emb_dense (models/deepmodel.py:348-361, Keras BN) -- *
+ * Training forward over x [N,C] (N = batch, or batch*fields for MultiheadAttention's BN):
+ *   mean/var: biased batch statistics (two-pass-accurate, Chan-merged Welford)
+ *   y = gamma*(x-mean)*rsqrt(var+eps)+beta
+ *   moving_mean = moving_mean*momentum + mean*(1-momentum)   (same for var; biased var)
+ * save_mean/save_rstd [C] are written for the backward.  ws: workspace of
+ * dt_bn_workspace_bytes(N,C) bytes.                                                          */
+int64_t dt_bn_workspace_bytes(int N, int C);
+int dt_bn_train_fwd(const float* x, int N, int C, const float* gamma, const float* beta,
+                    float eps, float momentum, float* moving_mean, float* moving_var,
+                    float* y, float* save_mean, float* save_rstd, void* ws, void* stream);
+int dt_bn_infer_fwd(const float* x, int N, int C, const float* gamma, const float* beta,
+                    float eps, const float* moving_mean, const float* moving_var, float* y,
+                    void* stream);
+/*   grad_x = gamma*rstd*(g - mean_N(g) - xhat*mean_N(g*xhat));  grad_gamma=sum g*xhat; grad_beta=sum g */
+int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C, const float* gamma,
+                    const float* save_mean, const float* save_rstd, float* grad_x,
+                    float* grad_gamma, float* grad_beta, void* ws, void* stream);
+
+/* ---- a8  Cross.call  (models/layers.py:428-436) ------------------------------------------ *
+ *   x [B,C]; w,b [L,C] (kernels_l / bias_l, each (C,1) in Keras, stacked)
+ *   x_{l+1} = x_0 * (x_l . w_l) + x_l + b_l ; out = x_L [B,C]
+ *   save_s [B,L]: the per-layer scalars s_l = x_l . w_l (all the backward needs besides x).  */
+int dt_cross_fwd(const float* x, const float* w, const float* b, int B, int C, int L,
+                 float* out, float* save_s, void* stream);
+/*   grad_w, grad_b [L,C] are ACCUMULATED (+=): zero them first.  ws: workspace of
+ *   dt_cross_workspace_bytes(B,C,L) bytes (per-block partial sums; no global float atomics). */
+int64_t dt_cross_workspace_bytes(int B, int C, int L);
+int dt_cross_bwd(const float* x, const float* w, const float* b, const float* save_s,
+                 const float* grad_out, int B, int C, int L, float* grad_x, float* grad_w,
+                 float* grad_b, void* ws, void* stream);
+
+/* ---- a9  InnerProduct.call  (models/layers.py:473-487) ----------------------------------- *
+ *   x [B,F,D] -> out [B,P], P=F(F-1)/2, pairs (i<j) row-major: out[b,p]=<x[b,i],x[b,j]>     */
+int dt_inner_product_fwd(const float* x, int B, int F, int D, float* out, void* stream);
+int dt_inner_product_bwd(const float* x, const float* grad_out, int B, int F, int D,
+                         float* grad_x, void* stream);
+
+/* ---- a10 OuterProduct.call  (models/layers.py:543-581) ----------------------------------- *
+ *   kernel_type mat: K [D,P,D]  out[b,p] = sum_a sum_d x[b,i,d]*K[a,p,d]*x[b,j,a]
+ *               vec: K [P,D]    out[b,p] = sum_d x[b,i,d]*x[b,j,d]*K[p,d]
+ *               num: K [P,1]    out[b,p] = K[p]*sum_d x[b,i,d]*x[b,j,d]
+ *   grad_kernel is ACCUMULATED with atomics: zero it first.                                  */
+int dt_outer_product_fwd(const float* x, const float* kernel, int kernel_type, int B, int F,
+                         int D, float* out, void* stream);
+int dt_outer_product_bwd(const float* x, const float* kernel, int kernel_type,
+                         const float* grad_out, int B, int F, int D, float* grad_x,
+                         float* grad_kernel, void* stream);
+
+/* ---- a11 CIN layer  (models/layers.py:689-710) -------------------------------------------- *
+ * One CIN layer: y[b,l,d] = act( sum_{i<F0, j<Hk} x0[b,i,d] * xk[b,j,d] * W[i*Hk+j, l] + bias[l] )
+ *   x0 [B,F0,D], xk [B,Hk,D] (batch strides x0_bstride / xk_bstride in floats, so xk can be the
+ *   [:, :Hk] channel slice of the previous layer's [B,L,D] output when direct=False),
+ *   W [F0*Hk, L] (Keras filter f_k with the leading 1 squeezed),
+ *   bias [L] or NULL, y [B,L,D] (already in the transposed layout of layers.py:710).
+ * Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the Z = x0 (x) xk tensor is generated on the fly
+ * in LDS and never written to HBM.
+ * Backward (G = grad_y * act'(y)): grad_x0, grad_xk (ACCUMULATED: caller zeroes or passes the
+ * running gradient), grad_W [F0*Hk, L] and grad_bias [L] (ACCUMULATED: zero first).          */
+int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W, const float* bias,
+                     int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride,
+                     int64_t xk_bstride, float* y, void* stream);
+int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const float* y,
+                     const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                     int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                     float* grad_W, float* grad_bias, void* stream);
+
+/* ---- a12 MultiheadAttention core (models/layers.py:129-145) ------------------------------- *
+ * q,k,v [B,F,D] (already relu(Dense(x)), layers.py:123-125); H heads split on the last axis
+ * (d_h = D/H); out[b,:,h] = softmax(q_h k_h^T / sqrt(d_h)) v_h, heads merged back on the last
+ * axis -> out [B,F,D].  Nothing of size [B,H,F,F] is written: the forward saves only
+ * lse [B,H,F] (log-sum-exp of each scaled score row) and the backward recomputes the
+ * probabilities from q,k,lse and uses `out` for delta = rowsum(dO * O).                     */
+int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D, int H,
+                    float* out, float* lse, void* stream);
+int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float* out,
+                    const float* lse, const float* grad_out, int B, int F, int D, int H,
+                    float* grad_q, float* grad_k, float* grad_v, void* stream);
+
+/* ---- a13 optimizer step (Keras Adam, models/deepmodel.py:321-322) ------------------------- *
+ * Keras semantics: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).
+ * Dense: n contiguous floats.  Rows: row-sparse ("lazy") variant touching only rows[i];
+ * duplicates were merged into grad_table_dense by dt_embedding_bwd_dense, the first thread to
+ * claim a row in row_epoch [n_table_rows] (atomicExch to `epoch`, a fresh value per step)
+ * applies the update and re-zeroes that gradient row.                                        */
+int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
+                       float beta1, float beta2, float eps, void* stream);
+int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense,
+                      const int64_t* rows, int n_rows, int D, int* row_epoch, int epoch,
+                      float lr_t, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DT_HIP_H */

@@ -1,0 +1,373 @@
+# -*- coding:utf-8 -*-
+"""CPU ORACLE — test infrastructure, never shipped, never measured as the product.
+
+Op-for-op restatement (torch CPU, float64 or float32) of the reference's hot path:
+`deeptables/models/layers.py`, the net functions of `deeptables/models/deepnets.py` that wire
+them, and the graph assembled by `deeptables/models/deepmodel.py:259-317`.  Each function
+mirrors the TF/Keras op SEQUENCE of the cited lines (split/concat/matmul/reduce in the same
+order), not a simplified closed form; `oracle/closed_form.py` holds the independent closed
+forms, and `tests/test_oracle.py` checks the two against each other and against the golden
+vectors in `tests/golden/`.
+
+PARITY UNPINNED: the reference ships no golden vectors / known-answer tests for this path
+(all its assertions are `AUC >= 0` or shapes: deeptables/tests/models/nets_test.py:43-44,
+layers_test.py:28-29) and TensorFlow/Keras — where the arithmetic lives (requirements.txt:1
+`tensorflow>=2.4`, CI pins 2.16.2-2.18.0) — is not installable in this environment.  The oracle
+is therefore anchored on the reference's own call sites and on the published semantics of the
+TF/Keras ops they call; every Keras default assumed is written down in KERAS_DEFAULTS below.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+Gradients of the oracle come from torch.autograd on these functions.
+"""
+import itertools
+import math
+
+import torch
+
+# Keras defaults this oracle assumes (each overridable by the caller):
+KERAS_DEFAULTS = {
+    'bn_epsilon': 1e-3,          # keras.layers.BatchNormalization(epsilon=0.001)
+    'bn_momentum': 0.99,         # keras.layers.BatchNormalization(momentum=0.99)
+    'bn_variance': 'biased',     # batch variance = mean((x-mean)^2); moving var fed with it
+    'embeddings_initializer': ('uniform', -0.05, 0.05),   # Keras 'uniform' == RandomUniform(+-0.05)
+    'dense_kernel_initializer': 'glorot_uniform', 'dense_bias_initializer': 'zeros',
+    'add_weight_default_initializer': 'glorot_uniform',   # OuterProduct.kernel etc.
+    'he_uniform_limit': 'sqrt(6/fan_in)',
+    'adam': dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7),
+    'bce': 'computed from logits in graph mode; probabilities clipped to [1e-7, 1-1e-7] otherwise',
+    'float_to_int_cast': 'truncation toward zero',
+    'oob_embedding_index': 'TF-CPU raises InvalidArgument; TF-GPU returns a zero row',
+}
+
+
+# ---------------------------------------------------------------------------------------------
+# layers.py
+# ---------------------------------------------------------------------------------------------
+def multi_column_embedding(inputs, tables):
+    """MultiColumnEmbedding.call — layers.py:889-904.
+    inputs [B,F] float32/int; tables: list of F tensors (vocab_f, D_f) -> list of F x [B,1,D_f]."""
+    if inputs.shape[1] == 0:                                   # :890-891
+        return []
+    if inputs.dtype not in (torch.int32, torch.int64):         # :893-895  cast(float->int32) truncates
+        inputs = inputs.to(torch.int32)
+    columns = torch.split(inputs, 1, dim=1)                    # :896 tf.split(inputs, F, axis=1)
+    out = []
+    for i, col in enumerate(columns):                          # :898-903
+        emb = tables[i][col.long()]                            # embedding_lookup -> [B,1,D]
+        out.append(emb)
+    return out
+
+
+def fm(x):
+    """FM.call — layers.py:53-62.  x [B,F,D] -> [B,1]."""
+    if x.dim() != 3:
+        raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {x.dim()}.')
+    square_of_sum = torch.square(torch.sum(x, dim=1, keepdim=True))      # :56-57
+    sum_of_square = torch.sum(x * x, dim=1, keepdim=True)                # :58-59
+    cross = square_of_sum - sum_of_square                                # :60
+    cross = 0.5 * torch.sum(cross, dim=2, keepdim=False)                 # :61
+    return cross
+
+
+def cross(x, kernels, biases):
+    """Cross.call — layers.py:428-436.  x [B,C]; kernels[i], biases[i]: (C,1)."""
+    if x.dim() != 2:
+        raise ValueError(f'Wrong dimensions of x, expected 2 but input {x.dim()}.')
+    x_f = x.unsqueeze(-1)                                                # :431 expand_dims
+    x_n = x_f
+    for i in range(len(kernels)):                                        # :433-434
+        xw = torch.tensordot(x_n, kernels[i], dims=([1], [0]))           # [B,1,1]
+        x_n = torch.matmul(x_f, xw) + x_n + biases[i]
+    return x_n.reshape(-1, x_f.shape[1])                                 # :435
+
+
+def _pair_rows_cols(n):
+    row, col = [], []
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            row.append(i)
+            col.append(j)
+    return row, col
+
+
+def inner_product(xs):
+    """InnerProduct.call — layers.py:473-487.  xs: list of F x [B,1,D] -> [B, F(F-1)/2]."""
+    if xs[0].dim() != 3:
+        raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {xs[0].dim()}.')
+    n = len(xs)
+    num_pairs = int(n * (n - 1) / 2)
+    row, col = _pair_rows_cols(n)                                        # :477-482
+    p = torch.cat([xs[i] for i in row], dim=1)                           # :483
+    q = torch.cat([xs[j] for j in col], dim=1)                           # :484
+    return torch.sum(p * q, dim=-1).reshape(-1, num_pairs)               # :485
+
+
+def outer_product(xs, kernel, kernel_type='mat'):
+    """OuterProduct.call — layers.py:543-581.
+    kernel: mat (D,P,D) | vec (P,D) | num (P,1)."""
+    if xs[0].dim() != 3:
+        raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {xs[0].dim()}.')
+    row, col = _pair_rows_cols(len(xs))                                  # :546-552
+    p = torch.cat([xs[i] for i in row], dim=1)                           # [B,P,D]
+    q = torch.cat([xs[i] for i in col], dim=1)
+    if kernel_type == 'mat':                                             # :557-574
+        p = p.unsqueeze(1)                                               # [B,1,P,D]
+        inner = torch.sum(p * kernel, dim=-1)                            # [B,D,P]   (p*kernel: [B,D,P,D])
+        inner = inner.permute(0, 2, 1)                                   # [B,P,D]
+        kp = torch.sum(inner * q, dim=-1)                                # [B,P]
+    else:                                                                # :575-580
+        k = kernel.unsqueeze(0)
+        kp = torch.sum(p * q * k, dim=-1)
+    return kp
+
+
+def _activation(name):
+    if name is None or name == 'linear':
+        return lambda t: t
+    if name == 'relu':
+        return torch.relu
+    if name == 'tanh':
+        return torch.tanh
+    if name == 'sigmoid':
+        return torch.sigmoid
+    raise ValueError(name)
+
+
+def cin(x, filters, biases, cross_layer_size, activation='relu', direct=False, dense_out=None,
+        dense_out0=None, return_hidden=False):
+    """CIN.call — layers.py:680-734 (reduce_D=False).
+    x [B,F,D]; filters[k]: (1, F*H_k, L_k); biases[k]: (L_k,) or None.
+    dense_out = (kernel (sum_out,1), bias (1,)) is exFM_out; dense_out0 the use_residual Dense.
+    Returns exFM_out [B,1] (or the pre-Dense `result` [B, sum_out] if dense_out is None)."""
+    if x.dim() != 3:
+        raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {x.dim()}.')
+    dim = int(x.shape[-1])
+    act = _activation(activation)
+    field_nums = [int(x.shape[1])]
+    hidden_nn_layers = [x]
+    final_result = []
+    split_tensor0 = torch.split(hidden_nn_layers[0], 1, dim=2)           # :688  D x [B,F,1]
+    n_layers = len(cross_layer_size)
+    for idx, layer_size in enumerate(cross_layer_size):
+        split_tensor = torch.split(hidden_nn_layers[-1], 1, dim=2)       # :690
+        # :691 tf.matmul(split_tensor0, split_tensor, transpose_b=True) -> [D,B,F,H]
+        dot_result_m = torch.stack([torch.matmul(a, b.transpose(1, 2))
+                                    for a, b in zip(split_tensor0, split_tensor)], dim=0)
+        dot_result_o = dot_result_m.reshape(dim, -1, field_nums[0] * field_nums[idx])   # :692
+        dot_result = dot_result_o.permute(1, 0, 2)                       # :693  [B,D,F*H]
+        filt = filters[idx]                                              # :702  (1, F*H, L)
+        curr_out = torch.matmul(dot_result, filt[0])                     # :703 conv1d, width-1 kernel
+        if biases is not None and biases[idx] is not None:               # :704-705
+            curr_out = curr_out + biases[idx]
+        curr_out = act(curr_out)                                         # :707
+        curr_out = curr_out.permute(0, 2, 1)                             # :708  [B,L,D]
+        if direct:                                                       # :710-712
+            direct_connect = curr_out
+            next_hidden = curr_out
+            field_nums.append(layer_size)
+        else:                                                            # :713-718
+            if idx != n_layers - 1:
+                next_hidden, direct_connect = torch.split(curr_out, [layer_size // 2] * 2, dim=1)
+            else:
+                direct_connect = curr_out
+                next_hidden = None
+            field_nums.append(layer_size // 2)
+        final_result.append(direct_connect)                              # :720
+        hidden_nn_layers.append(next_hidden)
+    result = torch.cat(final_result, dim=1)                              # :723
+    result = torch.sum(result, dim=-1)                                   # :724  [B, sum]
+    if return_hidden:
+        return result
+    if dense_out is None:
+        return result
+    if dense_out0 is not None:                                           # :726-729 use_residual
+        k0, b0 = dense_out0
+        ex0 = act(result @ k0 + b0)
+        result = torch.cat([ex0, result], dim=1)
+    k, b = dense_out
+    return result @ k + b                                                # :731
+
+
+def keras_batchnorm(x, gamma, beta, moving_mean=None, moving_var=None, training=True,
+                    eps=KERAS_DEFAULTS['bn_epsilon'], momentum=KERAS_DEFAULTS['bn_momentum']):
+    """keras.layers.BatchNormalization over the last axis [ext].  Returns (y, new_mean, new_var)."""
+    red = tuple(range(x.dim() - 1))
+    if training:
+        mean = x.mean(dim=red)
+        var = ((x - mean) ** 2).mean(dim=red)                            # biased
+        y = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+        nm = None if moving_mean is None else moving_mean * momentum + mean * (1 - momentum)
+        nv = None if moving_var is None else moving_var * momentum + var * (1 - momentum)
+        return y, nm, nv
+    y = (x - moving_mean) / torch.sqrt(moving_var + eps) * gamma + beta
+    return y, moving_mean, moving_var
+
+
+def multihead_attention(x, w, num_heads=1, use_residual=True, training=True):
+    """MultiheadAttention.call — layers.py:119-153 (dropout_rate=0).
+    w: dict with Q,K,V,(R): (kernel (D,D), bias (D,)), bn: (gamma, beta)."""
+    if x.dim() != 3:
+        raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {x.dim()}.')
+    q = torch.relu(x @ w['Q'][0] + w['Q'][1])                            # :123  Dense(relu)
+    k = torch.relu(x @ w['K'][0] + w['K'][1])                            # :124
+    v = torch.relu(x @ w['V'][0] + w['V'][1])                            # :125
+    if use_residual:
+        v_res = torch.relu(x @ w['R'][0] + w['R'][1])                    # :126-127
+    D = x.shape[-1]
+    hs = D // num_heads
+    Q_ = torch.cat(torch.split(q, hs, dim=2), dim=0)                     # :130
+    K_ = torch.cat(torch.split(k, hs, dim=2), dim=0)                     # :131
+    V_ = torch.cat(torch.split(v, hs, dim=2), dim=0)                     # :132
+    weights = torch.matmul(Q_, K_.transpose(1, 2))                       # :135
+    weights = weights / (K_.shape[-1] ** 0.5)                            # :137
+    weights = torch.softmax(weights, dim=-1)                             # :139
+    outputs = torch.matmul(weights, V_)                                  # :143
+    outputs = torch.cat(torch.split(outputs, x.shape[0], dim=0), dim=2)  # :145
+    if use_residual:
+        outputs = outputs + v_res                                        # :148-149
+    outputs = torch.relu(outputs)                                        # :150
+    gamma, beta = w['bn'][0], w['bn'][1]
+    mm = w['bn'][2] if len(w['bn']) > 2 else None
+    mv = w['bn'][3] if len(w['bn']) > 3 else None
+    outputs, _, _ = keras_batchnorm(outputs, gamma, beta, mm, mv, training=training)   # :152
+    return outputs
+
+
+# ---------------------------------------------------------------------------------------------
+# deepnets.py net functions + deepmodel.py graph (explicit-weights functional form)
+# ---------------------------------------------------------------------------------------------
+def dnn(x, layers_w, activation='relu'):
+    """deepnets.dnn — deepnets.py:401-427 with (units, dropout=0, batch_norm=False) cells:
+    Dense(bias) -> Activation.  layers_w: list of (kernel, bias)."""
+    act = _activation(activation)
+    for k, b in layers_w:
+        x = x @ k
+        if b is not None:
+            x = x + b
+        x = act(x)
+    return x
+
+
+def linear_net(embeddings, dense, kernel):
+    """deepnets.linear — deepnets.py:43-66."""
+    x_emb = None
+    if embeddings:
+        concat = torch.cat(embeddings, dim=1) if len(embeddings) > 1 else embeddings[0]   # :49
+        x_emb = torch.sum(concat, dim=-1)                                                   # :51
+    if x_emb is not None and dense is not None:
+        x = torch.cat([x_emb, dense], dim=-1)                                               # :55
+    elif x_emb is not None:
+        x = x_emb
+    else:
+        x = dense
+    return x @ kernel                                                                      # :64 Dense(1,no bias)
+
+
+def model_forward(weights, cat_idx, dense, nets, config=None, training=True, return_parts=False):
+    """DeepModel.__build_model — deepmodel.py:259-317, binary task, stacking 'add', dropout 0.
+    weights: dict keyed with the Keras layer/weight names (see tests/golden/make_golden.py).
+    cat_idx [B,F] float32 (reference input contract), dense [B,Nd] or None.
+    Returns the LOGIT fed to the sigmoid of `task_output` ([B,1]) and the probability."""
+    config = config or {}
+    tables = weights['emb_categorical_vars_all']                     # list of (V_f, D)
+    embeddings = multi_column_embedding(cat_idx, tables)             # :264 / :388-404
+    flatten_emb = None
+    if embeddings:
+        flatten_emb = torch.cat(embeddings, dim=-1).reshape(cat_idx.shape[0], -1)   # :269-274
+    if flatten_emb is not None and dense is not None:                # :348-353
+        x = torch.cat([flatten_emb, dense], dim=-1)
+    elif flatten_emb is not None:
+        x = flatten_emb
+    else:
+        x = dense
+    bn = weights['bn_concat_emb_dense']                              # :359
+    concat_emb_dense, _, _ = keras_batchnorm(x, bn[0], bn[1], bn[2] if len(bn) > 2 else None,
+                                             bn[3] if len(bn) > 3 else None, training=training)
+    outs = {}
+    for net in nets:                                                 # :281-285
+        if net == 'linear':
+            outs[net] = linear_net(embeddings, dense, weights['linear_logit'])
+        elif net == 'fm_nets':
+            outs[net] = fm(torch.cat(embeddings, dim=1))             # deepnets.py:88-94
+        elif net == 'dnn_nets':
+            outs[net] = dnn(concat_emb_dense, weights['dnn'], config.get('dnn_activation', 'relu'))
+        elif net == 'cin_nets':
+            cp = config['cin_params']
+            outs[net] = cin(torch.cat(embeddings, dim=1), weights['cin_filters'], weights.get('cin_bias'),
+                            cp['cross_layer_size'], cp.get('activation', 'relu'), cp.get('direct', False),
+                            dense_out=weights['cin_exFM_out'])       # deepnets.py:75-80
+        elif net == 'dcn_nets':                                      # deepnets.py:194-207
+            cross_out = cross(concat_emb_dense, weights['dcn_cross_kernels'], weights['dcn_cross_bias'])
+            dnn_out = dnn(concat_emb_dense, weights['dcn_dnn'], config.get('dnn_activation', 'relu'))
+            outs[net] = torch.cat([cross_out, dnn_out], dim=-1)
+        elif net == 'autoint_nets':                                  # deepnets.py:210-224
+            ap = config['autoint_params']
+            o = torch.cat(embeddings, dim=1)
+            for lw in weights['autoint_layers']:
+                o = multihead_attention(o, lw, ap.get('num_heads', 1), ap.get('use_residual', True),
+                                        training=training)
+            outs[net] = o.reshape(o.shape[0], -1)
+        else:
+            raise ValueError(net)
+    if len(outs) > 1:                                                # :286-297
+        logits = []
+        for name, out in outs.items():
+            if out.shape[-1] > 1:
+                out = out @ weights[f'dense_logit_{name}']           # Dense(1, no bias)
+            logits.append(out)
+        xs = logits[0]
+        for t in logits[1:]:
+            xs = xs + t                                              # Add()
+    else:
+        xs = next(iter(outs.values()))
+    k, b = weights['task_output']                                    # :455 Dense(1, sigmoid)
+    logit = xs @ k
+    if b is not None:
+        logit = logit + b
+    prob = torch.sigmoid(logit)
+    if return_parts:
+        return logit, prob, outs, concat_emb_dense
+    return logit, prob
+
+
+def binary_crossentropy_from_logits(logit, y):
+    """keras.losses.BinaryCrossentropy on a sigmoid output, evaluated from logits (graph mode):
+    mean(max(z,0) - z*y + log1p(exp(-|z|)))."""
+    z = logit.reshape(-1)
+    y = y.reshape(-1).to(z.dtype)
+    return (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# Keras initializers (for building reference-shaped random weights)
+# ---------------------------------------------------------------------------------------------
+def glorot_uniform(shape, gen, fan_in=None, fan_out=None, dtype=torch.float32):
+    if fan_in is None:
+        fan_in, fan_out = _fans(shape)
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1).mul(limit).to(dtype)
+
+
+def he_uniform(shape, gen, fan_in=None, dtype=torch.float32):
+    if fan_in is None:
+        fan_in, _ = _fans(shape)
+    limit = math.sqrt(6.0 / fan_in)
+    return (torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1).mul(limit).to(dtype)
+
+
+def _fans(shape):
+    """keras.initializers compute_fans: 2-D (in,out); N-D: receptive field * in / out."""
+    if len(shape) < 1:
+        return 1, 1
+    if len(shape) == 1:
+        return shape[0], shape[0]
+    if len(shape) == 2:
+        return shape[0], shape[1]
+    rf = 1
+    for s in shape[:-2]:
+        rf *= s
+    return shape[-2] * rf, shape[-1] * rf
+
+
+def pairs(n):
+    return list(itertools.combinations(range(n), 2))
