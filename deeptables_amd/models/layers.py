@@ -1,0 +1,500 @@
+# -*- coding:utf-8 -*-
+"""Drop-in for `deeptables.models.layers` (deeptables/models/layers.py): same class names,
+constructor arguments, `build/call/get_config` protocol, error behaviour and custom-object
+registry — but `call` dispatches to the MI355X HIP kernels through the C-ABI (deeptables_amd.ops)
+instead of a chain of TF ops.  Weight names/shapes follow the Keras layer so checkpoints map 1:1.
+"""
+import itertools
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..functional import (Layer, Dense, Dropout, BatchNormalization, Activation, Concatenate, Flatten,  # noqa: F401
+                          Input, Lambda, Add, SpatialDropout1D, ReduceSum, initialize, get_activation)
+from ..utils import consts  # noqa: F401
+
+
+def _ndim_check(x, expected, what='inputs'):
+    nd = x.dim() if torch.is_tensor(x) else len(x.shape)
+    if nd != expected:
+        raise ValueError(f'Wrong dimensions of {what}, expected {expected} but input {nd}.')
+
+
+# =============================================================================================
+# FM — deeptables/models/layers.py:27-62
+# =============================================================================================
+class FM(Layer):
+    """Factorization Machine 2nd-order term.  Input (batch, field, emb) -> output (batch, 1)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape)}.')
+        return (input_shape[0], 1)
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 3)
+        return ops.fm(x)
+
+
+# =============================================================================================
+# MultiheadAttention — layers.py:65-158
+# =============================================================================================
+class MultiheadAttention(Layer):
+    """AutoInt interacting layer: relu-Dense Q/K/V(/residual) projections, per-head field attention
+    (HIP kernel), residual add, relu, BatchNormalization.  Output width = embedding_size
+    (the reference docstring says embedding_size*num_head; its code keeps embedding_size)."""
+
+    def __init__(self, params, **kwargs):
+        self.params = params
+        self.num_heads = params.get('num_heads', 1)
+        self.dropout_rate = params.get('dropout_rate', 0)
+        self.use_residual = params.get('use_residual', True)
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        self.num_units = input_shape[-1]
+        if self.num_units % self.num_heads != 0:
+            raise ValueError(f'embedding size {self.num_units} is not divisible by num_heads {self.num_heads}')
+        mk = lambda n: Dense(self.num_units, activation='relu', kernel_initializer='he_uniform',
+                             name=f'{self.name}_dense_{n}')
+        self.dense_Q, self.dense_K, self.dense_V = mk('q'), mk('k'), mk('v')
+        self.dense_residual = mk('residual')
+        self.dropout_weights = Dropout(rate=self.dropout_rate, name=f'{self.name}_dropout')
+        self.batch_normalize = BatchNormalization(name=f'{self.name}_bn')
+        for l in (self.dense_Q, self.dense_K, self.dense_V, self.dense_residual, self.batch_normalize):
+            l.build(input_shape)
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape)}.')
+        return tuple(input_shape)
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 3)
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError('attention-weight dropout > 0 is not implemented in the HIP attention '
+                                      'kernel (the probabilities are never materialised); use dropout_rate=0.')
+        q = self.dense_Q(x)
+        k = self.dense_K(x)
+        v = self.dense_V(x)
+        outputs = ops.mha_core(q, k, v, self.num_heads)
+        if self.use_residual:
+            outputs = outputs + self.dense_residual(x)
+        outputs = torch.relu(outputs)
+        return self.batch_normalize(outputs)
+
+    def get_config(self):
+        c = super().get_config()
+        c['params'] = self.params
+        return c
+
+
+# =============================================================================================
+# Cross — layers.py:385-441
+# =============================================================================================
+class Cross(Layer):
+    def __init__(self, params, **kwargs):
+        self.params = params
+        self.num_cross_layer = params.get('num_cross_layer', 2)
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        num_dims = input_shape[-1]
+        self.kernels = nn.ParameterList()
+        self.bias = nn.ParameterList()
+        for i in range(self.num_cross_layer):   # Keras shapes (num_dims, 1)
+            self.kernels.append(nn.Parameter(initialize((num_dims, 1), 'glorot_uniform')))
+            self.bias.append(nn.Parameter(initialize((num_dims, 1), 'zeros')))
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 2:
+            raise ValueError(f'Wrong dimensions of x, expected 2 but input {len(input_shape)}.')
+        return tuple(input_shape)
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 2, 'x')
+        if self.num_cross_layer == 0:
+            return x
+        w = torch.stack([k.reshape(-1) for k in self.kernels], 0)
+        b = torch.stack([k.reshape(-1) for k in self.bias], 0)
+        return ops.cross(x, w, b)
+
+    def get_config(self):
+        c = super().get_config()
+        c['params'] = self.params
+        return c
+
+
+# =============================================================================================
+# InnerProduct / OuterProduct — layers.py:444-586
+# =============================================================================================
+def _stack_fields(xs):
+    """list of F x [B,1,D] -> [B,F,D] (free when they are the views of one embedding block)."""
+    from ..functional import _packed_view
+    pv = _packed_view(list(xs), 1)
+    return pv if pv is not None else torch.cat(list(xs), dim=1)
+
+
+class InnerProduct(Layer):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+    def compute_output_shape(self, input_shape):
+        n = len(input_shape)
+        if len(input_shape[0]) != 3:
+            raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape[0])}.')
+        return (input_shape[0][0], n * (n - 1) // 2)
+
+    def call(self, x, **kwargs):
+        _ndim_check(x[0], 3)
+        return ops.inner_product(_stack_fields(x))
+
+
+class OuterProduct(Layer):
+    def __init__(self, params, **kwargs):
+        self.params = params
+        self.kernel_type = params.get('outer_product_kernel_type', 'mat')
+        if self.kernel_type not in ['mat', 'vec', 'num']:
+            raise ValueError("kernel_type must be mat,vec or num")
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        n = len(input_shape)
+        num_pairs = n * (n - 1) // 2
+        embed_size = input_shape[0][-1]
+        shape = {'mat': (embed_size, num_pairs, embed_size), 'vec': (num_pairs, embed_size),
+                 'num': (num_pairs, 1)}[self.kernel_type]
+        self.kernel = self.add_weight('kernel', shape, 'glorot_uniform')   # add_weight default initializer
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        n = len(input_shape)
+        if len(input_shape[0]) != 3:
+            raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape[0])}.')
+        return (input_shape[0][0], n * (n - 1) // 2)
+
+    def call(self, x, **kwargs):
+        _ndim_check(x[0], 3)
+        return ops.outer_product(_stack_fields(x), self.kernel, self.kernel_type)
+
+    def get_config(self):
+        c = super().get_config()
+        c['params'] = self.params
+        return c
+
+
+# =============================================================================================
+# CIN — layers.py:589-739
+# =============================================================================================
+class CIN(Layer):
+    def __init__(self, params, **kwargs):
+        self.params = params
+        self.cross_layer_size = params.get('cross_layer_size', (128, 128,))
+        self.activation = params.get('activation', 'relu')
+        self.use_residual = params.get('use_residual', False)
+        self.use_bias = params.get('use_bias', False)
+        self.direct = params.get('direct', False)
+        self.reduce_D = params.get('reduce_D', False)
+        if len(self.cross_layer_size) == 0:
+            raise ValueError("cross_layer_size must be a list(tuple) of length greater than 1")
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError("Unexpected inputs dimensions %d, expect to be 3 dimensions" % (len(input_shape)))
+        self.field_nums = [int(input_shape[1])]
+        embed_dim = input_shape[-1]
+        self.f_ = nn.ParameterList()
+        self.f0_ = nn.ParameterList()
+        self.f__ = nn.ParameterList()
+        self.bias = nn.ParameterList()
+        n = len(self.cross_layer_size)
+        for i, layer_size in enumerate(self.cross_layer_size):
+            if self.reduce_D:
+                self.f0_.append(nn.Parameter(initialize((1, layer_size, self.field_nums[0], embed_dim), 'he_uniform')))
+                self.f__.append(nn.Parameter(initialize((1, layer_size, embed_dim, self.field_nums[-1]), 'he_uniform')))
+            else:
+                self.f_.append(nn.Parameter(
+                    initialize((1, self.field_nums[-1] * self.field_nums[0], layer_size), 'he_uniform')))
+            if self.use_bias:
+                self.bias.append(nn.Parameter(initialize((layer_size,), 'zeros')))
+            if self.direct:
+                self.field_nums.append(layer_size)
+            else:
+                if i != n - 1 and layer_size % 2 > 0:
+                    raise ValueError(
+                        "cross_layer_size must be even number except for the last layer when direct=True")
+                self.field_nums.append(layer_size // 2)
+        out_width = self._result_width()
+        if self.use_residual:
+            self.exFM_out0 = Dense(self.cross_layer_size[-1], activation=self.activation,
+                                   kernel_initializer='he_uniform', name=f'{self.name}_exFM_out0')
+            self.exFM_out0.build((None, out_width))
+            self.exFM_out = Dense(1, activation=None, name=f'{self.name}_exFM_out')
+            self.exFM_out.build((None, out_width + self.cross_layer_size[-1]))
+        else:
+            self.exFM_out = Dense(1, activation=None, name=f'{self.name}_exFM_out')
+            self.exFM_out.build((None, out_width))
+        self.built = True
+
+    def _result_width(self):
+        n = len(self.cross_layer_size)
+        if self.direct:
+            return int(sum(self.cross_layer_size))
+        return int(sum(l // 2 if i != n - 1 else l for i, l in enumerate(self.cross_layer_size)))
+
+    def compute_output_shape(self, input_shape):
+        if len(input_shape) != 3:
+            raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape)}.')
+        return (input_shape[0], 1)
+
+    def _filter(self, idx, layer_size):
+        """[F0*Hk, L] filter of layer idx; reduce_D composes the low-rank factors (layers.py:697-702)."""
+        if not self.reduce_D:
+            return self.f_[idx][0]
+        f_m = torch.matmul(self.f0_[idx], self.f__[idx])                       # [1,L,F0,Hk]
+        f_o = f_m.reshape(1, layer_size, self.field_nums[0] * self.field_nums[idx])
+        return f_o.permute(0, 2, 1)[0]
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 3)
+        if self.activation not in ('relu', 'linear', None):
+            raise NotImplementedError(f'CIN activation {self.activation!r}: the HIP kernel fuses relu/linear only')
+        hidden = x
+        final_result = []
+        n = len(self.cross_layer_size)
+        for idx, layer_size in enumerate(self.cross_layer_size):
+            bias = self.bias[idx] if self.use_bias else None
+            curr_out = ops.cin_layer(x, hidden, self._filter(idx, layer_size), bias, self.activation)  # [B,L,D]
+            if self.direct:
+                direct_connect, hidden = curr_out, curr_out
+            elif idx != n - 1:
+                half = layer_size // 2
+                hidden, direct_connect = curr_out[:, :half], curr_out[:, half:]
+            else:
+                direct_connect, hidden = curr_out, None
+            final_result.append(direct_connect)
+        result = torch.cat(final_result, dim=1) if len(final_result) > 1 else final_result[0]
+        result = torch.sum(result, -1)
+        if self.use_residual:
+            ex0 = self.exFM_out0(result)
+            return self.exFM_out(torch.cat([ex0, result], dim=1))
+        return self.exFM_out(result)
+
+    def get_config(self):
+        c = super().get_config()
+        c['params'] = self.params
+        return c
+
+
+# =============================================================================================
+# MultiColumnEmbedding — layers.py:815-922
+# =============================================================================================
+# tables up to this many floats get an exact dense gradient (TF densifies IndexedSlices for Keras Adam);
+# larger tables keep the (rows, values) pair for the row-sparse optimizer / sparse all-gather.
+DENSE_GRAD_MAX_ELEMS = 1 << 22
+
+
+class MultiColumnEmbedding(Layer):
+    """One embedding table per categorical column, all looked up from one [B,F] input.
+
+    HBM layout: columns with the same output_dim share ONE packed table [sum vocab, D]
+    (column f starts at row_offset[f]); `embeddings[i]` are views of it with the Keras weight
+    names `embeddings_{i}`.  `call` returns the reference's list of F tensors [B,1,D_f]; they are
+    views of one [B,F,D] block so the graph's three Concatenate layers over them cost nothing."""
+
+    def __init__(self, input_dims, output_dims, dropout_rate=0., embeddings_initializer='uniform',
+                 embeddings_regularizer=None, activity_regularizer=None, embeddings_constraint=None,
+                 mask_zero=False, **kwargs):
+        kwargs.pop('input_shape', None)
+        kwargs.pop('autocast', None)
+        super().__init__(**kwargs)
+        if not isinstance(input_dims, (list, tuple)):
+            raise ValueError(f'[input_dims] must be a list or tuple.')
+        if not isinstance(output_dims, (list, tuple)):
+            raise ValueError(f'[output_dims] must be a list or tuple.')
+        if len(input_dims) != len(output_dims):
+            raise ValueError(f'The length of [input_dims] and [output_dims] must be the same.')
+        self.input_dims = [int(v) for v in input_dims]
+        self.output_dims = [int(v) for v in output_dims]
+        self.dropout_rate = dropout_rate
+        self.embeddings_initializer = embeddings_initializer
+        self.mask_zero = mask_zero
+        self.sparse_grads = {}      # group key -> list[SparseRowGrad] (filled by backward)
+        self.check_oob = False
+
+    def build(self, input_shape):
+        if input_shape[1] == 0:
+            return
+        if input_shape[1] != len(self.input_dims):
+            raise ValueError('The inputs dimension on axis 1 must be the same as the length of [input_dims].')
+        self.groups = []   # (D, [column indices])
+        for D in sorted(set(self.output_dims)):
+            self.groups.append((D, [i for i, d in enumerate(self.output_dims) if d == D]))
+        self.tables = nn.ParameterDict()
+        for D, cols in self.groups:
+            vocabs = [self.input_dims[i] for i in cols]
+            rows = int(sum(vocabs))
+            # initialise column by column so that each `embeddings_i` is an independent Keras init
+            t = torch.empty((rows, D), dtype=torch.float32)
+            o = 0
+            for v in vocabs:
+                t[o:o + v] = initialize((v, D), self.embeddings_initializer)
+                o += v
+            self.tables[f'd{D}'] = nn.Parameter(t)
+            offs = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).astype(np.int64)
+            self.register_buffer(f'row_offset_d{D}', torch.from_numpy(offs), persistent=False)
+            self.register_buffer(f'vocab_d{D}', torch.tensor(vocabs, dtype=torch.int32), persistent=False)
+            self.register_buffer(f'cols_d{D}', torch.tensor(cols, dtype=torch.int64), persistent=False)
+        self.register_buffer('oob_count', torch.zeros(1, dtype=torch.int32), persistent=False)
+        self.dropouts = nn.ModuleList(
+            [SpatialDropout1D(self.dropout_rate) for _ in self.input_dims]) if self.dropout_rate > 0 else []
+        self.built = True
+
+    @property
+    def embeddings(self):
+        """Per-column [vocab_i, D_i] views in column order (Keras weights `embeddings_{i}`)."""
+        out = [None] * len(self.input_dims)
+        for D, cols in self.groups:
+            t = self.tables[f'd{D}']
+            o = 0
+            for i in cols:
+                out[i] = t[o:o + self.input_dims[i]]
+                o += self.input_dims[i]
+        return out
+
+    def set_embeddings(self, arrays):
+        with torch.no_grad():
+            for dst, src in zip(self.embeddings, arrays):
+                dst.copy_(torch.as_tensor(np.asarray(src), dtype=torch.float32))
+
+    def get_weights_dict(self):
+        return {f'embeddings_{i}': e.detach().cpu().numpy() for i, e in enumerate(self.embeddings)}
+
+    def add_sparse_grad(self, key, grad):
+        self.sparse_grads.setdefault(key, []).append(grad)
+
+    def uses_dense_grad(self, D):
+        return self.tables[f'd{D}'].numel() <= DENSE_GRAD_MAX_ELEMS
+
+    def compute_output_shape(self, input_shape):
+        if input_shape[1] == 0:
+            return []
+        return [(input_shape[0], 1, d) for d in self.output_dims]
+
+    def compute_mask(self, inputs, mask=None):
+        if not self.mask_zero:
+            return None
+        return inputs != 0
+
+    def lookup_group(self, inputs, D, cols):
+        key = f'd{D}'
+        table = self.tables[key]
+        idx = inputs
+        if len(self.groups) > 1 or len(cols) != inputs.shape[1]:
+            idx = inputs.index_select(1, getattr(self, f'cols_{key}'))
+        holder = _GroupHolder(self, key)
+        return ops.embedding_lookup(idx, table, getattr(self, f'row_offset_{key}'), getattr(self, f'vocab_{key}'),
+                                    holder=holder, dense_grad=self.uses_dense_grad(D),
+                                    oob=self.oob_count if self.check_oob else None)
+
+    def call(self, inputs, **kwargs):
+        if inputs.shape[1] == 0:
+            return []
+        if inputs.dtype not in (torch.float32, torch.int32):
+            inputs = inputs.to(torch.int32)
+        out = [None] * len(self.input_dims)
+        for D, cols in self.groups:
+            emb, _rows = self.lookup_group(inputs, D, cols)       # [B, len(cols), D]
+            for k, i in enumerate(cols):
+                v = emb[:, k:k + 1, :]
+                if self.dropout_rate > 0:
+                    v = self.dropouts[i](v)
+                elif len(self.groups) == 1:
+                    v._dt_pack = (emb, k)      # lets Concatenate return the packed block for free
+                out[i] = v
+        return out
+
+    def get_config(self):
+        c = super().get_config()
+        c.update(input_dims=self.input_dims, output_dims=self.output_dims, dropout_rate=self.dropout_rate,
+                 embeddings_initializer=self.embeddings_initializer, mask_zero=self.mask_zero)
+        return c
+
+
+class _GroupHolder:
+    """Receives the sparse gradient of one packed table from the gather's backward."""
+
+    def __init__(self, layer, key):
+        self.layer, self.key = layer, key
+
+    def add_sparse_grad(self, grad):
+        self.layer.add_sparse_grad(self.key, grad)
+
+
+# =============================================================================================
+# "next" layer types — present so the registry / net names resolve; they raise until
+# their HIP kernels land, rather than silently running an unaccelerated composition.
+# =============================================================================================
+class _NotYet(Layer):
+    def __init__(self, *args, **kwargs):
+        kwargs = {k: v for k, v in kwargs.items() if k in ('name',)}
+        super().__init__(**kwargs)
+
+    def call(self, x, **kwargs):
+        raise NotImplementedError(f'{self.__class__.__name__} is outside the accelerated hot path of this round '
+                                  f'(SURVEY §8 f3); no unaccelerated fallback is provided.')
+
+
+class AFM(_NotYet):
+    pass
+
+
+class SENET(_NotYet):
+    pass
+
+
+class BilinearInteraction(_NotYet):
+    pass
+
+
+class FGCNN(_NotYet):
+    pass
+
+
+class VarLenColumnEmbedding(_NotYet):
+    pass
+
+
+# =============================================================================================
+# custom-object registry — layers.py:1165-1186
+# =============================================================================================
+def register_custom_objects(objs_dict: dict):
+    import logging
+    for k, v in objs_dict.items():
+        if dt_custom_objects.get(k) is None:
+            dt_custom_objects[k] = v
+        else:
+            logging.getLogger(__name__).error(f'`register_custom_objects` cannot register duplicate key [{k}].')
+
+
+dt_custom_objects = {
+    'MultiColumnEmbedding': MultiColumnEmbedding,
+    'FM': FM,
+    'AFM': AFM,
+    'CIN': CIN,
+    'MultiheadAttention': MultiheadAttention,
+    'FGCNN': FGCNN,
+    'SENET': SENET,
+    'BilinearInteraction': BilinearInteraction,
+    'Cross': Cross,
+    'InnerProduct': InnerProduct,
+    'OuterProduct': OuterProduct,
+}

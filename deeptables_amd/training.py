@@ -1,0 +1,225 @@
+# -*- coding:utf-8 -*-
+"""Train-step glue around the layers hot path: losses, Keras-semantics Adam
+(dense + row-sparse embedding update, HIP kernels), metrics, batching, and the data-parallel
+gradient exchange hook.  This is what `keras.Model.fit` does for the reference
+(deeptables/models/deepmodel.py:114-129, :319-346)."""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .utils import consts
+
+
+# ---------------------------------------------------------------------------------------------
+# losses (keras.losses.* selected by DeepModel.__compile_model, deepmodel.py:324-338)
+# ---------------------------------------------------------------------------------------------
+def bce_from_logits(logit, y):
+    """BinaryCrossentropy on a sigmoid output evaluated from the logits (stable form)."""
+    z = logit.reshape(y.shape[0], -1)
+    y = y.reshape(z.shape).to(z.dtype)
+    return (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-z.abs()))).mean()
+
+
+def categorical_ce_from_logits(logit, y_onehot):
+    return -(torch.log_softmax(logit, dim=-1) * y_onehot).sum(-1).mean()
+
+
+def mse(pred, y):
+    return ((pred.reshape(y.shape[0], -1) - y.reshape(y.shape[0], -1).to(pred.dtype)) ** 2).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# Keras Adam
+# ---------------------------------------------------------------------------------------------
+class KerasAdam:
+    """keras.optimizers.Adam(learning_rate=1e-3, beta_1=.9, beta_2=.999, epsilon=1e-7):
+        lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
+    Dense parameters: one fused HIP launch each.  Packed embedding tables with a sparse gradient
+    (MultiColumnEmbedding.sparse_grads): duplicates merged by scatter-add into a persistent dense
+    scratch table, then a row-sparse ("lazy") update of only the rows touched this step — a
+    documented deviation from Keras' dense semantics for tables too large to sweep every step."""
+
+    _name = 'Adam'
+
+    def __init__(self, params, embedding_layers=(), learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
+        self.params = [p for p in params if p.requires_grad]
+        self.state = {}
+        self.t = 0
+        self.embedding_layers = list(embedding_layers)
+
+    def _st(self, p):
+        s = self.state.get(id(p))
+        if s is None:
+            s = {'m': torch.zeros_like(p), 'v': torch.zeros_like(p)}
+            self.state[id(p)] = s
+        return s
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+        for layer in self.embedding_layers:
+            layer.sparse_grads.clear()
+
+    def step(self):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        st = stream_ptr()
+        for p in self.params:
+            if p.grad is None:
+                continue
+            s = self._st(p)
+            g = p.grad.contiguous()
+            check(lib().dt_adam_dense_step(ptr(p.data), ptr(g), ptr(s['m']), ptr(s['v']), p.numel(), lr_t,
+                                           self.b1, self.b2, self.eps, st), 'dt_adam_dense_step')
+        for layer in self.embedding_layers:
+            for key, grads in layer.sparse_grads.items():
+                table = layer.tables[key]
+                s = self._st(table)
+                if 'scratch' not in s:
+                    s['scratch'] = torch.zeros_like(table)
+                    s['epoch'] = torch.zeros(table.shape[0], dtype=torch.int32, device=table.device)
+                D = table.shape[1]
+                for gr in grads:
+                    check(lib().dt_embedding_bwd_dense(ptr(gr.rows), ptr(gr.values), gr.rows.numel(), D,
+                                                       ptr(s['scratch']), st), 'dt_embedding_bwd_dense')
+                rows = grads[0].rows if len(grads) == 1 else torch.cat([g.rows for g in grads])
+                check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(s['scratch']),
+                                              ptr(rows), rows.numel(), D, ptr(s['epoch']), self.t, lr_t,
+                                              self.b1, self.b2, self.eps, st), 'dt_adam_rows_step')
+            layer.sparse_grads.clear()
+
+
+class SGD:
+    _name = 'SGD'
+
+    def __init__(self, params, embedding_layers=(), learning_rate=0.01):
+        self.lr = learning_rate
+        self.params = [p for p in params if p.requires_grad]
+        self.embedding_layers = list(embedding_layers)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+        for layer in self.embedding_layers:
+            layer.sparse_grads.clear()
+
+    def step(self):
+        with torch.no_grad():
+            for p in self.params:
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-self.lr)
+            for layer in self.embedding_layers:
+                for key, grads in layer.sparse_grads.items():
+                    table = layer.tables[key]
+                    for gr in grads:
+                        ok = gr.rows >= 0
+                        table.index_add_(0, gr.rows[ok], gr.values[ok], alpha=-self.lr)
+                layer.sparse_grads.clear()
+
+
+def make_optimizer(spec, params, embedding_layers):
+    if spec == 'auto' or spec is None or (isinstance(spec, str) and spec.lower() == 'adam'):
+        return KerasAdam(params, embedding_layers)
+    if isinstance(spec, str) and spec.lower() == 'sgd':
+        return SGD(params, embedding_layers)
+    if callable(spec):
+        return spec(params, embedding_layers)
+    raise ValueError(f'Unsupported optimizer: {spec!r}')
+
+
+# ---------------------------------------------------------------------------------------------
+# metrics (host side, outside any timed region)
+# ---------------------------------------------------------------------------------------------
+def metric_name(m):
+    if isinstance(m, str):
+        return m
+    return getattr(m, 'name', None) or getattr(m, '__name__', str(m))
+
+
+def compute_metric(m, y_true, y_prob, task):
+    name = metric_name(m)
+    key = name.lower()
+    y_true = np.asarray(y_true)
+    y_prob = np.asarray(y_prob)
+    if callable(m) and not isinstance(m, str):
+        return float(m(y_true, y_prob))
+    if key in ('accuracy', 'acc'):
+        if task == consts.TASK_MULTICLASS and y_prob.ndim == 2 and y_prob.shape[1] > 1:
+            yt = y_true.argmax(-1) if y_true.ndim == 2 else y_true
+            return float((y_prob.argmax(-1) == yt).mean())
+        return float(((y_prob.reshape(-1) > 0.5).astype(np.int64) == y_true.reshape(-1).astype(np.int64)).mean())
+    if key == 'auc':
+        from sklearn.metrics import roc_auc_score
+        try:
+            if y_prob.ndim == 2 and y_prob.shape[1] > 1:
+                return float(roc_auc_score(y_true, y_prob, multi_class='ovr'))
+            return float(roc_auc_score(y_true.reshape(-1), y_prob.reshape(-1)))
+        except ValueError:
+            return float('nan')
+    if key in ('mse', 'mean_squared_error'):
+        return float(((y_prob.reshape(-1) - y_true.reshape(-1)) ** 2).mean())
+    if key in ('rmse', 'rootmeansquarederror', 'root_mean_squared_error'):
+        return float(np.sqrt(((y_prob.reshape(-1) - y_true.reshape(-1)) ** 2).mean()))
+    if key in ('mae', 'mean_absolute_error'):
+        return float(np.abs(y_prob.reshape(-1) - y_true.reshape(-1)).mean())
+    raise ValueError(f'Unsupported metric: {name}')
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+    def add(self, epoch, logs):
+        self.epoch.append(epoch)
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+# ---------------------------------------------------------------------------------------------
+# data feed (replaces utils/dataset_generator.py:36-72 for in-memory frames)
+# ---------------------------------------------------------------------------------------------
+class TableBatches:
+    """Device-resident table: categorical ids [N,F] int32 (or float32, the reference contract),
+    one float32 block per ContinuousColumn, labels.  Yields aligned batch slices."""
+
+    def __init__(self, X, y, categorical_columns, continuous_columns, device, task=None, num_classes=None,
+                 cat_dtype=torch.int32):
+        self.n = len(X)
+        self.device = device
+        get = (lambda cols: X[cols].values) if hasattr(X, 'columns') else None
+        self.cat = None
+        if categorical_columns:
+            names = [c.name for c in categorical_columns]
+            arr = get(names) if get else np.asarray(X['cat'])
+            self.cat = torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype).to(device)
+        self.conts = []
+        for c in continuous_columns or []:
+            arr = get(list(c.column_names)) if get else np.asarray(X[c.name])
+            self.conts.append(torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32)).to(device))
+        self.y = None
+        if y is not None:
+            y = np.asarray(y)
+            if task == consts.TASK_MULTICLASS and y.ndim == 1:
+                y = np.eye(num_classes, dtype=np.float32)[y.astype(np.int64)]
+            self.y = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32)).to(device)
+
+    def batch(self, sel):
+        ins = []
+        if self.cat is not None:
+            ins.append(self.cat[sel])
+        ins += [c[sel] for c in self.conts]
+        return ins, (None if self.y is None else self.y[sel])
+
+    def iterate(self, batch_size, shuffle, drop_remainder, generator=None):
+        n = self.n
+        if shuffle:
+            perm = torch.randperm(n, device=self.device, generator=generator)
+        stop = (n // batch_size) * batch_size if drop_remainder else n
+        for s in range(0, stop, batch_size):
+            e = min(s + batch_size, n)
+            yield self.batch(perm[s:e] if shuffle else slice(s, e))

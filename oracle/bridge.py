@@ -1,0 +1,79 @@
+# -*- coding:utf-8 -*-
+"""CPU ORACLE (test infrastructure) — reads the weights out of a deeptables_amd DeepModel and
+evaluates the oracle's restatement of the reference graph (reference_layers.model_forward) on the
+same inputs.  Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+import torch
+
+from . import reference_layers as R
+
+
+def _t(p, dtype):
+    return p.detach().to('cpu', dtype).clone()
+
+
+def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
+    """deeptables_amd.models.deepmodel.DeepModel -> weights dict for R.model_forward."""
+    m = dm.model
+    L = m.layers_by_name
+    w = {}
+
+    def g(t):
+        t = _t(t, dtype)
+        return t.requires_grad_(True) if requires_grad else t
+
+    emb = L.get('emb_categorical_vars_all')
+    w['emb_categorical_vars_all'] = [g(e) for e in emb.embeddings] if emb is not None else []
+    bn = L['bn_concat_emb_dense']
+    w['bn_concat_emb_dense'] = (g(bn.gamma), g(bn.beta), _t(bn.moving_mean, dtype), _t(bn.moving_variance, dtype))
+    if 'linear_logit' in L:
+        w['linear_logit'] = g(L['linear_logit'].kernel)
+
+    def dnn(prefix):
+        out, i = [], 1
+        while f'{prefix}_dense_{i}' in L:
+            d = L[f'{prefix}_dense_{i}']
+            out.append((g(d.kernel), None if d.bias is None else g(d.bias)))
+            i += 1
+        return out
+
+    if 'dnn_dense_1' in L:
+        w['dnn'] = dnn('dnn')
+    if 'dcn_dense_1' in L:
+        w['dcn_dnn'] = dnn('dcn')
+    for name, layer in L.items():
+        if name.startswith('dense_logit_'):
+            w[name] = g(layer.kernel)
+        cls = layer.__class__.__name__
+        if cls == 'CIN':
+            w['cin_filters'] = [g(f) for f in layer.f_]
+            w['cin_bias'] = [g(b) for b in layer.bias] if layer.use_bias else None
+            w['cin_exFM_out'] = (g(layer.exFM_out.kernel), g(layer.exFM_out.bias))
+        elif cls == 'Cross' and name == 'dcn_cross_layer':
+            w['dcn_cross_kernels'] = [g(k) for k in layer.kernels]
+            w['dcn_cross_bias'] = [g(b) for b in layer.bias]
+        elif cls == 'MultiheadAttention':
+            w.setdefault('autoint_layers', []).append({
+                'Q': (g(layer.dense_Q.kernel), g(layer.dense_Q.bias)),
+                'K': (g(layer.dense_K.kernel), g(layer.dense_K.bias)),
+                'V': (g(layer.dense_V.kernel), g(layer.dense_V.bias)),
+                'R': (g(layer.dense_residual.kernel), g(layer.dense_residual.bias)),
+                'bn': (g(layer.batch_normalize.gamma), g(layer.batch_normalize.beta),
+                       _t(layer.batch_normalize.moving_mean, dtype), _t(layer.batch_normalize.moving_variance, dtype)),
+            })
+    out = L['task_output']
+    w['task_output'] = (g(out.kernel), None if out.bias is None else g(out.bias))
+    return w
+
+
+def oracle_config(dm):
+    c = dm.config
+    return {'cin_params': c.cin_params, 'autoint_params': c.autoint_params,
+            'dnn_activation': c.dnn_params.get('activation', 'relu')}
+
+
+def oracle_forward(dm, cat, dense, dtype=torch.float64, training=True, weights=None):
+    """-> (logit [B,1], prob [B,1]) of the oracle for the model's current weights."""
+    w = weights if weights is not None else oracle_weights(dm, dtype)
+    cat_f = None if cat is None else cat.detach().cpu().to(torch.float32)     # reference contract: float32 ids
+    dn = None if dense is None else dense.detach().cpu().to(dtype)
+    return R.model_forward(w, cat_f, dn, dm.config.nets, oracle_config(dm), training=training)

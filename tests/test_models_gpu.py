@@ -1,0 +1,194 @@
+# -*- coding:utf-8 -*-
+"""Whole-model parity: DeepModel graphs assembled through the drop-in API (ModelConfig + deepnets
+net functions + layers) vs the oracle's restatement of deepmodel.py:259-317, for the four
+BASELINE.json model configs.  Tolerance: logits within 1e-4 (north_star), gradients 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    'DeepFM': dict(nets=['linear', 'fm_nets', 'dnn_nets'], D=16),
+    'xDeepFM': dict(nets=['linear', 'cin_nets', 'dnn_nets'], D=16,
+                    cin_params={'cross_layer_size': (128, 128, 128), 'activation': 'relu', 'use_residual': False,
+                                'use_bias': False, 'direct': False, 'reduce_D': False}),
+    'AutoInt': dict(nets=['autoint_nets'], D=32,
+                    autoint_params={'num_attention': 3, 'num_heads': 4, 'dropout_rate': 0, 'use_residual': True}),
+    'DCN': dict(nets=['dcn_nets'], D=16, cross_params={'num_cross_layer': 6}),
+}
+
+
+def build(name, F=26, Nd=13, vocab=1000, seed=3):
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    spec = dict(CONFIGS[name])
+    D = spec.pop('D')
+    functional.set_seed(seed)
+    conf = ModelConfig(fixed_embedding_dim=True, embeddings_output_dim=D, embedding_dropout=0, dense_dropout=0,
+                       metrics=['AUC'], **spec)
+    cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])] if Nd else []
+    dm = DeepModel('binary', 2, conf, cats, conts)
+    dm.build()
+    return dm, cats
+
+
+def batch(cats, Nd, B, dev, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.stack([torch.randint(0, c.vocabulary_size, (B,), generator=g) for c in cats], 1)
+    dense = torch.randn(B, Nd, generator=g) if Nd else None
+    y = (torch.rand(B, generator=g) < 0.25).float().reshape(B, 1)
+    return idx, dense, y
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+@pytest.mark.parametrize('idx_dtype', ['int32', 'float32'])
+def test_logits_match_oracle(dev, name, idx_dtype):
+    from oracle import bridge
+    dm, cats = build(name)
+    B = 256
+    idx, dense, y = batch(cats, 13, B, dev)
+    # perturb BN/bias params away from their ones/zeros init so every term is exercised
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n, p in dm.model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g).to(p.device) * 0.1)
+    idx_in = idx.to(getattr(torch, idx_dtype)).to(dev)
+    dm.model.train()
+    logit = dm.model([idx_in, dense.to(dev)])
+    ref_logit, ref_prob = bridge.oracle_forward(dm, idx, dense, training=True)
+    err = (logit.detach().double().cpu() - ref_logit).abs().max().item()
+    assert err < 1e-4, f'{name}: logit error {err}'
+    dm.model.eval()
+    logit_e = dm.model([idx_in, dense.to(dev)])
+    ref_e, _ = bridge.oracle_forward(dm, idx, dense, training=False)
+    # (the train-mode forward above moved the moving statistics; oracle_weights re-reads them)
+    assert (logit_e.detach().double().cpu() - ref_e).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_gradients_match_oracle(dev, name):
+    from oracle import bridge, reference_layers as R
+    dm, cats = build(name, vocab=50)
+    B = 128
+    idx, dense, y = batch(cats, 13, B, dev)
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    R.binary_crossentropy_from_logits(ref_logit, y.double()).backward()
+
+    dm.model.train()
+    dm.optimizer.zero_grad()
+    logit = dm.model([idx.int().to(dev), dense.to(dev)])
+    loss = dm._loss(logit, y.to(dev))
+    loss.backward()
+
+    def rel(a, b):
+        b = b.double()
+        return (a.detach().double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+    L = dm.model.layers_by_name
+    emb = L['emb_categorical_vars_all']
+    table = emb.tables[f'd{cats[0].embeddings_output_dim}']
+    assert table.grad is not None            # small vocab -> dense exact gradient path
+    ref_table_grad = torch.cat([t.grad for t in w['emb_categorical_vars_all']], 0)
+    assert rel(table.grad, ref_table_grad) < 2e-4, name
+    assert rel(L['task_output'].kernel.grad, w['task_output'][0].grad) < 2e-4
+    bn = L['bn_concat_emb_dense']
+    assert rel(bn.gamma.grad, w['bn_concat_emb_dense'][0].grad) < 2e-4
+    if name == 'DeepFM':
+        assert rel(L['linear_logit'].kernel.grad, w['linear_logit'].grad) < 2e-4
+        assert rel(L['dnn_dense_1'].kernel.grad, w['dnn'][0][0].grad) < 2e-4
+    if name == 'xDeepFM':
+        cin = [l for l in dm.model.layers if l.__class__.__name__ == 'CIN'][0]
+        for i in range(3):
+            assert rel(cin.f_[i].grad, w['cin_filters'][i].grad) < 2e-4, f'cin filter {i}'
+    if name == 'DCN':
+        cr = L['dcn_cross_layer']
+        for i in range(6):
+            assert rel(cr.kernels[i].grad, w['dcn_cross_kernels'][i].grad) < 2e-4
+            assert rel(cr.bias[i].grad, w['dcn_cross_bias'][i].grad) < 2e-4
+    if name == 'AutoInt':
+        mh = [l for l in dm.model.layers if l.__class__.__name__ == 'MultiheadAttention']
+        for i, l in enumerate(mh):
+            assert rel(l.dense_Q.kernel.grad, w['autoint_layers'][i]['Q'][0].grad) < 5e-4
+            assert rel(l.dense_V.kernel.grad, w['autoint_layers'][i]['V'][0].grad) < 5e-4
+
+
+def test_sparse_grad_path_equals_dense(dev):
+    """Large-table path: (rows, values) pairs + row-sparse Adam == dense-gradient Adam on touched rows."""
+    from deeptables_amd.models import layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    try:
+        outs = []
+        for thresh in (old, 0):
+            dl.DENSE_GRAD_MAX_ELEMS = thresh
+            dm, cats = build('DeepFM', vocab=200, seed=11)
+            idx, dense, y = batch(cats, 13, 64, dev)
+            dm.model.train()
+            loss, _ = dm.train_step([idx.int().to(dev), dense.to(dev)], y.to(dev))
+            emb = dm.model.layers_by_name['emb_categorical_vars_all']
+            outs.append((emb.tables['d16'].detach().cpu().clone(), idx, float(loss)))
+        dense_t, idx, l0 = outs[0]
+        sparse_t, _, l1 = outs[1]
+        assert abs(l0 - l1) < 1e-6
+        offs = np.concatenate([[0], np.cumsum([c.vocabulary_size for c in cats])[:-1]])
+        rows = (idx.numpy() + offs[None, :]).reshape(-1)
+        assert torch.allclose(dense_t[rows], sparse_t[rows], atol=1e-7)
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+def test_fit_predict_evaluate_api(dev):
+    """DeepTable drop-in surface on a bank-shaped synthetic frame (BASELINE config 1 stand-in)."""
+    import pandas as pd
+    from deeptables_amd.models import DeepTable, ModelConfig, deepnets
+    rng = np.random.default_rng(0)
+    n = 2000
+    df = pd.DataFrame({
+        'job': rng.choice(['admin', 'tech', 'services', 'retired'], n),
+        'marital': rng.choice(['m', 's', 'd'], n),
+        'age': rng.integers(18, 80, n).astype(np.float32),
+        'balance': rng.normal(1000, 500, n).astype(np.float32),
+    })
+    y = ((df['age'] > 50) ^ (df['job'] == 'tech')).map({True: 'yes', False: 'no'})
+    conf = ModelConfig(nets=['linear', 'fm_nets'], metrics=['AUC', 'accuracy'], embedding_dropout=0,
+                       earlystopping_patience=0)
+    dt = DeepTable(config=conf)
+    model, history = dt.fit(df, y, batch_size=128, epochs=3, verbose=0)
+    assert 'auc' in history.history and 'val_AUC' in history.history
+    res = dt.evaluate(df, y)
+    assert res['AUC'] >= 0.0 and 'loss' in res
+    proba = dt.predict_proba(df)
+    assert proba.shape == (n, 2) and np.allclose(proba.sum(1), 1, atol=1e-5)
+    pred = dt.predict(df)
+    assert set(pred) <= {'yes', 'no'}
+    feats = dt.apply(df, output_layers=['flatten_embeddings'])
+    assert feats.shape[0] == n
+
+
+def test_custom_net_plugin_and_signature_check(dev):
+    """Plugin boundary: a user net function with the `linear` signature is registered and stacked."""
+    from deeptables_amd.models import deepnets, layers
+    from deeptables_amd.functional import Dense, Concatenate
+
+    def my_net(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+        x = layers.FM(name='my_fm')(Concatenate(axis=1, name='my_concat')(embeddings))
+        return Dense(1, name='my_dense')(Concatenate(name='my_cc')([x, concat_emb_dense]))
+
+    def bad(a, b):
+        return None
+
+    with pytest.raises(ValueError):
+        deepnets.register_nets(bad)
+    CONFIGS['custom'] = dict(nets=['linear', my_net], D=8)
+    try:
+        dm, cats = build('custom', F=5, Nd=3, vocab=20)
+        idx, dense, y = batch(cats, 3, 32, dev)
+        out = dm.model([idx.int().to(dev), dense.to(dev)])
+        assert out.shape == (32, 1)
+        assert 'my_dense' in dm.model.layers_by_name
+    finally:
+        CONFIGS.pop('custom')
