@@ -1,0 +1,334 @@
+# -*- coding:utf-8 -*-
+"""bench.py — BASELINE.json metric: training rows/s (fwd+bwd), DeepFM, Criteo-shaped synthetic
+table (26 categorical x 1M vocab, 13 dense, embed_dim 16), batch 8192 per GPU.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch already resident in HBM: forward, BCE loss,
+backward down to the embedding row-gradients (the IndexedSlices values) and — for N > 1 — the
+RCCL gradient exchange (flat dense all-reduce + sparse all-gather).  The optimizer is NOT in the
+timed region (the metric is fwd+bwd; `train_step_rows_per_s` reports the rate with the Keras-Adam
+update included).  The whole step is captured once into a hipGraph and replayed.
+
+Rank 0 prints ONE JSON line (see the fields at the bottom).  The `cpu_baseline` leg times the CPU
+oracle (a torch-CPU op-for-op restatement of the reference graph; TensorFlow is not installable
+here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F, VOCAB, ND, D = 26, 1_000_000, 13, 16
+N_BATCHES = 50
+
+
+def algorithmic_bytes_per_row(n_dense_params, batch):
+    """4F + 4Nd + 8 + 3*4*F*D + 12*P_dense/B  (= 5,250 B/row for DeepFM at B=8192)."""
+    return 4 * F + 4 * ND + 8 + 12 * F * D + 12.0 * n_dense_params / batch
+
+
+def build_model(nets, device, strategy=None, dim=D):
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    functional.set_seed(20241218)
+    conf = ModelConfig(nets=nets, fixed_embedding_dim=True, embeddings_output_dim=dim, embedding_dropout=0,
+                       dense_dropout=0, metrics=['AUC'], distribute_strategy=strategy)
+    cats = [CategoricalColumn(f'C{i}', VOCAB, dim) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(ND)])]
+    dm = DeepModel('binary', 2, conf, cats, conts)
+    dm.build(device)
+    return dm
+
+
+def make_batches(batch, device, seed, dist_kind='uniform'):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    out = []
+    for _ in range(N_BATCHES):
+        if dist_kind == 'zipf':
+            u = torch.rand(batch, F, generator=g, dtype=torch.float64)
+            idx = (VOCAB ** u - 1).clamp(0, VOCAB - 1).to(torch.int32)     # log-uniform ~ Zipf(1) ranks
+        else:
+            idx = torch.randint(0, VOCAB, (batch, F), generator=g, dtype=torch.int32)
+        dense = torch.randn(batch, ND, generator=g)
+        y = (torch.rand(batch, 1, generator=g) < 0.25).float()
+        out.append((idx.to(device), dense.to(device), y.to(device)))
+    return out
+
+
+class GraphedStep:
+    """fwd + loss + bwd (+ gradient exchange) captured into one hipGraph over static input buffers."""
+
+    def __init__(self, dm, batch, device, with_optimizer=False, use_graph=True):
+        self.dm = dm
+        self.with_optimizer = with_optimizer
+        self.idx = torch.zeros(batch, F, dtype=torch.int32, device=device)
+        self.dense = torch.zeros(batch, ND, device=device)
+        self.y = torch.zeros(batch, 1, device=device)
+        self.graph = None
+        self.use_graph = use_graph
+        self.strategy = dm.config.distribute_strategy
+
+    def _body(self):
+        dm = self.dm
+        dm.optimizer.zero_grad()
+        logit = dm.model([self.idx, self.dense])
+        loss = dm._loss(logit, self.y)
+        loss.backward()
+        if self.with_optimizer:
+            dm.optimizer.step()
+        self.loss = loss.detach()
+
+    def load(self, b):
+        self.idx.copy_(b[0], non_blocking=True)
+        self.dense.copy_(b[1], non_blocking=True)
+        self.y.copy_(b[2], non_blocking=True)
+
+    def capture(self, sample):
+        self.dm.model.train()
+        self.load(sample)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if self.use_graph:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+        torch.cuda.synchronize()
+        # python side effects (sparse-gradient registration) are not replayed by the graph: keep the
+        # captured static (rows, values) tensors and re-attach them after every replay
+        from deeptables_amd.models.layers import MultiColumnEmbedding
+        self.sparse_refs = [(l, {k: list(v) for k, v in l.sparse_grads.items()})
+                            for l in self.dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
+
+    def run(self, b):
+        self.load(b)
+        if self.graph is not None:
+            self.graph.replay()
+            for layer, refs in self.sparse_refs:
+                layer.sparse_grads = {k: list(v) for k, v in refs.items()}
+        else:
+            self._body()
+        if self.strategy is not None and self.strategy.world_size > 1:
+            self.strategy.exchange_gradients(self.dm.model)
+
+
+def time_steps(step, batches, steps, warmup, barrier):
+    for i in range(warmup):
+        step.run(batches[i % len(batches)])
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        step.run(batches[(warmup + i) % len(batches)])
+    ev1.record()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1) / 1e3
+
+
+def kernel_breakdown(dm, batch, device, sample):
+    """HIP-event timing of each hot-path kernel in isolation on the current stream (diagnostic)."""
+    from deeptables_amd import ops
+    emb_layer = dm.model.layers_by_name['emb_categorical_vars_all']
+    table = emb_layer.tables[f'd{D}']
+    offs, voc = emb_layer.row_offset_d16, emb_layer.vocab_d16
+    idx, dense, y = sample
+    out = {}
+
+    def timeit(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3   # us
+
+    with torch.no_grad():
+        emb, concat, fsum, fmo, rows = ops.embed_fm_linear(idx, table, offs, voc, dense)
+        t = timeit(lambda: ops.embed_fm_linear(idx, table, offs, voc, dense))
+        by = batch * (4 * F + F * D * 4 + ND * 4 + F * D * 4 + (F * D + ND) * 4 + F * 4 + 4 + F * 8)
+        out['embed_fm_linear_fwd'] = {'us': t, 'bytes': by, 'GBps': by / t / 1e3}
+        t = timeit(lambda: ops.embedding_lookup(idx, table, offs, voc))
+        by = batch * (4 * F + 2 * F * D * 4 + F * 8)
+        out['embedding_gather'] = {'us': t, 'bytes': by, 'GBps': by / t / 1e3}
+        t = timeit(lambda: ops.fm(emb))
+        by = batch * (F * D * 4 + 4)
+        out['fm_fwd'] = {'us': t, 'bytes': by, 'GBps': by / t / 1e3}
+    return out
+
+
+def cpu_baseline(dm, batches, batch, sample_steps=6):
+    """Oracle (torch CPU, all host cores) fwd+bwd on the same synthetic batches; tables are looked up
+    into row tensors first so the backward produces row-gradients (IndexedSlices-like), not 1.66 GB
+    dense table gradients."""
+    from oracle import bridge, reference_layers as R
+    torch.set_num_threads(os.cpu_count())
+    w = bridge.oracle_weights(dm, dtype=torch.float32)
+    tables = w['emb_categorical_vars_all']
+    cfg = bridge.oracle_config(dm)
+    def mark(o):
+        if torch.is_tensor(o):
+            if o.is_floating_point():
+                o.requires_grad_(True)
+        elif isinstance(o, dict):
+            for v in o.values():
+                mark(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                mark(v)
+
+    for k, v in w.items():
+        if k == 'emb_categorical_vars_all':
+            continue
+        if k == 'bn_concat_emb_dense':
+            mark(v[:2])
+        else:
+            mark(v)
+
+    class RowTables:   # tables[i][col] -> rows that require grad
+        def __init__(self, t):
+            self.t, self.leaves = t, []
+
+        def __getitem__(self, col):
+            r = self.t[col].detach().requires_grad_(True)
+            self.leaves.append(r)
+            return r
+
+    def one(b):
+        idx, dense, y = (t.cpu() for t in b)
+        w2 = dict(w)
+        w2['emb_categorical_vars_all'] = [RowTables(t) for t in tables]
+        logit, _ = R.model_forward(w2, idx.float(), dense, dm.config.nets, cfg, training=True)
+        R.binary_crossentropy_from_logits(logit, y).backward()
+
+    one(batches[0])
+    t0 = time.perf_counter()
+    for i in range(sample_steps):
+        one(batches[(i + 1) % len(batches)])
+    dt = time.perf_counter() - t0
+    return {'value': batch * sample_steps / dt, 'unit': 'rows/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'{sample_steps} fwd+bwd steps of batch {batch} (torch-CPU oracle, {torch.get_num_threads()} threads, '
+                      f'{dt:.1f}s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=8192)
+    ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN'])
+    ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    strategy = None
+    if world > 1:
+        from deeptables_amd.parallel import DataParallelStrategy
+        strategy = DataParallelStrategy.from_env('nccl')
+        device = strategy.device
+        rank = strategy.rank
+    else:
+        device = torch.device('cuda', 0)
+        torch.cuda.set_device(device)
+        rank = 0
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    barrier()
+
+    from deeptables_amd.models import deepnets
+    nets = {'DeepFM': deepnets.DeepFM, 'xDeepFM': deepnets.xDeepFM, 'AutoInt': deepnets.AutoInt,
+            'DCN': deepnets.DCN}[args.model]
+    dim = 32 if args.model == 'AutoInt' else D
+    dm = build_model(nets, device, strategy, dim)
+    if args.model == 'xDeepFM':
+        pass
+    if strategy is not None:
+        strategy.broadcast_parameters(dm.model)
+    batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
+
+    step = GraphedStep(dm, args.batch, device, with_optimizer=False, use_graph=not args.no_graph)
+    step.capture(batches[0])
+    wall, ev_s = time_steps(step, batches, args.steps, args.warmup, barrier)
+    t = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    rows = args.batch * args.steps * world
+    value = rows / wall
+
+    if rank == 0:
+        n_dense = sum(p.numel() for n, p in dm.model.named_parameters() if 'tables' not in n)
+        bpr = algorithmic_bytes_per_row(n_dense, args.batch)
+        step_s = ev_s / args.steps
+        achieved = args.batch * bpr / step_s / 1e9
+        result = {
+            'metric': 'training rows/sec (fwd+bwd) DeepFM Criteo-shape batch 8192' if args.model == 'DeepFM'
+            else f'training rows/sec (fwd+bwd) {args.model} Criteo-shape batch {args.batch}',
+            'value': value, 'unit': 'rows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.model} fwd+bwd, Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
+                                   f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'hipgraph': not args.no_graph, 'optimizer_in_timed_region': False},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'launch': 'one hipGraph replay = one fwd+bwd step',
+                         'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
+        }
+        if not args.no_extras and world == 1:
+            try:
+                result['kernels'] = kernel_breakdown(dm, args.batch, device, batches[1]) if args.model == 'DeepFM' else {}
+                opt_step = GraphedStep(dm, args.batch, device, with_optimizer=True, use_graph=False)
+                opt_step.dm.model.train()
+                w2, _ = time_steps(opt_step, batches, max(args.steps // 4, 10), 5, barrier)
+                result['train_step_rows_per_s'] = args.batch * max(args.steps // 4, 10) / w2
+            except Exception as e:   # diagnostics must not kill the contract line
+                result['extras_error'] = repr(e)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result['cpu_baseline'] = cpu_baseline(dm, batches, args.batch)
+            except Exception as e:
+                result['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(result))
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -75,16 +75,18 @@ __global__ __launch_bounds__(kBnThreads) void k_bn_stats(const float* __restrict
     }
 }
 
+// one wavefront per column: lanes stride over the chunk partials, then a Chan-merge butterfly
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int chunks,
                                                      int C, float eps, float momentum,
                                                      float* __restrict__ moving_mean,
                                                      float* __restrict__ moving_var,
                                                      float* __restrict__ save_mean,
                                                      float* __restrict__ save_rstd) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= C) return;
+    const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (col >= C) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
+    for (int k = lane; k < chunks; k += 64) {
         const float* p = partial + (int64_t)k * 3 * C;
         const float nb = p[col];
         if (nb <= 0.f) continue;
@@ -95,6 +97,20 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
         m2 += m2b + delta * delta * (n * nb / nt);
         n = nt;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+        const float nt = n + nb;
+        if (nt > 0.f) {
+            const float delta = mb - mean;
+            // symmetric form so both partners compute the same merged value
+            const float new_mean = (n * mean + nb * mb) / nt;
+            m2 = m2 + m2b + delta * delta * (n * nb / nt);
+            mean = new_mean;
+        }
+        n = nt;
+    }
+    if (lane != 0) return;
     const float var = n > 0.f ? m2 / n : 0.f;
     save_mean[col] = mean;
     save_rstd[col] = 1.0f / sqrtf(var + eps);
@@ -179,13 +195,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
                                                          float* __restrict__ sum_gx,
                                                          float* __restrict__ grad_gamma,
                                                          float* __restrict__ grad_beta) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (col >= C) return;
+    const int lane = threadIdx.x & 63;
     float s = 0.f, q = 0.f;
-    for (int k = 0; k < chunks; ++k) {
+    for (int k = lane; k < chunks; k += 64) {
         s += partial[(int64_t)k * 2 * C + col];
         q += partial[(int64_t)k * 2 * C + C + col];
     }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane != 0) return;
     sum_g[col] = s;
     sum_gx[col] = q;
     if (grad_gamma) grad_gamma[col] = q;
@@ -236,7 +256,7 @@ extern "C" int dt_bn_train_fwd(const float* x, int N, int C, const float* gamma,
     float* partial = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(k_bn_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, N, C, CW, rpc,
                        partial);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, chunks, C,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, chunks, C,
                        eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
     const int64_t total = (int64_t)N * C;
     hipLaunchKernelGGL(k_bn_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, total, C,
@@ -272,7 +292,7 @@ extern "C" int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C
     float* sums = partial + (int64_t)kBnMaxChunks * 3 * C;
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, grad_y, N, C, CW,
                        rpc, save_mean, save_rstd, partial);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, chunks,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, chunks,
                        C, sums, sums + C, grad_gamma, grad_beta);
     const int64_t total = (int64_t)N * C;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, grad_y,

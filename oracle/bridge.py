@@ -23,8 +23,10 @@ def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
 
     emb = L.get('emb_categorical_vars_all')
     w['emb_categorical_vars_all'] = [g(e) for e in emb.embeddings] if emb is not None else []
-    bn = L['bn_concat_emb_dense']
-    w['bn_concat_emb_dense'] = (g(bn.gamma), g(bn.beta), _t(bn.moving_mean, dtype), _t(bn.moving_variance, dtype))
+    bn = L.get('bn_concat_emb_dense')     # absent when no net consumes concat_emb_dense (e.g. AutoInt)
+    if bn is not None:
+        w['bn_concat_emb_dense'] = (g(bn.gamma), g(bn.beta), _t(bn.moving_mean, dtype),
+                                    _t(bn.moving_variance, dtype))
     if 'linear_logit' in L:
         w['linear_logit'] = g(L['linear_logit'].kernel)
 
@@ -77,3 +79,59 @@ def oracle_forward(dm, cat, dense, dtype=torch.float64, training=True, weights=N
     cat_f = None if cat is None else cat.detach().cpu().to(torch.float32)     # reference contract: float32 ids
     dn = None if dense is None else dense.detach().cpu().to(dtype)
     return R.model_forward(w, cat_f, dn, dm.config.nets, oracle_config(dm), training=training)
+
+
+def load_weights(dm, w):
+    """Inverse of oracle_weights: copy an oracle weights dict (numpy/torch) into the DeepModel."""
+    import numpy as np
+    L = dm.model.layers_by_name
+
+    def put(param, value):
+        with torch.no_grad():
+            param.copy_(torch.as_tensor(np.asarray(value), dtype=torch.float32).reshape(param.shape))
+
+    emb = L.get('emb_categorical_vars_all')
+    if emb is not None:
+        emb.set_embeddings(w['emb_categorical_vars_all'])
+    if 'bn_concat_emb_dense' in L:
+        bn = L['bn_concat_emb_dense']
+        put(bn.gamma, w['bn_concat_emb_dense'][0])
+        put(bn.beta, w['bn_concat_emb_dense'][1])
+    if 'linear_logit' in L:
+        put(L['linear_logit'].kernel, w['linear_logit'])
+    for prefix, key in (('dnn', 'dnn'), ('dcn', 'dcn_dnn')):
+        i = 1
+        while f'{prefix}_dense_{i}' in L and key in w:
+            k, b = w[key][i - 1]
+            put(L[f'{prefix}_dense_{i}'].kernel, k)
+            if b is not None:
+                put(L[f'{prefix}_dense_{i}'].bias, b)
+            i += 1
+    att = 0
+    for name, layer in L.items():
+        cls = layer.__class__.__name__
+        if name.startswith('dense_logit_'):
+            put(layer.kernel, w[name])
+        elif cls == 'CIN':
+            for p, v in zip(layer.f_, w['cin_filters']):
+                put(p, v)
+            put(layer.exFM_out.kernel, w['cin_exFM_out'][0])
+            put(layer.exFM_out.bias, w['cin_exFM_out'][1])
+        elif cls == 'Cross' and name == 'dcn_cross_layer':
+            for p, v in zip(layer.kernels, w['dcn_cross_kernels']):
+                put(p, v)
+            for p, v in zip(layer.bias, w['dcn_cross_bias']):
+                put(p, v)
+        elif cls == 'MultiheadAttention':
+            lw = w['autoint_layers'][att]
+            att += 1
+            for dn, key in ((layer.dense_Q, 'Q'), (layer.dense_K, 'K'), (layer.dense_V, 'V'),
+                            (layer.dense_residual, 'R')):
+                put(dn.kernel, lw[key][0])
+                put(dn.bias, lw[key][1])
+            put(layer.batch_normalize.gamma, lw['bn'][0])
+            put(layer.batch_normalize.beta, lw['bn'][1])
+    out = L['task_output']
+    put(out.kernel, w['task_output'][0])
+    if out.bias is not None and w['task_output'][1] is not None:
+        put(out.bias, w['task_output'][1])

@@ -280,9 +280,11 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
         x = flatten_emb
     else:
         x = dense
-    bn = weights['bn_concat_emb_dense']                              # :359
-    concat_emb_dense, _, _ = keras_batchnorm(x, bn[0], bn[1], bn[2] if len(bn) > 2 else None,
-                                             bn[3] if len(bn) > 3 else None, training=training)
+    concat_emb_dense = None
+    bn = weights.get('bn_concat_emb_dense')                          # :359 (pruned by keras.Model when no net
+    if bn is not None:                                               #       consumes it, e.g. nets=['autoint_nets'])
+        concat_emb_dense, _, _ = keras_batchnorm(x, bn[0], bn[1], bn[2] if len(bn) > 2 else None,
+                                                 bn[3] if len(bn) > 3 else None, training=training)
     outs = {}
     for net in nets:                                                 # :281-285
         if net == 'linear':

@@ -1,0 +1,222 @@
+# -*- coding:utf-8 -*-
+"""CPU: host-side logic of the drop-in API (no kernel launches) and the C-ABI library surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C-ABI ------------------------------------------------------------------------------------
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'dt_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dt_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from deeptables_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'build the library first: python __graft_entry__.py'
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(handle, n), f'{n} declared in include/dt_hip.h but not exported'
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    h = _lib.lib()
+    assert h.dt_version() == 1 and h.dt_build_arch() == b'gfx950'
+
+
+def test_argument_validation_without_a_gpu():
+    """bad sizes are rejected before any launch -> exercisable on CPU"""
+    from deeptables_amd import _lib
+    h = _lib.lib()
+    assert h.dt_fm_fwd(None, -1, 3, 4, None, None) == -1
+    assert b'dt_fm_fwd' in h.dt_last_error()
+    assert h.dt_fm_fwd(None, 0, 3, 4, None, None) == 0            # empty batch is a no-op
+    assert h.dt_embedding_fwd(None, 7, None, None, None, 4, 2, 8, None, None, None, None) == -1
+    assert h.dt_mha_core_fwd(None, None, None, 4, 3, 10, 3, None, None, None) == -1    # D % H != 0
+    assert h.dt_bn_workspace_bytes(8192, 429) > 0 and h.dt_cross_workspace_bytes(8192, 429, 6) > 0
+
+
+def test_ops_reject_cpu_tensors_loudly():
+    from deeptables_amd import ops
+    from deeptables_amd._lib import DtHipError
+    with pytest.raises(DtHipError):
+        ops.fm(torch.zeros(2, 3, 4))
+    with pytest.raises(DtHipError):
+        ops.cross(torch.zeros(2, 3), torch.zeros(1, 3), torch.zeros(1, 3))
+
+
+def test_product_path_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import deeptables_amd, deeptables_amd.models, deeptables_amd.ops, "
+            "deeptables_amd.parallel, deeptables_amd.training; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
+    subprocess.check_call([sys.executable, '-c', code])
+
+
+# ---- ModelConfig / metainfo / deepnets --------------------------------------------------------
+def test_model_config_defaults_and_fields():
+    from deeptables_amd.models import ModelConfig, deepnets
+    c = ModelConfig()
+    assert len(c._fields) == 45
+    assert c.nets == ['dnn_nets'] and c.embeddings_output_dim == 4 and c.embedding_dropout == 0.3
+    assert c.dnn_params['hidden_units'] == ((128, 0, False), (64, 0, False))
+    assert c.cross_params == {'num_cross_layer': 4} and c.stacking_op == 'add'
+    assert c.cin_params['cross_layer_size'] == (128, 128) and c.autoint_params['num_heads'] == 1
+    c2 = ModelConfig(nets=deepnets.DeepFM, metrics=['AUC'])
+    assert c2.nets == ['linear', 'fm_nets', 'dnn_nets'] and c2.first_metric_name == 'AUC'
+    assert hash(c2) == hash('conf-1')
+    with pytest.raises(TypeError):
+        ModelConfig(no_such_field=1)
+    with pytest.raises(ValueError):
+        ModelConfig(var_len_categorical_columns=[('a', '|')])
+
+
+def test_nets_registry_and_signature_check():
+    from deeptables_amd.models import deepnets
+
+    def custom_net(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+        return None
+
+    assert deepnets.get('fm_nets') is deepnets.fm_nets
+    assert deepnets.get(custom_net) is custom_net and deepnets.custom_nets['custom_net'] is custom_net
+    assert deepnets.get_nets(['linear', custom_net, 'linear']) == ['linear', 'custom_net']
+    with pytest.raises(ValueError):
+        deepnets.register_nets(lambda a, b: None)
+    with pytest.raises(TypeError):
+        deepnets.get(3)
+    with pytest.raises(ValueError):
+        deepnets.get(None)
+
+
+def test_metainfo():
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn, VarLenCategoricalColumn
+    c = CategoricalColumn('x', 10000, 0)
+    assert c.embeddings_output_dim == 10 and c.input_name == 'cat_x' and c.dtype == 'int32'
+    assert ContinuousColumn('n', ['a', 'b', 'c']).input_dim == 3
+    assert VarLenCategoricalColumn('v', 5).sep == '|'
+
+
+def test_ignore_case_dict():
+    from deeptables_amd.models.deepmodel import IgnoreCaseDict
+    d = IgnoreCaseDict({'AUC': 0.5, 'loss': 1.0})
+    assert d['auc'] == 0.5 and d['Auc'] == 0.5 and 'LOSS' in d
+    d['Accuracy'] = 0.9
+    assert d['accuracy'] == 0.9
+    with pytest.raises(KeyError):
+        d[1]
+    with pytest.raises(KeyError):
+        IgnoreCaseDict({1: 2})
+
+
+# ---- symbolic graph construction (no compute) -------------------------------------------------
+def _build_graph(nets, F=6, Nd=3, D=8, **kw):
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    conf = ModelConfig(nets=nets, embeddings_output_dim=D, embedding_dropout=0, **kw)
+    cats = [CategoricalColumn(f'C{i}', 10 + i, D) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])] if Nd else []
+    dm = DeepModel('binary', 2, conf, cats, conts)
+    model = dm._build_model('binary', 2, conf.nets, cats, conts, conf)
+    return dm, model
+
+
+def test_deepfm_graph_has_reference_layer_names_and_shapes():
+    dm, model = _build_graph(['linear', 'fm_nets', 'dnn_nets'])
+    names = list(model.layers_by_name)
+    for n in ['emb_categorical_vars_all', 'concat_embeddings_axis_0', 'flatten_embeddings', 'concat_embedding_dense',
+              'bn_concat_emb_dense', 'concat_linear_embedding', 'concat_linear_emb_dense', 'linear_logit',
+              'concat_fm_embedding', 'fm_layer', 'dnn_dense_1', 'dnn_activation_1', 'dnn_dense_2',
+              'dense_logit_dnn_nets', 'add_logits', 'task_output']:
+        assert n in names, n
+    L = model.layers_by_name
+    assert tuple(L['linear_logit'].kernel.shape) == (6 + 3, 1) and L['linear_logit'].bias is None
+    assert tuple(L['dnn_dense_1'].kernel.shape) == (6 * 8 + 3, 128)
+    assert tuple(L['bn_concat_emb_dense'].gamma.shape) == (51,)
+    assert L['bn_concat_emb_dense'].epsilon == 1e-3 and L['bn_concat_emb_dense'].momentum == 0.99
+    assert [tuple(e.shape) for e in L['emb_categorical_vars_all'].embeddings] == [(10 + i, 8) for i in range(6)]
+    assert model.input_names == ['input_categorical_vars_all', 'input_continuous_all']
+    assert 'linear' in str(dm.model_desc) and 'fm: input_shape (None, 6, 8), output_shape (None, 1)' in str(dm.model_desc)
+
+
+def test_embedding_init_is_keras_uniform_and_dense_glorot():
+    dm, model = _build_graph(['linear', 'dnn_nets'])
+    L = model.layers_by_name
+    t = L['emb_categorical_vars_all'].tables['d8']
+    assert float(t.abs().max()) <= 0.05 and float(t.std()) > 0.02
+    k = L['dnn_dense_1'].kernel                     # he_uniform: limit sqrt(6/fan_in)
+    assert float(k.abs().max()) <= np.sqrt(6.0 / 51) + 1e-6
+    k = L['task_output'].kernel                     # glorot_uniform
+    assert float(k.abs().max()) <= np.sqrt(6.0 / 2) + 1e-6
+
+
+def test_other_graphs_build():
+    _, m = _build_graph(['linear', 'cin_nets', 'dnn_nets'],
+                        cin_params={'cross_layer_size': (8, 8, 4), 'direct': False})
+    cin = [l for l in m.layers if l.__class__.__name__ == 'CIN'][0]
+    assert [tuple(f.shape) for f in cin.f_] == [(1, 36, 8), (1, 24, 8), (1, 24, 4)]
+    assert tuple(cin.exFM_out.kernel.shape) == (4 + 4 + 4, 1)
+    _, m = _build_graph(['dcn_nets'], cross_params={'num_cross_layer': 6})
+    assert len(m.layers_by_name['dcn_cross_layer'].kernels) == 6
+    assert tuple(m.layers_by_name['task_output'].kernel.shape) == (51 + 64, 1)
+    _, m = _build_graph(['autoint_nets'], autoint_params={'num_attention': 3, 'num_heads': 2, 'dropout_rate': 0,
+                                                          'use_residual': True})
+    assert sum(l.__class__.__name__ == 'MultiheadAttention' for l in m.layers) == 3
+    assert 'bn_concat_emb_dense' not in m.layers_by_name      # pruned: no net consumes it
+    _, m = _build_graph(['pnn_nets'])
+    assert tuple(m.layers_by_name['pnn_outer_product_layer'].kernel.shape) == (8, 15, 8)
+    _, m = _build_graph(['linear', 'fm_nets'], stacking_op='concat')
+    assert 'concat_logits' in m.layers_by_name
+
+
+def test_error_behaviour_matches_reference():
+    from deeptables_amd.models import layers
+    from deeptables_amd.functional import Input
+    with pytest.raises(ValueError):
+        layers.FM()(Input(shape=(8,)))                                       # needs 3-D
+    with pytest.raises(ValueError):
+        layers.Cross({'num_cross_layer': 2})(Input(shape=(4, 8)))           # needs 2-D
+    with pytest.raises(ValueError):
+        layers.OuterProduct({'outer_product_kernel_type': 'bad'})
+    with pytest.raises(ValueError):
+        layers.CIN({'cross_layer_size': ()})
+    with pytest.raises(ValueError):
+        layers.CIN({'cross_layer_size': (7, 4)})(Input(shape=(4, 8)))       # odd, not last, direct=False
+    with pytest.raises(ValueError):
+        layers.MultiColumnEmbedding([3, 4], [2])
+    with pytest.raises(ValueError):
+        _build_graph(['linear'], F=0, Nd=0)                                  # 'No input layer exists.'
+    with pytest.raises(ValueError):
+        _build_graph(['linear', 'fm_nets'], stacking_op='mul')
+    assert set(layers.dt_custom_objects) >= {'MultiColumnEmbedding', 'FM', 'CIN', 'MultiheadAttention', 'Cross',
+                                             'InnerProduct', 'OuterProduct'}
+
+
+def test_single_categorical_column_edge_case():
+    """nets_test.py:166-189: one categorical column — fm/ipnn opt out or degrade gracefully."""
+    _, m = _build_graph(['linear', 'fm_nets', 'dnn_nets', 'ipnn_nets'], F=1, Nd=2)
+    assert 'inner_product_layer' not in m.layers_by_name     # ipnn returns None with < 2 embeddings
+    assert 'fm_layer' in m.layers_by_name
+
+
+def test_preprocessor_metadata():
+    import pandas as pd
+    from deeptables_amd.models import ModelConfig
+    from deeptables_amd.models.deeptable import SimplePreprocessor
+    df = pd.DataFrame({'a': ['x', 'y', 'x', None], 'b': [1.0, np.nan, 3.0, 4.0], 'c': [True, False, True, True]})
+    pp = SimplePreprocessor(ModelConfig())
+    X, y = pp.fit_transform(df, ['p', 'n', 'p', 'n'])
+    assert pp.task_ == 'binary' and pp.labels_ == ['n', 'p']
+    assert [c.name for c in pp.categorical_columns] == ['a', 'c']
+    assert pp.categorical_columns[0].vocabulary_size == 2 + 2          # nunique + 2 (preprocessor.py:333)
+    assert pp.continuous_columns[0].column_names == ['b'] and X['b'].isna().sum() == 0
+    Xt = pp.transform_X(pd.DataFrame({'a': ['zzz'], 'b': [1.0], 'c': [False]}))
+    assert int(Xt['a'][0]) == 0                                        # unseen value -> 0
+    assert list(y) == [1.0, 0.0, 1.0, 0.0]

@@ -1,0 +1,115 @@
+# -*- coding:utf-8 -*-
+"""CPU, world_size 2, gloo: the data-parallel exchange (flat dense all-reduce + sparse all-gather)
+of deeptables_amd.parallel.DataParallelStrategy — the role tf.distribute.MirroredStrategy plays for
+the reference (deepmodel.py:88-103).  Compute kernels are not involved: gradients are synthetic."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from deeptables_amd.parallel import DataParallelStrategy
+    from deeptables_amd.ops import SparseRowGrad
+    from deeptables_amd.models.layers import MultiColumnEmbedding
+    st = DataParallelStrategy.from_env('gloo')
+    assert st.world_size == world and st.rank == rank
+
+    # --- sharding: AutoShardPolicy.DATA ---
+    X = np.arange(10).reshape(10, 1)
+    Xs, ys = st.shard(X, np.arange(10))
+    assert list(Xs[:, 0]) == list(range(rank, 10, world)) and list(ys) == list(range(rank, 10, world))
+
+    # --- parameters are broadcast from rank 0 ---
+    lin = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    st.broadcast_parameters(lin)
+    assert torch.all(lin.weight == 1.0)
+
+    # --- dense: one flat bucket, mean over ranks ---
+    lin.weight.grad = torch.full_like(lin.weight, float(rank))        # 0 and 1 -> 0.5
+    lin.bias.grad = torch.arange(3, dtype=torch.float32) * (rank + 1)  # x1 and x2 -> x1.5
+    n = st.allreduce_dense(list(lin.parameters()))
+    assert n == 15
+    assert torch.allclose(lin.weight.grad, torch.full_like(lin.weight, 0.5))
+    assert torch.allclose(lin.bias.grad, torch.arange(3, dtype=torch.float32) * 1.5)
+
+    # --- sparse: ragged all-gather of (rows, values), values pre-divided by world size ---
+    nloc = 3 + rank                                                    # ragged on purpose
+    rows = torch.arange(nloc, dtype=torch.int64) + 10 * rank
+    vals = torch.ones(nloc, 4) * (rank + 1)
+    out = st.allgather_sparse(SparseRowGrad(rows, vals))
+    valid = out.rows >= 0
+    assert int(valid.sum()) == 3 + 4
+    dense = torch.zeros(32, 4)
+    dense.index_add_(0, out.rows[valid], out.values[valid])
+    expect = torch.zeros(32, 4)
+    expect[0:3] = 1.0 / world
+    expect[10:14] = 2.0 / world
+    assert torch.allclose(dense, expect)
+
+    # --- exchange_gradients walks the model: dense params + every MultiColumnEmbedding's sparse grads ---
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = MultiColumnEmbedding([5, 6], [4, 4])
+            self.emb.build((None, 2))
+            self.fc = torch.nn.Linear(2, 1)
+
+    m = Tiny()
+    m.fc.weight.grad = torch.full_like(m.fc.weight, float(rank))
+    m.fc.bias.grad = torch.full_like(m.fc.bias, 2.0)
+    m.emb.add_sparse_grad('d4', SparseRowGrad(torch.tensor([rank, 7]), torch.ones(2, 4)))
+    st.exchange_gradients(m)
+    assert torch.allclose(m.fc.weight.grad, torch.full_like(m.fc.weight, 0.5))
+    g = m.emb.sparse_grads['d4'][0]
+    assert sorted(g.rows.tolist()) == [0, 1, 7, 7] and torch.allclose(g.values, torch.full((4, 4), 0.5))
+    assert m.emb.tables['d4'].grad is None          # the table itself is never densified / all-reduced
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, 'ok'))
+
+
+def test_data_parallel_exchange_world2_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, 'ok'), (1, 'ok')]
+
+
+def test_world_size_one_is_a_no_op():
+    port = _free_port()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    from deeptables_amd.parallel import DataParallelStrategy
+    from deeptables_amd.ops import SparseRowGrad
+    st = DataParallelStrategy.from_env('gloo')
+    try:
+        g = SparseRowGrad(torch.tensor([1, 2]), torch.ones(2, 3))
+        assert st.allgather_sparse(g) is g
+        lin = torch.nn.Linear(2, 2)
+        lin.weight.grad = torch.ones_like(lin.weight)
+        assert st.allreduce_dense(list(lin.parameters())) == 0
+    finally:
+        dist.destroy_process_group()
