@@ -1,0 +1,156 @@
+# -*- coding:utf-8 -*-
+"""Fused train-step plans: when the graph DeepModel assembled is one the library has a whole-step
+kernel sequence for, `DeepModel.train_step` runs that instead of the layer-by-layer autograd
+path.  Same weights, same gradients (tests/test_fused_gpu.py checks both against the oracle).
+
+DeepFM (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) -> `dt_deepfm_train_step`
+(csrc/deepfm.hip): 6 launches + 1 memset instead of ~60 launches.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .ops import SparseRowGrad
+from .utils import consts
+
+_ACC_NAMES = ['dW1', 'dW2', 'db1', 'db2', 'dw3', 'dwo', 'dbo', 'loss', 'dgamma', 'dbeta', 'dwlin']
+
+
+def fused_enabled():
+    return os.environ.get('DT_AMD_FUSED', '1') != '0'
+
+
+class FusedDeepFM:
+    """Whole-step executor for the DeepFM graph.  Holds the static workspace / gradient buffers."""
+
+    NETS = {'linear', 'fm_nets', 'dnn_nets'}
+
+    @classmethod
+    def eligible(cls, dm):
+        c = dm.config
+        try:
+            if set(c.nets) != cls.NETS or len(c.nets) != 3:
+                return False
+            if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
+                return False
+            if c.stacking_op != consts.STACKING_OP_ADD or c.embedding_dropout or c.dense_dropout:
+                return False
+            hu = tuple(tuple(h) for h in c.dnn_params.get('hidden_units', ()))
+            if hu != ((128, 0, False), (64, 0, False)) or c.dnn_params.get('activation', 'relu') != 'relu':
+                return False
+            if c.dnn_params.get('custom_dnn_fn') is not None:
+                return False
+            L = dm.model.layers_by_name
+            need = ['emb_categorical_vars_all', 'bn_concat_emb_dense', 'linear_logit', 'dnn_dense_1', 'dnn_dense_2',
+                    'dense_logit_dnn_nets', 'task_output', 'fm_layer']
+            if any(n not in L for n in need):
+                return False
+            emb = L['emb_categorical_vars_all']
+            if len(emb.groups) != 1 or len(dm.continuous_columns or []) > 1:
+                return False
+            D = emb.groups[0][0]
+            F = len(emb.input_dims)
+            Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
+            return bool(lib().dt_deepfm_supported(8192, F, D, Nd, 128, 64))
+        except Exception:
+            return False
+
+    def __init__(self, dm):
+        self.dm = dm
+        L = dm.model.layers_by_name
+        self.emb = L['emb_categorical_vars_all']
+        self.bn = L['bn_concat_emb_dense']
+        self.lin = L['linear_logit']
+        self.d1, self.d2 = L['dnn_dense_1'], L['dnn_dense_2']
+        self.dl = L['dense_logit_dnn_nets']
+        self.out = L['task_output']
+        self.D = self.emb.groups[0][0]
+        self.F = len(self.emb.input_dims)
+        self.Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
+        self.C = self.F * self.D + self.Nd
+        self.key = f'd{self.D}'
+        self.device = self.emb.tables[self.key].device
+        n_acc = lib().dt_deepfm_accum_floats(self.F, self.D, self.Nd)
+        offs = (ctypes.c_int64 * 11)()
+        check(lib().dt_deepfm_accum_offsets(self.F, self.D, self.Nd, ctypes.cast(offs, ctypes.c_void_p)),
+              'dt_deepfm_accum_offsets')
+        self.off = dict(zip(_ACC_NAMES, [int(v) for v in offs]))
+        self.accum = torch.zeros(n_acc, dtype=torch.float32, device=self.device)
+        self._bufs = {}
+        a, o, C = self.accum, self.off, self.C
+        self.grad_views = [
+            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * 128].view(C, 128)),
+            (self.d2.kernel, a[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)),
+            (self.d1.bias, a[o['db1']:o['db1'] + 128]),
+            (self.d2.bias, a[o['db2']:o['db2'] + 64]),
+            (self.dl.kernel, a[o['dw3']:o['dw3'] + 64].view(64, 1)),
+            (self.out.kernel, a[o['dwo']:o['dwo'] + 1].view(1, 1)),
+            (self.bn.gamma, a[o['dgamma']:o['dgamma'] + C]),
+            (self.bn.beta, a[o['dbeta']:o['dbeta'] + C]),
+            (self.lin.kernel, a[o['dwlin']:o['dwlin'] + self.F + self.Nd].view(self.F + self.Nd, 1)),
+        ]
+        if self.out.bias is not None:
+            self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
+        self.loss_view = a[o['loss']:o['loss'] + 1]
+
+    def _buffers(self, B):
+        b = self._bufs.get(B)
+        if b is None:
+            nbytes = lib().dt_deepfm_workspace_bytes(B, self.F, self.D, self.Nd)
+            if nbytes < 0:
+                raise _lib.DtHipError('fused DeepFM step: unsupported shape')
+            dev = self.device
+            b = {'ws': torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev),
+                 'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
+                 'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
+                 'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev)}
+            self._bufs[B] = b
+        return b
+
+    def run(self, idx, dense, y, backward=True):
+        """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
+        (views of one static buffer) and registers the embedding table's sparse gradient."""
+        B = idx.shape[0]
+        buf = self._buffers(B)
+        idx = idx.contiguous()
+        kind = _lib.DT_IDX_F32 if idx.dtype == torch.float32 else _lib.DT_IDX_I32
+        if idx.dtype not in (torch.float32, torch.int32):
+            idx = idx.to(torch.int32)
+        dense = None if dense is None else dense.contiguous()
+        y = y.reshape(-1).contiguous()
+        table = self.emb.tables[self.key]
+        training = self.dm.model.training
+        check(lib().dt_deepfm_train_step(
+            ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
+            ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
+            ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
+            ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
+            float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
+            ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
+            ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+            ptr(self.emb.oob_count) if self.emb.check_oob else None, 2 if backward else 1, stream_ptr()),
+            'dt_deepfm_train_step')
+        if backward:
+            for p, g in self.grad_views:
+                p.grad = g
+            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1),
+                                                             buf['grad_rows'].view(-1, self.D))]
+            if self.emb.uses_dense_grad(self.D):
+                # small tables keep exact dense-Adam semantics: densify the row gradients
+                g = torch.zeros_like(table)
+                check(lib().dt_embedding_bwd_dense(ptr(buf['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
+                                                   ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
+                table.grad = g
+                self.emb.sparse_grads.pop(self.key, None)
+        return self.loss_view, buf['logit']
+
+
+def make_fused_plan(dm):
+    if not fused_enabled() or dm.model is None:
+        return None
+    if FusedDeepFM.eligible(dm):
+        return FusedDeepFM(dm)
+    return None

@@ -226,17 +226,35 @@ class DeepModel:
             return torch.softmax(logit, dim=-1)
         return logit
 
-    def train_step(self, inputs, y):
-        """forward -> loss -> backward -> (data-parallel gradient exchange) -> optimizer step."""
+    def fused_plan(self):
+        """Whole-step kernel plan for this graph, if the library has one (deeptables_amd/fused.py)."""
+        if not hasattr(self, '_fused_plan'):
+            from ..fused import make_fused_plan
+            self._fused_plan = make_fused_plan(self)
+        return self._fused_plan
+
+    def forward_backward(self, inputs, y):
+        """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads."""
         self.optimizer.zero_grad()
+        plan = self.fused_plan() if self.model.training else None
+        if plan is not None:
+            cat = inputs[0]
+            dense = inputs[1] if len(inputs) > 1 else None
+            loss, logit = plan.run(cat, dense, y)
+            return loss[0], logit
         logit = self.model(inputs)
         loss = self._loss(logit, y)
         loss.backward()
+        return loss.detach(), logit.detach()
+
+    def train_step(self, inputs, y):
+        """forward -> loss -> backward -> (data-parallel gradient exchange) -> optimizer step."""
+        loss, logit = self.forward_backward(inputs, y)
         strategy = self.config.distribute_strategy
         if strategy is not None:
             strategy.exchange_gradients(self.model)
         self.optimizer.step()
-        return loss.detach(), logit.detach()
+        return loss.detach(), logit.detach().clone() if self.fused_plan() is not None else logit.detach()
 
     def fit(self, X=None, y=None, batch_size=128, epochs=1, verbose=1, callbacks=None, validation_split=0.2,
             validation_data=None, shuffle=True, class_weight=None, sample_weight=None, initial_epoch=0,

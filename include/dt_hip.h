@@ -192,6 +192,33 @@ int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense,
                       const int64_t* rows, int n_rows, int D, int* row_epoch, int epoch,
                       float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* ---- fused DeepFM train step (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) ------------- *
+ * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
+ * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,
+ * the per-net Dense(1) logits, Add, Dense(1) output, BinaryCrossentropy (from logits, mean over B)
+ * — forward AND backward in six launches (csrc/deepfm.hip).  Hidden sizes are fixed to the
+ * ModelConfig default dnn_params ((128,0,False),(64,0,False)), relu; dt_deepfm_supported() says
+ * whether a shape is covered (else the host uses the per-layer entry points above).
+ *   W1 [C,128] b1 [128] W2 [128,64] b2 [64] w3 [64] (dense_logit_dnn_nets) w_out [1] b_out [1]|NULL
+ *   w_lin [F+Nd] (linear_logit), bn_* [C] with C = F*D+Nd.
+ * Outputs: logit_out [B]; rows_out [B,F] + grad_rows [B,F,D] = the embedding table's sparse gradient
+ * (IndexedSlices indices/values); accum: dt_deepfm_accum_floats() floats holding every dense gradient
+ * and the mean loss at the offsets reported by dt_deepfm_accum_offsets() in the order
+ * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
+ * phases: 1 = forward only (logits + loss), 2 = forward + backward.                               */
+int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
+int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
+int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
+int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11_host);
+int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,
+                         const int32_t* vocab, const float* dense, const float* y, int B, int F, int D,
+                         int Nd, const float* w_lin, const float* bn_gamma, const float* bn_beta,
+                         float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum,
+                         const float* W1, const float* b1, const float* W2, const float* b2,
+                         const float* w3, const float* w_out, const float* b_out, float* logit_out,
+                         int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
+                         int* oob_count, int phases, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

