@@ -177,12 +177,13 @@ def kernel_breakdown(dm, batch, device, sample):
     return out
 
 
-def cpu_baseline(dm, batches, batch, sample_steps=6):
+def cpu_baseline(dm, batches, batch, sample_steps=150, max_threads=32):
     """Oracle (torch CPU, all host cores) fwd+bwd on the same synthetic batches; tables are looked up
     into row tensors first so the backward produces row-gradients (IndexedSlices-like), not 1.66 GB
     dense table gradients."""
     from oracle import bridge, reference_layers as R
-    torch.set_num_threads(os.cpu_count())
+    # tiny-op torch graphs scale badly past a few dozen threads (256 threads: 27 s/step on the GPU box)
+    torch.set_num_threads(min(os.cpu_count(), max_threads))
     w = bridge.oracle_weights(dm, dtype=torch.float32)
     tables = w['emb_categorical_vars_all']
     cfg = bridge.oracle_config(dm)
@@ -226,7 +227,8 @@ def cpu_baseline(dm, batches, batch, sample_steps=6):
     for i in range(sample_steps):
         one(batches[(i + 1) % len(batches)])
     dt = time.perf_counter() - t0
-    return {'value': batch * sample_steps / dt, 'unit': 'rows/s', 'cores': os.cpu_count(), 'kind': 'port',
+    return {'value': batch * sample_steps / dt, 'unit': 'rows/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'host_cpus': os.cpu_count(),
             'sample': f'{sample_steps} fwd+bwd steps of batch {batch} (torch-CPU oracle, {torch.get_num_threads()} threads, '
                       f'{dt:.1f}s)'}
 

@@ -117,14 +117,102 @@ __global__ __launch_bounds__(256) void k_cross_bwd(
     for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) p[i] = lds[i];
 }
 
+// Register-accumulating variant for L <= LMAX: each wave keeps its grad_w / grad_b contributions in registers
+// across all of its rows and touches LDS once at the end (the generic kernel above does 2 LDS atomics per
+// (row, layer, column)).
+template <int PER, int LMAX>
+__global__ __launch_bounds__(256) void k_cross_bwd_reg(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ save_s, const float* __restrict__ gout, int B, int C, int L,
+    float* __restrict__ gx, float* __restrict__ partial /* [grid][2][L][C] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][L][C]
+    for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    float gwa[LMAX][PER], gba[LMAX][PER];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { gwa[l][k] = 0.f; gba[l][k] = 0.f; }
+    for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+        float x0[PER], g[PER], acc[PER], xl[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            x0[k] = col < C ? x[(int64_t)b * C + col] : 0.f;
+            g[k] = col < C ? gout[(int64_t)b * C + col] : 0.f;
+            acc[k] = 0.f;
+        }
+#pragma unroll
+        for (int l = LMAX - 1; l >= 0; --l) {
+            if (l >= L) continue;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) xl[k] = x0[k];
+            for (int m = 0; m < l; ++m) {
+                const float sm = save_s[(int64_t)b * L + m];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int col = k * 64 + lane;
+                    if (col < C) xl[k] = x0[k] * sm + xl[k] + bias[(int64_t)m * C + col];
+                }
+            }
+            const float s = save_s[(int64_t)b * L + l];
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) p += g[k] * x0[k];
+            const float t = wave_sum(p);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int col = k * 64 + lane;
+                if (col < C) {
+                    gwa[l][k] += xl[k] * t;
+                    gba[l][k] += g[k];
+                    acc[k] += g[k] * s;
+                    g[k] += w[(int64_t)l * C + col] * t;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            if (col < C) gx[(int64_t)b * C + col] = g[k] + acc[k];
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        if (l >= L) continue;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int col = k * 64 + lane;
+            if (col < C) {
+                atomicAdd(&lds[(int64_t)l * C + col], gwa[l][k]);
+                atomicAdd(&lds[(int64_t)(L + l) * C + col], gba[l][k]);
+            }
+        }
+    }
+    __syncthreads();
+    float* pp = partial + (int64_t)blockIdx.x * 2 * L * C;
+    for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) pp[i] = lds[i];
+}
+
+// one wavefront per (layer, column) element: lanes stride over the block partials
 __global__ __launch_bounds__(256) void k_cross_bwd_reduce(const float* __restrict__ partial,
                                                           int nblocks, int LC,
                                                           float* __restrict__ grad_w,
                                                           float* __restrict__ grad_b) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= 2 * LC) return;
-    float s = 0.f;
-    for (int k = 0; k < nblocks; ++k) s += partial[(int64_t)k * 2 * LC + i];
+    const int lane = threadIdx.x & 63;
+    float s0 = 0.f, s1 = 0.f;
+    int k = lane;
+    for (; k + 64 < nblocks; k += 128) {
+        s0 += partial[(int64_t)k * 2 * LC + i];
+        s1 += partial[(int64_t)(k + 64) * 2 * LC + i];
+    }
+    if (k < nblocks) s0 += partial[(int64_t)k * 2 * LC + i];
+    const float s = wave_sum(s0 + s1);
+    if (lane != 0) return;
     if (i < LC) {
         if (grad_w) grad_w[i] += s;
     } else {
@@ -191,10 +279,14 @@ extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, cons
     const int nblocks = cross_blocks(B);
     dim3 grid(nblocks), block(256);
     float* partial = reinterpret_cast<float*>(ws);
-#define DT_CROSS_BWD(P)                                                                       \
-    case P:                                                                                   \
-        hipLaunchKernelGGL((k_cross_bwd<P>), grid, block, lds, st, x, w, b, save_s, grad_out, \
-                           B, C, L, grad_x, partial);                                         \
+#define DT_CROSS_BWD(P)                                                                               \
+    case P:                                                                                           \
+        if (L <= 8 && P <= 8)                                                                         \
+            hipLaunchKernelGGL((k_cross_bwd_reg<(P <= 8 ? P : 8), 8>), grid, block, lds, st, x, w, b, \
+                               save_s, grad_out, B, C, L, grad_x, partial);                           \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_cross_bwd<P>), grid, block, lds, st, x, w, b, save_s, grad_out, B,  \
+                               C, L, grad_x, partial);                                                \
         break;
     switch (per) {
         DT_CROSS_BWD(1) DT_CROSS_BWD(2) DT_CROSS_BWD(4) DT_CROSS_BWD(8) DT_CROSS_BWD(16)
@@ -202,7 +294,7 @@ extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, cons
     }
 #undef DT_CROSS_BWD
     if (L > 0 && (grad_w || grad_b))
-        hipLaunchKernelGGL(k_cross_bwd_reduce, dim3(ceil_div(2 * L * C, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_cross_bwd_reduce, dim3(ceil_div(2 * L * C, 4)), dim3(256), 0, st,
                            partial, nblocks, L * C, grad_w, grad_b);
     return launch_status("dt_cross_bwd");
 }
