@@ -61,6 +61,10 @@ SIGNATURES = {
                                     _ptr]),
     'dt_adam_rows_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _c_int, _c_f32,
                                    _c_f32, _c_f32, _c_f32, _ptr]),
+    'dt_dense_supported': (_c_int, [_c_int] * 3),
+    'dt_dense_workspace_bytes': (_c_i64, [_c_int] * 3),
+    'dt_dense_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_dense_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_deepfm_supported': (_c_int, [_c_int] * 6),
     'dt_deepfm_workspace_bytes': (_c_i64, [_c_int] * 4),
     'dt_deepfm_accum_floats': (_c_i64, [_c_int] * 3),

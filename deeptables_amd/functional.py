@@ -266,7 +266,14 @@ class Dense(Layer):
         return tuple(input_shape[:-1]) + (self.units,)
 
     def call(self, x, **kwargs):
-        lead = x.shape[:-1]
+        fused_act = self.activation_name if self.activation_name in (None, 'linear', 'relu') else None
+        if x.is_cuda and ops.dense_supported(x, self.kernel):
+            # hand-written fp32 MFMA / GEMV kernels (csrc/dense.hip); relu and bias fused
+            y = ops.dense(x, self.kernel, self.bias, fused_act)
+            if self.activation is not None and fused_act is None:
+                y = self.activation(y)
+            return y
+        lead = x.shape[:-1]                      # shapes outside the kernels' LDS tile: vendor GEMM
         x2 = x.reshape(-1, x.shape[-1])
         y = torch.addmm(self.bias, x2, self.kernel) if self.bias is not None else x2 @ self.kernel
         if self.activation is not None:

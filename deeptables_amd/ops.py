@@ -394,3 +394,53 @@ class _MhaCore(torch.autograd.Function):
 
 def mha_core(q, k, v, num_heads):
     return _MhaCore.apply(q, k, v, int(num_heads))
+
+
+# ------------------------------------------------------------------------------------------------
+# Keras Dense — deepnets.py:401-427, deepmodel.py:291-292,455, layers.py:104-108
+# ------------------------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, bias, act):
+        require_cuda(x, W)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        W = _f32c(W)
+        N, K = x2.shape
+        M = W.shape[1]
+        y = torch.empty((N, M), dtype=torch.float32, device=x.device)
+        bias_c = None if bias is None else _f32c(bias)
+        check(lib().dt_dense_fwd(ptr(x2), ptr(W), ptr(bias_c), act, N, K, M, ptr(y), stream_ptr()), 'dt_dense_fwd')
+        ctx.save_for_backward(x2, W, y)
+        ctx.act, ctx.has_bias, ctx.x_shape = act, bias is not None, x.shape
+        return y.reshape(*x.shape[:-1], M)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, W, y = ctx.saved_tensors
+        N, K = x2.shape
+        M = W.shape[1]
+        gy2 = _f32c(gy).reshape(N, M)
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.empty_like(x2) if need_x else None
+        gW = torch.zeros_like(W)
+        gb = torch.zeros((M,), dtype=torch.float32, device=W.device) if ctx.has_bias else None
+        nbytes = lib().dt_dense_workspace_bytes(N, K, M)
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=W.device)
+        check(lib().dt_dense_bwd(ptr(x2), ptr(W), ptr(y), ptr(gy2), ctx.act, N, K, M, ptr(gx), ptr(gW), ptr(gb),
+                                 ptr(ws), stream_ptr()), 'dt_dense_bwd')
+        return (gx.reshape(ctx.x_shape) if need_x else None), gW, gb, None
+
+
+def dense_supported(x, W):
+    if not x.is_cuda:
+        return False
+    n = 1
+    for d in x.shape[:-1]:
+        n *= int(d)
+    return n > 0 and bool(lib().dt_dense_supported(n, int(x.shape[-1]), int(W.shape[1])))
+
+
+def dense(x, W, bias=None, activation=None):
+    """y = act(x @ W + bias) with act in {None/'linear', 'relu'} on the HIP Dense kernels."""
+    act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}[activation]
+    return _Dense.apply(x, W, bias, act)

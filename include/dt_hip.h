@@ -192,6 +192,19 @@ int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense,
                       const int64_t* rows, int n_rows, int D, int* row_epoch, int epoch,
                       float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* ---- Keras Dense (deepnets.dnn deepnets.py:401-427; Dense(1) logits / task_output deepmodel.py:291-292,455;
+ *      Q/K/V/residual projections layers.py:104-108) --------------------------------------------------- *
+ *   y [N,M] = act(x [N,K] . W [K,M] + bias [M]|NULL),  act in {DT_ACT_LINEAR, DT_ACT_RELU}.
+ *   fp32 MFMA for M >= 2, one-wave-per-row GEMV for M == 1 (vendor GEMMs pick pathological tiles at these
+ *   shapes, see profiles/).  Backward: G = grad_y * act'(y); grad_x = G W^T (may be NULL), grad_W += x^T G and
+ *   grad_b += colsum(G) are ACCUMULATED (zero them first); ws: dt_dense_workspace_bytes(N,K,M) bytes.        */
+int dt_dense_supported(int N, int K, int M);
+int64_t dt_dense_workspace_bytes(int N, int K, int M);
+int dt_dense_fwd(const float* x, const float* W, const float* bias, int act, int N, int K, int M, float* y,
+                 void* stream);
+int dt_dense_bwd(const float* x, const float* W, const float* y, const float* grad_y, int act, int N, int K,
+                 int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
+
 /* ---- fused DeepFM train step (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) ------------- *
  * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
  * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,

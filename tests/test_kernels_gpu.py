@@ -289,3 +289,29 @@ def test_cpu_tensor_is_rejected_loudly():
     from deeptables_amd._lib import DtHipError
     with pytest.raises(DtHipError):
         ops.fm(torch.zeros(2, 3, 4))
+
+
+@pytest.mark.parametrize('N,K,M,act,bias', [(64, 429, 128, 'relu', True), (300, 128, 64, 'relu', True), (8192, 64, 1, None, False),
+                                            (1000, 39, 1, None, True), (26 * 37, 32, 32, 'relu', True), (50, 7, 5, None, True),
+                                            (129, 493, 1, 'relu', True), (70, 33, 40, 'relu', False), (5, 3, 2, None, True)])
+def test_dense(dev, N, K, M, act, bias):
+    from deeptables_amd import ops
+    g = gen(N + K + M)
+    x = rnd((N, K), g)
+    W = rnd((K, M), g, 1.0 / np.sqrt(K))
+    b = rnd((M,), g, 0.3) if bias else None
+    up = rnd((N, M), g)
+    xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = xr @ Wr + (br if bias else 0)
+    if act == 'relu':
+        ref = torch.relu(ref)
+    (ref * up).sum().backward()
+    xd, Wd = x.float().to(dev).requires_grad_(True), W.float().to(dev).requires_grad_(True)
+    bd = b.float().to(dev).requires_grad_(True) if bias else None
+    out = ops.dense(xd, Wd, bd, act)
+    (out * up.float().to(dev)).sum().backward()
+    assert rel_err(out, ref) < TOL
+    assert rel_err(xd.grad, xr.grad) < TOL and rel_err(Wd.grad, Wr.grad) < TOL
+    if bias:
+        assert rel_err(bd.grad, br.grad) < TOL
