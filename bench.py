@@ -251,6 +251,7 @@ def main():
     if world > 1:
         from deeptables_amd.parallel import DataParallelStrategy
         strategy = DataParallelStrategy.from_env('nccl')
+        strategy.assume_uniform_batches = True      # fixed batch per rank: no count exchange / host sync
         device = strategy.device
         rank = strategy.rank
     else:

@@ -95,6 +95,7 @@ class FusedDeepFM:
         if self.out.bias is not None:
             self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
         self.loss_view = a[o['loss']:o['loss'] + 1]
+        dm.model._dt_flat_grad = self.accum     # lets DataParallelStrategy all-reduce the gradients in place
 
     def _buffers(self, B):
         b = self._bufs.get(B)

@@ -241,7 +241,10 @@ class DeepModel:
             cat = inputs[0]
             dense = inputs[1] if len(inputs) > 1 else None
             loss, logit = plan.run(cat, dense, y)
+            self.model._dt_flat_grad = plan.accum
             return loss[0], logit
+        if getattr(self.model, '_dt_flat_grad', None) is not None:
+            self.model._dt_flat_grad = None      # generic path: gradients are separate tensors again
         logit = self.model(inputs)
         loss = self._loss(logit, y)
         loss.backward()

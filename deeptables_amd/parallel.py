@@ -26,13 +26,16 @@ from .ops import SparseRowGrad
 class DataParallelStrategy:
     """Pass as `ModelConfig(distribute_strategy=...)`."""
 
-    def __init__(self, device=None, process_group=None):
+    def __init__(self, device=None, process_group=None, assume_uniform_batches=False):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; use DataParallelStrategy.from_env()')
         self.group = process_group
         self.rank = dist.get_rank(process_group)
         self.world_size = dist.get_world_size(process_group)
         self.device = device
+        # every rank contributes the same number of lookups per step (fixed batch, drop_remainder=True):
+        # skips the count exchange and its host synchronisation
+        self.assume_uniform_batches = assume_uniform_batches
 
     @classmethod
     def from_env(cls, backend=None):
@@ -85,6 +88,13 @@ class DataParallelStrategy:
         W = self.world_size
         if W == 1:
             return grad
+        if self.assume_uniform_batches:
+            all_rows = torch.empty((W * grad.rows.numel(),), dtype=torch.int64, device=grad.rows.device)
+            all_vals = torch.empty((W * grad.values.shape[0], grad.values.shape[1]), dtype=grad.values.dtype,
+                                   device=grad.values.device)
+            dist.all_gather_into_tensor(all_rows, grad.rows.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(all_vals, (grad.values / W).contiguous(), group=self.group)
+            return SparseRowGrad(all_rows, all_vals)
         n = torch.tensor([grad.rows.numel()], dtype=torch.int64, device=grad.rows.device)
         counts = [torch.zeros_like(n) for _ in range(W)]
         dist.all_gather(counts, n, group=self.group)
@@ -105,8 +115,23 @@ class DataParallelStrategy:
         from .models.layers import MultiColumnEmbedding
         if self.world_size == 1:
             return
-        self.allreduce_dense([p for p in model.parameters() if p.requires_grad])
+        flat = getattr(model, '_dt_flat_grad', None)
+        work = None
+        if flat is not None:
+            # the fused train step already keeps every dense gradient in ONE contiguous buffer: all-reduce it in
+            # place (async, overlapped with the sparse all-gathers below), no bucket copy in or out
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            base = flat.untyped_storage().data_ptr()
+            rest = [p for p in model.parameters() if p.requires_grad and p.grad is not None and
+                    p.grad.untyped_storage().data_ptr() != base]     # e.g. a small table's dense gradient
+            if rest:
+                self.allreduce_dense(rest)
+        else:
+            self.allreduce_dense([p for p in model.parameters() if p.requires_grad])
         for layer in model.modules():
             if isinstance(layer, MultiColumnEmbedding):
                 for key, grads in list(layer.sparse_grads.items()):
                     layer.sparse_grads[key] = [self.allgather_sparse(g) for g in grads]
+        if work is not None:
+            work.wait()
+            flat.div_(self.world_size)

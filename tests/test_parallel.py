@@ -62,6 +62,13 @@ def _worker(rank, world, port, q):
     expect[10:14] = 2.0 / world
     assert torch.allclose(dense, expect)
 
+    # --- uniform fast path (fixed batch per rank): no count exchange ---
+    st.assume_uniform_batches = True
+    out_u = st.allgather_sparse(SparseRowGrad(torch.tensor([rank, 5 + rank]), torch.ones(2, 4) * (rank + 1)))
+    assert out_u.rows.tolist() == [0, 5, 1, 6]
+    assert torch.allclose(out_u.values, torch.tensor([[0.5] * 4, [0.5] * 4, [1.0] * 4, [1.0] * 4]))
+    st.assume_uniform_batches = False
+
     # --- exchange_gradients walks the model: dense params + every MultiColumnEmbedding's sparse grads ---
     class Tiny(torch.nn.Module):
         def __init__(self):
