@@ -274,6 +274,8 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
 // ------------------------------------------------------------------------------------------
 constexpr int kCinMC = 64;  // (b,d) rows per LDS chunk
 
+constexpr int kCinKT = 2;   // 32-row K sub-tiles per wave: every staged G value feeds 2 MFMAs
+
 __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
@@ -288,39 +290,51 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
-    const int k = blockIdx.x * 128 + wave * 32 + c;  // this lane's A row (i,j)
-    const bool kvalid = k < K;
-    const int ki = kvalid ? k / Hk : 0, kj = kvalid ? k % Hk : 0;
+    const int kbase = blockIdx.x * (128 * kCinKT) + wave * (32 * kCinKT);
+    int ki[kCinKT], kj[kCinKT];
+    bool kvalid[kCinKT];
+#pragma unroll
+    for (int u = 0; u < kCinKT; ++u) {
+        const int k = kbase + 32 * u + c;   // this lane's A row (i,j) in sub-tile u
+        kvalid[u] = k < K;
+        ki[u] = kvalid[u] ? k / Hk : 0;
+        kj[u] = kvalid[u] ? k % Hk : 0;
+    }
     const int n0 = blockIdx.z * kCinTileN;
     const int nblocks_n = min(4, (L - n0 + 31) / 32);
     const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
     const int64_t m_end = min(M, m_begin + rows_per_split);
 
-    floatx16 acc[4];
+    floatx16 acc[kCinKT][4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int u = 0; u < kCinKT; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.f;
 
     for (int64_t mc = m_begin; mc < m_end; mc += kCinMC) {
         __syncthreads();
-        // stage transposed tiles: rows mm = mc + r
+        // stage transposed tiles: rows mm = mc + r ; (b, d) of a row in 32-bit arithmetic
+        const int64_t b0 = mc / D;
+        const int d0 = (int)(mc - b0 * D);
+        const int rows = (int)min((int64_t)kCinMC, m_end - mc);
         for (int e = threadIdx.x; e < kCinMC * F0; e += 256) {
             const int i = e / kCinMC, r = e - i * kCinMC;  // r fastest -> d fastest in global
-            const int64_t mm = mc + r;
-            x0T[r * F0P + i] = mm < m_end ? x0[(mm / D) * x0_bs + (int64_t)i * D + (mm % D)] : 0.f;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
+            x0T[r * F0P + i] = r < rows ? x0[(b0 + bq) * x0_bs + i * D + dq] : 0.f;
         }
         for (int e = threadIdx.x; e < kCinMC * Hk; e += 256) {
             const int j = e / kCinMC, r = e - j * kCinMC;
-            const int64_t mm = mc + r;
-            xkT[r * HkP + j] = mm < m_end ? xk[(mm / D) * xk_bs + (int64_t)j * D + (mm % D)] : 0.f;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
+            xkT[r * HkP + j] = r < rows ? xk[(b0 + bq) * xk_bs + j * D + dq] : 0.f;
         }
         for (int e = threadIdx.x; e < kCinMC * kCinTileN; e += 256) {
             const int l = e / kCinMC, r = e - l * kCinMC;
-            const int64_t mm = mc + r;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
             float g = 0.f;
-            if (mm < m_end && n0 + l < L) {
-                const int64_t o = ((mm / D) * L + n0 + l) * D + (mm % D);
+            if (r < rows && n0 + l < L) {
+                const int64_t o = ((b0 + bq) * L + n0 + l) * D + dq;
                 g = gy[o];
                 if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
             }
@@ -330,26 +344,35 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 #pragma unroll 4
         for (int t = 0; t < kCinMC / 2; ++t) {
             const int r = 2 * t + s;
-            const float a = kvalid ? x0T[r * F0P + ki] * xkT[r * HkP + kj] : 0.f;
+            float a[kCinKT];
+#pragma unroll
+            for (int u = 0; u < kCinKT; ++u)
+                a[u] = kvalid[u] ? x0T[r * F0P + ki[u]] * xkT[r * HkP + kj[u]] : 0.f;
             const float* grow = gT + r * LPAD + c;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                if (nb < nblocks_n)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, grow[nb * 32], acc[nb], 0, 0, 0);
+                if (nb < nblocks_n) {
+                    const float g = grow[nb * 32];
+#pragma unroll
+                    for (int u = 0; u < kCinKT; ++u)
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], g, acc[u][nb], 0, 0, 0);
+                }
         }
     }
     // out: row = k_local = (r&3)+8*(r>>2)+4*s, col = l_local = c
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        if (nb >= nblocks_n) continue;
-        const int l = n0 + nb * 32 + c;
-        if (l >= L) continue;
+    for (int u = 0; u < kCinKT; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
-            if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[nb][r]);
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb >= nblocks_n) continue;
+            const int l = n0 + nb * 32 + c;
+            if (l >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[u][nb][r]);
+            }
         }
-    }
 }
 
 // grad_bias[l] += sum_{b,d} G[b,l,d]
@@ -451,8 +474,10 @@ extern "C" int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W
 
     const int K = F0 * Hk;
     const int64_t M = (int64_t)B * D;
-    const int kblocks = ceil_div(K, 128), nblocks = ceil_div(L, kCinTileN);
-    int splits = (512 + kblocks * nblocks - 1) / (kblocks * nblocks);
+    const int kblocks = ceil_div(K, 128 * kCinKT), nblocks = ceil_div(L, kCinTileN);
+    // exactly one residency round: 256 CUs x 2 blocks (<= 256 registers per lane, 57 KB of LDS per block)
+    int splits = 512 / (kblocks * nblocks);
+    if (splits < 1) splits = 1;
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + kCinMC - 1) / kCinMC * kCinMC;
     splits = (int)((M + rps - 1) / rps);
