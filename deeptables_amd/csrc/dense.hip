@@ -42,15 +42,36 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const float* __restrict__ A,
     const int64_t m0 = (int64_t)blockIdx.x * rows_blk;
 
     // ---- stage the A tile (coalesced along K), zero padded ----
-    for (int e = threadIdx.x; e < rows_blk * KS; e += blockDim.x) {
-        const int r = e / KS, k = e - r * KS;
-        const int64_t m = m0 + r;
-        float v = 0.f;
-        if (m < N && k < Kd) {
-            v = A[m * Kd + k];
-            if (MASKED) v = dact(v, ya[m * Kd + k], mask_act);
+    if ((Kd & 3) == 0) {   // 16-byte loads: 4 consecutive k per thread
+        const int q4 = Kd >> 2;
+        for (int e = threadIdx.x; e < rows_blk * q4; e += blockDim.x) {
+            const int r = e / q4, q = e - r * q4;
+            const int64_t m = m0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < N) {
+                v = *reinterpret_cast<const float4*>(A + m * Kd + 4 * q);
+                if (MASKED) {
+                    const float4 yv = *reinterpret_cast<const float4*>(ya + m * Kd + 4 * q);
+                    v.x = dact(v.x, yv.x, mask_act); v.y = dact(v.y, yv.y, mask_act);
+                    v.z = dact(v.z, yv.z, mask_act); v.w = dact(v.w, yv.w, mask_act);
+                }
+            }
+            float* dst = lds + r * KS + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
-        lds[e] = v;
+        for (int r = threadIdx.x; r < rows_blk; r += blockDim.x)
+            for (int k = Kd; k < KS; ++k) lds[r * KS + k] = 0.f;
+    } else {
+        for (int e = threadIdx.x; e < rows_blk * KS; e += blockDim.x) {
+            const int r = e / KS, k = e - r * KS;
+            const int64_t m = m0 + r;
+            float v = 0.f;
+            if (m < N && k < Kd) {
+                v = A[m * Kd + k];
+                if (MASKED) v = dact(v, ya[m * Kd + k], mask_act);
+            }
+            lds[e] = v;
+        }
     }
     __syncthreads();
 
@@ -310,9 +331,10 @@ extern "C" int dt_dense_bwd(const float* x, const float* W, const float* y, cons
                            WT, nullptr, DT_ACT_LINEAR, N, M, K, nbw, grad_x);
     }
     const int tiles = ceil_div(K, 32) * ceil_div(M, 32);
+    // enough (tile, batch-split) blocks for ~4 waves per SIMD; each wave keeps >= 64 rows of work
     int splits = 1024 / tiles;
     if (splits < 1) splits = 1;
-    if (splits > 64) splits = 64;
+    if (splits > 512) splits = 512;
     while (splits > 1 && N / splits < 256) splits >>= 1;
     hipLaunchKernelGGL(k_dense_wgrad, dim3(tiles, splits), dim3(256), 0, st, x, y, grad_y, act, N, K, M, splits,
                        grad_W, grad_b);
