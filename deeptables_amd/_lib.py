@@ -68,6 +68,7 @@ SIGNATURES = {
     'dt_deepfm_supported': (_c_int, [_c_int] * 6),
     'dt_deepfm_workspace_bytes': (_c_i64, [_c_int] * 4),
     'dt_deepfm_accum_floats': (_c_i64, [_c_int] * 3),
+    'dt_deepfm_stamps_offset_floats': (_c_i64, [_c_int] * 4),
     'dt_deepfm_accum_offsets': (_c_int, [_c_int, _c_int, _c_int, _ptr]),
     'dt_deepfm_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,

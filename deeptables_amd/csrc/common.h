@@ -67,6 +67,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() lowers to
+// `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e. it also drains every global load in flight; this form waits
+// for the LDS traffic alone, so operand prefetches issued before the barrier stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // categorical id -> int, reproducing keras.ops.cast(float32 -> int32) (truncation toward zero)
 template <int KIND>
 __device__ __forceinline__ int load_id(const void* idx, int64_t i) {

@@ -22,6 +22,7 @@
 // All GEMM operands are zero-padded to K = CP (a multiple of 64) so the MFMA loops are straight-line:
 // 16-step chunks, operands for the next chunk already in flight (no per-load predication, counted waits).
 // No same-address float atomics: per-tile partials + one reduction pass (dW1/dW2 tiles: 4 adds/address).
+#include <stdlib.h>
 #include "common.h"
 
 namespace dt {
@@ -303,13 +304,22 @@ struct MlpParams {
 
 constexpr int kCH = 16;   // MFMA steps per operand chunk
 
+// phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][8] u64,
+// read back by tools/phase_times.py; costs one scalar load + store per phase
+#define DT_STAMP(buf, slot)                                                            \
+    do {                                                                               \
+        if ((buf) && threadIdx.x == 0)                                                 \
+            (buf)[(int64_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+
 __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
                                                  const float* __restrict__ lin, const float* __restrict__ fm,
                                                  const float* __restrict__ y, float* __restrict__ H1,
                                                  float* __restrict__ H2, float* __restrict__ z_out,
                                                  float* __restrict__ logit_out, float* __restrict__ dlogit,
-                                                 float* __restrict__ part) {
+                                                 float* __restrict__ part, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    DT_STAMP(stamps, 0);
     const int XS = dm.CP + 1;  // odd stride: lanes walk rows conflict-free
     float* xn = lds;                    // [32][XS]
     float* h1 = xn + kTM * XS;          // [32][129]
@@ -320,67 +330,110 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, Ml
     const int m0 = blockIdx.x * kTM;
     const PartLayout pl = part_layout(dm.CP);
 
-    // ---- stage Xn = BN(X): pad columns carry sc = beta = 0 -> Xn = 0 ----
-    const int q4 = dm.CP >> 2;
-    for (int e = threadIdx.x; e < kTM * q4; e += blockDim.x) {
-        const int r = e / q4, q = e - r * q4;
-        const int m = m0 + r;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < dm.B) x = *reinterpret_cast<const float4*>(X + (int64_t)m * dm.CP + 4 * q);
-        const float4 mu = *reinterpret_cast<const float4*>(p.mean + 4 * q);
-        const float4 sc = *reinterpret_cast<const float4*>(p.sc + 4 * q);
-        const float4 be = *reinterpret_cast<const float4*>(p.betap + 4 * q);
-        float* dst = xn + r * XS + 4 * q;
-        dst[0] = (x.x - mu.x) * sc.x + be.x;
-        dst[1] = (x.y - mu.y) * sc.y + be.y;
-        dst[2] = (x.z - mu.z) * sc.z + be.z;
-        dst[3] = (x.w - mu.w) * sc.w + be.w;
+    // GEMM2's B operands (W2, L2-resident) do not depend on anything computed here: fetch them now so their
+    // latency hides under the staging and GEMM1 phases (one block per CU = no other wave to hide it)
+    float w2q[32];
+    {
+        const int nb2 = wave & 1, kh2 = wave >> 1;
+        const float* bcol2 = p.W2 + (int64_t)(64 * kh2 + s) * kH2 + 32 * nb2 + c;
+#pragma unroll
+        for (int st = 0; st < 32; ++st) w2q[st] = bcol2[(int64_t)2 * st * kH2];
     }
-    __syncthreads();
+    const float bias1 = p.b1[32 * wave + c];
+
+    // ---- stage Xn = BN(X): pad columns carry sc = beta = 0 -> Xn = 0.  The X tile was written by another
+    // XCD a moment ago (HBM/MALL latency): issue every load of this thread before touching any result. ----
+    const int q4 = dm.CP >> 2;
+    {
+        constexpr int U = 8;
+        const int total = kTM * q4;
+        for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * U) {
+            float4 xv[U], mu[U], sc[U], be[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * blockDim.x;
+                const int r = e / q4, q = e - r * q4;
+                const int m = m0 + r;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < total) {
+                    if (m < dm.B) xv[u] = *reinterpret_cast<const float4*>(X + (int64_t)m * dm.CP + 4 * q);
+                    mu[u] = *reinterpret_cast<const float4*>(p.mean + 4 * q);
+                    sc[u] = *reinterpret_cast<const float4*>(p.sc + 4 * q);
+                    be[u] = *reinterpret_cast<const float4*>(p.betap + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * blockDim.x;
+                if (e < total) {
+                    const int r = e / q4, q = e - r * q4;
+                    float* dst = xn + r * XS + 4 * q;
+                    dst[0] = (xv[u].x - mu[u].x) * sc[u].x + be[u].x;
+                    dst[1] = (xv[u].y - mu[u].y) * sc[u].y + be[u].y;
+                    dst[2] = (xv[u].z - mu[u].z) * sc[u].z + be[u].z;
+                    dst[3] = (xv[u].w - mu[u].w) * sc[u].w + be[u].w;
+                }
+            }
+        }
+    }
+    lds_barrier();
+    DT_STAMP(stamps, 1);
 
     // ---- GEMM1: [32 x CP] . [CP x 128], zero padded: straight-line chunks of 16 MFMA steps ----
-    floatx16 acc;
+    // A dependent MFMA chain on ONE accumulator pays ~+43 cycles for every instruction (s_waitcnt, address math)
+    // the compiler leaves between two links; alternating two accumulators hides that gap behind the other chain.
+    floatx16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     {
         const float* arow = xn + c * XS + s;                       // A[row c][k = 2 st + s]
         const float* bcol = p.W1P + (int64_t)s * kH1 + 32 * wave + c;   // B[k][col]
-        const int nchunks = dm.CP / (2 * kCH);                     // CP % 64 == 0 -> even count
-        float a0[kCH], b0[kCH], a1[kCH], b1[kCH];
+        const int nchunks = dm.CP / (2 * kCH);
+        // THREE operand buffers: chunk j+2 is issued while chunk j runs.  With two buffers the compiler's
+        // s_waitcnt in front of a chain also waits for the first load of the chunk issued just before it
+        // (vmcnt is conservative by one across the loop back-edge) and the chain starts a full memory latency late.
+        float a0[kCH], b0[kCH], a1[kCH], b1[kCH], a2[kCH], b2[kCH];
+        auto load = [&](float (&aq)[kCH], float (&bq)[kCH], int ch) {
+            const float* an = arow + 2 * kCH * ch;
+            const float* bn = bcol + (int64_t)2 * kCH * ch * kH1;
 #pragma unroll
-        for (int i = 0; i < kCH; ++i) { a0[i] = arow[2 * i]; b0[i] = bcol[(int64_t)2 * i * kH1]; }
-        for (int ch = 0; ch < nchunks; ch += 2) {
-            const float* an = arow + 2 * kCH * (ch + 1);
-            const float* bn = bcol + (int64_t)2 * kCH * (ch + 1) * kH1;
-#pragma unroll
-            for (int i = 0; i < kCH; ++i) { a1[i] = an[2 * i]; b1[i] = bn[(int64_t)2 * i * kH1]; }
+            for (int i = 0; i < kCH; ++i) { aq[i] = an[2 * i]; bq[i] = bn[(int64_t)2 * i * kH1]; }
+        };
+        auto run = [&](const float (&aq)[kCH], const float (&bq)[kCH]) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kCH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ch + 2 < nchunks) {
-                const float* a2 = arow + 2 * kCH * (ch + 2);
-                const float* b2 = bcol + (int64_t)2 * kCH * (ch + 2) * kH1;
-#pragma unroll
-                for (int i = 0; i < kCH; ++i) { a0[i] = a2[2 * i]; b0[i] = b2[(int64_t)2 * i * kH1]; }
+            for (int i = 0; i < kCH; i += 2) {   // two independent accumulator chains (see acc2 above)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i], bq[i], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i + 1], bq[i + 1], acc2, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < kCH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        load(a0, b0, 0);
+        if (nchunks > 1) load(a1, b1, 1);
+        for (int ch = 0; ch < nchunks; ch += 3) {
+            if (ch + 2 < nchunks) load(a2, b2, ch + 2);
+            run(a0, b0);
+            if (ch + 1 >= nchunks) break;
+            if (ch + 3 < nchunks) load(a0, b0, ch + 3);
+            run(a1, b1);
+            if (ch + 2 >= nchunks) break;
+            if (ch + 4 < nchunks) load(a1, b1, ch + 4);
+            run(a2, b2);
         }
     }
+    DT_STAMP(stamps, 2);
     {
-        const float bias = p.b1[32 * wave + c];
+        const float bias = bias1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            const float h = fmaxf(acc[r] + bias, 0.f);
+            const float h = fmaxf((acc[r] + acc2[r]) + bias, 0.f);
             h1[row * (kH1 + 1) + 32 * wave + c] = h;
             if (m0 + row < dm.B) H1[(int64_t)(m0 + row) * kH1 + 32 * wave + c] = h;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    DT_STAMP(stamps, 3);
 
     // ---- GEMM2: [32 x 128] . [128 x 64]; wave = (n-block nb, k-half kh) ----
     {
@@ -388,19 +441,24 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, Ml
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* arow = h1 + c * (kH1 + 1) + 64 * kh + s;
-        const float* bcol = p.W2 + (int64_t)(64 * kh + s) * kH2 + 32 * nb + c;
-        float aq[32], bq[32];
+        float aq[32];
+        const float (&bq)[32] = w2q;
 #pragma unroll
-        for (int st = 0; st < 32; ++st) { aq[st] = arow[2 * st]; bq[st] = bcol[(int64_t)2 * st * kH2]; }
+        for (int st = 0; st < 32; ++st) aq[st] = arow[2 * st];
 #pragma unroll
-        for (int st = 0; st < 32; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 32; st += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], acc2, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            red[(kh * kTM + row) * (kH2 + 1) + 32 * nb + c] = acc[r];
+            red[(kh * kTM + row) * (kH2 + 1) + 32 * nb + c] = acc[r] + acc2[r];
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int e = threadIdx.x; e < kTM * kH2; e += blockDim.x) {
         const int row = e / kH2, n = e - row * kH2;
         const float v = red[row * (kH2 + 1) + n] + red[(kTM + row) * (kH2 + 1) + n] + p.b2[n];
@@ -408,7 +466,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, Ml
         h2[row * (kH2 + 1) + n] = h;
         if (m0 + row < dm.B) H2[(int64_t)(m0 + row) * kH2 + n] = h;
     }
-    __syncthreads();
+    lds_barrier();
+    DT_STAMP(stamps, 4);
 
     // ---- logits, loss, dlogit (wave 0) ----
     if (wave == 0) {
@@ -432,6 +491,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, Ml
         loss = wave_sum(loss);
         if (lane == 0) part[(int64_t)blockIdx.x * pl.stride + pl.loss] = loss / (float)dm.B;
     }
+    DT_STAMP(stamps, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,8 +503,9 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
                                                  const float* __restrict__ z, const float* __restrict__ dlogit,
                                                  float* __restrict__ dH1, float* __restrict__ dH2,
                                                  float* __restrict__ dXn, float* __restrict__ dz_out,
-                                                 float* __restrict__ part) {
+                                                 float* __restrict__ part, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    DT_STAMP(stamps, 0);
     float* w2s = lds;                        // [128][65]
     float* dh2 = w2s + kH1 * (kH2 + 1);      // [32][65]
     float* dh1 = dh2 + kTM * (kH2 + 1);      // [32][129]
@@ -455,10 +516,43 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
     const PartLayout pl = part_layout(dm.CP);
     float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
-    for (int e = threadIdx.x; e < kH1 * kH2; e += blockDim.x) {
-        const int k = e / kH2, n = e - k * kH2;
-        w2s[k * (kH2 + 1) + n] = p.W2[e];
+    // W2 (32 KB) and this tile's H2 (8 KB): all 16-byte loads of a thread in flight together
+    float4 w2r[(kH1 * kH2 / 4) / 256], h2r[(kTM * kH2 / 4) / 256];
+#pragma unroll
+    for (int u = 0; u < (kH1 * kH2 / 4) / 256; ++u)
+        w2r[u] = *reinterpret_cast<const float4*>(p.W2 + 4 * (threadIdx.x + 256 * u));
+#pragma unroll
+    for (int u = 0; u < (kTM * kH2 / 4) / 256; ++u) {
+        const int e4 = threadIdx.x + 256 * u;                    // float4 index in the [32][64] tile
+        const int m = m0 + e4 / (kH2 / 4);
+        h2r[u] = m < dm.B ? *reinterpret_cast<const float4*>(H2 + (int64_t)m * kH2 + 4 * (e4 % (kH2 / 4)))
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // everything that does not depend on values computed in this kernel is requested now, AFTER the loads the prologue needs first
+    // (vmcnt retires in order) (one block per CU:
+    // nothing else hides HBM/MALL latency): the relu masks of dH1, and the first dXn operand block
+    float h1v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * s;
+        h1v[r] = m < dm.B ? H1[(int64_t)m * kH1 + 32 * wave + c] : 0.f;
+    }
+    float bq0[kH1 / 2], bq1[kH1 / 2], xv0[16], xv1[16], mr0[2], mr1[2];
+    auto load_nb = [&](float (&bq)[kH1 / 2], float (&xv)[16], float (&mr)[2], int nb) {
+        const int col = 32 * nb + c;
+        mr[0] = p.mean[col];
+        mr[1] = p.rstd[col];
+        const float* bcol = W1T + (int64_t)s * dm.CP + col;
+#pragma unroll
+        for (int st = 0; st < kH1 / 2; ++st) bq[st] = bcol[(int64_t)2 * st * dm.CP];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
+            xv[r] = X[(int64_t)(m0 + row) * dm.CP + col];      // workspace rows are padded to the tile: in range
+        }
+    };
+    const int nblocks = dm.CP >> 5;
+    if (wave < nblocks) load_nb(bq0, xv0, mr0, wave);
     if (threadIdx.x < kTM) {
         const int m = m0 + threadIdx.x;
         float dl = 0.f, zz = 0.f;
@@ -471,18 +565,31 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
         for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
         if (threadIdx.x == 0) { prec[pl.dwo] = a; prec[pl.dbo] = b; }
     }
-    __syncthreads();
-    // dH2 tile (H2 parked in the not-yet-used dh1 buffer for the column sums below)
-    for (int e = threadIdx.x; e < kTM * kH2; e += blockDim.x) {
-        const int row = e / kH2, n = e - row * kH2;
-        const int m = m0 + row;
-        const float h = m < dm.B ? H2[(int64_t)m * kH2 + n] : 0.f;
-        const float g = h > 0.f ? dzs[row] * p.w3[n] : 0.f;
-        dh2[row * (kH2 + 1) + n] = g;
-        if (m < dm.B) dH2[(int64_t)m * kH2 + n] = g;
-        dh1[row * (kH1 + 1) + n] = h;
+#pragma unroll
+    for (int u = 0; u < (kH1 * kH2 / 4) / 256; ++u) {
+        const int e = 4 * (threadIdx.x + 256 * u);
+        const int k = e / kH2, n = e - k * kH2;
+        float* dst = w2s + k * (kH2 + 1) + n;
+        dst[0] = w2r[u].x; dst[1] = w2r[u].y; dst[2] = w2r[u].z; dst[3] = w2r[u].w;
     }
-    __syncthreads();
+    lds_barrier();
+    // dH2 tile (H2 parked in the not-yet-used dh1 buffer for the column sums below)
+#pragma unroll
+    for (int u = 0; u < (kTM * kH2 / 4) / 256; ++u) {
+        const int e4 = threadIdx.x + 256 * u;
+        const int row = e4 / (kH2 / 4), n = 4 * (e4 % (kH2 / 4));
+        const int m = m0 + row;
+        const float hv[4] = {h2r[u].x, h2r[u].y, h2r[u].z, h2r[u].w};
+        float gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gv[i] = hv[i] > 0.f ? dzs[row] * p.w3[n + i] : 0.f;
+            dh2[row * (kH2 + 1) + n + i] = gv[i];
+            dh1[row * (kH1 + 1) + n + i] = hv[i];
+        }
+        if (m < dm.B) *reinterpret_cast<float4*>(dH2 + (int64_t)m * kH2 + n) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    }
+    lds_barrier();
     if (threadIdx.x < kH2) {
         const int n = threadIdx.x;
         float sw = 0.f, sb = 0.f;
@@ -493,7 +600,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
         prec[pl.dw3 + n] = sw;
         prec[pl.db2 + n] = sb;
     }
-    __syncthreads();
+    lds_barrier();
+    DT_STAMP(stamps, 1);
 
     // dH1 = dH2 . W2^T  (wave w -> hidden units [32w, 32w+32))
     floatx16 acc;
@@ -505,15 +613,22 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
         float aq[kH2 / 2], bq[kH2 / 2];
 #pragma unroll
         for (int st = 0; st < kH2 / 2; ++st) { aq[st] = arow[2 * st]; bq[st] = brow[2 * st]; }
+        floatx16 accb;
 #pragma unroll
-        for (int st = 0; st < kH2 / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < kH2 / 2; st += 2) {   // two accumulator chains (see k_mlp_fwd)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], accb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += accb[r];
         float colsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
             const int m = m0 + row;
-            const float h = m < dm.B ? H1[(int64_t)m * kH1 + 32 * wave + c] : 0.f;
-            const float g = h > 0.f ? acc[r] : 0.f;
+            const float g = h1v[r] > 0.f ? acc[r] : 0.f;
             dh1[row * (kH1 + 1) + 32 * wave + c] = g;
             if (m < dm.B) dH1[(int64_t)m * kH1 + 32 * wave + c] = g;
             colsum += g;
@@ -521,36 +636,33 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
         colsum += __shfl_xor(colsum, 32, 64);
         if (s == 0) prec[pl.db1 + 32 * wave + c] = colsum;
     }
-    __syncthreads();
+    lds_barrier();
+    DT_STAMP(stamps, 2);
 
     // dXn = dH1 . W1^T : column blocks of 32 (CP/32 of them), round-robin over the 4 waves
-    const int nblocks = dm.CP >> 5;
     const float* arow = dh1 + c * (kH1 + 1) + s;
     float aq[kH1 / 2];
 #pragma unroll
     for (int st = 0; st < kH1 / 2; ++st) aq[st] = arow[2 * st];   // A operand is the same for every column block
     // operands of column block nb: 64 W1T values + this lane's 16 X values; the next block's operands are
     // issued before the current block's MFMA chain so HBM/L2 latency hides under 4096 MFMA cycles
-    float bq0[kH1 / 2], bq1[kH1 / 2], xv0[16], xv1[16];
-    auto load_nb = [&](float (&bq)[kH1 / 2], float (&xv)[16], int nb) {
+    float dzr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dzr[r] = dzs[(r & 3) + 8 * (r >> 2) + 4 * s];
+    auto run_nb = [&](const float (&bq)[kH1 / 2], const float (&xv)[16], const float (&mr)[2], int nb) {
         const int col = 32 * nb + c;
-        const float* bcol = W1T + (int64_t)s * dm.CP + col;
+        floatx16 accb;
 #pragma unroll
-        for (int st = 0; st < kH1 / 2; ++st) bq[st] = bcol[(int64_t)2 * st * dm.CP];
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            xv[r] = X[(int64_t)(m0 + row) * dm.CP + col];      // workspace rows are padded to the tile: in range
+        for (int st = 0; st < kH1 / 2; st += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], accb, 0, 0, 0);
         }
-    };
-    auto run_nb = [&](const float (&bq)[kH1 / 2], const float (&xv)[16], int nb) {
-        const int col = 32 * nb + c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < kH1 / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[r] += accb[r];
         float sg = 0.f, sgx = 0.f, sl = 0.f;
-        const float mu = p.mean[col], rs = p.rstd[col];
+        const float mu = mr[0], rs = mr[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
@@ -560,7 +672,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
                 dXn[(int64_t)m * dm.CP + col] = g;
                 sg += g;
                 sgx += g * ((xv[r] - mu) * rs);
-                sl += dzs[row] * xv[r];
+                sl += dzr[r] * xv[r];
             }
         }
         sg += __shfl_xor(sg, 32, 64);
@@ -573,20 +685,20 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, Ml
         }
     };
     int nb = wave;
-    if (nb < nblocks) load_nb(bq0, xv0, nb);
     while (nb < nblocks) {
-        if (nb + 4 < nblocks) load_nb(bq1, xv1, nb + 4);
+        if (nb + 4 < nblocks) load_nb(bq1, xv1, mr1, nb + 4);
         __builtin_amdgcn_sched_barrier(0);
-        run_nb(bq0, xv0, nb);
+        run_nb(bq0, xv0, mr0, nb);
         __builtin_amdgcn_sched_barrier(0);
         nb += 4;
         if (nb >= nblocks) break;
-        if (nb + 4 < nblocks) load_nb(bq0, xv0, nb + 4);
+        if (nb + 4 < nblocks) load_nb(bq0, xv0, mr0, nb + 4);
         __builtin_amdgcn_sched_barrier(0);
-        run_nb(bq1, xv1, nb);
+        run_nb(bq1, xv1, mr1, nb);
         __builtin_amdgcn_sched_barrier(0);
         nb += 4;
     }
+    DT_STAMP(stamps, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,9 +780,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpP
     const int r_begin = split * rows_per_split + wave * rq;
     const int r_end = min(dm.B, r_begin + rq);
 
-    floatx16 acc;
+    floatx16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     const bool first = tile < T1;
     const float* pa; const float* pb; int sa, sb, offa, offb;
     float mu = 0.f, sc = 1.f, be = 0.f;
@@ -687,26 +799,34 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpP
         pb = dH2; sb = kH2; offb = s * kH2 + 32 * nb + c;
     }
     {
-        float a0[kCH], b0[kCH], a1[kCH], b1[kCH];
+        float a0[kCH], b0[kCH], a1[kCH], b1[kCH], a2[kCH], b2[kCH];
         const int span = 2 * kCH;                    // rows per chunk
-        int base = r_begin;
-        const int full_end = r_begin + ((r_end - r_begin) / (2 * span)) * (2 * span);
-        if (base < full_end) wg_load<false>(a0, b0, pa, sa, offa, pb, sb, offb, base, s, r_end);
-        for (; base < full_end; base += 2 * span) {
-            wg_load<false>(a1, b1, pa, sa, offa, pb, sb, offb, base + span, s, r_end);
+        const int nfull = (r_end - r_begin) / span;  // unguarded chunks
+        auto load = [&](float (&aq)[kCH], float (&bq)[kCH], int ch) {
+            wg_load<false>(aq, bq, pa, sa, offa, pb, sb, offb, r_begin + ch * span, s, r_end);
+        };
+        auto run = [&](const float (&aq)[kCH], const float (&bq)[kCH]) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kCH; ++i)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a0[i] - mu) * sc + be, b0[i], acc, 0, 0, 0);
+            for (int i = 0; i < kCH; i += 2) {   // two accumulator chains (see k_mlp_fwd)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((aq[i] - mu) * sc + be, bq[i], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aq[i + 1] - mu) * sc + be, bq[i + 1], acc2, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (base + 2 * span < full_end) wg_load<false>(a0, b0, pa, sa, offa, pb, sb, offb, base + 2 * span, s, r_end);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < kCH; ++i)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a1[i] - mu) * sc + be, b1[i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (nfull > 0) load(a0, b0, 0);
+        if (nfull > 1) load(a1, b1, 1);
+        for (int ch = 0; ch < nfull; ch += 3) {      // three operand buffers: see k_mlp_fwd
+            if (ch + 2 < nfull) load(a2, b2, ch + 2);
+            run(a0, b0);
+            if (ch + 1 >= nfull) break;
+            if (ch + 3 < nfull) load(a0, b0, ch + 3);
+            run(a1, b1);
+            if (ch + 2 >= nfull) break;
+            if (ch + 4 < nfull) load(a1, b1, ch + 4);
+            run(a2, b2);
         }
-        for (; base < r_end; base += span) {          // ragged tail (batch not a multiple of 64 per wave)
+        for (int base = r_begin + nfull * span; base < r_end; base += span) {   // ragged tail
             wg_load<true>(a0, b0, pa, sa, offa, pb, sb, offb, base, s, r_end);
 #pragma unroll
             for (int i = 0; i < kCH; ++i) {
@@ -716,7 +836,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpP
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * s][c] = acc[r];
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * s][c] = acc[r] + acc2[r];
     __syncthreads();
     for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
         const int i = e >> 5, j = e & 31;
@@ -827,7 +947,7 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 
 // workspace layout (floats)
 struct DeepFmWs {
-    int64_t X, dXn, H1, dH1, H2, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1P, W1T, bnp, part, total;
+    int64_t X, dXn, H1, dH1, H2, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1P, W1T, bnp, part, stamps, total;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     DeepFmWs w;
@@ -848,6 +968,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     w.W1T = take((int64_t)kH1 * dm.CP);
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
     w.part = take((int64_t)tiles * part_layout(dm.CP).stride);
+    w.stamps = take((int64_t)2 * tiles * 8 * 2);   // u64 [2 kernels][tiles][8]
     w.total = o;
     return w;
 }
@@ -856,6 +977,12 @@ extern "C" int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd) {
     DeepFmDims dm; int lpr;
     if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return -1;
     return deepfm_ws_layout(dm).total * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t dt_deepfm_stamps_offset_floats(int B, int F, int D, int Nd) {
+    DeepFmDims dm; int lpr;
+    if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return -1;
+    return deepfm_ws_layout(dm).stamps;
 }
 
 extern "C" int64_t dt_deepfm_accum_floats(int F, int D, int Nd) {
@@ -897,6 +1024,7 @@ extern "C" int dt_deepfm_train_step(
                  ws + wl.betap};
     const int blocksA = ceil_div(B, 4 * kRowsPerWaveA);
     const int tiles = ceil_div(B, kTM);
+    static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
 
     // A
 #define DT_A(KIND, L)                                                                                        \
@@ -923,7 +1051,8 @@ extern "C" int dt_deepfm_train_step(
     const size_t ldsC = ((size_t)kTM * (dm.CP + 1) + kTM * (kH1 + 1) + 3 * kTM * (kH2 + 1)) * sizeof(float);
     hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC);
     hipLaunchKernelGGL(k_mlp_fwd, dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin, ws + wl.fm, y,
-                       ws + wl.H1, ws + wl.H2, ws + wl.z, logit_out, ws + wl.dlogit, ws + wl.part);
+                       ws + wl.H1, ws + wl.H2, ws + wl.z, logit_out, ws + wl.dlogit, ws + wl.part,
+                       stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr);
     // D (forward-only calls still need the loss reduced: E runs with zero tiles below)
     const int ntiles_w = ((dm.C + 31) >> 5) * (kH1 / 32) + (kH1 / 32) * (kH2 / 32);
     const PartLayout pl = part_layout(dm.CP);
@@ -935,7 +1064,8 @@ extern "C" int dt_deepfm_train_step(
         hipFuncSetAttribute((const void*)k_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
         hipLaunchKernelGGL(k_mlp_bwd, dim3(tiles), dim3(256), ldsD, st, ws + wl.X, mp, ws + wl.W1T, dm, ws + wl.H1,
                            ws + wl.H2, ws + wl.z, ws + wl.dlogit, ws + wl.dH1, ws + wl.dH2, ws + wl.dXn,
-                           ws + wl.dz, ws + wl.part);
+                           ws + wl.dz, ws + wl.part,
+                           stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) + (int64_t)tiles * 8 : nullptr);
         // E
         // 2 blocks (8 waves) per CU: two waves per SIMD so one wave's operand waits hide under the other's MFMAs
         int splits = 1024 / ntiles_w;

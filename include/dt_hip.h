@@ -222,6 +222,8 @@ int dt_dense_bwd(const float* x, const float* W, const float* y, const float* gr
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
 int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
+/* debugging aid: offset (floats) of the per-block phase timestamps written when DT_DEEPFM_STAMPS is set */
+int64_t dt_deepfm_stamps_offset_floats(int B, int F, int D, int Nd);
 int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11_host);
 int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,
                          const int32_t* vocab, const float* dense, const float* y, int B, int F, int D,
