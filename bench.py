@@ -142,6 +142,18 @@ def time_steps(step, batches, steps, warmup, barrier):
     return wall, ev0.elapsed_time(ev1) / 1e3
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch (= per step) from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+    read from inside the process); only valid for the configuration they were collected on."""
+    path = os.path.join(ROOT, 'profiles', 'r01_deepfm_traffic.json')
+    if args.model != 'DeepFM' or args.batch != 8192 or args.dist != 'uniform' or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))['bytes_per_step_corrected']
+    except Exception:
+        return None
+
+
 def kernel_breakdown(dm, batch, device, sample):
     """HIP-event timing of each hot-path kernel in isolation on the current stream (diagnostic)."""
     from deeptables_amd import ops
@@ -307,7 +319,7 @@ def main():
                        'hipgraph': not args.no_graph, 'optimizer_in_timed_region': False,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
                          'launch': 'one hipGraph replay = one fwd+bwd step',
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
         }

@@ -737,11 +737,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpP
     __shared__ float red[4][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PartLayout pl = part_layout(dm.CP);
-    if ((int)blockIdx.x >= ntiles) {
+    const int nheavy = ntiles * row_splits;     // 1-D grid: heavy (tile, split) blocks first, then reducers
+    if ((int)blockIdx.x >= nheavy) {
         // ---- reduction of the per-tile partials: element id -> destination in accum ----
-        if (blockIdx.y != 0) return;
         const int nsimple = 3 * dm.CP + kH1 + 2 * kH2 + 3;          // sg, sgx, slin, db1, db2, dw3, dwo, dbo, loss
-        const int e = ((int)blockIdx.x - ntiles) * 4 + wave;
+        const int e = ((int)blockIdx.x - nheavy) * 4 + wave;
         if (e < nsimple) {
             int src; int64_t dst;
             if (e < dm.CP) { src = pl.sg + e; dst = al.dbeta + e; }
@@ -773,8 +773,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpP
     const int s = lane >> 5, c = lane & 31;
     const int cblocks = (dm.C + 31) >> 5;
     const int T1 = cblocks * (kH1 / 32);
-    const int tile = blockIdx.x;
-    const int split = blockIdx.y;
+    // XCD-aware (tile, split) assignment: workgroups are dealt round-robin to the 8 XCDs (id % 8) and every XCD
+    // has its own 4 MB L2.  All tiles of one batch split read the same rows of X / dH1, so a split's tiles are
+    // given ids with the same id % 8: each L2 then holds 1/8 of X instead of thrashing through all of it.
+    int tile, split;
+    {
+        const int hid = blockIdx.x;                                // 0 .. ntiles*row_splits-1
+        if ((row_splits & 7) == 0) {
+            const int xcd = hid & 7, j = hid >> 3;
+            const int per = row_splits >> 3;                       // splits per XCD
+            tile = j % ntiles;
+            split = xcd * per + j / ntiles;
+        } else {
+            tile = hid % ntiles;
+            split = hid / ntiles;
+        }
+    }
     const int rows_per_split = ((dm.B + row_splits - 1) / row_splits + 7) & ~7;
     const int rq = rows_per_split >> 2;  // rows per wave (even)
     const int r_begin = split * rows_per_split + wave * rq;
@@ -1072,7 +1086,7 @@ extern "C" int dt_deepfm_train_step(
         if (splits < 1) splits = 1;
         if (splits > 32) splits = 32;
         while (splits > 1 && (B + splits - 1) / splits < 128) splits >>= 1;
-        hipLaunchKernelGGL(k_wgrad, dim3(ntiles_w + red_blocks, splits), dim3(256), 0, st, ws + wl.X, mp, dm,
+        hipLaunchKernelGGL(k_wgrad, dim3(ntiles_w * splits + red_blocks), dim3(256), 0, st, ws + wl.X, mp, dm,
                            ws + wl.H1, ws + wl.dH1, ws + wl.dH2, splits, ntiles_w, ws + wl.part, tiles, accum, al);
         // G
         const int gblocks = ceil_div(B, 4);
@@ -1085,7 +1099,7 @@ extern "C" int dt_deepfm_train_step(
 #undef DT_G
     } else {
         // forward only: reduce just the loss (the other partial slots are stale and ignored by the caller)
-        hipLaunchKernelGGL(k_wgrad, dim3(red_blocks, 1), dim3(256), 0, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
+        hipLaunchKernelGGL(k_wgrad, dim3(red_blocks), dim3(256), 0, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
                            ws + wl.dH2, 1, 0, ws + wl.part, tiles, accum, al);
     }
     return launch_status("dt_deepfm_train_step");
