@@ -125,8 +125,11 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ save_s, const float* __restrict__ gout, int B, int C, int L,
     float* __restrict__ gx, float* __restrict__ partial /* [grid][2][L][C] */) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][L][C]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][L][C] accumulators, then [2][L][C] w|bias
+    float* wl = lds + (int64_t)2 * L * C;     // weights staged once per block: the layer loops below would
+    float* bl = wl + (int64_t)L * C;          // otherwise issue L^2 * PER global loads per row
     for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) { wl[i] = w[i]; bl[i] = bias[i]; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
 #pragma unroll
         for (int k = 0; k < PER; ++k) { gwa[l][k] = 0.f; gba[l][k] = 0.f; }
     for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
-        float x0[PER], g[PER], acc[PER], xl[PER];
+        float x0[PER], g[PER], acc[PER], xl[PER], sv[LMAX];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int col = k * 64 + lane;
@@ -145,19 +148,21 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
             acc[k] = 0.f;
         }
 #pragma unroll
+        for (int l = 0; l < LMAX; ++l) sv[l] = l < L ? save_s[(int64_t)b * L + l] : 0.f;
+#pragma unroll
         for (int l = LMAX - 1; l >= 0; --l) {
             if (l >= L) continue;
 #pragma unroll
             for (int k = 0; k < PER; ++k) xl[k] = x0[k];
-            for (int m = 0; m < l; ++m) {
-                const float sm = save_s[(int64_t)b * L + m];
+#pragma unroll
+            for (int m = 0; m < LMAX; ++m) {
+                if (m >= l) continue;
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
                     const int col = k * 64 + lane;
-                    if (col < C) xl[k] = x0[k] * sm + xl[k] + bias[(int64_t)m * C + col];
+                    if (col < C) xl[k] = x0[k] * sv[m] + xl[k] + bl[m * C + col];
                 }
             }
-            const float s = save_s[(int64_t)b * L + l];
             float p = 0.f;
 #pragma unroll
             for (int k = 0; k < PER; ++k) p += g[k] * x0[k];
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
                 if (col < C) {
                     gwa[l][k] += xl[k] * t;
                     gba[l][k] += g[k];
-                    acc[k] += g[k] * s;
-                    g[k] += w[(int64_t)l * C + col] * t;
+                    acc[k] += g[k] * sv[l];
+                    g[k] += wl[l * C + col] * t;
                 }
             }
         }
@@ -281,8 +286,8 @@ extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, cons
     float* partial = reinterpret_cast<float*>(ws);
 #define DT_CROSS_BWD(P)                                                                               \
     case P:                                                                                           \
-        if (L <= 8 && P <= 8)                                                                         \
-            hipLaunchKernelGGL((k_cross_bwd_reg<(P <= 8 ? P : 8), 8>), grid, block, lds, st, x, w, b, \
+        if (L <= 8 && P <= 8 && 2 * lds <= 64 * 1024)                                                 \
+            hipLaunchKernelGGL((k_cross_bwd_reg<(P <= 8 ? P : 8), 8>), grid, block, 2 * lds, st, x, w, b, \
                                save_s, grad_out, B, C, L, grad_x, partial);                           \
         else                                                                                          \
             hipLaunchKernelGGL((k_cross_bwd<P>), grid, block, lds, st, x, w, b, save_s, grad_out, B,  \

@@ -86,6 +86,20 @@ def _worker(rank, world, port, q):
     g = m.emb.sparse_grads['d4'][0]
     assert sorted(g.rows.tolist()) == [0, 1, 7, 7] and torch.allclose(g.values, torch.full((4, 4), 0.5))
     assert m.emb.tables['d4'].grad is None          # the table itself is never densified / all-reduced
+
+    # --- fused-step path: all dense gradients live in ONE flat buffer that is all-reduced in place ---
+    m2 = Tiny()
+    flat = torch.arange(3, dtype=torch.float32) * (rank + 1)        # [0,1,2]*1 and *2 -> mean *1.5
+    m2._dt_flat_grad = flat
+    m2.fc.weight.grad = flat[:2].view(1, 2)                         # views of the flat buffer (like fused.py)
+    m2.fc.bias.grad = flat[2:3]
+    m2.emb.tables['d4'].grad = torch.full_like(m2.emb.tables['d4'], float(rank))   # a small table's dense gradient
+    m2.emb.add_sparse_grad('d4', SparseRowGrad(torch.tensor([3 + rank]), torch.ones(1, 4)))
+    st.exchange_gradients(m2)
+    assert torch.allclose(flat, torch.arange(3, dtype=torch.float32) * 1.5)
+    assert torch.allclose(m2.fc.weight.grad, torch.tensor([[0.0, 1.5]]))
+    assert torch.allclose(m2.emb.tables['d4'].grad, torch.full_like(m2.emb.tables['d4'], 0.5))
+    assert sorted(m2.emb.sparse_grads['d4'][0].rows.tolist()) == [3, 4]
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, 'ok'))
