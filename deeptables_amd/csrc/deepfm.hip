@@ -12,7 +12,7 @@
 // The reference runs this as ~100 small TF ops per step; the generic path of this repo as ~60
 // launches.  Here:
 //   A  k_sparse_fwd   gather + FM + linear + concat row X + per-block BN statistics      (HBM-bound)
-//   B  k_prep         BN finalize (mean/rstd, moving stats), zero-padded W1 and W1^T
+//   B  k_prep + k_bn_final   two-level BN reduction (mean/rstd, moving stats), zero-padded W1 and W1^T
 //   C  k_mlp_fwd      X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit  (fp32 MFMA)
 //   D  k_mlp_bwd      dH2, dH1, dXn tiles + per-tile partial sums of every small gradient
 //   E  k_wgrad        dW1 = Xn^T dH1, dW2 = H1^T dH2 (fp32 MFMA) + reduction of D's partial sums
@@ -62,94 +62,62 @@ __host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F,
 }
 
 // ---------------------------------------------------------------------------------------------
-// A: sparse forward.  One wave = 4 batch rows (all loads issued up front), one block = 16 rows.
+// A: sparse forward.  One wave = one batch row, 16 waves (16 rows) per block: 8192 waves at B = 8192, all
+//    resident at once (2 blocks of 1024 threads per CU) so the two dependent HBM round trips of a gather
+//    (ids -> table rows) overlap across 32 waves per CU.  The block's 16 rows meet in LDS for the BN statistics.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRowsPerWaveA = 4;
+constexpr int kRowsPerBlockA = 16;
+constexpr int kMaxC = 544;
 
 template <int KIND, int LPR>
-__global__ __launch_bounds__(256) void k_sparse_fwd(
+__global__ __launch_bounds__(1024) void k_sparse_fwd(
     const void* __restrict__ idx, const float4* __restrict__ table, const int64_t* __restrict__ row_offset,
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
     int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial) {
-    __shared__ float red[4][3][544];  // per wave {n, mean, M2} per column (CP <= 544)
+    __shared__ __attribute__((aligned(16))) float rowbuf[kRowsPerBlockA][kMaxC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & (LPR - 1);
     const int NV = dm.F * LPR;  // float4 per row (<= 128)
     const int D = 4 * LPR;
-    const int b0 = (blockIdx.x * 4 + wave) * kRowsPerWaveA;
-
-    float4 v[kRowsPerWaveA][2];
-    float dv[kRowsPerWaveA];
-    // ---- issue every gather of this wave's rows ----
-#pragma unroll
-    for (int r = 0; r < kRowsPerWaveA; ++r) {
-        const int b = b0 + r;
+    const int b = blockIdx.x * kRowsPerBlockA + wave;
+    if (b < dm.B) {
+        float4 v[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = lane + 64 * t;
-            v[r][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < dm.B && j < NV) {
+            v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < NV) {
                 const int f = j / LPR;
                 const int id = load_id<KIND>(idx, (int64_t)b * dm.F + f);
                 const bool ok = (unsigned)id < (unsigned)vocab[f];
                 const int64_t row = ok ? row_offset[f] + id : (int64_t)-1;
-                if (ok) v[r][t] = table[row * LPR + c];
+                if (ok) v[t] = table[row * LPR + c];
                 if (c == 0) {
                     rows_out[(int64_t)b * dm.F + f] = row;
                     if (!ok && oob) atomicAdd(oob, 1);
                 }
             }
         }
-        dv[r] = (b < dm.B && lane < dm.Nd) ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
-    }
-    // per-lane constants: linear weights of this lane's fields / dense column
-    float wl[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int j = lane + 64 * t;
-        wl[t] = j < NV ? wlin[j / LPR] : 0.f;
-    }
-    const float wld = lane < dm.Nd ? wlin[dm.F + lane] : 0.f;
-
-    // shifted BN sums (shift = this wave's first row)
-    float4 K4[2], s4[2], q4[2];
-    float Kd = dv[0], sd = 0.f, qd = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        K4[t] = v[0][t];
-        s4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    int nrows = 0;
-#pragma unroll
-    for (int r = 0; r < kRowsPerWaveA; ++r) {
-        const int b = b0 + r;
-        if (b >= dm.B) break;  // wave-uniform
-        ++nrows;
+        const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
+        float lp = dv * (lane < dm.Nd ? wlin[dm.F + lane] : 0.f);
         float4 S = make_float4(0.f, 0.f, 0.f, 0.f), Q = S;
-        float lp = dv[r] * wld;
         float* xrow = X + (int64_t)b * dm.CP;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = lane + 64 * t;
-            const float4 x = v[r][t];
-            if (j < NV) *reinterpret_cast<float4*>(xrow + 4 * j) = x;
+            const float4 x = v[t];
+            if (j < NV) {
+                *reinterpret_cast<float4*>(xrow + 4 * j) = x;
+                *reinterpret_cast<float4*>(&rowbuf[wave][4 * j]) = x;
+                lp += ((x.x + x.y) + (x.z + x.w)) * wlin[j / LPR];
+            }
             S.x += x.x; S.y += x.y; S.z += x.z; S.w += x.w;
             Q.x += x.x * x.x; Q.y += x.y * x.y; Q.z += x.z * x.z; Q.w += x.w * x.w;
-            lp += ((x.x + x.y) + (x.z + x.w)) * wl[t];
-            float d;
-            d = x.x - K4[t].x; s4[t].x += d; q4[t].x += d * d;
-            d = x.y - K4[t].y; s4[t].y += d; q4[t].y += d * d;
-            d = x.z - K4[t].z; s4[t].z += d; q4[t].z += d * d;
-            d = x.w - K4[t].w; s4[t].w += d; q4[t].w += d * d;
         }
         for (int k = lane; k < dm.CP - dm.F * D; k += 64)   // dense columns, then zero padding up to CP
-            xrow[dm.F * D + k] = k < dm.Nd ? dv[r] : 0.f;
-        {
-            const float d = dv[r] - Kd;
-            sd += d; qd += d * d;
-        }
+            xrow[dm.F * D + k] = k < dm.Nd ? dv : 0.f;
+        if (lane < dm.Nd) rowbuf[wave][dm.F * D + lane] = dv;
         S.x = wave_sum_strided<LPR>(S.x); S.y = wave_sum_strided<LPR>(S.y);
         S.z = wave_sum_strided<LPR>(S.z); S.w = wave_sum_strided<LPR>(S.w);
         Q.x = wave_sum_strided<LPR>(Q.x); Q.y = wave_sum_strided<LPR>(Q.y);
@@ -162,114 +130,136 @@ __global__ __launch_bounds__(256) void k_sparse_fwd(
             lin_out[b] = lp;
         }
     }
-    // ---- per-wave {n, mean, M2} per column -> LDS ----
-    const float n = (float)nrows;
-    auto put = [&](int col, float K, float s, float q) {
-        float mean = 0.f, m2 = 0.f;
-        if (n > 0.f) {
-            mean = K + s / n;
-            m2 = fmaxf(q - s * s / n, 0.f);
-        }
-        red[wave][0][col] = n;
-        red[wave][1][col] = mean;
-        red[wave][2][col] = m2;
-    };
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int j = lane + 64 * t;
-        if (j < NV) {
-            put(4 * j + 0, K4[t].x, s4[t].x, q4[t].x);
-            put(4 * j + 1, K4[t].y, s4[t].y, q4[t].y);
-            put(4 * j + 2, K4[t].z, s4[t].z, q4[t].z);
-            put(4 * j + 3, K4[t].w, s4[t].w, q4[t].w);
-        }
-    }
-    if (lane < dm.Nd) put(dm.F * D + lane, Kd, sd, qd);
     __syncthreads();
+    // ---- BN statistics of this block's rows: exact two-pass {n, mean, M2} per column ----
+    const int nrows = min(kRowsPerBlockA, dm.B - (int)blockIdx.x * kRowsPerBlockA);
     for (int col = threadIdx.x; col < dm.C; col += blockDim.x) {
-        float nn = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float nb = red[w][0][col];
-            if (nb <= 0.f) continue;
-            const float mb = red[w][1][col], m2b = red[w][2][col];
-            const float nt = nn + nb;
-            const float delta = mb - mean;
-            mean += delta * (nb / nt);
-            m2 += m2b + delta * delta * (nn * nb / nt);
-            nn = nt;
+        float sum = 0.f;
+        for (int w = 0; w < nrows; ++w) sum += rowbuf[w][col];
+        const float mean = nrows > 0 ? sum / (float)nrows : 0.f;
+        float m2 = 0.f;
+        for (int w = 0; w < nrows; ++w) {
+            const float d = rowbuf[w][col] - mean;
+            m2 += d * d;
         }
         float* p = bn_partial + (int64_t)blockIdx.x * 3 * dm.C;
-        p[col] = nn;
+        p[col] = (float)max(nrows, 0);
         p[dm.C + col] = mean;
         p[2 * dm.C + col] = m2;
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// B: BN finalize + zero-padded W1P [CP][H1] and W1T [H1][CP] + zeroing of dW1|dW2
+//    BN blocks: 64 columns x 16 waves; lanes run along the columns (256-byte coalesced partial rows), every
+//    wave Chan-merges a slice of the chunk list, the 16 slices meet in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBnSlices = 16;   // level-1 BN reduction blocks per 64-column group
 
-// ---------------------------------------------------------------------------------------------
-// B: BN finalize (one wave per column) + zero-padded W1P [CP][H1] and W1T [H1][CP]
-// ---------------------------------------------------------------------------------------------
 struct PrepOut {
     float *mean, *rstd, *sc, *beta, *W1P, *W1T;   // all padded to CP
+    float* bn2;                                   // [kBnSlices][3][C] level-1 results
 };
 
-__global__ __launch_bounds__(256) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
-                                              float eps, float momentum, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, float* __restrict__ moving_mean,
-                                              float* __restrict__ moving_var, const float* __restrict__ W1,
-                                              PrepOut o, int bn_blocks, float* __restrict__ zero_region,
-                                              int zero_floats) {
+__global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
+                                               float eps, float momentum, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                               float* __restrict__ moving_var, const float* __restrict__ W1,
+                                               PrepOut o, int bn_blocks, float* __restrict__ zero_region,
+                                               int zero_floats) {
     if ((int)blockIdx.x >= bn_blocks) {  // weight copies + zeroing of the atomically accumulated dW1/dW2
-        for (int e = ((int)blockIdx.x - bn_blocks) * blockDim.x + threadIdx.x; e < zero_floats;
-             e += (gridDim.x - bn_blocks) * blockDim.x)
-            zero_region[e] = 0.f;
+        __shared__ float tile[32][33];
+        const int wb = (int)blockIdx.x - bn_blocks, nwb = gridDim.x - bn_blocks;
+        for (int e = wb * blockDim.x + threadIdx.x; e < zero_floats; e += nwb * blockDim.x) zero_region[e] = 0.f;
         const int total = kH1 * dm.CP;
-        for (int e = ((int)blockIdx.x - bn_blocks) * blockDim.x + threadIdx.x; e < total;
-             e += (gridDim.x - bn_blocks) * blockDim.x) {
-            {   // W1T[k][col]
-                const int k = e / dm.CP, col = e - k * dm.CP;
-                o.W1T[e] = col < dm.C ? W1[(int64_t)col * kH1 + k] : 0.f;
-            }
-            {   // W1P[col][k]
-                const int col = e / kH1;
-                o.W1P[e] = col < dm.C ? W1[e] : 0.f;
-            }
+        for (int e = wb * blockDim.x + threadIdx.x; e < total; e += nwb * blockDim.x) {   // W1P[col][k]: plain copy
+            const int col = e / kH1;
+            o.W1P[e] = col < dm.C ? W1[e] : 0.f;
+        }
+        // W1T[k][col] = W1[col][k]: 32x32 tiles through LDS so that both the read (along k) and the write
+        // (along col) are coalesced
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 32 threads
+        const int ctiles = dm.CP >> 5, ktiles = kH1 >> 5;
+        for (int t = wb; t < ctiles * ktiles; t += nwb) {
+            const int c0 = (t / ktiles) << 5, k0 = (t % ktiles) << 5;
+            __syncthreads();
+            tile[ty][tx] = (c0 + ty) < dm.C ? W1[(int64_t)(c0 + ty) * kH1 + k0 + tx] : 0.f;
+            __syncthreads();
+            o.W1T[(int64_t)(k0 + ty) * dm.CP + c0 + tx] = tile[tx][ty];
         }
         return;
     }
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (col >= dm.CP) return;
+    // level 1 of the BN reduction: block = (64-column group, slice of the chunk list), ONE wave, lanes along the
+    // columns (256-byte coalesced partial rows).  A CU pulls only ~20 GB/s from HBM, so the 2.6 MB of partials
+    // must be spread over >= 100 CUs; level 2 (k_bn_final) merges the kBnSlices results per column.
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x >= 64) return;
+    const int cgroups = (dm.C + 63) >> 6;
+    const int cg = blockIdx.x % cgroups, slice = blockIdx.x / cgroups;
+    const int col = cg * 64 + lane;
+    const bool cok = col < dm.C;
+    const int per = (chunks + kBnSlices - 1) / kBnSlices;
+    const int k0 = slice * per, k1 = min(chunks, k0 + per);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    constexpr int UB = 16;
+    for (int kb = k0; kb < k1; kb += UB) {
+        float nb[UB], mb[UB], qb[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = kb + u;
+            const bool ok = cok && k < k1;
+            const float* p = partial + (int64_t)(ok ? k : 0) * 3 * dm.C + (cok ? col : 0);
+            // unconditional loads from a clamped (always valid) address, selected afterwards
+            const float v0 = p[0], v1 = p[dm.C], v2 = p[2 * dm.C];
+            nb[u] = ok ? v0 : 0.f;
+            mb[u] = ok ? v1 : 0.f;
+            qb[u] = ok ? v2 : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (nb[u] <= 0.f) continue;
+            const float nt = n + nb[u];
+            const float delta = mb[u] - mean;
+            mean += delta * (nb[u] / nt);
+            m2 += qb[u] + delta * delta * (n * nb[u] / nt);
+            n = nt;
+        }
+    }
+    if (cok) {
+        float* q = o.bn2 + (int64_t)slice * 3 * dm.C;
+        q[col] = n;
+        q[dm.C + col] = mean;
+        q[2 * dm.C + col] = m2;
+    }
+}
+
+// level 2: merge the kBnSlices per-column results, publish mean / rstd / scale / beta (padded) + moving stats
+__global__ __launch_bounds__(256) void k_bn_final(DeepFmDims dm, float eps, float momentum,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                  PrepOut o) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= dm.CP) return;
     if (col >= dm.C) {  // pad columns
-        if (lane == 0) { o.mean[col] = 0.f; o.rstd[col] = 0.f; o.sc[col] = 0.f; o.beta[col] = 0.f; }
+        o.mean[col] = 0.f; o.rstd[col] = 0.f; o.sc[col] = 0.f; o.beta[col] = 0.f;
         return;
+    }
+    float nb[kBnSlices], mb[kBnSlices], qb[kBnSlices];
+#pragma unroll
+    for (int w = 0; w < kBnSlices; ++w) {
+        const float* q = o.bn2 + (int64_t)w * 3 * dm.C + col;
+        nb[w] = q[0]; mb[w] = q[dm.C]; qb[w] = q[2 * dm.C];
     }
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = lane; k < chunks; k += 64) {
-        const float* p = partial + (int64_t)k * 3 * dm.C;
-        const float nb = p[col];
-        if (nb <= 0.f) continue;
-        const float mb = p[dm.C + col], m2b = p[2 * dm.C + col];
-        const float nt = n + nb;
-        const float delta = mb - mean;
-        mean += delta * (nb / nt);
-        m2 += m2b + delta * delta * (n * nb / nt);
-        n = nt;
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mean, off, 64), m2b = __shfl_xor(m2, off, 64);
-        const float nt = n + nb;
-        if (nt > 0.f) {
-            const float delta = mb - mean;
-            const float new_mean = (n * mean + nb * mb) / nt;
-            m2 = m2 + m2b + delta * delta * (n * nb / nt);
-            mean = new_mean;
-        }
+    for (int w = 0; w < kBnSlices; ++w) {
+        if (nb[w] <= 0.f) continue;
+        const float nt = n + nb[w];
+        const float delta = mb[w] - mean;
+        mean += delta * (nb[w] / nt);
+        m2 += qb[w] + delta * delta * (n * nb[w] / nt);
         n = nt;
     }
-    if (lane != 0) return;
     const float var = n > 0.f ? m2 / n : 0.f;
     const float rstd = 1.0f / sqrtf(var + eps);
     o.mean[col] = mean;
@@ -961,13 +951,13 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 
 // workspace layout (floats)
 struct DeepFmWs {
-    int64_t X, dXn, H1, dH1, H2, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1P, W1T, bnp, part, stamps, total;
+    int64_t X, dXn, H1, dH1, H2, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1P, W1T, bnp, bn2, part, stamps, total;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     DeepFmWs w;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
-    const int blocksA = ceil_div(dm.B, 4 * kRowsPerWaveA);
+    const int blocksA = ceil_div(dm.B, kRowsPerBlockA);
     const int tiles = ceil_div(dm.B, kTM);
     const int64_t rows = (int64_t)tiles * kTM;
     w.X = take(rows * dm.CP);
@@ -981,6 +971,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     w.W1P = take((int64_t)dm.CP * kH1);
     w.W1T = take((int64_t)kH1 * dm.CP);
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
+    w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
     w.part = take((int64_t)tiles * part_layout(dm.CP).stride);
     w.stamps = take((int64_t)2 * tiles * 8 * 2);   // u64 [2 kernels][tiles][8]
     w.total = o;
@@ -1036,13 +1027,14 @@ extern "C" int dt_deepfm_train_step(
     float* ws = reinterpret_cast<float*>(workspace);
     MlpParams mp{ws + wl.W1P, b1, W2, b2, w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc,
                  ws + wl.betap};
-    const int blocksA = ceil_div(B, 4 * kRowsPerWaveA);
+    const int blocksA = ceil_div(B, kRowsPerBlockA);
     const int tiles = ceil_div(B, kTM);
     static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
 
-    // A
+    // A  (DT_A_DYNLDS: experiment knob — extra dynamic LDS caps residency to one 1024-thread block per CU)
+    static const size_t a_dyn_lds = getenv("DT_A_DYNLDS") ? (size_t)atoi(getenv("DT_A_DYNLDS")) : 0;
 #define DT_A(KIND, L)                                                                                        \
-    hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(256), 0, st, idx, (const float4*)table,  \
+    hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), a_dyn_lds, st, idx, (const float4*)table,  \
                        row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, rows_out,    \
                        oob_count, ws + wl.bnp)
 #define DT_A_L(KIND)                                                                  \
@@ -1056,11 +1048,13 @@ extern "C" int dt_deepfm_train_step(
 #undef DT_A_L
 #undef DT_A
     // B
-    const int bn_blocks = ceil_div(dm.CP, 4);
-    PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.W1P, ws + wl.W1T};
-    hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 64), dim3(256), 0, st, ws + wl.bnp, blocksA, dm, bn_eps, bn_momentum,
+    const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
+    PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.W1P, ws + wl.W1T, ws + wl.bn2};
+    hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56), dim3(1024), 0, st, ws + wl.bnp, blocksA, dm, bn_eps, bn_momentum,
                        bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, accum + al.dW1,
                        (int)(al.db1 - al.dW1));
+    hipLaunchKernelGGL(k_bn_final, dim3(ceil_div(dm.CP, 256)), dim3(256), 0, st, dm, bn_eps, bn_momentum, bn_gamma,
+                       bn_beta, bn_moving_mean, bn_moving_var, po);
     // C
     const size_t ldsC = ((size_t)kTM * (dm.CP + 1) + kTM * (kH1 + 1) + 3 * kTM * (kH2 + 1)) * sizeof(float);
     hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC);
