@@ -65,6 +65,14 @@ SIGNATURES = {
     'dt_dense_workspace_bytes': (_c_i64, [_c_int] * 3),
     'dt_dense_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     'dt_dense_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'dt_afm_fwd': (_c_int, [_ptr] * 4 + [_c_int] * 5 + [_ptr] * 3),
+    'dt_afm_bwd': (_c_int, [_ptr] * 6 + [_c_int] * 5 + [_ptr] * 5),
+    'dt_bilinear_fwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_bilinear_bwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_field_pool_fwd': (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_field_pool_bwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_field_scale_fwd': (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_field_scale_bwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     'dt_deepfm_supported': (_c_int, [_c_int] * 6),
     'dt_deepfm_workspace_bytes': (_c_i64, [_c_int] * 4),
     'dt_deepfm_accum_floats': (_c_i64, [_c_int] * 3),

@@ -1,0 +1,523 @@
+// interaction.hip — the remaining pairwise field-interaction layers of deeptables/models/layers.py
+// (SURVEY §8 f3): AFM attention pooling, BilinearInteraction (FiBiNet), SENET re-weighting.
+//
+//   AFM.call                  layers.py:789-807   softmax over the P = F(F-1)/2 pair interactions
+//   BilinearInteraction.call  layers.py:363-377   (v_i . W) * v_j  for every pair
+//   SENET.call                layers.py:291-302   squeeze (mean|max over D) ... scale
+//
+// Same design as product.hip: a batch row's [F, D] block is staged once in LDS and every pair is formed from
+// it; the reference materialises p, q = [B, P, D] (and the AFM attention tensor [B, P, H]).  Parameter
+// gradients are accumulated per block (persistent blocks looping over rows) and flushed once with atomics.
+#include "common.h"
+
+namespace dt {
+
+__device__ __forceinline__ int pair_of(int i, int j, int F) { return i * F - (i * (i + 1)) / 2 + (j - i - 1); }
+
+__device__ __forceinline__ float block_sum(float v, float* scratch /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += scratch[w];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, scratch[w]);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AFM:  bi[p] = x_i * x_j ; a[p,h] = act(bi[p] . Wa[:,h] + ba[h]) ; logit[p] = a[p] . pv ;
+//       score = softmax_p(logit) ; out[d] = sum_p score[p] bi[p,d]
+// ---------------------------------------------------------------------------------------------
+template <int HMAX>
+__global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, const float* __restrict__ Wa,
+                                                 const float* __restrict__ ba, const float* __restrict__ pv,
+                                                 int act, int B, int F, int D, int H, float* __restrict__ out,
+                                                 float* __restrict__ score_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P = F * (F - 1) / 2;
+    float* xr = lds;               // [F*D]
+    float* wa = xr + F * D;        // [D*H]
+    float* bb = wa + D * H;        // [H]
+    float* pp = bb + H;            // [H]
+    float* sc = pp + H;            // [P]
+    float* scratch = sc + P;       // [8]
+    short* pi = reinterpret_cast<short*>(scratch + 8);
+    short* pj = pi + P;
+    for (int e = threadIdx.x; e < D * H; e += blockDim.x) wa[e] = Wa[e];
+    for (int e = threadIdx.x; e < H; e += blockDim.x) { bb[e] = ba ? ba[e] : 0.f; pp[e] = pv[e]; }
+    for (int i = threadIdx.x; i < F; i += blockDim.x)
+        for (int j = i + 1; j < F; ++j) { const int p = pair_of(i, j, F); pi[p] = (short)i; pj[p] = (short)j; }
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < F * D; e += blockDim.x) xr[e] = x[(int64_t)b * F * D + e];
+        __syncthreads();
+        float lmax = -INFINITY;
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float* xi = xr + pi[p] * D;
+            const float* xj = xr + pj[p] * D;
+            float acc[HMAX];
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) acc[h] = h < H ? bb[h] : 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float bi = xi[d] * xj[d];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h)
+                    if (h < H) acc[h] += bi * wa[d * H + h];
+            }
+            float lg = 0.f;
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h)
+                if (h < H) lg += (act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h]) * pp[h];
+            sc[p] = lg;
+            lmax = fmaxf(lmax, lg);
+        }
+        lmax = block_max(lmax, scratch);
+        float lsum = 0.f;
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float e = expf(sc[p] - lmax);
+            sc[p] = e;
+            lsum += e;
+        }
+        lsum = block_sum(lsum, scratch);
+        const float inv = 1.0f / lsum;
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float s = sc[p] * inv;
+            sc[p] = s;
+            if (score_out) score_out[(int64_t)b * P + p] = s;
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            float o = 0.f;
+            for (int p = 0; p < P; ++p) o += sc[p] * xr[pi[p] * D + d] * xr[pj[p] * D + d];
+            out[(int64_t)b * D + d] = o;
+        }
+    }
+}
+
+template <int HMAX>
+__global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, const float* __restrict__ Wa,
+                                                 const float* __restrict__ ba, const float* __restrict__ pv,
+                                                 const float* __restrict__ score, const float* __restrict__ gout,
+                                                 int act, int B, int F, int D, int H, float* __restrict__ gx,
+                                                 float* __restrict__ gWa, float* __restrict__ gba,
+                                                 float* __restrict__ gpv) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P = F * (F - 1) / 2;
+    float* xr = lds;               // [F*D]
+    float* wa = xr + F * D;        // [D*H]
+    float* bb = wa + D * H;        // [H]
+    float* pp = bb + H;            // [H]
+    float* gr = pp + H;            // [D]   grad_out row
+    float* datt = gr + D;          // [P*H]
+    float* dbi = datt + P * H;     // [P*D]
+    float* accW = dbi + P * D;     // [D*H] block accumulators
+    float* accb = accW + D * H;    // [H]
+    float* accp = accb + H;        // [H]
+    float* scratch = accp + H;     // [8]
+    short* pi = reinterpret_cast<short*>(scratch + 8);
+    short* pj = pi + P;
+    for (int e = threadIdx.x; e < D * H; e += blockDim.x) { wa[e] = Wa[e]; accW[e] = 0.f; }
+    for (int e = threadIdx.x; e < H; e += blockDim.x) { bb[e] = ba ? ba[e] : 0.f; pp[e] = pv[e]; accb[e] = 0.f; accp[e] = 0.f; }
+    for (int i = threadIdx.x; i < F; i += blockDim.x)
+        for (int j = i + 1; j < F; ++j) { const int p = pair_of(i, j, F); pi[p] = (short)i; pj[p] = (short)j; }
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < F * D; e += blockDim.x) xr[e] = x[(int64_t)b * F * D + e];
+        for (int e = threadIdx.x; e < D; e += blockDim.x) gr[e] = gout[(int64_t)b * D + e];
+        __syncthreads();
+        // S = sum_q score_q dscore_q,  dscore_p = sum_d g[d] bi[p,d]
+        float part = 0.f;
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float* xi = xr + pi[p] * D;
+            const float* xj = xr + pj[p] * D;
+            float ds = 0.f;
+            for (int d = 0; d < D; ++d) ds += gr[d] * xi[d] * xj[d];
+            part += score[(int64_t)b * P + p] * ds;
+        }
+        const float S = block_sum(part, scratch);
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float* xi = xr + pi[p] * D;
+            const float* xj = xr + pj[p] * D;
+            const float sp = score[(int64_t)b * P + p];
+            float acc[HMAX];
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) acc[h] = h < H ? bb[h] : 0.f;
+            float ds = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float bi = xi[d] * xj[d];
+                ds += gr[d] * bi;
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h)
+                    if (h < H) acc[h] += bi * wa[d * H + h];
+            }
+            const float dlogit = sp * (ds - S);
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h)
+                if (h < H) {
+                    const float a = act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h];
+                    const float da = (act == DT_ACT_RELU && !(acc[h] > 0.f)) ? 0.f : dlogit * pp[h];
+                    datt[p * H + h] = da;
+                    atomicAdd(&accp[h], dlogit * a);
+                    atomicAdd(&accb[h], da);
+                    acc[h] = da;   // reuse as datt
+                }
+            for (int d = 0; d < D; ++d) {
+                float v = sp * gr[d];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h)
+                    if (h < H) v += acc[h] * wa[d * H + h];
+                dbi[p * D + d] = v;
+            }
+        }
+        __syncthreads();
+        // grad_Wa[d,h] += sum_p bi[p,d] datt[p,h]
+        for (int e = threadIdx.x; e < D * H; e += blockDim.x) {
+            const int d = e / H, h = e - d * H;
+            float v = 0.f;
+            for (int p = 0; p < P; ++p) v += xr[pi[p] * D + d] * xr[pj[p] * D + d] * datt[p * H + h];
+            accW[e] += v;
+        }
+        // grad_x[f,d] = sum_{o != f} dbi[p(f,o), d] x[o,d]
+        for (int e = threadIdx.x; e < F * D; e += blockDim.x) {
+            const int f = e / D, d = e - f * D;
+            float v = 0.f;
+            for (int o = 0; o < F; ++o) {
+                if (o == f) continue;
+                const int p = o > f ? pair_of(f, o, F) : pair_of(o, f, F);
+                v += dbi[p * D + d] * xr[o * D + d];
+            }
+            gx[(int64_t)b * F * D + e] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < D * H; e += blockDim.x) atomicAdd(gWa + e, accW[e]);
+    for (int e = threadIdx.x; e < H; e += blockDim.x) {
+        if (gba) atomicAdd(gba + e, accb[e]);
+        atomicAdd(gpv + e, accp[e]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BilinearInteraction: out[b,p,:] = (x_i . W_q) * x_j ,  q = p ('field_interaction'), i ('field_each'), 0 ('field_all')
+//   wave = one pair x 64 batch rows (lane = row); W_q [D,D] broadcast from LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bilinear_fwd(const float* __restrict__ x, const float* __restrict__ W,
+                                                     int wtype, int B, int F, int D, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P = F * (F - 1) / 2;
+    const int DP = D + 1;
+    float* Wq = lds;             // [D][D]
+    float* xi = lds + D * D;     // [64][DP]
+    float* xj = xi + 64 * DP;    // [64][DP]
+    const int lane = threadIdx.x, p = blockIdx.y, b0 = blockIdx.x * 64;
+    int i = 0, rem = p;
+    while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const int q = wtype == 0 ? p : (wtype == 1 ? i : 0);
+    for (int e = lane; e < D * D; e += 64) Wq[e] = W[(int64_t)q * D * D + e];
+    for (int e = lane; e < 64 * D; e += 64) {
+        const int r = e / D, d = e - r * D;
+        const int b = b0 + r;
+        xi[r * DP + d] = b < B ? x[((int64_t)b * F + i) * D + d] : 0.f;
+        xj[r * DP + d] = b < B ? x[((int64_t)b * F + j) * D + d] : 0.f;
+    }
+    __syncthreads();
+    if (b0 + lane >= B) return;
+    for (int d2 = 0; d2 < D; ++d2) {
+        float u = 0.f;
+        for (int d = 0; d < D; ++d) u += xi[lane * DP + d] * Wq[d * D + d2];
+        out[((int64_t)(b0 + lane) * P + p) * D + d2] = u * xj[lane * DP + d2];
+    }
+}
+
+// grad_x for field f (all partners), lane = row
+__global__ __launch_bounds__(64) void k_bilinear_bwd_x(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ gout, int wtype, int B, int F,
+                                                       int D, float* __restrict__ gx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P = F * (F - 1) / 2;
+    const int DP = D + 1;
+    float* Wq = lds;              // [D][D]
+    float* xo = lds + D * D;      // [64][DP] partner rows
+    float* xf = xo + 64 * DP;     // [64][DP] own rows
+    float* acc = xf + 64 * DP;    // [64][DP]
+    const int lane = threadIdx.x, f = blockIdx.y, b0 = blockIdx.x * 64;
+    const int b = b0 + lane;
+    for (int e = lane; e < 64 * D; e += 64) {
+        const int r = e / D, d = e - r * D;
+        xf[r * DP + d] = (b0 + r) < B ? x[((int64_t)(b0 + r) * F + f) * D + d] : 0.f;
+    }
+    for (int d = 0; d < D; ++d) acc[lane * DP + d] = 0.f;
+    for (int o = 0; o < F; ++o) {
+        if (o == f) continue;
+        const bool f_is_i = f < o;
+        const int i = f_is_i ? f : o;
+        const int p = f_is_i ? pair_of(f, o, F) : pair_of(o, f, F);
+        const int q = wtype == 0 ? p : (wtype == 1 ? i : 0);
+        __syncthreads();
+        for (int e = lane; e < D * D; e += 64) Wq[e] = W[(int64_t)q * D * D + e];
+        for (int e = lane; e < 64 * D; e += 64) {
+            const int r = e / D, d = e - r * D;
+            xo[r * DP + d] = (b0 + r) < B ? x[((int64_t)(b0 + r) * F + o) * D + d] : 0.f;
+        }
+        __syncthreads();
+        if (b >= B) continue;
+        const float* g = gout + ((int64_t)b * P + p) * D;
+        if (f_is_i) {   // out[d2] = (sum_d x_f[d] W[d,d2]) x_o[d2]  ->  grad x_f[d] += sum_d2 g[d2] x_o[d2] W[d,d2]
+            for (int d = 0; d < D; ++d) {
+                float v = 0.f;
+                for (int d2 = 0; d2 < D; ++d2) v += g[d2] * xo[lane * DP + d2] * Wq[d * D + d2];
+                acc[lane * DP + d] += v;
+            }
+        } else {        // f = j: grad x_f[d2] += g[d2] * (sum_d x_o[d] W[d,d2])
+            for (int d2 = 0; d2 < D; ++d2) {
+                float u = 0.f;
+                for (int d = 0; d < D; ++d) u += xo[lane * DP + d] * Wq[d * D + d2];
+                acc[lane * DP + d2] += g[d2] * u;
+            }
+        }
+    }
+    if (b < B)
+        for (int d = 0; d < D; ++d) gx[((int64_t)b * F + f) * D + d] = acc[lane * DP + d];
+}
+
+// grad_W[q][d,d2] += sum_b x_i[b,d] g[b,p,d2] x_j[b,d2];  block = (pair, batch split), thread = (d,d2) entries
+__global__ __launch_bounds__(256) void k_bilinear_bwd_w(const float* __restrict__ x, const float* __restrict__ gout,
+                                                        int wtype, int B, int F, int D, int rows_per_split,
+                                                        float* __restrict__ gW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P = F * (F - 1) / 2;
+    constexpr int TB = 64;
+    float* xi = lds;              // [TB][D]
+    float* gj = lds + TB * D;     // [TB][D]   g * x_j
+    const int p = blockIdx.x;
+    int i = 0, rem = p;
+    while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const int q = wtype == 0 ? p : (wtype == 1 ? i : 0);
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(B, r_begin + rows_per_split);
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int r0 = r_begin; r0 < r_end; r0 += TB) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < TB * D; e += blockDim.x) {
+            const int r = e / D, d = e - r * D;
+            const int b = r0 + r;
+            const bool ok = b < r_end;
+            xi[e] = ok ? x[((int64_t)b * F + i) * D + d] : 0.f;
+            gj[e] = ok ? gout[((int64_t)b * P + p) * D + d] * x[((int64_t)b * F + j) * D + d] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = threadIdx.x + k * 256;
+            if (t < D * D) {
+                const int d = t / D, d2 = t - d * D;
+                float sacc = 0.f;
+                for (int r = 0; r < TB; ++r) sacc += xi[r * D + d] * gj[r * D + d2];
+                acc[k] += sacc;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = threadIdx.x + k * 256;
+        if (t < D * D) atomicAdd(&gW[(int64_t)q * D * D + t], acc[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SENET: z[b,f] = mean_d | max_d x[b,f,d]  ;  v[b,f,d] = x[b,f,d] * a[b,f]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_field_pool_fwd(const float* __restrict__ x, int64_t n_fields, int D,
+                                                        int use_max, float* __restrict__ z, int* __restrict__ arg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_fields) return;
+    const float* p = x + t * D;
+    if (use_max) {
+        float m = p[0];
+        int am = 0;
+        for (int d = 1; d < D; ++d)
+            if (p[d] > m) { m = p[d]; am = d; }
+        z[t] = m;
+        if (arg) arg[t] = am;
+    } else {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += p[d];
+        z[t] = s / (float)D;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_field_pool_bwd(const float* __restrict__ gz, const int* __restrict__ arg,
+                                                        int64_t total, int D, int use_max, float* __restrict__ gx) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = t / D;
+        const int d = (int)(t - f * D);
+        gx[t] = use_max ? (arg[f] == d ? gz[f] : 0.f) : gz[f] / (float)D;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_field_scale(const float* __restrict__ x, const float* __restrict__ a,
+                                                     int64_t total, int D, float* __restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = x[t] * a[t / D];
+}
+
+// grad_a[b,f] = sum_d g[b,f,d] x[b,f,d]
+__global__ __launch_bounds__(256) void k_field_scale_bwd_a(const float* __restrict__ x, const float* __restrict__ g,
+                                                           int64_t n_fields, int D, float* __restrict__ ga) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_fields) return;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += g[t * D + d] * x[t * D + d];
+    ga[t] = s;
+}
+
+static int ew_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return b < 1 ? 1 : (int)b;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+static size_t afm_lds_fwd(int F, int D, int H) {
+    const int P = F * (F - 1) / 2;
+    return ((size_t)F * D + (size_t)D * H + 2 * H + P + 8) * sizeof(float) + 2 * (size_t)P * sizeof(short) + 16;
+}
+static size_t afm_lds_bwd(int F, int D, int H) {
+    const int P = F * (F - 1) / 2;
+    return ((size_t)F * D + 2 * (size_t)D * H + 4 * H + D + (size_t)P * H + (size_t)P * D + 8) * sizeof(float) +
+           2 * (size_t)P * sizeof(short) + 16;
+}
+
+extern "C" int dt_afm_fwd(const float* x, const float* Wa, const float* ba, const float* pv, int act, int B, int F,
+                          int D, int H, float* out, float* score, void* stream) {
+    DT_REQUIRE(B >= 0 && F >= 2 && D > 0 && H > 0, "dt_afm_fwd: bad sizes B=%d F=%d D=%d H=%d", B, F, D, H);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && Wa && pv && out, "dt_afm_fwd: null pointer");
+    DT_UNSUPPORTED(H > 64, "dt_afm_fwd: attention factor %d > 64", H);
+    const size_t lds = afm_lds_fwd(F, D, H);
+    DT_UNSUPPORTED(lds > 150 * 1024, "dt_afm_fwd: needs %zu B of LDS", lds);
+    int blocks = B < 2048 ? B : 2048;
+    hipStream_t st = as_stream(stream);
+#define DT_AFM_F(HM)                                                                                          \
+    do {                                                                                                      \
+        hipFuncSetAttribute((const void*)k_afm_fwd<HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_afm_fwd<HM>), dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, act, B, F, D, H, \
+                           out, score);                                                                       \
+    } while (0)
+    if (H <= 16) DT_AFM_F(16); else if (H <= 32) DT_AFM_F(32); else DT_AFM_F(64);
+#undef DT_AFM_F
+    return launch_status("dt_afm_fwd");
+}
+
+extern "C" int dt_afm_bwd(const float* x, const float* Wa, const float* ba, const float* pv, const float* score,
+                          const float* grad_out, int act, int B, int F, int D, int H, float* grad_x,
+                          float* grad_Wa, float* grad_ba, float* grad_pv, void* stream) {
+    DT_REQUIRE(B >= 0 && F >= 2 && D > 0 && H > 0, "dt_afm_bwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && Wa && pv && score && grad_out && grad_x && grad_Wa && grad_pv, "dt_afm_bwd: null pointer");
+    DT_UNSUPPORTED(H > 64, "dt_afm_bwd: attention factor %d > 64", H);
+    const size_t lds = afm_lds_bwd(F, D, H);
+    DT_UNSUPPORTED(lds > 150 * 1024, "dt_afm_bwd: needs %zu B of LDS", lds);
+    int blocks = B < 512 ? B : 512;
+    hipStream_t st = as_stream(stream);
+#define DT_AFM_B(HM)                                                                                          \
+    do {                                                                                                      \
+        hipFuncSetAttribute((const void*)k_afm_bwd<HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_afm_bwd<HM>), dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, score, grad_out,  \
+                           act, B, F, D, H, grad_x, grad_Wa, grad_ba, grad_pv);                               \
+    } while (0)
+    if (H <= 16) DT_AFM_B(16); else if (H <= 32) DT_AFM_B(32); else DT_AFM_B(64);
+#undef DT_AFM_B
+    return launch_status("dt_afm_bwd");
+}
+
+extern "C" int dt_bilinear_fwd(const float* x, const float* W, int wtype, int B, int F, int D, float* out,
+                               void* stream) {
+    DT_REQUIRE(B >= 0 && F >= 2 && D > 0 && wtype >= 0 && wtype <= 2, "dt_bilinear_fwd: bad arguments");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && W && out, "dt_bilinear_fwd: null pointer");
+    const size_t lds = ((size_t)D * D + 2 * 64 * (D + 1)) * sizeof(float);
+    DT_UNSUPPORTED(lds > 64 * 1024, "dt_bilinear_fwd: D=%d too large", D);
+    hipLaunchKernelGGL(k_bilinear_fwd, dim3(ceil_div(B, 64), F * (F - 1) / 2), dim3(64), lds, as_stream(stream), x, W,
+                       wtype, B, F, D, out);
+    return launch_status("dt_bilinear_fwd");
+}
+
+extern "C" int dt_bilinear_bwd(const float* x, const float* W, const float* grad_out, int wtype, int B, int F,
+                               int D, float* grad_x, float* grad_W, void* stream) {
+    DT_REQUIRE(B >= 0 && F >= 2 && D > 0 && wtype >= 0 && wtype <= 2, "dt_bilinear_bwd: bad arguments");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && W && grad_out && grad_x && grad_W, "dt_bilinear_bwd: null pointer");
+    DT_UNSUPPORTED(D > 64, "dt_bilinear_bwd: D=%d > 64", D);
+    hipStream_t st = as_stream(stream);
+    const size_t lds = ((size_t)D * D + 3 * 64 * (D + 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_bilinear_bwd_x, dim3(ceil_div(B, 64), F), dim3(64), lds, st, x, W, grad_out, wtype, B, F, D,
+                       grad_x);
+    int splits = ceil_div(B, 1024);
+    if (splits > 16) splits = 16;
+    const int rps = ceil_div(ceil_div(B, splits), 64) * 64;
+    splits = ceil_div(B, rps);
+    hipLaunchKernelGGL(k_bilinear_bwd_w, dim3(F * (F - 1) / 2, splits), dim3(256), (size_t)2 * 64 * D * sizeof(float), st,
+                       x, grad_out, wtype, B, F, D, rps, grad_W);
+    return launch_status("dt_bilinear_bwd");
+}
+
+extern "C" int dt_field_pool_fwd(const float* x, int B, int F, int D, int use_max, float* z, int* argmax,
+                                 void* stream) {
+    DT_REQUIRE(B >= 0 && F > 0 && D > 0, "dt_field_pool_fwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && z && (!use_max || argmax), "dt_field_pool_fwd: null pointer");
+    const int64_t n = (int64_t)B * F;
+    hipLaunchKernelGGL(k_field_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, D,
+                       use_max, z, argmax);
+    return launch_status("dt_field_pool_fwd");
+}
+
+extern "C" int dt_field_pool_bwd(const float* grad_z, const int* argmax, int B, int F, int D, int use_max,
+                                 float* grad_x, void* stream) {
+    DT_REQUIRE(B >= 0 && F > 0 && D > 0, "dt_field_pool_bwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(grad_z && grad_x && (!use_max || argmax), "dt_field_pool_bwd: null pointer");
+    const int64_t total = (int64_t)B * F * D;
+    hipLaunchKernelGGL(k_field_pool_bwd, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), grad_z, argmax, total,
+                       D, use_max, grad_x);
+    return launch_status("dt_field_pool_bwd");
+}
+
+extern "C" int dt_field_scale_fwd(const float* x, const float* a, int B, int F, int D, float* out, void* stream) {
+    DT_REQUIRE(B >= 0 && F > 0 && D > 0, "dt_field_scale_fwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && a && out, "dt_field_scale_fwd: null pointer");
+    const int64_t total = (int64_t)B * F * D;
+    hipLaunchKernelGGL(k_field_scale, dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), x, a, total, D, out);
+    return launch_status("dt_field_scale_fwd");
+}
+
+extern "C" int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, int B, int F, int D,
+                                  float* grad_x, float* grad_a, void* stream) {
+    DT_REQUIRE(B >= 0 && F > 0 && D > 0, "dt_field_scale_bwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && a && grad_out && grad_x && grad_a, "dt_field_scale_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int64_t total = (int64_t)B * F * D, n = (int64_t)B * F;
+    hipLaunchKernelGGL(k_field_scale, dim3(ew_blocks(total)), dim3(256), 0, st, grad_out, a, total, D, grad_x);
+    hipLaunchKernelGGL(k_field_scale_bwd_a, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, grad_out, n, D,
+                       grad_a);
+    return launch_status("dt_field_scale_bwd");
+}

@@ -7,7 +7,8 @@ construction and returns a tensor (or None to opt out, deepmodel.py:284).
 from inspect import signature
 
 from . import layers
-from ..functional import Dense, Concatenate, Flatten, BatchNormalization, Activation, Dropout, ReduceSum
+from ..functional import Dense, Concatenate, Flatten, BatchNormalization, Activation, Dropout, ReduceSum, Layer
+from ..utils import counter
 
 WideDeep = ['linear', 'dnn_nets']
 DeepFM = ['linear', 'fm_nets', 'dnn_nets']
@@ -167,22 +168,149 @@ def autoint_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, c
     return output
 
 
-def _not_yet(name):
-    def fn(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-        raise NotImplementedError(f'net "{name}" needs layer types outside this round\'s accelerated hot path '
-                                  f'(SURVEY §8 f3: FGCNN / SENET / BilinearInteraction).')
-    fn.__name__ = name
-    return fn
+class _ExpandDims(Layer):
+    """keras.ops.expand_dims(x, -1) (deepnets.py:245)."""
+
+    def compute_output_shape(self, input_shape):
+        return tuple(input_shape) + (1,)
+
+    def call(self, x, **kwargs):
+        return x.unsqueeze(-1)
 
 
-fg_nets = _not_yet('fg_nets')
-fgcnn_cin_nets = _not_yet('fgcnn_cin_nets')
-fgcnn_fm_nets = _not_yet('fgcnn_fm_nets')
-fgcnn_afm_nets = _not_yet('fgcnn_afm_nets')
-fgcnn_ipnn_nets = _not_yet('fgcnn_ipnn_nets')
-fgcnn_dnn_nets = _not_yet('fgcnn_dnn_nets')
-fibi_nets = _not_yet('fibi_nets')
-fibi_dnn_nets = _not_yet('fibi_dnn_nets')
+class _SplitFields(Layer):
+    """keras.ops.split(x, x.shape[1], axis=1) -> list of [B,1,D] (deepnets.py:301,315).  The pieces carry the
+    packed-view tag so the pairwise layers downstream re-stack them for free."""
+
+    def compute_output_shape(self, input_shape):
+        return [(input_shape[0], 1, input_shape[2]) for _ in range(int(input_shape[1]))]
+
+    def call(self, x, **kwargs):
+        x = x.contiguous()
+        outs = []
+        for i in range(x.shape[1]):
+            v = x[:, i:i + 1, :]
+            v._dt_pack = (x, i)
+            outs.append(v)
+        return outs
+
+
+def fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN feature generation: stacked Conv/MaxPool/recombine blocks; output = new features ++ raw
+    embeddings along the field axis (deepnets.py:227-261)."""
+    fgcnn_emb_concat_index = counter.next_num('concat_fgcnn_embedding')
+    fgcnn_emb_concat = _concat_embeddings(embeddings, f'concat_fgcnn_embedding_{fgcnn_emb_concat_index}')
+    if fgcnn_emb_concat is None:
+        model_desc.add_net('fgcnn', (None), (None))
+        return None
+    fg_inputs = _ExpandDims()(fgcnn_emb_concat)
+    fg_filters = config.fgcnn_params.get('fg_filters', (14, 16))
+    fg_heights = config.fgcnn_params.get('fg_heights', (7, 7))
+    fg_pool_heights = config.fgcnn_params.get('fg_pool_heights', (2, 2))
+    fg_new_feat_filters = config.fgcnn_params.get('fg_new_feat_filters', (2, 2))
+    new_features = list()
+    for filters, width, pool, new_filters in zip(fg_filters, fg_heights, fg_pool_heights, fg_new_feat_filters):
+        fg_inputs, new_feats = layers.FGCNN(filters=filters, kernel_height=width, pool_height=pool,
+                                            new_filters=new_filters)(fg_inputs)
+        new_features.append(new_feats)
+    concat_all_features = Concatenate(axis=1)(new_features + [fgcnn_emb_concat])
+    model_desc.add_net('fg', fgcnn_emb_concat.shape, concat_all_features.shape)
+    return concat_all_features
+
+
+def fgcnn_cin_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN with CIN as deep classifier (deepnets.py:264-275)."""
+    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    if fg_output is None:
+        return None
+    cin_output = layers.CIN(params=config.cin_params)(fg_output)
+    model_desc.add_net('fgcnn-cin', fg_output.shape, cin_output.shape)
+    return cin_output
+
+
+def fgcnn_fm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN with FM as deep classifier (deepnets.py:278-289)."""
+    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    if fg_output is None:
+        return None
+    fm_output = layers.FM(name='fm_fgcnn_layer')(fg_output)
+    model_desc.add_net('fgcnn-fm', fg_output.shape, fm_output.shape)
+    return fm_output
+
+
+def fgcnn_afm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN with AFM as deep classifier (deepnets.py:292-303)."""
+    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    if fg_output is None:
+        return None
+    split_features = _SplitFields()(fg_output)
+    afm_output = layers.AFM(params=config.afm_params)(split_features)
+    model_desc.add_net('fgcnn-afm', fg_output.shape, afm_output.shape)
+    return afm_output
+
+
+def fgcnn_ipnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN with IPNN as deep classifier (deepnets.py:306-323)."""
+    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    if fg_output is None:
+        return None
+    split_features = _SplitFields()(fg_output)
+    inner_product = layers.InnerProduct()(split_features)
+    dnn_input_layers = [Flatten()(fg_output), inner_product]
+    if dense_layer is not None:
+        dnn_input_layers.append(dense_layer)
+    dnn_input = Concatenate()(dnn_input_layers)
+    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fgcnn_ipnn')
+    model_desc.add_net('fgcnn-ipnn', fg_output.shape, dnn_out.shape)
+    return dnn_out
+
+
+def fgcnn_dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FGCNN with DNN as deep classifier (deepnets.py:326-341)."""
+    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    if fg_output is None:
+        return None
+    if dense_layer is not None:
+        dnn_input = Concatenate()([Flatten()(fg_output), dense_layer])
+    else:
+        dnn_input = Flatten()(fg_output)
+    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fgcnn_dnn')
+    model_desc.add_net('fgcnn-ipnn', fg_output.shape, dnn_out.shape)
+    return dnn_out
+
+
+def fibi_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FiBiNet: SENET re-weighted embeddings and the raw embeddings each go through a bilinear interaction;
+    the two [B,P,D] blocks are concatenated along the pair axis (deepnets.py:344-371)."""
+    senet_index = counter.next_num('senet_layer')
+    senet_emb_concat = _concat_embeddings(embeddings, f'concat_senet_embedding_{senet_index}')
+    if senet_emb_concat is None:
+        model_desc.add_net('fibi', (None), (None))
+        return None
+    senet_pooling_op = config.fibinet_params.get('senet_pooling_op', 'mean')
+    senet_reduction_ratio = config.fibinet_params.get('senet_reduction_ratio', 3)
+    bilinear_type = config.fibinet_params.get('bilinear_type', 'field_interaction')
+    senet_embedding = layers.SENET(pooling_op=senet_pooling_op, reduction_ratio=senet_reduction_ratio,
+                                   name=f'senet_layer_{senet_index}')(senet_emb_concat)
+    senet_bilinear_out = layers.BilinearInteraction(bilinear_type=bilinear_type,
+                                                    name=f'senet_bilinear_layer_{senet_index}')(senet_embedding)
+    bilinear_out = layers.BilinearInteraction(bilinear_type=bilinear_type,
+                                              name=f'embedding_bilinear_layer_{senet_index}')(senet_emb_concat)
+    concat_bilinear = Concatenate(axis=1, name=f'concat_bilinear_{senet_index}')([senet_bilinear_out, bilinear_out])
+    model_desc.add_net('fibi', senet_emb_concat.shape, concat_bilinear.shape)
+    return concat_bilinear
+
+
+def fibi_dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+    """FiBiNet with DNN as deep classifier (deepnets.py:374-386; like the reference it needs a dense input)."""
+    if embeddings is None or len(embeddings) <= 1:
+        return None
+    fibi_output = fibi_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
+    dnn_input = Concatenate(name='concat_bilinear_dense')(
+        [Flatten(name='flatten_fibi_output')(fibi_output), dense_layer])
+    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fibi_dnn')
+    model_desc.add_net('fibi-dnn', fibi_output.shape, dnn_out.shape)
+    return dnn_out
 
 
 def dnn(x, params, cellname='dnn'):

@@ -440,37 +440,361 @@ class _GroupHolder:
 
 
 # =============================================================================================
-# "next" layer types — present so the registry / net names resolve; they raise until
-# their HIP kernels land, rather than silently running an unaccelerated composition.
+# AFM — layers.py:742-812
 # =============================================================================================
-class _NotYet(Layer):
-    def __init__(self, *args, **kwargs):
-        kwargs = {k: v for k, v in kwargs.items() if k in ('name',)}
+class AFM(Layer):
+    """Attentional FM: pair interactions pooled by a learnt softmax attention, then Dense(1, no bias).
+    The pair loop, attention MLP, softmax and weighted sum run in one HIP kernel (ops.afm_pool)."""
+
+    def __init__(self, params, **kwargs):
+        self.params = params
+        self.hidden_factor = params.get('hidden_factor', 16)
+        self.dropout_rate = params.get('dropout_rate', 0)
+        self.activation_function = params.get('activation', 'relu')
+        self.kernel_regularizer = params.get('kernel_regularizer', None)
         super().__init__(**kwargs)
 
+    def build(self, input_shape):
+        if not isinstance(input_shape, list) or len(input_shape) < 2:
+            raise ValueError('A `AttentionalFM` layer should be called on a list of at least 2 inputs')
+        D = int(input_shape[0][-1])
+        self.dense_attention = Dense(self.hidden_factor, activation=self.activation_function,
+                                     kernel_initializer='glorot_normal', name='dense_afm_attention')
+        self.dense_attention.build((None, D))
+        self.dense_out = Dense(1, use_bias=False, name=f'{self.name}_dense_out')
+        self.dense_out.build((None, D))
+        self.attention_p = self.add_weight(shape=(self.hidden_factor, 1), name='projection_h')
+        self.dropout = Dropout(self.dropout_rate)
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0][0], 1)
+
     def call(self, x, **kwargs):
-        raise NotImplementedError(f'{self.__class__.__name__} is outside the accelerated hot path of this round '
-                                  f'(SURVEY §8 f3); no unaccelerated fallback is provided.')
+        _ndim_check(x[0], 3)
+        if self.activation_function not in ('relu', 'linear', None):
+            raise NotImplementedError(f'AFM activation {self.activation_function!r}: the HIP kernel fuses relu/linear')
+        xs = _stack_fields(x)
+        attention_out = ops.afm_pool(xs, self.dense_attention.kernel, self.dense_attention.bias, self.attention_p,
+                                     self.activation_function)
+        attention_out = self.dropout(attention_out)
+        return self.dense_out(attention_out)
+
+    def get_config(self):
+        c = super().get_config()
+        c['params'] = self.params
+        return c
 
 
-class AFM(_NotYet):
-    pass
+# =============================================================================================
+# SENET — layers.py:245-308
+# =============================================================================================
+class SENET(Layer):
+    def __init__(self, pooling_op='mean', reduction_ratio=3, **kwargs):
+        self.pooling_op = pooling_op
+        self.reduction_ratio = reduction_ratio
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        self.field_num = int(input_shape[1])
+        self.embedding_size = int(input_shape[-1])
+        self.reduction_num = max(self.field_num // self.reduction_ratio, 1)
+        self.dense_att1 = Dense(self.reduction_num, activation='relu', kernel_initializer='he_uniform',
+                                name=f'{self.name}_att1')
+        self.dense_att1.build((None, self.field_num))
+        self.dense_att2 = Dense(self.field_num, activation='relu', kernel_initializer='he_uniform',
+                                name=f'{self.name}_att2')
+        self.dense_att2.build((None, self.reduction_num))
+        self.built = True
+
+    def call(self, x, training=None, **kwargs):
+        _ndim_check(x, 3)
+        Z = ops.field_pool(x, 'max' if self.pooling_op == 'max' else 'mean')
+        A1 = self.dense_att1(Z)
+        A2 = self.dense_att2(A1)
+        return ops.field_scale(x, A2)
+
+    def get_config(self):
+        c = super().get_config()
+        c.update(reduction_ratio=self.reduction_ratio, pooling_op=self.pooling_op)
+        return c
 
 
-class SENET(_NotYet):
-    pass
+# =============================================================================================
+# BilinearInteraction — layers.py:311-382
+# =============================================================================================
+class BilinearInteraction(Layer):
+    """Weights are kept as one stacked tensor `W` [nW, D, D] whose slices are the Keras variables
+    bilinear_weight / bilinear_weight{i} / bilinear_weight{i}_{j} in creation order (layers.py:346-359)."""
+
+    def __init__(self, bilinear_type='field_interaction', **kwargs):
+        self.bilinear_type = bilinear_type
+        super().__init__(**kwargs)
+
+    def weight_names(self):
+        F = self.field_num
+        if self.bilinear_type == 'field_all':
+            return ['bilinear_weight']
+        if self.bilinear_type == 'field_each':
+            return [f'bilinear_weight{i}' for i in range(F - 1)]
+        return [f'bilinear_weight{i}_{j}' for i, j in itertools.combinations(range(F), 2)]
+
+    def build(self, input_shape):
+        D = int(input_shape[-1])
+        self.field_num = int(input_shape[1])
+        n = len(self.weight_names())
+        self.W = nn.Parameter(torch.stack([initialize((D, D), 'glorot_uniform') for _ in range(n)], 0))
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        F = int(input_shape[1])
+        return (input_shape[0], F * (F - 1) // 2, input_shape[-1])
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 3)
+        btype = self.bilinear_type if self.bilinear_type in ('field_all', 'field_each') else 'field_interaction'
+        return ops.bilinear_interaction(x, self.W, btype)
+
+    def get_config(self):
+        c = super().get_config()
+        c['bilinear_type'] = self.bilinear_type
+        return c
 
 
-class BilinearInteraction(_NotYet):
-    pass
+# =============================================================================================
+# FGCNN — layers.py:161-242
+# =============================================================================================
+def _same_pad(size, k, stride):
+    """Keras/TF 'same' padding along one axis -> (out, pad_before, pad_after)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2, total - total // 2
 
 
-class FGCNN(_NotYet):
-    pass
+class FGCNN(Layer):
+    """Feature generation: Conv2D((h,1), same) -> MaxPooling2D((p,1), same) -> Flatten -> Dense recombination.
+    The convolution / pooling are Keras built-ins (not deeptables code) and run on MIOpen through torch; the
+    recombination Dense is the HIP Dense kernel.  Tensors keep the Keras channels-last layout [B,F,D,C] at the
+    layer boundary (Flatten order feeds the Dense weights), kernel stored as Keras [h,1,Cin,Cout]."""
+
+    def __init__(self, filters, kernel_height, new_filters, pool_height, activation='tanh', **kwargs):
+        self.filters = filters
+        self.kernel_height = kernel_height
+        self.new_filters = new_filters
+        self.pool_height = pool_height
+        self.activation = activation
+        super().__init__(**kwargs)
+
+    def build(self, input_shape):
+        _, F, D, C = [None if v is None else int(v) for v in input_shape]
+        self.conv_kernel = self.add_weight('conv2d_kernel', (self.kernel_height, 1, C, self.filters), 'glorot_uniform')
+        self.conv_bias = self.add_weight('conv2d_bias', (self.filters,), 'zeros')
+        Fp = _same_pad(F, self.pool_height, self.pool_height)[0]
+        self.dense_output = Dense(F * D * self.new_filters, activation=self.activation,
+                                  kernel_initializer='glorot_uniform', name=f'{self.name}_dense_output')
+        self.dense_output.build((None, Fp * D * self.filters))
+        self._act = get_activation(self.activation)
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        B, F, D, C = input_shape
+        Fp = _same_pad(int(F), self.pool_height, self.pool_height)[0]
+        return [(B, Fp, int(D), self.filters), (B, int(F) * self.new_filters, int(D))]
+
+    def call(self, x, **kwargs):
+        _ndim_check(x, 4)
+        B, F, D, C = x.shape
+        h = self.kernel_height
+        xc = x.permute(0, 3, 1, 2)                                      # NHWC -> NCHW view
+        _, pb, pa = _same_pad(F, h, 1)
+        xc = torch.nn.functional.pad(xc, (0, 0, pb, pa))
+        out = torch.nn.functional.conv2d(xc, self.conv_kernel.permute(3, 2, 0, 1), self.conv_bias)
+        if self._act is not None:
+            out = self._act(out)
+        ph = self.pool_height
+        _, qb, qa = _same_pad(F, ph, ph)
+        if qb or qa:
+            out_p = torch.nn.functional.pad(out, (0, 0, qb, qa), value=float('-inf'))
+        else:
+            out_p = out
+        pooled = torch.nn.functional.max_pool2d(out_p, (ph, 1), (ph, 1))
+        pooling_output = pooled.permute(0, 2, 3, 1).contiguous()          # back to [B,F',D,filters]
+        new_features = self.dense_output(pooling_output.reshape(B, -1))
+        new_features = new_features.reshape(-1, F * self.new_filters, D)
+        return [pooling_output, new_features]
+
+    def get_config(self):
+        c = super().get_config()
+        c.update(filters=self.filters, kernel_height=self.kernel_height, new_filters=self.new_filters,
+                 pool_height=self.pool_height, activation=self.activation)
+        return c
 
 
-class VarLenColumnEmbedding(_NotYet):
-    pass
+# =============================================================================================
+# VarLenColumnEmbedding — layers.py:925-980
+# =============================================================================================
+class VarLenColumnEmbedding(Layer):
+    """One table shared by the L positions of a multi-valued column: [B,L] ids -> [B,1,L*D].
+    The gather is the same HIP kernel as MultiColumnEmbedding with every 'field' pointing at one table."""
+
+    def __init__(self, emb_vocab_size, emb_output_dim, embeddings_initializer='uniform',
+                 embeddings_regularizer=None, activity_regularizer=None, dropout_rate=0., **kwargs):
+        self.emb_vocab_size = int(emb_vocab_size)
+        self.emb_output_dim = int(emb_output_dim)
+        self.embeddings_initializer = embeddings_initializer
+        self.embeddings_regularizer = embeddings_regularizer
+        self.activity_regularizer = activity_regularizer
+        self.dropout_rate = dropout_rate
+        super().__init__(**kwargs)
+        self.dropout = None
+        self.sparse_grads = {}
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], 1, self.emb_output_dim * int(input_shape[1]))
+
+    def build(self, input_shape=None):
+        L = int(input_shape[1])
+        self.embeddings = nn.Parameter(initialize((self.emb_vocab_size, self.emb_output_dim),
+                                                  self.embeddings_initializer))
+        self.register_buffer('row_offset', torch.zeros(L, dtype=torch.int64))
+        self.register_buffer('vocab', torch.full((L,), self.emb_vocab_size, dtype=torch.int32))
+        self.dropout = SpatialDropout1D(self.dropout_rate, name='var_len_emb_dropout') \
+            if self.dropout_rate > 0 else None
+        self.built = True
+
+    def call(self, inputs, **kwargs):
+        out, _rows = ops.embedding_lookup(inputs, self.embeddings, self.row_offset, self.vocab, dense_grad=True)
+        out = out.reshape(out.shape[0], 1, -1)
+        return self.dropout(out) if self.dropout is not None else out
+
+    def compute_mask(self, inputs, mask=None):
+        return None
+
+    def get_config(self):
+        c = super().get_config()
+        c.update(dropout_rate=self.dropout_rate, embeddings_initializer=self.embeddings_initializer,
+                 embeddings_regularizer=self.embeddings_regularizer, emb_vocab_size=self.emb_vocab_size,
+                 emb_output_dim=self.emb_output_dim)
+        return c
+
+
+# =============================================================================================
+# losses shipped with the layers module — layers.py:983-1163.  Element-wise work on [B, classes]
+# predictions (a few KB per step); expressed with torch ops on the device, no dedicated kernel.
+# =============================================================================================
+K_EPSILON = 1e-7   # keras.backend.epsilon()
+
+
+class _Loss:
+    """keras.losses.Loss protocol: __call__(y_true, y_pred) = reduction(call(...)); AUTO = mean over the batch."""
+
+    def __init__(self, reduction='auto', name=None):
+        self.reduction = reduction
+        self.name = name
+        self.__name__ = name or self.__class__.__name__
+
+    def __call__(self, y_true, y_pred):
+        v = self.call(y_true, y_pred)
+        if self.reduction in ('none', None):
+            return v
+        if self.reduction == 'sum':
+            return v.sum()
+        return v.mean()
+
+    def get_config(self):
+        return {'reduction': self.reduction, 'name': self.name}
+
+
+class BinaryFocalLoss(_Loss):
+    """FL(p_t) = -alpha (1-p_t)^gamma log(p_t) on sigmoid probabilities (layers.py:983-1024)."""
+
+    def __init__(self, gamma=2., alpha=.25, reduction='auto', name='focal_loss'):
+        super().__init__(reduction=reduction, name=name)
+        self.gamma = float(gamma)
+        self.alpha = float(alpha)
+
+    def call(self, y_true, y_pred):
+        y_true = y_true.reshape(y_pred.shape).to(y_pred.dtype)
+        pt_1 = torch.where(y_true == 1, y_pred, torch.ones_like(y_pred))
+        pt_0 = torch.where(y_true == 0, y_pred, torch.zeros_like(y_pred))
+        pt_1 = pt_1.clamp(K_EPSILON, 1. - K_EPSILON)
+        pt_0 = pt_0.clamp(K_EPSILON, 1. - K_EPSILON)
+        return -(self.alpha * (1. - pt_1) ** self.gamma * torch.log(pt_1)).mean() \
+            - ((1 - self.alpha) * pt_0 ** self.gamma * torch.log(1. - pt_0)).mean()
+
+    def get_config(self):
+        return dict(super().get_config(), gamma=self.gamma, alpha=self.alpha)
+
+
+class CategoricalFocalLoss(_Loss):
+    """Softmax focal loss, summed over classes per sample (layers.py:1027-1081)."""
+
+    def __init__(self, gamma=2., alpha=.25, reduction='auto', name='focal_loss'):
+        super().__init__(reduction=reduction, name=name)
+        self.gamma = float(gamma)
+        self.alpha = float(alpha)
+
+    def call(self, y_true, y_pred):
+        y_true = y_true.to(y_pred.dtype)
+        y_pred = y_pred / y_pred.sum(-1, keepdim=True)
+        y_pred = y_pred.clamp(K_EPSILON, 1. - K_EPSILON)
+        cross_entropy = -y_true * torch.log(y_pred)
+        loss = self.alpha * (1. - y_pred) ** self.gamma * cross_entropy
+        return loss.sum(1)
+
+    def get_config(self):
+        return dict(super().get_config(), gamma=self.gamma, alpha=self.alpha)
+
+
+class GHMCLoss:
+    """Gradient Harmonising Mechanism (classification) loss on logits with a momentum-smoothed histogram of
+    gradient lengths (layers.py:1084-1163)."""
+
+    def __init__(self, bins=10, momentum=0.75):
+        self.bins = bins
+        self.momentum = momentum
+        self.edges_left, self.edges_right = self.get_edges(self.bins)
+        if momentum > 0:
+            self.acc_sum = self.get_acc_sum(self.bins)
+
+    def get_edges(self, bins):
+        edges_left = torch.tensor([float(x) / bins for x in range(bins)], dtype=torch.float32).reshape(bins, 1, 1)
+        right = [float(x) / bins for x in range(1, bins + 1)]
+        right[-1] += 1e-6
+        edges_right = torch.tensor(right, dtype=torch.float32).reshape(bins, 1, 1)
+        return edges_left, edges_right
+
+    def get_acc_sum(self, bins):
+        return torch.zeros(bins, dtype=torch.float32)
+
+    def calc(self, input, target, mask=None, is_mask=False):
+        dev = input.device
+        target = target.reshape(input.shape).to(input.dtype)
+        edges_left, edges_right = self.edges_left.to(dev), self.edges_right.to(dev)
+        mmt = self.momentum
+        self.g = (torch.sigmoid(input) - target).abs().detach()
+        g = self.g.unsqueeze(0)
+        in_bin = (g >= edges_left) & (g < edges_right)                      # [bins, B, C]
+        if is_mask:
+            mask_pos = mask > 0
+            inds = (in_bin & mask_pos).to(torch.float32)
+            tot = torch.clamp(mask_pos.to(torch.float32).sum(), min=1.0)
+        else:
+            inds = in_bin.to(torch.float32)
+            tot = torch.tensor(max(float(input.shape[0] * input.shape[1]), 1.0), device=dev)
+        num_in_bin = inds.sum(dim=(1, 2))
+        nonempty = num_in_bin > 0
+        num_valid_bin = nonempty.to(torch.float32).sum()
+        if mmt > 0:
+            self.acc_sum = torch.where(nonempty, mmt * self.acc_sum.to(dev) + (1 - mmt) * num_in_bin,
+                                       self.acc_sum.to(dev))
+            denom = self.acc_sum.reshape(-1, 1, 1)
+        else:
+            denom = num_in_bin.reshape(-1, 1, 1)
+        weights = torch.where(inds == 1, tot / denom, torch.zeros_like(inds)).sum(0)
+        weights = weights / num_valid_bin
+        loss = torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-input.abs()))
+        return (loss * weights).sum() / tot
 
 
 # =============================================================================================
@@ -497,4 +821,7 @@ dt_custom_objects = {
     'Cross': Cross,
     'InnerProduct': InnerProduct,
     'OuterProduct': OuterProduct,
+    'VarLenColumnEmbedding': VarLenColumnEmbedding,
+    'CategoricalFocalLoss': CategoricalFocalLoss,
+    'BinaryFocalLoss': BinaryFocalLoss,
 }

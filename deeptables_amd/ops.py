@@ -444,3 +444,141 @@ def dense(x, W, bias=None, activation=None):
     """y = act(x @ W + bias) with act in {None/'linear', 'relu'} on the HIP Dense kernels."""
     act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}[activation]
     return _Dense.apply(x, W, bias, act)
+
+
+# ------------------------------------------------------------------------------------------------
+# AFM attention pooling — AFM.call layers.py:789-807
+# ------------------------------------------------------------------------------------------------
+class _AfmPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wa, ba, pv, act):
+        require_cuda(x, Wa)
+        x, Wa, pv = _f32c(x), _f32c(Wa), _f32c(pv).reshape(-1)
+        ba_c = None if ba is None else _f32c(ba)
+        B, F, D = x.shape
+        H = Wa.shape[1]
+        out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        score = torch.empty((B, F * (F - 1) // 2), dtype=torch.float32, device=x.device)
+        check(lib().dt_afm_fwd(ptr(x), ptr(Wa), ptr(ba_c), ptr(pv), act, B, F, D, H, ptr(out), ptr(score),
+                               stream_ptr()), 'dt_afm_fwd')
+        ctx.save_for_backward(x, Wa, pv, score, *([] if ba_c is None else [ba_c]))
+        ctx.act, ctx.pv_shape = act, pv.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wa, pv, score, *rest = ctx.saved_tensors
+        ba = rest[0] if rest else None
+        B, F, D = x.shape
+        H = Wa.shape[1]
+        gx = torch.empty_like(x)
+        gWa = torch.zeros_like(Wa)
+        gba = None if ba is None else torch.zeros_like(ba)
+        gpv = torch.zeros_like(pv)
+        check(lib().dt_afm_bwd(ptr(x), ptr(Wa), ptr(ba), ptr(pv), ptr(score), ptr(_f32c(g)), ctx.act, B, F, D, H,
+                               ptr(gx), ptr(gWa), ptr(gba), ptr(gpv), stream_ptr()), 'dt_afm_bwd')
+        return gx, gWa, gba, gpv, None
+
+
+def afm_pool(x, Wa, ba, pv, activation='relu'):
+    """x [B,F,D] -> attention-pooled pair interactions [B,D]; Wa [D,H], ba [H]|None, pv [H] or [H,1]."""
+    act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}[activation]
+    return _AfmPool.apply(x, Wa, ba, pv.reshape(-1), act)
+
+
+# ------------------------------------------------------------------------------------------------
+# BilinearInteraction — layers.py:363-377
+# ------------------------------------------------------------------------------------------------
+BILINEAR_TYPES = {'field_interaction': 0, 'field_each': 1, 'field_all': 2}
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, wtype):
+        require_cuda(x, W)
+        x, W = _f32c(x), _f32c(W)
+        B, F, D = x.shape
+        out = torch.empty((B, F * (F - 1) // 2, D), dtype=torch.float32, device=x.device)
+        check(lib().dt_bilinear_fwd(ptr(x), ptr(W), wtype, B, F, D, ptr(out), stream_ptr()), 'dt_bilinear_fwd')
+        ctx.save_for_backward(x, W)
+        ctx.wtype = wtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        B, F, D = x.shape
+        gx = torch.empty_like(x)
+        gW = torch.zeros_like(W)
+        check(lib().dt_bilinear_bwd(ptr(x), ptr(W), ptr(_f32c(g)), ctx.wtype, B, F, D, ptr(gx), ptr(gW),
+                                    stream_ptr()), 'dt_bilinear_bwd')
+        return gx, gW, None
+
+
+def bilinear_interaction(x, W, bilinear_type='field_interaction'):
+    """x [B,F,D], W [nW,D,D] (nW = P | F-1 | 1) -> [B,P,D]."""
+    F, D = x.shape[1], x.shape[2]
+    wtype = BILINEAR_TYPES[bilinear_type]
+    need = {0: F * (F - 1) // 2, 1: F - 1, 2: 1}[wtype]
+    if tuple(W.shape) != (need, D, D):
+        raise ValueError(f'bilinear_interaction: W must be [{need},{D},{D}] for {bilinear_type}, got {tuple(W.shape)}')
+    return _Bilinear.apply(x, W, wtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# SENET squeeze + re-weight — layers.py:291-302
+# ------------------------------------------------------------------------------------------------
+class _FieldPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, use_max):
+        require_cuda(x)
+        x = _f32c(x)
+        B, F, D = x.shape
+        z = torch.empty((B, F), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, F), dtype=torch.int32, device=x.device) if use_max else None
+        check(lib().dt_field_pool_fwd(ptr(x), B, F, D, use_max, ptr(z), ptr(arg), stream_ptr()), 'dt_field_pool_fwd')
+        ctx.shape, ctx.use_max = (B, F, D), use_max
+        if use_max:
+            ctx.save_for_backward(arg)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        B, F, D = ctx.shape
+        arg = ctx.saved_tensors[0] if ctx.use_max else None
+        gz = _f32c(gz)
+        gx = torch.empty((B, F, D), dtype=torch.float32, device=gz.device)
+        check(lib().dt_field_pool_bwd(ptr(gz), ptr(arg), B, F, D, ctx.use_max, ptr(gx), stream_ptr()),
+              'dt_field_pool_bwd')
+        return gx, None
+
+
+def field_pool(x, pooling_op='mean'):
+    return _FieldPool.apply(x, 1 if pooling_op == 'max' else 0)
+
+
+class _FieldScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        require_cuda(x, a)
+        x, a = _f32c(x), _f32c(a)
+        B, F, D = x.shape
+        out = torch.empty_like(x)
+        check(lib().dt_field_scale_fwd(ptr(x), ptr(a), B, F, D, ptr(out), stream_ptr()), 'dt_field_scale_fwd')
+        ctx.save_for_backward(x, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a = ctx.saved_tensors
+        B, F, D = x.shape
+        gx = torch.empty_like(x)
+        ga = torch.empty_like(a)
+        check(lib().dt_field_scale_bwd(ptr(x), ptr(a), ptr(_f32c(g)), B, F, D, ptr(gx), ptr(ga), stream_ptr()),
+              'dt_field_scale_bwd')
+        return gx, ga
+
+
+def field_scale(x, a):
+    """x [B,F,D] * a [B,F,1|None]."""
+    return _FieldScale.apply(x, a.reshape(x.shape[0], x.shape[1]))

@@ -1,1 +1,1 @@
-from . import consts  # noqa: F401
+from . import consts, counter  # noqa: F401

@@ -205,6 +205,36 @@ int dt_dense_fwd(const float* x, const float* W, const float* bias, int act, int
 int dt_dense_bwd(const float* x, const float* W, const float* y, const float* grad_y, int act, int N, int K,
                  int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
 
+/* ---- f3: AFM attention pooling (AFM.call layers.py:789-807) ---------------------------------------- *
+ * x [B,F,D]; P = F(F-1)/2 pairs in itertools.combinations order (layers.py:790-795).
+ *   bi[p] = x_i*x_j ; a = act(bi . Wa [D,H] + ba [H]|NULL) (dense_attention, layers.py:776-778) ;
+ *   score = softmax_p(a . pv [H]) (layers.py:799-800) ; out [B,D] = sum_p score[p] bi[p] (layers.py:801).
+ * score [B,P] is saved for the backward.  The trailing Dropout + Dense(1) (layers.py:803-806) are host
+ * layers.  Parameter gradients are ACCUMULATED (zero them first).                                      */
+int dt_afm_fwd(const float* x, const float* Wa, const float* ba, const float* pv, int act, int B, int F, int D,
+               int H, float* out, float* score, void* stream);
+int dt_afm_bwd(const float* x, const float* Wa, const float* ba, const float* pv, const float* score,
+               const float* grad_out, int act, int B, int F, int D, int H, float* grad_x, float* grad_Wa,
+               float* grad_ba, float* grad_pv, void* stream);
+
+/* ---- f3: BilinearInteraction (FiBiNet; layers.py:363-377) --------------------------------------- *
+ * out [B,P,D]: out[b,p,:] = (x_i . W_q) * x_j with W [nW,D,D]:
+ *   wtype 0 'field_interaction' q = p (nW = P), 1 'field_each' q = i (nW = F-1, layers.py:352-354),
+ *   2 'field_all' q = 0 (nW = 1).  grad_W is ACCUMULATED.                                              */
+int dt_bilinear_fwd(const float* x, const float* W, int wtype, int B, int F, int D, float* out, void* stream);
+int dt_bilinear_bwd(const float* x, const float* W, const float* grad_out, int wtype, int B, int F, int D,
+                    float* grad_x, float* grad_W, void* stream);
+
+/* ---- f3: SENET squeeze / re-weight (layers.py:291-302) --------------------------------------------- *
+ * pool: z [B,F] = mean_d x (use_max 0) | max_d x (use_max 1, argmax [B,F] saved: first maximum wins, as
+ * the gradient of tf.reduce_max on ties is not used by the parity tests); scale: out = x * a[:, :, None]. */
+int dt_field_pool_fwd(const float* x, int B, int F, int D, int use_max, float* z, int* argmax, void* stream);
+int dt_field_pool_bwd(const float* grad_z, const int* argmax, int B, int F, int D, int use_max, float* grad_x,
+                      void* stream);
+int dt_field_scale_fwd(const float* x, const float* a, int B, int F, int D, float* out, void* stream);
+int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, int B, int F, int D, float* grad_x,
+                       float* grad_a, void* stream);
+
 /* ---- fused DeepFM train step (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) ------------- *
  * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
  * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,

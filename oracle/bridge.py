@@ -42,6 +42,9 @@ def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
         w['dnn'] = dnn('dnn')
     if 'dcn_dense_1' in L:
         w['dcn_dnn'] = dnn('dcn')
+    for cell in ('fibi_dnn', 'fgcnn_dnn', 'fgcnn_ipnn'):
+        if f'{cell}_dense_1' in L:
+            w[cell] = dnn(cell)
     for name, layer in L.items():
         if name.startswith('dense_logit_'):
             w[name] = g(layer.kernel)
@@ -53,6 +56,24 @@ def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
         elif cls == 'Cross' and name == 'dcn_cross_layer':
             w['dcn_cross_kernels'] = [g(k) for k in layer.kernels]
             w['dcn_cross_bias'] = [g(b) for b in layer.bias]
+        elif cls == 'AFM':
+            da = layer.dense_attention
+            w.setdefault('afm', []).append({
+                'att_kernel': g(da.kernel), 'att_bias': None if da.bias is None else g(da.bias),
+                'projection_h': g(layer.attention_p), 'out_kernel': g(layer.dense_out.kernel),
+                'activation': layer.activation_function})
+        elif cls == 'SENET':
+            w.setdefault('senet', []).append({
+                'att1': (g(layer.dense_att1.kernel), g(layer.dense_att1.bias)),
+                'att2': (g(layer.dense_att2.kernel), g(layer.dense_att2.bias))})
+        elif cls == 'BilinearInteraction':
+            Wg = g(layer.W)
+            key = 'senet' if name.startswith('senet_bilinear') else 'embedding'
+            w.setdefault('bilinear', {})[key] = Wg          # [nW,D,D], slices in creation order
+        elif cls == 'FGCNN':
+            w.setdefault('fgcnn', []).append({
+                'conv_kernel': g(layer.conv_kernel), 'conv_bias': g(layer.conv_bias),
+                'dense_kernel': g(layer.dense_output.kernel), 'dense_bias': g(layer.dense_output.bias)})
         elif cls == 'MultiheadAttention':
             w.setdefault('autoint_layers', []).append({
                 'Q': (g(layer.dense_Q.kernel), g(layer.dense_Q.bias)),
@@ -69,8 +90,8 @@ def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
 
 def oracle_config(dm):
     c = dm.config
-    return {'cin_params': c.cin_params, 'autoint_params': c.autoint_params,
-            'dnn_activation': c.dnn_params.get('activation', 'relu')}
+    return {'cin_params': c.cin_params, 'autoint_params': c.autoint_params, 'fibinet_params': c.fibinet_params,
+            'fgcnn_params': c.fgcnn_params, 'dnn_activation': c.dnn_params.get('activation', 'relu')}
 
 
 def oracle_forward(dm, cat, dense, dtype=torch.float64, training=True, weights=None):

@@ -309,6 +309,58 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
                 o = multihead_attention(o, lw, ap.get('num_heads', 1), ap.get('use_residual', True),
                                         training=training)
             outs[net] = o.reshape(o.shape[0], -1)
+        elif net == 'afm_nets':                                      # deepnets.py:99-107
+            a = weights['afm'][0]
+            outs[net] = afm(embeddings, a['att_kernel'], a['att_bias'], a['projection_h'], a['out_kernel'],
+                            a.get('activation', 'relu'))
+        elif net in ('fibi_nets', 'fibi_dnn_nets'):                  # deepnets.py:344-386
+            fp = config.get('fibinet_params', {})
+            e = torch.cat(embeddings, dim=1)
+            se = weights['senet'][0]
+            senet_embedding = senet(e, se['att1'], se['att2'], fp.get('senet_pooling_op', 'mean'))
+            btype = fp.get('bilinear_type', 'field_interaction')
+            Ws, We = weights['bilinear']['senet'], weights['bilinear']['embedding']
+            senet_bilinear_out = bilinear_interaction(senet_embedding, [Ws[i] for i in range(Ws.shape[0])], btype)
+            bilinear_out = bilinear_interaction(e, [We[i] for i in range(We.shape[0])], btype)
+            fibi = torch.cat([senet_bilinear_out, bilinear_out], dim=1)
+            if net == 'fibi_nets':
+                outs[net] = fibi
+            else:
+                outs[net] = dnn(torch.cat([fibi.reshape(fibi.shape[0], -1), dense], dim=-1), weights['fibi_dnn'],
+                                config.get('dnn_activation', 'relu'))
+        elif net.startswith('fgcnn_'):                               # deepnets.py:227-341
+            gp = config.get('fgcnn_params', {})
+            e = torch.cat(embeddings, dim=1)
+            fg_inputs = e.unsqueeze(-1)
+            new_features = []
+            for lw, pool, nf in zip(weights['fgcnn'], gp.get('fg_pool_heights', (2, 2)),
+                                    gp.get('fg_new_feat_filters', (2, 2))):
+                fg_inputs, nfeat = fgcnn(fg_inputs, lw['conv_kernel'], lw['conv_bias'], lw['dense_kernel'],
+                                         lw['dense_bias'], pool, nf)
+                new_features.append(nfeat)
+            fg_output = torch.cat(new_features + [e], dim=1)
+            flat = fg_output.reshape(fg_output.shape[0], -1)
+            if net == 'fgcnn_fm_nets':
+                outs[net] = fm(fg_output)
+            elif net == 'fgcnn_cin_nets':
+                cp = config['cin_params']
+                outs[net] = cin(fg_output, weights['cin_filters'], weights.get('cin_bias'), cp['cross_layer_size'],
+                                cp.get('activation', 'relu'), cp.get('direct', False),
+                                dense_out=weights['cin_exFM_out'])
+            elif net == 'fgcnn_afm_nets':
+                a = weights['afm'][0]
+                outs[net] = afm(list(torch.split(fg_output, 1, dim=1)), a['att_kernel'], a['att_bias'],
+                                a['projection_h'], a['out_kernel'], a.get('activation', 'relu'))
+            elif net == 'fgcnn_ipnn_nets':
+                parts = [flat, inner_product(list(torch.split(fg_output, 1, dim=1)))]
+                if dense is not None:
+                    parts.append(dense)
+                outs[net] = dnn(torch.cat(parts, dim=-1), weights['fgcnn_ipnn'], config.get('dnn_activation', 'relu'))
+            elif net == 'fgcnn_dnn_nets':
+                x_in = torch.cat([flat, dense], dim=-1) if dense is not None else flat
+                outs[net] = dnn(x_in, weights['fgcnn_dnn'], config.get('dnn_activation', 'relu'))
+            else:
+                raise ValueError(net)
         else:
             raise ValueError(net)
     if len(outs) > 1:                                                # :286-297
@@ -330,6 +382,143 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
     if return_parts:
         return logit, prob, outs, concat_emb_dense
     return logit, prob
+
+
+# ---------------------------------------------------------------------------------------------
+# layers.py — the f3 layer types (AFM, SENET, BilinearInteraction, FGCNN, VarLenColumnEmbedding, losses)
+# ---------------------------------------------------------------------------------------------
+def afm(xs, att_kernel, att_bias, projection_h, out_kernel, activation='relu'):
+    """AFM.call — layers.py:786-807.  xs: list of F tensors [B,1,D]; att_kernel [D,H] (dense_afm_attention),
+    projection_h [H,1], out_kernel [D,1] (Dense(1, use_bias=False)); dropout_rate 0."""
+    row, col = [], []
+    for r, c in itertools.combinations(xs, 2):                        # :792-794
+        row.append(r)
+        col.append(c)
+    p = torch.cat(row, dim=1)                                          # :795
+    q = torch.cat(col, dim=1)                                          # :796
+    bi_interaction = p * q                                             # :797
+    attention_2 = bi_interaction @ att_kernel                          # :799 Dense(hidden_factor, activation)
+    if att_bias is not None:
+        attention_2 = attention_2 + att_bias
+    act = _activation(activation)
+    if act is not None:
+        attention_2 = act(attention_2)
+    attention_score = torch.softmax(torch.tensordot(attention_2, projection_h, dims=([-1], [0])), dim=1)   # :800
+    attention_out = torch.sum(attention_score * bi_interaction, dim=1)  # :801
+    return attention_out @ out_kernel                                   # :803
+
+
+def senet(x, att1, att2, pooling_op='mean'):
+    """SENET.call — layers.py:291-302.  att1/att2 = (kernel, bias) of the two relu Dense layers."""
+    if pooling_op == 'max':
+        Z = torch.max(x, dim=-1).values                                # :296
+    else:
+        Z = torch.mean(x, dim=-1)                                      # :298
+    A1 = torch.relu(Z @ att1[0] + att1[1])                             # :299
+    A2 = torch.relu(A1 @ att2[0] + att2[1])                            # :300
+    return x * A2.unsqueeze(2)                                         # :301
+
+
+def bilinear_interaction(x, W_list, bilinear_type='field_interaction'):
+    """BilinearInteraction.call — layers.py:363-377.  W_list: list of [D,D] in creation order
+    (field_all: 1, field_each: F-1, field_interaction: one per pair)."""
+    F = x.shape[1]
+    xs = list(torch.split(x, 1, dim=1))                                # :366
+    if bilinear_type == 'field_all':
+        p = [torch.tensordot(v_i, W_list[0], dims=([-1], [0])) * v_j for v_i, v_j in itertools.combinations(xs, 2)]
+    elif bilinear_type == 'field_each':
+        p = [torch.tensordot(xs[i], W_list[i], dims=([-1], [0])) * xs[j]
+             for i, j in itertools.combinations(range(F), 2)]
+    else:
+        p = [torch.tensordot(v[0], w, dims=([-1], [0])) * v[1]
+             for v, w in zip(itertools.combinations(xs, 2), W_list)]
+    return torch.cat(p, dim=1)                                         # :375
+
+
+def _same_pad_1d(size, k, stride):
+    """TF 'SAME' padding: out = ceil(size/stride); total = max((out-1)*stride + k - size, 0); before = total//2."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def fgcnn(x, conv_kernel, conv_bias, dense_kernel, dense_bias, pool_height, new_filters, activation='tanh'):
+    """FGCNN.call — layers.py:220-230.  x [B,F,D,C] channels-last; conv_kernel [h,1,C,filters] (Keras layout),
+    Conv2D(strides 1, padding 'same', activation) -> MaxPooling2D((pool,1), padding 'same', stride = pool) ->
+    Flatten (channels-last order) -> Dense(F*D*new_filters, activation) -> reshape [B, F*new_filters, D]."""
+    B, F, D, C = x.shape
+    h = conv_kernel.shape[0]
+    act = _activation(activation)
+    _, pb, pa = _same_pad_1d(F, h, 1)
+    xp = torch.nn.functional.pad(x, (0, 0, 0, 0, pb, pa))              # zero-pad the field axis
+    # explicit correlation: out[b,f,d,o] = sum_{t,c} xp[b,f+t,d,c] k[t,0,c,o] + bias[o]
+    out = torch.zeros(B, F, D, conv_kernel.shape[3], dtype=x.dtype)
+    for t in range(h):
+        out = out + torch.einsum('bfdc,co->bfdo', xp[:, t:t + F], conv_kernel[t, 0])
+    out = out + conv_bias
+    if act is not None:
+        out = act(out)
+    Fp, qb, qa = _same_pad_1d(F, pool_height, pool_height)
+    outp = torch.nn.functional.pad(out, (0, 0, 0, 0, qb, qa), value=float('-inf'))
+    pooled = torch.stack([outp[:, i * pool_height:(i + 1) * pool_height].max(dim=1).values for i in range(Fp)],
+                         dim=1)                                        # [B,Fp,D,filters]
+    new_features = pooled.reshape(B, -1) @ dense_kernel + dense_bias   # :226-227
+    if act is not None:
+        new_features = act(new_features)
+    new_features = new_features.reshape(-1, F * new_filters, D)        # :228-229
+    return pooled, new_features
+
+
+def var_len_embedding(inputs, table):
+    """VarLenColumnEmbedding.call — layers.py:961-968 (dropout 0): Embedding then reshape [B,1,L*D]."""
+    idx = inputs.to(torch.int64)
+    e = table[idx]                                                     # [B,L,D]
+    return e.reshape(e.shape[0], 1, -1)
+
+
+K_EPSILON = 1e-7
+
+
+def binary_focal_loss(y_true, y_pred, gamma=2., alpha=.25):
+    """BinaryFocalLoss.call — layers.py:1006-1017."""
+    pt_1 = torch.where(y_true == 1, y_pred, torch.ones_like(y_pred))
+    pt_0 = torch.where(y_true == 0, y_pred, torch.zeros_like(y_pred))
+    pt_1 = torch.clamp(pt_1, K_EPSILON, 1. - K_EPSILON)
+    pt_0 = torch.clamp(pt_0, K_EPSILON, 1. - K_EPSILON)
+    return -torch.mean(alpha * torch.pow(1. - pt_1, gamma) * torch.log(pt_1)) \
+        - torch.mean((1 - alpha) * torch.pow(pt_0, gamma) * torch.log(1. - pt_0))
+
+
+def categorical_focal_loss(y_true, y_pred, gamma=2., alpha=.25):
+    """CategoricalFocalLoss.call — layers.py:1062-1076 (per-sample; Keras AUTO reduction then means)."""
+    y_pred = y_pred / torch.sum(y_pred, dim=-1, keepdim=True)
+    y_pred = torch.clamp(y_pred, K_EPSILON, 1. - K_EPSILON)
+    cross_entropy = -y_true * torch.log(y_pred)
+    loss = alpha * torch.pow(1. - y_pred, gamma) * cross_entropy
+    return torch.sum(loss, dim=1)
+
+
+def ghmc_loss(input, target, acc_sum, bins=10, momentum=0.75):
+    """GHMCLoss.calc (is_mask False) — layers.py:1111-1162.  Returns (loss, updated acc_sum)."""
+    edges_left = torch.tensor([float(x) / bins for x in range(bins)], dtype=input.dtype).reshape(bins, 1, 1)
+    right = [float(x) / bins for x in range(1, bins + 1)]
+    right[-1] += 1e-6
+    edges_right = torch.tensor(right, dtype=input.dtype).reshape(bins, 1, 1)
+    g = torch.abs(torch.sigmoid(input) - target).detach().unsqueeze(0)
+    inds = ((g >= edges_left) & (g < edges_right)).to(input.dtype)
+    tot = max(float(input.shape[0] * input.shape[1]), 1.0)
+    num_in_bin = inds.sum(dim=(1, 2))
+    nonempty = num_in_bin > 0
+    num_valid_bin = nonempty.to(input.dtype).sum()
+    if momentum > 0:
+        acc_sum = torch.where(nonempty, momentum * acc_sum + (1 - momentum) * num_in_bin, acc_sum)
+        denom = acc_sum.reshape(-1, 1, 1) + torch.zeros_like(inds)
+    else:
+        denom = num_in_bin.reshape(-1, 1, 1) + torch.zeros_like(inds)
+    weights = torch.where(inds == 1, tot / denom, torch.zeros_like(inds)).sum(0)
+    weights = weights / num_valid_bin
+    loss = torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+    return torch.sum(loss * weights) / tot, acc_sum
 
 
 def binary_crossentropy_from_logits(logit, y):
