@@ -32,7 +32,7 @@ class FusedDeepFM:
     def eligible(cls, dm):
         c = dm.config
         try:
-            if set(c.nets) != cls.NETS or len(c.nets) != 3:
+            if set(c.nets) != cls.NETS or len(c.nets) != 3 or dm.var_len_categorical_columns:
                 return False
             if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
                 return False

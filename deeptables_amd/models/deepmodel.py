@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import deepnets
-from .layers import MultiColumnEmbedding, dt_custom_objects
+from .layers import MultiColumnEmbedding, VarLenColumnEmbedding, dt_custom_objects
 from .. import functional as F
 from .. import training
 from ..functional import Dense, Concatenate, Flatten, Input, Add, BatchNormalization, Dropout, Model
@@ -42,9 +42,6 @@ class DeepModel:
         self.model = None
         self.optimizer = None
         self.device = None
-        if var_categorical_len_columns:
-            raise NotImplementedError('VarLenCategoricalColumn inputs are outside this round\'s hot path '
-                                      '(SURVEY §8 f3).')
         if model_file is not None:
             objs = dict(dt_custom_objects)
             if custom_objects is not None:
@@ -57,15 +54,19 @@ class DeepModel:
     def build(self, device=None):
         self.device = device or default_device()
         self.model = self._build_model(self.task, self.num_classes, self.config.nets, self.categorical_columns,
-                                       self.continuous_columns, self.config).to(self.device)
+                                       self.continuous_columns, self.config,
+                                       self.var_len_categorical_columns).to(self.device)
         self._compile_model(self.model, self.task, self.num_classes, self.config.optimizer, self.config.loss)
         return self.model
 
-    def _build_model(self, task, num_classes, nets, categorical_columns, continuous_columns, config):
+    def _build_model(self, task, num_classes, nets, categorical_columns, continuous_columns, config,
+                     var_len_categorical_columns=None):
         F.reset_uids()
         self.model_desc = ModelDesc()
-        categorical_inputs, continuous_inputs = self._build_inputs(categorical_columns, continuous_columns)
-        embeddings = self._build_embeddings(categorical_columns, categorical_inputs, config.embedding_dropout)
+        categorical_inputs, continuous_inputs, var_len_categorical_inputs = \
+            self._build_inputs(categorical_columns, continuous_columns, var_len_categorical_columns)
+        embeddings = self._build_embeddings(categorical_columns, categorical_inputs, var_len_categorical_columns,
+                                            var_len_categorical_inputs, config.embedding_dropout)
         dense_layer = self._build_denses(continuous_columns, continuous_inputs, config.dense_dropout)
 
         flatten_emb_layer = None
@@ -108,7 +109,8 @@ class DeepModel:
             x = out
         else:
             raise ValueError(f'Unexpected logit output.{outs}')
-        all_inputs = list(categorical_inputs.values()) + list(continuous_inputs.values())
+        all_inputs = list(categorical_inputs.values()) + list(var_len_categorical_inputs.values()) + \
+            list(continuous_inputs.values())                          # deepmodel.py:310
         output = self._output_layer(x, task, num_classes, use_bias=self.config.output_use_bias)
         return Model(inputs=all_inputs, outputs=output)
 
@@ -146,9 +148,10 @@ class DeepModel:
         self.model_desc.set_concat_embed_dense(x.shape)
         return x
 
-    def _build_inputs(self, categorical_columns, continuous_columns):
+    def _build_inputs(self, categorical_columns, continuous_columns, var_len_categorical_columns=None):
         categorical_inputs = OrderedDict()
         continuous_inputs = OrderedDict()
+        var_len_categorical_inputs = OrderedDict()
         if categorical_columns is not None and len(categorical_columns) > 0:
             categorical_inputs['all_categorical_vars'] = Input(shape=(len(categorical_columns),),
                                                                name='input_categorical_vars_all')
@@ -156,18 +159,30 @@ class DeepModel:
         for column in continuous_columns or []:
             continuous_inputs[column.name] = Input(shape=(column.input_dim,), name=column.name, dtype=column.dtype)
             self.model_desc.add_input(column.name, column.input_dim)
-        return categorical_inputs, continuous_inputs
+        for col in var_len_categorical_columns or []:                 # deepmodel.py:375-378
+            var_len_categorical_inputs[col.name] = Input(shape=(col.max_elements_length,), name=col.name)
+            self.model_desc.add_input(col.name, col.max_elements_length)
+        return categorical_inputs, continuous_inputs, var_len_categorical_inputs
 
-    def _build_embeddings(self, categorical_columns, categorical_inputs, embedding_dropout):
-        if 'all_categorical_vars' not in categorical_inputs:
-            return []
-        input_layer = categorical_inputs['all_categorical_vars']
-        input_dims = [column.vocabulary_size for column in categorical_columns]
-        output_dims = [column.embeddings_output_dim for column in categorical_columns]
-        embeddings = MultiColumnEmbedding(input_dims, output_dims, embedding_dropout,
-                                          name=consts.LAYER_PREFIX_EMBEDDING + 'categorical_vars_all',
-                                          embeddings_initializer=self.config.embeddings_initializer)(input_layer)
-        self.model_desc.set_embeddings(input_dims, output_dims, embedding_dropout)
+    def _build_embeddings(self, categorical_columns, categorical_inputs, var_len_categorical_columns=None,
+                          var_len_inputs=None, embedding_dropout=0.):
+        if 'all_categorical_vars' in categorical_inputs:
+            input_layer = categorical_inputs['all_categorical_vars']
+            input_dims = [column.vocabulary_size for column in categorical_columns]
+            output_dims = [column.embeddings_output_dim for column in categorical_columns]
+            embeddings = MultiColumnEmbedding(input_dims, output_dims, embedding_dropout,
+                                              name=consts.LAYER_PREFIX_EMBEDDING + 'categorical_vars_all',
+                                              embeddings_initializer=self.config.embeddings_initializer)(input_layer)
+            self.model_desc.set_embeddings(input_dims, output_dims, embedding_dropout)
+            embeddings = list(embeddings)
+        else:
+            embeddings = []
+        for column in var_len_categorical_columns or []:              # deepmodel.py:406-418
+            embeddings.append(VarLenColumnEmbedding(
+                emb_vocab_size=column.vocabulary_size, emb_output_dim=column.embeddings_output_dim,
+                dropout_rate=embedding_dropout, name=consts.LAYER_PREFIX_EMBEDDING + column.name,
+                embeddings_initializer=self.config.embeddings_initializer, embeddings_regularizer=None,
+                activity_regularizer=None)(var_len_inputs[column.name]))
         return embeddings
 
     def _build_denses(self, continuous_columns, continuous_inputs, dense_dropout, use_batchnormalization=False):
@@ -290,11 +305,13 @@ class DeepModel:
             strategy.broadcast_parameters(self.model)
             X, y = strategy.shard(X, y)
         train = training.TableBatches(X, y, self.categorical_columns, self.continuous_columns, self.device,
-                                      self.task, self.num_classes)
+                                      self.task, self.num_classes,
+                                      var_len_categorical_columns=self.var_len_categorical_columns)
         val = None
         if X_val is not None and len(X_val) > 0:
             val = training.TableBatches(X_val, y_val, self.categorical_columns, self.continuous_columns,
-                                        self.device, self.task, self.num_classes)
+                                        self.device, self.task, self.num_classes,
+                                        var_len_categorical_columns=self.var_len_categorical_columns)
         if steps_per_epoch is None:
             steps_per_epoch = max(len(X) // batch_size, 1)
         history = training.History()
@@ -366,7 +383,8 @@ class DeepModel:
         return self._predict(self.model, X, batch_size=batch_size, activate=True)
 
     def _predict(self, model, X, batch_size=128, activate=True):
-        data = training.TableBatches(X, None, self.categorical_columns, self.continuous_columns, self.device)
+        data = training.TableBatches(X, None, self.categorical_columns, self.continuous_columns, self.device,
+                                     var_len_categorical_columns=self.var_len_categorical_columns)
         model.eval()
         outs = []
         with torch.no_grad():
@@ -396,7 +414,8 @@ class DeepModel:
 
     def evaluate(self, X_test, y_test, batch_size=256, verbose=0, return_dict=True):
         data = training.TableBatches(X_test, y_test, self.categorical_columns, self.continuous_columns, self.device,
-                                     self.task, self.num_classes)
+                                     self.task, self.num_classes,
+                                     var_len_categorical_columns=self.var_len_categorical_columns)
         result = self._evaluate_batches(data, batch_size, list(self.config.metrics or []))
         return IgnoreCaseDict(inputs=result) if return_dict else list(result.values())
 

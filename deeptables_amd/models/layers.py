@@ -647,7 +647,6 @@ class VarLenColumnEmbedding(Layer):
         self.dropout_rate = dropout_rate
         super().__init__(**kwargs)
         self.dropout = None
-        self.sparse_grads = {}
 
     def compute_output_shape(self, input_shape):
         return (input_shape[0], 1, self.emb_output_dim * int(input_shape[1]))

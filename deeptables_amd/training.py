@@ -188,7 +188,7 @@ class TableBatches:
     one float32 block per ContinuousColumn, labels.  Yields aligned batch slices."""
 
     def __init__(self, X, y, categorical_columns, continuous_columns, device, task=None, num_classes=None,
-                 cat_dtype=torch.int32):
+                 cat_dtype=torch.int32, var_len_categorical_columns=None):
         self.n = len(X)
         self.device = device
         get = (lambda cols: X[cols].values) if hasattr(X, 'columns') else None
@@ -197,6 +197,11 @@ class TableBatches:
             names = [c.name for c in categorical_columns]
             arr = get(names) if get else np.asarray(X['cat'])
             self.cat = torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype).to(device)
+        self.var_lens = []     # one [N, max_elements_length] id block per VarLenCategoricalColumn (padded lists)
+        for c in var_len_categorical_columns or []:
+            col = X[c.name]
+            arr = np.array(col.tolist() if hasattr(col, 'tolist') else list(col))
+            self.var_lens.append(torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype).to(device))
         self.conts = []
         for c in continuous_columns or []:
             arr = get(list(c.column_names)) if get else np.asarray(X[c.name])
@@ -212,6 +217,7 @@ class TableBatches:
         ins = []
         if self.cat is not None:
             ins.append(self.cat[sel])
+        ins += [v[sel] for v in self.var_lens]        # model input order: deepmodel.py:310
         ins += [c[sel] for c in self.conts]
         return ins, (None if self.y is None else self.y[sel])
 

@@ -328,3 +328,41 @@ def test_f3_train_step_and_focal_loss(dev):
     dm.model.train()
     losses = [float(dm.train_step([idx, dense], y)[0]) for _ in range(30)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_var_len_columns_in_model(dev):
+    """VarLenCategoricalColumn inputs: model input order (cat, var-len, continuous) as deepmodel.py:310, the
+    var-len embedding joins the embeddings list, and the model trains on a frame holding padded id lists."""
+    import pandas as pd
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn, VarLenCategoricalColumn
+    from oracle import reference_layers as R
+    functional.set_seed(2)
+    conf = ModelConfig(nets=['dnn_nets'], fixed_embedding_dim=True, embeddings_output_dim=4, embedding_dropout=0,
+                       metrics=['AUC'], earlystopping_patience=0)
+    cats = [CategoricalColumn(f'C{i}', 10, 4) for i in range(3)]
+    conts = [ContinuousColumn('input_continuous_all', ['a', 'b'])]
+    vl = VarLenCategoricalColumn('genres', 12, 4)
+    vl.max_elements_length = 5
+    dm = DeepModel('binary', 2, conf, cats, conts, var_categorical_len_columns=[vl])
+    dm.build()
+    L = dm.model.layers_by_name
+    assert 'emb_genres' in L and [t.name for t in dm.model.inputs][1] == 'genres'
+    g = torch.Generator().manual_seed(0)
+    n = 300
+    idx = torch.randint(0, 10, (n, 3), generator=g)
+    seq = torch.randint(0, 12, (n, 5), generator=g)
+    dense = torch.randn(n, 2, generator=g)
+    emb = L['emb_categorical_vars_all']
+    df = pd.DataFrame({'C0': idx[:, 0], 'C1': idx[:, 1], 'C2': idx[:, 2], 'a': dense[:, 0], 'b': dense[:, 1]})
+    df['genres'] = list(seq.numpy())
+    y = (seq[:, 0] % 2 == 0).float().numpy()
+    hist = dm.fit(df, y, batch_size=64, epochs=8, verbose=0)
+    assert hist.history['loss'][-1] < hist.history['loss'][0]
+    # what the DNN sees: [cat embeddings | var-len embedding] flattened, bit-exact gathers
+    got = dm.apply(df, output_layers=['flatten_embeddings'], batch_size=100)
+    assert np.array_equal(np.asarray(got), torch.cat(
+        [torch.cat([e.detach().cpu()[idx[:, i]] for i, e in enumerate(emb.embeddings)], 1),
+         R.var_len_embedding(seq.float(), L['emb_genres'].embeddings.detach().cpu()).reshape(n, -1)], 1).numpy())
+    assert dm.predict(df).shape[0] == n
