@@ -33,9 +33,15 @@ F, VOCAB, ND, D = 26, 1_000_000, 13, 16
 N_BATCHES = 50
 
 
-def algorithmic_bytes_per_row(n_dense_params, batch):
-    """4F + 4Nd + 8 + 3*4*F*D + 12*P_dense/B  (= 5,250 B/row for DeepFM at B=8192)."""
-    return 4 * F + 4 * ND + 8 + 12 * F * D + 12.0 * n_dense_params / batch
+def algorithmic_bytes_per_row(n_dense_params, batch, dim=D, optimizer=True):
+    """SURVEY §8(d) fwd+bwd: 4F + 4Nd + 8 + 3*4*F*D + 12*P_dense/B  (= 5,250 B/row for DeepFM at B=8192).
+    With the Adam step in the timed region: + the row-sparse update of the F looked-up rows
+    (read the row gradient; read and write p, m, v: 7 streams of 4*F*D bytes) + 28*P_dense/B for the dense
+    parameters (read g, p, m, v; write p, m, v)."""
+    fwd_bwd = 4 * F + 4 * ND + 8 + 12 * F * dim + 12.0 * n_dense_params / batch
+    if not optimizer:
+        return fwd_bwd
+    return fwd_bwd + 7 * 4 * F * dim + 28.0 * n_dense_params / batch
 
 
 def build_model(nets, device, strategy=None, dim=D):
@@ -77,13 +83,14 @@ class GraphedStep:
         self.graphs = {}
         self.use_graph = use_graph
         self.strategy = dm.config.distribute_strategy
+        self._dp = self.strategy is not None and self.strategy.world_size > 1
         self.sparse_refs = {}
 
     def _body(self, b):
         dm = self.dm
         loss, logit = dm.forward_backward([b[0], b[1]], b[2])   # fused plan when the graph has one
-        if self.with_optimizer:
-            dm.optimizer.step()
+        if self.with_optimizer and not self._dp:
+            dm.optimizer.step()          # single GPU: the Adam step is part of the captured graph
         self.loss = loss
 
     def capture(self, batches):
@@ -120,8 +127,10 @@ class GraphedStep:
                 layer.sparse_grads = {k: list(v) for k, v in refs.items()}
         else:
             self._body(b)
-        if self.strategy is not None and self.strategy.world_size > 1:
+        if self._dp:
             self.strategy.exchange_gradients(self.dm.model)
+            if self.with_optimizer:
+                self.dm.optimizer.step()     # data parallel: after the gradient exchange, eager launches
 
 
 def time_steps(step, batches, steps, warmup, barrier):
@@ -254,6 +263,7 @@ def main():
     ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN'])
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
     args = ap.parse_args()
@@ -292,7 +302,7 @@ def main():
         strategy.broadcast_parameters(dm.model)
     batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
 
-    step = GraphedStep(dm, args.batch, device, with_optimizer=False, use_graph=not args.no_graph)
+    step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph)
     step.capture(batches)
     wall, ev_s = time_steps(step, batches, args.steps, args.warmup, barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=device)
@@ -304,7 +314,7 @@ def main():
 
     if rank == 0:
         n_dense = sum(p.numel() for n, p in dm.model.named_parameters() if 'tables' not in n)
-        bpr = algorithmic_bytes_per_row(n_dense, args.batch)
+        bpr = algorithmic_bytes_per_row(n_dense, args.batch, dim, optimizer=not args.no_optimizer)
         step_s = ev_s / args.steps
         achieved = args.batch * bpr / step_s / 1e9
         result = {
@@ -316,20 +326,21 @@ def main():
             'config': {'workload': f'{args.model} fwd+bwd, Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'hipgraph': not args.no_graph, 'optimizer_in_timed_region': False,
+                       'hipgraph': not args.no_graph, 'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
-                         'launch': 'one hipGraph replay = one fwd+bwd step',
+                         'launch': 'one hipGraph replay = one train step (fwd+bwd' + ('' if args.no_optimizer else '+Adam') + ')',
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
         }
         if not args.no_extras and world == 1:
             try:
                 result['kernels'] = kernel_breakdown(dm, args.batch, device, batches[1]) if args.model == 'DeepFM' else {}
-                opt_step = GraphedStep(dm, args.batch, device, with_optimizer=True, use_graph=False)
-                opt_step.capture(batches)
-                w2, _ = time_steps(opt_step, batches, max(args.steps // 4, 10), 5, barrier)
-                result['train_step_rows_per_s'] = args.batch * max(args.steps // 4, 10) / w2
+                if not args.no_optimizer:      # the same step without the Adam launches, for comparison
+                    fb = GraphedStep(dm, args.batch, device, with_optimizer=False, use_graph=not args.no_graph)
+                    fb.capture(batches)
+                    w2, _ = time_steps(fb, batches, args.steps, 5, barrier)
+                    result['fwd_bwd_only_rows_per_s'] = args.batch * args.steps / w2
             except Exception as e:   # diagnostics must not kill the contract line
                 result['extras_error'] = repr(e)
         if not args.no_cpu_baseline and world == 1:

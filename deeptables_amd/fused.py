@@ -95,6 +95,20 @@ class FusedDeepFM:
         if self.out.bias is not None:
             self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
         self.loss_view = a[o['loss']:o['loss'] + 1]
+        # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
+        # the model with ONE launch over (flat_params, accum) instead of one launch per tensor.
+        self.flat_params = torch.zeros_like(self.accum)
+        members = []
+        for p, gview in self.grad_views:
+            off = (gview.data_ptr() - a.data_ptr()) // 4
+            n = p.numel()
+            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_params[off:off + n].view(p.shape)
+            members.append((p, off, n))
+        n_flat = o['dwlin'] + self.F + self.Nd
+        opt = getattr(dm, 'optimizer', None)
+        if opt is not None and hasattr(opt, 'register_flat_group'):
+            opt.register_flat_group(self.flat_params, self.accum, members, n_flat)
         dm.model._dt_flat_grad = self.accum     # lets DataParallelStrategy all-reduce the gradients in place
 
     def _buffers(self, B):

@@ -573,9 +573,11 @@ def _same_pad(size, k, stride):
 
 class FGCNN(Layer):
     """Feature generation: Conv2D((h,1), same) -> MaxPooling2D((p,1), same) -> Flatten -> Dense recombination.
-    The convolution / pooling are Keras built-ins (not deeptables code) and run on MIOpen through torch; the
-    recombination Dense is the HIP Dense kernel.  Tensors keep the Keras channels-last layout [B,F,D,C] at the
-    layer boundary (Flatten order feeds the Dense weights), kernel stored as Keras [h,1,Cin,Cout]."""
+    A (h,1) convolution along the field axis is a GEMM over the h stacked field taps: the taps are gathered
+    ([B*F*D, h*Cin], a strided view copy) and multiplied by the [h*Cin, filters] kernel on the library's own
+    fp32-MFMA Dense kernel (csrc/dense.hip) — no MIOpen/vendor convolution; the pooling is a reshape + max.
+    Tensors keep the Keras channels-last layout [B,F,D,C] (the Flatten order feeds the recombination Dense),
+    kernel stored in the Keras layout [h,1,Cin,Cout]."""
 
     def __init__(self, filters, kernel_height, new_filters, pool_height, activation='tanh', **kwargs):
         self.filters = filters
@@ -605,20 +607,20 @@ class FGCNN(Layer):
         _ndim_check(x, 4)
         B, F, D, C = x.shape
         h = self.kernel_height
-        xc = x.permute(0, 3, 1, 2)                                      # NHWC -> NCHW view
         _, pb, pa = _same_pad(F, h, 1)
-        xc = torch.nn.functional.pad(xc, (0, 0, pb, pa))
-        out = torch.nn.functional.conv2d(xc, self.conv_kernel.permute(3, 2, 0, 1), self.conv_bias)
+        xp = torch.nn.functional.pad(x, (0, 0, 0, 0, pb, pa))             # zero-pad the field axis
+        taps = xp.unfold(1, h, 1).permute(0, 1, 2, 4, 3).reshape(B * F * D, h * C)   # [B,F,D,C,h] -> rows of taps
+        out = ops.dense(taps, self.conv_kernel.reshape(h * C, self.filters), self.conv_bias, None) \
+            if ops.dense_supported(taps, self.conv_kernel.reshape(h * C, self.filters)) \
+            else torch.addmm(self.conv_bias, taps, self.conv_kernel.reshape(h * C, self.filters))
         if self._act is not None:
             out = self._act(out)
+        out = out.reshape(B, F, D, self.filters)
         ph = self.pool_height
-        _, qb, qa = _same_pad(F, ph, ph)
+        Fp, qb, qa = _same_pad(F, ph, ph)
         if qb or qa:
-            out_p = torch.nn.functional.pad(out, (0, 0, qb, qa), value=float('-inf'))
-        else:
-            out_p = out
-        pooled = torch.nn.functional.max_pool2d(out_p, (ph, 1), (ph, 1))
-        pooling_output = pooled.permute(0, 2, 3, 1).contiguous()          # back to [B,F',D,filters]
+            out = torch.nn.functional.pad(out, (0, 0, 0, 0, qb, qa), value=float('-inf'))
+        pooling_output = out.reshape(B, Fp, ph, D, self.filters).amax(dim=2)   # [B,F',D,filters]
         new_features = self.dense_output(pooling_output.reshape(B, -1))
         new_features = new_features.reshape(-1, F * self.new_filters, D)
         return [pooling_output, new_features]

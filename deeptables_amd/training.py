@@ -37,10 +37,13 @@ def mse(pred, y):
 class KerasAdam:
     """keras.optimizers.Adam(learning_rate=1e-3, beta_1=.9, beta_2=.999, epsilon=1e-7):
         lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
-    Dense parameters: one fused HIP launch each.  Packed embedding tables with a sparse gradient
-    (MultiColumnEmbedding.sparse_grads): duplicates merged by scatter-add into a persistent dense
-    scratch table, then a row-sparse ("lazy") update of only the rows touched this step — a
-    documented deviation from Keras' dense semantics for tables too large to sweep every step."""
+    Dense parameters: one fused HIP launch each — or ONE launch for a whole registered flat group (the fused
+    train-step plans keep parameters and gradients of all dense layers in two contiguous buffers).
+    Packed embedding tables with a sparse gradient (MultiColumnEmbedding.sparse_grads): duplicates merged by
+    scatter-add into a persistent dense scratch table, then a row-sparse ("lazy") update of only the rows touched
+    this step — a documented deviation from Keras' dense semantics for tables too large to sweep every step.
+    The step counter and lr_t live on the device (dt_adam_advance), so a captured hipGraph of the step replays
+    with the right bias correction."""
 
     _name = 'Adam'
 
@@ -48,8 +51,27 @@ class KerasAdam:
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
         self.params = [p for p in params if p.requires_grad]
         self.state = {}
-        self.t = 0
         self.embedding_layers = list(embedding_layers)
+        self._dev_state = None        # int32 view of 8 bytes: [t, bits(lr_t)]
+        self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param)})
+
+    # -- step counter ----------------------------------------------------------------------------
+    def _state_tensor(self, device):
+        if self._dev_state is None:
+            self._dev_state = torch.zeros(2, dtype=torch.int32, device=device)
+        return self._dev_state
+
+    @property
+    def t(self):
+        return 0 if self._dev_state is None else int(self._dev_state[0].item())
+
+    @t.setter
+    def t(self, value):
+        if self._dev_state is None:
+            if not self.params:
+                return
+            self._state_tensor(self.params[0].device)
+        self._dev_state[0] = int(value)
 
     def _st(self, p):
         s = self.state.get(id(p))
@@ -58,6 +80,19 @@ class KerasAdam:
             self.state[id(p)] = s
         return s
 
+    def register_flat_group(self, flat_param, flat_grad, members, n):
+        """members: [(param, offset, numel)] whose .data are views of flat_param and whose fused-plan gradients
+        are the matching views of flat_grad.  Their m/v become views of one flat m/v (existing state is kept)."""
+        m = torch.zeros_like(flat_param)
+        v = torch.zeros_like(flat_param)
+        for p, off, cnt in members:
+            old = self.state.get(id(p))
+            if old is not None:
+                m[off:off + cnt].copy_(old['m'].reshape(-1))
+                v[off:off + cnt].copy_(old['v'].reshape(-1))
+            self.state[id(p)] = {'m': m[off:off + cnt].view(p.shape), 'v': v[off:off + cnt].view(p.shape)}
+        self._flat = (flat_param, flat_grad, m, v, int(n), {id(p): off for p, off, _ in members})
+
     def zero_grad(self):
         for p in self.params:
             p.grad = None
@@ -65,16 +100,29 @@ class KerasAdam:
             layer.sparse_grads.clear()
 
     def step(self):
-        self.t += 1
-        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        if not self.params:
+            return
+        dev_state = self._state_tensor(self.params[0].device)
         st = stream_ptr()
+        sp = ptr(dev_state)
+        check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
+        flat_done = set()
+        if self._flat is not None:
+            fp, fg, fm, fv, n, members = self._flat
+            base = fg.data_ptr()
+            in_flat = [p for p in self.params if id(p) in members and p.grad is not None and
+                       p.grad.data_ptr() == base + 4 * members[id(p)]]
+            if len(in_flat) == len(members):       # every member's gradient is its flat view: one launch
+                check(lib().dt_adam_dense_step(ptr(fp), ptr(fg), ptr(fm), ptr(fv), n, 0.0, self.b1, self.b2,
+                                               self.eps, sp, st), 'dt_adam_dense_step')
+                flat_done = set(members)
         for p in self.params:
-            if p.grad is None:
+            if p.grad is None or id(p) in flat_done:
                 continue
             s = self._st(p)
             g = p.grad.contiguous()
-            check(lib().dt_adam_dense_step(ptr(p.data), ptr(g), ptr(s['m']), ptr(s['v']), p.numel(), lr_t,
-                                           self.b1, self.b2, self.eps, st), 'dt_adam_dense_step')
+            check(lib().dt_adam_dense_step(ptr(p.data), ptr(g), ptr(s['m']), ptr(s['v']), p.numel(), 0.0,
+                                           self.b1, self.b2, self.eps, sp, st), 'dt_adam_dense_step')
         for layer in self.embedding_layers:
             for key, grads in layer.sparse_grads.items():
                 table = layer.tables[key]
@@ -88,8 +136,8 @@ class KerasAdam:
                                                        ptr(s['scratch']), st), 'dt_embedding_bwd_dense')
                 rows = grads[0].rows if len(grads) == 1 else torch.cat([g.rows for g in grads])
                 check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(s['scratch']),
-                                              ptr(rows), rows.numel(), D, ptr(s['epoch']), self.t, lr_t,
-                                              self.b1, self.b2, self.eps, st), 'dt_adam_rows_step')
+                                              ptr(rows), rows.numel(), D, ptr(s['epoch']), 0, 0.0,
+                                              self.b1, self.b2, self.eps, sp, st), 'dt_adam_rows_step')
             layer.sparse_grads.clear()
 
 

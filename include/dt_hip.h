@@ -185,12 +185,16 @@ int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float*
  * Dense: n contiguous floats.  Rows: row-sparse ("lazy") variant touching only rows[i];
  * duplicates were merged into grad_table_dense by dt_embedding_bwd_dense, the first thread to
  * claim a row in row_epoch [n_table_rows] (atomicExch to `epoch`, a fresh value per step)
- * applies the update and re-zeroes that gradient row.                                        */
+ * applies the update and re-zeroes that gradient row.
+ * `state` (8 device bytes: int32 t, float lr_t; may be NULL): when given, lr_t and epoch are READ FROM THE
+ * DEVICE instead of the scalar arguments, so a captured hipGraph of the whole step replays correctly;
+ * dt_adam_advance(state, lr, b1, b2) does t += 1 and recomputes lr_t on the device.                 */
+int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
 int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
-                       float beta1, float beta2, float eps, void* stream);
+                       float beta1, float beta2, float eps, const void* state, void* stream);
 int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense,
                       const int64_t* rows, int n_rows, int D, int* row_epoch, int epoch,
-                      float lr_t, float beta1, float beta2, float eps, void* stream);
+                      float lr_t, float beta1, float beta2, float eps, const void* state, void* stream);
 
 /* ---- Keras Dense (deepnets.dnn deepnets.py:401-427; Dense(1) logits / task_output deepmodel.py:291-292,455;
  *      Q/K/V/residual projections layers.py:104-108) --------------------------------------------------- *

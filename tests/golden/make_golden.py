@@ -109,6 +109,78 @@ def layer_cases():
     return out
 
 
+def f3_cases():
+    """SURVEY §8 f3 layers: AFM, BilinearInteraction, SENET, FGCNN, focal / GHM-C losses."""
+    out = {}
+    for tag, (B, F, D, H) in {'tiny': (5, 4, 3, 2), 'medium': (48, 26, 16, 16)}.items():
+        g = gen(4321 + B)
+        P = F * (F - 1) // 2
+        x = f32(torch.randn(B, F, D, generator=g, dtype=F64) * 0.6).requires_grad_(True)
+        xs = [x[:, i:i + 1] for i in range(F)]
+        # AFM (out_kernel = Dense(1, no bias))
+        Wa = f32(torch.randn(D, H, generator=g, dtype=F64) * 0.4).requires_grad_(True)
+        ba = f32(torch.randn(H, generator=g, dtype=F64) * 0.2).requires_grad_(True)
+        pv = f32(torch.randn(H, 1, generator=g, dtype=F64)).requires_grad_(True)
+        wo = f32(torch.randn(D, 1, generator=g, dtype=F64)).requires_grad_(True)
+        up = f32(torch.randn(B, 1, generator=g, dtype=F64))
+        y = R.afm(xs, Wa, ba, pv, wo, 'relu')
+        gx, gWa, gba, gpv, gwo = torch.autograd.grad((y * up).sum(), [x, Wa, ba, pv, wo])
+        out[f'afm_{tag}'] = dict(x=x, Wa=Wa, ba=ba, pv=pv, wo=wo, up=up, y=y, gx=gx, gWa=gWa, gba=gba, gpv=gpv,
+                                 gwo=gwo)
+        # BilinearInteraction x3
+        Bb = min(B, 12)                                              # [B,P,D] outputs: keep the fixture small
+        xb = x[:Bb].detach().clone().requires_grad_(True)
+        up = f32(torch.randn(Bb, P, D, generator=g, dtype=F64))
+        for bt, nW in (('field_interaction', P), ('field_each', F - 1), ('field_all', 1)):
+            W = f32(torch.randn(nW, D, D, generator=g, dtype=F64) * 0.3).requires_grad_(True)
+            y = R.bilinear_interaction(xb, [W[i] for i in range(nW)], bt)
+            gx, gW = torch.autograd.grad((y * up).sum(), [xb, W])
+            out[f'bilinear_{bt}_{tag}'] = dict(x=xb, W=W, up=up, y=y, gx=gx, gW=gW)
+        # SENET mean / max
+        Rn = max(F // 3, 1)
+        k1 = f32(torch.randn(F, Rn, generator=g, dtype=F64) * 0.5).requires_grad_(True)
+        b1 = f32(torch.rand(Rn, generator=g, dtype=F64) * 0.5).requires_grad_(True)
+        k2 = f32(torch.randn(Rn, F, generator=g, dtype=F64) * 0.5).requires_grad_(True)
+        b2 = f32(torch.rand(F, generator=g, dtype=F64) * 0.5).requires_grad_(True)
+        up = f32(torch.randn(B, F, D, generator=g, dtype=F64))
+        for op in ('mean', 'max'):
+            y = R.senet(x, (k1, b1), (k2, b2), op)
+            gx, gk1, gb1, gk2, gb2 = torch.autograd.grad((y * up).sum(), [x, k1, b1, k2, b2])
+            out[f'senet_{op}_{tag}'] = dict(x=x, k1=k1, b1=b1, k2=k2, b2=b2, up=up, y=y, gx=gx, gk1=gk1, gb1=gb1,
+                                            gk2=gk2, gb2=gb2)
+    # FGCNN: the default first block (F=26, D=4, 14 filters, height 7, pool 2, 2 new filters) and an odd-sized one
+    for tag, (B, F, D, C, filters, h, pool, nf) in {'default': (8, 26, 4, 1, 14, 7, 2, 2),
+                                                    'odd': (6, 9, 4, 3, 5, 4, 3, 1)}.items():
+        g = gen(99 + F)
+        x = f32(torch.randn(B, F, D, C, generator=g, dtype=F64)).requires_grad_(True)
+        ck = f32(torch.randn(h, 1, C, filters, generator=g, dtype=F64) * 0.3).requires_grad_(True)
+        cb = f32(torch.randn(filters, generator=g, dtype=F64) * 0.1).requires_grad_(True)
+        Fp = -(-F // pool)
+        dk = f32(torch.randn(Fp * D * filters, F * D * nf, generator=g, dtype=F64) * 0.05).requires_grad_(True)
+        db = f32(torch.randn(F * D * nf, generator=g, dtype=F64) * 0.1).requires_grad_(True)
+        pooled, newf = R.fgcnn(x, ck, cb, dk, db, pool, nf)
+        up_p = f32(torch.randn(pooled.shape, generator=g, dtype=F64))
+        up_n = f32(torch.randn(newf.shape, generator=g, dtype=F64))
+        gx, gck, gcb, gdk = torch.autograd.grad((pooled * up_p).sum() + (newf * up_n).sum(), [x, ck, cb, dk])
+        out[f'fgcnn_{tag}'] = dict(x=x, ck=ck, cb=cb, dk=dk, db=db, up_p=up_p, up_n=up_n, pooled=pooled, newf=newf,
+                                   gx=gx, gck=gck, gcb=gcb, gdk=gdk, meta=np.array([pool, nf]))
+    # losses
+    g = gen(2024)
+    B, C = 200, 5
+    yb = (torch.rand(B, 1, generator=g) < 0.3).double()
+    pb = f32(torch.rand(B, 1, generator=g, dtype=F64).clamp(1e-3, 1 - 1e-3))
+    yc = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).double()
+    pc = f32(torch.softmax(torch.randn(B, C, generator=g, dtype=F64), -1))
+    z1 = f32(torch.randn(B, 1, generator=g, dtype=F64) * 2)
+    z2 = f32(torch.randn(B, 1, generator=g, dtype=F64) * 2)
+    l1, acc = R.ghmc_loss(z1, yb, torch.zeros(10, dtype=F64))
+    l2, acc = R.ghmc_loss(z2, yb, acc)
+    out['losses'] = dict(yb=yb, pb=pb, yc=yc, pc=pc, z1=z1, z2=z2,
+                         binary_focal=R.binary_focal_loss(yb, pb), categorical_focal=R.categorical_focal_loss(yc, pc),
+                         ghmc1=l1, ghmc2=l2, ghmc_acc=acc)
+    return out
+
+
 MODEL_CONFIGS = {
     'DeepFM': dict(nets=['linear', 'fm_nets', 'dnn_nets'], D=16),
     'xDeepFM': dict(nets=['linear', 'cin_nets', 'dnn_nets'], D=16,
@@ -214,7 +286,9 @@ def model_cases():
     return out
 
 
-EXPECTED = ('y', 'gx', 'gk', 'gw', 'gb', 'gf0', 'gf1', 'gf2', 'emb')
+EXPECTED = ('y', 'gx', 'gk', 'gw', 'gb', 'gf0', 'gf1', 'gf2', 'emb', 'gWa', 'gba', 'gpv', 'gwo', 'gW', 'gk1', 'gb1', 'gk2',
+            'gb2', 'pooled', 'newf', 'gck', 'gcb', 'gdk', 'binary_focal', 'categorical_focal', 'ghmc1', 'ghmc2',
+            'ghmc_acc')
 
 
 def save(path, d):
@@ -229,7 +303,12 @@ def save(path, d):
 
 
 def main():
-    for name, case in layer_cases().items():
+    if '--f3' in sys.argv:          # only the f3 fixtures (leaves the earlier files byte-identical)
+        for name, case in f3_cases().items():
+            save(os.path.join(OUT, f'layer_{name}.npz'), case)
+        print('f3 golden fixtures written to', OUT)
+        return
+    for name, case in list(layer_cases().items()) + list(f3_cases().items()):
         save(os.path.join(OUT, f'layer_{name}.npz'), case)
     for name, case in model_cases().items():
         # inputs / weights are float32-representable: store them as float32 to keep the fixtures small

@@ -153,3 +153,81 @@ def test_model_logits_and_grads(dev, name):
     emb = dm.model.layers_by_name['emb_categorical_vars_all']
     gt = emb.tables[f'd{D}'].grad[:cats[0].vocabulary_size]
     assert rel(gt, g['g_emb0']) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY §8 f3 layers against their committed fixtures
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['tiny', 'medium'])
+def test_afm_golden(dev, tag):
+    from deeptables_amd import ops
+    g = load(f'layer_afm_{tag}.npz')
+    x, Wa, ba, pv, wo = [dv(g[k], dev, True) for k in ('x', 'Wa', 'ba', 'pv', 'wo')]
+    y = ops.afm_pool(x, Wa, ba, pv, 'relu') @ wo
+    (y * dv(g['up'], dev)).sum().backward()
+    assert rel(y, g['y']) < TOL
+    for t, k in ((x, 'gx'), (Wa, 'gWa'), (ba, 'gba'), (pv, 'gpv'), (wo, 'gwo')):
+        assert rel(t.grad, g[k]) < 2 * TOL, k
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'medium'])
+@pytest.mark.parametrize('bt', ['field_interaction', 'field_each', 'field_all'])
+def test_bilinear_golden(dev, tag, bt):
+    from deeptables_amd import ops
+    g = load(f'layer_bilinear_{bt}_{tag}.npz')
+    x, W = dv(g['x'], dev, True), dv(g['W'], dev, True)
+    y = ops.bilinear_interaction(x, W, bt)
+    (y * dv(g['up'], dev)).sum().backward()
+    assert rel(y, g['y']) < TOL and rel(x.grad, g['gx']) < TOL and rel(W.grad, g['gW']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'medium'])
+@pytest.mark.parametrize('op', ['mean', 'max'])
+def test_senet_golden(dev, tag, op):
+    from deeptables_amd import ops
+    g = load(f'layer_senet_{op}_{tag}.npz')
+    x, k1, b1, k2, b2 = [dv(g[k], dev, True) for k in ('x', 'k1', 'b1', 'k2', 'b2')]
+    z = ops.field_pool(x, op)
+    a = torch.relu(torch.relu(z @ k1 + b1) @ k2 + b2)
+    y = ops.field_scale(x, a)
+    (y * dv(g['up'], dev)).sum().backward()
+    assert rel(y, g['y']) < TOL
+    for t, k in ((x, 'gx'), (k1, 'gk1'), (b1, 'gb1'), (k2, 'gk2'), (b2, 'gb2')):
+        assert rel(t.grad, g[k]) < 2 * TOL, k
+
+
+@pytest.mark.parametrize('tag', ['default', 'odd'])
+def test_fgcnn_golden(dev, tag):
+    from deeptables_amd.models import layers
+    g = load(f'layer_fgcnn_{tag}.npz')
+    pool, nf = [int(v) for v in g['meta']]
+    h, _, C, filters = g['ck'].shape
+    B, F, D, _ = g['x'].shape
+    layer = layers.FGCNN(filters=filters, kernel_height=h, new_filters=nf, pool_height=pool)
+    layer.build((None, F, D, C))
+    layer.to(dev)
+    with torch.no_grad():
+        layer.conv_kernel.copy_(dv(g['ck'], dev))
+        layer.conv_bias.copy_(dv(g['cb'], dev))
+        layer.dense_output.kernel.copy_(dv(g['dk'], dev))
+        layer.dense_output.bias.copy_(dv(g['db'], dev))
+    x = dv(g['x'], dev, True)
+    pooled, newf = layer(x)
+    ((pooled * dv(g['up_p'], dev)).sum() + (newf * dv(g['up_n'], dev)).sum()).backward()
+    assert rel(pooled, g['pooled']) < TOL and rel(newf, g['newf']) < TOL
+    assert rel(x.grad, g['gx']) < 2 * TOL and rel(layer.conv_kernel.grad, g['gck']) < 2 * TOL
+    assert rel(layer.conv_bias.grad, g['gcb']) < 2 * TOL and rel(layer.dense_output.kernel.grad, g['gdk']) < 2 * TOL
+
+
+def test_losses_golden(dev):
+    from deeptables_amd.models import layers
+    g = load('layer_losses.npz')
+    bf = layers.BinaryFocalLoss()(dv(g['yb'], dev), dv(g['pb'], dev))
+    assert abs(bf.item() - float(g['binary_focal'])) < 1e-6
+    cf = layers.CategoricalFocalLoss(reduction='none')(dv(g['yc'], dev), dv(g['pc'], dev))
+    assert rel(cf, g['categorical_focal']) < TOL
+    ghm = layers.GHMCLoss(bins=10, momentum=0.75)
+    l1 = ghm.calc(dv(g['z1'], dev), dv(g['yb'], dev))
+    l2 = ghm.calc(dv(g['z2'], dev), dv(g['yb'], dev))
+    assert abs(l1.item() - float(g['ghmc1'])) < 1e-5 and abs(l2.item() - float(g['ghmc2'])) < 1e-5
+    assert rel(ghm.acc_sum, g['ghmc_acc']) < 1e-6

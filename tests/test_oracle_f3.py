@@ -129,3 +129,47 @@ def test_losses_closed_form():
     l2, acc2 = R.ghmc_loss(torch.tensor(z), torch.tensor(y), acc, bins=bins, momentum=0.75)
     assert np.allclose(acc2.numpy(), np.where(counts > 0, 0.75 * 0.25 * counts + 0.25 * counts, 0))
     assert l2.item() < l1.item()
+
+
+# ---------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/make_golden.py --f3) re-derived by the oracle
+# ---------------------------------------------------------------------------------------------
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _load(name):
+    return {k: torch.as_tensor(np.asarray(v, dtype=np.float64)) for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'medium'])
+def test_f3_golden(tag):
+    g = _load(f'layer_afm_{tag}.npz')
+    F = g['x'].shape[1]
+    y = R.afm([g['x'][:, i:i + 1] for i in range(F)], g['Wa'], g['ba'], g['pv'], g['wo'], 'relu')
+    assert torch.allclose(y, g['y'], atol=1e-12)
+    for bt in ('field_interaction', 'field_each', 'field_all'):
+        g = _load(f'layer_bilinear_{bt}_{tag}.npz')
+        y = R.bilinear_interaction(g['x'], [g['W'][i] for i in range(g['W'].shape[0])], bt)
+        assert torch.allclose(y, g['y'], atol=1e-12), bt
+    for op in ('mean', 'max'):
+        g = _load(f'layer_senet_{op}_{tag}.npz')
+        y = R.senet(g['x'], (g['k1'], g['b1']), (g['k2'], g['b2']), op)
+        assert torch.allclose(y, g['y'], atol=1e-12), op
+
+
+def test_f3_golden_fgcnn_and_losses():
+    for tag in ('default', 'odd'):
+        g = _load(f'layer_fgcnn_{tag}.npz')
+        pool, nf = [int(v) for v in g['meta']]
+        pooled, newf = R.fgcnn(g['x'], g['ck'], g['cb'], g['dk'], g['db'], pool, nf)
+        assert torch.allclose(pooled, g['pooled'], atol=1e-12) and torch.allclose(newf, g['newf'], atol=1e-12)
+    g = _load('layer_losses.npz')
+    assert abs(R.binary_focal_loss(g['yb'], g['pb']) - g['binary_focal']) < 1e-12
+    assert torch.allclose(R.categorical_focal_loss(g['yc'], g['pc']), g['categorical_focal'], atol=1e-12)
+    l1, acc = R.ghmc_loss(g['z1'], g['yb'], torch.zeros(10, dtype=torch.float64))
+    l2, acc = R.ghmc_loss(g['z2'], g['yb'], acc)
+    assert abs(l1 - g['ghmc1']) < 1e-12 and abs(l2 - g['ghmc2']) < 1e-12 and torch.allclose(acc, g['ghmc_acc'])
