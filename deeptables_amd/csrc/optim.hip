@@ -10,9 +10,8 @@
 //    small embedding tables.
 //  * dt_adam_rows_step  : "lazy" row-sparse variant for 1M-row tables: only rows looked up in
 //    this step are touched (m/v of other rows do not decay — a documented deviation from
-//    Keras' dense semantics).  Duplicate lookups of a row are merged beforehand by
-//    dt_embedding_bwd_dense into a dense gradient table; the first thread to claim the row
-//    (atomicCAS on row_epoch) applies the update and re-zeroes the gradient row.
+//    Keras' dense semantics).  Duplicate lookups of a row are merged through a small
+//    hash of the step's row ids (see below); each distinct row is updated exactly once.
 #include "common.h"
 
 namespace dt {
@@ -46,67 +45,169 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
     }
 }
 
-// 4 floats per lane, LPR = D/4 lanes per row (power of two): the 4 row-sized streams (table, m, v, merged
-// gradient) are touched as contiguous 16-byte pieces by neighbouring lanes.  The group's first lane claims the row
-// and shares the verdict by shuffle.
-__global__ __launch_bounds__(256) void k_adam_rows_v4(float* __restrict__ table, float* __restrict__ m,
-                                                      float* __restrict__ v, float* __restrict__ grad_table,
-                                                      const int64_t* __restrict__ rows, int n_rows, int lpr_log2,
-                                                      int* __restrict__ row_epoch, int epoch_host, float lr_host,
-                                                      const AdamState* __restrict__ st, float b1, float b2,
-                                                      float eps) {
-    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = gt >> lpr_log2;
-    const int part = (int)(gt & ((1 << lpr_log2) - 1));
-    if (r >= n_rows) return;                                  // whole groups leave together (groups are aligned)
-    const int64_t row = rows[r];
-    const int epoch = st ? st->t : epoch_host;
-    const float lr_t = st ? st->lr_t : lr_host;
-    int won = 0;
-    if (part == 0 && row >= 0) won = atomicExch(&row_epoch[row], epoch) != epoch;
-    won = __shfl(won, (int)(threadIdx.x & 63) - part, 64);
-    if (!won) return;
-    const int64_t i0 = (row << (lpr_log2 + 2)) + part * 4;
-    const float4 g4 = *reinterpret_cast<const float4*>(grad_table + i0);
-    float4 m4 = *reinterpret_cast<const float4*>(m + i0);
-    float4 v4 = *reinterpret_cast<const float4*>(v + i0);
-    float4 p4 = *reinterpret_cast<const float4*>(table + i0);
-#define DT_ADAM1(c)                                     \
-    m4.c = b1 * m4.c + (1.f - b1) * g4.c;               \
-    v4.c = b2 * v4.c + (1.f - b2) * g4.c * g4.c;        \
-    p4.c -= lr_t * m4.c / (sqrtf(v4.c) + eps);
-    DT_ADAM1(x) DT_ADAM1(y) DT_ADAM1(z) DT_ADAM1(w)
-#undef DT_ADAM1
-    *reinterpret_cast<float4*>(grad_table + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(m + i0) = m4;
-    *reinterpret_cast<float4*>(v + i0) = v4;
-    *reinterpret_cast<float4*>(table + i0) = p4;
+// ---- row-sparse ("lazy") Adam on (rows, values) pairs --------------------------------------------------------
+// Pass 1 (k_rows_dedupe): one thread per looked-up row occurrence inserts its table row into a small open-addressing
+// hash (64-bit slots: (row+1) << 32 | occurrence).  The first occurrence of a row owns it; later duplicates add
+// their gradient row into the owner's (atomics on an L2/MALL-resident [n,D] buffer — duplicates are rare) and mark
+// themselves done.  Pass 2 (k_adam_rows_owner): D/4 lanes per owner read the merged gradient (coalesced), update
+// p/m/v of that one table row (16-byte pieces), and the owner clears its hash slot so the table is empty again for
+// the next step — no dense gradient scratch table, no per-row epoch array, no memset.
+__device__ __forceinline__ unsigned hash_row(unsigned row, int shift) { return (row * 0x9E3779B1u) >> shift; }
+
+// dst[0..D) += src[0..D) with atomics.  dst and src live in the same buffer, so the compiler must keep every load
+// behind the previous atomic; loading a chunk into registers first keeps the loads independent (one latency, not D).
+template <int CH>
+__device__ __forceinline__ int merge_chunks(float* dst, const float* src, int d, int D) {
+    for (; d + CH <= D; d += CH) {
+        float t[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) t[k] = src[d + k];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) atomicAdd(dst + d + k, t[k]);
+    }
+    return d;
+}
+__device__ __forceinline__ void merge_row(float* dst, const float* src, int D) {
+    int d = merge_chunks<16>(dst, src, 0, D);
+    d = merge_chunks<4>(dst, src, d, D);
+    merge_chunks<1>(dst, src, d, D);
 }
 
-// any D: one lane per row
-__global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ table, float* __restrict__ m,
-                                                   float* __restrict__ v, float* __restrict__ grad_table,
-                                                   const int64_t* __restrict__ rows, int n_rows, int D,
-                                                   int* __restrict__ row_epoch, int epoch_host, float lr_host,
-                                                   const AdamState* __restrict__ st, float b1, float b2,
-                                                   float eps) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_rows) return;
-    const int64_t row = rows[t];
-    if (row < 0) return;
-    const int epoch = st ? st->t : epoch_host;
-    const float lr_t = st ? st->lr_t : lr_host;
-    if (atomicExch(&row_epoch[row], epoch) == epoch) return;  // someone else owns this row
-    for (int d = 0; d < D; ++d) {
-        const int64_t i = row * D + d;
-        const float gi = grad_table[i];
-        grad_table[i] = 0.f;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        table[i] -= lr_t * mi / (sqrtf(vi) + eps);
+__global__ __launch_bounds__(256) void k_rows_dedupe(const int64_t* __restrict__ rows, float* __restrict__ values,
+                                                     int64_t n, int D, unsigned long long* __restrict__ slots,
+                                                     int slots_log2, int* __restrict__ mark) {
+    const int64_t occ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (occ >= n) return;
+    const int64_t row = rows[occ];
+    if (row < 0) {            // out-of-range lookup: contributes nothing
+        mark[occ] = -1;
+        return;
     }
+    const unsigned mask = (1u << slots_log2) - 1u;
+    unsigned h = hash_row((unsigned)row, 32 - slots_log2);
+    const unsigned long long mine = ((unsigned long long)(row + 1) << 32) | (unsigned long long)(unsigned)occ;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&slots[h], 0ULL, mine);
+        if (prev == 0ULL) {   // owner
+            mark[occ] = (int)h;
+            return;
+        }
+        if ((prev >> 32) == (unsigned long long)(row + 1)) {   // duplicate of an earlier occurrence
+            const int64_t owner = (int64_t)(prev & 0xffffffffULL);
+            merge_row(values + owner * D, values + occ * D, D);
+            mark[occ] = -1;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// Field-local variant of pass 1 for lookups of a PACKED table laid out [.., fields]: occurrence occ belongs to field
+// occ % fields and the fields' row ranges are disjoint, so each field dedupes on its own — one workgroup per field
+// with the hash in LDS (16K slots), no global atomics except the rare duplicate merges.  Block 0 also advances the
+// optimizer's step state when asked (this kernel does not read it, the later passes do).
+constexpr int kFieldSlotsLog2 = 14;
+constexpr int kFieldSlots = 1 << kFieldSlotsLog2;
+
+__global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __restrict__ rows,
+                                                             float* __restrict__ values, int64_t n, int D, int fields,
+                                                             int* __restrict__ mark, AdamState* st_adv, float lr,
+                                                             float b1, float b2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
+    unsigned* keys = lds_u;                                  // [kFieldSlots] row+1, 0 = empty
+    int* owner = reinterpret_cast<int*>(lds_u + kFieldSlots);  // [kFieldSlots] smallest occurrence index i
+    const int f = blockIdx.x;
+    const int cnt = (int)(n / fields);
+    if (f == 0 && threadIdx.x == 0 && st_adv) {
+        const int t = st_adv->t + 1;
+        st_adv->t = t;
+        st_adv->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    }
+    // this thread's (up to 8) lookups: all loads issued before the first LDS atomic, kept in registers for pass 2
+    constexpr int kPer = kFieldSlots / 2 / 1024;
+    int64_t row[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = threadIdx.x + k * 1024;
+        row[k] = i < cnt ? rows[(int64_t)i * fields + f] : -1;
+    }
+    for (int e = threadIdx.x; e < kFieldSlots; e += blockDim.x) { keys[e] = 0u; owner[e] = 0x7fffffff; }
+    __syncthreads();
+    constexpr unsigned mask = kFieldSlots - 1;
+    unsigned slot[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        if (row[k] < 0) continue;
+        const unsigned key = (unsigned)row[k] + 1u;
+        unsigned h = hash_row((unsigned)row[k], 32 - kFieldSlotsLog2);
+        for (;;) {
+            const unsigned prev = atomicCAS(&keys[h], 0u, key);
+            if (prev == 0u || prev == key) break;
+            h = (h + 1) & mask;
+        }
+        atomicMin(&owner[h], threadIdx.x + k * 1024);
+        slot[k] = h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = threadIdx.x + k * 1024;
+        if (i >= cnt) continue;
+        const int64_t occ = (int64_t)i * fields + f;
+        if (row[k] < 0) { mark[occ] = -1; continue; }
+        const int o = owner[slot[k]];
+        if (o == i) {
+            mark[occ] = 0;
+        } else {
+            merge_row(values + ((int64_t)o * fields + f) * D, values + occ * D, D);
+            mark[occ] = -1;
+        }
+    }
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ table, float* __restrict__ m,
+                                                         float* __restrict__ v, const int64_t* __restrict__ rows,
+                                                         const float* __restrict__ values, int64_t n, int D,
+                                                         unsigned long long* __restrict__ slots,
+                                                         const int* __restrict__ mark, float lr_host,
+                                                         const AdamState* __restrict__ st, float b1, float b2,
+                                                         float eps) {
+    const int lpr = D / VW;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t occ = gt / lpr;
+    const int part = (int)(gt - occ * lpr);
+    if (occ >= n) return;
+    const int slot = mark[occ];
+    if (slot < 0) return;
+    const float lr_t = st ? st->lr_t : lr_host;
+    const int64_t i0 = rows[occ] * D + part * VW;
+    const float* gsrc = values + occ * D + part * VW;
+    float gi[VW], mi[VW], vi[VW], pi[VW];
+    if (VW == 4) {
+        *reinterpret_cast<float4*>(gi) = *reinterpret_cast<const float4*>(gsrc);
+        *reinterpret_cast<float4*>(mi) = *reinterpret_cast<const float4*>(m + i0);
+        *reinterpret_cast<float4*>(vi) = *reinterpret_cast<const float4*>(v + i0);
+        *reinterpret_cast<float4*>(pi) = *reinterpret_cast<const float4*>(table + i0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) { gi[k] = gsrc[k]; mi[k] = m[i0 + k]; vi[k] = v[i0 + k]; pi[k] = table[i0 + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        mi[k] = b1 * mi[k] + (1.f - b1) * gi[k];
+        vi[k] = b2 * vi[k] + (1.f - b2) * gi[k] * gi[k];
+        pi[k] -= lr_t * mi[k] / (sqrtf(vi[k]) + eps);
+    }
+    if (VW == 4) {
+        *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<float4*>(mi);
+        *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<float4*>(vi);
+        *reinterpret_cast<float4*>(table + i0) = *reinterpret_cast<float4*>(pi);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) { m[i0 + k] = mi[k]; v[i0 + k] = vi[k]; table[i0 + k] = pi[k]; }
+    }
+    if (part == 0 && slots) slots[slot] = 0ULL;   // global-hash variant: leave the hash empty for the next step
 }
 
 }  // namespace dt
@@ -131,24 +232,53 @@ extern "C" int dt_adam_dense_step(float* p, const float* g, float* m, float* v, 
     return launch_status("dt_adam_dense_step");
 }
 
-extern "C" int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense, const int64_t* rows,
-                                 int n_rows, int D, int* row_epoch, int epoch, float lr_t, float beta1,
-                                 float beta2, float eps, const void* state, void* stream) {
-    DT_REQUIRE(n_rows >= 0 && D > 0, "dt_adam_rows_step: bad sizes");
-    if (n_rows == 0) return DT_OK;
-    DT_REQUIRE(table && m && v && grad_table_dense && rows && row_epoch, "dt_adam_rows_step: null pointer");
-    const AdamState* st = (const AdamState*)state;
-    const int lpr = D / 4;
-    if (D % 4 == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0) {
-        int lg = 0;
-        while ((1 << lg) < lpr) ++lg;
-        const int64_t threads = (int64_t)n_rows * lpr;
-        hipLaunchKernelGGL(k_adam_rows_v4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream),
-                           table, m, v, grad_table_dense, rows, n_rows, lg, row_epoch, epoch, lr_t, st, beta1, beta2,
-                           eps);
+extern "C" int64_t dt_adam_rows_slots(int64_t n_rows) {
+    int64_t s = 1024;
+    while (s < 2 * n_rows) s <<= 1;
+    return s;
+}
+
+extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
+                                 int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t,
+                                 float beta1, float beta2, float eps, void* state, int advance, float lr,
+                                 void* stream) {
+    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= 0, "dt_adam_rows_step: bad sizes");
+    DT_REQUIRE(!advance || state, "dt_adam_rows_step: advance needs the device state");
+    hipStream_t st = as_stream(stream);
+    AdamState* as = (AdamState*)state;
+    if (n_rows == 0) {
+        if (advance) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, st, as, lr, beta1, beta2);
+        return launch_status("dt_adam_rows_step");
+    }
+    DT_REQUIRE(table && m && v && rows && values && mark, "dt_adam_rows_step: null pointer");
+    DT_REQUIRE(n_rows < (1LL << 31), "dt_adam_rows_step: %lld occurrences do not fit the 32-bit slot field",
+               (long long)n_rows);
+    const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2;
+    unsigned long long* gslots = nullptr;
+    if (field_local) {
+        const size_t lds = (size_t)kFieldSlots * 8;
+        hipFuncSetAttribute((const void*)k_rows_dedupe_fields, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_rows_dedupe_fields, dim3(fields), dim3(1024), lds, st, rows, values, n_rows, D, fields, mark,
+                           advance ? as : nullptr, lr, beta1, beta2);
     } else {
-        hipLaunchKernelGGL(k_adam_rows, dim3(ceil_div(n_rows, 256)), dim3(256), 0, as_stream(stream), table, m, v,
-                           grad_table_dense, rows, n_rows, D, row_epoch, epoch, lr_t, st, beta1, beta2, eps);
+        DT_REQUIRE(slots, "dt_adam_rows_step: null slots");
+        int lg = 0;
+        while ((1LL << lg) < n_slots) ++lg;
+        DT_REQUIRE((1LL << lg) == n_slots && n_slots >= 2 * n_rows && lg <= 31 && lg >= 1,
+                   "dt_adam_rows_step: n_slots=%lld must be a power of two >= 2*n_rows", (long long)n_slots);
+        gslots = (unsigned long long*)slots;
+        if (advance) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, st, as, lr, beta1, beta2);
+        hipLaunchKernelGGL(k_rows_dedupe, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, rows, values, n_rows,
+                           D, gslots, lg, mark);
+    }
+    if (D % 4 == 0) {
+        const int64_t threads = n_rows * (D / 4);
+        hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
+                           rows, values, n_rows, D, gslots, mark, lr_t, as, beta1, beta2, eps);
+    } else {
+        const int64_t threads = n_rows * D;
+        hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
+                           rows, values, n_rows, D, gslots, mark, lr_t, as, beta1, beta2, eps);
     }
     return launch_status("dt_adam_rows_step");
 }

@@ -39,8 +39,8 @@ class KerasAdam:
         lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
     Dense parameters: one fused HIP launch each — or ONE launch for a whole registered flat group (the fused
     train-step plans keep parameters and gradients of all dense layers in two contiguous buffers).
-    Packed embedding tables with a sparse gradient (MultiColumnEmbedding.sparse_grads): duplicates merged by
-    scatter-add into a persistent dense scratch table, then a row-sparse ("lazy") update of only the rows touched
+    Packed embedding tables with a sparse gradient (MultiColumnEmbedding.sparse_grads): duplicate lookups merged
+    through a per-step hash of the row ids, then a row-sparse ("lazy") update of only the rows touched
     this step — a documented deviation from Keras' dense semantics for tables too large to sweep every step.
     The step counter and lr_t live on the device (dt_adam_advance), so a captured hipGraph of the step replays
     with the right bias correction."""
@@ -105,7 +105,35 @@ class KerasAdam:
         dev_state = self._state_tensor(self.params[0].device)
         st = stream_ptr()
         sp = ptr(dev_state)
-        check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
+        advanced = False
+        # sparse tables first: the first pass of dt_adam_rows_step (row dedupe) does not read the step state, so the
+        # t += 1 / lr_t update rides along in it instead of costing a launch of its own
+        for layer in self.embedding_layers:
+            for key, grads in layer.sparse_grads.items():
+                table = layer.tables[key]
+                s = self._st(table)
+                D = table.shape[1]
+                if len(grads) == 1:
+                    rows, values = grads[0].rows, grads[0].values
+                else:
+                    rows = torch.cat([g.rows.reshape(-1) for g in grads])
+                    values = torch.cat([g.values.reshape(-1, D) for g in grads])
+                n = rows.numel()
+                fields = len(dict(layer.groups)[D]) if hasattr(layer, 'groups') else 0
+                n_slots = lib().dt_adam_rows_slots(n)
+                if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
+                    s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)
+                    s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
+                    s['n_slots'] = n_slots
+                values = values if values.is_contiguous() else values.contiguous()
+                check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
+                                              D, fields, ptr(s['slots']), s['n_slots'], ptr(s['mark']), 0.0,
+                                              self.b1, self.b2, self.eps, sp, 0 if advanced else 1, self.lr, st),
+                      'dt_adam_rows_step')
+                advanced = True
+            layer.sparse_grads.clear()
+        if not advanced:
+            check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
         flat_done = set()
         if self._flat is not None:
             fp, fg, fm, fv, n, members = self._flat
@@ -123,22 +151,6 @@ class KerasAdam:
             g = p.grad.contiguous()
             check(lib().dt_adam_dense_step(ptr(p.data), ptr(g), ptr(s['m']), ptr(s['v']), p.numel(), 0.0,
                                            self.b1, self.b2, self.eps, sp, st), 'dt_adam_dense_step')
-        for layer in self.embedding_layers:
-            for key, grads in layer.sparse_grads.items():
-                table = layer.tables[key]
-                s = self._st(table)
-                if 'scratch' not in s:
-                    s['scratch'] = torch.zeros_like(table)
-                    s['epoch'] = torch.zeros(table.shape[0], dtype=torch.int32, device=table.device)
-                D = table.shape[1]
-                for gr in grads:
-                    check(lib().dt_embedding_bwd_dense(ptr(gr.rows), ptr(gr.values), gr.rows.numel(), D,
-                                                       ptr(s['scratch']), st), 'dt_embedding_bwd_dense')
-                rows = grads[0].rows if len(grads) == 1 else torch.cat([g.rows for g in grads])
-                check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(s['scratch']),
-                                              ptr(rows), rows.numel(), D, ptr(s['epoch']), 0, 0.0,
-                                              self.b1, self.b2, self.eps, sp, st), 'dt_adam_rows_step')
-            layer.sparse_grads.clear()
 
 
 class SGD:

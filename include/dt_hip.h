@@ -182,19 +182,24 @@ int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float*
 
 /* ---- a13 optimizer step (Keras Adam, models/deepmodel.py:321-322) ------------------------- *
  * Keras semantics: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).
- * Dense: n contiguous floats.  Rows: row-sparse ("lazy") variant touching only rows[i];
- * duplicates were merged into grad_table_dense by dt_embedding_bwd_dense, the first thread to
- * claim a row in row_epoch [n_table_rows] (atomicExch to `epoch`, a fresh value per step)
- * applies the update and re-zeroes that gradient row.
- * `state` (8 device bytes: int32 t, float lr_t; may be NULL): when given, lr_t and epoch are READ FROM THE
- * DEVICE instead of the scalar arguments, so a captured hipGraph of the whole step replays correctly;
+ * Dense: n contiguous floats.
+ * Rows: row-sparse ("lazy") variant over the step's sparse gradient (rows [n] packed row ids, -1 = skipped;
+ * values [n,D]): duplicate lookups of a row are merged INTO `values` (the first occurrence's row receives the
+ * sum) through an open-addressing hash — slots: dt_adam_rows_slots(n) 8-byte entries, all zero on entry and
+ * left all zero on return; mark: n int32 scratch — then every distinct row's p/m/v is updated once.
+ * fields > 0 promises that rows is laid out [.., fields] over a packed table whose fields own disjoint row
+ * ranges (MultiColumnEmbedding): each field then dedupes in LDS (one workgroup per field, up to 8192 lookups
+ * per field) and `slots` is not touched.  advance != 0 folds dt_adam_advance(state, lr, ..) into the first pass.
+ * `state` (8 device bytes: int32 t, float lr_t; may be NULL): when given, lr_t is READ FROM THE DEVICE instead
+ * of the scalar argument, so a captured hipGraph of the whole step replays correctly;
  * dt_adam_advance(state, lr, b1, b2) does t += 1 and recomputes lr_t on the device.                 */
 int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
 int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                        float beta1, float beta2, float eps, const void* state, void* stream);
-int dt_adam_rows_step(float* table, float* m, float* v, float* grad_table_dense,
-                      const int64_t* rows, int n_rows, int D, int* row_epoch, int epoch,
-                      float lr_t, float beta1, float beta2, float eps, const void* state, void* stream);
+int64_t dt_adam_rows_slots(int64_t n_rows);
+int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
+                      int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
+                      float beta2, float eps, void* state, int advance, float lr, void* stream);
 
 /* ---- Keras Dense (deepnets.dnn deepnets.py:401-427; Dense(1) logits / task_output deepmodel.py:291-292,455;
  *      Q/K/V/residual projections layers.py:104-108) --------------------------------------------------- *

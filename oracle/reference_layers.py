@@ -530,6 +530,22 @@ def binary_crossentropy_from_logits(logit, y):
 
 
 # ---------------------------------------------------------------------------------------------
+# keras.optimizers.Adam (selected by DeepModel.__compile_model, deepmodel.py:321-322)
+# ---------------------------------------------------------------------------------------------
+def keras_adam_step(p, g, m, v, t, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """One Keras Adam update (keras/src/optimizers/adam.py update_step): t is the 1-based step number.
+        alpha = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t);  m += (g - m)(1 - beta_1);  v += (g^2 - v)(1 - beta_2)
+        p -= alpha * m / (sqrt(v) + epsilon)
+    Returns (p, m, v).  A sparse (IndexedSlices) gradient is densified by Keras 3 before this update; the product's
+    row-sparse variant applies the same formula to the touched rows only (documented deviation)."""
+    alpha = lr * math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    m = m + (g - m) * (1.0 - beta_1)
+    v = v + (g * g - v) * (1.0 - beta_2)
+    p = p - alpha * m / (torch.sqrt(v) + epsilon)
+    return p, m, v
+
+
+# ---------------------------------------------------------------------------------------------
 # Keras initializers (for building reference-shaped random weights)
 # ---------------------------------------------------------------------------------------------
 def glorot_uniform(shape, gen, fan_in=None, fan_out=None, dtype=torch.float32):

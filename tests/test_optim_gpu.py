@@ -1,0 +1,153 @@
+# -*- coding:utf-8 -*-
+"""Keras-semantics Adam kernels (csrc/optim.hip) against the oracle's restatement of keras.optimizers.Adam:
+dense step, row-sparse step (field-local LDS dedupe and global-hash dedupe, duplicate lookups, skipped rows),
+the device-resident step counter, and replay of a captured step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _adam(dev, params, emb_layers=()):
+    from deeptables_amd.training import KerasAdam
+    return KerasAdam(params, emb_layers)
+
+
+def test_dense_adam_matches_keras_formula(dev):
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(1000, 7, generator=g)
+    p = torch.nn.Parameter(p0.clone().to(dev))
+    opt = _adam(dev, [p])
+    rp, rm, rv = p0.double(), torch.zeros(1000, 7, dtype=torch.float64), torch.zeros(1000, 7, dtype=torch.float64)
+    for t in range(1, 6):
+        grad = torch.randn(1000, 7, generator=g) * (0.1 if t % 2 else 3.0)
+        p.grad = grad.to(dev)
+        opt.step()
+        rp, rm, rv = R.keras_adam_step(rp, grad.double(), rm, rv, t)
+        assert opt.t == t
+        assert (p.detach().cpu().double() - rp).abs().max().item() < 2e-6, t
+
+
+class _FakeEmb:
+    """Minimal stand-in for MultiColumnEmbedding as the optimizer sees it."""
+
+    def __init__(self, table, n_fields):
+        self.tables = {f'd{table.shape[1]}': table}
+        self.groups = [(table.shape[1], list(range(n_fields)))]
+        self.sparse_grads = {}
+
+
+@pytest.mark.parametrize('D,F,B,vocab,use_fields', [(16, 26, 512, 40, True), (16, 26, 512, 40, False),
+                                                    (8, 3, 8192, 50000, True), (6, 5, 300, 20, True),
+                                                    (32, 4, 9000, 3000, True), (4, 1, 64, 5, True)])
+def test_rows_adam_merges_duplicates(dev, D, F, B, vocab, use_fields):
+    """Packed table of F fields x vocab rows; ids drawn with many duplicates (and some skipped rows, -1)."""
+    from deeptables_amd.ops import SparseRowGrad
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(D * 100 + F)
+    V = F * vocab
+    t0 = torch.randn(V, D, generator=g) * 0.05
+    table = torch.nn.Parameter(t0.clone().to(dev))
+    emb = _FakeEmb(table, F if use_fields else 0)
+    if not use_fields:
+        emb.groups = [(D, [])]          # fields = 0 -> global-hash dedupe
+    opt = _adam(dev, [table], [emb])
+    rp = t0.double()
+    rm, rv = torch.zeros_like(rp), torch.zeros_like(rp)
+    for t in range(1, 4):
+        ids = torch.randint(0, vocab, (B, F), generator=g)
+        rows = ids + torch.arange(F) * vocab
+        rows[torch.rand(B, F, generator=g) < 0.02] = -1                     # out-of-range lookups are skipped
+        vals = torch.randn(B * F, D, generator=g)
+        emb.sparse_grads = {f'd{D}': [SparseRowGrad(rows.reshape(-1).to(dev), vals.clone().to(dev))]}
+        opt.step()
+        dense = torch.zeros(V, D, dtype=torch.float64)
+        ok = rows.reshape(-1) >= 0
+        dense.index_add_(0, rows.reshape(-1)[ok], vals.double()[ok])
+        touched = torch.zeros(V, dtype=torch.bool)
+        touched[rows.reshape(-1)[ok]] = True
+        np_, nm, nv = R.keras_adam_step(rp, dense, rm, rv, t)
+        rp = torch.where(touched[:, None], np_, rp)                         # lazy: untouched rows keep p, m, v
+        rm = torch.where(touched[:, None], nm, rm)
+        rv = torch.where(touched[:, None], nv, rv)
+        assert (table.detach().cpu().double() - rp).abs().max().item() < 2e-6, t
+    st = opt.state[id(table)]
+    assert (st['m'].cpu().double() - rm).abs().max().item() < 1e-6
+    if not use_fields:
+        assert int(st['slots'].abs().sum().item()) == 0                     # global hash left empty for the next step
+
+
+def test_two_gradient_pieces_and_dp_sized_input(dev):
+    """Several SparseRowGrad pieces for one table (what the data-parallel all-gather hands over): rows repeat across
+    pieces; more than 8192 lookups per field falls back to the global hash."""
+    from deeptables_amd.ops import SparseRowGrad
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(5)
+    D, F, B, vocab = 16, 4, 6000, 700
+    V = F * vocab
+    t0 = torch.randn(V, D, generator=g) * 0.05
+    table = torch.nn.Parameter(t0.clone().to(dev))
+    emb = _FakeEmb(table, F)
+    opt = _adam(dev, [table], [emb])
+    pieces, dense = [], torch.zeros(V, D, dtype=torch.float64)
+    for _ in range(2):
+        rows = (torch.randint(0, vocab, (B, F), generator=g) + torch.arange(F) * vocab).reshape(-1)
+        vals = torch.randn(B * F, D, generator=g)
+        dense.index_add_(0, rows, vals.double())
+        pieces.append(SparseRowGrad(rows.to(dev), vals.to(dev)))
+    emb.sparse_grads = {'d16': pieces}
+    opt.step()
+    rp, _, _ = R.keras_adam_step(t0.double(), dense, torch.zeros_like(dense), torch.zeros_like(dense), 1)
+    touched = dense.abs().sum(1) > 0
+    assert (table.detach().cpu().double() - torch.where(touched[:, None], rp, t0.double())).abs().max().item() < 2e-6
+
+
+def test_captured_step_replays_with_advancing_bias_correction(dev):
+    """The step (advance + dense + rows) captured once in a hipGraph and replayed: t and lr_t advance on the
+    device, so replay k equals eager step k."""
+    from deeptables_amd.ops import SparseRowGrad
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(1)
+    D, F, B, vocab = 16, 3, 256, 1000
+    t0 = torch.randn(F * vocab, D, generator=g) * 0.05
+    w0 = torch.randn(50, generator=g)
+    table = torch.nn.Parameter(t0.clone().to(dev))
+    w = torch.nn.Parameter(w0.clone().to(dev))
+    emb = _FakeEmb(table, F)
+    opt = _adam(dev, [table, w], [emb])
+    rows = (torch.randint(0, vocab, (B, F), generator=g) + torch.arange(F) * vocab).reshape(-1)
+    vals = torch.randn(B * F, D, generator=g)
+    wg = torch.randn(50, generator=g)
+    rows_d, vals_src, vals_d, wg_d = rows.to(dev), vals.to(dev), torch.empty_like(vals).to(dev), wg.to(dev)
+
+    def body():
+        vals_d.copy_(vals_src)                      # the rows step merges duplicates into its input
+        w.grad = wg_d
+        emb.sparse_grads = {'d16': [SparseRowGrad(rows_d, vals_d)]}
+        opt.step()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()                                      # warm-up (allocates state): step 1
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()                                      # capture only (not executed)
+    for _ in range(3):
+        graph.replay()                              # steps 2, 3, 4
+    torch.cuda.synchronize()
+    assert opt.t == 4
+    dense = torch.zeros(F * vocab, D, dtype=torch.float64)
+    dense.index_add_(0, rows, vals.double())
+    touched = dense.abs().sum(1) > 0
+    rp, rm, rv = t0.double(), torch.zeros_like(dense), torch.zeros_like(dense)
+    rw, rwm, rwv = w0.double(), torch.zeros(50, dtype=torch.float64), torch.zeros(50, dtype=torch.float64)
+    for t in range(1, 5):
+        np_, nm, nv = R.keras_adam_step(rp, dense, rm, rv, t)
+        rp, rm, rv = [torch.where(touched[:, None], a, b) for a, b in ((np_, rp), (nm, rm), (nv, rv))]
+        rw, rwm, rwv = R.keras_adam_step(rw, wg.double(), rwm, rwv, t)
+    assert (w.detach().cpu().double() - rw).abs().max().item() < 2e-6
+    assert (table.detach().cpu().double() - rp).abs().max().item() < 2e-6
