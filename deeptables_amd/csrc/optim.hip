@@ -104,26 +104,37 @@ __global__ __launch_bounds__(256) void k_rows_dedupe(const int64_t* __restrict__
 
 // Field-local variant of pass 1 for lookups of a PACKED table laid out [.., fields]: occurrence occ belongs to field
 // occ % fields and the fields' row ranges are disjoint, so each field dedupes on its own — one workgroup per field
-// with the hash in LDS (16K slots), no global atomics except the rare duplicate merges.  Block 0 also advances the
+// with the hash in LDS (16K slots: the key word, and one word holding the owner's index in the low 13 bits and the
+// duplicate count above them).  Rows looked up kHotMin+ times in the step (skewed ids: the head of a Zipf
+// distribution, low-cardinality columns) get an LDS accumulator: their occurrences are summed with LDS atomics and
+// the owner's gradient row is overwritten with the sum, so the hot rows never serialise on one global address.  The
+// remaining (rare) duplicates add into their owner's row with global atomics.  Block 0 also advances the
 // optimizer's step state when asked (this kernel does not read it, the later passes do).
 constexpr int kFieldSlotsLog2 = 14;
 constexpr int kFieldSlots = 1 << kFieldSlotsLog2;
+constexpr int kOwnerBits = 13;                  // up to 8192 lookups per field
+constexpr int kHotMin = 4;                      // duplicates (beyond the owner) that make a row "hot"
+constexpr int kHotBytes = 30 * 1024;            // LDS left for the hot accumulators
 
 __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __restrict__ rows,
                                                              float* __restrict__ values, int64_t n, int D, int fields,
                                                              int* __restrict__ mark, AdamState* st_adv, float lr,
                                                              float b1, float b2) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
-    unsigned* keys = lds_u;                                  // [kFieldSlots] row+1, 0 = empty
-    int* owner = reinterpret_cast<int*>(lds_u + kFieldSlots);  // [kFieldSlots] smallest occurrence index i
+    unsigned* keys = lds_u;                                  // [kFieldSlots] row+1, 0 = empty; later: hot index+1
+    unsigned* oc = lds_u + kFieldSlots;                      // [kFieldSlots] owner index | dup count << 13
+    float* acc = reinterpret_cast<float*>(lds_u + 2 * kFieldSlots);   // [hot_cap][D+1]
+    __shared__ int n_hot;
     const int f = blockIdx.x;
     const int cnt = (int)(n / fields);
+    const int accs = D + 1;                                  // odd stride: hot rows spread over the banks
+    const int hot_cap = kHotBytes / (4 * accs);
     if (f == 0 && threadIdx.x == 0 && st_adv) {
         const int t = st_adv->t + 1;
         st_adv->t = t;
         st_adv->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
     }
-    // this thread's (up to 8) lookups: all loads issued before the first LDS atomic, kept in registers for pass 2
+    // this thread's (up to 8) lookups: all loads issued before the first LDS atomic, kept in registers
     constexpr int kPer = kFieldSlots / 2 / 1024;
     int64_t row[kPer];
 #pragma unroll
@@ -131,7 +142,9 @@ __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __re
         const int i = threadIdx.x + k * 1024;
         row[k] = i < cnt ? rows[(int64_t)i * fields + f] : -1;
     }
-    for (int e = threadIdx.x; e < kFieldSlots; e += blockDim.x) { keys[e] = 0u; owner[e] = 0x7fffffff; }
+    for (int e = threadIdx.x; e < kFieldSlots; e += blockDim.x) { keys[e] = 0u; oc[e] = 0u; }
+    for (int e = threadIdx.x; e < hot_cap * accs; e += blockDim.x) acc[e] = 0.f;
+    if (threadIdx.x == 0) n_hot = 0;
     __syncthreads();
     constexpr unsigned mask = kFieldSlots - 1;
     unsigned slot[kPer];
@@ -140,13 +153,25 @@ __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __re
         if (row[k] < 0) continue;
         const unsigned key = (unsigned)row[k] + 1u;
         unsigned h = hash_row((unsigned)row[k], 32 - kFieldSlotsLog2);
+        unsigned prev;
         for (;;) {
-            const unsigned prev = atomicCAS(&keys[h], 0u, key);
+            prev = atomicCAS(&keys[h], 0u, key);
             if (prev == 0u || prev == key) break;
             h = (h + 1) & mask;
         }
-        atomicMin(&owner[h], threadIdx.x + k * 1024);
+        // exactly one inserter per slot: it deposits its index; everyone else counts as a duplicate
+        atomicAdd(&oc[h], prev == 0u ? (unsigned)(threadIdx.x + k * 1024) : (1u << kOwnerBits));
         slot[k] = h;
+    }
+    __syncthreads();
+    // hot slots get an accumulator; `keys` is free now (every lookup remembers its slot) and holds hot index + 1
+    for (int e = threadIdx.x; e < kFieldSlots; e += blockDim.x) {
+        unsigned hi = 0u;
+        if ((oc[e] >> kOwnerBits) >= (unsigned)kHotMin) {
+            const int idx = atomicAdd(&n_hot, 1);
+            if (idx < hot_cap) hi = (unsigned)idx + 1u;
+        }
+        keys[e] = hi;
     }
     __syncthreads();
 #pragma unroll
@@ -155,13 +180,38 @@ __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __re
         if (i >= cnt) continue;
         const int64_t occ = (int64_t)i * fields + f;
         if (row[k] < 0) { mark[occ] = -1; continue; }
-        const int o = owner[slot[k]];
-        if (o == i) {
+        const unsigned hi = keys[slot[k]];
+        const int o = (int)(oc[slot[k]] & ((1u << kOwnerBits) - 1u));
+        if (hi) {                                            // hot: every occurrence (the owner too) adds in LDS
+            float* a = acc + (hi - 1u) * accs;
+            const float* src = values + occ * D;
+            int d = 0;
+            for (; d + 16 <= D; d += 16) {
+                float t[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t[q] = src[d + q];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) atomicAdd(a + d + q, t[q]);
+            }
+            for (; d < D; ++d) atomicAdd(a + d, src[d]);
+            mark[occ] = (o == i) ? 0 : -1;
+        } else if (o == i) {
             mark[occ] = 0;
         } else {
             merge_row(values + ((int64_t)o * fields + f) * D, values + occ * D, D);
             mark[occ] = -1;
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {                          // hot owners: gradient row := LDS sum
+        const int i = threadIdx.x + k * 1024;
+        if (i >= cnt || row[k] < 0) continue;
+        const unsigned hi = keys[slot[k]];
+        if (!hi || (int)(oc[slot[k]] & ((1u << kOwnerBits) - 1u)) != i) continue;
+        const float* a = acc + (hi - 1u) * accs;
+        float* dst = values + ((int64_t)i * fields + f) * D;
+        for (int d = 0; d < D; ++d) dst[d] = a[d];
     }
 }
 
@@ -256,7 +306,8 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
     const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2;
     unsigned long long* gslots = nullptr;
     if (field_local) {
-        const size_t lds = (size_t)kFieldSlots * 8;
+        const size_t lds = (size_t)kFieldSlots * 8 + kHotBytes;
+        DT_UNSUPPORTED(D + 1 > kHotBytes / 4, "dt_adam_rows_step: D=%d too large", D);
         hipFuncSetAttribute((const void*)k_rows_dedupe_fields, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_rows_dedupe_fields, dim3(fields), dim3(1024), lds, st, rows, values, n_rows, D, fields, mark,
                            advance ? as : nullptr, lr, beta1, beta2);
