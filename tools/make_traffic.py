@@ -1,0 +1,67 @@
+"""Builds profiles/r01_deepfm_traffic.json from the two rocprofv3 PMC passes (tools_pmc.sh):
+    python tools/make_traffic.py gpurun_out/r01_pmc_fetch/r01_pmc_fetch_counter_collection.csv \
+                                 gpurun_out/r01_pmc_write/r01_pmc_write_counter_collection.csv
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Correction (MI355X_MICROARCH.md §HBM): on gfx950
+FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced STREAMING read -> doubled for the kernels whose
+reads are float4 streams; everything else is left as reported (uncalibrated)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+WIDE = {'k_mlp_fwd': 'X tile streamed as float4', 'k_sparse_bwd': 'X and dXn rows streamed as float4'}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    n = name.split('(')[0].replace('void ', '').replace('dt::', '')
+    return n.split('<')[0]
+
+
+def avg_per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter and 'dt::' in r['Kernel_Name']:
+            acc[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, nf = avg_per_kernel(sys.argv[1], 'FETCH_SIZE')
+    write, _ = avg_per_kernel(sys.argv[2], 'WRITE_SIZE')
+    per = {}
+    raw = corr = 0.0
+    for k in fetch:
+        f, w = fetch[k], write.get(k, 0.0)
+        per[k] = {'FETCH_SIZE': round(f, 1), 'WRITE_SIZE': round(w, 1), 'wide_16B_reads': k in WIDE,
+                  'launches_averaged': nf[k]}
+        raw += (f + w) * 1024
+        corr += ((2 * f if k in WIDE else f) + w) * 1024
+    B, F, D, ND = 8192, 26, 16, 13
+    n_dense = (F * D + ND) * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1 + 2 * (F * D + ND) + (F + ND)
+    fwd_bwd = B * (4 * F + 4 * ND + 8 + 12 * F * D) + 12 * n_dense
+    opt = B * 7 * 4 * F * D + 28 * n_dense
+    out = {
+        'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py '
+                  '--steps 20 --warmup 3 --no-extras --no-cpu-baseline (tools_pmc.sh), averages per launch, KB -> bytes '
+                  'x1024; built by tools/make_traffic.py',
+        'step': 'fwd + bwd + Adam (the timed region of bench.py)',
+        'per_kernel_KB': per,
+        'correction': 'MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) '
+                      'coalesced streaming read -> doubled for ' + ', '.join(f'{k} ({v})' for k, v in WIDE.items()) +
+                      '; other widths (incl. the 64-byte random row accesses of k_adam_rows_owner / k_sparse_fwd) and '
+                      'WRITE_SIZE left as reported (uncalibrated)',
+        'bytes_per_step_raw': int(raw),
+        'bytes_per_step_corrected': int(corr),
+        'algorithmic_bytes_per_step': int(fwd_bwd + opt),
+        'algorithmic_fwd_bwd': int(fwd_bwd), 'algorithmic_adam': int(opt),
+    }
+    out['traffic_over_algorithmic'] = round(out['bytes_per_step_corrected'] / out['algorithmic_bytes_per_step'], 2)
+    path = os.path.join(ROOT, 'profiles', 'r01_deepfm_traffic.json')
+    json.dump(out, open(path, 'w'), indent=2)
+    print(json.dumps(out, indent=2))
+
+
+if __name__ == '__main__':
+    main()
