@@ -260,9 +260,49 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
     if (part == 0 && slots) slots[slot] = 0ULL;   // global-hash variant: leave the hash empty for the next step
 }
 
+// ---- SGD (keras.optimizers.SGD, momentum 0): p -= lr * g; duplicates of a row simply add up ----------------
+__global__ __launch_bounds__(256) void k_sgd_dense(float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                   float lr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] -= lr * g[i];
+}
+
+__global__ __launch_bounds__(256) void k_sgd_rows(float* __restrict__ table, const int64_t* __restrict__ rows,
+                                                  const float* __restrict__ values, int64_t total, int D, float lr) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t occ = t / D;
+        const int64_t row = rows[occ];
+        if (row >= 0) atomicAdd(table + row * D + (t - occ * D), -lr * values[t]);
+    }
+}
+
 }  // namespace dt
 
 using namespace dt;
+
+extern "C" int dt_sgd_dense_step(float* p, const float* g, int64_t n, float lr, void* stream) {
+    DT_REQUIRE(n >= 0, "dt_sgd_dense_step: n < 0");
+    if (n == 0) return DT_OK;
+    DT_REQUIRE(p && g, "dt_sgd_dense_step: null pointer");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_sgd_dense, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, n, lr);
+    return launch_status("dt_sgd_dense_step");
+}
+
+extern "C" int dt_sgd_rows_step(float* table, const int64_t* rows, const float* values, int64_t n_rows, int D,
+                                float lr, void* stream) {
+    DT_REQUIRE(n_rows >= 0 && D > 0, "dt_sgd_rows_step: bad sizes");
+    if (n_rows == 0) return DT_OK;
+    DT_REQUIRE(table && rows && values, "dt_sgd_rows_step: null pointer");
+    const int64_t total = n_rows * D;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_sgd_rows, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), table, rows, values, total, D,
+                       lr);
+    return launch_status("dt_sgd_rows_step");
+}
+
 
 extern "C" int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream) {
     DT_REQUIRE(state, "dt_adam_advance: null state");

@@ -306,7 +306,8 @@ class DeepModel:
             X, y = strategy.shard(X, y)
         train = training.TableBatches(X, y, self.categorical_columns, self.continuous_columns, self.device,
                                       self.task, self.num_classes,
-                                      var_len_categorical_columns=self.var_len_categorical_columns)
+                                      var_len_categorical_columns=self.var_len_categorical_columns,
+                                      resident=getattr(self, 'feed_resident', None))
         val = None
         if X_val is not None and len(X_val) > 0:
             val = training.TableBatches(X_val, y_val, self.categorical_columns, self.continuous_columns,
@@ -422,17 +423,21 @@ class DeepModel:
     # ------------------------------------------------------------------------------------------
     # persistence: state dict with Keras-style names (h5py is not available; deepmodel.py:205-221)
     # ------------------------------------------------------------------------------------------
-    def save(self, filepath):
+    def save(self, filepath, include_optimizer=False):
+        """deepmodel.py:205-210 saves the Keras model as .h5; here: one safetensors file with the Keras weight
+        names (deeptables_amd/checkpoint.py), optionally with the optimizer slots."""
+        from .. import checkpoint
         os.makedirs(os.path.dirname(os.path.abspath(filepath)) or '.', exist_ok=True)
-        with open(filepath, 'wb') as f:
-            pickle.dump({'weights': self.model.get_weights_dict(),
-                         'state': {k: v.cpu() for k, v in self.model.state_dict().items()}}, f, protocol=4)
+        checkpoint.save_model(self.model, filepath, optimizer=self.optimizer if include_optimizer else None,
+                              metadata={'task': str(self.task), 'nets': [str(n) for n in self.config.nets]})
 
     def _load_model(self, filepath, custom_objects=None):
-        with open(filepath, 'rb') as f:
-            blob = pickle.load(f)
+        from .. import checkpoint
         model = self.build()
-        model.load_state_dict({k: v.to(self.device) for k, v in blob['state'].items()})
+        if str(filepath).endswith('.h5'):
+            checkpoint.import_keras_h5(model, filepath)
+        else:
+            checkpoint.load_model(model, filepath, optimizer=self.optimizer)
         return model
 
     def release(self):

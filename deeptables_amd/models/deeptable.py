@@ -2,9 +2,10 @@
 """Thin drop-in for `deeptables.models.deeptable.DeepTable` (deeptables/models/deeptable.py:30-822):
 `DeepTable(config).fit(X_df, y) -> (DeepModel, History)`, `predict`, `predict_proba`, `evaluate`,
 `save`/`load`.  Orchestration only — cross-validation, ensembling, GBM features and the
-hypernets toolbox are outside the accelerated hot path.  The preprocessor
-here is a minimal TF/hypernets-free stand-in that produces the same column metadata
-(`vocabulary_size = nunique + 2`, deeptables/models/preprocessor.py:333)."""
+hypernets toolbox are outside the accelerated hot path.  The default preprocessor is
+`preprocessor.DefaultPreprocessor` (the TF/hypernets-free restatement of the reference's pipeline);
+`SimplePreprocessor` below is a smaller impute + label-encode variant kept for callers that want ids with 0
+reserved for unseen values."""
 import os
 import pickle
 
@@ -14,6 +15,7 @@ import pandas as pd
 from . import deepmodel
 from .config import ModelConfig
 from .metainfo import CategoricalColumn, ContinuousColumn
+from .preprocessor import DefaultPreprocessor
 from ..utils import consts
 
 
@@ -119,7 +121,7 @@ class DeepTable:
     def __init__(self, config=None, preprocessor=None):
         self.config = config if config is not None else ModelConfig()
         self.nets = self.config.nets
-        self.preprocessor = preprocessor if preprocessor is not None else SimplePreprocessor(self.config)
+        self.preprocessor = preprocessor if preprocessor is not None else DefaultPreprocessor(self.config)
         self.model = None
         self._models = {}
 
@@ -148,7 +150,9 @@ class DeepTable:
         if len(self.preprocessor.categorical_columns) == 0 and len(self.preprocessor.continuous_columns) == 0:
             raise ValueError('No valid input columns.')
         model = deepmodel.DeepModel(self.task, self.num_classes, self.config,
-                                    self.preprocessor.categorical_columns, self.preprocessor.continuous_columns)
+                                    self.preprocessor.categorical_columns, self.preprocessor.continuous_columns,
+                                    var_categorical_len_columns=getattr(self.preprocessor,
+                                                                        'var_len_categorical_columns', None))
         history = model.fit(X_t, y_t, batch_size=batch_size, epochs=epochs, verbose=verbose, callbacks=callbacks,
                             validation_split=validation_split, validation_data=validation_data, shuffle=shuffle,
                             initial_epoch=initial_epoch, steps_per_epoch=steps_per_epoch,
@@ -191,10 +195,10 @@ class DeepTable:
         self._require_model()
         os.makedirs(filepath, exist_ok=True)
         name = deepmodel_basename or 'dt-1'
-        self.model.save(os.path.join(filepath, f'{name}.pkl'))
+        self.model.save(os.path.join(filepath, f'{name}.safetensors'))
         cfg = self.config._replace(distribute_strategy=None)      # strategy is stripped on pickle (deeptable.py:756-771)
         with open(os.path.join(filepath, 'dt.pkl'), 'wb') as f:
-            pickle.dump({'config': cfg, 'preprocessor': self.preprocessor, 'model_file': f'{name}.pkl'}, f,
+            pickle.dump({'config': cfg, 'preprocessor': self.preprocessor, 'model_file': f'{name}.safetensors'}, f,
                         protocol=4)
 
     @staticmethod
@@ -204,5 +208,7 @@ class DeepTable:
         dt = DeepTable(config=blob['config'], preprocessor=blob['preprocessor'])
         dt.model = deepmodel.DeepModel(dt.task, dt.num_classes, dt.config, dt.preprocessor.categorical_columns,
                                        dt.preprocessor.continuous_columns,
-                                       model_file=os.path.join(filepath, blob['model_file']))
+                                       model_file=os.path.join(filepath, blob['model_file']),
+                                       var_categorical_len_columns=getattr(dt.preprocessor,
+                                                                           'var_len_categorical_columns', None))
         return dt

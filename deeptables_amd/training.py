@@ -168,17 +168,19 @@ class SGD:
             layer.sparse_grads.clear()
 
     def step(self):
-        with torch.no_grad():
-            for p in self.params:
-                if p.grad is not None:
-                    p.add_(p.grad, alpha=-self.lr)
-            for layer in self.embedding_layers:
-                for key, grads in layer.sparse_grads.items():
-                    table = layer.tables[key]
-                    for gr in grads:
-                        ok = gr.rows >= 0
-                        table.index_add_(0, gr.rows[ok], gr.values[ok], alpha=-self.lr)
-                layer.sparse_grads.clear()
+        st = stream_ptr()
+        for p in self.params:
+            if p.grad is not None:
+                g = p.grad.contiguous()
+                check(lib().dt_sgd_dense_step(ptr(p.data), ptr(g), p.numel(), self.lr, st), 'dt_sgd_dense_step')
+        for layer in self.embedding_layers:
+            for key, grads in layer.sparse_grads.items():
+                table = layer.tables[key]
+                for gr in grads:
+                    vals = gr.values if gr.values.is_contiguous() else gr.values.contiguous()
+                    check(lib().dt_sgd_rows_step(ptr(table.data), ptr(gr.rows), ptr(vals), gr.rows.numel(),
+                                                 table.shape[1], self.lr, st), 'dt_sgd_rows_step')
+            layer.sparse_grads.clear()
 
 
 def make_optimizer(spec, params, embedding_layers):
@@ -244,48 +246,144 @@ class History:
 # data feed (replaces utils/dataset_generator.py:36-72 for in-memory frames)
 # ---------------------------------------------------------------------------------------------
 class TableBatches:
-    """Device-resident table: categorical ids [N,F] int32 (or float32, the reference contract),
-    one float32 block per ContinuousColumn, labels.  Yields aligned batch slices."""
+    """Input feed for in-memory frames (replaces `to_dataset`, utils/dataset_generator.py:36-72, which
+    converts whole frames through `.tolist()` into tf.constants and feeds float32 ids).
+
+    Ids are int32 end to end.  Two modes, same batches for the same seed:
+      * resident (default when the table fits `max_resident_bytes`): the whole table lives in HBM, a shuffled epoch
+        is one `randperm` on the device and every batch an index-select — no host work per step;
+      * streamed: the table stays in PINNED host memory; batch k+1 is gathered on the host into a ring of pinned
+        staging buffers and copied with an async H2D on a side stream while batch k trains; the compute stream
+        waits on the copy's event only.
+    Yields ([cat ids [B,F] int32, var-len id blocks..., dense blocks...], y)."""
 
     def __init__(self, X, y, categorical_columns, continuous_columns, device, task=None, num_classes=None,
-                 cat_dtype=torch.int32, var_len_categorical_columns=None):
+                 cat_dtype=torch.int32, var_len_categorical_columns=None, resident=None,
+                 max_resident_bytes=32 << 30, ring=3):
         self.n = len(X)
-        self.device = device
+        self.device = torch.device(device)
         get = (lambda cols: X[cols].values) if hasattr(X, 'columns') else None
-        self.cat = None
+        host = []          # [(kind, host tensor)] in model input order: cat, var-len..., dense... (deepmodel.py:310)
         if categorical_columns:
             names = [c.name for c in categorical_columns]
             arr = get(names) if get else np.asarray(X['cat'])
-            self.cat = torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype).to(device)
-        self.var_lens = []     # one [N, max_elements_length] id block per VarLenCategoricalColumn (padded lists)
-        for c in var_len_categorical_columns or []:
+            host.append(('cat', torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype)))
+        for c in var_len_categorical_columns or []:       # padded id lists, [N, max_elements_length]
             col = X[c.name]
             arr = np.array(col.tolist() if hasattr(col, 'tolist') else list(col))
-            self.var_lens.append(torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype).to(device))
-        self.conts = []
+            host.append(('var', torch.as_tensor(np.ascontiguousarray(arr).astype(np.int64)).to(cat_dtype)))
         for c in continuous_columns or []:
             arr = get(list(c.column_names)) if get else np.asarray(X[c.name])
-            self.conts.append(torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32)).to(device))
-        self.y = None
+            host.append(('cont', torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32))))
+        y_host = None
         if y is not None:
             y = np.asarray(y)
             if task == consts.TASK_MULTICLASS and y.ndim == 1:
                 y = np.eye(num_classes, dtype=np.float32)[y.astype(np.int64)]
-            self.y = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32)).to(device)
+            y_host = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32))
+        nbytes = sum(t.numel() * t.element_size() for _, t in host) + (0 if y_host is None else y_host.numel() * 4)
+        self.resident = (nbytes <= max_resident_bytes) if resident is None else bool(resident)
+        self.kinds = [k for k, _ in host]
+        if self.resident:
+            self.blocks = [t.to(self.device) for _, t in host]
+            self.y = None if y_host is None else y_host.to(self.device)
+        else:
+            pin = self.device.type == 'cuda'
+            self.blocks = [t.pin_memory() if pin else t for _, t in host]
+            self.y = None if y_host is None else (y_host.pin_memory() if pin else y_host)
+            self._ring = max(2, int(ring))
+            self._staging = None
+            self._copy_stream = torch.cuda.Stream(self.device) if pin else None
+
+    # kept for callers that look at the pieces
+    @property
+    def cat(self):
+        return self.blocks[self.kinds.index('cat')] if 'cat' in self.kinds else None
+
+    @property
+    def var_lens(self):
+        return [b for k, b in zip(self.kinds, self.blocks) if k == 'var']
+
+    @property
+    def conts(self):
+        return [b for k, b in zip(self.kinds, self.blocks) if k == 'cont']
 
     def batch(self, sel):
-        ins = []
-        if self.cat is not None:
-            ins.append(self.cat[sel])
-        ins += [v[sel] for v in self.var_lens]        # model input order: deepmodel.py:310
-        ins += [c[sel] for c in self.conts]
-        return ins, (None if self.y is None else self.y[sel])
+        return [b[sel] for b in self.blocks], (None if self.y is None else self.y[sel])
+
+    def _permutation(self, generator):
+        """The same permutation in both modes: drawn on the device when there is one."""
+        if self.device.type == 'cuda':
+            return torch.randperm(self.n, device=self.device, generator=generator)
+        return torch.randperm(self.n, generator=generator)
 
     def iterate(self, batch_size, shuffle, drop_remainder, generator=None):
         n = self.n
-        if shuffle:
-            perm = torch.randperm(n, device=self.device, generator=generator)
         stop = (n // batch_size) * batch_size if drop_remainder else n
-        for s in range(0, stop, batch_size):
-            e = min(s + batch_size, n)
-            yield self.batch(perm[s:e] if shuffle else slice(s, e))
+        perm = self._permutation(generator) if shuffle else None
+        if self.resident:
+            for s in range(0, stop, batch_size):
+                e = min(s + batch_size, n)
+                yield self.batch(perm[s:e] if shuffle else slice(s, e))
+            return
+        yield from self._stream(batch_size, stop, None if perm is None else perm.cpu())
+
+    # -- streamed mode ---------------------------------------------------------------------------------
+    def _alloc_staging(self, batch_size):
+        pin = self._copy_stream is not None
+        srcs = self.blocks + ([] if self.y is None else [self.y])
+        self._staging = []
+        for _ in range(self._ring):
+            hostbufs = [torch.empty((batch_size,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=pin) for t in srcs]
+            devbufs = [torch.empty_like(h, device=self.device) for h in hostbufs]
+            ev = torch.cuda.Event() if pin else None
+            self._staging.append((hostbufs, devbufs, ev, [None]))
+        self._staging_batch = batch_size
+
+    def _stage(self, slot, s, e, perm_host):
+        """host gather into the slot's pinned buffers + async H2D on the copy stream; records the slot's event"""
+        hostbufs, devbufs, ev, consumed = self._staging[slot]
+        srcs = self.blocks + ([] if self.y is None else [self.y])
+        k = e - s
+        if consumed[0] is not None:
+            consumed[0].synchronize()         # the step that used this slot's device buffers must be done
+        for src, hb in zip(srcs, hostbufs):
+            if perm_host is None:
+                hb[:k].copy_(src[s:e])
+            else:
+                torch.index_select(src, 0, perm_host[s:e], out=hb[:k])
+        if self._copy_stream is not None:
+            with torch.cuda.stream(self._copy_stream):
+                for hb, db in zip(hostbufs, devbufs):
+                    db[:k].copy_(hb[:k], non_blocking=True)
+                ev.record(self._copy_stream)
+        else:
+            for hb, db in zip(hostbufs, devbufs):
+                db[:k].copy_(hb[:k])
+        return k
+
+    def _stream(self, batch_size, stop, perm_host):
+        if self._staging is None or self._staging_batch != batch_size:
+            self._alloc_staging(batch_size)
+        starts = list(range(0, stop, batch_size))
+        sizes = {}
+        depth = self._ring - 1
+        for j in range(min(depth, len(starts))):                       # prime the ring
+            sizes[j] = self._stage(j % self._ring, starts[j], min(starts[j] + batch_size, self.n), perm_host)
+        for i, s in enumerate(starts):
+            slot = i % self._ring
+            hostbufs, devbufs, ev, consumed = self._staging[slot]
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)  # compute waits for this batch's copy only
+            k = sizes.pop(i)
+            outs = [d[:k] for d in devbufs]
+            nxt = i + depth
+            if nxt < len(starts):                                      # overlap: stage a later batch now
+                sizes[nxt] = self._stage(nxt % self._ring, starts[nxt], min(starts[nxt] + batch_size, self.n),
+                                         perm_host)
+            yb = outs.pop() if self.y is not None else None
+            yield outs, yb
+            if ev is not None:                                         # mark where the consumer finished with it
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                consumed[0] = done

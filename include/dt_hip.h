@@ -201,6 +201,12 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
                       int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
                       float beta2, float eps, void* state, int advance, float lr, void* stream);
 
+/* keras.optimizers.SGD (momentum 0), selectable through ModelConfig.optimizer (deepmodel.py:319-323):
+ * p -= lr*g; the rows variant applies the (rows, values) gradient directly (duplicate rows add up).   */
+int dt_sgd_dense_step(float* p, const float* g, int64_t n, float lr, void* stream);
+int dt_sgd_rows_step(float* table, const int64_t* rows, const float* values, int64_t n_rows, int D, float lr,
+                     void* stream);
+
 /* ---- Keras Dense (deepnets.dnn deepnets.py:401-427; Dense(1) logits / task_output deepmodel.py:291-292,455;
  *      Q/K/V/residual projections layers.py:104-108) --------------------------------------------------- *
  *   y [N,M] = act(x [N,K] . W [K,M] + bias [M]|NULL),  act in {DT_ACT_LINEAR, DT_ACT_RELU}.
