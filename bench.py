@@ -266,14 +266,25 @@ def main():
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
+                    help='N>1: embedding rows owned per field by one rank (all-to-all exchange) or replicated '
+                         'tables with a sparse all-gather')
+    ap.add_argument('--force-sharded', action='store_true', help='N=1: run the sharded-table step anyway (eager)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     strategy = None
-    if world > 1:
-        from deeptables_amd.parallel import DataParallelStrategy
-        strategy = DataParallelStrategy.from_env('nccl')
+    if world > 1 or args.force_sharded:
+        from deeptables_amd.parallel import DataParallelStrategy, ShardedEmbeddingStrategy
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        cls = ShardedEmbeddingStrategy if (args.tables == 'sharded' or args.force_sharded) else DataParallelStrategy
+        strategy = cls.from_env('nccl')
         strategy.assume_uniform_batches = True      # fixed batch per rank: no count exchange / host sync
+        if args.force_sharded:
+            strategy.force = True
         device = strategy.device
         rank = strategy.rank
     else:
@@ -302,6 +313,9 @@ def main():
         strategy.broadcast_parameters(dm.model)
     batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
 
+    sharded = getattr(strategy, 'sharded_embeddings', False) and strategy.active and dm.fused_plan() is not None
+    if sharded:
+        args.no_graph = True        # collectives inside the step: launched eagerly, not captured
     step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph)
     step.capture(batches)
     wall, ev_s = time_steps(step, batches, args.steps, args.warmup, barrier)
@@ -325,7 +339,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.model} fwd+bwd, Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
                        'hipgraph': not args.no_graph, 'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

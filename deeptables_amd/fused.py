@@ -125,9 +125,83 @@ class FusedDeepFM:
             self._bufs[B] = b
         return b
 
+    # -- model-parallel tables (parallel.ShardedEmbeddingStrategy) --------------------------------------
+    def _sharded_buffers(self, B, st):
+        key = ('sharded', B)
+        sb = self._bufs.get(key)
+        if sb is None:
+            dev, F, D, W = self.device, self.F, self.D, st.world_size
+            s, e = st.field_bounds(F)[st.rank]
+            Fo = e - s
+            f_idx = torch.arange(F, device=dev, dtype=torch.int32)
+            b_idx = torch.arange(B, device=dev, dtype=torch.int32)
+            sb = {'Fo': Fo, 's': s, 'e': e,
+                  # the received rows [F,B,D] are read by the fused step as a "table" of F*B rows: id(b,f) = f*B + b
+                  'iota': (f_idx[None, :] * B + b_idx[:, None]).contiguous(),
+                  'zero_off': torch.zeros(F, dtype=torch.int64, device=dev),
+                  'fb_vocab': torch.full((F,), F * B, dtype=torch.int32, device=dev),
+                  'one_off': torch.zeros(1, dtype=torch.int64, device=dev),
+                  'emb_own': torch.empty((W * Fo * B, 1, D), dtype=torch.float32, device=dev),
+                  'rows_own': torch.empty((W * Fo * B, 1), dtype=torch.int64, device=dev),
+                  'emb_T': torch.empty((F * B, D), dtype=torch.float32, device=dev),
+                  'grad_own': torch.empty((W * Fo * B, D), dtype=torch.float32, device=dev),
+                  'rows_dummy': torch.empty((B, F), dtype=torch.int64, device=dev),
+                  'total_rows': torch.tensor([self.emb.tables[self.key].shape[0]], dtype=torch.int32, device=dev)}
+            self._bufs[key] = sb
+        return sb
+
+    def _run_sharded(self, idx, dense, y, st):
+        """One train step with the table rows owned per field by the ranks of `st` (see ShardedEmbeddingStrategy):
+        ids all-gather -> owner gather -> all-to-all -> the same fused kernels on the local minibatch (reading the
+        received rows) -> all-to-all of the row gradients -> the owner's sparse gradient."""
+        B, F, D, W = idx.shape[0], self.F, self.D, st.world_size
+        buf = self._buffers(B)
+        sb = self._sharded_buffers(B, st)
+        if idx.dtype != torch.int32:
+            idx = idx.to(torch.int32)             # float ids: truncation, as the gather's own cast
+        table = self.emb.tables[self.key]
+        row_offset = getattr(self.emb, f'row_offset_{self.key}')
+        vocab = getattr(self.emb, f'vocab_{self.key}')
+        s, e, Fo = sb['s'], sb['e'], sb['Fo']
+        ids_own = st.gather_ids(idx.contiguous(), F)                               # [W, Fo, B] int32
+        if Fo > 0:
+            voc = vocab[s:e].view(1, Fo, 1)
+            ok = (ids_own >= 0) & (ids_own < voc)
+            rows32 = torch.where(ok, ids_own + row_offset[s:e].view(1, Fo, 1).to(torch.int32),
+                                 torch.full_like(ids_own, -1)).reshape(-1, 1)
+            check(lib().dt_embedding_fwd(ptr(rows32), _lib.DT_IDX_I32, ptr(table), ptr(sb['one_off']), ptr(sb['total_rows']),
+                                         rows32.shape[0], 1, D, ptr(sb['emb_own']), ptr(sb['rows_own']),
+                                         ptr(self.emb.oob_count) if self.emb.check_oob else None, stream_ptr()),
+                  'dt_embedding_fwd')
+        emb_T = st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
+        dense = None if dense is None else dense.contiguous()
+        y = y.reshape(-1).contiguous()
+        training = self.dm.model.training
+        check(lib().dt_deepfm_train_step(
+            ptr(sb['iota']), _lib.DT_IDX_I32, ptr(emb_T), ptr(sb['zero_off']), ptr(sb['fb_vocab']), ptr(dense), ptr(y),
+            B, F, D, self.Nd, ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
+            ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
+            float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
+            ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
+            ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+            None, 2, stream_ptr()), 'dt_deepfm_train_step')
+        for p, g in self.grad_views:
+            p.grad = g
+        # the loss is a mean over the LOCAL minibatch; the global objective is the mean over W of them
+        grad_T = (buf['grad_rows'].view(B, F, D) * (1.0 / W)).permute(1, 0, 2).contiguous()
+        grad_own = st.backward_exchange(grad_T, F, B, out=sb['grad_own'])
+        self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
+        self.dm.model._dt_sharded_step = True
+        return self.loss_view, buf['logit']
+
     def run(self, idx, dense, y, backward=True):
         """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
         (views of one static buffer) and registers the embedding table's sparse gradient."""
+        st = self.dm.config.distribute_strategy
+        if backward and getattr(st, 'sharded_embeddings', False) and st.active and \
+                not self.emb.uses_dense_grad(self.D):
+            return self._run_sharded(idx, dense, y, st)
+        self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
         idx = idx.contiguous()

@@ -31,11 +31,14 @@ def _idx_kind(idx):
 class SparseRowGrad:
     """The (indices, values) pair TF calls IndexedSlices: gradient of a packed embedding table."""
 
-    __slots__ = ('rows', 'values')
+    __slots__ = ('rows', 'values', 'fields')
 
-    def __init__(self, rows, values):
+    def __init__(self, rows, values, fields=None):
         self.rows = rows        # int64 [n]   packed row ids, -1 = out-of-range lookup
         self.values = values    # float32 [n, D]
+        # layout promise for the optimizer's per-field dedupe: None = the owning layer's default ([.., F] lookups of
+        # a packed table), 0 = no field structure (use the global hash)
+        self.fields = fields
 
 
 class _EmbeddingLookup(torch.autograd.Function):

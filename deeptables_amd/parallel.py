@@ -135,3 +135,143 @@ class DataParallelStrategy:
         if work is not None:
             work.wait()
             flat.div_(self.world_size)
+
+
+class ShardedEmbeddingStrategy(DataParallelStrategy):
+    """Dense layers data-parallel, embedding ROWS owned by one rank each (model-parallel tables).
+
+    The replicated-table exchange above makes every rank receive and apply all W x B x F row gradients, so its step
+    time grows with W.  Here field f of the packed table is owned by one rank (contiguous field
+    ranges); per step
+        ids       all-gather            W x B x F x 4 B          (0.85 MB per rank at B=8192, F=26)
+        rows      owner gathers [W, F_own, B, D] from ITS fields of the table
+        forward   all-to-all            -> every rank gets [F, B, D] for its own minibatch (13.6 MB)
+        ...       the fused train step runs on the local minibatch, reading those rows as its "table"
+        backward  all-to-all            row gradients [F, B, D] (already divided by W) back to the owners (13.6 MB)
+        update    the owner applies the row-sparse Adam to its fields for all W minibatches
+    and the dense gradients take the one flat all-reduce as before.  Every exchanged block is FIELD-MAJOR so that the
+    per-owner pieces are contiguous — no packing copies on either side of the all-to-all; over xGMI each peer's piece
+    rides its own link.  Arithmetic is unchanged: a row's gradient is the sum over all minibatches / W, exactly what
+    the replicated exchange computes; only where rows live differs (each rank's copy of the table is current for the
+    fields it owns; `sync_tables` makes every copy whole again, e.g. before predict / save).
+    Used by the fused DeepFM plan (deeptables_amd/fused.py); other graphs fall back to the replicated exchange."""
+
+    sharded_embeddings = True
+
+    def __init__(self, *args, force=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.force = force                       # run the sharded path even with one rank (single-GPU validation)
+        self._a2a_ok = None
+
+    @property
+    def active(self):
+        return self.world_size > 1 or self.force
+
+    def field_bounds(self, F):
+        """contiguous field ranges, the first F % W owners get one more"""
+        W = self.world_size
+        base, extra = divmod(F, W)
+        out, s = [], 0
+        for r in range(W):
+            n = base + (1 if r < extra else 0)
+            out.append((s, s + n))
+            s += n
+        return out
+
+    # -- collectives (all_to_all_single where the backend has it; gloo: all_gather + slice) -----------
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        W = self.world_size
+        if W == 1:
+            out.copy_(inp)
+            return
+        if self._a2a_ok is None:
+            self._a2a_ok = dist.get_backend(self.group) != 'gloo'
+        if self._a2a_ok:
+            dist.all_to_all_single(out, inp, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
+                                   group=self.group)
+            return
+        # gloo has no all_to_all: everybody gathers everybody's (padded) input and cuts its piece out
+        n = torch.tensor([inp.shape[0]], dtype=torch.int64)
+        sizes = [torch.zeros_like(n) for _ in range(W)]
+        dist.all_gather(sizes, n, group=self.group)
+        nmax = max(int(t.item()) for t in sizes)
+        pad = torch.zeros((nmax,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        pad[:inp.shape[0]] = inp
+        bufs = [torch.empty_like(pad) for _ in range(W)]
+        dist.all_gather(bufs, pad, group=self.group)
+        splits_of = [torch.zeros(W, dtype=torch.int64) for _ in range(W)]
+        dist.all_gather(splits_of, torch.tensor(list(in_splits), dtype=torch.int64), group=self.group)
+        o = 0
+        for src in range(W):
+            sp = [int(v) for v in splits_of[src]]
+            start = sum(sp[:self.rank])
+            k = sp[self.rank]
+            out[o:o + k] = bufs[src][start:start + k]
+            o += k
+
+    def gather_ids(self, idx, F):
+        """idx [B,F] int32 of the local minibatch -> ids [W, F_own, B] int32 of the fields this rank owns."""
+        W = self.world_size
+        B = idx.shape[0]
+        s, e = self.field_bounds(F)[self.rank]
+        if W == 1:
+            all_idx = idx.reshape(1, B, F)
+        else:
+            all_idx = torch.empty((W * B, F), dtype=idx.dtype, device=idx.device)
+            dist.all_gather_into_tensor(all_idx, idx.contiguous(), group=self.group)
+            all_idx = all_idx.view(W, B, F)
+        return all_idx[:, :, s:e].permute(0, 2, 1).contiguous()
+
+    def forward_exchange(self, emb_own, F, B, out=None):
+        """emb_own [W, F_own, B, D] (rows gathered by the owner) -> [F, B, D] for the local minibatch."""
+        D = emb_own.shape[-1]
+        bounds = self.field_bounds(F)
+        Fo = bounds[self.rank][1] - bounds[self.rank][0]
+        if out is None:
+            out = torch.empty((F * B, D), dtype=emb_own.dtype, device=emb_own.device)
+        self._all_to_all(out.view(F * B, D), emb_own.reshape(-1, D), [(e - s) * B for s, e in bounds],
+                         [Fo * B] * self.world_size)
+        return out.view(F, B, D)
+
+    def backward_exchange(self, grad_T, F, B, out=None):
+        """grad_T [F, B, D] (gradient of the local loss w.r.t. the received rows) -> [W, F_own, B, D] at the owner."""
+        D = grad_T.shape[-1]
+        bounds = self.field_bounds(F)
+        Fo = bounds[self.rank][1] - bounds[self.rank][0]
+        W = self.world_size
+        if out is None:
+            out = torch.empty((W * Fo * B, D), dtype=grad_T.dtype, device=grad_T.device)
+        self._all_to_all(out.view(W * Fo * B, D), grad_T.reshape(F * B, D), [Fo * B] * W,
+                         [(e - s) * B for s, e in bounds])
+        return out.view(W, Fo, B, D)
+
+    def sync_tables(self, emb_layer):
+        """Make every rank's copy of the packed tables whole again: each owner broadcasts its fields' rows."""
+        if self.world_size == 1:
+            return
+        for D, cols in emb_layer.groups:
+            key = f'd{D}'
+            table = emb_layer.tables[key]
+            offs = getattr(emb_layer, f'row_offset_{key}').tolist()
+            voc = getattr(emb_layer, f'vocab_{key}').tolist()
+            for r, (s, e) in enumerate(self.field_bounds(len(cols))):
+                if e > s:
+                    lo, hi = offs[s], offs[e - 1] + voc[e - 1]
+                    dist.broadcast(table.data[lo:hi], src=r, group=self.group)
+
+    def exchange_gradients(self, model):
+        """Dense gradients only — the embedding gradients already travelled to their owners inside the step."""
+        if self.world_size == 1:
+            return
+        if getattr(model, '_dt_sharded_step', False):
+            flat = getattr(model, '_dt_flat_grad', None)
+            if flat is not None:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(self.world_size)
+                base = flat.untyped_storage().data_ptr()
+                rest = [p for p in model.parameters() if p.requires_grad and p.grad is not None and
+                        p.grad.untyped_storage().data_ptr() != base]
+                if rest:
+                    self.allreduce_dense(rest)
+                return
+        super().exchange_gradients(model)

@@ -120,6 +120,10 @@ class KerasAdam:
                     values = torch.cat([g.values.reshape(-1, D) for g in grads])
                 n = rows.numel()
                 fields = len(dict(layer.groups)[D]) if hasattr(layer, 'groups') else 0
+                hints = {getattr(g, 'fields', None) for g in grads}
+                if hints != {None}:                       # an explicit layout promise overrides the layer default
+                    fields = hints.pop() if len(hints) == 1 else 0
+                    fields = 0 if fields is None else int(fields)
                 n_slots = lib().dt_adam_rows_slots(n)
                 if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
                     s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)

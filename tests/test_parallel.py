@@ -134,3 +134,84 @@ def test_world_size_one_is_a_no_op():
         assert st.allreduce_dense(list(lin.parameters())) == 0
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# ShardedEmbeddingStrategy: field-owned table rows, ids all-gather + two all-to-alls
+# ---------------------------------------------------------------------------------------------
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from deeptables_amd.parallel import ShardedEmbeddingStrategy
+    st = ShardedEmbeddingStrategy.from_env('gloo')
+    F, B, D, V = 5, 4, 3, 7                     # 5 fields over 3 ranks -> 2, 2, 1
+    bounds = st.field_bounds(F)
+    assert bounds == [(0, 2), (2, 4), (4, 5)] and st.active
+    g = torch.Generator().manual_seed(0)        # same on every rank: a replicated packed table [F*V, D]
+    table = torch.randn(F * V, D, generator=g)
+    row_offset = torch.arange(F) * V
+    idx_all = torch.randint(0, V, (world, B, F), generator=g, dtype=torch.int32)
+    idx = idx_all[rank]
+    s, e = bounds[rank]
+    # forward: ids -> owner gather -> all-to-all
+    ids_own = st.gather_ids(idx, F)
+    assert ids_own.shape == (world, e - s, B)
+    assert torch.equal(ids_own, idx_all[:, :, s:e].permute(0, 2, 1))
+    rows_own = ids_own.long() + row_offset[s:e].view(1, -1, 1)
+    emb_own = table[rows_own]                                          # [W, Fo, B, D] (stand-in for the HIP gather)
+    emb_T = st.forward_exchange(emb_own, F, B)
+    want = table[(idx.long() + row_offset[None, :])].permute(1, 0, 2)  # [F,B,D] of MY minibatch, all fields
+    assert torch.equal(emb_T, want)
+    # backward: per-row gradients travel to the owner; summed there they equal the dense-table gradient of all ranks
+    grad_all = torch.randn(world, F, B, D, generator=g)
+    grad_own = st.backward_exchange(grad_all[rank].contiguous(), F, B)
+    assert grad_own.shape == (world, e - s, B, D)
+    assert torch.equal(grad_own, grad_all[:, s:e])
+    dense = torch.zeros(F * V, D)
+    dense.index_add_(0, rows_own.reshape(-1), grad_own.reshape(-1, D))
+    ref = torch.zeros(F * V, D)
+    for r in range(world):
+        rows_r = (idx_all[r].long() + row_offset[None, :]).permute(1, 0)          # [F,B]
+        ref.index_add_(0, rows_r.reshape(-1), grad_all[r].reshape(-1, D))
+    lo, hi = row_offset[s].item(), row_offset[e - 1].item() + V
+    assert torch.allclose(dense[lo:hi], ref[lo:hi], atol=1e-6)         # complete for the fields I own ...
+    assert float(dense[:lo].abs().sum() + dense[hi:].abs().sum()) == 0.0   # ... and nothing else
+
+    # sync_tables: each owner's rows win
+    class Emb:
+        groups = [(D, list(range(F)))]
+        tables = {f'd{D}': table.clone() + (rank + 1) * 100.0}
+    setattr(Emb, f'row_offset_d{D}', row_offset)
+    setattr(Emb, f'vocab_d{D}', torch.full((F,), V))
+    st.sync_tables(Emb)
+    for r, (a, b) in enumerate(bounds):
+        assert torch.allclose(Emb.tables[f'd{D}'][a * V:b * V], table[a * V:b * V] + (r + 1) * 100.0)
+
+    # exchange_gradients in a sharded step: dense (flat) only, sparse gradients stay with the owner
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(2, 1)
+    m = M()
+    flat = torch.full((3,), float(rank))
+    m._dt_flat_grad, m._dt_sharded_step = flat, True
+    m.fc.weight.grad, m.fc.bias.grad = flat[:2].view(1, 2), flat[2:]
+    st.exchange_gradients(m)
+    assert torch.allclose(flat, torch.full((3,), 1.0))                 # mean of 0,1,2
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, 'ok'))
+
+
+def test_sharded_embedding_routing_world3_gloo():
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, 'ok'), (1, 'ok'), (2, 'ok')]
