@@ -57,12 +57,13 @@ SIGNATURES = {
     'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                  _ptr, _ptr, _ptr, _ptr]),
+    'dt_adam_state_init': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _c_int, _ptr]),
     'dt_adam_advance': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _ptr]),
     'dt_adam_dense_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32,
-                                    _ptr, _ptr]),
+                                    _ptr, _c_int, _c_f32, _ptr]),
     'dt_adam_rows_slots': (_c_i64, [_c_i64]),
     'dt_adam_rows_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
-                                   _c_f32, _c_f32, _c_f32, _ptr, _c_int, _c_f32, _ptr]),
+                                   _c_f32, _c_f32, _c_f32, _ptr, _ptr]),
     'dt_sgd_dense_step': (_c_int, [_ptr, _ptr, _c_i64, _c_f32, _ptr]),
     'dt_sgd_rows_step': (_c_int, [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr]),
     'dt_dense_supported': (_c_int, [_c_int] * 3),
@@ -84,7 +85,9 @@ SIGNATURES = {
     'dt_deepfm_accum_offsets': (_c_int, [_c_int, _c_int, _c_int, _ptr]),
     'dt_deepfm_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr]),
+                                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _ptr]),
+    'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),
+    'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
 }
 
 DT_IDX_F32, DT_IDX_I32 = 0, 1

@@ -74,6 +74,9 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// multiplicative hash of a packed table row id into `32 - shift` bits (row-dedupe hash tables)
+__device__ __forceinline__ unsigned hash_row(unsigned row, int shift) { return (row * 0x9E3779B1u) >> shift; }
+
 // categorical id -> int, reproducing keras.ops.cast(float32 -> int32) (truncation toward zero)
 template <int KIND>
 __device__ __forceinline__ int load_id(const void* idx, int64_t i) {

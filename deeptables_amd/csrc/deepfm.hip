@@ -61,6 +61,20 @@ __host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F,
     return a;
 }
 
+// Optional row dedupe inside the step (dt_deepfm_train_step, dedupe_ws != NULL): the sparse gradient leaves the step
+// with every table row appearing ONCE, so the row-sparse optimizer needs no dedupe pass of its own.
+//   A: every valid lookup inserts (row+1) << 32 | occurrence into an open-addressing hash with a 64-bit CAS.  The
+//      winner owns the row (mark = its slot); a later lookup of the same row is a duplicate: mark = -(owner)-2, it sets
+//      flags[owner], zeroes the owner's gradient row and reports row -1.
+//   G: owners without duplicates store their gradient row; owners with duplicates and the duplicates themselves
+//      atomicAdd into the owner's row; owners clear their hash slot and flag, so the workspace is all-zero again.
+struct DedupeWs {
+    unsigned long long* slots;   // [1 << slots_log2], zero outside a step
+    int slots_log2;
+    int* mark;                   // [B*F]
+    int* flags;                  // [B*F], zero outside a step
+};
+
 // ---------------------------------------------------------------------------------------------
 // A: sparse forward.  One wave = one batch row, 16 waves (16 rows) per block: 8192 waves at B = 8192, all
 //    resident at once (2 blocks of 1024 threads per CU) so the two dependent HBM round trips of a gather
@@ -74,7 +88,8 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
     const void* __restrict__ idx, const float4* __restrict__ table, const int64_t* __restrict__ row_offset,
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
-    int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial) {
+    int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial, DedupeWs dd,
+    float* __restrict__ grad_rows) {
     __shared__ __attribute__((aligned(16))) float rowbuf[kRowsPerBlockA][kMaxC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & (LPR - 1);
@@ -94,7 +109,35 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
                 const int64_t row = ok ? row_offset[f] + id : (int64_t)-1;
                 if (ok) v[t] = table[row * LPR + c];
                 if (c == 0) {
-                    rows_out[(int64_t)b * dm.F + f] = row;
+                    const int64_t occ = (int64_t)b * dm.F + f;
+                    int64_t row_w = row;
+                    if (dd.slots) {
+                        // ownership of the row for this step (see DedupeWs): the first lookup to claim the hash
+                        // slot owns it, later ones become duplicates that G folds into the owner's gradient row
+                        int mk = -1;
+                        if (ok) {
+                            const unsigned mask = (1u << dd.slots_log2) - 1u;
+                            unsigned h = hash_row((unsigned)row, 32 - dd.slots_log2);
+                            const unsigned long long mine =
+                                ((unsigned long long)(row + 1) << 32) | (unsigned long long)(unsigned)occ;
+                            for (;;) {
+                                const unsigned long long prev = atomicCAS(&dd.slots[h], 0ULL, mine);
+                                if (prev == 0ULL) { mk = (int)h; break; }
+                                if ((prev >> 32) == (unsigned long long)(row + 1)) {
+                                    const int64_t owner = (int64_t)(prev & 0xffffffffULL);
+                                    mk = -(int)owner - 2;
+                                    dd.flags[owner] = 1;                     // the owner's row is accumulated atomically:
+                                    float4* z = reinterpret_cast<float4*>(grad_rows + owner * D);   // start it from 0
+                                    for (int q = 0; q < LPR; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    row_w = -1;                              // not a separate row of the gradient
+                                    break;
+                                }
+                                h = (h + 1) & mask;
+                            }
+                        }
+                        dd.mark[occ] = mk;
+                    }
+                    rows_out[occ] = row_w;
                     if (!ok && oob) atomicAdd(oob, 1);
                 }
             }
@@ -867,7 +910,7 @@ __global__ __launch_bounds__(256) void k_sparse_bwd(const float* __restrict__ X,
                                                     const float* __restrict__ dz, MlpParams p,
                                                     const float* __restrict__ wlin, DeepFmDims dm,
                                                     const float* accum, DeepFmAccum al,
-                                                    float* __restrict__ grad_rows, float* dwlin_out) {
+                                                    float* __restrict__ grad_rows, float* dwlin_out, DedupeWs dd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NV = dm.F * LPR;
     const int D = 4 * LPR;
@@ -923,7 +966,31 @@ __global__ __launch_bounds__(256) void k_sparse_bwd(const float* __restrict__ X,
         o.y = ca[t].y * (gx[t].y - cm1[t].y - (x[t].y - cmu[t].y) * cm2[t].y) + lin_g + g * (S.y - x[t].y);
         o.z = ca[t].z * (gx[t].z - cm1[t].z - (x[t].z - cmu[t].z) * cm2[t].z) + lin_g + g * (S.z - x[t].z);
         o.w = ca[t].w * (gx[t].w - cm1[t].w - (x[t].w - cmu[t].w) * cm2[t].w) + lin_g + g * (S.w - x[t].w);
-        *reinterpret_cast<float4*>(grad_rows + (int64_t)b * dm.F * D + 4 * j) = o;
+        if (!dd.slots) {
+            *reinterpret_cast<float4*>(grad_rows + (int64_t)b * dm.F * D + 4 * j) = o;
+            continue;
+        }
+        const int f = j / LPR, c = j - f * LPR;
+        const int64_t occ = (int64_t)b * dm.F + f;
+        const int mk = dd.mark[occ];
+        int64_t target = occ;
+        bool atomic = false;
+        if (mk >= 0) {                       // owner
+            atomic = dd.flags[occ] != 0;
+            if (c == 0) {
+                dd.slots[mk] = 0ULL;
+                if (atomic) dd.flags[occ] = 0;
+            }
+        } else if (mk <= -2) {               // duplicate: into the owner's (zero-started) row
+            target = (int64_t)(-mk - 2);
+            atomic = true;
+        }
+        float* dst = grad_rows + target * D + 4 * c;
+        if (atomic) {
+            atomicAdd(dst, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
+        } else {
+            *reinterpret_cast<float4*>(dst) = o;
+        }
     }
 }
 
@@ -1005,6 +1072,16 @@ extern "C" int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11) {
     return DT_OK;
 }
 
+extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
+    int64_t s = 1024;
+    while (s < 8LL * B * F) s <<= 1;   // load <= 1/8 keeps the serialised probe chains short
+    return s;
+}
+
+extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) {
+    return dt_deepfm_dedupe_slots(B, F) * 8 + 2LL * B * F * 4;
+}
+
 extern "C" int dt_deepfm_train_step(
     const void* idx, int idx_kind, const float* table, const int64_t* row_offset, const int32_t* vocab,
     const float* dense, const float* y, int B, int F, int D, int Nd,
@@ -1012,7 +1089,7 @@ extern "C" int dt_deepfm_train_step(
     float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1, const float* W2,
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
-    int phases, void* stream) {
+    void* dedupe_ws, int64_t dedupe_slots, int phases, void* stream) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
@@ -1029,6 +1106,18 @@ extern "C" int dt_deepfm_train_step(
                  ws + wl.betap};
     const int blocksA = ceil_div(B, kRowsPerBlockA);
     const int tiles = ceil_div(B, kTM);
+    DedupeWs dd{nullptr, 0, nullptr, nullptr};
+    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach G, which empties the hash again
+        int lg = 0;
+        while ((1LL << lg) < dedupe_slots) ++lg;
+        DT_REQUIRE((1LL << lg) == dedupe_slots && dedupe_slots >= 2LL * B * F && lg <= 31 &&
+                       (int64_t)B * F < (1LL << 31),
+                   "dt_deepfm_train_step: dedupe_slots=%lld must be a power of two >= 2*B*F", (long long)dedupe_slots);
+        dd.slots = reinterpret_cast<unsigned long long*>(dedupe_ws);
+        dd.slots_log2 = lg;
+        dd.mark = reinterpret_cast<int*>(dd.slots + dedupe_slots);
+        dd.flags = dd.mark + (int64_t)B * F;
+    }
     static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
 
     // A  (DT_A_DYNLDS: experiment knob — extra dynamic LDS caps residency to one 1024-thread block per CU)
@@ -1036,7 +1125,7 @@ extern "C" int dt_deepfm_train_step(
 #define DT_A(KIND, L)                                                                                        \
     hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), a_dyn_lds, st, idx, (const float4*)table,  \
                        row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, rows_out,    \
-                       oob_count, ws + wl.bnp)
+                       oob_count, ws + wl.bnp, dd, grad_rows)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
@@ -1087,7 +1176,7 @@ extern "C" int dt_deepfm_train_step(
 #define DT_G(L)                                                                                              \
     case L:                                                                                                  \
         hipLaunchKernelGGL((k_sparse_bwd<L>), dim3(gblocks), dim3(256), 0, st, ws + wl.X, ws + wl.dXn,       \
-                           ws + wl.dz, mp, w_lin, dm, accum, al, grad_rows, accum + al.dwlin);                                 \
+                           ws + wl.dz, mp, w_lin, dm, accum, al, grad_rows, accum + al.dwlin, dd);                             \
         break;
         switch (lpr) { DT_G(1) DT_G(2) DT_G(4) DT_G(8) DT_G(16) DT_G(32) DT_G(64) }
 #undef DT_G

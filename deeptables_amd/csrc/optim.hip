@@ -16,23 +16,41 @@
 
 namespace dt {
 
-// device-resident step state (8 bytes): int32 t, float lr_t.  Keeping it on the device makes the whole
-// optimizer step replayable from a hipGraph (no host scalar baked into the captured launches).
+// device-resident step state (16 bytes): t = the step number the NEXT update uses (1-based), lr_t = its
+// bias-corrected rate, done = block counter of the kernel that advances the state.  Keeping it on the device makes the
+// whole optimizer step replayable from a hipGraph (no host scalar baked into the captured launches).  The state is
+// advanced at the END of a step by the last block of the last kernel the host launches for that step (every block
+// has read lr_t by then), so advancing costs no launch of its own.
 struct AdamState {
     int t;
     float lr_t;
+    unsigned done;
+    int pad;
 };
+
+__device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, int t) {
+    // float is enough: the factor multiplies a 1e-3 step (tests/test_optim_gpu.py checks 5 steps to 2e-6 absolute),
+    // and a double pow costs microseconds on one lane at the tail of the step's last kernel
+    return lr * sqrtf(1.0f - powf(b2, (float)t)) / (1.0f - powf(b1, (float)t));
+}
+
+__global__ void k_adam_state_init(AdamState* st, float lr, float b1, float b2, int steps_done) {
+    st->t = steps_done + 1;
+    st->lr_t = adam_lr_t(lr, b1, b2, steps_done + 1);
+    st->done = 0u;
+    st->pad = 0;
+}
 
 __global__ void k_adam_advance(AdamState* st, float lr, float b1, float b2) {
     const int t = st->t + 1;
     st->t = t;
-    st->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    st->lr_t = adam_lr_t(lr, b1, b2, t);
 }
 
 __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                    float lr_host, const AdamState* __restrict__ st, float b1,
-                                                    float b2, float eps) {
+                                                    float lr_host, AdamState* __restrict__ st, float b1, float b2,
+                                                    float eps, int advance, float lr) {
     const float lr_t = st ? st->lr_t : lr_host;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -43,6 +61,19 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
         v[i] = vi;
         p[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
+    if (advance && st) {          // the last block to get here has seen every block read lr_t
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // no fence: nothing this block WROTE has to be seen by the advancing block, and its read of lr_t has
+            // completed (the value was consumed above); a device-wide fence here writes back the whole L2 (+4 us)
+            if (atomicAdd(&st->done, 1u) == gridDim.x - 1) {
+                st->done = 0u;
+                const int t = st->t + 1;
+                st->t = t;
+                st->lr_t = adam_lr_t(lr, b1, b2, t);
+            }
+        }
+    }
 }
 
 // ---- row-sparse ("lazy") Adam on (rows, values) pairs --------------------------------------------------------
@@ -52,7 +83,6 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
 // themselves done.  Pass 2 (k_adam_rows_owner): D/4 lanes per owner read the merged gradient (coalesced), update
 // p/m/v of that one table row (16-byte pieces), and the owner clears its hash slot so the table is empty again for
 // the next step — no dense gradient scratch table, no per-row epoch array, no memset.
-__device__ __forceinline__ unsigned hash_row(unsigned row, int shift) { return (row * 0x9E3779B1u) >> shift; }
 
 // dst[0..D) += src[0..D) with atomics.  dst and src live in the same buffer, so the compiler must keep every load
 // behind the previous atomic; loading a chunk into registers first keeps the loads independent (one latency, not D).
@@ -108,8 +138,7 @@ __global__ __launch_bounds__(256) void k_rows_dedupe(const int64_t* __restrict__
 // duplicate count above them).  Rows looked up kHotMin+ times in the step (skewed ids: the head of a Zipf
 // distribution, low-cardinality columns) get an LDS accumulator: their occurrences are summed with LDS atomics and
 // the owner's gradient row is overwritten with the sum, so the hot rows never serialise on one global address.  The
-// remaining (rare) duplicates add into their owner's row with global atomics.  Block 0 also advances the
-// optimizer's step state when asked (this kernel does not read it, the later passes do).
+// remaining (rare) duplicates add into their owner's row with global atomics.
 constexpr int kFieldSlotsLog2 = 14;
 constexpr int kFieldSlots = 1 << kFieldSlotsLog2;
 constexpr int kOwnerBits = 13;                  // up to 8192 lookups per field
@@ -118,8 +147,7 @@ constexpr int kHotBytes = 30 * 1024;            // LDS left for the hot accumula
 
 __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __restrict__ rows,
                                                              float* __restrict__ values, int64_t n, int D, int fields,
-                                                             int* __restrict__ mark, AdamState* st_adv, float lr,
-                                                             float b1, float b2) {
+                                                             int* __restrict__ mark) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
     unsigned* keys = lds_u;                                  // [kFieldSlots] row+1, 0 = empty; later: hot index+1
     unsigned* oc = lds_u + kFieldSlots;                      // [kFieldSlots] owner index | dup count << 13
@@ -129,11 +157,6 @@ __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __re
     const int cnt = (int)(n / fields);
     const int accs = D + 1;                                  // odd stride: hot rows spread over the banks
     const int hot_cap = kHotBytes / (4 * accs);
-    if (f == 0 && threadIdx.x == 0 && st_adv) {
-        const int t = st_adv->t + 1;
-        st_adv->t = t;
-        st_adv->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
-    }
     // this thread's (up to 8) lookups: all loads issued before the first LDS atomic, kept in registers
     constexpr int kPer = kFieldSlots / 2 / 1024;
     int64_t row[kPer];
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
     const int64_t occ = gt / lpr;
     const int part = (int)(gt - occ * lpr);
     if (occ >= n) return;
-    const int slot = mark[occ];
+    const int slot = mark ? mark[occ] : (rows[occ] >= 0 ? 0 : -1);   // no mark: rows are already distinct
     if (slot < 0) return;
     const float lr_t = st ? st->lr_t : lr_host;
     const int64_t i0 = rows[occ] * D + part * VW;
@@ -304,6 +327,13 @@ extern "C" int dt_sgd_rows_step(float* table, const int64_t* rows, const float* 
 }
 
 
+extern "C" int dt_adam_state_init(void* state, float lr, float beta1, float beta2, int steps_done, void* stream) {
+    DT_REQUIRE(state && steps_done >= 0, "dt_adam_state_init: bad arguments");
+    hipLaunchKernelGGL(k_adam_state_init, dim3(1), dim3(1), 0, as_stream(stream), (AdamState*)state, lr, beta1, beta2,
+                       steps_done);
+    return launch_status("dt_adam_state_init");
+}
+
 extern "C" int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream) {
     DT_REQUIRE(state, "dt_adam_advance: null state");
     hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, as_stream(stream), (AdamState*)state, lr, beta1, beta2);
@@ -311,65 +341,70 @@ extern "C" int dt_adam_advance(void* state, float lr, float beta1, float beta2, 
 }
 
 extern "C" int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
-                                  float beta1, float beta2, float eps, const void* state, void* stream) {
+                                  float beta1, float beta2, float eps, void* state, int advance, float lr,
+                                  void* stream) {
     DT_REQUIRE(n >= 0, "dt_adam_dense_step: n < 0");
-    if (n == 0) return DT_OK;
+    DT_REQUIRE(!advance || state, "dt_adam_dense_step: advance needs the device state");
+    if (n == 0) {
+        if (advance) return dt_adam_advance(state, lr, beta1, beta2, stream);
+        return DT_OK;
+    }
     DT_REQUIRE(p && g && m && v, "dt_adam_dense_step: null pointer");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adam_dense, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr_t,
-                       (const AdamState*)state, beta1, beta2, eps);
+                       (AdamState*)state, beta1, beta2, eps, advance, lr);
     return launch_status("dt_adam_dense_step");
 }
 
 extern "C" int64_t dt_adam_rows_slots(int64_t n_rows) {
     int64_t s = 1024;
-    while (s < 2 * n_rows) s <<= 1;
+    while (s < 8 * n_rows) s <<= 1;   // load <= 1/8: probe chains are serialised device atomics (21 -> 12 us at 213 K rows)
     return s;
 }
 
 extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
                                  int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t,
-                                 float beta1, float beta2, float eps, void* state, int advance, float lr,
-                                 void* stream) {
-    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= 0, "dt_adam_rows_step: bad sizes");
-    DT_REQUIRE(!advance || state, "dt_adam_rows_step: advance needs the device state");
+                                 float beta1, float beta2, float eps, const void* state, void* stream) {
+    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -1, "dt_adam_rows_step: bad sizes");
+    if (n_rows == 0) return DT_OK;
     hipStream_t st = as_stream(stream);
-    AdamState* as = (AdamState*)state;
-    if (n_rows == 0) {
-        if (advance) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, st, as, lr, beta1, beta2);
-        return launch_status("dt_adam_rows_step");
-    }
-    DT_REQUIRE(table && m && v && rows && values && mark, "dt_adam_rows_step: null pointer");
+    const AdamState* as = (const AdamState*)state;
+    DT_REQUIRE(table && m && v && rows && values, "dt_adam_rows_step: null pointer");
     DT_REQUIRE(n_rows < (1LL << 31), "dt_adam_rows_step: %lld occurrences do not fit the 32-bit slot field",
                (long long)n_rows);
-    const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2;
     unsigned long long* gslots = nullptr;
-    if (field_local) {
-        const size_t lds = (size_t)kFieldSlots * 8 + kHotBytes;
-        DT_UNSUPPORTED(D + 1 > kHotBytes / 4, "dt_adam_rows_step: D=%d too large", D);
-        hipFuncSetAttribute((const void*)k_rows_dedupe_fields, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_rows_dedupe_fields, dim3(fields), dim3(1024), lds, st, rows, values, n_rows, D, fields, mark,
-                           advance ? as : nullptr, lr, beta1, beta2);
+    int* mk = mark;
+    if (fields == -1) {
+        mk = nullptr;                                      // rows are already distinct: no dedupe pass
     } else {
-        DT_REQUIRE(slots, "dt_adam_rows_step: null slots");
-        int lg = 0;
-        while ((1LL << lg) < n_slots) ++lg;
-        DT_REQUIRE((1LL << lg) == n_slots && n_slots >= 2 * n_rows && lg <= 31 && lg >= 1,
-                   "dt_adam_rows_step: n_slots=%lld must be a power of two >= 2*n_rows", (long long)n_slots);
-        gslots = (unsigned long long*)slots;
-        if (advance) hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, st, as, lr, beta1, beta2);
-        hipLaunchKernelGGL(k_rows_dedupe, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, rows, values, n_rows,
-                           D, gslots, lg, mark);
+        DT_REQUIRE(mark, "dt_adam_rows_step: null mark");
+        const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2;
+        if (field_local) {
+            const size_t lds = (size_t)kFieldSlots * 8 + kHotBytes;
+            DT_UNSUPPORTED(D + 1 > kHotBytes / 4, "dt_adam_rows_step: D=%d too large", D);
+            hipFuncSetAttribute((const void*)k_rows_dedupe_fields, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_rows_dedupe_fields, dim3(fields), dim3(1024), lds, st, rows, values, n_rows, D, fields,
+                               mark);
+        } else {
+            DT_REQUIRE(slots, "dt_adam_rows_step: null slots");
+            int lg = 0;
+            while ((1LL << lg) < n_slots) ++lg;
+            DT_REQUIRE((1LL << lg) == n_slots && n_slots >= 2 * n_rows && lg <= 31 && lg >= 1,
+                       "dt_adam_rows_step: n_slots=%lld must be a power of two >= 2*n_rows", (long long)n_slots);
+            gslots = (unsigned long long*)slots;
+            hipLaunchKernelGGL(k_rows_dedupe, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, rows, values,
+                               n_rows, D, gslots, lg, mark);
+        }
     }
     if (D % 4 == 0) {
         const int64_t threads = n_rows * (D / 4);
         hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
-                           rows, values, n_rows, D, gslots, mark, lr_t, as, beta1, beta2, eps);
+                           rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps);
     } else {
         const int64_t threads = n_rows * D;
         hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
-                           rows, values, n_rows, D, gslots, mark, lr_t, as, beta1, beta2, eps);
+                           rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps);
     }
     return launch_status("dt_adam_rows_step");
 }

@@ -95,6 +95,8 @@ class FusedDeepFM:
         if self.out.bias is not None:
             self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
         self.loss_view = a[o['loss']:o['loss'] + 1]
+        # duplicate lookups are resolved inside the step (kernels A and G) unless DT_AMD_FUSED_DEDUPE=0
+        self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
         # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
         # the model with ONE launch over (flat_params, accum) instead of one launch per tensor.
         self.flat_params = torch.zeros_like(self.accum)
@@ -121,7 +123,10 @@ class FusedDeepFM:
             b = {'ws': torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev),
                  'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
                  'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
-                 'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev)}
+                 'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),
+                 'dedupe': torch.zeros((lib().dt_deepfm_dedupe_bytes(B, self.F) + 7) // 8, dtype=torch.int64,
+                                       device=dev),
+                 'dedupe_slots': lib().dt_deepfm_dedupe_slots(B, self.F)}
             self._bufs[B] = b
         return b
 
@@ -184,7 +189,7 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, 2, stream_ptr()), 'dt_deepfm_train_step')
+            None, None, 0, 2, stream_ptr()), 'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
         # the loss is a mean over the LOCAL minibatch; the global objective is the mean over W of them
@@ -220,13 +225,15 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            ptr(self.emb.oob_count) if self.emb.check_oob else None, 2 if backward else 1, stream_ptr()),
-            'dt_deepfm_train_step')
+            ptr(self.emb.oob_count) if self.emb.check_oob else None,
+            ptr(buf['dedupe']) if (backward and self.dedupe) else None, buf['dedupe_slots'],
+            2 if backward else 1, stream_ptr()), 'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
-            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1),
-                                                             buf['grad_rows'].view(-1, self.D))]
+            # with the in-step dedupe every table row appears once (duplicates report row -1, the owner holds the sum)
+            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
+                                                             fields=-1 if self.dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)

@@ -55,15 +55,18 @@ class KerasAdam:
         self._dev_state = None        # int32 view of 8 bytes: [t, bits(lr_t)]
         self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param)})
 
-    # -- step counter ----------------------------------------------------------------------------
+    # -- step counter (device resident: int32 t_next, float lr_t, uint32 block counter, pad) -------------
     def _state_tensor(self, device):
         if self._dev_state is None:
-            self._dev_state = torch.zeros(2, dtype=torch.int32, device=device)
+            self._dev_state = torch.zeros(4, dtype=torch.int32, device=device)
+            check(lib().dt_adam_state_init(ptr(self._dev_state), self.lr, self.b1, self.b2, 0, stream_ptr()),
+                  'dt_adam_state_init')
         return self._dev_state
 
     @property
     def t(self):
-        return 0 if self._dev_state is None else int(self._dev_state[0].item())
+        """number of completed steps (keras `optimizer.iterations`)"""
+        return 0 if self._dev_state is None else int(self._dev_state[0].item()) - 1
 
     @t.setter
     def t(self, value):
@@ -71,7 +74,8 @@ class KerasAdam:
             if not self.params:
                 return
             self._state_tensor(self.params[0].device)
-        self._dev_state[0] = int(value)
+        check(lib().dt_adam_state_init(ptr(self._dev_state), self.lr, self.b1, self.b2, int(value), stream_ptr()),
+              'dt_adam_state_init')
 
     def _st(self, p):
         s = self.state.get(id(p))
@@ -105,9 +109,7 @@ class KerasAdam:
         dev_state = self._state_tensor(self.params[0].device)
         st = stream_ptr()
         sp = ptr(dev_state)
-        advanced = False
-        # sparse tables first: the first pass of dt_adam_rows_step (row dedupe) does not read the step state, so the
-        # t += 1 / lr_t update rides along in it instead of costing a launch of its own
+        # every launch of the step reads lr_t from the device state; the LAST one advances it (no extra launch)
         for layer in self.embedding_layers:
             for key, grads in layer.sparse_grads.items():
                 table = layer.tables[key]
@@ -124,20 +126,24 @@ class KerasAdam:
                 if hints != {None}:                       # an explicit layout promise overrides the layer default
                     fields = hints.pop() if len(hints) == 1 else 0
                     fields = 0 if fields is None else int(fields)
-                n_slots = lib().dt_adam_rows_slots(n)
-                if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
-                    s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)
-                    s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
-                    s['n_slots'] = n_slots
+                if fields == -1 and len(grads) != 1:
+                    fields = 0                            # distinct within each piece only
                 values = values if values.is_contiguous() else values.contiguous()
+                if fields == -1:
+                    slots = mark = None
+                    n_slots = 0
+                else:
+                    n_slots = lib().dt_adam_rows_slots(n)
+                    if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
+                        s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)
+                        s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
+                        s['n_slots'] = n_slots
+                    slots, mark, n_slots = s['slots'], s['mark'], s['n_slots']
                 check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
-                                              D, fields, ptr(s['slots']), s['n_slots'], ptr(s['mark']), 0.0,
-                                              self.b1, self.b2, self.eps, sp, 0 if advanced else 1, self.lr, st),
-                      'dt_adam_rows_step')
-                advanced = True
+                                              D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
+                                              self.b1, self.b2, self.eps, sp, st), 'dt_adam_rows_step')
             layer.sparse_grads.clear()
-        if not advanced:
-            check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
+        launches = []                                     # (param ptr, grad ptr, m ptr, v ptr, n) + keep-alive refs
         flat_done = set()
         if self._flat is not None:
             fp, fg, fm, fv, n, members = self._flat
@@ -145,16 +151,19 @@ class KerasAdam:
             in_flat = [p for p in self.params if id(p) in members and p.grad is not None and
                        p.grad.data_ptr() == base + 4 * members[id(p)]]
             if len(in_flat) == len(members):       # every member's gradient is its flat view: one launch
-                check(lib().dt_adam_dense_step(ptr(fp), ptr(fg), ptr(fm), ptr(fv), n, 0.0, self.b1, self.b2,
-                                               self.eps, sp, st), 'dt_adam_dense_step')
+                launches.append((fp, fg, fm, fv, n))
                 flat_done = set(members)
         for p in self.params:
             if p.grad is None or id(p) in flat_done:
                 continue
             s = self._st(p)
-            g = p.grad.contiguous()
-            check(lib().dt_adam_dense_step(ptr(p.data), ptr(g), ptr(s['m']), ptr(s['v']), p.numel(), 0.0,
-                                           self.b1, self.b2, self.eps, sp, st), 'dt_adam_dense_step')
+            launches.append((p.data, p.grad.contiguous(), s['m'], s['v'], p.numel()))
+        if not launches:
+            check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
+        for i, (pp, gg, mm, vv, n) in enumerate(launches):
+            last = 1 if i == len(launches) - 1 else 0
+            check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
+                                           sp, last, self.lr, st), 'dt_adam_dense_step')
 
 
 class SGD:

@@ -189,17 +189,21 @@ int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float*
  * left all zero on return; mark: n int32 scratch — then every distinct row's p/m/v is updated once.
  * fields > 0 promises that rows is laid out [.., fields] over a packed table whose fields own disjoint row
  * ranges (MultiColumnEmbedding): each field then dedupes in LDS (one workgroup per field, up to 8192 lookups
- * per field) and `slots` is not touched.  advance != 0 folds dt_adam_advance(state, lr, ..) into the first pass.
- * `state` (8 device bytes: int32 t, float lr_t; may be NULL): when given, lr_t is READ FROM THE DEVICE instead
- * of the scalar argument, so a captured hipGraph of the whole step replays correctly;
- * dt_adam_advance(state, lr, b1, b2) does t += 1 and recomputes lr_t on the device.                 */
+ * per field) and `slots` is not touched.  fields = -1: the rows are already distinct (e.g. deduplicated by
+ * dt_deepfm_train_step) — no dedupe pass, slots/mark may be NULL.
+ * `state` (16 device bytes, may be NULL): {int32 t = the step the NEXT update uses, float lr_t for that step,
+ * uint32 block counter, pad}.  When given, lr_t is READ FROM THE DEVICE instead of the scalar argument, so a
+ * captured hipGraph of the whole step replays correctly.  dt_adam_state_init writes it for `steps_done` completed
+ * steps; the state is advanced (t += 1, lr_t recomputed) either by dt_adam_advance or — with no launch of its own —
+ * by the last block of a dt_adam_dense_step called with advance != 0, which must be the LAST launch of the step.  */
+int dt_adam_state_init(void* state, float lr, float beta1, float beta2, int steps_done, void* stream);
 int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
 int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
-                       float beta1, float beta2, float eps, const void* state, void* stream);
+                       float beta1, float beta2, float eps, void* state, int advance, float lr, void* stream);
 int64_t dt_adam_rows_slots(int64_t n_rows);
 int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
                       int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
-                      float beta2, float eps, void* state, int advance, float lr, void* stream);
+                      float beta2, float eps, const void* state, void* stream);
 
 /* keras.optimizers.SGD (momentum 0), selectable through ModelConfig.optimizer (deepmodel.py:319-323):
  * p -= lr*g; the rows variant applies the (rows, values) gradient directly (duplicate rows add up).   */
@@ -263,7 +267,13 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * (IndexedSlices indices/values); accum: dt_deepfm_accum_floats() floats holding every dense gradient
  * and the mean loss at the offsets reported by dt_deepfm_accum_offsets() in the order
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
- * phases: 1 = forward only (logits + loss), 2 = forward + backward.                               */
+ * phases: 1 = forward only (logits + loss), 2 = forward + backward.
+ * dedupe_ws (may be NULL): dt_deepfm_dedupe_bytes(B,F) bytes, ALL ZERO on entry and left all zero on return, with
+ * dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step resolves duplicate lookups
+ * itself: each table row appears once in rows_out (later lookups of it report -1) and its grad_rows entry holds the
+ * SUM over all its lookups — dt_adam_rows_step can then be called with fields = -1 (no dedupe pass).            */
+int64_t dt_deepfm_dedupe_slots(int B, int F);
+int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
 int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
@@ -277,7 +287,7 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
                          const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* w3, const float* w_out, const float* b_out, float* logit_out,
                          int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
-                         int* oob_count, int phases, void* stream);
+                         int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases, void* stream);
 
 #ifdef __cplusplus
 }

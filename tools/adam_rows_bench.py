@@ -8,9 +8,11 @@ dev = torch.device('cuda')
 B, F, D, V = 8192, 26, 16, 1_000_000
 table = torch.zeros(F * V, D, device=dev)
 m, v = torch.zeros_like(table), torch.zeros_like(table)
-state = torch.zeros(2, dtype=torch.int32, device=dev)
+state = torch.zeros(4, dtype=torch.int32, device=dev)
+check(lib().dt_adam_state_init(ptr(state), 1e-3, 0.9, 0.999, 0, stream_ptr()), 'init')
 n = B * F
-slots = torch.zeros(lib().dt_adam_rows_slots(n), dtype=torch.int64, device=dev)
+SLOT_MULT = int(os.environ.get('SLOT_MULT', '1'))
+slots = torch.zeros(lib().dt_adam_rows_slots(n) * SLOT_MULT, dtype=torch.int64, device=dev)
 mark = torch.empty(n, dtype=torch.int32, device=dev)
 vals = torch.randn(n, D, device=dev)
 off = (torch.arange(F, device=dev) * V)[None, :]
@@ -19,7 +21,7 @@ off = (torch.arange(F, device=dev) * V)[None, :]
 def run(rows, fields, tag):
     def once():
         check(lib().dt_adam_rows_step(ptr(table), ptr(m), ptr(v), ptr(rows), ptr(vals), n, D, fields, ptr(slots),
-                                      slots.numel(), ptr(mark), 0.0, 0.9, 0.999, 1e-7, ptr(state), 1, 1e-3, stream_ptr()), 'x')
+                                      slots.numel(), ptr(mark), 0.0, 0.9, 0.999, 1e-7, ptr(state), stream_ptr()), 'x')
     for _ in range(5):
         once()
     torch.cuda.synchronize()
