@@ -21,11 +21,13 @@ namespace dt {
 // whole optimizer step replayable from a hipGraph (no host scalar baked into the captured launches).  The state is
 // advanced at the END of a step by the last block of the last kernel the host launches for that step (every block
 // has read lr_t by then), so advancing costs no launch of its own.
+constexpr int kAdamSub = 64;
 struct AdamState {
     int t;
     float lr_t;
-    unsigned done;
+    unsigned done;            // sub-counters completed
     int pad;
+    unsigned sub[kAdamSub];   // blocks arrived, by blockIdx % kAdamSub (spreads the arrivals over 64 addresses)
 };
 
 __device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, int t) {
@@ -39,6 +41,7 @@ __global__ void k_adam_state_init(AdamState* st, float lr, float b1, float b2, i
     st->lr_t = adam_lr_t(lr, b1, b2, steps_done + 1);
     st->done = 0u;
     st->pad = 0;
+    for (int k = 0; k < kAdamSub; ++k) st->sub[k] = 0u;
 }
 
 __global__ void k_adam_advance(AdamState* st, float lr, float b1, float b2) {
@@ -47,26 +50,39 @@ __global__ void k_adam_advance(AdamState* st, float lr, float b1, float b2) {
     st->lr_t = adam_lr_t(lr, b1, b2, t);
 }
 
-__global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                    float lr_host, AdamState* __restrict__ st, float b1, float b2,
-                                                    float eps, int advance, float lr) {
-    const float lr_t = st ? st->lr_t : lr_host;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+struct DenseTail {              // a dense Adam update riding along another launch's trailing blocks
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+};
+
+__device__ __forceinline__ void adam_dense_range(const DenseTail& d, int64_t first, int64_t stride, float lr_t,
+                                                 float b1, float b2, float eps) {
+    for (int64_t i = first; i < d.n; i += stride) {
+        const float gi = d.g[i];
+        const float mi = b1 * d.m[i] + (1.f - b1) * gi;
+        const float vi = b2 * d.v[i] + (1.f - b2) * gi * gi;
+        d.m[i] = mi;
+        d.v[i] = vi;
+        d.p[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
-    if (advance && st) {          // the last block to get here has seen every block read lr_t
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // no fence: nothing this block WROTE has to be seen by the advancing block, and its read of lr_t has
-            // completed (the value was consumed above); a device-wide fence here writes back the whole L2 (+4 us)
-            if (atomicAdd(&st->done, 1u) == gridDim.x - 1) {
+}
+
+// call from every thread at the end of a step's LAST kernel: the last block to arrive advances the state
+__device__ __forceinline__ void adam_advance_by_last_block(AdamState* st, float lr, float b1, float b2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // no fence: nothing this block WROTE has to be seen by the advancing block, and its read of lr_t has
+        // completed (the value was consumed); a device-wide fence here writes back the whole L2 (+4 us)
+        // thousands of blocks arriving on ONE address serialise (a 3,600-block launch took +23 us): two levels
+        const unsigned k = blockIdx.x % kAdamSub;
+        const unsigned expect = (gridDim.x + kAdamSub - 1 - k) / kAdamSub;       // blocks with this residue
+        if (atomicAdd(&st->sub[k], 1u) == expect - 1) {
+            st->sub[k] = 0u;
+            const unsigned groups = gridDim.x < (unsigned)kAdamSub ? gridDim.x : (unsigned)kAdamSub;
+            if (atomicAdd(&st->done, 1u) == groups - 1) {
                 st->done = 0u;
                 const int t = st->t + 1;
                 st->t = t;
@@ -74,6 +90,17 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    float lr_host, AdamState* __restrict__ st, float b1, float b2,
+                                                    float eps, int advance, float lr) {
+    const float lr_t = st ? st->lr_t : lr_host;
+    const DenseTail d{p, g, m, v, n};
+    adam_dense_range(d, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, lr_t, b1, b2,
+                     eps);
+    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
 }
 
 // ---- row-sparse ("lazy") Adam on (rows, values) pairs --------------------------------------------------------
@@ -239,13 +266,39 @@ __global__ __launch_bounds__(1024) void k_rows_dedupe_fields(const int64_t* __re
 }
 
 template <int VW>
+__device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, float* __restrict__ m,
+                                                     float* __restrict__ v, const int64_t* __restrict__ rows,
+                                                     const float* __restrict__ values, int64_t n, int D,
+                                                     unsigned long long* __restrict__ slots,
+                                                     const int* __restrict__ mark, float lr_t, float b1, float b2,
+                                                     float eps);
+
+template <int VW>
 __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ table, float* __restrict__ m,
                                                          float* __restrict__ v, const int64_t* __restrict__ rows,
                                                          const float* __restrict__ values, int64_t n, int D,
                                                          unsigned long long* __restrict__ slots,
                                                          const int* __restrict__ mark, float lr_host,
-                                                         const AdamState* __restrict__ st, float b1, float b2,
-                                                         float eps) {
+                                                         AdamState* __restrict__ st, float b1, float b2, float eps,
+                                                         int row_blocks, DenseTail tail, int advance, float lr) {
+    const float lr_t = st ? st->lr_t : lr_host;
+    if ((int)blockIdx.x >= row_blocks) {      // trailing blocks: the model's dense parameters (one flat buffer)
+        adam_dense_range(tail, (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x,
+                         (int64_t)(gridDim.x - row_blocks) * blockDim.x, lr_t, b1, b2, eps);
+        if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+        return;
+    }
+    adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps);
+    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+}
+
+template <int VW>
+__device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, float* __restrict__ m,
+                                                     float* __restrict__ v, const int64_t* __restrict__ rows,
+                                                     const float* __restrict__ values, int64_t n, int D,
+                                                     unsigned long long* __restrict__ slots,
+                                                     const int* __restrict__ mark, float lr_t, float b1, float b2,
+                                                     float eps) {
     const int lpr = D / VW;
     const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t occ = gt / lpr;
@@ -253,7 +306,6 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
     if (occ >= n) return;
     const int slot = mark ? mark[occ] : (rows[occ] >= 0 ? 0 : -1);   // no mark: rows are already distinct
     if (slot < 0) return;
-    const float lr_t = st ? st->lr_t : lr_host;
     const int64_t i0 = rows[occ] * D + part * VW;
     const float* gsrc = values + occ * D + part * VW;
     float gi[VW], mi[VW], vi[VW], pi[VW];
@@ -365,11 +417,22 @@ extern "C" int64_t dt_adam_rows_slots(int64_t n_rows) {
 
 extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
                                  int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t,
-                                 float beta1, float beta2, float eps, const void* state, void* stream) {
-    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -1, "dt_adam_rows_step: bad sizes");
-    if (n_rows == 0) return DT_OK;
+                                 float beta1, float beta2, float eps, void* state, float* dense_p,
+                                 const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int advance,
+                                 float lr, void* stream) {
+    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -1 && dense_n >= 0, "dt_adam_rows_step: bad sizes");
+    DT_REQUIRE(!advance || state, "dt_adam_rows_step: advance needs the device state");
+    DT_REQUIRE(dense_n == 0 || (dense_p && dense_g && dense_m && dense_v), "dt_adam_rows_step: null dense tail");
+    if (n_rows == 0)      // nothing sparse this step: the tail (and the advance) run as a plain dense step
+        return (dense_n > 0 || advance)
+                   ? dt_adam_dense_step(dense_p, dense_g, dense_m, dense_v, dense_n, lr_t, beta1, beta2, eps, state,
+                                        advance, lr, stream)
+                   : DT_OK;
     hipStream_t st = as_stream(stream);
-    const AdamState* as = (const AdamState*)state;
+    AdamState* as = (AdamState*)state;
+    const DenseTail tail{dense_p, dense_g, dense_m, dense_v, dense_n};
+    int tail_blocks = (int)((dense_n + 255) / 256);
+    if (tail_blocks > 1024) tail_blocks = 1024;
     DT_REQUIRE(table && m && v && rows && values, "dt_adam_rows_step: null pointer");
     DT_REQUIRE(n_rows < (1LL << 31), "dt_adam_rows_step: %lld occurrences do not fit the 32-bit slot field",
                (long long)n_rows);
@@ -398,13 +461,15 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
         }
     }
     if (D % 4 == 0) {
-        const int64_t threads = n_rows * (D / 4);
-        hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
-                           rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps);
+        const int row_blocks = (int)((n_rows * (D / 4) + 255) / 256);
+        hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
+                           v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
+                           lr);
     } else {
-        const int64_t threads = n_rows * D;
-        hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, table, m, v,
-                           rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps);
+        const int row_blocks = (int)((n_rows * D + 255) / 256);
+        hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
+                           v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
+                           lr);
     }
     return launch_status("dt_adam_rows_step");
 }

@@ -55,10 +55,10 @@ class KerasAdam:
         self._dev_state = None        # int32 view of 8 bytes: [t, bits(lr_t)]
         self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param)})
 
-    # -- step counter (device resident: int32 t_next, float lr_t, uint32 block counter, pad) -------------
+    # -- step counter (device resident: int32 t_next, float lr_t, block-arrival counters) -----------------
     def _state_tensor(self, device):
         if self._dev_state is None:
-            self._dev_state = torch.zeros(4, dtype=torch.int32, device=device)
+            self._dev_state = torch.zeros(68, dtype=torch.int32, device=device)     # DT_ADAM_STATE_BYTES / 4
             check(lib().dt_adam_state_init(ptr(self._dev_state), self.lr, self.b1, self.b2, 0, stream_ptr()),
                   'dt_adam_state_init')
         return self._dev_state
@@ -110,40 +110,7 @@ class KerasAdam:
         st = stream_ptr()
         sp = ptr(dev_state)
         # every launch of the step reads lr_t from the device state; the LAST one advances it (no extra launch)
-        for layer in self.embedding_layers:
-            for key, grads in layer.sparse_grads.items():
-                table = layer.tables[key]
-                s = self._st(table)
-                D = table.shape[1]
-                if len(grads) == 1:
-                    rows, values = grads[0].rows, grads[0].values
-                else:
-                    rows = torch.cat([g.rows.reshape(-1) for g in grads])
-                    values = torch.cat([g.values.reshape(-1, D) for g in grads])
-                n = rows.numel()
-                fields = len(dict(layer.groups)[D]) if hasattr(layer, 'groups') else 0
-                hints = {getattr(g, 'fields', None) for g in grads}
-                if hints != {None}:                       # an explicit layout promise overrides the layer default
-                    fields = hints.pop() if len(hints) == 1 else 0
-                    fields = 0 if fields is None else int(fields)
-                if fields == -1 and len(grads) != 1:
-                    fields = 0                            # distinct within each piece only
-                values = values if values.is_contiguous() else values.contiguous()
-                if fields == -1:
-                    slots = mark = None
-                    n_slots = 0
-                else:
-                    n_slots = lib().dt_adam_rows_slots(n)
-                    if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
-                        s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)
-                        s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
-                        s['n_slots'] = n_slots
-                    slots, mark, n_slots = s['slots'], s['mark'], s['n_slots']
-                check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
-                                              D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
-                                              self.b1, self.b2, self.eps, sp, st), 'dt_adam_rows_step')
-            layer.sparse_grads.clear()
-        launches = []                                     # (param ptr, grad ptr, m ptr, v ptr, n) + keep-alive refs
+        dense = []                                        # (param, grad, m, v, n)
         flat_done = set()
         if self._flat is not None:
             fp, fg, fm, fv, n, members = self._flat
@@ -151,19 +118,62 @@ class KerasAdam:
             in_flat = [p for p in self.params if id(p) in members and p.grad is not None and
                        p.grad.data_ptr() == base + 4 * members[id(p)]]
             if len(in_flat) == len(members):       # every member's gradient is its flat view: one launch
-                launches.append((fp, fg, fm, fv, n))
+                dense.append((fp, fg, fm, fv, n))
                 flat_done = set(members)
         for p in self.params:
             if p.grad is None or id(p) in flat_done:
                 continue
             s = self._st(p)
-            launches.append((p.data, p.grad.contiguous(), s['m'], s['v'], p.numel()))
-        if not launches:
-            check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
-        for i, (pp, gg, mm, vv, n) in enumerate(launches):
-            last = 1 if i == len(launches) - 1 else 0
+            dense.append((p.data, p.grad.contiguous(), s['m'], s['v'], p.numel()))
+        sparse = []
+        for layer in self.embedding_layers:
+            for key, grads in layer.sparse_grads.items():
+                sparse.append((layer, key, grads))
+        # launch order: dense updates that cannot ride along, then the table updates; the last table update carries
+        # one dense update (normally the model's flat buffer) in its trailing blocks and advances the state
+        tail = dense.pop(0) if (sparse and dense) else None
+        for i, (pp, gg, mm, vv, n) in enumerate(dense):
+            last = 1 if (not sparse and i == len(dense) - 1) else 0
             check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
                                            sp, last, self.lr, st), 'dt_adam_dense_step')
+        if not sparse and not dense:
+            check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
+        for i, (layer, key, grads) in enumerate(sparse):
+            table = layer.tables[key]
+            s = self._st(table)
+            D = table.shape[1]
+            if len(grads) == 1:
+                rows, values = grads[0].rows, grads[0].values
+            else:
+                rows = torch.cat([g.rows.reshape(-1) for g in grads])
+                values = torch.cat([g.values.reshape(-1, D) for g in grads])
+            n = rows.numel()
+            fields = len(dict(layer.groups)[D]) if hasattr(layer, 'groups') else 0
+            hints = {getattr(g, 'fields', None) for g in grads}
+            if hints != {None}:                           # an explicit layout promise overrides the layer default
+                fields = hints.pop() if len(hints) == 1 else 0
+                fields = 0 if fields is None else int(fields)
+            if fields == -1 and len(grads) != 1:
+                fields = 0                                # distinct within each piece only
+            values = values if values.is_contiguous() else values.contiguous()
+            if fields == -1:
+                slots = mark = None
+                n_slots = 0
+            else:
+                n_slots = lib().dt_adam_rows_slots(n)
+                if s.get('n_slots', 0) < n_slots or s['mark'].numel() < n:
+                    s['slots'] = torch.zeros(n_slots, dtype=torch.int64, device=table.device)
+                    s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
+                    s['n_slots'] = n_slots
+                slots, mark, n_slots = s['slots'], s['mark'], s['n_slots']
+            is_last = i == len(sparse) - 1
+            tl = tail if (is_last and tail is not None) else (None, None, None, None, 0)
+            check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
+                                          D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
+                                          self.b1, self.b2, self.eps, sp, ptr(tl[0]), ptr(tl[1]), ptr(tl[2]),
+                                          ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, st), 'dt_adam_rows_step')
+        for layer in self.embedding_layers:
+            layer.sparse_grads.clear()
 
 
 class SGD:

@@ -191,11 +191,14 @@ int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float*
  * ranges (MultiColumnEmbedding): each field then dedupes in LDS (one workgroup per field, up to 8192 lookups
  * per field) and `slots` is not touched.  fields = -1: the rows are already distinct (e.g. deduplicated by
  * dt_deepfm_train_step) — no dedupe pass, slots/mark may be NULL.
- * `state` (16 device bytes, may be NULL): {int32 t = the step the NEXT update uses, float lr_t for that step,
- * uint32 block counter, pad}.  When given, lr_t is READ FROM THE DEVICE instead of the scalar argument, so a
+ * `state` (DT_ADAM_STATE_BYTES = 272 device bytes, may be NULL): {int32 t = the step the NEXT update uses, float
+ * lr_t for that step, block-arrival counters}.  When given, lr_t is READ FROM THE DEVICE instead of the scalar argument, so a
  * captured hipGraph of the whole step replays correctly.  dt_adam_state_init writes it for `steps_done` completed
  * steps; the state is advanced (t += 1, lr_t recomputed) either by dt_adam_advance or — with no launch of its own —
- * by the last block of a dt_adam_dense_step called with advance != 0, which must be the LAST launch of the step.  */
+ * by the last block of a dt_adam_dense_step / dt_adam_rows_step called with advance != 0, which must be the LAST
+ * launch of the step.  dt_adam_rows_step can carry one dense update (dense_* arrays, dense_n elements; 0 = none) in
+ * trailing blocks of its row kernel, so a model with one big table and one flat dense buffer updates in ONE launch. */
+#define DT_ADAM_STATE_BYTES 272
 int dt_adam_state_init(void* state, float lr, float beta1, float beta2, int steps_done, void* stream);
 int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
 int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
@@ -203,7 +206,8 @@ int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, 
 int64_t dt_adam_rows_slots(int64_t n_rows);
 int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
                       int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
-                      float beta2, float eps, const void* state, void* stream);
+                      float beta2, float eps, void* state, float* dense_p, const float* dense_g, float* dense_m,
+                      float* dense_v, int64_t dense_n, int advance, float lr, void* stream);
 
 /* keras.optimizers.SGD (momentum 0), selectable through ModelConfig.optimizer (deepmodel.py:319-323):
  * p -= lr*g; the rows variant applies the (rows, values) gradient directly (duplicate rows add up).   */

@@ -8,7 +8,7 @@ dev = torch.device('cuda')
 B, F, D, V = 8192, 26, 16, 1_000_000
 table = torch.zeros(F * V, D, device=dev)
 m, v = torch.zeros_like(table), torch.zeros_like(table)
-state = torch.zeros(4, dtype=torch.int32, device=dev)
+state = torch.zeros(68, dtype=torch.int32, device=dev)
 check(lib().dt_adam_state_init(ptr(state), 1e-3, 0.9, 0.999, 0, stream_ptr()), 'init')
 n = B * F
 SLOT_MULT = int(os.environ.get('SLOT_MULT', '1'))
@@ -21,7 +21,7 @@ off = (torch.arange(F, device=dev) * V)[None, :]
 def run(rows, fields, tag):
     def once():
         check(lib().dt_adam_rows_step(ptr(table), ptr(m), ptr(v), ptr(rows), ptr(vals), n, D, fields, ptr(slots),
-                                      slots.numel(), ptr(mark), 0.0, 0.9, 0.999, 1e-7, ptr(state), stream_ptr()), 'x')
+                                      slots.numel(), ptr(mark), 0.0, 0.9, 0.999, 1e-7, ptr(state), None, None, None, None, 0, 1, 1e-3, stream_ptr()), 'x')
     for _ in range(5):
         once()
     torch.cuda.synchronize()
