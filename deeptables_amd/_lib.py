@@ -86,7 +86,10 @@ SIGNATURES = {
     'dt_deepfm_accum_offsets': (_c_int, [_c_int, _c_int, _c_int, _ptr]),
     'dt_deepfm_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _ptr]),
+                                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_f32, _c_int, _c_int,
+                                      _ptr]),
+    'dt_embedding_gather_owned': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                           _c_int, _ptr, _ptr, _ptr, _ptr]),
     'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
 }

@@ -910,7 +910,8 @@ __global__ __launch_bounds__(256) void k_sparse_bwd(const float* __restrict__ X,
                                                     const float* __restrict__ dz, MlpParams p,
                                                     const float* __restrict__ wlin, DeepFmDims dm,
                                                     const float* accum, DeepFmAccum al,
-                                                    float* __restrict__ grad_rows, float* dwlin_out, DedupeWs dd) {
+                                                    float* __restrict__ grad_rows, float* dwlin_out, DedupeWs dd,
+                                                    float grad_scale, int field_major) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NV = dm.F * LPR;
     const int D = 4 * LPR;
@@ -966,11 +967,16 @@ __global__ __launch_bounds__(256) void k_sparse_bwd(const float* __restrict__ X,
         o.y = ca[t].y * (gx[t].y - cm1[t].y - (x[t].y - cmu[t].y) * cm2[t].y) + lin_g + g * (S.y - x[t].y);
         o.z = ca[t].z * (gx[t].z - cm1[t].z - (x[t].z - cmu[t].z) * cm2[t].z) + lin_g + g * (S.z - x[t].z);
         o.w = ca[t].w * (gx[t].w - cm1[t].w - (x[t].w - cmu[t].w) * cm2[t].w) + lin_g + g * (S.w - x[t].w);
+        const int f = j / LPR, c = j - f * LPR;
+        if (field_major) {       // model-parallel tables: [F,B,D], already divided by the world size
+            o.x *= grad_scale; o.y *= grad_scale; o.z *= grad_scale; o.w *= grad_scale;
+            *reinterpret_cast<float4*>(grad_rows + ((int64_t)f * dm.B + b) * D + 4 * c) = o;
+            continue;
+        }
         if (!dd.slots) {
             *reinterpret_cast<float4*>(grad_rows + (int64_t)b * dm.F * D + 4 * j) = o;
             continue;
         }
-        const int f = j / LPR, c = j - f * LPR;
         const int64_t occ = (int64_t)b * dm.F + f;
         const int mk = dd.mark[occ];
         int64_t target = occ;
@@ -1089,7 +1095,8 @@ extern "C" int dt_deepfm_train_step(
     float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1, const float* W2,
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
-    void* dedupe_ws, int64_t dedupe_slots, int phases, void* stream) {
+    void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
+    void* stream) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
@@ -1107,6 +1114,8 @@ extern "C" int dt_deepfm_train_step(
     const int blocksA = ceil_div(B, kRowsPerBlockA);
     const int tiles = ceil_div(B, kTM);
     DedupeWs dd{nullptr, 0, nullptr, nullptr};
+    DT_REQUIRE(!(dedupe_ws && grad_rows_field_major), "dt_deepfm_train_step: dedupe and field-major row gradients "
+                                                      "are mutually exclusive");
     if (dedupe_ws && phases >= 2) {          // forward-only calls never reach G, which empties the hash again
         int lg = 0;
         while ((1LL << lg) < dedupe_slots) ++lg;
@@ -1176,7 +1185,8 @@ extern "C" int dt_deepfm_train_step(
 #define DT_G(L)                                                                                              \
     case L:                                                                                                  \
         hipLaunchKernelGGL((k_sparse_bwd<L>), dim3(gblocks), dim3(256), 0, st, ws + wl.X, ws + wl.dXn,       \
-                           ws + wl.dz, mp, w_lin, dm, accum, al, grad_rows, accum + al.dwlin, dd);                             \
+                           ws + wl.dz, mp, w_lin, dm, accum, al, grad_rows, accum + al.dwlin, dd, grad_rows_scale,            \
+                           grad_rows_field_major);                                                           \
         break;
         switch (lpr) { DT_G(1) DT_G(2) DT_G(4) DT_G(8) DT_G(16) DT_G(32) DT_G(64) }
 #undef DT_G

@@ -248,6 +248,40 @@ __global__ __launch_bounds__(256) void k_gather_vec4(
     }
 }
 
+// Owner-side gather of the model-parallel exchange (parallel.ShardedEmbeddingStrategy): the ids of ALL W minibatches
+// [W,B,F] for the fields [f0,f1) this rank owns -> rows [W, F_own, B, D] (field-major inside each minibatch, so the
+// piece for rank w is contiguous) + the packed row ids for the optimizer.  One launch instead of a slice / permute /
+// range-check / offset chain of element-wise kernels followed by a gather.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_gather_owned(const void* __restrict__ idx_all,
+                                                      const float4* __restrict__ table,
+                                                      const int64_t* __restrict__ row_offset,
+                                                      const int32_t* __restrict__ vocab, int W, int B, int F, int f0,
+                                                      int f1, int LPR, float4* __restrict__ out,
+                                                      int64_t* __restrict__ rows_out, int* __restrict__ oob_count) {
+    const int Fo = f1 - f0;
+    const int64_t total = (int64_t)W * Fo * B * LPR;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / LPR;                  // output lookup index in [W, Fo, B] order
+        const int c = (int)(t - r * LPR);
+        const int b = (int)(r % B);
+        const int fo = (int)((r / B) % Fo);
+        const int w = (int)(r / ((int64_t)B * Fo));
+        const int f = f0 + fo;
+        const int id = load_id<KIND>(idx_all, ((int64_t)w * B + b) * F + f);
+        const bool ok = (unsigned)id < (unsigned)vocab[f];
+        const int64_t row = ok ? row_offset[f] + id : (int64_t)-1;
+        float4 v = f4_zero();
+        if (ok) v = table[row * LPR + c];
+        out[t] = v;
+        if (c == 0) {
+            rows_out[r] = row;
+            if (!ok && oob_count) atomicAdd(oob_count, 1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_scatter_add_rows(const int64_t* __restrict__ rows,
                                                          const float* __restrict__ g,
                                                          int64_t total, int D,
@@ -361,6 +395,29 @@ extern "C" int dt_embedding_fwd(const void* idx, int idx_kind, const float* tabl
                                                 st);
     return launch_row_fwd<DT_IDX_I32, true>(idx, table, row_offset, vocab, nullptr, B, F, D, 0, out,
                                             nullptr, nullptr, nullptr, rows_out, oob_count, st);
+}
+
+extern "C" int dt_embedding_gather_owned(const void* idx_all, int idx_kind, const float* table,
+                                         const int64_t* row_offset, const int32_t* vocab, int W, int B, int F,
+                                         int f_begin, int f_end, int D, float* out, int64_t* rows_out,
+                                         int* oob_count, void* stream) {
+    DT_REQUIRE(W > 0 && B >= 0 && F > 0 && D > 0 && D % 4 == 0 && 0 <= f_begin && f_begin <= f_end && f_end <= F,
+               "dt_embedding_gather_owned: bad sizes W=%d B=%d F=%d fields [%d,%d) D=%d", W, B, F, f_begin, f_end, D);
+    DT_REQUIRE(idx_kind == DT_IDX_F32 || idx_kind == DT_IDX_I32, "dt_embedding_gather_owned: idx_kind %d", idx_kind);
+    const int64_t total = (int64_t)W * (f_end - f_begin) * B * (D / 4);
+    if (total == 0) return DT_OK;
+    DT_REQUIRE(idx_all && table && row_offset && vocab && out && rows_out, "dt_embedding_gather_owned: null pointer");
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (idx_kind == DT_IDX_F32)
+        hipLaunchKernelGGL((k_gather_owned<DT_IDX_F32>), dim3(blocks), dim3(256), 0, as_stream(stream), idx_all,
+                           (const float4*)table, row_offset, vocab, W, B, F, f_begin, f_end, D / 4, (float4*)out,
+                           rows_out, oob_count);
+    else
+        hipLaunchKernelGGL((k_gather_owned<DT_IDX_I32>), dim3(blocks), dim3(256), 0, as_stream(stream), idx_all,
+                           (const float4*)table, row_offset, vocab, W, B, F, f_begin, f_end, D / 4, (float4*)out,
+                           rows_out, oob_count);
+    return launch_status("dt_embedding_gather_owned");
 }
 
 extern "C" int dt_embedding_bwd_dense(const int64_t* rows, const float* grad_out, int n_lookups,

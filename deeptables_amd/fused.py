@@ -145,13 +145,11 @@ class FusedDeepFM:
                   'iota': (f_idx[None, :] * B + b_idx[:, None]).contiguous(),
                   'zero_off': torch.zeros(F, dtype=torch.int64, device=dev),
                   'fb_vocab': torch.full((F,), F * B, dtype=torch.int32, device=dev),
-                  'one_off': torch.zeros(1, dtype=torch.int64, device=dev),
                   'emb_own': torch.empty((W * Fo * B, 1, D), dtype=torch.float32, device=dev),
                   'rows_own': torch.empty((W * Fo * B, 1), dtype=torch.int64, device=dev),
                   'emb_T': torch.empty((F * B, D), dtype=torch.float32, device=dev),
                   'grad_own': torch.empty((W * Fo * B, D), dtype=torch.float32, device=dev),
-                  'rows_dummy': torch.empty((B, F), dtype=torch.int64, device=dev),
-                  'total_rows': torch.tensor([self.emb.tables[self.key].shape[0]], dtype=torch.int32, device=dev)}
+                  'rows_dummy': torch.empty((B, F), dtype=torch.int64, device=dev)}
             self._bufs[key] = sb
         return sb
 
@@ -168,16 +166,11 @@ class FusedDeepFM:
         row_offset = getattr(self.emb, f'row_offset_{self.key}')
         vocab = getattr(self.emb, f'vocab_{self.key}')
         s, e, Fo = sb['s'], sb['e'], sb['Fo']
-        ids_own = st.gather_ids(idx.contiguous(), F)                               # [W, Fo, B] int32
-        if Fo > 0:
-            voc = vocab[s:e].view(1, Fo, 1)
-            ok = (ids_own >= 0) & (ids_own < voc)
-            rows32 = torch.where(ok, ids_own + row_offset[s:e].view(1, Fo, 1).to(torch.int32),
-                                 torch.full_like(ids_own, -1)).reshape(-1, 1)
-            check(lib().dt_embedding_fwd(ptr(rows32), _lib.DT_IDX_I32, ptr(table), ptr(sb['one_off']), ptr(sb['total_rows']),
-                                         rows32.shape[0], 1, D, ptr(sb['emb_own']), ptr(sb['rows_own']),
-                                         ptr(self.emb.oob_count) if self.emb.check_oob else None, stream_ptr()),
-                  'dt_embedding_fwd')
+        idx_all = st.gather_all_ids(idx.contiguous())                                 # [W, B, F] int32
+        check(lib().dt_embedding_gather_owned(ptr(idx_all), _lib.DT_IDX_I32, ptr(table), ptr(row_offset), ptr(vocab),
+                                              W, B, F, s, e, D, ptr(sb['emb_own']), ptr(sb['rows_own']),
+                                              ptr(self.emb.oob_count) if self.emb.check_oob else None, stream_ptr()),
+              'dt_embedding_gather_owned')
         emb_T = st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
         dense = None if dense is None else dense.contiguous()
         y = y.reshape(-1).contiguous()
@@ -189,12 +182,12 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 2, stream_ptr()), 'dt_deepfm_train_step')
+            None, None, 0, 1.0 / W, 1, 2, stream_ptr()), 'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
-        # the loss is a mean over the LOCAL minibatch; the global objective is the mean over W of them
-        grad_T = (buf['grad_rows'].view(B, F, D) * (1.0 / W)).permute(1, 0, 2).contiguous()
-        grad_own = st.backward_exchange(grad_T, F, B, out=sb['grad_own'])
+        # the loss is a mean over the LOCAL minibatch, the global objective the mean over W of them: kernel G already
+        # wrote the row gradients field-major [F,B,D] and divided by W
+        grad_own = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'])
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
         self.dm.model._dt_sharded_step = True
         return self.loss_view, buf['logit']
@@ -226,7 +219,7 @@ class FusedDeepFM:
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
-            ptr(buf['dedupe']) if (backward and self.dedupe) else None, buf['dedupe_slots'],
+            ptr(buf['dedupe']) if (backward and self.dedupe) else None, buf['dedupe_slots'], 1.0, 0,
             2 if backward else 1, stream_ptr()), 'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:

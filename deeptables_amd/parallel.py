@@ -209,6 +209,16 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
             out[o:o + k] = bufs[src][start:start + k]
             o += k
 
+    def gather_all_ids(self, idx):
+        """idx [B,F] int32 of the local minibatch -> [W, B, F] ids of every rank's minibatch."""
+        W = self.world_size
+        B, F = idx.shape
+        if W == 1:
+            return idx.reshape(1, B, F)
+        all_idx = torch.empty((W * B, F), dtype=idx.dtype, device=idx.device)
+        dist.all_gather_into_tensor(all_idx, idx.contiguous(), group=self.group)
+        return all_idx.view(W, B, F)
+
     def gather_ids(self, idx, F):
         """idx [B,F] int32 of the local minibatch -> ids [W, F_own, B] int32 of the fields this rank owns."""
         W = self.world_size

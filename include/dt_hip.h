@@ -228,6 +228,15 @@ int dt_dense_fwd(const float* x, const float* W, const float* bias, int act, int
 int dt_dense_bwd(const float* x, const float* W, const float* y, const float* grad_y, int act, int N, int K,
                  int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
 
+/* ---- model-parallel tables: owner-side gather (parallel.ShardedEmbeddingStrategy; the role the sharded
+ *      embedding_lookup of a parameter-server strategy plays) ------------------------------------------- *
+ * idx_all [W,B,F] ids of all W minibatches; this rank owns fields [f_begin, f_end) of the packed table.
+ * out [W, F_own, B, D] (each rank's piece contiguous, field-major), rows_out [W, F_own, B] packed rows (-1 = id out
+ * of range -> zero row).                                                                                 */
+int dt_embedding_gather_owned(const void* idx_all, int idx_kind, const float* table, const int64_t* row_offset,
+                              const int32_t* vocab, int W, int B, int F, int f_begin, int f_end, int D, float* out,
+                              int64_t* rows_out, int* oob_count, void* stream);
+
 /* ---- f3: AFM attention pooling (AFM.call layers.py:789-807) ---------------------------------------- *
  * x [B,F,D]; P = F(F-1)/2 pairs in itertools.combinations order (layers.py:790-795).
  *   bi[p] = x_i*x_j ; a = act(bi . Wa [D,H] + ba [H]|NULL) (dense_attention, layers.py:776-778) ;
@@ -275,7 +284,9 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * dedupe_ws (may be NULL): dt_deepfm_dedupe_bytes(B,F) bytes, ALL ZERO on entry and left all zero on return, with
  * dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step resolves duplicate lookups
  * itself: each table row appears once in rows_out (later lookups of it report -1) and its grad_rows entry holds the
- * SUM over all its lookups — dt_adam_rows_step can then be called with fields = -1 (no dedupe pass).            */
+ * SUM over all its lookups — dt_adam_rows_step can then be called with fields = -1 (no dedupe pass).
+ * grad_rows_field_major != 0 (model-parallel tables, no dedupe_ws): grad_rows is written as [F,B,D] and multiplied
+ * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.                              */
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
@@ -291,7 +302,8 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
                          const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* w3, const float* w_out, const float* b_out, float* logit_out,
                          int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
-                         int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases, void* stream);
+                         int* oob_count, void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale,
+                         int grad_rows_field_major, int phases, void* stream);
 
 #ifdef __cplusplus
 }
