@@ -128,7 +128,7 @@ class GraphedStep:
         else:
             self._body(b)
         if self._dp:
-            self.strategy.exchange_gradients(self.dm.model)
+            self.strategy.exchange_gradients(self.dm.model, self.dm.optimizer if self.with_optimizer else None)
             if self.with_optimizer:
                 self.dm.optimizer.step()     # data parallel: after the gradient exchange, eager launches
 

@@ -270,7 +270,7 @@ class DeepModel:
         loss, logit = self.forward_backward(inputs, y)
         strategy = self.config.distribute_strategy
         if strategy is not None:
-            strategy.exchange_gradients(self.model)
+            strategy.exchange_gradients(self.model, self.optimizer)
         self.optimizer.step()
         return loss.detach(), logit.detach().clone() if self.fused_plan() is not None else logit.detach()
 

@@ -111,7 +111,7 @@ class DataParallelStrategy:
         dist.all_gather_into_tensor(all_vals, vals, group=self.group)
         return SparseRowGrad(all_rows, all_vals)     # padded entries carry row -1 and are skipped
 
-    def exchange_gradients(self, model):
+    def exchange_gradients(self, model, optimizer=None):
         from .models.layers import MultiColumnEmbedding
         if self.world_size == 1:
             return
@@ -269,18 +269,29 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
                     lo, hi = offs[s], offs[e - 1] + voc[e - 1]
                     dist.broadcast(table.data[lo:hi], src=r, group=self.group)
 
-    def exchange_gradients(self, model):
-        """Dense gradients only — the embedding gradients already travelled to their owners inside the step."""
+    def exchange_gradients(self, model, optimizer=None):
+        """Dense gradients only — the embedding gradients already travelled to their owners inside the step.
+        With an optimizer that has a `pre_dense_hook`, the flat all-reduce is started asynchronously and waited for
+        only right before the dense update, so it overlaps the owners' table updates."""
         if self.world_size == 1:
             return
         if getattr(model, '_dt_sharded_step', False):
             flat = getattr(model, '_dt_flat_grad', None)
             if flat is not None:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.div_(self.world_size)
+                W = self.world_size
                 base = flat.untyped_storage().data_ptr()
                 rest = [p for p in model.parameters() if p.requires_grad and p.grad is not None and
                         p.grad.untyped_storage().data_ptr() != base]
+                if optimizer is not None and hasattr(optimizer, 'pre_dense_hook') and not rest:
+                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+                    def finish():
+                        work.wait()
+                        flat.div_(W)
+                    optimizer.pre_dense_hook = finish
+                    return
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(W)
                 if rest:
                     self.allreduce_dense(rest)
                 return

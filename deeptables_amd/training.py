@@ -52,7 +52,10 @@ class KerasAdam:
         self.params = [p for p in params if p.requires_grad]
         self.state = {}
         self.embedding_layers = list(embedding_layers)
-        self._dev_state = None        # int32 view of 8 bytes: [t, bits(lr_t)]
+        self._dev_state = None        # device-resident step state (DT_ADAM_STATE_BYTES)
+        # optional callable run right before the dense updates of a step (after the table updates were launched):
+        # the data-parallel strategy uses it to wait for an all-reduce it started asynchronously
+        self.pre_dense_hook = None
         self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param)})
 
     # -- step counter (device resident: int32 t_next, float lr_t, block-arrival counters) -----------------
@@ -131,11 +134,16 @@ class KerasAdam:
                 sparse.append((layer, key, grads))
         # launch order: dense updates that cannot ride along, then the table updates; the last table update carries
         # one dense update (normally the model's flat buffer) in its trailing blocks and advances the state
-        tail = dense.pop(0) if (sparse and dense) else None
-        for i, (pp, gg, mm, vv, n) in enumerate(dense):
-            last = 1 if (not sparse and i == len(dense) - 1) else 0
-            check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
-                                           sp, last, self.lr, st), 'dt_adam_dense_step')
+        hook, self.pre_dense_hook = self.pre_dense_hook, None
+        dense_after = hook is not None and bool(sparse)     # table updates first, overlapping the pending reduce
+        tail = dense.pop(0) if (sparse and dense and not dense_after) else None
+        if hook is not None and not dense_after:
+            hook()
+        if not dense_after:
+            for i, (pp, gg, mm, vv, n) in enumerate(dense):
+                last = 1 if (not sparse and i == len(dense) - 1) else 0
+                check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
+                                               sp, last, self.lr, st), 'dt_adam_dense_step')
         if not sparse and not dense:
             check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
         for i, (layer, key, grads) in enumerate(sparse):
@@ -166,12 +174,17 @@ class KerasAdam:
                     s['mark'] = torch.empty(n, dtype=torch.int32, device=table.device)
                     s['n_slots'] = n_slots
                 slots, mark, n_slots = s['slots'], s['mark'], s['n_slots']
-            is_last = i == len(sparse) - 1
+            is_last = i == len(sparse) - 1 and not (dense_after and dense)
             tl = tail if (is_last and tail is not None) else (None, None, None, None, 0)
             check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
                                           D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
                                           self.b1, self.b2, self.eps, sp, ptr(tl[0]), ptr(tl[1]), ptr(tl[2]),
                                           ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, st), 'dt_adam_rows_step')
+        if dense_after:
+            hook()
+            for i, (pp, gg, mm, vv, n) in enumerate(dense):
+                check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
+                                               sp, 1 if i == len(dense) - 1 else 0, self.lr, st), 'dt_adam_dense_step')
         for layer in self.embedding_layers:
             layer.sparse_grads.clear()
 

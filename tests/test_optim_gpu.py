@@ -151,3 +151,35 @@ def test_captured_step_replays_with_advancing_bias_correction(dev):
         rw, rwm, rwv = R.keras_adam_step(rw, wg.double(), rwm, rwv, t)
     assert (w.detach().cpu().double() - rw).abs().max().item() < 2e-6
     assert (table.detach().cpu().double() - rp).abs().max().item() < 2e-6
+
+
+def test_pre_dense_hook_orders_table_updates_first(dev):
+    """With a pre-dense hook (an all-reduce pending on the dense gradients) the table update is launched first, the
+    hook runs, then the dense update advances the state — results identical to the fused single launch."""
+    from deeptables_amd.ops import SparseRowGrad
+    g = torch.Generator().manual_seed(9)
+    D, F, B, vocab = 16, 2, 128, 500
+    t0 = torch.randn(F * vocab, D, generator=g) * 0.05
+    w0 = torch.randn(300, generator=g)
+    rows = (torch.randint(0, vocab, (B, F), generator=g) + torch.arange(F) * vocab).reshape(-1)
+    vals = torch.randn(B * F, D, generator=g)
+    wg = torch.randn(300, generator=g)
+    out = []
+    for use_hook in (False, True):
+        table = torch.nn.Parameter(t0.clone().to(dev))
+        w = torch.nn.Parameter(w0.clone().to(dev))
+        emb = _FakeEmb(table, F)
+        opt = _adam(dev, [table, w], [emb])
+        called = []
+        for step in range(2):
+            w.grad = wg.to(dev) * (0.5 if use_hook else 1.0)
+            emb.sparse_grads = {'d16': [SparseRowGrad(rows.to(dev), vals.clone().to(dev))]}
+            if use_hook:
+                def hook(w=w):
+                    called.append(1)
+                    w.grad.mul_(2.0)              # what the pending all-reduce would deliver
+                opt.pre_dense_hook = hook
+            opt.step()
+        assert opt.t == 2 and (len(called) == 2) == use_hook and opt.pre_dense_hook is None
+        out.append((table.detach().cpu().clone(), w.detach().cpu().clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.allclose(out[0][1], out[1][1], atol=1e-7)

@@ -198,6 +198,16 @@ def _sharded_worker(rank, world, port, q):
     m.fc.weight.grad, m.fc.bias.grad = flat[:2].view(1, 2), flat[2:]
     st.exchange_gradients(m)
     assert torch.allclose(flat, torch.full((3,), 1.0))                 # mean of 0,1,2
+    # with an optimizer the reduce is started asynchronously and finished by the optimizer's pre-dense hook
+
+    class Opt:
+        pre_dense_hook = None
+    opt = Opt()
+    flat.fill_(float(rank) * 2)
+    st.exchange_gradients(m, opt)
+    assert callable(opt.pre_dense_hook)
+    opt.pre_dense_hook()
+    assert torch.allclose(flat, torch.full((3,), 2.0))                 # mean of 0,2,4
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, 'ok'))
