@@ -260,7 +260,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=8192)
-    ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN'])
+    ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN', 'AFM', 'FiBiNet', 'FGCNN', 'PNN'])
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
@@ -304,7 +304,8 @@ def main():
 
     from deeptables_amd.models import deepnets
     nets = {'DeepFM': deepnets.DeepFM, 'xDeepFM': deepnets.xDeepFM, 'AutoInt': deepnets.AutoInt,
-            'DCN': deepnets.DCN}[args.model]
+            'DCN': deepnets.DCN, 'AFM': deepnets.AFM, 'FiBiNet': deepnets.FiBiNet, 'FGCNN': deepnets.FGCNN,
+            'PNN': deepnets.PNN}[args.model]
     dim = 32 if args.model == 'AutoInt' else D
     dm = build_model(nets, device, strategy, dim)
     if args.model == 'xDeepFM':

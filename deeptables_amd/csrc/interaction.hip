@@ -36,7 +36,27 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // ---------------------------------------------------------------------------------------------
 // AFM:  bi[p] = x_i * x_j ; a[p,h] = act(bi[p] . Wa[:,h] + ba[h]) ; logit[p] = a[p] . pv ;
 //       score = softmax_p(logit) ; out[d] = sum_p score[p] bi[p,d]
+// Persistent blocks, one batch row at a time in LDS.  The attention weights live in LDS padded to a compile-time
+// stride HMAX (zeros beyond H), so the inner loops are guard-free and read 16 bytes at a time.
 // ---------------------------------------------------------------------------------------------
+template <int HMAX>
+__device__ __forceinline__ void afm_att_preact(const float* __restrict__ xi, const float* __restrict__ xj,
+                                               const float* __restrict__ wa, const float* __restrict__ bb, int D,
+                                               float (&acc)[HMAX]) {
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) acc[h] = bb[h];
+    for (int d = 0; d < D; ++d) {
+        const float bi = xi[d] * xj[d];
+        const float4* w4 = reinterpret_cast<const float4*>(wa + d * HMAX);
+#pragma unroll
+        for (int q = 0; q < HMAX / 4; ++q) {
+            const float4 w = w4[q];
+            acc[4 * q + 0] += bi * w.x; acc[4 * q + 1] += bi * w.y;
+            acc[4 * q + 2] += bi * w.z; acc[4 * q + 3] += bi * w.w;
+        }
+    }
+}
+
 template <int HMAX>
 __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, const float* __restrict__ Wa,
                                                  const float* __restrict__ ba, const float* __restrict__ pv,
@@ -44,16 +64,23 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
                                                  float* __restrict__ score_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int P = F * (F - 1) / 2;
-    float* xr = lds;               // [F*D]
-    float* wa = xr + F * D;        // [D*H]
-    float* bb = wa + D * H;        // [H]
-    float* pp = bb + H;            // [H]
-    float* sc = pp + H;            // [P]
-    float* scratch = sc + P;       // [8]
-    short* pi = reinterpret_cast<short*>(scratch + 8);
+    float* wa = lds;                   // [D][HMAX]   (16-byte aligned rows)
+    float* bb = wa + D * HMAX;         // [HMAX]
+    float* pp = bb + HMAX;             // [HMAX]
+    float* red = pp + HMAX;            // [4][16]
+    float* scratch = red + 64;         // [8]
+    float* xr = scratch + 8;           // [F*D]
+    float* sc = xr + F * D;            // [P]
+    short* pi = reinterpret_cast<short*>(sc + P);
     short* pj = pi + P;
-    for (int e = threadIdx.x; e < D * H; e += blockDim.x) wa[e] = Wa[e];
-    for (int e = threadIdx.x; e < H; e += blockDim.x) { bb[e] = ba ? ba[e] : 0.f; pp[e] = pv[e]; }
+    for (int e = threadIdx.x; e < D * HMAX; e += blockDim.x) {
+        const int d = e / HMAX, h = e - d * HMAX;
+        wa[e] = h < H ? Wa[d * H + h] : 0.f;
+    }
+    for (int e = threadIdx.x; e < HMAX; e += blockDim.x) {
+        bb[e] = (ba && e < H) ? ba[e] : 0.f;
+        pp[e] = e < H ? pv[e] : 0.f;
+    }
     for (int i = threadIdx.x; i < F; i += blockDim.x)
         for (int j = i + 1; j < F; ++j) { const int p = pair_of(i, j, F); pi[p] = (short)i; pj[p] = (short)j; }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -62,21 +89,11 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
         __syncthreads();
         float lmax = -INFINITY;
         for (int p = threadIdx.x; p < P; p += blockDim.x) {
-            const float* xi = xr + pi[p] * D;
-            const float* xj = xr + pj[p] * D;
             float acc[HMAX];
-#pragma unroll
-            for (int h = 0; h < HMAX; ++h) acc[h] = h < H ? bb[h] : 0.f;
-            for (int d = 0; d < D; ++d) {
-                const float bi = xi[d] * xj[d];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h)
-                    if (h < H) acc[h] += bi * wa[d * H + h];
-            }
+            afm_att_preact<HMAX>(xr + pi[p] * D, xr + pj[p] * D, wa, bb, D, acc);
             float lg = 0.f;
 #pragma unroll
-            for (int h = 0; h < HMAX; ++h)
-                if (h < H) lg += (act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h]) * pp[h];
+            for (int h = 0; h < HMAX; ++h) lg += (act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h]) * pp[h];
             sc[p] = lg;
             lmax = fmaxf(lmax, lg);
         }
@@ -95,14 +112,40 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
             if (score_out) score_out[(int64_t)b * P + p] = s;
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
-            float o = 0.f;
-            for (int p = 0; p < P; ++p) o += sc[p] * xr[pi[p] * D + d] * xr[pj[p] * D + d];
-            out[(int64_t)b * D + d] = o;
+        // pooled sum over pairs: every thread folds ITS pairs into a private [16] vector, the vectors meet through wave
+        // shuffles and a [waves][16] LDS buffer (a d-per-thread loop over all P pairs leaves 240 of 256 lanes idle)
+        for (int d0 = 0; d0 < D; d0 += 16) {
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) part[k] = 0.f;
+            for (int p = threadIdx.x; p < P; p += blockDim.x) {
+                const float s = sc[p];
+                const float* xi = xr + pi[p] * D + d0;
+                const float* xj = xr + pj[p] * D + d0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (d0 + k < D) part[k] += s * xi[k] * xj[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) part[k] = wave_sum(part[k]);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) red[(threadIdx.x >> 6) * 16 + k] = part[k];
+            }
+            __syncthreads();
+            if (threadIdx.x < 16 && d0 + threadIdx.x < D) {
+                float o = 0.f;
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) o += red[w * 16 + threadIdx.x];
+                out[(int64_t)b * D + d0 + threadIdx.x] = o;
+            }
         }
     }
 }
 
+// Backward.  Per row: (1) S = sum_p score_p dscore_p; (2) per pair: recompute the attention pre-activations, form
+// datt[p,:] and dbi[p,:] in LDS; (3) grad_Wa += bi^T datt as 4x4 register blocks — thread = (d-block, h-block, pair
+// group), accumulators persist over the block's rows; (4) grad_x from dbi.  grad_pv / grad_ba accumulate per thread.
 template <int HMAX>
 __global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, const float* __restrict__ Wa,
                                                  const float* __restrict__ ba, const float* __restrict__ pv,
@@ -112,94 +155,147 @@ __global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, co
                                                  float* __restrict__ gpv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int P = F * (F - 1) / 2;
-    float* xr = lds;               // [F*D]
-    float* wa = xr + F * D;        // [D*H]
-    float* bb = wa + D * H;        // [H]
-    float* pp = bb + H;            // [H]
-    float* gr = pp + H;            // [D]   grad_out row
-    float* datt = gr + D;          // [P*H]
-    float* dbi = datt + P * H;     // [P*D]
-    float* accW = dbi + P * D;     // [D*H] block accumulators
-    float* accb = accW + D * H;    // [H]
-    float* accp = accb + H;        // [H]
-    float* scratch = accp + H;     // [8]
-    short* pi = reinterpret_cast<short*>(scratch + 8);
+    const int DP4 = (D + 3) & ~3;          // bi / dbi rows padded to 16 bytes
+    float* wa = lds;                       // [D][HMAX]
+    float* bb = wa + D * HMAX;             // [HMAX]
+    float* pp = bb + HMAX;                 // [HMAX]
+    float* accb = pp + HMAX;               // [HMAX]
+    float* accp = accb + HMAX;             // [HMAX]
+    float* datt = accp + HMAX;             // [P][HMAX]
+    float* bi = datt + P * HMAX;           // [P][DP4]
+    float* dbi = bi + P * DP4;             // [P][DP4]
+    float* accW = dbi + P * DP4;           // [D][HMAX]
+    float* scratch = accW + D * HMAX;      // [8]
+    float* xr = scratch + 8;               // [F*D]
+    float* gr = xr + F * D;                // [D]
+    short* pi = reinterpret_cast<short*>(gr + D);
     short* pj = pi + P;
-    for (int e = threadIdx.x; e < D * H; e += blockDim.x) { wa[e] = Wa[e]; accW[e] = 0.f; }
-    for (int e = threadIdx.x; e < H; e += blockDim.x) { bb[e] = ba ? ba[e] : 0.f; pp[e] = pv[e]; accb[e] = 0.f; accp[e] = 0.f; }
+    for (int e = threadIdx.x; e < D * HMAX; e += blockDim.x) {
+        const int d = e / HMAX, h = e - d * HMAX;
+        wa[e] = h < H ? Wa[d * H + h] : 0.f;
+        accW[e] = 0.f;
+    }
+    for (int e = threadIdx.x; e < HMAX; e += blockDim.x) {
+        bb[e] = (ba && e < H) ? ba[e] : 0.f;
+        pp[e] = e < H ? pv[e] : 0.f;
+        accb[e] = 0.f;
+        accp[e] = 0.f;
+    }
     for (int i = threadIdx.x; i < F; i += blockDim.x)
         for (int j = i + 1; j < F; ++j) { const int p = pair_of(i, j, F); pi[p] = (short)i; pj[p] = (short)j; }
+    // grad_Wa blocking: thread = (4x4 block of (d,h), pair group); needs D % 4 == 0
+    const int nblk = (DP4 / 4) * (HMAX / 4);
+    const bool blocked = (D % 4 == 0) && nblk <= 256;
+    const int pgroups = blocked ? 256 / nblk : 0;
+    const int blk = threadIdx.x % (blocked ? nblk : 1), pg = blocked ? threadIdx.x / nblk : 0;
+    const int db = blk / (HMAX / 4), hb = blk % (HMAX / 4);
+    float wacc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wacc[k] = 0.f;
+    float my_dp[HMAX], my_db[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) { my_dp[h] = 0.f; my_db[h] = 0.f; }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int e = threadIdx.x; e < F * D; e += blockDim.x) xr[e] = x[(int64_t)b * F * D + e];
         for (int e = threadIdx.x; e < D; e += blockDim.x) gr[e] = gout[(int64_t)b * D + e];
         __syncthreads();
-        // S = sum_q score_q dscore_q,  dscore_p = sum_d g[d] bi[p,d]
+        // (1) bi[p,:] and S = sum_q score_q (g . bi_q)
         float part = 0.f;
         for (int p = threadIdx.x; p < P; p += blockDim.x) {
             const float* xi = xr + pi[p] * D;
             const float* xj = xr + pj[p] * D;
             float ds = 0.f;
-            for (int d = 0; d < D; ++d) ds += gr[d] * xi[d] * xj[d];
+            for (int d = 0; d < D; ++d) {
+                const float v = xi[d] * xj[d];
+                bi[p * DP4 + d] = v;
+                ds += gr[d] * v;
+            }
             part += score[(int64_t)b * P + p] * ds;
         }
         const float S = block_sum(part, scratch);
+        // (2) datt, dbi
         for (int p = threadIdx.x; p < P; p += blockDim.x) {
-            const float* xi = xr + pi[p] * D;
-            const float* xj = xr + pj[p] * D;
             const float sp = score[(int64_t)b * P + p];
             float acc[HMAX];
-#pragma unroll
-            for (int h = 0; h < HMAX; ++h) acc[h] = h < H ? bb[h] : 0.f;
+            afm_att_preact<HMAX>(xr + pi[p] * D, xr + pj[p] * D, wa, bb, D, acc);
             float ds = 0.f;
-            for (int d = 0; d < D; ++d) {
-                const float bi = xi[d] * xj[d];
-                ds += gr[d] * bi;
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h)
-                    if (h < H) acc[h] += bi * wa[d * H + h];
-            }
+            for (int d = 0; d < D; ++d) ds += gr[d] * bi[p * DP4 + d];
             const float dlogit = sp * (ds - S);
 #pragma unroll
-            for (int h = 0; h < HMAX; ++h)
-                if (h < H) {
-                    const float a = act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h];
-                    const float da = (act == DT_ACT_RELU && !(acc[h] > 0.f)) ? 0.f : dlogit * pp[h];
-                    datt[p * H + h] = da;
-                    atomicAdd(&accp[h], dlogit * a);
-                    atomicAdd(&accb[h], da);
-                    acc[h] = da;   // reuse as datt
-                }
+            for (int h = 0; h < HMAX; ++h) {
+                const float a = act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h];
+                const float da = (act == DT_ACT_RELU && !(acc[h] > 0.f)) ? 0.f : dlogit * pp[h];
+                my_dp[h] += dlogit * a;
+                my_db[h] += da;
+                acc[h] = da;
+            }
+#pragma unroll
+            for (int q = 0; q < HMAX / 4; ++q)
+                *reinterpret_cast<float4*>(datt + p * HMAX + 4 * q) =
+                    make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             for (int d = 0; d < D; ++d) {
+                const float4* w4 = reinterpret_cast<const float4*>(wa + d * HMAX);
                 float v = sp * gr[d];
 #pragma unroll
-                for (int h = 0; h < HMAX; ++h)
-                    if (h < H) v += acc[h] * wa[d * H + h];
-                dbi[p * D + d] = v;
+                for (int q = 0; q < HMAX / 4; ++q) {
+                    const float4 w = w4[q];
+                    v += acc[4 * q] * w.x + acc[4 * q + 1] * w.y + acc[4 * q + 2] * w.z + acc[4 * q + 3] * w.w;
+                }
+                dbi[p * DP4 + d] = v;
             }
         }
         __syncthreads();
-        // grad_Wa[d,h] += sum_p bi[p,d] datt[p,h]
-        for (int e = threadIdx.x; e < D * H; e += blockDim.x) {
-            const int d = e / H, h = e - d * H;
-            float v = 0.f;
-            for (int p = 0; p < P; ++p) v += xr[pi[p] * D + d] * xr[pj[p] * D + d] * datt[p * H + h];
-            accW[e] += v;
+        // (3) grad_Wa[d,h] += sum_p bi[p,d] datt[p,h]
+        if (blocked) {
+            if (pg < pgroups) {
+                for (int p = pg; p < P; p += pgroups) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bi + p * DP4 + 4 * db);
+                    const float4 av = *reinterpret_cast<const float4*>(datt + p * HMAX + 4 * hb);
+                    wacc[0] += bv.x * av.x; wacc[1] += bv.x * av.y; wacc[2] += bv.x * av.z; wacc[3] += bv.x * av.w;
+                    wacc[4] += bv.y * av.x; wacc[5] += bv.y * av.y; wacc[6] += bv.y * av.z; wacc[7] += bv.y * av.w;
+                    wacc[8] += bv.z * av.x; wacc[9] += bv.z * av.y; wacc[10] += bv.z * av.z; wacc[11] += bv.z * av.w;
+                    wacc[12] += bv.w * av.x; wacc[13] += bv.w * av.y; wacc[14] += bv.w * av.z; wacc[15] += bv.w * av.w;
+                }
+            }
+        } else {
+            for (int e = threadIdx.x; e < D * HMAX; e += blockDim.x) {
+                const int d = e / HMAX, h = e - d * HMAX;
+                float v = 0.f;
+                for (int p = 0; p < P; ++p) v += bi[p * DP4 + d] * datt[p * HMAX + h];
+                accW[e] += v;
+            }
         }
-        // grad_x[f,d] = sum_{o != f} dbi[p(f,o), d] x[o,d]
+        // (4) grad_x[f,d] = sum_{o != f} dbi[p(f,o), d] x[o,d]
         for (int e = threadIdx.x; e < F * D; e += blockDim.x) {
             const int f = e / D, d = e - f * D;
             float v = 0.f;
             for (int o = 0; o < F; ++o) {
                 if (o == f) continue;
                 const int p = o > f ? pair_of(f, o, F) : pair_of(o, f, F);
-                v += dbi[p * D + d] * xr[o * D + d];
+                v += dbi[p * DP4 + d] * xr[o * D + d];
             }
             gx[(int64_t)b * F * D + e] = v;
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < D * H; e += blockDim.x) atomicAdd(gWa + e, accW[e]);
+    if (blocked && pg < pgroups) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(&accW[(4 * db + (k >> 2)) * HMAX + 4 * hb + (k & 3)], wacc[k]);
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        const float a = wave_sum(my_dp[h]), c = wave_sum(my_db[h]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&accp[h], a);
+            atomicAdd(&accb[h], c);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < D * H; e += blockDim.x) {
+        const int d = e / H, h = e - d * H;
+        atomicAdd(gWa + e, accW[d * HMAX + h]);
+    }
     for (int e = threadIdx.x; e < H; e += blockDim.x) {
         if (gba) atomicAdd(gba + e, accb[e]);
         atomicAdd(gpv + e, accp[e]);
@@ -394,13 +490,14 @@ static int ew_blocks(int64_t total) {
 
 using namespace dt;
 
+static int afm_hmax(int H) { return H <= 16 ? 16 : (H <= 32 ? 32 : 64); }
 static size_t afm_lds_fwd(int F, int D, int H) {
-    const int P = F * (F - 1) / 2;
-    return ((size_t)F * D + (size_t)D * H + 2 * H + P + 8) * sizeof(float) + 2 * (size_t)P * sizeof(short) + 16;
+    const int P = F * (F - 1) / 2, HM = afm_hmax(H);
+    return ((size_t)D * HM + 2 * HM + 64 + 8 + (size_t)F * D + P) * sizeof(float) + 2 * (size_t)P * sizeof(short) + 16;
 }
 static size_t afm_lds_bwd(int F, int D, int H) {
-    const int P = F * (F - 1) / 2;
-    return ((size_t)F * D + 2 * (size_t)D * H + 4 * H + D + (size_t)P * H + (size_t)P * D + 8) * sizeof(float) +
+    const int P = F * (F - 1) / 2, HM = afm_hmax(H), DP4 = (D + 3) & ~3;
+    return (2 * (size_t)D * HM + 4 * HM + (size_t)P * HM + 2 * (size_t)P * DP4 + 8 + (size_t)F * D + D) * sizeof(float) +
            2 * (size_t)P * sizeof(short) + 16;
 }
 
