@@ -434,6 +434,137 @@ __global__ __launch_bounds__(256) void k_bilinear_bwd_w(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// BilinearInteraction, D == 16: the three per-pair 16x16 products on v_mfma_f32_16x16x4_f32 (exact fp32).
+//   A operand lane l: A[m = l&15][k = l>>4]; B operand: B[k = l>>4][n = l&15]; C/D: col = l&15, row = 4*(l>>4) + r.
+// A wave owns a 16-row batch tile; pairs are dealt round-robin to the block's waves.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pair_ij(int p, int F, int& i, int& j) {
+    i = 0;
+    int rem = p;
+    while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+    j = i + 1 + rem;
+}
+__device__ __forceinline__ int bil_q(int wtype, int p, int i) { return wtype == 0 ? p : (wtype == 1 ? i : 0); }
+
+// forward: out[b,p,:] = (x_i W_q) * x_j.   grid (ceil(B/16)), block 256: wave w takes pairs p = w, w+4, ...
+__global__ __launch_bounds__(256) void k_bil16_fwd(const float* __restrict__ x, const float* __restrict__ W, int wtype,
+                                                   int B, int F, float* __restrict__ out) {
+    constexpr int D = 16;
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int brow = b0 + m;                        // A-operand row of this lane
+    const bool row_ok = brow < B;
+    for (int p = wave; p < P; p += 4) {
+        int i, j;
+        pair_ij(p, F, i, j);
+        const float* Wq = W + (int64_t)bil_q(wtype, p, i) * D * D;
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = kq + 4 * s4;
+            const float a = row_ok ? x[((int64_t)brow * F + i) * D + k] : 0.f;
+            const float bb = Wq[k * D + m];
+            u = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, u, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {               // C layout: row 4*kq + r, col m
+            const int b = b0 + 4 * kq + r;
+            if (b < B) out[((int64_t)b * P + p) * D + m] = u[r] * x[((int64_t)b * F + j) * D + m];
+        }
+    }
+}
+
+// grad_x.  grid (ceil(B/16)), block 256; the tile's grad rows [16][F][16] accumulate in LDS.
+//   u = x_i W ; grad x_j = g * u ; t = g * x_j ; grad x_i = t W^T
+__global__ __launch_bounds__(256) void k_bil16_bwd_x(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ gout, int wtype, int B, int F,
+                                                     float* __restrict__ gx) {
+    constexpr int D = 16;
+    extern __shared__ __attribute__((aligned(16))) float acc[];     // [16][F*D]
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int FD = F * D;
+    for (int e = threadIdx.x; e < 16 * FD; e += blockDim.x) acc[e] = 0.f;
+    __syncthreads();
+    const int brow = b0 + m;
+    const bool row_ok = brow < B;
+    for (int p = wave; p < P; p += 4) {
+        int i, j;
+        pair_ij(p, F, i, j);
+        const float* Wq = W + (int64_t)bil_q(wtype, p, i) * D * D;
+        f32x4 u = {0.f, 0.f, 0.f, 0.f}, dxi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = kq + 4 * s4;
+            // forward product: A = x_i[row m][k], B = W[k][n=m]
+            const float a = row_ok ? x[((int64_t)brow * F + i) * D + k] : 0.f;
+            u = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Wq[k * D + m], u, 0, 0, 0);
+            // grad x_i = t W^T: A = t[row m][k = d2], B = W^T[k = d2][n = d] = W[d = m][d2 = k]
+            const float t = row_ok ? gout[((int64_t)brow * P + p) * D + k] * x[((int64_t)brow * F + j) * D + k] : 0.f;
+            dxi = __builtin_amdgcn_mfma_f32_16x16x4f32(t, Wq[m * D + k], dxi, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            const int b = b0 + row;
+            if (b < B) {
+                atomicAdd(&acc[row * FD + i * D + m], dxi[r]);
+                atomicAdd(&acc[row * FD + j * D + m], gout[((int64_t)b * P + p) * D + m] * u[r]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * FD; e += blockDim.x) {
+        const int row = e / FD;
+        if (b0 + row < B) gx[(int64_t)(b0 + row) * FD + (e - row * FD)] = acc[e];
+    }
+}
+
+// grad_W[q] += x_i^T (g * x_j).   grid (P, splits), block 256: the block's waves stride over the 16-row tiles of the
+// split; A = x_i^T: A[m = d][k = row], B = t[k = row][n = d2]; one 16x16 accumulator per wave, met in LDS.
+__global__ __launch_bounds__(256) void k_bil16_bwd_w(const float* __restrict__ x, const float* __restrict__ gout,
+                                                     int wtype, int B, int F, int tiles_per_split,
+                                                     float* __restrict__ gW) {
+    constexpr int D = 16;
+    __shared__ float red[4][256];
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int p = blockIdx.x;
+    int i, j;
+    pair_ij(p, F, i, j);
+    const int tile0 = blockIdx.y * tiles_per_split;
+    const int ntiles = (B + 15) / 16;
+    const int tile1 = min(ntiles, tile0 + tiles_per_split);
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tile0 + wave; t < tile1; t += 4) {
+        const int b0 = t * 16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int b = b0 + kq + 4 * s4;          // k index = batch row
+            float a = 0.f, tv = 0.f;
+            if (b < B) {
+                a = x[((int64_t)b * F + i) * D + m];                                  // x_i[b][d = m]
+                tv = gout[((int64_t)b * P + p) * D + m] * x[((int64_t)b * F + j) * D + m];   // t[b][d2 = m]
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tv, c, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * D + m] = c[r];      // dW[d = row][d2 = col]
+    __syncthreads();
+    const int e = threadIdx.x;
+    const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    atomicAdd(&gW[(int64_t)bil_q(wtype, p, i) * D * D + e], v);
+}
+
+// ---------------------------------------------------------------------------------------------
 // SENET: z[b,f] = mean_d | max_d x[b,f,d]  ;  v[b,f,d] = x[b,f,d] * a[b,f]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_field_pool_fwd(const float* __restrict__ x, int64_t n_fields, int D,
@@ -549,6 +680,10 @@ extern "C" int dt_bilinear_fwd(const float* x, const float* W, int wtype, int B,
     DT_REQUIRE(B >= 0 && F >= 2 && D > 0 && wtype >= 0 && wtype <= 2, "dt_bilinear_fwd: bad arguments");
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && W && out, "dt_bilinear_fwd: null pointer");
+    if (D == 16) {
+        hipLaunchKernelGGL(k_bil16_fwd, dim3(ceil_div(B, 16)), dim3(256), 0, as_stream(stream), x, W, wtype, B, F, out);
+        return launch_status("dt_bilinear_fwd");
+    }
     const size_t lds = ((size_t)D * D + 2 * 64 * (D + 1)) * sizeof(float);
     DT_UNSUPPORTED(lds > 64 * 1024, "dt_bilinear_fwd: D=%d too large", D);
     hipLaunchKernelGGL(k_bilinear_fwd, dim3(ceil_div(B, 64), F * (F - 1) / 2), dim3(64), lds, as_stream(stream), x, W,
@@ -563,6 +698,19 @@ extern "C" int dt_bilinear_bwd(const float* x, const float* W, const float* grad
     DT_REQUIRE(x && W && grad_out && grad_x && grad_W, "dt_bilinear_bwd: null pointer");
     DT_UNSUPPORTED(D > 64, "dt_bilinear_bwd: D=%d > 64", D);
     hipStream_t st = as_stream(stream);
+    if (D == 16 && (size_t)16 * F * 16 * sizeof(float) <= 150 * 1024) {
+        const size_t lds16 = (size_t)16 * F * 16 * sizeof(float);
+        hipFuncSetAttribute((const void*)k_bil16_bwd_x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(k_bil16_bwd_x, dim3(ceil_div(B, 16)), dim3(256), lds16, st, x, W, grad_out, wtype, B, F,
+                           grad_x);
+        const int ntiles = ceil_div(B, 16);
+        int splits16 = ntiles >= 64 ? 8 : 1;
+        const int tps = ceil_div(ntiles, splits16);
+        splits16 = ceil_div(ntiles, tps);
+        hipLaunchKernelGGL(k_bil16_bwd_w, dim3(F * (F - 1) / 2, splits16), dim3(256), 0, st, x, grad_out, wtype, B, F, tps,
+                           grad_W);
+        return launch_status("dt_bilinear_bwd");
+    }
     const size_t lds = ((size_t)D * D + 3 * 64 * (D + 1)) * sizeof(float);
     hipLaunchKernelGGL(k_bilinear_bwd_x, dim3(ceil_div(B, 64), F), dim3(64), lds, st, x, W, grad_out, wtype, B, F, D,
                        grad_x);

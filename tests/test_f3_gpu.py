@@ -62,7 +62,7 @@ def test_afm_pool_no_bias_and_limits(dev):
 
 
 @pytest.mark.parametrize('btype', ['field_interaction', 'field_each', 'field_all'])
-@pytest.mark.parametrize('B,F,D', [(130, 6, 8), (64, 26, 16), (5, 2, 3), (70, 4, 33)])
+@pytest.mark.parametrize('B,F,D', [(130, 6, 8), (64, 26, 16), (5, 2, 3), (70, 4, 33), (1000, 7, 16), (13, 3, 16)])
 def test_bilinear(dev, btype, B, F, D):
     from deeptables_amd import ops
     from oracle import reference_layers as R
