@@ -448,81 +448,134 @@ __device__ __forceinline__ void pair_ij(int p, int F, int& i, int& j) {
 }
 __device__ __forceinline__ int bil_q(int wtype, int p, int i) { return wtype == 0 ? p : (wtype == 1 ? i : 0); }
 
-// forward: out[b,p,:] = (x_i W_q) * x_j.   grid (ceil(B/16)), block 256: wave w takes pairs p = w, w+4, ...
+// forward, pair-major: out[b,p,:] = (x_i W_q) * x_j.  grid (P, splits); W_q sits in 4 registers per lane (the MFMA B
+// operand) while the block's waves walk the 16-row tiles of their split.
 __global__ __launch_bounds__(256) void k_bil16_fwd(const float* __restrict__ x, const float* __restrict__ W, int wtype,
-                                                   int B, int F, float* __restrict__ out) {
+                                                   int B, int F, int tiles_per_split, float* __restrict__ out) {
     constexpr int D = 16;
     const int P = F * (F - 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.x * 16;
-    const int brow = b0 + m;                        // A-operand row of this lane
-    const bool row_ok = brow < B;
-    for (int p = wave; p < P; p += 4) {
-        int i, j;
-        pair_ij(p, F, i, j);
-        const float* Wq = W + (int64_t)bil_q(wtype, p, i) * D * D;
+    const int p = blockIdx.x;
+    int i, j;
+    pair_ij(p, F, i, j);
+    const float* Wq = W + (int64_t)bil_q(wtype, p, i) * D * D;
+    float wb[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) wb[s4] = Wq[(kq + 4 * s4) * D + m];
+    const int ntiles = (B + 15) / 16;
+    const int tile0 = blockIdx.y * tiles_per_split, tile1 = min(ntiles, tile0 + tiles_per_split);
+    for (int t = tile0 + wave; t < tile1; t += 4) {
+        const int b0 = t * 16;
+        const int brow = b0 + m;
+        const bool row_ok = brow < B;
+        float xa[4], xj4[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xa[s4] = row_ok ? x[((int64_t)brow * F + i) * D + kq + 4 * s4] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * kq + r;
+            xj4[r] = b < B ? x[((int64_t)b * F + j) * D + m] : 0.f;
+        }
         f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int k = kq + 4 * s4;
-            const float a = row_ok ? x[((int64_t)brow * F + i) * D + k] : 0.f;
-            const float bb = Wq[k * D + m];
-            u = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, u, 0, 0, 0);
-        }
+        for (int s4 = 0; s4 < 4; ++s4) u = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], wb[s4], u, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {               // C layout: row 4*kq + r, col m
             const int b = b0 + 4 * kq + r;
-            if (b < B) out[((int64_t)b * P + p) * D + m] = u[r] * x[((int64_t)b * F + j) * D + m];
+            if (b < B) out[((int64_t)b * P + p) * D + m] = u[r] * xj4[r];
         }
     }
 }
 
 // grad_x.  grid (ceil(B/16)), block 256; the tile's grad rows [16][F][16] accumulate in LDS.
 //   u = x_i W ; grad x_j = g * u ; t = g * x_j ; grad x_i = t W^T
+struct Bil16Regs {          // everything one (pair, 16-row tile) step reads from memory
+    float xi[4], tj[4], wf[4], wt[4], gc[4];
+    int i, j;
+};
+
+__device__ __forceinline__ void bil16_load(Bil16Regs& r, const float* __restrict__ x, const float* __restrict__ W,
+                                           const float* __restrict__ gout, const short* __restrict__ pij, int wtype,
+                                           int p, int P, int F, int B, int b0, int m, int kq) {
+    constexpr int D = 16;
+    r.i = pij[2 * p];
+    r.j = pij[2 * p + 1];
+    const float* Wq = W + (int64_t)bil_q(wtype, p, r.i) * D * D;
+    const int brow = b0 + m;
+    const bool row_ok = brow < B;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = kq + 4 * s4;
+        r.xi[s4] = row_ok ? x[((int64_t)brow * F + r.i) * D + k] : 0.f;
+        r.tj[s4] = row_ok ? gout[((int64_t)brow * P + p) * D + k] * x[((int64_t)brow * F + r.j) * D + k] : 0.f;
+        r.wf[s4] = Wq[k * D + m];      // forward:  B = W[k][n = m]
+        r.wt[s4] = Wq[m * D + k];      // grad x_i: B = W^T[k = d2][n = d] = W[d = m][d2 = k]
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + 4 * kq + q;
+        r.gc[q] = b < B ? gout[((int64_t)b * P + p) * D + m] : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bil16_bwd_x(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ gout, int wtype, int B, int F,
                                                      float* __restrict__ gx) {
     constexpr int D = 16;
-    extern __shared__ __attribute__((aligned(16))) float acc[];     // [16][F*D]
+    extern __shared__ __attribute__((aligned(16))) float acc[];     // [4 waves][16][F*D] + pair table
     const int P = F * (F - 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int b0 = blockIdx.x * 16;
     const int FD = F * D;
-    for (int e = threadIdx.x; e < 16 * FD; e += blockDim.x) acc[e] = 0.f;
-    __syncthreads();
-    const int brow = b0 + m;
-    const bool row_ok = brow < B;
-    for (int p = wave; p < P; p += 4) {
+    short* pij = reinterpret_cast<short*>(acc + 4 * 16 * FD);       // [P][2]
+    for (int e = threadIdx.x; e < 4 * 16 * FD; e += blockDim.x) acc[e] = 0.f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
         int i, j;
         pair_ij(p, F, i, j);
-        const float* Wq = W + (int64_t)bil_q(wtype, p, i) * D * D;
-        f32x4 u = {0.f, 0.f, 0.f, 0.f}, dxi = {0.f, 0.f, 0.f, 0.f};
+        pij[2 * p] = (short)i;
+        pij[2 * p + 1] = (short)j;
+    }
+    __syncthreads();
+    // Each wave owns a contiguous range of pairs and a PRIVATE copy of the tile's gradient rows, so its updates are
+    // plain LDS read-modify-writes (LDS atomics issue at ~0.5 lane/clk and were the whole cost of this kernel);
+    // combinations order keeps field i constant over long runs, so grad x_i accumulates in registers and is flushed
+    // when i changes.  The next pair's loads are in flight while this pair's MFMAs run.
+    float* mine = acc + (size_t)wave * 16 * FD;
+    const int p_begin = (int)((int64_t)P * wave / 4), p_end = (int)((int64_t)P * (wave + 1) / 4);
+    Bil16Regs cur, nxt;
+    if (p_begin < p_end) bil16_load(cur, x, W, gout, pij, wtype, p_begin, P, F, B, b0, m, kq);
+    f32x4 dxi = {0.f, 0.f, 0.f, 0.f};
+    int run_i = p_begin < p_end ? cur.i : -1;
+    for (int p = p_begin; p < p_end; ++p) {
+        if (p + 1 < p_end) bil16_load(nxt, x, W, gout, pij, wtype, p + 1, P, F, B, b0, m, kq);
+        if (cur.i != run_i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(4 * kq + r) * FD + run_i * D + m] += dxi[r];
+            dxi = f32x4{0.f, 0.f, 0.f, 0.f};
+            run_i = cur.i;
+        }
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const int k = kq + 4 * s4;
-            // forward product: A = x_i[row m][k], B = W[k][n=m]
-            const float a = row_ok ? x[((int64_t)brow * F + i) * D + k] : 0.f;
-            u = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Wq[k * D + m], u, 0, 0, 0);
-            // grad x_i = t W^T: A = t[row m][k = d2], B = W^T[k = d2][n = d] = W[d = m][d2 = k]
-            const float t = row_ok ? gout[((int64_t)brow * P + p) * D + k] * x[((int64_t)brow * F + j) * D + k] : 0.f;
-            dxi = __builtin_amdgcn_mfma_f32_16x16x4f32(t, Wq[m * D + k], dxi, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.xi[s4], cur.wf[s4], u, 0, 0, 0);
+            dxi = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.tj[s4], cur.wt[s4], dxi, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kq + r;
-            const int b = b0 + row;
-            if (b < B) {
-                atomicAdd(&acc[row * FD + i * D + m], dxi[r]);
-                atomicAdd(&acc[row * FD + j * D + m], gout[((int64_t)b * P + p) * D + m] * u[r]);
-            }
-        }
+        for (int r = 0; r < 4; ++r) mine[(4 * kq + r) * FD + cur.j * D + m] += cur.gc[r] * u[r];
+        cur = nxt;
+    }
+    if (run_i >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(4 * kq + r) * FD + run_i * D + m] += dxi[r];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * FD; e += blockDim.x) {
         const int row = e / FD;
-        if (b0 + row < B) gx[(int64_t)(b0 + row) * FD + (e - row * FD)] = acc[e];
+        if (b0 + row < B)
+            gx[(int64_t)(b0 + row) * FD + (e - row * FD)] =
+                (acc[e] + acc[16 * FD + e]) + (acc[2 * 16 * FD + e] + acc[3 * 16 * FD + e]);
     }
 }
 
@@ -681,7 +734,12 @@ extern "C" int dt_bilinear_fwd(const float* x, const float* W, int wtype, int B,
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && W && out, "dt_bilinear_fwd: null pointer");
     if (D == 16) {
-        hipLaunchKernelGGL(k_bil16_fwd, dim3(ceil_div(B, 16)), dim3(256), 0, as_stream(stream), x, W, wtype, B, F, out);
+        const int ntiles = ceil_div(B, 16);
+        int splits16 = ntiles >= 64 ? 8 : 1;
+        const int tps = ceil_div(ntiles, splits16);
+        splits16 = ceil_div(ntiles, tps);
+        hipLaunchKernelGGL(k_bil16_fwd, dim3(F * (F - 1) / 2, splits16), dim3(256), 0, as_stream(stream), x, W, wtype, B,
+                           F, tps, out);
         return launch_status("dt_bilinear_fwd");
     }
     const size_t lds = ((size_t)D * D + 2 * 64 * (D + 1)) * sizeof(float);
@@ -698,8 +756,8 @@ extern "C" int dt_bilinear_bwd(const float* x, const float* W, const float* grad
     DT_REQUIRE(x && W && grad_out && grad_x && grad_W, "dt_bilinear_bwd: null pointer");
     DT_UNSUPPORTED(D > 64, "dt_bilinear_bwd: D=%d > 64", D);
     hipStream_t st = as_stream(stream);
-    if (D == 16 && (size_t)16 * F * 16 * sizeof(float) <= 150 * 1024) {
-        const size_t lds16 = (size_t)16 * F * 16 * sizeof(float);
+    if (D == 16 && (size_t)4 * 16 * F * 16 * sizeof(float) + (size_t)F * F * 2 <= 150 * 1024) {
+        const size_t lds16 = (size_t)4 * 16 * F * 16 * sizeof(float) + (size_t)F * (F - 1) * sizeof(short) + 16;
         hipFuncSetAttribute((const void*)k_bil16_bwd_x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipLaunchKernelGGL(k_bil16_bwd_x, dim3(ceil_div(B, 16)), dim3(256), lds16, st, x, W, grad_out, wtype, B, F,
                            grad_x);

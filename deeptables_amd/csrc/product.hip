@@ -263,6 +263,184 @@ static int row_grid(int B, int wpb, int cap) {
     return g < 1 ? 1 : g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// OuterProduct 'mat', D == 16, on v_mfma_f32_16x16x4_f32 (exact fp32).  Kp[a][d] = K[a,p,d].
+//   u = x_i Kp^T ; out = sum_a u[a] x_j[a] ; grad x_j = g u ; grad x_i = g (x_j Kp) ; grad Kp = (g x_j)^T x_i
+// A operand lane l: A[m = l&15][k = l>>4]; B: B[k = l>>4][n = l&15]; C/D: col = l&15, row = 4*(l>>4) + r.
+// A wave owns a 16-row batch tile; pairs are dealt round-robin to the block's 4 waves.
+// ---------------------------------------------------------------------------------------------
+typedef float op_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void op_pair_ij(int p, int F, int& i, int& j) {
+    i = 0;
+    int rem = p;
+    while (rem >= F - 1 - i) { rem -= F - 1 - i; ++i; }
+    j = i + 1 + rem;
+}
+
+// forward, pair-major: grid (P, splits); the pair's Kp^T sits in 4 registers per lane (the MFMA B operand) while
+// the block's waves walk the 16-row tiles of their split.
+__global__ __launch_bounds__(256) void k_op16_fwd(const float* __restrict__ x, const float* __restrict__ K, int B,
+                                                  int F, int tiles_per_split, float* __restrict__ out) {
+    constexpr int D = 16;
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int p = blockIdx.x;
+    int i, j;
+    op_pair_ij(p, F, i, j);
+    float kb[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) kb[s4] = K[((int64_t)m * P + p) * D + kq + 4 * s4];   // Kp^T[k = d][n = a = m]
+    const int ntiles = (B + 15) / 16;
+    const int tile0 = blockIdx.y * tiles_per_split, tile1 = min(ntiles, tile0 + tiles_per_split);
+    for (int t = tile0 + wave; t < tile1; t += 4) {
+        const int b0 = t * 16;
+        const int brow = b0 + m;
+        const bool row_ok = brow < B;
+        op_f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        float xa[4], xj4[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xa[s4] = row_ok ? x[((int64_t)brow * F + i) * D + kq + 4 * s4] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * kq + r;
+            xj4[r] = b < B ? x[((int64_t)b * F + j) * D + m] : 0.f;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) u = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], kb[s4], u, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                        // row 4*kq + r, col a = m: dot with x_j over the 16 cols
+            const int b = b0 + 4 * kq + r;
+            const float v = group_sum<16>(u[r] * xj4[r]);
+            if (m == 0 && b < B) out[(int64_t)b * P + p] = v;
+        }
+    }
+}
+
+struct Op16Regs {           // everything one (pair, 16-row tile) step reads from memory
+    float xi[4], xj[4], kt[4], kn[4], g[4];
+    int i, j;
+};
+
+__device__ __forceinline__ void op16_load(Op16Regs& r, const float* __restrict__ x, const float* __restrict__ K,
+                                          const float* __restrict__ gout, const short* __restrict__ pij, int p, int P,
+                                          int F, int B, int b0, int m, int kq) {
+    constexpr int D = 16;
+    r.i = pij[2 * p];
+    r.j = pij[2 * p + 1];
+    const int brow = b0 + m;
+    const bool row_ok = brow < B;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = kq + 4 * s4;
+        r.xi[s4] = row_ok ? x[((int64_t)brow * F + r.i) * D + k] : 0.f;    // A[row][k = d]
+        r.xj[s4] = row_ok ? x[((int64_t)brow * F + r.j) * D + k] : 0.f;    // A[row][k = a]
+        r.kt[s4] = K[((int64_t)m * P + p) * D + k];                        // Kp^T[k = d][n = a = m]
+        r.kn[s4] = K[((int64_t)k * P + p) * D + m];                        // Kp[k = a][n = d = m]
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + 4 * kq + q;
+        r.g[q] = b < B ? gout[(int64_t)b * P + p] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_op16_bwd_x(const float* __restrict__ x, const float* __restrict__ K,
+                                                    const float* __restrict__ gout, int B, int F,
+                                                    float* __restrict__ gx) {
+    constexpr int D = 16;
+    extern __shared__ __attribute__((aligned(16))) float acc[];     // [4 waves][16][F*D] + pair table
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int FD = F * D;
+    short* pij = reinterpret_cast<short*>(acc + 4 * 16 * FD);
+    for (int e = threadIdx.x; e < 4 * 16 * FD; e += blockDim.x) acc[e] = 0.f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        int i, j;
+        op_pair_ij(p, F, i, j);
+        pij[2 * p] = (short)i;
+        pij[2 * p + 1] = (short)j;
+    }
+    __syncthreads();
+    // private per-wave gradient rows + contiguous pair ranges: plain LDS read-modify-writes instead of LDS atomics,
+    // grad x_i accumulated in registers while field i stays the same (see k_bil16_bwd_x)
+    float* mine = acc + (size_t)wave * 16 * FD;
+    const int p_begin = (int)((int64_t)P * wave / 4), p_end = (int)((int64_t)P * (wave + 1) / 4);
+    Op16Regs cur, nxt;
+    if (p_begin < p_end) op16_load(cur, x, K, gout, pij, p_begin, P, F, B, b0, m, kq);
+    float dxi[4] = {0.f, 0.f, 0.f, 0.f};
+    int run_i = p_begin < p_end ? cur.i : -1;
+    for (int p = p_begin; p < p_end; ++p) {
+        if (p + 1 < p_end) op16_load(nxt, x, K, gout, pij, p + 1, P, F, B, b0, m, kq);
+        if (cur.i != run_i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { mine[(4 * kq + r) * FD + run_i * D + m] += dxi[r]; dxi[r] = 0.f; }
+            run_i = cur.i;
+        }
+        op_f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            u = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.xi[s4], cur.kt[s4], u, 0, 0, 0);   // x_i Kp^T
+            w = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.xj[s4], cur.kn[s4], w, 0, 0, 0);   // x_j Kp
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dxi[r] += cur.g[r] * w[r];                                                 // grad x_i[d = m]
+            mine[(4 * kq + r) * FD + cur.j * D + m] += cur.g[r] * u[r];               // grad x_j[a = m]
+        }
+        cur = nxt;
+    }
+    if (run_i >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(4 * kq + r) * FD + run_i * D + m] += dxi[r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * FD; e += blockDim.x) {
+        const int row = e / FD;
+        if (b0 + row < B)
+            gx[(int64_t)(b0 + row) * FD + (e - row * FD)] =
+                (acc[e] + acc[16 * FD + e]) + (acc[2 * 16 * FD + e] + acc[3 * 16 * FD + e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_op16_bwd_k(const float* __restrict__ x, const float* __restrict__ gout, int B,
+                                                    int F, int tiles_per_split, float* __restrict__ gK) {
+    constexpr int D = 16;
+    __shared__ float red[4][256];
+    const int P = F * (F - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int p = blockIdx.x;
+    int i, j;
+    op_pair_ij(p, F, i, j);
+    const int tile0 = blockIdx.y * tiles_per_split;
+    const int ntiles = (B + 15) / 16;
+    const int tile1 = min(ntiles, tile0 + tiles_per_split);
+    op_f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tile0 + wave; t < tile1; t += 4) {
+        const int b0 = t * 16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int b = b0 + kq + 4 * s4;                  // k = batch row
+            float a = 0.f, bv = 0.f;
+            if (b < B) {
+                a = gout[(int64_t)b * P + p] * x[((int64_t)b * F + j) * D + m];    // A[m = a][k = b] = g x_j[b][a]
+                bv = x[((int64_t)b * F + i) * D + m];                              // B[k = b][n = d] = x_i[b][d]
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, c, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * D + m] = c[r];      // [a = row][d = col]
+    __syncthreads();
+    const int e = threadIdx.x;
+    const int a = e / D, d = e - a * D;
+    atomicAdd(&gK[((int64_t)a * P + p) * D + d], red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+}
+
 }  // namespace dt
 
 using namespace dt;
@@ -317,6 +495,14 @@ extern "C" int dt_outer_product_fwd(const float* x, const float* kernel, int ker
         return pair_fwd(x, nullptr, kernel, B, F, D, out, stream, "dt_outer_product_fwd(num)");
     DT_REQUIRE(kernel_type == DT_OP_KERNEL_MAT, "dt_outer_product_fwd: kernel_type %d", kernel_type);
     const int P = F * (F - 1) / 2;
+    if (D == 16) {
+        const int ntiles = ceil_div(B, 16);
+        int splits16 = ntiles >= 64 ? 8 : 1;
+        const int tps = ceil_div(ntiles, splits16);
+        splits16 = ceil_div(ntiles, tps);
+        hipLaunchKernelGGL(k_op16_fwd, dim3(P, splits16), dim3(256), 0, as_stream(stream), x, kernel, B, F, tps, out);
+        return launch_status("dt_outer_product_fwd(mat)");
+    }
     const size_t lds = ((size_t)D * D + 2 * 64 * (D + 1)) * sizeof(float);
     DT_UNSUPPORTED(lds > 64 * 1024, "dt_outer_product_fwd(mat): D=%d too large for LDS tiling", D);
     hipLaunchKernelGGL(k_op_mat_fwd, dim3(ceil_div(B, 64), P), dim3(64), lds, as_stream(stream), x,
@@ -342,6 +528,19 @@ extern "C" int dt_outer_product_bwd(const float* x, const float* kernel, int ker
     DT_UNSUPPORTED(lds > 64 * 1024 || D > 64,
                    "dt_outer_product_bwd(mat): D=%d too large for LDS tiling", D);
     hipStream_t st = as_stream(stream);
+    if (D == 16 && (size_t)4 * 16 * F * 16 * sizeof(float) + (size_t)F * F * 2 <= 150 * 1024) {
+        const size_t lds16 = (size_t)4 * 16 * F * 16 * sizeof(float) + (size_t)F * (F - 1) * sizeof(short) + 16;
+        hipFuncSetAttribute((const void*)k_op16_bwd_x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(k_op16_bwd_x, dim3(ceil_div(B, 16)), dim3(256), lds16, st, x, kernel, grad_out, B, F, grad_x);
+        if (grad_kernel) {
+            const int ntiles = ceil_div(B, 16);
+            int splits16 = ntiles >= 64 ? 8 : 1;
+            const int tps = ceil_div(ntiles, splits16);
+            splits16 = ceil_div(ntiles, tps);
+            hipLaunchKernelGGL(k_op16_bwd_k, dim3(P, splits16), dim3(256), 0, st, x, grad_out, B, F, tps, grad_kernel);
+        }
+        return launch_status("dt_outer_product_bwd(mat)");
+    }
     hipLaunchKernelGGL(k_op_mat_bwd_x, dim3(ceil_div(B, 64), F), dim3(64), lds, st, x, kernel,
                        grad_out, B, F, D, grad_x);
     if (grad_kernel) {

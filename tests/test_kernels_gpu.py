@@ -197,7 +197,7 @@ def test_inner_product(dev, B, F, D):
 
 
 @pytest.mark.parametrize('kt', ['mat', 'vec', 'num'])
-@pytest.mark.parametrize('B,F,D', [(5, 4, 3), (64, 26, 16), (130, 6, 8)])
+@pytest.mark.parametrize('B,F,D', [(5, 4, 3), (64, 26, 16), (130, 6, 8), (1000, 7, 16), (13, 3, 16)])
 def test_outer_product(dev, B, F, D, kt):
     from deeptables_amd import ops
     g = gen(B + F + D)
