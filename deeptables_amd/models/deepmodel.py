@@ -346,6 +346,7 @@ class DeepModel:
                 for m in metrics:
                     logs[training.metric_name(m)] = training.compute_metric(m, yt, yp, self.task)
             if val is not None and (epoch + 1) % max(validation_freq, 1) == 0:
+                self._sync_sharded_tables()        # table rows owned by other ranks: fetch their current values
                 vlogs = self._evaluate_batches(val, batch_size, metrics)
                 logs.update({f'val_{k}': v for k, v in vlogs.items()})
             history.add(epoch, logs)
@@ -358,11 +359,24 @@ class DeepModel:
                     stop = True
             if stop:
                 break
+        self._sync_sharded_tables()
         for cb in callbacks or []:
             if hasattr(cb, 'on_train_end'):
                 cb.on_train_end()
         history.history = IgnoreCaseDict(history.history)
         return history
+
+    def _sync_sharded_tables(self):
+        """With parallel.ShardedEmbeddingStrategy each rank's packed table is current only for the fields it owns;
+        before the model is evaluated / saved every owner broadcasts its rows."""
+        strategy = self.config.distribute_strategy
+        if strategy is None or not getattr(strategy, 'sharded_embeddings', False) or strategy.world_size == 1:
+            return
+        if not getattr(self.model, '_dt_sharded_step', False):
+            return
+        for layer in self.model.modules():
+            if isinstance(layer, MultiColumnEmbedding):
+                strategy.sync_tables(layer)
 
     def _evaluate_batches(self, data, batch_size, metrics):
         self.model.eval()
