@@ -54,6 +54,12 @@ def named_weights(model):
             for k, wname in enumerate(layer.weight_names()):
                 out[f'{lname}/{wname}'] = layer.W[k]
             continue
+        if cls == 'Cross':
+            for i in range(layer.num_cross_layer):
+                out[f'{lname}/kernels_{i}'] = layer.kernel_stack[i].view(-1, 1)     # Keras shape (num_dims, 1)
+            for i in range(layer.num_cross_layer):
+                out[f'{lname}/bias_{i}'] = layer.bias_stack[i].view(-1, 1)
+            continue
         if cls == 'VarLenColumnEmbedding':
             out[f'{lname}/embedding/embeddings'] = layer.embeddings
             continue

@@ -106,12 +106,22 @@ class Cross(Layer):
 
     def build(self, input_shape):
         num_dims = input_shape[-1]
-        self.kernels = nn.ParameterList()
-        self.bias = nn.ParameterList()
-        for i in range(self.num_cross_layer):   # Keras shapes (num_dims, 1)
-            self.kernels.append(nn.Parameter(initialize((num_dims, 1), 'glorot_uniform')))
-            self.bias.append(nn.Parameter(initialize((num_dims, 1), 'zeros')))
+        L = self.num_cross_layer
+        # the reference keeps L pairs of (num_dims, 1) variables kernels_i / bias_i (layers.py:423-426); here they are
+        # the rows of two stacked parameters, which is the layout the depth-fused kernel reads (and lets its backward
+        # accumulate straight into the model's flat gradient buffer).  `kernels` / `bias` expose the Keras shapes.
+        self.kernel_stack = nn.Parameter(torch.stack([initialize((num_dims, 1), 'glorot_uniform').reshape(-1)
+                                                      for _ in range(L)], 0) if L else torch.zeros(0, num_dims))
+        self.bias_stack = nn.Parameter(torch.zeros(L, num_dims))
         self.built = True
+
+    @property
+    def kernels(self):
+        return [self.kernel_stack[i].view(-1, 1) for i in range(self.num_cross_layer)]
+
+    @property
+    def bias(self):
+        return [self.bias_stack[i].view(-1, 1) for i in range(self.num_cross_layer)]
 
     def compute_output_shape(self, input_shape):
         if len(input_shape) != 2:
@@ -122,9 +132,7 @@ class Cross(Layer):
         _ndim_check(x, 2, 'x')
         if self.num_cross_layer == 0:
             return x
-        w = torch.stack([k.reshape(-1) for k in self.kernels], 0)
-        b = torch.stack([k.reshape(-1) for k in self.bias], 0)
-        return ops.cross(x, w, b)
+        return ops.cross(x, self.kernel_stack, self.bias_stack)
 
     def get_config(self):
         c = super().get_config()

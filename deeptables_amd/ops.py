@@ -28,6 +28,20 @@ def _idx_kind(idx):
 # ------------------------------------------------------------------------------------------------
 # MultiColumnEmbedding.call — deeptables/models/layers.py:889-904
 # ------------------------------------------------------------------------------------------------
+def _grad_target(p):
+    """-> (buffer the backward kernel ACCUMULATES this parameter's gradient into, value `backward` returns for it).
+    Parameters of a model whose dense weights were flattened (training.flatten_dense_parameters) carry a pre-zeroed
+    view of the model's ONE flat gradient buffer: the kernel adds straight into it and autograd is told there is
+    nothing left to accumulate (None) — no zero-fill, no AccumulateGrad add, and the optimizer updates the whole
+    model with one launch.  Anything else gets a fresh zero tensor that is returned as the gradient."""
+    view = getattr(p, '_dt_grad_view', None)
+    g = p.grad if view is not None else None
+    if g is not None and g.data_ptr() == view.data_ptr() and g.shape == view.shape:
+        return view, None
+    z = torch.zeros_like(p)
+    return z, z
+
+
 class SparseRowGrad:
     """The (indices, values) pair TF calls IndexedSlices: gradient of a packed embedding table."""
 
@@ -238,6 +252,7 @@ class _Cross(torch.autograd.Function):
         check(lib().dt_cross_fwd(ptr(x), ptr(w), ptr(b), B, C, L, ptr(out), ptr(save_s), stream_ptr()),
               'dt_cross_fwd')
         ctx.save_for_backward(x, w, b, save_s)
+        ctx.w_ref, ctx.b_ref = w, b
         return out
 
     @staticmethod
@@ -247,13 +262,13 @@ class _Cross(torch.autograd.Function):
         L = w.shape[0]
         g = _f32c(g)
         gx = torch.empty_like(x)
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(b)
+        gw, gw_ret = _grad_target(ctx.w_ref)
+        gb, gb_ret = _grad_target(ctx.b_ref)
         nbytes = lib().dt_cross_workspace_bytes(B, C, L)
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
         check(lib().dt_cross_bwd(ptr(x), ptr(w), ptr(b), ptr(save_s), ptr(g), B, C, L, ptr(gx), ptr(gw),
                                  ptr(gb), ptr(ws), stream_ptr()), 'dt_cross_bwd')
-        return gx, gw, gb
+        return gx, gw_ret, gb_ret
 
 
 def cross(x, w, b):
@@ -300,6 +315,7 @@ class _OuterProduct(torch.autograd.Function):
                                          stream_ptr()), 'dt_outer_product_fwd')
         ctx.save_for_backward(x, kernel)
         ctx.kernel_type = kernel_type
+        ctx.k_ref = kernel
         return out
 
     @staticmethod
@@ -307,10 +323,10 @@ class _OuterProduct(torch.autograd.Function):
         x, kernel = ctx.saved_tensors
         B, F, D = x.shape
         gx = torch.empty_like(x)
-        gk = torch.zeros_like(kernel)
+        gk, gk_ret = _grad_target(ctx.k_ref)
         check(lib().dt_outer_product_bwd(ptr(x), ptr(kernel), ctx.kernel_type, ptr(_f32c(g)), B, F, D,
                                          ptr(gx), ptr(gk), stream_ptr()), 'dt_outer_product_bwd')
-        return gx, gk, None
+        return gx, gk_ret, None
 
 
 def outer_product(x, kernel, kernel_type='mat'):
@@ -415,6 +431,7 @@ class _Dense(torch.autograd.Function):
         check(lib().dt_dense_fwd(ptr(x2), ptr(W), ptr(bias_c), act, N, K, M, ptr(y), stream_ptr()), 'dt_dense_fwd')
         ctx.save_for_backward(x2, W, y)
         ctx.act, ctx.has_bias, ctx.x_shape = act, bias is not None, x.shape
+        ctx.W_ref, ctx.b_ref = W, bias_c
         return y.reshape(*x.shape[:-1], M)
 
     @staticmethod
@@ -425,13 +442,13 @@ class _Dense(torch.autograd.Function):
         gy2 = _f32c(gy).reshape(N, M)
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty_like(x2) if need_x else None
-        gW = torch.zeros_like(W)
-        gb = torch.zeros((M,), dtype=torch.float32, device=W.device) if ctx.has_bias else None
+        gW, gW_ret = _grad_target(ctx.W_ref)
+        gb, gb_ret = _grad_target(ctx.b_ref) if ctx.has_bias else (None, None)
         nbytes = lib().dt_dense_workspace_bytes(N, K, M)
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=W.device)
         check(lib().dt_dense_bwd(ptr(x2), ptr(W), ptr(y), ptr(gy2), ctx.act, N, K, M, ptr(gx), ptr(gW), ptr(gb),
                                  ptr(ws), stream_ptr()), 'dt_dense_bwd')
-        return (gx.reshape(ctx.x_shape) if need_x else None), gW, gb, None
+        return (gx.reshape(ctx.x_shape) if need_x else None), gW_ret, gb_ret, None
 
 
 def dense_supported(x, W):
@@ -505,6 +522,7 @@ class _Bilinear(torch.autograd.Function):
         check(lib().dt_bilinear_fwd(ptr(x), ptr(W), wtype, B, F, D, ptr(out), stream_ptr()), 'dt_bilinear_fwd')
         ctx.save_for_backward(x, W)
         ctx.wtype = wtype
+        ctx.W_ref = W
         return out
 
     @staticmethod
@@ -512,10 +530,10 @@ class _Bilinear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         B, F, D = x.shape
         gx = torch.empty_like(x)
-        gW = torch.zeros_like(W)
+        gW, gW_ret = _grad_target(ctx.W_ref)
         check(lib().dt_bilinear_bwd(ptr(x), ptr(W), ptr(_f32c(g)), ctx.wtype, B, F, D, ptr(gx), ptr(gW),
                                     stream_ptr()), 'dt_bilinear_bwd')
-        return gx, gW, None
+        return gx, gW_ret, None
 
 
 def bilinear_interaction(x, W, bilinear_type='field_interaction'):

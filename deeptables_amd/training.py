@@ -56,7 +56,8 @@ class KerasAdam:
         # optional callable run right before the dense updates of a step (after the table updates were launched):
         # the data-parallel strategy uses it to wait for an all-reduce it started asynchronously
         self.pre_dense_hook = None
-        self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param)})
+        self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param): offset})
+        self._flat_views = None       # [(param, grad view)] when gradients may be accumulated straight into flat_grad
 
     # -- step counter (device resident: int32 t_next, float lr_t, block-arrival counters) -----------------
     def _state_tensor(self, device):
@@ -87,9 +88,10 @@ class KerasAdam:
             self.state[id(p)] = s
         return s
 
-    def register_flat_group(self, flat_param, flat_grad, members, n):
+    def register_flat_group(self, flat_param, flat_grad, members, n, grad_views=False):
         """members: [(param, offset, numel)] whose .data are views of flat_param and whose fused-plan gradients
-        are the matching views of flat_grad.  Their m/v become views of one flat m/v (existing state is kept)."""
+        are the matching views of flat_grad.  Their m/v become views of one flat m/v (existing state is kept).
+        grad_views=True: `zero_grad()` zeroes flat_grad and hands its views out as `.grad` (generic autograd path)."""
         m = torch.zeros_like(flat_param)
         v = torch.zeros_like(flat_param)
         for p, off, cnt in members:
@@ -99,10 +101,24 @@ class KerasAdam:
                 v[off:off + cnt].copy_(old['v'].reshape(-1))
             self.state[id(p)] = {'m': m[off:off + cnt].view(p.shape), 'v': v[off:off + cnt].view(p.shape)}
         self._flat = (flat_param, flat_grad, m, v, int(n), {id(p): off for p, off, _ in members})
+        self._flat_views = [(p, flat_grad[off:off + cnt].view(p.shape)) for p, off, cnt in members] \
+            if grad_views else None
+        for p, off, cnt in members:
+            p._dt_grad_view = flat_grad[off:off + cnt].view(p.shape) if grad_views else None
+        if grad_views:                       # same tensor objects in both places (`p.grad is p._dt_grad_view`)
+            for p, view in self._flat_views:
+                p._dt_grad_view = view
 
-    def zero_grad(self):
+    def zero_grad(self, flat=True):
+        """flat=True: members of the registered flat group get their (zeroed) views of the flat gradient buffer as
+        `.grad` — backward kernels and autograd accumulate straight into it; flat=False: the caller (a fused step)
+        fills the flat buffer itself."""
         for p in self.params:
             p.grad = None
+        if flat and self._flat is not None and self._flat_views is not None:
+            self._flat[1].zero_()
+            for p, view in self._flat_views:
+                p.grad = view
         for layer in self.embedding_layers:
             layer.sparse_grads.clear()
 
@@ -227,6 +243,32 @@ def make_optimizer(spec, params, embedding_layers):
     if callable(spec):
         return spec(params, embedding_layers)
     raise ValueError(f'Unsupported optimizer: {spec!r}')
+
+
+def flatten_dense_parameters(model, optimizer, exclude=()):
+    """Re-home every trainable dense parameter of `model` in ONE flat buffer (and its gradient in another), so that
+    backward kernels accumulate in place (ops._grad_target), a data-parallel exchange is one all-reduce of the flat
+    gradient and the optimizer is one launch.  `exclude`: parameters that stay on their own (embedding tables).
+    Returns (flat_param, flat_grad) or None when the optimizer has no flat-group support."""
+    if not hasattr(optimizer, 'register_flat_group'):
+        return None
+    skip = {id(p) for p in exclude}
+    members, off = [], 0
+    params = [p for p in model.parameters() if p.requires_grad and id(p) not in skip and p.dtype == torch.float32]
+    if not params:
+        return None
+    for p in params:
+        members.append((p, off, p.numel()))
+        off += (p.numel() + 63) // 64 * 64            # 256-byte aligned starts (float4 / MFMA operand loads)
+    device = params[0].device
+    flat_param = torch.zeros(off, dtype=torch.float32, device=device)
+    flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
+    with torch.no_grad():
+        for p, o, n in members:
+            flat_param[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat_param[o:o + n].view(p.shape)
+    optimizer.register_flat_group(flat_param, flat_grad, members, off, grad_views=True)
+    return flat_param, flat_grad
 
 
 # ---------------------------------------------------------------------------------------------
