@@ -1173,11 +1173,15 @@ extern "C" int dt_deepfm_train_step(
                            ws + wl.dz, ws + wl.part,
                            stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) + (int64_t)tiles * 8 : nullptr);
         // E
-        // 2 blocks (8 waves) per CU: two waves per SIMD so one wave's operand waits hide under the other's MFMAs
-        int splits = 1024 / ntiles_w;
+        // 2 blocks (8 waves) per CU: two waves per SIMD so one wave's operand waits hide under the other's MFMAs.
+        // 512 blocks = exactly one residency round at that occupancy (250 registers per lane): 8 batch splits
+        // measured 21.2 us against 23.0 (16 splits, two rounds), 24.9 (4) and 25.4 (32)
+        int splits = 512 / ntiles_w;
         if (splits < 1) splits = 1;
         if (splits > 32) splits = 32;
         while (splits > 1 && (B + splits - 1) / splits < 128) splits >>= 1;
+        static const int splits_env = getenv("DT_WGRAD_SPLITS") ? atoi(getenv("DT_WGRAD_SPLITS")) : 0;   // experiment knob
+        if (splits_env > 0) splits = splits_env;
         hipLaunchKernelGGL(k_wgrad, dim3(ntiles_w * splits + red_blocks), dim3(256), 0, st, ws + wl.X, mp, dm,
                            ws + wl.H1, ws + wl.dH1, ws + wl.dH2, splits, ntiles_w, ws + wl.part, tiles, accum, al);
         // G
