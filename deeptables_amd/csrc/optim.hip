@@ -310,9 +310,10 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
     const float* gsrc = values + occ * D + part * VW;
     float gi[VW], mi[VW], vi[VW], pi[VW];
     if (VW == 4) {
-        *reinterpret_cast<float4*>(gi) = *reinterpret_cast<const float4*>(gsrc);
-        *reinterpret_cast<float4*>(mi) = *reinterpret_cast<const float4*>(m + i0);
-        *reinterpret_cast<float4*>(vi) = *reinterpret_cast<const float4*>(v + i0);
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<nt_f4*>(gi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(gsrc));
+        *reinterpret_cast<nt_f4*>(mi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m + i0));
+        *reinterpret_cast<nt_f4*>(vi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v + i0));
         *reinterpret_cast<float4*>(pi) = *reinterpret_cast<const float4*>(table + i0);
     } else {
 #pragma unroll
@@ -325,8 +326,9 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
         pi[k] -= lr_t * mi[k] / (sqrtf(vi[k]) + eps);
     }
     if (VW == 4) {
-        *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<float4*>(mi);
-        *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<float4*>(vi);
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(mi), reinterpret_cast<nt_f4*>(m + i0));
+        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(vi), reinterpret_cast<nt_f4*>(v + i0));
         *reinterpret_cast<float4*>(table + i0) = *reinterpret_cast<float4*>(pi);
     } else {
 #pragma unroll
