@@ -44,13 +44,22 @@ def algorithmic_bytes_per_row(n_dense_params, batch, dim=D, optimizer=True):
     return fwd_bwd + 7 * 4 * F * dim + 28.0 * n_dense_params / batch
 
 
-def build_model(nets, device, strategy=None, dim=D):
+# BASELINE.json configs[2..4]: the non-default layer parameters of the other benchmarked graphs
+MODEL_PARAMS = {
+    'xDeepFM': dict(cin_params={'cross_layer_size': (128, 128, 128), 'activation': 'relu', 'use_residual': False,
+                                'use_bias': False, 'direct': False, 'reduce_D': False}),
+    'AutoInt': dict(autoint_params={'num_attention': 3, 'num_heads': 4, 'dropout_rate': 0, 'use_residual': True}),
+    'DCN': dict(cross_params={'num_cross_layer': 6}),
+}
+
+
+def build_model(nets, device, strategy=None, dim=D, extra=None):
     from deeptables_amd import functional
     from deeptables_amd.models import ModelConfig, DeepModel
     from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
     functional.set_seed(20241218)
     conf = ModelConfig(nets=nets, fixed_embedding_dim=True, embeddings_output_dim=dim, embedding_dropout=0,
-                       dense_dropout=0, metrics=['AUC'], distribute_strategy=strategy)
+                       dense_dropout=0, metrics=['AUC'], distribute_strategy=strategy, **(extra or {}))
     cats = [CategoricalColumn(f'C{i}', VOCAB, dim) for i in range(F)]
     conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(ND)])]
     dm = DeepModel('binary', 2, conf, cats, conts)
@@ -307,9 +316,7 @@ def main():
             'DCN': deepnets.DCN, 'AFM': deepnets.AFM, 'FiBiNet': deepnets.FiBiNet, 'FGCNN': deepnets.FGCNN,
             'PNN': deepnets.PNN}[args.model]
     dim = 32 if args.model == 'AutoInt' else D
-    dm = build_model(nets, device, strategy, dim)
-    if args.model == 'xDeepFM':
-        pass
+    dm = build_model(nets, device, strategy, dim, MODEL_PARAMS.get(args.model))
     if strategy is not None:
         strategy.broadcast_parameters(dm.model)
     batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
