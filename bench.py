@@ -35,13 +35,13 @@ N_BATCHES = 50
 
 def algorithmic_bytes_per_row(n_dense_params, batch, dim=D, optimizer=True):
     """SURVEY §8(d) fwd+bwd: 4F + 4Nd + 8 + 3*4*F*D + 12*P_dense/B  (= 5,250 B/row for DeepFM at B=8192).
-    With the Adam step in the timed region: + the row-sparse update of the F looked-up rows
-    (read the row gradient; read and write p, m, v: 7 streams of 4*F*D bytes) + 28*P_dense/B for the dense
-    parameters (read g, p, m, v; write p, m, v)."""
+    With the row-sparse Adam step in the timed region SURVEY §8(d) adds F*D*4*(3 reads + 3 writes) = 9,984 B/row
+    (p, m, v of the looked-up rows) -> 15,234 B/row; the dense parameters' optimizer traffic (28*P_dense/B = 220 B/row)
+    is not part of that figure and is left out."""
     fwd_bwd = 4 * F + 4 * ND + 8 + 12 * F * dim + 12.0 * n_dense_params / batch
     if not optimizer:
         return fwd_bwd
-    return fwd_bwd + 7 * 4 * F * dim + 28.0 * n_dense_params / batch
+    return fwd_bwd + 6 * 4 * F * dim
 
 
 # BASELINE.json configs[2..4]: the non-default layer parameters of the other benchmarked graphs

@@ -41,7 +41,7 @@ def main():
     B, F, D, ND = 8192, 26, 16, 13
     n_dense = (F * D + ND) * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1 + 2 * (F * D + ND) + (F + ND)
     fwd_bwd = B * (4 * F + 4 * ND + 8 + 12 * F * D) + 12 * n_dense
-    opt = B * 7 * 4 * F * D + 28 * n_dense
+    opt = B * 6 * 4 * F * D                      # p, m, v of the looked-up rows, read + write
     out = {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py '
                   '--steps 20 --warmup 3 --no-extras --no-cpu-baseline (tools_pmc.sh), averages per launch, KB -> bytes '
