@@ -340,7 +340,8 @@ def main():
         step_s = ev_s / args.steps
         achieved = args.batch * bpr / step_s / 1e9
         result = {
-            'metric': 'training rows/sec (fwd+bwd) DeepFM Criteo-shape batch 8192' if args.model == 'DeepFM'
+            'metric': 'training rows/sec (fwd+bwd) DeepFM Criteo-shape batch 8192'
+            if (args.model == 'DeepFM' and args.batch == 8192)
             else f'training rows/sec (fwd+bwd) {args.model} Criteo-shape batch {args.batch}',
             'value': value, 'unit': 'rows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
