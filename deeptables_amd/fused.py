@@ -4,7 +4,8 @@ kernel sequence for, `DeepModel.train_step` runs that instead of the layer-by-la
 path.  Same weights, same gradients (tests/test_fused_gpu.py checks both against the oracle).
 
 DeepFM (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) -> `dt_deepfm_train_step`
-(csrc/deepfm.hip): 6 launches + 1 memset instead of ~60 launches.
+(csrc/deepfm.hip): 7 launches instead of ~60, the sparse gradient leaving the step already deduplicated;
+under `parallel.ShardedEmbeddingStrategy` the same kernels run on rows gathered by their owning ranks.
 """
 import ctypes
 import os
