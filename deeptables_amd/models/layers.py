@@ -80,12 +80,20 @@ class MultiheadAttention(Layer):
         if self.training and self.dropout_rate > 0:
             raise NotImplementedError('attention-weight dropout > 0 is not implemented in the HIP attention '
                                       'kernel (the probabilities are never materialised); use dropout_rate=0.')
-        q = self.dense_Q(x)
-        k = self.dense_K(x)
-        v = self.dense_V(x)
+        # The four projections read the same [B,F,D] block: one [D, 4D] GEMM (relu and bias fused) instead of four
+        # reads x once and quarters the launches; the Keras variables stay separate (dense_Q/K/V/residual).
+        projs = [self.dense_Q, self.dense_K, self.dense_V] + ([self.dense_residual] if self.use_residual else [])
+        W_cat = torch.cat([p.kernel for p in projs], dim=1)
+        b_cat = torch.cat([p.bias for p in projs], dim=0)
+        if x.is_cuda and ops.dense_supported(x, W_cat):
+            y = ops.dense(x, W_cat, b_cat, 'relu')
+            parts = [t.contiguous() for t in y.split(self.num_units, dim=-1)]
+        else:
+            parts = [p(x) for p in projs]
+        q, k, v = parts[0], parts[1], parts[2]
         outputs = ops.mha_core(q, k, v, self.num_heads)
         if self.use_residual:
-            outputs = outputs + self.dense_residual(x)
+            outputs = outputs + parts[3]
         outputs = torch.relu(outputs)
         return self.batch_normalize(outputs)
 
