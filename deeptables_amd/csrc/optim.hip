@@ -337,6 +337,23 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
     if (part == 0 && slots) slots[slot] = 0ULL;   // global-hash variant: leave the hash empty for the next step
 }
 
+// ---- BinaryCrossentropy from logits (the loss Keras evaluates for a sigmoid output in graph mode, deepmodel.py:326-328):
+//   loss = mean(max(z,0) - z*y + log1p(exp(-|z|))),  dloss/dz = (sigmoid(z) - y) / n      (one launch for both)
+__global__ __launch_bounds__(256) void k_bce_logits(const float* __restrict__ z, const float* __restrict__ y, int64_t n,
+                                                    float* __restrict__ loss, float* __restrict__ dz) {
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float zi = z[i], yi = y[i];
+        const float e = expf(-fabsf(zi));
+        acc += fmaxf(zi, 0.f) - zi * yi + log1pf(e);
+        const float sig = zi >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        dz[i] = (sig - yi) * inv_n;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n);
+}
+
 // ---- SGD (keras.optimizers.SGD, momentum 0): p -= lr * g; duplicates of a row simply add up ----------------
 __global__ __launch_bounds__(256) void k_sgd_dense(float* __restrict__ p, const float* __restrict__ g, int64_t n,
                                                    float lr) {
@@ -356,6 +373,16 @@ __global__ __launch_bounds__(256) void k_sgd_rows(float* __restrict__ table, con
 }  // namespace dt
 
 using namespace dt;
+
+extern "C" int dt_bce_logits(const float* z, const float* y, int64_t n, float* loss, float* dz, void* stream) {
+    DT_REQUIRE(n > 0 && z && y && loss && dz, "dt_bce_logits: bad arguments");
+    hipStream_t st = as_stream(stream);
+    hipMemsetAsync(loss, 0, sizeof(float), st);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_bce_logits, dim3((unsigned)blocks), dim3(256), 0, st, z, y, n, loss, dz);
+    return launch_status("dt_bce_logits");
+}
 
 extern "C" int dt_sgd_dense_step(float* p, const float* g, int64_t n, float lr, void* stream) {
     DT_REQUIRE(n >= 0, "dt_sgd_dense_step: n < 0");

@@ -442,8 +442,14 @@ class _Dense(torch.autograd.Function):
         gy2 = _f32c(gy).reshape(N, M)
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty_like(x2) if need_x else None
-        gW, gW_ret = _grad_target(ctx.W_ref)
-        gb, gb_ret = _grad_target(ctx.b_ref) if ctx.has_bias else (None, None)
+        if getattr(ctx.W_ref, '_dt_grad_view', None) is None:
+            # kernel and bias gradients share ONE zero-filled buffer (one fill launch instead of two)
+            buf = torch.zeros(K * M + (M if ctx.has_bias else 0), dtype=torch.float32, device=W.device)
+            gW = gW_ret = buf[:K * M].view(K, M)
+            gb = gb_ret = buf[K * M:] if ctx.has_bias else None
+        else:
+            gW, gW_ret = _grad_target(ctx.W_ref)
+            gb, gb_ret = _grad_target(ctx.b_ref) if ctx.has_bias else (None, None)
         nbytes = lib().dt_dense_workspace_bytes(N, K, M)
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=W.device)
         check(lib().dt_dense_bwd(ptr(x2), ptr(W), ptr(y), ptr(gy2), ctx.act, N, K, M, ptr(gx), ptr(gW), ptr(gb),

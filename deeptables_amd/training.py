@@ -16,10 +16,29 @@ from .utils import consts
 # ---------------------------------------------------------------------------------------------
 # losses (keras.losses.* selected by DeepModel.__compile_model, deepmodel.py:324-338)
 # ---------------------------------------------------------------------------------------------
+class _BceFromLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, y):
+        z, y = z.contiguous(), y.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        check(lib().dt_bce_logits(ptr(z), ptr(y), z.numel(), ptr(loss), ptr(dz), stream_ptr()), 'dt_bce_logits')
+        ctx.save_for_backward(dz)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
 def bce_from_logits(logit, y):
-    """BinaryCrossentropy on a sigmoid output evaluated from the logits (stable form)."""
+    """BinaryCrossentropy on a sigmoid output evaluated from the logits (stable form); one HIP launch for the
+    loss and its gradient on the GPU."""
     z = logit.reshape(y.shape[0], -1)
     y = y.reshape(z.shape).to(z.dtype)
+    if z.is_cuda and z.dtype == torch.float32:
+        return _BceFromLogits.apply(z, y)
     return (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-z.abs()))).mean()
 
 

@@ -209,6 +209,11 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
                       float beta2, float eps, void* state, float* dense_p, const float* dense_g, float* dense_m,
                       float* dense_v, int64_t dense_n, int advance, float lr, void* stream);
 
+/* BinaryCrossentropy on a sigmoid output, evaluated from the logits as Keras does in graph mode (deepmodel.py:326-328;
+ * the `task_output` activation, deepmodel.py:436-457): loss [1] = mean(max(z,0) - z*y + log1p(exp(-|z|))) and
+ * dz [n] = (sigmoid(z) - y) / n in one launch (the op chain is ~16 element-wise launches otherwise).            */
+int dt_bce_logits(const float* z, const float* y, int64_t n, float* loss, float* dz, void* stream);
+
 /* keras.optimizers.SGD (momentum 0), selectable through ModelConfig.optimizer (deepmodel.py:319-323):
  * p -= lr*g; the rows variant applies the (rows, values) gradient directly (duplicate rows add up).   */
 int dt_sgd_dense_step(float* p, const float* g, int64_t n, float lr, void* stream);
