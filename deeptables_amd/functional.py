@@ -265,19 +265,22 @@ class Dense(Layer):
     def compute_output_shape(self, input_shape):
         return tuple(input_shape[:-1]) + (self.units,)
 
-    def call(self, x, **kwargs):
-        fused_act = self.activation_name if self.activation_name in (None, 'linear', 'relu') else None
+    def call(self, x, fused_activation=None, **kwargs):
+        """fused_activation: an activation the model's execution plan folds into this layer (Model.__init__)."""
+        act_name = self.activation_name if self.activation_name not in (None, 'linear') else fused_activation
+        activation = self.activation if self.activation is not None else get_activation(fused_activation)
+        fused_act = act_name if act_name in (None, 'linear', 'relu') else None
         if x.is_cuda and ops.dense_supported(x, self.kernel):
             # hand-written fp32 MFMA / GEMV kernels (csrc/dense.hip); relu and bias fused
             y = ops.dense(x, self.kernel, self.bias, fused_act)
-            if self.activation is not None and fused_act is None:
-                y = self.activation(y)
+            if activation is not None and fused_act is None:
+                y = activation(y)
             return y
         lead = x.shape[:-1]                      # shapes outside the kernels' LDS tile: vendor GEMM
         x2 = x.reshape(-1, x.shape[-1])
         y = torch.addmm(self.bias, x2, self.kernel) if self.bias is not None else x2 @ self.kernel
-        if self.activation is not None:
-            y = self.activation(y)
+        if activation is not None:
+            y = activation(y)
         return y.reshape(*lead, self.units)
 
     def get_config(self):
@@ -475,6 +478,22 @@ class Model(nn.Module):
             self.layers_by_name[lname] = node.layer
         self._layers = nn.ModuleList(list(self.layers_by_name.values()))
         self.input_names = [t.name for t in self.inputs]
+        # peephole for THIS model's execution plan: Dense -> Activation('relu') where the Dense output feeds nothing
+        # else and is not one of the model's outputs runs as one kernel (relu fused in the GEMM epilogue and in its
+        # backward mask); the layers, their names and `apply(output_layers=[dense])` proxies are unaffected
+        consumers = {}
+        for node in order:
+            for t in _flatten(node.inputs):
+                consumers.setdefault(id(t), []).append(node)
+        outs = {id(t) for t in self.output_list}
+        self._fused_relu, self._passthrough = set(), set()
+        for node in order:
+            if isinstance(node.layer, Dense) and node.layer.activation_name in (None, 'linear') \
+                    and not isinstance(node.outputs, list) and id(node.outputs) not in outs:
+                cons = consumers.get(id(node.outputs), [])
+                if len(cons) == 1 and isinstance(cons[0].layer, Activation) and cons[0].layer.activation_name == 'relu':
+                    self._fused_relu.add(id(node))
+                    self._passthrough.add(id(cons[0]))
 
     @property
     def input(self):
@@ -507,7 +526,12 @@ class Model(nn.Module):
             return env[id(x)]
 
         for node in self.nodes:
-            out = node.layer(fetch(node.inputs))
+            if id(node) in self._passthrough:
+                out = fetch(node.inputs)                      # its relu already ran inside the producing Dense
+            elif id(node) in self._fused_relu:
+                out = node.layer(fetch(node.inputs), fused_activation='relu')
+            else:
+                out = node.layer(fetch(node.inputs))
             if isinstance(node.outputs, list):
                 for t, v in zip(node.outputs, out):
                     env[id(t)] = v

@@ -193,3 +193,22 @@ def test_custom_net_plugin_and_signature_check(dev):
         assert 'my_dense' in dm.model.layers_by_name
     finally:
         CONFIGS.pop('custom')
+
+
+def test_dense_relu_peephole_keeps_layer_outputs(dev):
+    """The execution plan folds Dense -> Activation('relu') into one kernel, but a proxy model asking for the Dense
+    layer's own output (DeepModel.apply) still gets the pre-activation values."""
+    dm, cats = build('DeepFM', F=6, Nd=3, vocab=30)
+    idx, dense, y = batch(cats, 3, 64, dev)
+    dm.model.eval()
+    ins = [idx.int().to(dev), dense.to(dev)]
+    main = dm.model
+    dense_nodes = [n for n in main.nodes if n.layer.name == 'dnn_dense_1']
+    assert id(dense_nodes[0]) in main._fused_relu                      # fused in the training graph
+    from deeptables_amd.functional import Model
+    pre = Model(inputs=main.inputs, outputs=main.get_layer('dnn_dense_1').output)
+    post = Model(inputs=main.inputs, outputs=main.get_layer('dnn_activation_1').output)
+    assert not pre._fused_relu and len(post._fused_relu) == 1
+    with torch.no_grad():
+        a, b = pre(ins), post(ins)
+    assert (a < 0).any() and torch.equal(torch.relu(a), b)
