@@ -68,12 +68,22 @@ def build_model(nets, device, strategy=None, dim=D, extra=None):
 
 
 def make_batches(batch, device, seed, dist_kind='uniform'):
+    """N_BATCHES distinct pre-generated batches.  'zipf': Zipf(alpha = 1.05) ranks per field through the
+    inverse CDF, mapped to ids by a per-field random permutation (hot rows are scattered over the table, as with
+    hashed Criteo ids) — the case the duplicate merge and the Infinity Cache matter for."""
     g = torch.Generator(device='cpu').manual_seed(seed)
+    perms = None
+    if dist_kind == 'zipf':
+        gp = torch.Generator(device='cpu').manual_seed(1234)          # the same id mapping on every rank
+        perms = torch.stack([torch.randperm(VOCAB, generator=gp) for _ in range(F)], 1)   # [VOCAB, F]
     out = []
     for _ in range(N_BATCHES):
         if dist_kind == 'zipf':
+            alpha = 1.05
             u = torch.rand(batch, F, generator=g, dtype=torch.float64)
-            idx = (VOCAB ** u - 1).clamp(0, VOCAB - 1).to(torch.int32)     # log-uniform ~ Zipf(1) ranks
+            rank = ((u * (float(VOCAB) ** (1.0 - alpha) - 1.0) + 1.0) ** (1.0 / (1.0 - alpha)) - 1.0)
+            rank = rank.clamp(0, VOCAB - 1).to(torch.int64)
+            idx = torch.gather(perms, 0, rank).to(torch.int32)
         else:
             idx = torch.randint(0, VOCAB, (batch, F), generator=g, dtype=torch.int32)
         dense = torch.randn(batch, ND, generator=g)
