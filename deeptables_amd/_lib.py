@@ -61,6 +61,8 @@ SIGNATURES = {
     'dt_adam_advance': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _ptr]),
     'dt_adam_dense_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_f32, _c_f32, _c_f32, _c_f32,
                                     _ptr, _c_int, _c_f32, _ptr]),
+    'dt_adam_multi_step': (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _c_f32, _c_f32, _ptr, _c_int,
+                                    _c_f32, _ptr]),
     'dt_adam_rows_slots': (_c_i64, [_c_i64]),
     'dt_adam_rows_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
                                    _c_f32, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32,

@@ -103,6 +103,40 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
     if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
 }
 
+// Several parameter tensors in ONE launch (the layer-by-layer path has one small tensor per Dense / BN / Cross
+// variable: ~4.5 us of launch each).  The tensor descriptors travel as kernel arguments (no device-side table to keep
+// in sync, replayable from a hipGraph); a block finds its tensor by scanning the block offsets.
+constexpr int kMultiMax = 32;
+constexpr int kMultiPerBlock = 1024;          // elements per block (256 threads x 4)
+struct AdamMulti {
+    float* p[kMultiMax];
+    const float* g[kMultiMax];
+    float* m[kMultiMax];
+    float* v[kMultiMax];
+    int n[kMultiMax];
+    int block_start[kMultiMax + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_adam_multi(AdamMulti d, float lr_host, AdamState* __restrict__ st, float b1,
+                                                    float b2, float eps, int advance, float lr) {
+    const float lr_t = st ? st->lr_t : lr_host;
+    int t = 0;
+    while (t + 1 < d.count && (int)blockIdx.x >= d.block_start[t + 1]) ++t;
+    const DenseTail tail{d.p[t], d.g[t], d.m[t], d.v[t], (int64_t)d.n[t]};
+    const int64_t first = (int64_t)(blockIdx.x - d.block_start[t]) * kMultiPerBlock + threadIdx.x;
+    const int64_t end = min((int64_t)d.n[t], (int64_t)(blockIdx.x - d.block_start[t] + 1) * kMultiPerBlock);
+    for (int64_t i = first; i < end; i += 256) {
+        const float gi = tail.g[i];
+        const float mi = b1 * tail.m[i] + (1.f - b1) * gi;
+        const float vi = b2 * tail.v[i] + (1.f - b2) * gi * gi;
+        tail.m[i] = mi;
+        tail.v[i] = vi;
+        tail.p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+}
+
 // ---- row-sparse ("lazy") Adam on (rows, values) pairs --------------------------------------------------------
 // Pass 1 (k_rows_dedupe): one thread per looked-up row occurrence inserts its table row into a small open-addressing
 // hash (64-bit slots: (row+1) << 32 | occurrence).  The first occurrence of a row owns it; later duplicates add
@@ -436,6 +470,38 @@ extern "C" int dt_adam_dense_step(float* p, const float* g, float* m, float* v, 
     hipLaunchKernelGGL(k_adam_dense, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr_t,
                        (AdamState*)state, beta1, beta2, eps, advance, lr);
     return launch_status("dt_adam_dense_step");
+}
+
+extern "C" int dt_adam_multi_step(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                  const int64_t* n, float lr_t, float beta1, float beta2, float eps, void* state,
+                                  int advance, float lr, void* stream) {
+    DT_REQUIRE(count >= 0 && (count == 0 || (p && g && m && v && n)), "dt_adam_multi_step: bad arguments");
+    DT_REQUIRE(!advance || state, "dt_adam_multi_step: advance needs the device state");
+    if (count == 0) return advance ? dt_adam_advance(state, lr, beta1, beta2, stream) : DT_OK;
+    hipStream_t st = as_stream(stream);
+    for (int c0 = 0; c0 < count; c0 += kMultiMax) {
+        AdamMulti d;
+        d.count = count - c0 < kMultiMax ? count - c0 : kMultiMax;
+        int blocks = 0;
+        for (int t = 0; t < d.count; ++t) {
+            const int64_t nt = n[c0 + t];
+            DT_REQUIRE(nt >= 0 && nt < (1LL << 31) && p[c0 + t] && g[c0 + t] && m[c0 + t] && v[c0 + t],
+                       "dt_adam_multi_step: tensor %d: bad size or null pointer", c0 + t);
+            d.p[t] = p[c0 + t]; d.g[t] = g[c0 + t]; d.m[t] = m[c0 + t]; d.v[t] = v[c0 + t];
+            d.n[t] = (int)nt;
+            d.block_start[t] = blocks;
+            blocks += (int)((nt + kMultiPerBlock - 1) / kMultiPerBlock);
+        }
+        d.block_start[d.count] = blocks;
+        const bool last_chunk = c0 + kMultiMax >= count;
+        if (blocks == 0) {
+            if (advance && last_chunk) return dt_adam_advance(state, lr, beta1, beta2, stream);
+            continue;
+        }
+        hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, st, d, lr_t, (AdamState*)state, beta1, beta2, eps,
+                           (advance && last_chunk) ? 1 : 0, lr);
+    }
+    return launch_status("dt_adam_multi_step");
 }
 
 extern "C" int64_t dt_adam_rows_slots(int64_t n_rows) {

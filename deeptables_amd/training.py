@@ -128,6 +128,25 @@ class KerasAdam:
             for p, view in self._flat_views:
                 p._dt_grad_view = view
 
+    def _dense_launch(self, dense, sp, st, advance):
+        """All dense tensors of the step in one launch (dt_adam_multi_step; chunks of 32 tensors)."""
+        if not dense:
+            return
+        if len(dense) == 1:
+            pp, gg, mm, vv, n = dense[0]
+            check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
+                                           sp, 1 if advance else 0, self.lr, st), 'dt_adam_dense_step')
+            return
+        import ctypes
+        T = len(dense)
+        arr = ctypes.c_void_p * T
+        ps, gs, ms, vs = (arr(*[t[k].data_ptr() for t in dense]) for k in range(4))
+        ns = (ctypes.c_int64 * T)(*[int(t[4]) for t in dense])
+        check(lib().dt_adam_multi_step(T, ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(gs, ctypes.c_void_p),
+                                       ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(vs, ctypes.c_void_p),
+                                       ctypes.cast(ns, ctypes.c_void_p), 0.0, self.b1, self.b2, self.eps, sp,
+                                       1 if advance else 0, self.lr, st), 'dt_adam_multi_step')
+
     def zero_grad(self, flat=True):
         """flat=True: members of the registered flat group get their (zeroed) views of the flat gradient buffer as
         `.grad` — backward kernels and autograd accumulate straight into it; flat=False: the caller (a fused step)
@@ -175,10 +194,7 @@ class KerasAdam:
         if hook is not None and not dense_after:
             hook()
         if not dense_after:
-            for i, (pp, gg, mm, vv, n) in enumerate(dense):
-                last = 1 if (not sparse and i == len(dense) - 1) else 0
-                check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
-                                               sp, last, self.lr, st), 'dt_adam_dense_step')
+            self._dense_launch(dense, sp, st, advance=not sparse)
         if not sparse and not dense:
             check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
         for i, (layer, key, grads) in enumerate(sparse):
@@ -217,9 +233,7 @@ class KerasAdam:
                                           ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, st), 'dt_adam_rows_step')
         if dense_after:
             hook()
-            for i, (pp, gg, mm, vv, n) in enumerate(dense):
-                check(lib().dt_adam_dense_step(ptr(pp), ptr(gg), ptr(mm), ptr(vv), n, 0.0, self.b1, self.b2, self.eps,
-                                               sp, 1 if i == len(dense) - 1 else 0, self.lr, st), 'dt_adam_dense_step')
+            self._dense_launch(dense, sp, st, advance=True)
         for layer in self.embedding_layers:
             layer.sparse_grads.clear()
 

@@ -203,6 +203,10 @@ int dt_adam_state_init(void* state, float lr, float beta1, float beta2, int step
 int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
 int dt_adam_dense_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                        float beta1, float beta2, float eps, void* state, int advance, float lr, void* stream);
+/* `count` dense tensors in one launch (chunks of 32): HOST arrays of device pointers / element counts. */
+int dt_adam_multi_step(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                       const int64_t* n, float lr_t, float beta1, float beta2, float eps, void* state, int advance,
+                       float lr, void* stream);
 int64_t dt_adam_rows_slots(int64_t n_rows);
 int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
                       int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
