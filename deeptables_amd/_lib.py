@@ -54,8 +54,8 @@ SIGNATURES = {
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr]),
     'dt_cin_layer_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
-    'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
+    'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  _ptr, _ptr, _ptr, _ptr]),
     'dt_adam_state_init': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _c_int, _ptr]),
     'dt_adam_advance': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _ptr]),

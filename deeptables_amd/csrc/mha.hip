@@ -57,7 +57,7 @@ template <int DHMAX, bool VEC4>
 __global__ __launch_bounds__(256) void k_mha_fwd(const float* __restrict__ q,
                                                  const float* __restrict__ k,
                                                  const float* __restrict__ v, int B, int F, int D,
-                                                 int H, float scale, float* __restrict__ out,
+                                                 int H, int ld, float scale, float* __restrict__ out,
                                                  float* __restrict__ lse) {
     const int dh = D / H;
     const int64_t total = (int64_t)B * H * F;
@@ -66,22 +66,23 @@ __global__ __launch_bounds__(256) void k_mha_fwd(const float* __restrict__ q,
     const int i = (int)(t % F);
     const int h = (int)((t / F) % H);
     const int64_t b = t / ((int64_t)F * H);
-    const int64_t base = b * F * D + (int64_t)h * dh;  // + row*D
+    const int64_t base = b * F * D + (int64_t)h * dh;   // out: contiguous rows of D
+    const int64_t ib = b * F * ld + (int64_t)h * dh;    // q / k / v: rows `ld` floats apart
     float qi[DHMAX], kr[DHMAX], acc[DHMAX];
 #pragma unroll
     for (int d = 0; d < DHMAX; ++d) { qi[d] = 0.f; kr[d] = 0.f; acc[d] = 0.f; }
-    RowIO<DHMAX, VEC4>::load(q + base + (int64_t)i * D, dh, qi);
+    RowIO<DHMAX, VEC4>::load(q + ib + (int64_t)i * ld, dh, qi);
     float m = -INFINITY;
     for (int j = 0; j < F; ++j) {
-        RowIO<DHMAX, VEC4>::load(k + base + (int64_t)j * D, dh, kr);
+        RowIO<DHMAX, VEC4>::load(k + ib + (int64_t)j * ld, dh, kr);
         m = fmaxf(m, dotn<DHMAX>(qi, kr, dh) * scale);
     }
     float l = 0.f;
     for (int j = 0; j < F; ++j) {
-        RowIO<DHMAX, VEC4>::load(k + base + (int64_t)j * D, dh, kr);
+        RowIO<DHMAX, VEC4>::load(k + ib + (int64_t)j * ld, dh, kr);
         const float p = expf(dotn<DHMAX>(qi, kr, dh) * scale - m);
         l += p;
-        RowIO<DHMAX, VEC4>::load(v + base + (int64_t)j * D, dh, kr);
+        RowIO<DHMAX, VEC4>::load(v + ib + (int64_t)j * ld, dh, kr);
 #pragma unroll
         for (int d = 0; d < DHMAX; ++d)
             if (d < dh) acc[d] += p * kr[d];
@@ -97,7 +98,7 @@ template <int DHMAX, bool VEC4>
 __global__ __launch_bounds__(256) void k_mha_bwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ gout,
-    int B, int F, int D, int H, float scale, float* __restrict__ gq, float* __restrict__ gk,
+    int B, int F, int D, int H, int ld, int ldg, float scale, float* __restrict__ gq, float* __restrict__ gk,
     float* __restrict__ gv) {
     const int dh = D / H;
     const int64_t total = (int64_t)B * H * F;
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
     const int r = (int)(t % F);
     const int h = (int)((t / F) % H);
     const int64_t b = t / ((int64_t)F * H);
-    const int64_t base = b * F * D + (int64_t)h * dh;
+    const int64_t base = b * F * D + (int64_t)h * dh;     // out / grad_out: contiguous rows of D
+    const int64_t ib = b * F * ld + (int64_t)h * dh;      // q / k / v rows `ld` apart
+    const int64_t gb = b * F * ldg + (int64_t)h * dh;     // grad_q / grad_k / grad_v rows `ldg` apart
     const int64_t lbase = (b * H + h) * F;
     using IO = RowIO<DHMAX, VEC4>;
     float a0[DHMAX], a1[DHMAX], a2[DHMAX], r0[DHMAX], r1[DHMAX], r2[DHMAX];
@@ -114,29 +117,29 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
     for (int d = 0; d < DHMAX; ++d) { a0[d] = a1[d] = a2[d] = 0.f; r0[d] = r1[d] = r2[d] = 0.f; }
 
     // ---- role 1: row r as a QUERY -> grad_q[r] = sum_j dS_rj k_j ----
-    IO::load(q + base + (int64_t)r * D, dh, r0);      // q_r
+    IO::load(q + ib + (int64_t)r * ld, dh, r0);      // q_r
     IO::load(gout + base + (int64_t)r * D, dh, r1);   // dO_r
     IO::load(out + base + (int64_t)r * D, dh, r2);    // O_r
     const float delta_r = dotn<DHMAX>(r1, r2, dh);
     const float lse_r = lse[lbase + r];
     for (int j = 0; j < F; ++j) {
-        IO::load(k + base + (int64_t)j * D, dh, a0);
-        IO::load(v + base + (int64_t)j * D, dh, a1);
+        IO::load(k + ib + (int64_t)j * ld, dh, a0);
+        IO::load(v + ib + (int64_t)j * ld, dh, a1);
         const float p = expf(dotn<DHMAX>(r0, a0, dh) * scale - lse_r);
         const float ds = p * (dotn<DHMAX>(r1, a1, dh) - delta_r) * scale;
 #pragma unroll
         for (int d = 0; d < DHMAX; ++d)
             if (d < dh) a2[d] += ds * a0[d];
     }
-    IO::store(gq + base + (int64_t)r * D, dh, a2);
+    IO::store(gq + gb + (int64_t)r * ldg, dh, a2);
 
     // ---- role 2: row r as a KEY/VALUE -> grad_k[r] = sum_i dS_ir q_i ; grad_v[r] = sum_i p_ir dO_i
-    IO::load(k + base + (int64_t)r * D, dh, r0);      // k_r
-    IO::load(v + base + (int64_t)r * D, dh, r1);      // v_r
+    IO::load(k + ib + (int64_t)r * ld, dh, r0);      // k_r
+    IO::load(v + ib + (int64_t)r * ld, dh, r1);      // v_r
 #pragma unroll
     for (int d = 0; d < DHMAX; ++d) { a2[d] = 0.f; r2[d] = 0.f; }  // a2 = grad_k, r2 = grad_v
     for (int i = 0; i < F; ++i) {
-        IO::load(q + base + (int64_t)i * D, dh, a0);     // q_i
+        IO::load(q + ib + (int64_t)i * ld, dh, a0);     // q_i
         IO::load(gout + base + (int64_t)i * D, dh, a1);  // dO_i
         const float p = expf(dotn<DHMAX>(a0, r0, dh) * scale - lse[lbase + i]);
         const float dP = dotn<DHMAX>(a1, r1, dh);
@@ -153,8 +156,8 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
         for (int d = 0; d < DHMAX; ++d)
             if (d < dh) a2[d] += ds * a0[d];
     }
-    IO::store(gk + base + (int64_t)r * D, dh, a2);
-    IO::store(gv + base + (int64_t)r * D, dh, r2);
+    IO::store(gk + gb + (int64_t)r * ldg, dh, a2);
+    IO::store(gv + gb + (int64_t)r * ldg, dh, r2);
 }
 
 }  // namespace dt
@@ -170,47 +173,48 @@ using namespace dt;
     } while (0)
 
 extern "C" int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D,
-                               int H, float* out, float* lse, void* stream) {
+                               int H, int ld, float* out, float* lse, void* stream) {
+    DT_REQUIRE(ld >= D, "dt_mha_core_fwd: row stride %d < D=%d", ld, D);
     DT_REQUIRE(B >= 0 && F > 0 && D > 0 && H > 0 && D % H == 0,
                "dt_mha_core_fwd: bad sizes B=%d F=%d D=%d H=%d", B, F, D, H);
     if (B == 0) return DT_OK;
     DT_REQUIRE(q && k && v && out, "dt_mha_core_fwd: null pointer");
     const int dh = D / H;
     DT_UNSUPPORTED(dh > 64, "dt_mha_core_fwd: head width %d > 64", dh);
-    const bool vec4 = (dh % 4 == 0) && (D % 4 == 0);
+    const bool vec4 = (dh % 4 == 0) && (D % 4 == 0) && (ld % 4 == 0);
     const float scale = 1.0f / sqrtf((float)dh);
     const int64_t total = (int64_t)B * H * F;
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = as_stream(stream);
-    if (dh <= 4) DT_MHA_LAUNCH(k_mha_fwd, 4, q, k, v, B, F, D, H, scale, out, lse);
-    else if (dh <= 8) DT_MHA_LAUNCH(k_mha_fwd, 8, q, k, v, B, F, D, H, scale, out, lse);
-    else if (dh <= 16) DT_MHA_LAUNCH(k_mha_fwd, 16, q, k, v, B, F, D, H, scale, out, lse);
-    else if (dh <= 32) DT_MHA_LAUNCH(k_mha_fwd, 32, q, k, v, B, F, D, H, scale, out, lse);
-    else DT_MHA_LAUNCH(k_mha_fwd, 64, q, k, v, B, F, D, H, scale, out, lse);
+    if (dh <= 4) DT_MHA_LAUNCH(k_mha_fwd, 4, q, k, v, B, F, D, H, ld, scale, out, lse);
+    else if (dh <= 8) DT_MHA_LAUNCH(k_mha_fwd, 8, q, k, v, B, F, D, H, ld, scale, out, lse);
+    else if (dh <= 16) DT_MHA_LAUNCH(k_mha_fwd, 16, q, k, v, B, F, D, H, ld, scale, out, lse);
+    else if (dh <= 32) DT_MHA_LAUNCH(k_mha_fwd, 32, q, k, v, B, F, D, H, ld, scale, out, lse);
+    else DT_MHA_LAUNCH(k_mha_fwd, 64, q, k, v, B, F, D, H, ld, scale, out, lse);
     return launch_status("dt_mha_core_fwd");
 }
 
 extern "C" int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float* out,
-                               const float* lse, const float* grad_out, int B, int F, int D, int H,
-                               float* grad_q, float* grad_k, float* grad_v, void* stream) {
-    DT_REQUIRE(B >= 0 && F > 0 && D > 0 && H > 0 && D % H == 0, "dt_mha_core_bwd: bad sizes");
+                               const float* lse, const float* grad_out, int B, int F, int D, int H, int ld,
+                               int ldg, float* grad_q, float* grad_k, float* grad_v, void* stream) {
+    DT_REQUIRE(B >= 0 && F > 0 && D > 0 && H > 0 && D % H == 0 && ld >= D && ldg >= D, "dt_mha_core_bwd: bad sizes");
     if (B == 0) return DT_OK;
     DT_REQUIRE(q && k && v && out && lse && grad_out && grad_q && grad_k && grad_v,
                "dt_mha_core_bwd: null pointer");
     const int dh = D / H;
     DT_UNSUPPORTED(dh > 32, "dt_mha_core_bwd: head width %d > 32", dh);
-    const bool vec4 = (dh % 4 == 0) && (D % 4 == 0);
+    const bool vec4 = (dh % 4 == 0) && (D % 4 == 0) && (ld % 4 == 0) && (ldg % 4 == 0);
     const float scale = 1.0f / sqrtf((float)dh);
     const int64_t total = (int64_t)B * H * F;
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = as_stream(stream);
     if (dh <= 4)
-        DT_MHA_LAUNCH(k_mha_bwd, 4, q, k, v, out, lse, grad_out, B, F, D, H, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 4, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
     else if (dh <= 8)
-        DT_MHA_LAUNCH(k_mha_bwd, 8, q, k, v, out, lse, grad_out, B, F, D, H, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 8, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
     else if (dh <= 16)
-        DT_MHA_LAUNCH(k_mha_bwd, 16, q, k, v, out, lse, grad_out, B, F, D, H, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 16, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
     else
-        DT_MHA_LAUNCH(k_mha_bwd, 32, q, k, v, out, lse, grad_out, B, F, D, H, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 32, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
     return launch_status("dt_mha_core_bwd");
 }

@@ -87,7 +87,7 @@ class MultiheadAttention(Layer):
         b_cat = torch.cat([p.bias for p in projs], dim=0)
         if x.is_cuda and ops.dense_supported(x, W_cat):
             y = ops.dense(x, W_cat, b_cat, 'relu')
-            parts = [t.contiguous() for t in y.split(self.num_units, dim=-1)]
+            parts = list(y.split(self.num_units, dim=-1))     # column blocks of y: the attention kernel reads them in place
         else:
             parts = [p(x) for p in projs]
         q, k, v = parts[0], parts[1], parts[2]

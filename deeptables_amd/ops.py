@@ -386,28 +386,45 @@ def cin_layer(x0, xk, W, bias=None, activation='relu'):
 # ------------------------------------------------------------------------------------------------
 # MultiheadAttention core — deeptables/models/layers.py:129-145
 # ------------------------------------------------------------------------------------------------
+def _row_stride(t, D):
+    """Row stride (floats) if t [B,F,D] is float32 with unit inner stride and rows `ld` apart (a contiguous tensor or
+    a column block of a wider [B,F,ld] buffer), else None."""
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
+        return None
+    ld = t.stride(1)
+    if ld < D or t.stride(0) != t.shape[1] * ld or (t.data_ptr() % 16) != 0:
+        return None
+    return ld
+
+
 class _MhaCore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, H):
         require_cuda(q, k, v)
-        q, k, v = _f32c(q), _f32c(k), _f32c(v)
         B, F, D = q.shape
-        out = torch.empty_like(q)
+        lds = {_row_stride(t, D) for t in (q, k, v)}
+        if len(lds) != 1 or None in lds:             # mixed layouts: make them contiguous
+            q, k, v = _f32c(q), _f32c(k), _f32c(v)
+            ld = D
+        else:
+            ld = lds.pop()
+        out = torch.empty((B, F, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, H, F), dtype=torch.float32, device=q.device)
-        check(lib().dt_mha_core_fwd(ptr(q), ptr(k), ptr(v), B, F, D, H, ptr(out), ptr(lse), stream_ptr()),
+        check(lib().dt_mha_core_fwd(ptr(q), ptr(k), ptr(v), B, F, D, H, ld, ptr(out), ptr(lse), stream_ptr()),
               'dt_mha_core_fwd')
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.H = H
+        ctx.H, ctx.ld = H, ld
         return out
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, out, lse = ctx.saved_tensors
-        B, F, D = q.shape
+        B, F, D = out.shape
         g = _f32c(g)
-        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        check(lib().dt_mha_core_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), B, F, D, ctx.H,
-                                    ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
+        G = torch.empty((B, F, 3 * D), dtype=torch.float32, device=out.device)    # gq | gk | gv side by side
+        gq, gk, gv = G[..., :D], G[..., D:2 * D], G[..., 2 * D:]
+        check(lib().dt_mha_core_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), B, F, D, ctx.H, ctx.ld,
+                                    3 * D, ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
         return gq, gk, gv, None
 
 

@@ -173,11 +173,13 @@ int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const flo
  * (d_h = D/H); out[b,:,h] = softmax(q_h k_h^T / sqrt(d_h)) v_h, heads merged back on the last
  * axis -> out [B,F,D].  Nothing of size [B,H,F,F] is written: the forward saves only
  * lse [B,H,F] (log-sum-exp of each scaled score row) and the backward recomputes the
- * probabilities from q,k,lse and uses `out` for delta = rowsum(dO * O).                     */
-int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D, int H,
+ * probabilities from q,k,lse and uses `out` for delta = rowsum(dO * O).
+ * ld: distance in floats between consecutive field rows of q/k/v (D when contiguous; 4D when they are column
+ * blocks of one fused [B,F,4D] projection output); ldg: the same for grad_q/grad_k/grad_v.        */
+int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D, int H, int ld,
                     float* out, float* lse, void* stream);
 int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float* out,
-                    const float* lse, const float* grad_out, int B, int F, int D, int H,
+                    const float* lse, const float* grad_out, int B, int F, int D, int H, int ld, int ldg,
                     float* grad_q, float* grad_k, float* grad_v, void* stream);
 
 /* ---- a13 optimizer step (Keras Adam, models/deepmodel.py:321-322) ------------------------- *
