@@ -87,11 +87,11 @@ class MultiheadAttention(Layer):
         b_cat = torch.cat([p.bias for p in projs], dim=0)
         if x.is_cuda and ops.dense_supported(x, W_cat):
             y = ops.dense(x, W_cat, b_cat, 'relu')
-            parts = list(y.split(self.num_units, dim=-1))     # column blocks of y: the attention kernel reads them in place
+            parts = list(ops.split_cols(y, self.num_units))  # column blocks of y: the attention kernel reads them in place
         else:
             parts = [p(x) for p in projs]
         q, k, v = parts[0], parts[1], parts[2]
-        outputs = ops.mha_core(q, k, v, self.num_heads)
+        outputs = ops.mha_core(q, k, v, self.num_heads, grad_cols=len(parts))
         if self.use_residual:
             outputs = outputs + parts[3]
         outputs = torch.relu(outputs)

@@ -399,9 +399,10 @@ def _row_stride(t, D):
 
 class _MhaCore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, H):
+    def forward(ctx, q, k, v, H, grad_cols):
         require_cuda(q, k, v)
         B, F, D = q.shape
+        ctx.grad_cols = max(int(grad_cols), 3)
         lds = {_row_stride(t, D) for t in (q, k, v)}
         if len(lds) != 1 or None in lds:             # mixed layouts: make them contiguous
             q, k, v = _f32c(q), _f32c(k), _f32c(v)
@@ -421,15 +422,56 @@ class _MhaCore(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         B, F, D = out.shape
         g = _f32c(g)
-        G = torch.empty((B, F, 3 * D), dtype=torch.float32, device=out.device)    # gq | gk | gv side by side
-        gq, gk, gv = G[..., :D], G[..., D:2 * D], G[..., 2 * D:]
+        # gq | gk | gv side by side in a buffer `grad_cols` blocks wide: when q/k/v are column blocks of a fused
+        # projection output, split_cols' backward completes this buffer in place instead of concatenating
+        W = ctx.grad_cols * D
+        G = torch.empty((B, F, W), dtype=torch.float32, device=out.device)
+        gq, gk, gv = G[..., :D], G[..., D:2 * D], G[..., 2 * D:3 * D]
         check(lib().dt_mha_core_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), B, F, D, ctx.H, ctx.ld,
-                                    3 * D, ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
-        return gq, gk, gv, None
+                                    W, ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
+        return gq, gk, gv, None, None
 
 
-def mha_core(q, k, v, num_heads):
-    return _MhaCore.apply(q, k, v, int(num_heads))
+def mha_core(q, k, v, num_heads, grad_cols=3):
+    """grad_cols: width (in blocks of D) of the buffer the q/k/v gradients are laid out in (see split_cols)."""
+    return _MhaCore.apply(q, k, v, int(num_heads), int(grad_cols))
+
+
+class _SplitCols(torch.autograd.Function):
+    """y [.., n*D] -> n column blocks [.., D] (views).  Backward: if the first incoming gradient already is column
+    block 0 of a buffer laid out like y (what mha_core(grad_cols=n) hands back for q), the other blocks are copied
+    into that buffer where they are not there already and the buffer IS the gradient — the full [.., n*D]
+    concatenation is skipped."""
+
+    @staticmethod
+    def forward(ctx, y, D):
+        y = y.contiguous()
+        ctx.D, ctx.shape = D, tuple(y.shape)
+        return tuple(y[..., i * D:(i + 1) * D] for i in range(y.shape[-1] // D))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        D, shape = ctx.D, ctx.shape
+        want = torch.empty(shape, device='meta').stride()          # strides of y == strides of a column block
+        g0 = grads[0]
+        numel = 1
+        for d in shape:
+            numel *= d
+        if (tuple(g0.shape) == shape[:-1] + (D,) and g0.stride() == want and g0.dtype == torch.float32 and
+                (g0.storage_offset() + numel) * 4 <= g0.untyped_storage().nbytes()):
+            G = torch.as_strided(g0, shape, want)                   # the whole buffer g0 is block 0 of
+            for i in range(1, len(grads)):
+                blk = G[..., i * D:(i + 1) * D]
+                g = grads[i]
+                if g.data_ptr() == blk.data_ptr() and g.stride() == want:
+                    continue                                        # already in place (gk, gv)
+                blk.copy_(g)
+            return G, None
+        return torch.cat(list(grads), dim=-1), None
+
+
+def split_cols(y, D):
+    return _SplitCols.apply(y, int(D))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -247,3 +247,23 @@ def test_dense_relu_peephole_cpu():
     pre = Fn.Model(inputs=[inp], outputs=d1.output)      # the Dense output itself requested: never fused
     assert not pre._fused_relu and torch.allclose(pre([x]), x @ d1.kernel + d1.bias, atol=1e-6)
     assert (pre([x]) < 0).any()
+
+
+def test_split_cols_backward_completes_the_shared_buffer():
+    """ops.split_cols: generic gradients are concatenated; gradients that already are column blocks of one buffer
+    (mha_core's layout) are completed in place and that buffer is returned (pure torch: runs on CPU)."""
+    import torch
+    from deeptables_amd.ops import split_cols
+    D = 4
+    want = torch.cat([torch.full((3, 5, D), float(k)) for k in (1, 2, 3, 4)], -1)
+    y = torch.randn(3, 5, 4 * D, requires_grad=True)
+    a, b, c, d = split_cols(y, D)
+    assert a.shape == (3, 5, D) and torch.equal(c, y[..., 2 * D:3 * D])
+    (a.sum() * 1 + b.sum() * 2 + c.sum() * 3 + d.sum() * 4).backward()
+    assert torch.equal(y.grad, want)
+    y.grad = None
+    a, b, c, d = split_cols(y, D)
+    G = torch.zeros(3, 5, 4 * D)
+    G[..., 0:D], G[..., D:2 * D], G[..., 2 * D:3 * D] = 1, 2, 3
+    torch.autograd.backward([a, b, c, d], [G[..., 0:D], G[..., D:2 * D], G[..., 2 * D:3 * D], torch.full((3, 5, D), 4.)])
+    assert torch.equal(y.grad, want) and y.grad.data_ptr() == G.data_ptr()
