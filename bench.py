@@ -7,10 +7,14 @@ table (26 categorical x 1M vocab, 13 dense, embed_dim 16), batch 8192 per GPU.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch already resident in HBM: forward, BCE loss,
-backward down to the embedding row-gradients (the IndexedSlices values) and — for N > 1 — the
-RCCL gradient exchange (flat dense all-reduce + sparse all-gather).  The optimizer is NOT in the
-timed region (the metric is fwd+bwd; `train_step_rows_per_s` reports the rate with the Keras-Adam
-update included).  The whole step is captured once into a hipGraph and replayed.
+backward down to the embedding row-gradients (the IndexedSlices values), the Keras-Adam update of
+every dense parameter and of the looked-up table rows and — for N > 1 — the RCCL gradient exchange.
+The optimizer IS in the timed region (`config.optimizer_in_timed_region`; `--no-optimizer` times
+fwd+bwd alone, and the default run also reports that as `fwd_bwd_only_rows_per_s`).  One hipGraph
+per pre-generated batch is captured once and replayed.
+
+Before anything is timed, rank 0 runs ONE step of the benchmarked configuration through
+oracle/headline.py (CPU oracle, float64) and reports `parity` (logit / gradient / Adam errors).
 
 Rank 0 prints ONE JSON line (see the fields at the bottom).  The `cpu_baseline` leg times the CPU
 oracle (a torch-CPU op-for-op restatement of the reference graph; TensorFlow is not installable
@@ -158,28 +162,67 @@ def time_steps(step, batches, steps, warmup, barrier):
         step.run(i % nb, batches[i % nb])
     barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
+    evs[0].record()
     for i in range(steps):
         step.run((warmup + i) % nb, batches[(warmup + i) % nb])
-    ev1.record()
+        evs[i + 1].record()            # HIP event on the launch stream after every step (median / p10 / p90 below)
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return wall, ev0.elapsed_time(ev1) / 1e3
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps))      # us
+
+    def pct(q):
+        return per[min(len(per) - 1, int(q * len(per)))]
+    stats = {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'mean': sum(per) / len(per), 'n': len(per)}
+    return wall, evs[0].elapsed_time(evs[-1]) / 1e3, stats
+
+
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
 
 
 def pmc_traffic(args):
     """HBM bytes per launch (= per step) from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
-    read from inside the process); only valid for the configuration they were collected on."""
-    path = os.path.join(ROOT, 'profiles', 'r01_deepfm_traffic.json')
-    if args.model != 'DeepFM' or args.batch != 8192 or args.dist != 'uniform' or not os.path.exists(path):
+    read from inside the process).  Only reported for the configuration they were collected on AND while the kernel
+    sources are the ones they were collected from (the json records __graft_entry__.source_hash()); stale -> null."""
+    if args.model != 'DeepFM' or args.batch != 8192 or args.dist != 'uniform' or not os.path.exists(TRAFFIC_JSON):
         return None
     try:
-        return json.load(open(path))['bytes_per_step_corrected']
+        import __graft_entry__ as ge
+        j = json.load(open(TRAFFIC_JSON))
+        if j.get('source_hash') != ge.source_hash():
+            return None
+        return j['bytes_per_step_corrected']
     except Exception:
         return None
+
+
+def parity_leg(args, device):
+    """ONE train step of the benchmarked configuration (a fresh model with the benchmark's seed, batch 0 of the uniform
+    stream and batch 0 of the zipf stream) compared with the CPU oracle: oracle/headline.py.  Checker only — it runs
+    before anything is timed and on its own model instance."""
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    nets = {'DeepFM': deepnets.DeepFM, 'DCN': deepnets.DCN}[args.model]
+    global N_BATCHES
+    keep, out = N_BATCHES, {}
+    dm = build_model(nets, device, None, D, MODEL_PARAMS.get(args.model))
+    try:
+        N_BATCHES = 1
+        for kind in ('uniform', 'zipf'):
+            b = make_batches(args.batch, device, seed=1234, dist_kind=kind)[0]
+            r = headline.check_train_step(dm, b)
+            out[kind] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in r.items()}
+    finally:
+        N_BATCHES = keep
+    ok = all(r['gather_bit_exact'] and r['rows_identical'] and r['max_abs_logit_err'] < 1e-4 and
+             r['rows_grad_rel_err'] < 2e-4 and r['dense_grad_rel_err'] < 2e-4 for r in out.values())
+    out['tolerance'] = 'gather bit-exact; logits 1e-4 abs (north_star); gradients 2e-4 of the tensor max; Adam 1e-3 of the step'
+    out['ok'] = bool(ok)
+    del dm
+    torch.cuda.empty_cache()
+    return out
 
 
 def kernel_breakdown(dm, batch, device, sample):
@@ -284,6 +327,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the benchmarked configuration')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
                     help='N>1: embedding rows owned per field by one rank (all-to-all exchange) or replicated '
@@ -326,6 +370,12 @@ def main():
             'DCN': deepnets.DCN, 'AFM': deepnets.AFM, 'FiBiNet': deepnets.FiBiNet, 'FGCNN': deepnets.FGCNN,
             'PNN': deepnets.PNN}[args.model]
     dim = 32 if args.model == 'AutoInt' else D
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity and args.model in ('DeepFM', 'DCN'):
+        try:
+            parity = parity_leg(args, device)
+        except Exception as e:      # the checker must not kill the contract line; the failure is reported in it
+            parity = {'ok': False, 'error': repr(e)}
     dm = build_model(nets, device, strategy, dim, MODEL_PARAMS.get(args.model))
     if strategy is not None:
         strategy.broadcast_parameters(dm.model)
@@ -336,7 +386,7 @@ def main():
         args.no_graph = True        # collectives inside the step: launched eagerly, not captured
     step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph)
     step.capture(batches)
-    wall, ev_s = time_steps(step, batches, args.steps, args.warmup, barrier)
+    wall, ev_s, step_stats = time_steps(step, batches, args.steps, args.warmup, barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,7 +406,8 @@ def main():
             'value': value, 'unit': 'rows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.model} fwd+bwd, Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
+            'config': {'workload': f'{args.model} train step = fwd+bwd' + ('' if args.no_optimizer else '+Adam') +
+                                   f', Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
                        'hipgraph': not args.no_graph, 'optimizer_in_timed_region': not args.no_optimizer,
@@ -365,14 +416,17 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
                          'launch': 'one hipGraph replay = one train step (fwd+bwd' + ('' if args.no_optimizer else '+Adam') + ')',
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
+            'step_us': step_stats,
         }
+        if parity is not None:
+            result['parity'] = parity
         if not args.no_extras and world == 1:
             try:
                 result['kernels'] = kernel_breakdown(dm, args.batch, device, batches[1]) if args.model == 'DeepFM' else {}
                 if not args.no_optimizer:      # the same step without the Adam launches, for comparison
                     fb = GraphedStep(dm, args.batch, device, with_optimizer=False, use_graph=not args.no_graph)
                     fb.capture(batches)
-                    w2, _ = time_steps(fb, batches, args.steps, 5, barrier)
+                    w2, _, _ = time_steps(fb, batches, args.steps, 5, barrier)
                     result['fwd_bwd_only_rows_per_s'] = args.batch * args.steps / w2
             except Exception as e:   # diagnostics must not kill the contract line
                 result['extras_error'] = repr(e)

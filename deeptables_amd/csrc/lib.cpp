@@ -16,3 +16,7 @@ void set_error(const char* fmt, ...) {
 extern "C" int dt_version(void) { return 1; }
 extern "C" const char* dt_last_error(void) { return dt::g_err; }
 extern "C" const char* dt_build_arch(void) { return "gfx950"; }
+#ifndef DT_SOURCE_HASH
+#define DT_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* dt_source_hash(void) { return DT_SOURCE_HASH; }

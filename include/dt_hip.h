@@ -51,6 +51,7 @@ extern "C" {
 int dt_version(void);                 /* ABI version, currently 1 */
 const char* dt_last_error(void);      /* thread-local message of the last failing call */
 const char* dt_build_arch(void);      /* "gfx950" */
+const char* dt_source_hash(void);     /* sha256[:16] of the sources this binary was built from (__graft_entry__.source_hash) */
 
 /* ---- a2  MultiColumnEmbedding.call  (models/layers.py:889-904) -------------------------- *
  * All F columns live in ONE packed table [sum_f vocab_f, D]; column f starts at row

@@ -11,8 +11,10 @@ def _t(p, dtype):
     return p.detach().to('cpu', dtype).clone()
 
 
-def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
-    """deeptables_amd.models.deepmodel.DeepModel -> weights dict for R.model_forward."""
+def oracle_weights(dm, dtype=torch.float64, requires_grad=False, tables=True):
+    """deeptables_amd.models.deepmodel.DeepModel -> weights dict for R.model_forward.
+    tables=False leaves 'emb_categorical_vars_all' empty (oracle/headline.py fills it with row-lookup stand-ins so
+    the 26 x 1M-row benchmark tables are never copied in float64)."""
     m = dm.model
     L = m.layers_by_name
     w = {}
@@ -22,7 +24,7 @@ def oracle_weights(dm, dtype=torch.float64, requires_grad=False):
         return t.requires_grad_(True) if requires_grad else t
 
     emb = L.get('emb_categorical_vars_all')
-    w['emb_categorical_vars_all'] = [g(e) for e in emb.embeddings] if emb is not None else []
+    w['emb_categorical_vars_all'] = [g(e) for e in emb.embeddings] if (emb is not None and tables) else []
     bn = L.get('bn_concat_emb_dense')     # absent when no net consumes concat_emb_dense (e.g. AutoInt)
     if bn is not None:
         w['bn_concat_emb_dense'] = (g(bn.gamma), g(bn.beta), _t(bn.moving_mean, dtype),

@@ -1,0 +1,213 @@
+# -*- coding:utf-8 -*-
+"""CPU ORACLE (test infrastructure) — one whole TRAIN STEP of a model at benchmark sizes, restated on the CPU, and
+the comparison of the product's step against it.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline/parity leg may import this file; nothing under deeptables_amd/ does.
+
+What is restated (reference lines):
+  forward + loss        DeepModel.__build_model, deeptables/models/deepmodel.py:259-317 (oracle.reference_layers.model_forward)
+                        BinaryCrossentropy on the sigmoid output evaluated from logits, deepmodel.py:324-338
+  gradients             autodiff of the above (torch CPU float64), tables replaced by the looked-up rows so that the
+                        embedding gradient is the IndexedSlices pair (rows, values) TF produces for embedding_lookup
+                        (layers.py:896-899)
+  optimizer             keras Adam, deepmodel.py:321-322 (oracle.reference_layers.keras_adam_step) on every dense
+                        parameter and on the touched table rows (row-sparse update: DESIGN.md §6 "Optimizer semantics")
+The 26 x 1M-row tables are never copied in float64: rows are gathered from a float32 CPU copy (bit-exact values) and
+cast afterwards.
+"""
+import torch
+
+from . import bridge
+from . import reference_layers as R
+
+
+class _RowTable:
+    """tables[f][ids] -> the looked-up rows as a float64 leaf that records its gradient (= IndexedSlices.values)."""
+
+    def __init__(self, table_f32_cpu, dtype, log):
+        self.t, self.dtype, self.log = table_f32_cpu, dtype, log
+
+    def __getitem__(self, ids):
+        ok = (ids >= 0) & (ids < self.t.shape[0])                     # TF-GPU embedding_lookup: out-of-range -> zeros
+        rows = self.t[ids.clamp(0, self.t.shape[0] - 1)].to(self.dtype) * ok.unsqueeze(-1).to(self.dtype)
+        rows = rows.detach().requires_grad_(True)
+        self.log.append((ids, rows, ok))
+        return rows
+
+
+def dense_parameters(dm):
+    """[(qualified name, torch parameter)] of every non-table parameter of the product model"""
+    return [(n, p) for n, p in dm.model.named_parameters() if 'tables' not in n]
+
+
+def oracle_train_step(dm, idx, dense, y, dtype=torch.float64, tables_cpu=None):
+    """One fwd + BCE + bwd of the oracle on the product model's CURRENT weights.
+    idx [B,F] int (per-column ids), dense [B,Nd] or None, y [B,1].
+    -> dict(logit [B,1], loss, weights (oracle weight dict with .grad), rows [B,F] packed table row ids (-1 invalid),
+            row_grads [B,F,D], tables_cpu (float32 CPU copies, reusable))"""
+    emb = dm.model.layers_by_name['emb_categorical_vars_all']
+    if tables_cpu is None:
+        tables_cpu = [e.detach().to('cpu', torch.float32) for e in emb.embeddings]
+    w = bridge.oracle_weights(dm, dtype, requires_grad=True, tables=False)
+    log = []
+    w['emb_categorical_vars_all'] = [_RowTable(t, dtype, log) for t in tables_cpu]
+    idx_c = idx.detach().cpu()
+    dn = None if dense is None else dense.detach().cpu().to(dtype)
+    logit, _ = R.model_forward(w, idx_c.to(torch.float32), dn, dm.config.nets, bridge.oracle_config(dm), training=True)
+    loss = R.binary_crossentropy_from_logits(logit, y.detach().cpu().to(dtype))
+    loss.backward()
+    B, F = idx_c.shape
+    offs, o = [], 0
+    for t in tables_cpu:
+        offs.append(o)
+        o += t.shape[0]
+    rows = torch.empty(B, F, dtype=torch.int64)
+    grads = []
+    for f, (ids, r, ok) in enumerate(log):
+        rows[:, f] = torch.where(ok.reshape(-1), ids.reshape(-1).long() + offs[f], torch.full((B,), -1, dtype=torch.int64))
+        grads.append(r.grad.reshape(B, 1, -1))
+    return {'logit': logit.detach(), 'loss': float(loss.detach()), 'weights': w, 'rows': rows,
+            'row_grads': torch.cat(grads, 1), 'tables_cpu': tables_cpu, 'row_offsets': offs}
+
+
+def merge_rows(rows, values):
+    """(rows [N] with -1 = skip, values [N,D]) -> (sorted unique rows, per-row sums): what a row-sparse optimizer sees"""
+    rows = rows.reshape(-1)
+    values = values.reshape(rows.shape[0], -1)
+    keep = rows >= 0
+    rows, values = rows[keep], values[keep]
+    uniq, inv = torch.unique(rows, return_inverse=True)
+    out = torch.zeros(uniq.shape[0], values.shape[1], dtype=values.dtype)
+    out.index_add_(0, inv, values)
+    return uniq, out
+
+
+def _rel(a, b):
+    b = b.detach().double().cpu()
+    return (a.detach().double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def oracle_dense_grads(dm, w):
+    """product parameter name -> oracle gradient, for the DeepFM graph (Keras layer names of deepmodel.py / deepnets.py)"""
+    L = dm.model.layers_by_name
+    out = []
+
+    def add(p, g):
+        if p is not None and g is not None:
+            out.append((p, g))
+    add(L['task_output'].kernel, w['task_output'][0].grad)
+    if L['task_output'].bias is not None:
+        add(L['task_output'].bias, w['task_output'][1].grad)
+    for name, layer in L.items():
+        if name.startswith('dense_logit_') and name in w:
+            add(layer.kernel, w[name].grad)
+    if 'linear_logit' in L:
+        add(L['linear_logit'].kernel, w['linear_logit'].grad)
+    if 'bn_concat_emb_dense' in L and 'bn_concat_emb_dense' in w:
+        add(L['bn_concat_emb_dense'].gamma, w['bn_concat_emb_dense'][0].grad)
+        add(L['bn_concat_emb_dense'].beta, w['bn_concat_emb_dense'][1].grad)
+    for prefix, key in (('dnn', 'dnn'), ('dcn', 'dcn_dnn')):
+        i = 1
+        while f'{prefix}_dense_{i}' in L and key in w:
+            d = L[f'{prefix}_dense_{i}']
+            add(d.kernel, w[key][i - 1][0].grad)
+            if d.bias is not None:
+                add(d.bias, w[key][i - 1][1].grad)
+            i += 1
+    if 'dcn_cross_layer' in L and 'dcn_cross_kernels' in w:
+        for k, kw in zip(L['dcn_cross_layer'].kernels, w['dcn_cross_kernels']):
+            add(k, kw.grad)
+        for b_, bw in zip(L['dcn_cross_layer'].bias, w['dcn_cross_bias']):
+            add(b_, bw.grad)
+    return out
+
+
+def check_train_step(dm, batch, adam=True, lr=1e-3):
+    """Run ONE product train step (forward_backward [+ optimizer.step]) on `batch` = (idx, dense, y) device tensors and
+    compare everything it produced with the oracle.  -> dict of error figures (see keys below).  The caller asserts."""
+    import numpy as np
+    from deeptables_amd import ops
+    idx, dense, y = batch
+    emb = dm.model.layers_by_name['emb_categorical_vars_all']
+    D = emb.groups[0][0]
+    key = f'd{D}'
+    table = emb.tables[key]
+    ref = oracle_train_step(dm, idx, dense, y)
+    res = {}
+    # (1) the gather itself, bit for bit (float32 ids = reference contract, int32 ids = fast path)
+    rows_ref32 = torch.cat([t[idx[:, f].long().cpu().clamp(0, t.shape[0] - 1)].unsqueeze(1)
+                            for f, t in enumerate(ref['tables_cpu'])], 1)          # [B,F,D] float32
+    exact = True
+    for ids in (idx.to(torch.int32), idx.to(torch.float32)):
+        got, _ = ops.embedding_lookup(ids.contiguous(), table, getattr(emb, f'row_offset_{key}'),
+                                      getattr(emb, f'vocab_{key}'))
+        exact = exact and torch.equal(got.detach().cpu().reshape(rows_ref32.shape), rows_ref32)
+    res['gather_bit_exact'] = bool(exact)
+    # (2) the step
+    dm.model.train()
+    dense_before = [(n, p.detach().clone()) for n, p in dense_parameters(dm)]
+    opt = dm.optimizer
+    t_before = opt.t
+    loss, logit = dm.forward_backward([idx, dense] if dense is not None else [idx], y)
+    torch.cuda.synchronize()
+    res['fused_plan'] = type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None
+    res['max_abs_logit_err'] = (logit.double().cpu().reshape(-1) - ref['logit'].reshape(-1)).abs().max().item()
+    res['loss_abs_err'] = abs(float(loss) - ref['loss'])
+    worst = 0.0
+    pairs = oracle_dense_grads(dm, ref['weights'])
+    for p, g in pairs:
+        worst = max(worst, _rel(p.grad.reshape(g.shape), g))
+    res['dense_grad_rel_err'] = worst
+    res['dense_grads_checked'] = len(pairs)
+    # (3) the sparse gradient, merged per table row on both sides
+    sg = emb.sparse_grads[key]
+    g_rows = torch.cat([s.rows.reshape(-1) for s in sg]).cpu()
+    g_vals = torch.cat([s.values.reshape(-1, D) for s in sg]).double().cpu()
+    u_got, v_got = merge_rows(g_rows, g_vals)
+    u_ref, v_ref = merge_rows(ref['rows'], ref['row_grads'].double())
+    res['rows_identical'] = bool(torch.equal(u_got, u_ref))
+    res['distinct_rows'] = int(u_ref.shape[0])
+    res['lookups'] = int(ref['rows'].numel())
+    if res['rows_identical']:
+        res['rows_grad_rel_err'] = (v_got - v_ref).abs().max().item() / max(v_ref.abs().max().item(), 1e-30)
+        # per lookup: the gradient the product holds for the row of lookup (b,f) is the oracle's sum over every
+        # lookup of that row in the batch
+        pos = torch.searchsorted(u_got, ref['rows'].reshape(-1).clamp(min=0))
+        per_lookup = v_got[pos]
+        want = v_ref[torch.searchsorted(u_ref, ref['rows'].reshape(-1).clamp(min=0))]
+        res['rows_grad_per_lookup_rel_err'] = (per_lookup - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+    else:
+        res['rows_grad_rel_err'] = float('inf')
+    # (4) one Keras-Adam step
+    if adam:
+        t_rows_before = table.detach()[u_ref.to(table.device)].double().cpu()
+        st = opt.state.get(id(table))
+        fresh = t_before == 0
+        opt.step()
+        torch.cuda.synchronize()
+        t = t_before + 1
+        if fresh:       # m = v = 0 before the step: the update is a closed form of the gradient
+            p_new, _, _ = R.keras_adam_step(t_rows_before, v_ref, torch.zeros_like(v_ref), torch.zeros_like(v_ref), t, lr=lr)
+            got = table.detach()[u_ref.to(table.device)].double().cpu()
+            step = (p_new - t_rows_before).abs().max().item()
+            res['adam_rows_rel_err'] = (got - p_new).abs().max().item() / max(step, 1e-30)
+            worst = 0.0
+            by_id = {id(p): g for p, g in pairs}
+            for n, before in dense_before:
+                p = dict(dense_parameters(dm))[n]
+                g = by_id.get(id(p))
+                if g is None:
+                    continue
+                pb = before.double().cpu()
+                pn, _, _ = R.keras_adam_step(pb, g.reshape(pb.shape), torch.zeros_like(pb), torch.zeros_like(pb), t, lr=lr)
+                stepsz = (pn - pb).abs().max().item()
+                worst = max(worst, (p.detach().double().cpu() - pn).abs().max().item() / max(stepsz, 1e-30))
+            res['adam_dense_rel_err'] = worst
+        # rows that were not looked up must be untouched (row-sparse update)
+        probe = torch.randint(0, table.shape[0], (4096,), generator=torch.Generator().manual_seed(11))
+        probe = probe[~torch.isin(probe, u_ref)]
+        cat_tables = ref['tables_cpu']
+        offs = ref['row_offsets']
+        f_of = np.searchsorted(np.asarray(offs), probe.numpy(), side='right') - 1
+        want = torch.stack([cat_tables[int(f)][int(r) - offs[int(f)]] for f, r in zip(f_of, probe)])
+        res['untouched_rows_unchanged'] = bool(torch.equal(table.detach()[probe.to(table.device)].cpu(), want))
+    return res

@@ -1,0 +1,59 @@
+# -*- coding:utf-8 -*-
+"""GPU: the configuration bench.py times — fused DeepFM step at B = 8192 on 26 x 1,000,000-row tables, in-step row
+dedupe, row-sparse Keras Adam — checked against the CPU oracle (oracle/headline.py): logits <= 1e-4 (north_star),
+gather bit-exact for int32 and float32 ids, loss, every dense gradient, the merged sparse gradient per table row and
+per lookup, one Adam step on the touched rows and on the dense parameters, untouched rows unchanged.
+Reference: deeptables/models/deepmodel.py:259-317 (graph), :321-338 (Adam + BCE), layers.py:889-904 (lookup)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(res, tol_grad=2e-4):
+    assert res['fused_plan'] == 'FusedDeepFM', res
+    assert res['gather_bit_exact'], res
+    assert res['max_abs_logit_err'] < 1e-4, res
+    assert res['loss_abs_err'] < 1e-5, res
+    assert res['dense_grads_checked'] >= 10 and res['dense_grad_rel_err'] < tol_grad, res
+    assert res['rows_identical'], res
+    assert res['rows_grad_rel_err'] < tol_grad and res['rows_grad_per_lookup_rel_err'] < tol_grad, res
+    assert res['adam_rows_rel_err'] < 1e-3 and res['adam_dense_rel_err'] < 1e-3, res
+    assert res['untouched_rows_unchanged'], res
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'zipf'])
+def test_headline_config_matches_oracle(dev, dist):
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.DeepFM, dev)
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind=dist)
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    if dist == 'zipf':
+        assert res['distinct_rows'] < res['lookups'] // 2      # the duplicate merge is really exercised
+    _check(res)
+
+
+def test_headline_config_float32_ids_second_step(dev):
+    """float32 ids (the reference's input contract, dataset_generator.py:41-42) through the same step; and a second
+    step on warm optimizer state stays consistent with the oracle's forward for the updated weights"""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.DeepFM, dev)
+    bench.N_BATCHES, keep = 2, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=99, dist_kind='uniform')
+    finally:
+        bench.N_BATCHES = keep
+    idx, dense, y = batches[0]
+    res = headline.check_train_step(dm, (idx.to(torch.float32), dense, y))
+    _check(res)
+    res2 = headline.check_train_step(dm, batches[1], adam=True)      # t = 2: only fwd/bwd figures are closed-form
+    assert res2['max_abs_logit_err'] < 1e-4 and res2['rows_identical'] and res2['rows_grad_rel_err'] < 2e-4, res2
+    assert res2['untouched_rows_unchanged'], res2

@@ -1,4 +1,4 @@
-"""Builds profiles/r01_deepfm_traffic.json from the two rocprofv3 PMC passes (tools_pmc.sh):
+"""Builds profiles/deepfm_traffic.json (stamped with the source hash of the kernels it was measured on) from the two rocprofv3 PMC passes (tools_pmc.sh):
     python tools/make_traffic.py gpurun_out/r01_pmc_fetch/r01_pmc_fetch_counter_collection.csv \
                                  gpurun_out/r01_pmc_write/r01_pmc_write_counter_collection.csv
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Correction (MI355X_MICROARCH.md §HBM): on gfx950
@@ -58,7 +58,18 @@ def main():
         'algorithmic_fwd_bwd': int(fwd_bwd), 'algorithmic_adam': int(opt),
     }
     out['traffic_over_algorithmic'] = round(out['bytes_per_step_corrected'] / out['algorithmic_bytes_per_step'], 2)
-    path = os.path.join(ROOT, 'profiles', 'r01_deepfm_traffic.json')
+    # the hash of the kernel sources the passes ran on: taken from the run's own record when given (argv[3] = the
+    # bench log holding the "[build] ok ... source hash X" line), else from the tree — bench.py only reports
+    # roofline.traffic while this matches the sources it is running
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    out['source_hash'] = ge.source_hash()
+    if len(sys.argv) > 3:
+        import re
+        m = re.search(r'source hash ([0-9a-f]{16})', open(sys.argv[3]).read())
+        if m:
+            out['source_hash'] = m.group(1)
+    path = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
     json.dump(out, open(path, 'w'), indent=2)
     print(json.dumps(out, indent=2))
 
