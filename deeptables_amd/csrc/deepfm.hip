@@ -1,4 +1,4 @@
-// deepfm.hip — the whole DeepFM train step (forward + BCE + backward) as SIX fused launches.
+// deepfm.hip — the whole DeepFM train step (forward + BCE + backward) as SEVEN fused launches.
 //
 // DeepFM = nets ['linear','fm_nets','dnn_nets'] (deeptables/models/deepnets.py:15) assembled by
 // DeepModel.__build_model (deeptables/models/deepmodel.py:259-317):
@@ -9,32 +9,30 @@
 //   fm    = FM()(Concatenate(emb, axis=1))                              layers.py:53-62
 //   dnn   = Dense(1,no bias)(relu(Dense(64)(relu(Dense(128)(xn)))))     deepnets.py:401-427, deepmodel.py:291-292
 //   logit = Dense(1, bias)(Add([lin, fm, dnn]))  (sigmoid applied by the loss)   deepmodel.py:296-297,455
-// The reference runs this as ~100 small TF ops per step; the generic path of this repo as ~60
-// launches.  Here:
-//   A  k_sparse_fwd   gather + FM + linear + concat row X + per-block BN statistics      (HBM-bound)
-//   B  k_prep + k_bn_final   two-level BN reduction (mean/rstd, moving stats), zero-padded W1 and W1^T
-//   C  k_mlp_fwd      X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit  (fp32 MFMA)
-//   D  k_mlp_bwd      dH2, dH1, dXn tiles + per-tile partial sums of every small gradient
-//   E  k_wgrad        dW1 = Xn^T dH1, dW2 = H1^T dH2 (fp32 MFMA) + reduction of D's partial sums
-//   G  k_sparse_bwd   BN backward + embedding row-gradients (the IndexedSlices values)
-// Matrix work uses v_mfma_f32_32x32x2_f32 (exact fp32) so logits stay within 1e-4 of the oracle.
-// Every wave owns one 32x32 output tile so that all 1024 SIMDs are busy at B=8192 (256 row tiles x 4).
-// All GEMM operands are zero-padded to K = CP (a multiple of 64) so the MFMA loops are straight-line:
-// 16-step chunks, operands for the next chunk already in flight (no per-load predication, counted waits).
-// No same-address float atomics: per-tile partials + one reduction pass (dW1/dW2 tiles: 4 adds/address).
+// The reference runs this as ~100 small TF ops per step; the generic path of this repo as ~60 launches.  Here:
+//   A  k_sparse_fwd     gather + FM + linear + concat row X + field sums S + per-block BN statistics   (HBM-bound)
+//   B  k_prep + k_bn_final   two-level BN reduction (mean/rstd, moving stats), MFMA operand layouts of W1 / W2 / W2^T
+//   C  k_mlp_fwd3       X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit + the top of the backward
+//   E  k_wgrad4         Xhat^T dH1 and H1^T dH2 (split over batch slices) + reduction of C's per-tile partial sums
+//   E' k_bn_grads2      slices added up; dgamma, dbeta, dW1, dW2, d w_lin finished
+//   D  k_dx_sparse_bwd  dXn = dH1 W1^T with BN backward + FM/linear terms + embedding row-gradients as its epilogue
+// (details in front of the kernels).  Matrix work uses v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32) so
+// logits stay within 1e-4 of the oracle.  No float atomics on any dense gradient: per-tile / per-slice partials + one
+// reduction pass each.
 #include <stdlib.h>
 #include "common.h"
 
 namespace dt {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kH1 = 128;  // dnn_params hidden_units[0]
 constexpr int kH2 = 64;   // dnn_params hidden_units[1]
 constexpr int kTM = 32;   // rows per MLP tile
 
 struct DeepFmDims {
-    int B, F, D, Nd, C, CP;  // C = F*D+Nd; CP = C rounded up to 64: row stride of X / dXn / W1T and the padded GEMM K
+    int B, F, D, Nd, C, CP;  // C = F*D+Nd; CP = C rounded up to 64: row stride of X and the padded GEMM K
 };
 
 // accumulator buffer layout (floats), zeroed once per step by one memset
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
     int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial, DedupeWs dd,
-    float* __restrict__ grad_rows) {
+    float* __restrict__ grad_rows, float* __restrict__ S_out) {
     __shared__ __attribute__((aligned(16))) float rowbuf[kRowsPerBlockA][kMaxC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & (LPR - 1);
@@ -165,6 +163,7 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
         S.z = wave_sum_strided<LPR>(S.z); S.w = wave_sum_strided<LPR>(S.w);
         Q.x = wave_sum_strided<LPR>(Q.x); Q.y = wave_sum_strided<LPR>(Q.y);
         Q.z = wave_sum_strided<LPR>(Q.z); Q.w = wave_sum_strided<LPR>(Q.w);
+        if (S_out && lane < LPR) *reinterpret_cast<float4*>(S_out + (int64_t)b * D + 4 * lane) = S;   // S[b][d] = sum_f E[b,f,d]
         float ts = ((S.x * S.x - Q.x) + (S.y * S.y - Q.y)) + ((S.z * S.z - Q.z) + (S.w * S.w - Q.w));
         ts = group_sum<LPR>(ts);
         lp = wave_sum(lp);
@@ -193,42 +192,54 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------
-// B: BN finalize + zero-padded W1P [CP][H1] and W1T [H1][CP] + zeroing of dW1|dW2
+// B: BN finalize + the MFMA operand layouts of W1 / W2 / W2^T (see the round-2 tower notes below)
 //    BN blocks: 64 columns x 16 waves; lanes run along the columns (256-byte coalesced partial rows), every
 //    wave Chan-merges a slice of the chunk list, the 16 slices meet in LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBnSlices = 16;   // level-1 BN reduction blocks per 64-column group
 
 struct PrepOut {
-    float *mean, *rstd, *sc, *beta, *W1P, *W1T;   // all padded to CP
+    float *mean, *rstd, *sc, *beta;               // all padded to CP
     float* bn2;                                   // [kBnSlices][3][C] level-1 results
+    float *W1L, *W2L, *W2TL;                      // MFMA operand layouts of W1 / W2 / W2^T (k_mlp_fwd3)
+    const float* W2;
 };
 
 __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
                                                float eps, float momentum, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ moving_mean,
                                                float* __restrict__ moving_var, const float* __restrict__ W1,
-                                               PrepOut o, int bn_blocks, float* __restrict__ zero_region,
-                                               int zero_floats) {
-    if ((int)blockIdx.x >= bn_blocks) {  // weight copies + zeroing of the atomically accumulated dW1/dW2
-        __shared__ float tile[32][33];
+                                               PrepOut o, int bn_blocks) {
+    if ((int)blockIdx.x >= bn_blocks) {  // weight layouts
         const int wb = (int)blockIdx.x - bn_blocks, nwb = gridDim.x - bn_blocks;
-        for (int e = wb * blockDim.x + threadIdx.x; e < zero_floats; e += nwb * blockDim.x) zero_region[e] = 0.f;
-        const int total = kH1 * dm.CP;
-        for (int e = wb * blockDim.x + threadIdx.x; e < total; e += nwb * blockDim.x) {   // W1P[col][k]: plain copy
-            const int col = e / kH1;
-            o.W1P[e] = col < dm.C ? W1[e] : 0.f;
+        // W1L: float4 j of lane (c = l%32, s = l/32) of wave w in k-group g = W1[8g + 4s + j][32w + c]  (k_mlp_fwd3 GEMM1)
+        floatx4_t* w1l = reinterpret_cast<floatx4_t*>(o.W1L);
+        const int n4 = dm.CP * kH1 / 4;
+        for (int e = wb * blockDim.x + threadIdx.x; e < n4; e += nwb * blockDim.x) {
+            const int c = e & 31, s = (e >> 5) & 1, w = (e >> 6) & 3, g = e >> 8;
+            const int k0 = 8 * g + 4 * s, n = 32 * w + c;
+            floatx4_t v;
+            v.x = k0 + 0 < dm.C ? W1[(int64_t)(k0 + 0) * kH1 + n] : 0.f;
+            v.y = k0 + 1 < dm.C ? W1[(int64_t)(k0 + 1) * kH1 + n] : 0.f;
+            v.z = k0 + 2 < dm.C ? W1[(int64_t)(k0 + 2) * kH1 + n] : 0.f;
+            v.w = k0 + 3 < dm.C ? W1[(int64_t)(k0 + 3) * kH1 + n] : 0.f;
+            w1l[e] = v;
         }
-        // W1T[k][col] = W1[col][k]: 32x32 tiles through LDS so that both the read (along k) and the write
-        // (along col) are coalesced
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 32 threads
-        const int ctiles = dm.CP >> 5, ktiles = kH1 >> 5;
-        for (int t = wb; t < ctiles * ktiles; t += nwb) {
-            const int c0 = (t / ktiles) << 5, k0 = (t % ktiles) << 5;
-            __syncthreads();
-            tile[ty][tx] = (c0 + ty) < dm.C ? W1[(int64_t)(c0 + ty) * kH1 + k0 + tx] : 0.f;
-            __syncthreads();
-            o.W1T[(int64_t)(k0 + ty) * dm.CP + c0 + tx] = tile[tx][ty];
+        // W2L: float4 j of lane (n = l%16, q = l/16) of wave w in k-group G = W2[16G + 4q + j][16w + n]  (GEMM2, 16x16x4)
+        floatx4_t* w2l = reinterpret_cast<floatx4_t*>(o.W2L);
+        for (int e = wb * blockDim.x + threadIdx.x; e < kH1 * kH2 / 4; e += nwb * blockDim.x) {
+            const int l = e & 63, w = (e >> 6) & 3, G = e >> 8;
+            const int k0 = 16 * G + 4 * (l >> 4), n = 16 * w + (l & 15);
+            floatx4_t v;
+            v.x = o.W2[(k0 + 0) * kH2 + n]; v.y = o.W2[(k0 + 1) * kH2 + n];
+            v.z = o.W2[(k0 + 2) * kH2 + n]; v.w = o.W2[(k0 + 3) * kH2 + n];
+            w2l[e] = v;
+        }
+        // W2TL: float4 j of lane (c = l%32, s = l/32) of wave w in k-group g = W2[32w + c][8g + 4s + j]  (dH1 = dH2 . W2^T)
+        floatx4_t* w2tl = reinterpret_cast<floatx4_t*>(o.W2TL);
+        for (int e = wb * blockDim.x + threadIdx.x; e < kH1 * kH2 / 4; e += nwb * blockDim.x) {
+            const int l = e & 63, w = (e >> 6) & 3, g = e >> 8;
+            w2tl[e] = *reinterpret_cast<const floatx4_t*>(o.W2 + (32 * w + (l & 31)) * kH2 + 8 * g + 4 * (l >> 5));
         }
         return;
     }
@@ -313,691 +324,804 @@ __global__ __launch_bounds__(256) void k_bn_final(DeepFmDims dm, float eps, floa
     if (moving_var) moving_var[col] = moving_var[col] * momentum + var * (1.f - momentum);
 }
 
-// ---------------------------------------------------------------------------------------------
-// per-tile partial sums written by C/D and reduced by E (layout of one tile's record, floats)
-// ---------------------------------------------------------------------------------------------
-struct PartLayout {
-    int sg, sgx, slin, db1, db2, dw3, dwo, dbo, loss, stride;
-};
-__host__ __device__ inline PartLayout part_layout(int CP) {
-    PartLayout l;
-    l.sg = 0; l.sgx = CP; l.slin = 2 * CP;
-    l.db1 = 3 * CP; l.db2 = l.db1 + kH1; l.dw3 = l.db2 + kH2;
-    l.dwo = l.dw3 + kH2; l.dbo = l.dwo + 1; l.loss = l.dbo + 1;
-    l.stride = (l.loss + 1 + 3) & ~3;
-    return l;
-}
-
-// ---------------------------------------------------------------------------------------------
-// C: MLP forward on a 32-row tile.  4 waves; GEMM1: wave w owns hidden units [32w, 32w+32).
-// ---------------------------------------------------------------------------------------------
 struct MlpParams {
-    const float *W1P, *b1, *W2, *b2, *w3, *wo, *bo, *gamma, *mean, *rstd, *sc, *betap;
+    const float *b1, *W2, *b2, *w3, *wo, *bo, *gamma, *mean, *rstd, *sc, *betap;
+    const float *W1, *W1L, *W2L, *W2TL;   // original W1 [C][128]; lane-major operand layouts written by k_prep (see k_mlp_fwd3)
 };
 
-constexpr int kCH = 16;   // MFMA steps per operand chunk
-
-// phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][8] u64,
+// phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
 // read back by tools/phase_times.py; costs one scalar load + store per phase
 #define DT_STAMP(buf, slot)                                                            \
     do {                                                                               \
         if ((buf) && threadIdx.x == 0)                                                 \
-            (buf)[(int64_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();    \
+            (buf)[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();    \
     } while (0)
 
-__global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
-                                                 const float* __restrict__ lin, const float* __restrict__ fm,
-                                                 const float* __restrict__ y, float* __restrict__ H1,
-                                                 float* __restrict__ H2, float* __restrict__ z_out,
-                                                 float* __restrict__ logit_out, float* __restrict__ dlogit,
-                                                 float* __restrict__ part, unsigned long long* stamps) {
+
+// =============================================================================================
+// Round-2 dense tower.  What round 1's kernels taught (phase stamps, tools/phase_times.py):
+//   * a wave issues in order and an MFMA holds its issue slot until the matrix pipe accepts it, so with ONE wave
+//     per SIMD every LDS read or global load placed "just before use" idles the pipe for its whole latency: all
+//     operand reads here are placed half a chunk (16 MFMAs) or more ahead of their use;
+//   * a burst of global loads blocks the issuing wave until the CU's memory pipeline has taken them (~20 cycles
+//     per wave-instruction, shared by the 4 SIMDs; ~100+ when every CU bursts at once): loads are issued one or
+//     two at a time BETWEEN groups of MFMAs, two chunks ahead, never as a prologue burst;
+//   * the memory pipeline's cost is per wave-instruction, not per byte: every operand is a 16-byte (or 8-byte)
+//     vector.  An MFMA contraction index may be permuted freely as long as A and B agree, so a lane takes FOUR
+//     consecutive k (one float4) and spends them on four consecutive MFMA steps:
+//       32x32x2: lane (c = l%32, s = l/32), step 4g+j  <->  k = 8g + 4s + j
+//       16x16x4: lane (n = l%16, q = l/16), step 4G+j  <->  k = 16G + 4q + j
+//     weights come from L2 in lane-major re-layouts written once per step by k_prep (W1L, W2L, W2TL) or, for
+//     dXn = dH1 . W1^T, straight from the ROW-major W1 whose rows are the k-contiguous vectors needed.
+// Launches (after A = k_sparse_fwd and B = k_prep + k_bn_final):
+//   C  k_mlp_fwd3     X tile -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit, and — still on the
+//                     tile — the TOP of the backward: dH2 (registers), dH1 = relu'(dH2 . W2^T); per-tile partial sums
+//                     of db1, db2, dw3, dw_out, db_out, d w_lin (raw X is still in registers) and the loss
+//   E  k_wgrad3       M = Xhat^T dH1 (Xhat = (X - mean) rstd, formed on the operand), dW2 = H1^T dH2, + the reduction
+//                     of C's per-tile partial sums
+//   E' k_bn_grads     dgamma = rowdot(W1, M), dbeta = W1 db1 (= the two batch sums BN's backward needs: they are linear
+//                     in dH1, so no pass over dXn is required), dW1 = gamma M + beta (x) db1 in place, d w_lin
+//   D  k_dx_sparse_bwd  dXn = dH1 . W1^T per 16-column block with the BN backward, the FM / linear terms and the
+//                     embedding row-gradient store (incl. the duplicate merge) as its epilogue: dXn never exists in HBM
+// =============================================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+constexpr int kPad = 4;      // LDS row pad in floats: stride == 4 (mod 64) -> the 16-byte operand reads of 16 rows hit 64 distinct banks
+constexpr int kH2S = kH2 + kPad;
+
+__device__ __forceinline__ floatx4 ld4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
+__device__ __forceinline__ void st4(float* p, floatx4 v) { *reinterpret_cast<floatx4*>(p) = v; }
+
+// per-tile partial sums written by C and reduced by E (layout of one tile's record, floats; contiguous)
+struct Part3 {
+    int slin, db1, db2, dw3, dwo, dbo, loss, n, stride;
+};
+__host__ __device__ inline Part3 part3_layout(int CP) {
+    Part3 l;
+    l.slin = 0; l.db1 = CP; l.db2 = l.db1 + kH1; l.dw3 = l.db2 + kH2;
+    l.dwo = l.dw3 + kH2; l.dbo = l.dwo + 1; l.loss = l.dbo + 1;
+    l.n = l.loss + 1;
+    l.stride = (l.n + 3) & ~3;
+    return l;
+}
+
+// C: MLP forward + top of the backward on a 32-row tile; NCH = CP / 64 column chunks.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
+                                                  const float* __restrict__ lin, const float* __restrict__ fm,
+                                                  const float* __restrict__ y, float* __restrict__ H1,
+                                                  float* __restrict__ dH1, float* __restrict__ dH2,
+                                                  float* __restrict__ z_out, float* __restrict__ logit_out,
+                                                  float* __restrict__ dlogit, float* __restrict__ dz_out,
+                                                  float* __restrict__ part, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
-    const int XS = dm.CP + 1;  // odd stride: lanes walk rows conflict-free
-    float* xn = lds;                    // [32][XS]
-    float* h1 = xn + kTM * XS;          // [32][129]
-    float* red = h1 + kTM * (kH1 + 1);  // [2][32][65]
-    float* h2 = red + 2 * kTM * (kH2 + 1);  // [32][65]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = lane >> 5, c = lane & 31;
+    constexpr int CP = 64 * NCH, XS = CP + kPad, HS = kH1 + kPad;
+    float* xs = lds;                   // [32][XS] Xn tile; reused for the 4 waves' d w_lin partials at the end
+    float* bnp = xs + kTM * XS;        // [3][CP]  mean | gamma*rstd | beta
+    float* h1s = bnp + 3 * CP;         // [32][HS] H1, later dH1
+    float* dh2s = h1s + kTM * HS;      // [32][kH2S] dH2
+    float* zp = dh2s + kTM * kH2S;     // [4][32]  per-wave partial dnn logits
+    float* dzs = zp + 4 * kTM;         // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane >> 5, c = lane & 31, n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
-    const PartLayout pl = part_layout(dm.CP);
+    const Part3 pl = part3_layout(dm.CP);
+    float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
-    // GEMM2's B operands (W2, L2-resident) do not depend on anything computed here: fetch them now so their
-    // latency hides under the staging and GEMM1 phases (one block per CU = no other wave to hide it)
-    float w2q[32];
-    {
-        const int nb2 = wave & 1, kh2 = wave >> 1;
-        const float* bcol2 = p.W2 + (int64_t)(64 * kh2 + s) * kH2 + 32 * nb2 + c;
+    // ---- prologue loads: BN parameters, chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
+    float bnv[3][(CP + 255) / 256];
 #pragma unroll
-        for (int st = 0; st < 32; ++st) w2q[st] = bcol2[(int64_t)2 * st * kH2];
+    for (int i = 0; i < (CP + 255) / 256; ++i) {
+        const int col = tid + 256 * i;
+        const bool ok = col < CP;
+        bnv[0][i] = ok ? p.mean[col] : 0.f;
+        bnv[1][i] = ok ? p.sc[col] : 0.f;
+        bnv[2][i] = ok ? p.betap[col] : 0.f;
     }
-    const float bias1 = p.b1[32 * wave + c];
-
-    // ---- stage Xn = BN(X): pad columns carry sc = beta = 0 -> Xn = 0.  The X tile was written by another
-    // XCD a moment ago (HBM/MALL latency): issue every load of this thread before touching any result. ----
-    const int q4 = dm.CP >> 2;
-    {
-        constexpr int U = 8;
-        const int total = kTM * q4;
-        for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * U) {
-            float4 xv[U], mu[U], sc[U], be[U];
+    const int qcol = 4 * (tid & 15), srow = tid >> 4;      // staging: this thread owns 4 columns of rows srow, srow + 16
+    floatx4 xv[NCH][2];                                    // raw X, kept to the end (d w_lin partial sums)
+    auto xload1 = [&](int j, int u) {       // unconditional: the workspace rows of a ragged last tile are zero (host memset)
+        xv[j][u] = ld4(X + (int64_t)(m0 + srow + 16 * u) * CP + 64 * j + qcol);
+    };
+    const floatx4* w1l = reinterpret_cast<const floatx4*>(p.W1L) + wave * 64 + lane;     // + 256 per k-group g
+    floatx4 bq[3][8];
+    xload1(0, 0); xload1(0, 1);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * blockDim.x;
-                const int r = e / q4, q = e - r * q4;
-                const int m = m0 + r;
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < total) {
-                    if (m < dm.B) xv[u] = *reinterpret_cast<const float4*>(X + (int64_t)m * dm.CP + 4 * q);
-                    mu[u] = *reinterpret_cast<const float4*>(p.mean + 4 * q);
-                    sc[u] = *reinterpret_cast<const float4*>(p.sc + 4 * q);
-                    be[u] = *reinterpret_cast<const float4*>(p.betap + 4 * q);
-                }
-            }
+    for (int g8 = 0; g8 < 8; ++g8) bq[0][g8] = w1l[g8 * 256];
+    if (NCH > 1) {
+        xload1(NCH > 1 ? 1 : 0, 0); xload1(NCH > 1 ? 1 : 0, 1);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * blockDim.x;
-                if (e < total) {
-                    const int r = e / q4, q = e - r * q4;
-                    float* dst = xn + r * XS + 4 * q;
-                    dst[0] = (xv[u].x - mu[u].x) * sc[u].x + be[u].x;
-                    dst[1] = (xv[u].y - mu[u].y) * sc[u].y + be[u].y;
-                    dst[2] = (xv[u].z - mu[u].z) * sc[u].z + be[u].z;
-                    dst[3] = (xv[u].w - mu[u].w) * sc[u].w + be[u].w;
-                }
-            }
-        }
+        for (int g8 = 0; g8 < 8; ++g8) bq[1][g8] = w1l[(8 + g8) * 256];
     }
+    DT_STAMP(stamps, 6);
+#pragma unroll
+    for (int i = 0; i < (CP + 255) / 256; ++i) {
+        const int col = tid + 256 * i;
+        if (col < CP) { bnp[col] = bnv[0][i]; bnp[CP + col] = bnv[1][i]; bnp[2 * CP + col] = bnv[2][i]; }
+    }
+    lds_barrier();
+    DT_STAMP(stamps, 7);
+    // Xn = BN(X) is formed on the way into LDS
+    floatx4 bnq[3];
+    auto bnread = [&](int j) {
+        bnq[0] = ld4(bnp + 64 * j + qcol);
+        bnq[1] = ld4(bnp + CP + 64 * j + qcol);
+        bnq[2] = ld4(bnp + 2 * CP + 64 * j + qcol);
+    };
+    auto xwrite = [&](int j) {
+        st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - bnq[0]) * bnq[1] + bnq[2]);
+        st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - bnq[0]) * bnq[1] + bnq[2]);
+    };
+    bnread(0);
+    xwrite(0);
     lds_barrier();
     DT_STAMP(stamps, 1);
 
-    // ---- GEMM1: [32 x CP] . [CP x 128], zero padded: straight-line chunks of 16 MFMA steps ----
-    // A dependent MFMA chain on ONE accumulator pays ~+43 cycles for every instruction (s_waitcnt, address math)
-    // the compiler leaves between two links; alternating two accumulators hides that gap behind the other chain.
+    // ---- GEMM1: [32 x CP] . [CP x 128]; wave w owns hidden units [32w, 32w+32); two accumulator chains ----
     floatx16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    floatx4 w2q[8];                    // GEMM2's B operand: fetched in the load slots of the last chunk
     {
-        const float* arow = xn + c * XS + s;                       // A[row c][k = 2 st + s]
-        const float* bcol = p.W1P + (int64_t)s * kH1 + 32 * wave + c;   // B[k][col]
-        const int nchunks = dm.CP / (2 * kCH);
-        // THREE operand buffers: chunk j+2 is issued while chunk j runs.  With two buffers the compiler's
-        // s_waitcnt in front of a chain also waits for the first load of the chunk issued just before it
-        // (vmcnt is conservative by one across the loop back-edge) and the chain starts a full memory latency late.
-        float a0[kCH], b0[kCH], a1[kCH], b1[kCH], a2[kCH], b2[kCH];
-        auto load = [&](float (&aq)[kCH], float (&bq)[kCH], int ch) {
-            const float* an = arow + 2 * kCH * ch;
-            const float* bn = bcol + (int64_t)2 * kCH * ch * kH1;
+        const floatx4* w2l = reinterpret_cast<const floatx4*>(p.W2L) + wave * 64 + lane;
+        const float* arow = xs + c * XS + 4 * s;
+        floatx4 aq[2][4];
+        auto aread = [&](int j, int h) {
 #pragma unroll
-            for (int i = 0; i < kCH; ++i) { aq[i] = an[2 * i]; bq[i] = bn[(int64_t)2 * i * kH1]; }
+            for (int i = 0; i < 4; ++i) aq[h][i] = ld4(arow + 64 * j + 32 * h + 8 * i);
         };
-        auto run = [&](const float (&aq)[kCH], const float (&bq)[kCH]) {
-            __builtin_amdgcn_sched_barrier(0);
+        auto half = [&](int j, int h) {
 #pragma unroll
-            for (int i = 0; i < kCH; i += 2) {   // two independent accumulator chains (see acc2 above)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i], bq[i], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i + 1], bq[i + 1], acc2, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const floatx4 a = aq[h][i];
+                const floatx4 b = bq[j % 3][4 * h + i];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);
+                // one or two loads per four MFMAs: chunk j+2's operands (or, in the last chunk, GEMM2's)
+                if (j + 2 < NCH) {
+                    bq[(j + 2) % 3][4 * h + i] = w1l[(8 * (j + 2) + 4 * h + i) * 256];
+                    if (i == 0) xload1(j + 2 < NCH ? j + 2 : 0, h);
+                } else if (j == NCH - 1) {
+                    w2q[4 * h + i] = w2l[(4 * h + i) * 256];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        aread(0, 0);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            aread(j, 1);
+            if (j + 1 < NCH) bnread(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            half(j, 0);
+            if (j + 1 < NCH) {
+                xwrite(j + 1);          // chunk j+1 lands in LDS between the two halves of chunk j
+                lds_barrier();
+                aread(j + 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        };
-        load(a0, b0, 0);
-        if (nchunks > 1) load(a1, b1, 1);
-        for (int ch = 0; ch < nchunks; ch += 3) {
-            if (ch + 2 < nchunks) load(a2, b2, ch + 2);
-            run(a0, b0);
-            if (ch + 1 >= nchunks) break;
-            if (ch + 3 < nchunks) load(a0, b0, ch + 3);
-            run(a1, b1);
-            if (ch + 2 >= nchunks) break;
-            if (ch + 4 < nchunks) load(a1, b1, ch + 4);
-            run(a2, b2);
+            half(j, 1);
         }
     }
     DT_STAMP(stamps, 2);
+    // operands needed after GEMM2 (their latency hides under it)
+    floatx4 w2tq[8];
     {
-        const float bias = bias1;
+        const floatx4* w2tl = reinterpret_cast<const floatx4*>(p.W2TL) + wave * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            const float h = fmaxf((acc[r] + acc2[r]) + bias, 0.f);
-            h1[row * (kH1 + 1) + 32 * wave + c] = h;
-            if (m0 + row < dm.B) H1[(int64_t)(m0 + row) * kH1 + 32 * wave + c] = h;
-        }
+        for (int g = 0; g < 8; ++g) w2tq[g] = w2tl[g * 256];
+    }
+    const float bias1 = p.b1[32 * wave + c];
+    const float b2v = p.b2[16 * wave + n16], w3v = p.w3[16 * wave + n16];
+    float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f;
+    if (wave == 0) {
+        wov = p.wo[0];
+        bov = p.bo ? p.bo[0] : 0.f;
+        if (lane < 32 && m0 + lane < dm.B) { linv = lin[m0 + lane]; fmv = fm[m0 + lane]; yv = y[m0 + lane]; }
+    }
+    float h1r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
+        h1r[r] = fmaxf((acc[r] + acc2[r]) + bias1, 0.f);
+        h1s[row * HS + 32 * wave + c] = h1r[r];
     }
     lds_barrier();
     DT_STAMP(stamps, 3);
 
-    // ---- GEMM2: [32 x 128] . [128 x 64]; wave = (n-block nb, k-half kh) ----
+    // ---- GEMM2: [32 x 128] . [128 x 64] on 16x16x4 tiles: wave w owns columns [16w, 16w+16), both row halves ----
+    float h2r[8];
     {
-        const int nb = wave & 1, kh = wave >> 1;
+        floatx4 a0[8], a1[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* arow = h1 + c * (kH1 + 1) + 64 * kh + s;
-        float aq[32];
-        const float (&bq)[32] = w2q;
+        for (int G = 0; G < 8; ++G) {
+            a0[G] = ld4(h1s + n16 * HS + 16 * G + 4 * kq);
+            a1[G] = ld4(h1s + (16 + n16) * HS + 16 * G + 4 * kq);
+        }
+        // H1 leaves for HBM (k_wgrad3 reads it) as whole rows, from LDS
+        floatx4 hrow[4];
 #pragma unroll
-        for (int st = 0; st < 32; ++st) aq[st] = arow[2 * st];
+        for (int u = 0; u < 4; ++u) hrow[u] = ld4(h1s + (tid >> 5) * HS + 4 * (tid & 31) + 8 * u * HS);
+        floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 32; st += 2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], acc2, 0, 0, 0);
+        for (int G = 0; G < 8; ++G) {
+            const floatx4 b = w2q[G];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[G].x, b.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[G].x, b.x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[G].y, b.y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[G].y, b.y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[G].z, b.z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[G].z, b.z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[G].w, b.w, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[G].w, b.w, c1, 0, 0, 0);
+            if (G < 4) {
+                const int m = m0 + (tid >> 5) + 8 * G;
+                if (m < dm.B) st4(H1 + (int64_t)m * kH1 + 4 * (tid & 31), hrow[G]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            red[(kh * kTM + row) * (kH2 + 1) + 32 * nb + c] = acc[r] + acc2[r];
+        for (int q = 0; q < 8; ++q) {
+            const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
+            h2r[q] = fmaxf(((q >> 2) ? c1[q & 3] : c0[q & 3]) + b2v, 0.f);
+            const float v = group_sum<16>(h2r[q] * w3v);
+            if (n16 == 0) zp[wave * kTM + row] = v;
         }
-    }
-    lds_barrier();
-    for (int e = threadIdx.x; e < kTM * kH2; e += blockDim.x) {
-        const int row = e / kH2, n = e - row * kH2;
-        const float v = red[row * (kH2 + 1) + n] + red[(kTM + row) * (kH2 + 1) + n] + p.b2[n];
-        const float h = fmaxf(v, 0.f);
-        h2[row * (kH2 + 1) + n] = h;
-        if (m0 + row < dm.B) H2[(int64_t)(m0 + row) * kH2 + n] = h;
     }
     lds_barrier();
     DT_STAMP(stamps, 4);
 
-    // ---- logits, loss, dlogit (wave 0) ----
+    // ---- logits, loss, dlogit, dz (wave 0) ----
     if (wave == 0) {
-        float pt = 0.f;
-        const float* hrow = h2 + c * (kH2 + 1) + 32 * s;
-#pragma unroll 8
-        for (int n = 0; n < 32; ++n) pt += hrow[n] * p.w3[32 * s + n];
-        pt += __shfl_xor(pt, 32, 64);
         const int m = m0 + c;
-        float loss = 0.f;
-        if (s == 0 && m < dm.B) {
-            const float z = (lin[m] + fm[m]) + pt;   // Add([linear, fm, dnn]) order
-            const float lg = z * p.wo[0] + (p.bo ? p.bo[0] : 0.f);
-            const float yy = y[m];
+        float loss = 0.f, dl = 0.f, zz = 0.f;
+        if (m < dm.B) {
+            const float pt = (zp[c] + zp[kTM + c]) + (zp[2 * kTM + c] + zp[3 * kTM + c]);
+            zz = (linv + fmv) + pt;                  // Add([linear, fm, dnn]) order
+            const float lg = zz * wov + bov;
             const float pr = 1.0f / (1.0f + expf(-lg));
-            loss = fmaxf(lg, 0.f) - lg * yy + log1pf(expf(-fabsf(lg)));
-            z_out[m] = z;
-            logit_out[m] = lg;
-            dlogit[m] = (pr - yy) / (float)dm.B;
+            loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
+            dl = (pr - yv) / (float)dm.B;
+            if (s == 0) {
+                z_out[m] = zz;
+                logit_out[m] = lg;
+                dlogit[m] = dl;
+                dz_out[m] = dl * wov;
+            }
         }
-        loss = wave_sum(loss);
-        if (lane == 0) part[(int64_t)blockIdx.x * pl.stride + pl.loss] = loss / (float)dm.B;
+        if (s == 0) dzs[c] = dl * wov;
+        if (s == 1) { loss = 0.f; dl = 0.f; }        // lanes 32..63 mirror rows 0..31 (linv/fmv/yv are zero there)
+        float aw = dl * zz, ab = dl;                 // d task_output kernel / bias
+        loss = wave_sum(loss); aw = wave_sum(aw); ab = wave_sum(ab);
+        if (lane == 0) { prec[pl.loss] = loss / (float)dm.B; prec[pl.dwo] = aw; prec[pl.dbo] = ab; }
     }
+    lds_barrier();
     DT_STAMP(stamps, 5);
-}
 
-// ---------------------------------------------------------------------------------------------
-// D: MLP backward on a 32-row tile
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mlp_bwd(const float* __restrict__ X, MlpParams p,
-                                                 const float* __restrict__ W1T, DeepFmDims dm,
-                                                 const float* __restrict__ H1, const float* __restrict__ H2,
-                                                 const float* __restrict__ z, const float* __restrict__ dlogit,
-                                                 float* __restrict__ dH1, float* __restrict__ dH2,
-                                                 float* __restrict__ dXn, float* __restrict__ dz_out,
-                                                 float* __restrict__ part, unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    DT_STAMP(stamps, 0);
-    float* w2s = lds;                        // [128][65]
-    float* dh2 = w2s + kH1 * (kH2 + 1);      // [32][65]
-    float* dh1 = dh2 + kTM * (kH2 + 1);      // [32][129]
-    float* dzs = dh1 + kTM * (kH1 + 1);      // [32]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.x * kTM;
-    const PartLayout pl = part_layout(dm.CP);
-    float* prec = part + (int64_t)blockIdx.x * pl.stride;
-
-    // W2 (32 KB) and this tile's H2 (8 KB): all 16-byte loads of a thread in flight together
-    float4 w2r[(kH1 * kH2 / 4) / 256], h2r[(kTM * kH2 / 4) / 256];
-#pragma unroll
-    for (int u = 0; u < (kH1 * kH2 / 4) / 256; ++u)
-        w2r[u] = *reinterpret_cast<const float4*>(p.W2 + 4 * (threadIdx.x + 256 * u));
-#pragma unroll
-    for (int u = 0; u < (kTM * kH2 / 4) / 256; ++u) {
-        const int e4 = threadIdx.x + 256 * u;                    // float4 index in the [32][64] tile
-        const int m = m0 + e4 / (kH2 / 4);
-        h2r[u] = m < dm.B ? *reinterpret_cast<const float4*>(H2 + (int64_t)m * kH2 + 4 * (e4 % (kH2 / 4)))
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // everything that does not depend on values computed in this kernel is requested now, AFTER the loads the prologue needs first
-    // (vmcnt retires in order) (one block per CU:
-    // nothing else hides HBM/MALL latency): the relu masks of dH1, and the first dXn operand block
-    float h1v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * s;
-        h1v[r] = m < dm.B ? H1[(int64_t)m * kH1 + 32 * wave + c] : 0.f;
-    }
-    float bq0[kH1 / 2], bq1[kH1 / 2], xv0[16], xv1[16], mr0[2], mr1[2];
-    auto load_nb = [&](float (&bq)[kH1 / 2], float (&xv)[16], float (&mr)[2], int nb) {
-        const int col = 32 * nb + c;
-        mr[0] = p.mean[col];
-        mr[1] = p.rstd[col];
-        const float* bcol = W1T + (int64_t)s * dm.CP + col;
-#pragma unroll
-        for (int st = 0; st < kH1 / 2; ++st) bq[st] = bcol[(int64_t)2 * st * dm.CP];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            xv[r] = X[(int64_t)(m0 + row) * dm.CP + col];      // workspace rows are padded to the tile: in range
-        }
-    };
-    const int nblocks = dm.CP >> 5;
-    if (wave < nblocks) load_nb(bq0, xv0, mr0, wave);
-    if (threadIdx.x < kTM) {
-        const int m = m0 + threadIdx.x;
-        float dl = 0.f, zz = 0.f;
-        if (m < dm.B) { dl = dlogit[m]; zz = z[m]; }
-        const float dzv = dl * p.wo[0];
-        dzs[threadIdx.x] = dzv;
-        if (m < dm.B) dz_out[m] = dzv;
-        float a = dl * zz, b = dl;   // d task_output kernel / bias
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (threadIdx.x == 0) { prec[pl.dwo] = a; prec[pl.dbo] = b; }
-    }
-#pragma unroll
-    for (int u = 0; u < (kH1 * kH2 / 4) / 256; ++u) {
-        const int e = 4 * (threadIdx.x + 256 * u);
-        const int k = e / kH2, n = e - k * kH2;
-        float* dst = w2s + k * (kH2 + 1) + n;
-        dst[0] = w2r[u].x; dst[1] = w2r[u].y; dst[2] = w2r[u].z; dst[3] = w2r[u].w;
-    }
-    lds_barrier();
-    // dH2 tile (H2 parked in the not-yet-used dh1 buffer for the column sums below)
-#pragma unroll
-    for (int u = 0; u < (kTM * kH2 / 4) / 256; ++u) {
-        const int e4 = threadIdx.x + 256 * u;
-        const int row = e4 / (kH2 / 4), n = 4 * (e4 % (kH2 / 4));
-        const int m = m0 + row;
-        const float hv[4] = {h2r[u].x, h2r[u].y, h2r[u].z, h2r[u].w};
-        float gv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gv[i] = hv[i] > 0.f ? dzs[row] * p.w3[n + i] : 0.f;
-            dh2[row * (kH2 + 1) + n + i] = gv[i];
-            dh1[row * (kH1 + 1) + n + i] = hv[i];
-        }
-        if (m < dm.B) *reinterpret_cast<float4*>(dH2 + (int64_t)m * kH2 + n) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-    }
-    lds_barrier();
-    if (threadIdx.x < kH2) {
-        const int n = threadIdx.x;
-        float sw = 0.f, sb = 0.f;
-        for (int row = 0; row < kTM; ++row) {
-            sw += dzs[row] * dh1[row * (kH1 + 1) + n];
-            sb += dh2[row * (kH2 + 1) + n];
-        }
-        prec[pl.dw3 + n] = sw;
-        prec[pl.db2 + n] = sb;
-    }
-    lds_barrier();
-    DT_STAMP(stamps, 1);
-
-    // dH1 = dH2 . W2^T  (wave w -> hidden units [32w, 32w+32))
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // ---- top of the backward: dH2 (C layout of GEMM2), its column sums, dH1 = relu'(dH2 . W2^T) ----
     {
-        const float* arow = dh2 + c * (kH2 + 1) + s;
-        const float* brow = w2s + (32 * wave + c) * (kH2 + 1) + s;
-        float aq[kH2 / 2], bq[kH2 / 2];
+        float sb = 0.f, sw = 0.f;
 #pragma unroll
-        for (int st = 0; st < kH2 / 2; ++st) { aq[st] = arow[2 * st]; bq[st] = brow[2 * st]; }
-        floatx16 accb;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < kH2 / 2; st += 2) {   // two accumulator chains (see k_mlp_fwd)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
-            accb = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], accb, 0, 0, 0);
+        for (int q = 0; q < 8; ++q) {
+            const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
+            const float dzv = dzs[row];
+            const float g = h2r[q] > 0.f ? dzv * w3v : 0.f;
+            dh2s[row * kH2S + 16 * wave + n16] = g;
+            sb += g;
+            sw += dzv * h2r[q];
         }
+        sb += __shfl_xor(sb, 16, 64); sw += __shfl_xor(sw, 16, 64);
+        sb += __shfl_xor(sb, 32, 64); sw += __shfl_xor(sw, 32, 64);
+        if (kq == 0) { prec[pl.db2 + 16 * wave + n16] = sb; prec[pl.dw3 + 16 * wave + n16] = sw; }
+    }
+    lds_barrier();
+    {
+        floatx4 a[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += accb[r];
+        for (int g = 0; g < 8; ++g) a[g] = ld4(dh2s + c * kH2S + 8 * g + 4 * s);
+        // dH2 leaves for HBM (k_wgrad3 reads it) as whole rows
+        floatx4 drow[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) drow[u] = ld4(dh2s + ((tid >> 4) + 16 * u) * kH2S + 4 * (tid & 15));
+        floatx16 da, db;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { da[r] = 0.f; db[r] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            da = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, w2tq[g].x, da, 0, 0, 0);
+            db = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, w2tq[g].y, db, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, w2tq[g].z, da, 0, 0, 0);
+            db = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, w2tq[g].w, db, 0, 0, 0);
+            if (g < 2) {
+                const int m = m0 + (tid >> 4) + 16 * g;
+                if (m < dm.B) st4(dH2 + (int64_t)m * kH2 + 4 * (tid & 15), drow[g]);
+            }
+        }
         float colsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            const int m = m0 + row;
-            const float g = h1v[r] > 0.f ? acc[r] : 0.f;
-            dh1[row * (kH1 + 1) + 32 * wave + c] = g;
-            if (m < dm.B) dH1[(int64_t)m * kH1 + 32 * wave + c] = g;
+            const float g = h1r[r] > 0.f ? da[r] + db[r] : 0.f;
+            h1s[row * HS + 32 * wave + c] = g;       // H1's LDS copy is dead: every read of it sits before the last barrier
             colsum += g;
         }
         colsum += __shfl_xor(colsum, 32, 64);
         if (s == 0) prec[pl.db1 + 32 * wave + c] = colsum;
     }
+    // d linear_logit kernel: sum_rows dz * X (raw) for this thread's 4 columns of every chunk, rows srow and srow+16;
+    // the 4 row groups of a wave meet by shuffles, the 4 waves in LDS (the Xn tile is dead)
+    {
+        const float dza = dzs[srow], dzb = dzs[srow + 16];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            floatx4 v = xv[j][0] * dza + xv[j][1] * dzb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                v[e] = t;
+            }
+            if (kq == 0) st4(xs + wave * CP + 64 * j + qcol, v);
+        }
+    }
     lds_barrier();
-    DT_STAMP(stamps, 2);
-
-    // dXn = dH1 . W1^T : column blocks of 32 (CP/32 of them), round-robin over the 4 waves
-    const float* arow = dh1 + c * (kH1 + 1) + s;
-    float aq[kH1 / 2];
 #pragma unroll
-    for (int st = 0; st < kH1 / 2; ++st) aq[st] = arow[2 * st];   // A operand is the same for every column block
-    // operands of column block nb: 64 W1T values + this lane's 16 X values; the next block's operands are
-    // issued before the current block's MFMA chain so HBM/L2 latency hides under 4096 MFMA cycles
-    float dzr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dzr[r] = dzs[(r & 3) + 8 * (r >> 2) + 4 * s];
-    auto run_nb = [&](const float (&bq)[kH1 / 2], const float (&xv)[16], const float (&mr)[2], int nb) {
-        const int col = 32 * nb + c;
-        floatx16 accb;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
-#pragma unroll
-        for (int st = 0; st < kH1 / 2; st += 2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st], bq[st], acc, 0, 0, 0);
-            accb = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st + 1], bq[st + 1], accb, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += accb[r];
-        float sg = 0.f, sgx = 0.f, sl = 0.f;
-        const float mu = mr[0], rs = mr[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * s;
-            const int m = m0 + row;
-            const float g = acc[r];                 // pad columns: W1T column is zero -> g = 0
-            if (m < dm.B) {
-                dXn[(int64_t)m * dm.CP + col] = g;
-                sg += g;
-                sgx += g * ((xv[r] - mu) * rs);
-                sl += dzr[r] * xv[r];
-            }
-        }
-        sg += __shfl_xor(sg, 32, 64);
-        sgx += __shfl_xor(sgx, 32, 64);
-        sl += __shfl_xor(sl, 32, 64);
-        if (s == 0) {
-            prec[pl.sg + col] = sg;
-            prec[pl.sgx + col] = sgx;
-            prec[pl.slin + col] = sl;
-        }
-    };
-    int nb = wave;
-    while (nb < nblocks) {
-        if (nb + 4 < nblocks) load_nb(bq1, xv1, mr1, nb + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        run_nb(bq0, xv0, mr0, nb);
-        __builtin_amdgcn_sched_barrier(0);
-        nb += 4;
-        if (nb >= nblocks) break;
-        if (nb + 4 < nblocks) load_nb(bq0, xv0, mr0, nb + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        run_nb(bq1, xv1, mr1, nb);
-        __builtin_amdgcn_sched_barrier(0);
-        nb += 4;
+    for (int u = 0; u < 4; ++u) {                    // dH1 leaves for HBM as whole rows
+        const int r = (tid >> 5) + 8 * u;
+        if (m0 + r < dm.B) st4(dH1 + (int64_t)(m0 + r) * kH1 + 4 * (tid & 31), ld4(h1s + r * HS + 4 * (tid & 31)));
     }
-    DT_STAMP(stamps, 3);
+    for (int col = tid; col < CP; col += 256)
+        prec[pl.slin + col] = (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]);
+    DT_STAMP(stamps, 8);
 }
 
-// ---------------------------------------------------------------------------------------------
-// E: weight gradients + reduction of the per-tile partial sums.
-//   blockIdx.x < ntiles: tile t < T1: dW1[32 cb.., 32 kb..] = sum_m Xn[m][c] dH1[m][k]
-//                        else        : dW2[32 kb.., 32 nb..] = sum_m H1[m][k] dH2[m][n]
-//     block = (tile, row split blockIdx.y); 4 waves take quarters of the split's rows, reduce via LDS.
-//   blockIdx.x >= ntiles (blockIdx.y == 0 only): one wave per reduced output element.
-// ---------------------------------------------------------------------------------------------
-// operand loads for one chunk of kCH MFMA steps: rows base + 2i (+ s folded into the lane offset).  The row
-// base is wave-uniform (SGPR) and the lane part constant, so every load is saddr + voffset with no 64-bit VALU.
-template <bool GUARD>
-__device__ __forceinline__ void wg_load(float (&aq)[kCH], float (&bq)[kCH], const float* pa, int sa, int offa,
-                                        const float* pb, int sb, int offb, int base, int s, int r_end) {
-#pragma unroll
-    for (int i = 0; i < kCH; ++i) {
-        const int row = base + 2 * i;                       // uniform
-        const float* ra = pa + (int64_t)row * sa;           // uniform pointer
-        const float* rb = pb + (int64_t)row * sb;
-        if (GUARD) {
-            const bool ok = row + s < r_end;
-            aq[i] = ok ? ra[offa] : 0.f;
-            bq[i] = ok ? rb[offb] : 0.f;
-        } else {
-            aq[i] = ra[offa];
-            bq[i] = rb[offb];
-        }
-    }
-}
+// E: weight gradients on 64x128 macro tiles = 2x4 MFMA tiles whose rows / columns INTERLEAVE (tile (t,u) holds outputs
+// (2i+t, 4j+u)), so ONE 8-byte load per lane feeds two tiles' worth of A and ONE 16-byte load four tiles' worth of B:
+// two loads per EIGHT MFMAs, issued between the MFMA groups two chunks ahead.
+//   macro a < CP/64 : M[64a .., :] = Xhat[:, 64a ..]^T dH1        (Xhat = (X - mean) rstd formed on the operand)
+//   macro CP/64     : dW2^T = dH2^T H1  (the same loop with A = dH2 [64 cols], B = H1 [128 cols]; E' transposes)
+// Each macro tile is split over `row_blocks` batch slices (blocks); a block's 4 waves take quarters of the slice and
+// meet in LDS; the block's partial tile goes to `wpart` [macro][slice][64*128] with plain coalesced stores and E'
+// adds the slices up — no atomics, no zero-fill, deterministic.  The first `nred_blocks` blocks reduce the per-tile
+// partial sums C left in `part` (a block owns 64 consecutive record entries).
+constexpr int kWgCh = 4;     // K steps (= 2 batch rows each) per operand chunk
 
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
-                                               const float* __restrict__ H1, const float* __restrict__ dH1,
-                                               const float* __restrict__ dH2, int row_splits, int ntiles,
-                                               const float* __restrict__ part, int nparts,
-                                               float* __restrict__ accum, DeepFmAccum al) {
-    __shared__ float red[4][32][33];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PartLayout pl = part_layout(dm.CP);
-    const int nheavy = ntiles * row_splits;     // 1-D grid: heavy (tile, split) blocks first, then reducers
-    if ((int)blockIdx.x >= nheavy) {
-        // ---- reduction of the per-tile partials: element id -> destination in accum ----
-        const int nsimple = 3 * dm.CP + kH1 + 2 * kH2 + 3;          // sg, sgx, slin, db1, db2, dw3, dwo, dbo, loss
-        const int e = ((int)blockIdx.x - nheavy) * 4 + wave;
-        if (e < nsimple) {
-            int src; int64_t dst;
-            if (e < dm.CP) { src = pl.sg + e; dst = al.dbeta + e; }
-            else if (e < 2 * dm.CP) { src = pl.sgx + (e - dm.CP); dst = al.dgamma + (e - dm.CP); }
-            else if (e < 3 * dm.CP) { src = pl.slin + (e - 2 * dm.CP); dst = al.slin + (e - 2 * dm.CP); }
-            else {
-                const int q = e - 3 * dm.CP;
-                if (q < kH1) { src = pl.db1 + q; dst = al.db1 + q; }
-                else if (q < kH1 + kH2) { src = pl.db2 + (q - kH1); dst = al.db2 + (q - kH1); }
-                else if (q < kH1 + 2 * kH2) { src = pl.dw3 + (q - kH1 - kH2); dst = al.dw3 + (q - kH1 - kH2); }
-                else if (q == kH1 + 2 * kH2) { src = pl.dwo; dst = al.dwo; }
-                else if (q == kH1 + 2 * kH2 + 1) { src = pl.dbo; dst = al.dbo; }
-                else { src = pl.loss; dst = al.loss; }
+__global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
+                                                const float* __restrict__ H1, const float* __restrict__ dH1,
+                                                const float* __restrict__ dH2, int nred_blocks, int row_blocks,
+                                                int rows_per_block, const float* __restrict__ part, int nparts,
+                                                float* __restrict__ accum, DeepFmAccum al, float* __restrict__ wpart,
+                                                unsigned long long* stamps_all) {
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128] (heavy) / [4][64] (reducers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Part3 pl = part3_layout(dm.CP);
+    if ((int)blockIdx.x < nred_blocks) {
+        // record entries in the order slin | db1 | db2 | dw3 | dwo | dbo | loss
+        const int e = (int)blockIdx.x * 64 + lane;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (e < pl.n) {
+            const float* src = part + e;
+            int t = wave;
+            for (; t + 12 < nparts; t += 16) {
+                v0 += src[(int64_t)t * pl.stride];
+                v1 += src[(int64_t)(t + 4) * pl.stride];
+                v2 += src[(int64_t)(t + 8) * pl.stride];
+                v3 += src[(int64_t)(t + 12) * pl.stride];
             }
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;   // 4 independent loads in flight per lane
-            int t = lane;
-            for (; t + 192 < nparts; t += 256) {
-                v0 += part[(int64_t)t * pl.stride + src];
-                v1 += part[(int64_t)(t + 64) * pl.stride + src];
-                v2 += part[(int64_t)(t + 128) * pl.stride + src];
-                v3 += part[(int64_t)(t + 192) * pl.stride + src];
-            }
-            for (; t < nparts; t += 64) v0 += part[(int64_t)t * pl.stride + src];
-            const float v = wave_sum((v0 + v1) + (v2 + v3));
-            if (lane == 0) accum[dst] = v;
+            for (; t < nparts; t += 4) v0 += src[(int64_t)t * pl.stride];
+        }
+        red[wave * 64 + lane] = (v0 + v1) + (v2 + v3);
+        __syncthreads();
+        if (wave == 0 && e < pl.n) {
+            const float v = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+            int64_t dst;
+            if (e < pl.db1) dst = al.slin + e;
+            else if (e < pl.db2) dst = al.db1 + (e - pl.db1);
+            else if (e < pl.dw3) dst = al.db2 + (e - pl.db2);
+            else if (e < pl.dwo) dst = al.dw3 + (e - pl.dw3);
+            else if (e == pl.dwo) dst = al.dwo;
+            else if (e == pl.dbo) dst = al.dbo;
+            else dst = al.loss;
+            accum[dst] = v;
         }
         return;
     }
     const int s = lane >> 5, c = lane & 31;
-    const int cblocks = (dm.C + 31) >> 5;
-    const int T1 = cblocks * (kH1 / 32);
-    // XCD-aware (tile, split) assignment: workgroups are dealt round-robin to the 8 XCDs (id % 8) and every XCD
-    // has its own 4 MB L2.  All tiles of one batch split read the same rows of X / dH1, so a split's tiles are
-    // given ids with the same id % 8: each L2 then holds 1/8 of X instead of thrashing through all of it.
-    int tile, split;
-    {
-        const int hid = blockIdx.x;                                // 0 .. ntiles*row_splits-1
-        if ((row_splits & 7) == 0) {
-            const int xcd = hid & 7, j = hid >> 3;
-            const int per = row_splits >> 3;                       // splits per XCD
-            tile = j % ntiles;
-            split = xcd * per + j / ntiles;
-        } else {
-            tile = hid % ntiles;
-            split = hid / ntiles;
-        }
-    }
-    const int rows_per_split = ((dm.B + row_splits - 1) / row_splits + 7) & ~7;
-    const int rq = rows_per_split >> 2;  // rows per wave (even)
-    const int r_begin = split * rows_per_split + wave * rq;
-    const int r_end = min(dm.B, r_begin + rq);
-
-    floatx16 acc, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    const bool first = tile < T1;
-    const float* pa; const float* pb; int sa, sb, offa, offb;
-    float mu = 0.f, sc = 1.f, be = 0.f;
-    if (first) {
-        const int cb = tile / (kH1 / 32), kb = tile % (kH1 / 32);
-        const int col = 32 * cb + c;           // < CP always (CP is a multiple of 64 >= C)
-        mu = p.mean[col]; sc = p.sc[col]; be = p.betap[col];
-        pa = X; sa = dm.CP; offa = s * dm.CP + col;
-        pb = dH1; sb = kH1; offb = s * kH1 + 32 * kb + c;
+    const int hid = (int)blockIdx.x - nred_blocks;      // nred_blocks is a multiple of 8: hid % 8 is still the XCD
+    unsigned long long* stamps = stamps_all ? stamps_all + (int64_t)(hid - (int)blockIdx.x) * 16 : nullptr;   // DT_STAMP adds blockIdx.x * 16
+    DT_STAMP(stamps, 0);
+    const int nmac1 = dm.CP >> 6, nmac = nmac1 + 1;
+    // XCD-aware (macro tile, slice) ids: all macro tiles of one batch slice read the same rows of X / dH1 / H1 / dH2,
+    // so a slice's blocks share id % 8 and each XCD's L2 holds 1/8 of those arrays
+    int mac, rb;
+    if ((row_blocks & 7) == 0) {
+        const int xcd = hid & 7, j = hid >> 3, per = row_blocks >> 3;
+        mac = j % nmac;
+        rb = xcd * per + j / nmac;
     } else {
-        const int t2 = tile - T1;
-        const int kb = t2 / (kH2 / 32), nb = t2 % (kH2 / 32);
-        pa = H1; sa = kH1; offa = s * kH1 + 32 * kb + c;
-        pb = dH2; sb = kH2; offb = s * kH2 + 32 * nb + c;
+        mac = hid % nmac;
+        rb = hid / nmac;
     }
+    const int rq = rows_per_block >> 2;                 // rows per wave (even)
+    const int r_begin = rb * rows_per_block + wave * rq;
+    const int r_end = min(dm.B, r_begin + rq);
+    const bool first = mac < nmac1;
+    const float* pa; const float* pb; int sa, sb;
+    floatx2 mu = {0.f, 0.f}, rs = {1.f, 1.f};
+    if (first) {
+        const int ca = 64 * mac + 2 * c;
+        pa = X + ca; sa = dm.CP; pb = dH1; sb = kH1;
+        mu = *reinterpret_cast<const floatx2*>(p.mean + ca);
+        rs = *reinterpret_cast<const floatx2*>(p.rstd + ca);
+    } else {
+        pa = dH2 + 2 * c; sa = kH2; pb = H1; sb = kH1;
+    }
+    pa += (int64_t)s * sa;
+    pb += (int64_t)s * sb + 4 * c;
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     {
-        float a0[kCH], b0[kCH], a1[kCH], b1[kCH], a2[kCH], b2[kCH];
-        const int span = 2 * kCH;                    // rows per chunk
-        const int nfull = (r_end - r_begin) / span;  // unguarded chunks
-        auto load = [&](float (&aq)[kCH], float (&bq)[kCH], int ch) {
-            wg_load<false>(aq, bq, pa, sa, offa, pb, sb, offb, r_begin + ch * span, s, r_end);
+        floatx2 aq[3][kWgCh];
+        floatx4 bq[3][kWgCh];
+        constexpr int span = 2 * kWgCh;                   // rows per chunk
+        const int nfull = max(0, r_end - r_begin) / span;
+        auto load1 = [&](int buf, int ch, int i) {
+            const int row = r_begin + ch * span + 2 * i;
+            aq[buf][i] = *reinterpret_cast<const floatx2*>(pa + (int64_t)row * sa);
+            bq[buf][i] = ld4(pb + (int64_t)row * sb);
         };
-        auto run = [&](const float (&aq)[kCH], const float (&bq)[kCH]) {
-            __builtin_amdgcn_sched_barrier(0);
+        auto step = [&](floatx2 av, floatx4 bv) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.z, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.w, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.z, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.w, acc[1][3], 0, 0, 0);
+        };
+        // chunk ch runs from buffer `buf` while chunk ch+2's loads are issued into buffer (buf + 2) % 3, one K step's
+        // pair of loads after each group of eight MFMAs
+        auto run = [&](int buf, int ch) {
+            const bool pre = ch + 2 < nfull;
 #pragma unroll
-            for (int i = 0; i < kCH; i += 2) {   // two accumulator chains (see k_mlp_fwd)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((aq[i] - mu) * sc + be, bq[i], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((aq[i + 1] - mu) * sc + be, bq[i + 1], acc2, 0, 0, 0);
+            for (int i = 0; i < kWgCh; ++i) {
+                step((aq[buf][i] - mu) * rs, bq[buf][i]);
+                if (pre) load1((buf + 2) % 3, ch + 2, i);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
-        if (nfull > 0) load(a0, b0, 0);
-        if (nfull > 1) load(a1, b1, 1);
-        for (int ch = 0; ch < nfull; ch += 3) {      // three operand buffers: see k_mlp_fwd
-            if (ch + 2 < nfull) load(a2, b2, ch + 2);
-            run(a0, b0);
+        if (nfull > 0) {
+#pragma unroll
+            for (int i = 0; i < kWgCh; ++i) load1(0, 0, i);
+        }
+        if (nfull > 1) {
+#pragma unroll
+            for (int i = 0; i < kWgCh; ++i) load1(1, 1, i);
+        }
+        DT_STAMP(stamps, 1);
+        for (int ch = 0; ch < nfull; ch += 3) {
+            run(0, ch);
+            if (ch == 0) DT_STAMP(stamps, 2);
             if (ch + 1 >= nfull) break;
-            if (ch + 3 < nfull) load(a0, b0, ch + 3);
-            run(a1, b1);
+            run(1, ch + 1);
             if (ch + 2 >= nfull) break;
-            if (ch + 4 < nfull) load(a1, b1, ch + 4);
-            run(a2, b2);
+            run(2, ch + 2);
         }
-        for (int base = r_begin + nfull * span; base < r_end; base += span) {   // ragged tail
-            wg_load<true>(a0, b0, pa, sa, offa, pb, sb, offb, base, s, r_end);
-#pragma unroll
-            for (int i = 0; i < kCH; ++i) {
-                const bool ok = base + 2 * i + s < r_end;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? (a0[i] - mu) * sc + be : 0.f, b0[i], acc, 0, 0, 0);
+        DT_STAMP(stamps, 3);
+        for (int base = r_begin + nfull * span; base < r_end; base += 2) {      // ragged tail, one K step at a time
+            floatx2 av = {0.f, 0.f};
+            floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (base + s < r_end) {
+                av = (*reinterpret_cast<const floatx2*>(pa + (int64_t)base * sa) - mu) * rs;
+                bv = ld4(pb + (int64_t)base * sb);
             }
+            step(av, bv);
         }
     }
+    // the four waves' partial macro tiles meet in LDS (four 32 KB slots): entry (2i+t)*128 + (4j+u)
+    auto put = [&](float* slot) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * s][c] = acc[r] + acc2[r];
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * s;
+                st4(slot + (2 * i + t) * 128 + 4 * c, floatx4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]});
+            }
+    };
+    put(red + wave * 8192);
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
-        const int i = e >> 5, j = e & 31;
-        const float v = (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]);
-        if (first) {
-            const int cb = tile / (kH1 / 32), kb = tile % (kH1 / 32);
-            const int col = 32 * cb + i;
-            if (col < dm.C) atomicAdd(accum + al.dW1 + (int64_t)col * kH1 + 32 * kb + j, v);
-        } else {
-            const int t2 = tile - T1;
-            const int kb = t2 / (kH2 / 32), nb = t2 % (kH2 / 32);
-            atomicAdd(accum + al.dW2 + (int64_t)(32 * kb + i) * kH2 + 32 * nb + j, v);
-        }
+    DT_STAMP(stamps, 4);
+    float* dst = wpart + ((int64_t)mac * row_blocks + rb) * 8192;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = 4 * (tid + 256 * u);
+        st4(dst + e, (ld4(red + e) + ld4(red + 8192 + e)) + (ld4(red + 16384 + e) + ld4(red + 24576 + e)));
     }
+    DT_STAMP(stamps, 5);
 }
 
-// ---------------------------------------------------------------------------------------------
-// G: sparse backward.  One wave per batch row, pure streaming (no atomics).
-//   dX[c]  = gamma rstd (dXn - mean_b(dXn) - xhat mean_b(dXn xhat))
-//   grad_rows[b,f,d] = dX[b,f*D+d] + dz[b] w_lin[f] + dz[b] (S[b,d] - E[b,f,d])
-// ---------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(256) void k_sparse_bwd(const float* __restrict__ X, const float* __restrict__ dXn,
-                                                    const float* __restrict__ dz, MlpParams p,
-                                                    const float* __restrict__ wlin, DeepFmDims dm,
-                                                    const float* accum, DeepFmAccum al,
-                                                    float* __restrict__ grad_rows, float* dwlin_out, DedupeWs dd,
-                                                    float grad_scale, int field_major) {
+// E': adds up the batch slices of E and finishes the BN / W1 gradients.  With M = Xhat^T dH1 and db1 = colsum(dH1):
+//   dgamma = sum_b dXn xhat = rowdot(W1, M)      dbeta = sum_b dXn = W1 . db1      dW1 = gamma M + beta (x) db1
+// (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
+// waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
+// d linear_logit kernel: field f = its D columns, dense k = one column.
+__global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, DeepFmDims dm, float* accum,
+                                                   DeepFmAccum al, const float* __restrict__ wpart, int row_blocks) {
+    __shared__ floatx2 sm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int NV = dm.F * LPR;
-    const int D = 4 * LPR;
-    const float invN = 1.0f / (float)dm.B;
-    if (blockIdx.x == 0) {   // d linear_logit kernel: field f = its D columns of the reduced slin, dense k = one column
+    if (blockIdx.x == 0) {
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
             float v = 0.f;
             if (q < dm.F) {
-                for (int d = 0; d < D; ++d) v += accum[al.slin + q * D + d];
+                for (int d = 0; d < dm.D; ++d) v += accum[al.slin + q * dm.D + d];
             } else {
-                v = accum[al.slin + dm.F * D + (q - dm.F)];
+                v = accum[al.slin + dm.F * dm.D + (q - dm.F)];
             }
-            dwlin_out[q] = v;
+            accum[al.dwlin + q] = v;
         }
     }
-    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= dm.B) return;
-    const float g = dz[b];
-    const float* xrow = X + (int64_t)b * dm.CP;
-    const float* grow = dXn + (int64_t)b * dm.CP;
-    float4 x[2], gx[2];
-    float4 ca[2], cm1[2], cmu[2], cm2[2];
-    float wl[2];
+    // one block per column (of X, then of dH2); its 4 waves add up every 4th batch slice with all loads in flight
+    const int col = blockIdx.x;
+    const bool w2 = col >= dm.C;
+    const int mac = w2 ? (dm.CP >> 6) : (col >> 6), row = w2 ? col - dm.C : (col & 63);
+    const float* src = wpart + (int64_t)mac * row_blocks * 8192 + row * 128 + 2 * lane;
+    floatx2 v[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int j = lane + 64 * t;
-        x[t] = gx[t] = ca[t] = cm1[t] = cmu[t] = cm2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        wl[t] = 0.f;
-        if (j < NV) {
-            x[t] = *reinterpret_cast<const float4*>(xrow + 4 * j);
-            gx[t] = *reinterpret_cast<const float4*>(grow + 4 * j);
-            const float4 sc = *reinterpret_cast<const float4*>(p.sc + 4 * j);        // gamma * rstd
-            const float4 r = *reinterpret_cast<const float4*>(p.rstd + 4 * j);
-            const float4 sg = *reinterpret_cast<const float4*>(accum + al.dbeta + 4 * j);
-            const float4 sgx = *reinterpret_cast<const float4*>(accum + al.dgamma + 4 * j);
-            ca[t] = sc;
-            cm1[t] = make_float4(sg.x * invN, sg.y * invN, sg.z * invN, sg.w * invN);
-            cm2[t] = make_float4(r.x * sgx.x * invN, r.y * sgx.y * invN, r.z * sgx.z * invN, r.w * sgx.w * invN);
-            cmu[t] = *reinterpret_cast<const float4*>(p.mean + 4 * j);
-            wl[t] = wlin[j / LPR];
+    for (int u = 0; u < 8; ++u) {
+        const int sl = wave + 4 * u;
+        v[u] = floatx2{0.f, 0.f};
+        if (sl < row_blocks) v[u] = *reinterpret_cast<const floatx2*>(src + (int64_t)sl * 8192);
+    }
+    floatx2 m = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int sl = wave + 32; sl < row_blocks; sl += 4) m += *reinterpret_cast<const floatx2*>(src + (int64_t)sl * 8192);
+    sm[wave][lane] = m;
+    __syncthreads();
+    if (wave != 0) return;
+    m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    if (w2) {       // row `row` of dW2^T: dW2[k][row] for k = 2 lane, 2 lane + 1
+        accum[al.dW2 + (int64_t)(2 * lane) * kH2 + row] = m.x;
+        accum[al.dW2 + (int64_t)(2 * lane + 1) * kH2 + row] = m.y;
+        return;
+    }
+    const floatx2 w = *reinterpret_cast<const floatx2*>(W1 + (int64_t)col * kH1 + 2 * lane);
+    const floatx2 d = *reinterpret_cast<const floatx2*>(accum + al.db1 + 2 * lane);
+    const float dg = wave_sum(w.x * m.x + w.y * m.y);
+    const float db = wave_sum(w.x * d.x + w.y * d.y);
+    const float ga = gamma[col], be = beta[col];
+    *reinterpret_cast<floatx2*>(accum + al.dW1 + (int64_t)col * kH1 + 2 * lane) =
+        floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
+    if (lane == 0) { accum[al.dgamma + col] = dg; accum[al.dbeta + col] = db; }
+}
+
+// D: dXn = dH1 . W1^T on 16x16x4 tiles, one 16-column block (x both 16-row halves, sharing the W1 operand) at a
+// time per wave, with everything kernel G of round 1 did as the epilogue:
+//   dX[c]  = gamma rstd (dXn - mean_b(dXn) - xhat mean_b(dXn xhat))
+//   grad_rows[b,f,d] = dX[b,f*D+d] + dz[b] w_lin[f] + dz[b] (S[b,d] - E[b,f,d])
+// Only the F*D embedding columns are computed (the dense inputs need no gradient).
+__global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__ X, const float* __restrict__ dH1,
+                                                       const float* __restrict__ dz, const float* __restrict__ S,
+                                                       MlpParams p, const float* __restrict__ wlin, DeepFmDims dm,
+                                                       const float* __restrict__ accum, DeepFmAccum al,
+                                                       float* __restrict__ grad_rows, DedupeWs dd, float grad_scale,
+                                                       int field_major, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    DT_STAMP(stamps, 0);
+    constexpr int HS = kH1 + kPad, NT = 512;
+    const int XS = dm.CP + kPad, FD = dm.F * dm.D;
+    const int FD16 = ((FD + 15) >> 4) << 4;
+    float* dh1s = lds;                    // [32][HS]
+    float* xs = dh1s + kTM * HS;          // [32][XS] raw X tile; every (row, col) is replaced by its gradient in place
+    float* Ss = xs + kTM * XS;            // [32][D]  S[b][d] = sum_f E[b,f,d]
+    float* cv = Ss + kTM * dm.D;          // [4][FD16]: gamma*rstd | mean | mean_b(dXn) | rstd mean_b(dXn xhat)
+    float* dzs = cv + 4 * FD16;
+    float* wls = dzs + kTM;                              // [F] linear_logit kernel rows of the fields
+    int* marks = reinterpret_cast<int*>(wls + ((dm.F + 3) & ~3));   // [32][F] (dedupe only)
+    int* flg = marks + kTM * dm.F;                       // [32][F]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves: two per SIMD
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * kTM;
+    const int nblk = FD16 >> 4;
+    const float invN = 1.0f / (float)dm.B;
+    int dshift = 0;
+    while ((1 << dshift) < dm.D) ++dshift;               // D is a power of two (4 * LPR)
+
+    // ---- staging.  No loaded value is touched before it is needed (a select on it would drain the queue there):
+    //      addresses are clamped instead, the workspace rows of a ragged last tile are zero (host memset) ----
+    floatx4 hv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) hv[u] = ld4(dH1 + (int64_t)(m0 + (tid >> 5) + 16 * u) * kH1 + 4 * (tid & 31));
+    floatx4 bW[2][8];
+    auto w1ptr = [&](int blk) {          // row `col` of W1, this lane's 4 k of every 16; columns beyond C are never stored
+        const int col = min(16 * blk + n16, dm.C - 1);
+        return p.W1 + (int64_t)col * kH1 + 4 * kq;
+    };
+    if (wave < nblk) {
+        const float* wrow = w1ptr(wave);
+#pragma unroll
+        for (int G = 0; G < 8; ++G) bW[0][G] = ld4(wrow + 16 * G);
+    }
+    const int q4 = dm.CP >> 2, total = kTM * q4;                  // float4 of the X tile, <= 9 per thread
+    floatx4 xv[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        const int e = min(tid + NT * u, total - 1);
+        const int r = e / q4, q = e - r * q4;
+        if (NT * u < total) xv[u] = ld4(X + (int64_t)(m0 + r) * dm.CP + 4 * q);
+    }
+    float cvv[4][2];                                              // FD16 <= 544: two columns per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = tid + NT * i;
+        if (col < FD) {                  // waves that own no column skip the loads altogether
+            cvv[0][i] = p.sc[col];
+            cvv[1][i] = p.mean[col];
+            cvv[2][i] = accum[al.dbeta + col];
+            cvv[3][i] = p.rstd[col] * accum[al.dgamma + col];
         }
     }
-    float4 S = make_float4(x[0].x + x[1].x, x[0].y + x[1].y, x[0].z + x[1].z, x[0].w + x[1].w);
-    S.x = wave_sum_strided<LPR>(S.x); S.y = wave_sum_strided<LPR>(S.y);
-    S.z = wave_sum_strided<LPR>(S.z); S.w = wave_sum_strided<LPR>(S.w);
+    float dzv = 0.f, wlv = 0.f;
+    if (tid < kTM) dzv = dz[min(m0 + tid, dm.B - 1)];
+    if (tid >= 64 && tid < 64 + dm.F) wlv = wlin[tid - 64];
+    floatx4 sv = {0.f, 0.f, 0.f, 0.f};
+    const int s4n = kTM * dm.D / 4;                               // float4 of the S tile (<= 512: D <= 64)
+    if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
+    int mkv[2], flv[2];
+    if (dd.slots) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int j = lane + 64 * t;
-        if (j >= NV) continue;
-        const float lin_g = g * wl[t];
-        float4 o;
-        o.x = ca[t].x * (gx[t].x - cm1[t].x - (x[t].x - cmu[t].x) * cm2[t].x) + lin_g + g * (S.x - x[t].x);
-        o.y = ca[t].y * (gx[t].y - cm1[t].y - (x[t].y - cmu[t].y) * cm2[t].y) + lin_g + g * (S.y - x[t].y);
-        o.z = ca[t].z * (gx[t].z - cm1[t].z - (x[t].z - cmu[t].z) * cm2[t].z) + lin_g + g * (S.z - x[t].z);
-        o.w = ca[t].w * (gx[t].w - cm1[t].w - (x[t].w - cmu[t].w) * cm2[t].w) + lin_g + g * (S.w - x[t].w);
-        const int f = j / LPR, c = j - f * LPR;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t occ = min((int64_t)m0 * dm.F + tid + NT * u, (int64_t)dm.B * dm.F - 1);
+            mkv[u] = dd.mark[occ];
+            flv[u] = dd.flags[occ];
+        }
+    }
+    DT_STAMP(stamps, 6);
+    // dH1 (the A operand) first: the MFMAs of every wave's first block start as soon as it is in LDS; X and the
+    // per-column / per-row constants (needed by the epilogues only) land behind those MFMAs
+#pragma unroll
+    for (int u = 0; u < 2; ++u) st4(dh1s + ((tid >> 5) + 16 * u) * HS + 4 * (tid & 31), hv[u]);
+    lds_barrier();
+    DT_STAMP(stamps, 7);
+    floatx4 aA[2][8];
+#pragma unroll
+    for (int G = 0; G < 8; ++G) {
+        aA[0][G] = ld4(dh1s + n16 * HS + 16 * G + 4 * kq);
+        aA[1][G] = ld4(dh1s + (16 + n16) * HS + 16 * G + 4 * kq);
+    }
+    DT_STAMP(stamps, 1);
+    float dzr[8];
+    auto stage_rest = [&]() {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int e = tid + NT * u;
+            const int r = e / q4, q = e - r * q4;
+            if (e < total) st4(xs + r * XS + 4 * q, xv[u]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = tid + NT * i;
+            if (col < FD16) {
+                const bool ok = col < FD;
+                cv[col] = ok ? cvv[0][i] : 0.f;
+                cv[FD16 + col] = ok ? cvv[1][i] : 0.f;
+                cv[2 * FD16 + col] = ok ? cvv[2][i] * invN : 0.f;
+                cv[3 * FD16 + col] = ok ? cvv[3][i] * invN : 0.f;
+            }
+        }
+        if (tid < kTM) dzs[tid] = m0 + tid < dm.B ? dzv : 0.f;
+        if (tid >= 64 && tid < 64 + dm.F) wls[tid - 64] = wlv;
+        if (tid < s4n) st4(Ss + 4 * tid, sv);
+        if (dd.slots) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + NT * u;
+                if (e < kTM * dm.F) { marks[e] = mkv[u]; flg[e] = flv[u]; }
+            }
+        }
+    };
+
+    auto mm = [&](int buf, int blk, bool more, floatx4& c0, floatx4& c1) {
+        c0 = floatx4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+        const float* wnext = w1ptr(blk + 8);
+#pragma unroll
+        for (int G = 0; G < 8; ++G) {
+            const floatx4 b = bW[buf][G];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].x, b.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].x, b.x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].y, b.y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].y, b.y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].z, b.z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].z, b.z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].w, b.w, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].w, b.w, c1, 0, 0, 0);
+            if (more) bW[buf ^ 1][G] = ld4(wnext + 16 * G);       // the next block's W1 operand, one load per 8 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (blk < 8) DT_STAMP(stamps, 4);
+    };
+    // epilogue: BN backward + FM / linear terms; the row gradient replaces X[row][col] in LDS
+    auto epi = [&](int blk, const floatx4& c0, const floatx4& c1) {
+        const int col = 16 * blk + n16;
+        if (col < FD) {
+            const int f = col >> dshift, d = col & (dm.D - 1);
+            const float ca = cv[col], cmu = cv[FD16 + col], cm1 = cv[2 * FD16 + col], cm2 = cv[3 * FD16 + col];
+            const float wl = wls[f];
+            float xr[8], sr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
+                xr[q] = xs[row * XS + col];
+                sr[q] = Ss[(row << dshift) + d];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
+                const float gx = (q >> 2) ? c1[q & 3] : c0[q & 3];
+                xs[row * XS + col] = ca * (gx - cm1 - (xr[q] - cmu) * cm2) + dzr[q] * wl + dzr[q] * (sr[q] - xr[q]);
+            }
+        }
+        if (blk < 8) DT_STAMP(stamps, 5);
+    };
+    // buffer ids are literals: the operand arrays stay in registers
+    floatx4 c0, c1;
+    if (wave < nblk) mm(0, wave, wave + 8 < nblk, c0, c1);
+    stage_rest();
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dzr[q] = dzs[16 * (q >> 2) + 4 * kq + (q & 3)];
+    if (wave < nblk) epi(wave, c0, c1);
+    if (wave + 8 < nblk) { mm(1, wave + 8, wave + 16 < nblk, c0, c1); epi(wave + 8, c0, c1); }
+    if (wave + 16 < nblk) { mm(0, wave + 16, wave + 24 < nblk, c0, c1); epi(wave + 16, c0, c1); }
+    if (wave + 24 < nblk) { mm(1, wave + 24, wave + 32 < nblk, c0, c1); epi(wave + 24, c0, c1); }
+    if (wave + 32 < nblk) { mm(0, wave + 32, false, c0, c1); epi(wave + 32, c0, c1); }        // nblk <= 34 (C <= 544)
+    __syncthreads();
+    DT_STAMP(stamps, 8);
+
+    // ---- the tile's row gradients leave as whole rows (16-byte lanes); duplicates of the step's row dedupe add
+    //      into their owner's row, owners clear their hash slot and flag ----
+    const int fq = FD >> 2;                                       // float4 per row
+    float* tile_rows = grad_rows + (int64_t)m0 * FD;
+    for (int e = tid; e < kTM * fq; e += NT) {
+        const int row = e / fq, q = e - row * fq;
+        const int b = m0 + row;
+        if (b >= dm.B) continue;
+        const int col = 4 * q, f = col >> dshift, d = col & (dm.D - 1);
+        floatx4 o = ld4(xs + row * XS + col);
         if (field_major) {       // model-parallel tables: [F,B,D], already divided by the world size
-            o.x *= grad_scale; o.y *= grad_scale; o.z *= grad_scale; o.w *= grad_scale;
-            *reinterpret_cast<float4*>(grad_rows + ((int64_t)f * dm.B + b) * D + 4 * c) = o;
+            st4(grad_rows + (((int64_t)f * dm.B + b) << dshift) + d, o * grad_scale);
             continue;
         }
-        if (!dd.slots) {
-            *reinterpret_cast<float4*>(grad_rows + (int64_t)b * dm.F * D + 4 * j) = o;
-            continue;
-        }
-        const int64_t occ = (int64_t)b * dm.F + f;
-        const int mk = dd.mark[occ];
-        int64_t target = occ;
+        float* dst = tile_rows + row * FD + col;
         bool atomic = false;
-        if (mk >= 0) {                       // owner
-            atomic = dd.flags[occ] != 0;
-            if (c == 0) {
-                dd.slots[mk] = 0ULL;
-                if (atomic) dd.flags[occ] = 0;
+        if (dd.slots) {
+            const int mk = marks[row * dm.F + f];
+            if (mk >= 0) {                       // owner
+                atomic = flg[row * dm.F + f] != 0;
+                if (d == 0) {
+                    dd.slots[mk] = 0ULL;
+                    if (atomic) dd.flags[(int64_t)b * dm.F + f] = 0;
+                }
+            } else if (mk <= -2) {               // duplicate: into the owner's (zero-started) row
+                dst = grad_rows + (((int64_t)(-mk - 2)) << dshift) + d;
+                atomic = true;
             }
-        } else if (mk <= -2) {               // duplicate: into the owner's (zero-started) row
-            target = (int64_t)(-mk - 2);
-            atomic = true;
         }
-        float* dst = grad_rows + target * D + 4 * c;
         if (atomic) {
             atomicAdd(dst, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
         } else {
-            *reinterpret_cast<float4*>(dst) = o;
+            st4(dst, o);
         }
     }
+    DT_STAMP(stamps, 3);
 }
 
 }  // namespace dt
@@ -1012,7 +1136,7 @@ static bool deepfm_dims(int B, int F, int D, int Nd, DeepFmDims* dm, int* lpr) {
     dm->B = B; dm->F = F; dm->D = D; dm->Nd = Nd;
     dm->C = F * D + Nd;
     dm->CP = (dm->C + 63) & ~63;
-    if (dm->C > 544) return false;
+    if (dm->C > 544 || D > 64) return false;
     *lpr = l;
     return true;
 }
@@ -1024,7 +1148,7 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 
 // workspace layout (floats)
 struct DeepFmWs {
-    int64_t X, dXn, H1, dH1, H2, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1P, W1T, bnp, bn2, part, stamps, total;
+    int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, total;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     DeepFmWs w;
@@ -1034,19 +1158,20 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     const int tiles = ceil_div(dm.B, kTM);
     const int64_t rows = (int64_t)tiles * kTM;
     w.X = take(rows * dm.CP);
-    w.dXn = take(rows * dm.CP);
     w.H1 = take(rows * kH1);
     w.dH1 = take(rows * kH1);
-    w.H2 = take(rows * kH2);
     w.dH2 = take(rows * kH2);
     w.lin = take(rows); w.fm = take(rows); w.z = take(rows); w.dz = take(rows); w.dlogit = take(rows);
     w.mean = take(dm.CP); w.rstd = take(dm.CP); w.sc = take(dm.CP); w.betap = take(dm.CP);
-    w.W1P = take((int64_t)dm.CP * kH1);
-    w.W1T = take((int64_t)kH1 * dm.CP);
+    w.W1L = take((int64_t)dm.CP * kH1);
+    w.W2L = take((int64_t)kH1 * kH2);
+    w.W2TL = take((int64_t)kH1 * kH2);
+    w.S = take(rows * dm.D);                        // S[b][d] = sum_f E[b,f,d] (kernel A -> kernel D)
+    w.wpart = take((int64_t)256 * 8192);            // k_wgrad4's per-slice partial macro tiles (<= 256 heavy blocks)
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
     w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
-    w.part = take((int64_t)tiles * part_layout(dm.CP).stride);
-    w.stamps = take((int64_t)2 * tiles * 8 * 2);   // u64 [2 kernels][tiles][8]
+    w.part = take((int64_t)tiles * part3_layout(dm.CP).stride);
+    w.stamps = take((int64_t)3 * tiles * 16 * 2);   // u64 [3 kernels][tiles][16]
     w.total = o;
     return w;
 }
@@ -1109,14 +1234,16 @@ extern "C" int dt_deepfm_train_step(
     const DeepFmWs wl = deepfm_ws_layout(dm);
     const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd);
     float* ws = reinterpret_cast<float*>(workspace);
-    MlpParams mp{ws + wl.W1P, b1, W2, b2, w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc,
-                 ws + wl.betap};
+    MlpParams mp{b1, W2, b2, w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
+                 W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL};
+    DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)w3 | (uintptr_t)accum) % 16 == 0,
+               "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int blocksA = ceil_div(B, kRowsPerBlockA);
     const int tiles = ceil_div(B, kTM);
     DedupeWs dd{nullptr, 0, nullptr, nullptr};
     DT_REQUIRE(!(dedupe_ws && grad_rows_field_major), "dt_deepfm_train_step: dedupe and field-major row gradients "
                                                       "are mutually exclusive");
-    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach G, which empties the hash again
+    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach D, which empties the hash again
         int lg = 0;
         while ((1LL << lg) < dedupe_slots) ++lg;
         DT_REQUIRE((1LL << lg) == dedupe_slots && dedupe_slots >= 2LL * B * F && lg <= 31 &&
@@ -1127,77 +1254,81 @@ extern "C" int dt_deepfm_train_step(
         dd.mark = reinterpret_cast<int*>(dd.slots + dedupe_slots);
         dd.flags = dd.mark + (int64_t)B * F;
     }
+    if (B % kTM) {       // ragged last tile: its workspace rows beyond B are read (unmasked) by the tile kernels -> keep them zero
+        const int64_t pad = (int64_t)tiles * kTM - B;
+        hipMemsetAsync(ws + wl.X + (int64_t)B * dm.CP, 0, (size_t)pad * dm.CP * sizeof(float), st);
+        hipMemsetAsync(ws + wl.dH1 + (int64_t)B * kH1, 0, (size_t)pad * kH1 * sizeof(float), st);
+    }
     static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
+    unsigned long long* stamps = stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
 
-    // A  (DT_A_DYNLDS: experiment knob — extra dynamic LDS caps residency to one 1024-thread block per CU)
-    static const size_t a_dyn_lds = getenv("DT_A_DYNLDS") ? (size_t)atoi(getenv("DT_A_DYNLDS")) : 0;
+    // A
 #define DT_A(KIND, L)                                                                                        \
-    hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), a_dyn_lds, st, idx, (const float4*)table,  \
+    hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), 0, st, idx, (const float4*)table, \
                        row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, rows_out,    \
-                       oob_count, ws + wl.bnp, dd, grad_rows)
+                       oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
         case 4: DT_A(KIND, 4); break; case 8: DT_A(KIND, 8); break;                   \
-        case 16: DT_A(KIND, 16); break; case 32: DT_A(KIND, 32); break;               \
-        default: DT_A(KIND, 64); break;                                               \
+        default: DT_A(KIND, 16); break;                                               \
     }
     if (idx_kind == DT_IDX_F32) { DT_A_L(DT_IDX_F32) } else { DT_A_L(DT_IDX_I32) }
 #undef DT_A_L
 #undef DT_A
     // B
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
-    PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.W1P, ws + wl.W1T, ws + wl.bn2};
+    PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
+               ws + wl.W2TL, W2};
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56), dim3(1024), 0, st, ws + wl.bnp, blocksA, dm, bn_eps, bn_momentum,
-                       bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, accum + al.dW1,
-                       (int)(al.db1 - al.dW1));
+                       bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks);
     hipLaunchKernelGGL(k_bn_final, dim3(ceil_div(dm.CP, 256)), dim3(256), 0, st, dm, bn_eps, bn_momentum, bn_gamma,
                        bn_beta, bn_moving_mean, bn_moving_var, po);
-    // C
-    const size_t ldsC = ((size_t)kTM * (dm.CP + 1) + kTM * (kH1 + 1) + 3 * kTM * (kH2 + 1)) * sizeof(float);
-    hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC);
-    hipLaunchKernelGGL(k_mlp_fwd, dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin, ws + wl.fm, y,
-                       ws + wl.H1, ws + wl.H2, ws + wl.z, logit_out, ws + wl.dlogit, ws + wl.part,
-                       stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr);
-    // D (forward-only calls still need the loss reduced: E runs with zero tiles below)
-    const int ntiles_w = ((dm.C + 31) >> 5) * (kH1 / 32) + (kH1 / 32) * (kH2 / 32);
-    const PartLayout pl = part_layout(dm.CP);
-    const int nred = 3 * dm.CP + kH1 + 2 * kH2 + 3;
-    const int red_blocks = ceil_div(nred, 4);
-    (void)pl;
-    if (phases >= 2) {
-        const size_t ldsD = ((size_t)kH1 * (kH2 + 1) + kTM * (kH2 + 1) + kTM * (kH1 + 1) + kTM) * sizeof(float);
-        hipFuncSetAttribute((const void*)k_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
-        hipLaunchKernelGGL(k_mlp_bwd, dim3(tiles), dim3(256), ldsD, st, ws + wl.X, mp, ws + wl.W1T, dm, ws + wl.H1,
-                           ws + wl.H2, ws + wl.z, ws + wl.dlogit, ws + wl.dH1, ws + wl.dH2, ws + wl.dXn,
-                           ws + wl.dz, ws + wl.part,
-                           stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) + (int64_t)tiles * 8 : nullptr);
-        // E
-        // 2 blocks (8 waves) per CU: two waves per SIMD so one wave's operand waits hide under the other's MFMAs.
-        // 512 blocks = exactly one residency round at that occupancy (250 registers per lane): 8 batch splits
-        // measured 21.2 us against 23.0 (16 splits, two rounds), 24.9 (4) and 25.4 (32)
-        int splits = 512 / ntiles_w;
-        if (splits < 1) splits = 1;
-        if (splits > 32) splits = 32;
-        while (splits > 1 && (B + splits - 1) / splits < 128) splits >>= 1;
-        static const int splits_env = getenv("DT_WGRAD_SPLITS") ? atoi(getenv("DT_WGRAD_SPLITS")) : 0;   // experiment knob
-        if (splits_env > 0) splits = splits_env;
-        hipLaunchKernelGGL(k_wgrad, dim3(ntiles_w * splits + red_blocks), dim3(256), 0, st, ws + wl.X, mp, dm,
-                           ws + wl.H1, ws + wl.dH1, ws + wl.dH2, splits, ntiles_w, ws + wl.part, tiles, accum, al);
-        // G
-        const int gblocks = ceil_div(B, 4);
-#define DT_G(L)                                                                                              \
-    case L:                                                                                                  \
-        hipLaunchKernelGGL((k_sparse_bwd<L>), dim3(gblocks), dim3(256), 0, st, ws + wl.X, ws + wl.dXn,       \
-                           ws + wl.dz, mp, w_lin, dm, accum, al, grad_rows, accum + al.dwlin, dd, grad_rows_scale,            \
-                           grad_rows_field_major);                                                           \
+    // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
+    {
+        const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 3 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM) * sizeof(float);
+#define DT_C(N)                                                                                                     \
+    case N:                                                                                                         \
+        hipFuncSetAttribute((const void*)k_mlp_fwd3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC);     \
+        hipLaunchKernelGGL(k_mlp_fwd3<N>, dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin,         \
+                           ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,               \
+                           ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps);                                       \
         break;
-        switch (lpr) { DT_G(1) DT_G(2) DT_G(4) DT_G(8) DT_G(16) DT_G(32) DT_G(64) }
-#undef DT_G
+        switch (dm.CP >> 6) { DT_C(1) DT_C(2) DT_C(3) DT_C(4) DT_C(5) DT_C(6) DT_C(7) DT_C(8) DT_C(9) }
+#undef DT_C
+    }
+    const Part3 pl3 = part3_layout(dm.CP);
+    const int nred3 = (ceil_div(pl3.n, 64) + 7) & ~7;        // k_wgrad4 reducer blocks (a multiple of 8, see the kernel)
+    if (phases >= 2) {
+        // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
+        const int nmac = (dm.CP >> 6) + 1;
+        int row_blocks = 256 / nmac;
+        if (row_blocks >= 8) row_blocks &= ~7;
+        while (row_blocks > 1 && (B + row_blocks - 1) / row_blocks < 64) row_blocks >>= 1;
+        if (row_blocks < 1) row_blocks = 1;
+        static const int rb_env = getenv("DT_WGRAD_ROWBLOCKS") ? atoi(getenv("DT_WGRAD_ROWBLOCKS")) : 0;   // experiment knob
+        if (rb_env > 0 && rb_env * nmac <= 256) row_blocks = rb_env;
+        const int rows_per_block = ((B + row_blocks - 1) / row_blocks + 7) & ~7;
+        const size_t ldsE = (size_t)4 * 8192 * sizeof(float);
+        hipFuncSetAttribute((const void*)k_wgrad4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
+        hipLaunchKernelGGL(k_wgrad4, dim3(nred3 + nmac * row_blocks), dim3(256), ldsE, st, ws + wl.X, mp, dm,
+                           ws + wl.H1, ws + wl.dH1, ws + wl.dH2, nred3, row_blocks, rows_per_block, ws + wl.part,
+                           tiles, accum, al, ws + wl.wpart, stamps ? stamps + (int64_t)tiles * 32 : nullptr);
+        // E'
+        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
+                           accum, al, ws + wl.wpart, row_blocks);
+        // D
+        const int FD16 = ((F * D + 15) >> 4) << 4;
+        const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM +
+                             ((F + 3) & ~3) + 2 * kTM * F) * sizeof(float);
+        hipFuncSetAttribute((const void*)k_dx_sparse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
+        hipLaunchKernelGGL(k_dx_sparse_bwd, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz, ws + wl.S,
+                           mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
+                           stamps ? stamps + (int64_t)tiles * 16 : nullptr);
     } else {
-        // forward only: reduce just the loss (the other partial slots are stale and ignored by the caller)
-        hipLaunchKernelGGL(k_wgrad, dim3(red_blocks), dim3(256), 0, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
-                           ws + wl.dH2, 1, 0, ws + wl.part, tiles, accum, al);
+        // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
+        hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
+                           ws + wl.dH2, nred3, 1, 8, ws + wl.part, tiles, accum, al, ws + wl.wpart, nullptr);
     }
     return launch_status("dt_deepfm_train_step");
 }

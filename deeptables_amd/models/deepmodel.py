@@ -293,7 +293,10 @@ class DeepModel:
             n = len(X)
             n_val = int(math.ceil(n * validation_split)) if validation_split else 0
             if n_val > 0:
-                perm = np.random.permutation(n)
+                # under a distribute strategy every rank must hold out the SAME rows (one partition, then sharded)
+                st_ = self.config.distribute_strategy
+                perm = st_.shared_permutation(n) if (st_ is not None and hasattr(st_, 'shared_permutation')) \
+                    else np.random.permutation(n)
                 val_i, tr_i = perm[:n_val], perm[n_val:]
                 take = (lambda a, i: a.iloc[i]) if hasattr(X, 'iloc') else (lambda a, i: a[i])
                 X_val, y_val = take(X, val_i), np.asarray(y)[val_i]

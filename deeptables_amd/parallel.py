@@ -54,10 +54,26 @@ class DataParallelStrategy:
 
     # -- data ------------------------------------------------------------------------------------
     def shard(self, X, y):
-        """AutoShardPolicy.DATA: rank r keeps rows r, r+W, r+2W, ... (deepmodel.py:92-95)."""
-        idx = np.arange(self.rank, len(X), self.world_size)
+        """AutoShardPolicy.DATA: rank r keeps rows r, r+W, r+2W, ... (deepmodel.py:92-95), truncated to the SAME
+        length on every rank (floor(n / W) rows): every train step issues collectives, so ranks must agree on the
+        number of steps per epoch — tf.distribute gives the reference consistent step counts the same way."""
+        per = len(X) // self.world_size
+        idx = np.arange(self.rank, len(X), self.world_size)[:per]
         Xs = X.iloc[idx] if hasattr(X, 'iloc') else X[idx]
         return Xs, (None if y is None else np.asarray(y)[idx])
+
+    def shared_permutation(self, n):
+        """A permutation of range(n) that is identical on every rank (drawn on rank 0, broadcast): the train /
+        validation split must be ONE partition of the frame, taken before the rows are dealt to the ranks."""
+        perm = torch.from_numpy(np.random.permutation(n).astype(np.int64))
+        if self.world_size > 1:
+            if self.device is not None and getattr(self.device, 'type', 'cpu') == 'cuda':
+                t = perm.to(self.device)
+                dist.broadcast(t, src=0, group=self.group)
+                perm = t.cpu()
+            else:
+                dist.broadcast(perm, src=0, group=self.group)
+        return perm.numpy()
 
     # -- parameters --------------------------------------------------------------------------------
     def broadcast_parameters(self, model):

@@ -32,6 +32,17 @@ def _worker(rank, world, port, q):
     X = np.arange(10).reshape(10, 1)
     Xs, ys = st.shard(X, np.arange(10))
     assert list(Xs[:, 0]) == list(range(rank, 10, world)) and list(ys) == list(range(rank, 10, world))
+    # uneven frames are truncated to the same length on every rank (a rank with one more step would hang in its
+    # collectives): 11 rows over 2 ranks -> 5 each
+    X11 = np.arange(11).reshape(11, 1)
+    Xo, yo = st.shard(X11, np.arange(11))
+    assert len(Xo) == 11 // world and list(Xo[:, 0]) == list(range(rank, 11, world))[:11 // world] and len(yo) == len(Xo)
+    # the validation split is ONE partition of the frame on all ranks
+    np.random.seed(100 + rank)                       # ranks deliberately disagree on their local RNG
+    perm = st.shared_permutation(37)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, perm.tolist())
+    assert all(g == gathered[0] for g in gathered) and sorted(gathered[0]) == list(range(37))
 
     # --- parameters are broadcast from rank 0 ---
     lin = torch.nn.Linear(4, 3)

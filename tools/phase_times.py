@@ -17,12 +17,22 @@ plan = dm.fused_plan()
 ws = plan._bufs[8192]['ws']
 off = lib().dt_deepfm_stamps_offset_floats(8192, plan.F, plan.D, plan.Nd)
 tiles = 256
-raw = ws[off: off + 2 * tiles * 8 * 2].cpu().numpy().view(np.uint64).reshape(2, tiles, 8).astype(np.float64)
-names = [['start', 'staged', 'gemm1', 'h1 stored', 'gemm2+h2', 'end'], ['start', 'prologue', 'dH1', 'end(dXn)']]
-for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd']):
-    st = raw[k][:, :len(names[k])]
-    d = np.diff(st, axis=1)
-    print(kn, 'phase cycles (mean over blocks, s_memtime ticks @100MHz => x10 ns):')
-    for j in range(d.shape[1]):
-        print(f'   {names[k][j]:>10s} -> {names[k][j+1]:<10s} mean {d[:, j].mean():9.0f}  min {d[:, j].min():9.0f}  max {d[:, j].max():9.0f}')
-    print('   total', (st[:, -1] - st[:, 0]).mean(), ' span over blocks', st[:, -1].max() - st[:, 0].min())
+raw = ws[off: off + 3 * tiles * 16 * 2].cpu().numpy().view(np.uint64).reshape(3, tiles, 16).astype(np.float64)
+v1 = 'DT_DEEPFM_V1' in os.environ
+labels = [{0: 'entry', 1: 'staged', 2: 'gemm1', 3: 'h1 stored', 4: 'gemm2+h2', 5: 'end'},
+          {0: 'entry', 1: 'prologue', 2: 'dH1', 3: 'end(dXn)'}] if v1 else \
+    [{0: 'entry', 6: 'prologue loads issued', 7: 'bn params in LDS', 1: 'chunk0 staged', 2: 'gemm1 done',
+      3: 'h1 in LDS', 4: 'gemm2 + partial logits', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)'},
+     {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'},
+     {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)'}]
+for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad'])):
+    st = raw[k]
+    rel = st - st[:, :1]
+    order = sorted(labels[k], key=lambda sl: rel[:, sl].mean())
+    print(kn, 'stamps of wave 0 (shader cycles since entry; mean / min / max over the 256 blocks, and the step from the previous stamp):')
+    prev = 0.0
+    for sl in order:
+        m = rel[:, sl].mean()
+        print(f'   {labels[k][sl]:>22s}  {m:9.0f}  {rel[:, sl].min():9.0f}  {rel[:, sl].max():9.0f}   +{m - prev:8.0f}')
+        prev = m
+    print('   entry skew over blocks (cycles):', st[:, 0].max() - st[:, 0].min())
