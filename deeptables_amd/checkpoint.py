@@ -68,6 +68,15 @@ def named_weights(model):
     return out
 
 
+def _slot_piece(slot, off, t):
+    """the part of an optimizer slot that belongs to variable `t`, which starts `off` elements into the parameter the
+    slot mirrors — as a VIEW (slots of packed tables can be row-strided, so no reshape(-1) which would copy)"""
+    if slot.dim() == 2 and t.dim() == 2 and off % slot.shape[1] == 0 and t.shape[1] == slot.shape[1]:
+        r0 = off // slot.shape[1]
+        return slot[r0:r0 + t.shape[0]]
+    return slot.reshape(-1)[off:off + t.numel()].reshape(t.shape)
+
+
 def save_model(model, path, optimizer=None, metadata=None):
     """Write `path` (safetensors).  optimizer: a KerasAdam whose m/v slots are stored next to the weights."""
     from safetensors.torch import save_file
@@ -89,9 +98,8 @@ def save_model(model, path, optimizer=None, metadata=None):
                      if _inside(t, p)]
             for name, t in views:
                 off = (t.data_ptr() - p.data_ptr()) // 4
-                for slot in ('m', 'v'):
-                    flat = st[slot].detach().reshape(-1)[off:off + t.numel()]
-                    tensors[f'optimizer/{name}/{slot}'] = flat.reshape(t.shape).to('cpu').contiguous()
+                for slot in ('m', 'v'):          # (a table's slots may be strided views of one [V,2,D] array)
+                    tensors[f'optimizer/{name}/{slot}'] = _slot_piece(st[slot], off, t).detach().to('cpu').contiguous()
         meta['optimizer'] = getattr(optimizer, '_name', optimizer.__class__.__name__)
         meta['optimizer_iterations'] = str(int(getattr(optimizer, 't', 0)))
         del by_id
@@ -139,8 +147,8 @@ def load_model(model, path, optimizer=None, strict=True):
                             continue
                         off = (t.data_ptr() - p.data_ptr()) // 4
                         for slot in ('m', 'v'):
-                            st[slot].reshape(-1)[off:off + t.numel()].copy_(
-                                f.get_tensor(f'optimizer/{name}/{slot}').reshape(-1))
+                            dst = _slot_piece(st[slot], off, t)
+                            dst.copy_(f.get_tensor(f'optimizer/{name}/{slot}').reshape(dst.shape))
                 optimizer.t = int(meta.get('optimizer_iterations', '0'))
     extra = [k for k in keys if not k.startswith('optimizer/') and k not in seen]
     if strict and extra:

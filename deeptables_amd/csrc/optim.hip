@@ -305,7 +305,7 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
                                                      const float* __restrict__ values, int64_t n, int D,
                                                      unsigned long long* __restrict__ slots,
                                                      const int* __restrict__ mark, float lr_t, float b1, float b2,
-                                                     float eps);
+                                                     float eps, int sstride);
 
 template <int VW>
 __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ table, float* __restrict__ m,
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
                                                          unsigned long long* __restrict__ slots,
                                                          const int* __restrict__ mark, float lr_host,
                                                          AdamState* __restrict__ st, float b1, float b2, float eps,
-                                                         int row_blocks, DenseTail tail, int advance, float lr) {
+                                                         int row_blocks, DenseTail tail, int advance, float lr,
+                                                         int sstride) {
     const float lr_t = st ? st->lr_t : lr_host;
     if ((int)blockIdx.x >= row_blocks) {      // trailing blocks: the model's dense parameters (one flat buffer)
         adam_dense_range(tail, (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x,
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
         if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
         return;
     }
-    adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps);
+    adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
     if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
 }
 
@@ -332,7 +333,7 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
                                                      const float* __restrict__ values, int64_t n, int D,
                                                      unsigned long long* __restrict__ slots,
                                                      const int* __restrict__ mark, float lr_t, float b1, float b2,
-                                                     float eps) {
+                                                     float eps, int sstride) {
     const int lpr = D / VW;
     const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t occ = gt / lpr;
@@ -341,17 +342,18 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
     const int slot = mark ? mark[occ] : (rows[occ] >= 0 ? 0 : -1);   // no mark: rows are already distinct
     if (slot < 0) return;
     const int64_t i0 = rows[occ] * D + part * VW;
+    const int64_t s0 = rows[occ] * sstride + part * VW;      // the row's slot record: m | v interleaved (sstride = 2D) or separate (D)
     const float* gsrc = values + occ * D + part * VW;
     float gi[VW], mi[VW], vi[VW], pi[VW];
     if (VW == 4) {
         typedef float nt_f4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<nt_f4*>(gi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(gsrc));
-        *reinterpret_cast<nt_f4*>(mi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m + i0));
-        *reinterpret_cast<nt_f4*>(vi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v + i0));
+        *reinterpret_cast<nt_f4*>(mi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m + s0));
+        *reinterpret_cast<nt_f4*>(vi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v + s0));
         *reinterpret_cast<float4*>(pi) = *reinterpret_cast<const float4*>(table + i0);
     } else {
 #pragma unroll
-        for (int k = 0; k < VW; ++k) { gi[k] = gsrc[k]; mi[k] = m[i0 + k]; vi[k] = v[i0 + k]; pi[k] = table[i0 + k]; }
+        for (int k = 0; k < VW; ++k) { gi[k] = gsrc[k]; mi[k] = m[s0 + k]; vi[k] = v[s0 + k]; pi[k] = table[i0 + k]; }
     }
 #pragma unroll
     for (int k = 0; k < VW; ++k) {
@@ -361,12 +363,12 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
     }
     if (VW == 4) {
         typedef float nt_f4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(mi), reinterpret_cast<nt_f4*>(m + i0));
-        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(vi), reinterpret_cast<nt_f4*>(v + i0));
+        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(mi), reinterpret_cast<nt_f4*>(m + s0));
+        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(vi), reinterpret_cast<nt_f4*>(v + s0));
         *reinterpret_cast<float4*>(table + i0) = *reinterpret_cast<float4*>(pi);
     } else {
 #pragma unroll
-        for (int k = 0; k < VW; ++k) { m[i0 + k] = mi[k]; v[i0 + k] = vi[k]; table[i0 + k] = pi[k]; }
+        for (int k = 0; k < VW; ++k) { m[s0 + k] = mi[k]; v[s0 + k] = vi[k]; table[i0 + k] = pi[k]; }
     }
     if (part == 0 && slots) slots[slot] = 0ULL;   // global-hash variant: leave the hash empty for the next step
 }
@@ -531,6 +533,9 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
     DT_REQUIRE(table && m && v && rows && values, "dt_adam_rows_step: null pointer");
     DT_REQUIRE(n_rows < (1LL << 31), "dt_adam_rows_step: %lld occurrences do not fit the 32-bit slot field",
                (long long)n_rows);
+    // slot layout: two separate [V, D] arrays, or ONE [V, 2, D] array with m and v of a row side by side (v == m + D):
+    // a row's m and v then share a 128-byte line and the update touches two random locations per row instead of three
+    const int sstride = (v == m + D) ? 2 * D : D;
     unsigned long long* gslots = nullptr;
     int* mk = mark;
     if (fields == -1) {
@@ -559,12 +564,12 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
         const int row_blocks = (int)((n_rows * (D / 4) + 255) / 256);
         hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
-                           lr);
+                           lr, sstride);
     } else {
         const int row_blocks = (int)((n_rows * D + 255) / 256);
         hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
-                           lr);
+                           lr, sstride);
     }
     return launch_status("dt_adam_rows_step");
 }

@@ -100,10 +100,20 @@ class KerasAdam:
         check(lib().dt_adam_state_init(ptr(self._dev_state), self.lr, self.b1, self.b2, int(value), stream_ptr()),
               'dt_adam_state_init')
 
-    def _st(self, p):
+    def _st(self, p, rows=False):
+        """slots of parameter p.  rows=True (the row-sparse table update): m and v of a row side by side in ONE
+        [V, 2, D] array (a 128-byte line at D = 16), so the update touches two random locations per row instead of
+        three; `m` / `v` are its strided views.  The dense update needs contiguous slots and converts back."""
         s = self.state.get(id(p))
         if s is None:
-            s = {'m': torch.zeros_like(p), 'v': torch.zeros_like(p)}
+            if rows and p.dim() == 2:
+                mv = torch.zeros((p.shape[0], 2, p.shape[1]), dtype=p.dtype, device=p.device)
+                s = {'m': mv[:, 0, :], 'v': mv[:, 1, :], 'mv': mv}
+            else:
+                s = {'m': torch.zeros_like(p), 'v': torch.zeros_like(p)}
+            self.state[id(p)] = s
+        elif not rows and 'mv' in s:
+            s = {'m': s['m'].contiguous(), 'v': s['v'].contiguous()}
             self.state[id(p)] = s
         return s
 
@@ -199,7 +209,7 @@ class KerasAdam:
             check(lib().dt_adam_advance(sp, self.lr, self.b1, self.b2, st), 'dt_adam_advance')
         for i, (layer, key, grads) in enumerate(sparse):
             table = layer.tables[key]
-            s = self._st(table)
+            s = self._st(table, rows=True)
             D = table.shape[1]
             if len(grads) == 1:
                 rows, values = grads[0].rows, grads[0].values

@@ -200,7 +200,9 @@ int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float*
  * steps; the state is advanced (t += 1, lr_t recomputed) either by dt_adam_advance or — with no launch of its own —
  * by the last block of a dt_adam_dense_step / dt_adam_rows_step called with advance != 0, which must be the LAST
  * launch of the step.  dt_adam_rows_step can carry one dense update (dense_* arrays, dense_n elements; 0 = none) in
- * trailing blocks of its row kernel, so a model with one big table and one flat dense buffer updates in ONE launch. */
+ * trailing blocks of its row kernel, so a model with one big table and one flat dense buffer updates in ONE launch.
+ * Row slots m / v: two separate [V, D] arrays, or the two halves of ONE [V, 2, D] array (pass v == m + D): a row's m
+ * and v then share a 128-byte line. */
 #define DT_ADAM_STATE_BYTES 272
 int dt_adam_state_init(void* state, float lr, float beta1, float beta2, int steps_done, void* stream);
 int dt_adam_advance(void* state, float lr, float beta1, float beta2, void* stream);
