@@ -1,0 +1,624 @@
+// autoint.hip — the AutoInt interacting layer (MultiheadAttention.call, deeptables/models/layers.py:119-153) as ONE
+// forward and ONE backward kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+//   Q,K,V,R = relu(x W_* + b_*)                      layers.py:104-108, :123-127   (four Keras Dense layers)
+//   per head h:  P = softmax(Q_h K_h^T / sqrt(d_h));  P = dropout(P);  O_h = P V_h      layers.py:129-143
+//   a = relu(concat_h(O_h) + R)                      layers.py:145-150   (BatchNormalization :151 stays bn.hip)
+//
+// One WAVE owns one batch row at a time (F <= 32 fields padded to two 16-row MFMA tiles); nothing is exchanged
+// between waves, so there is no workgroup barrier anywhere.  Per row:
+//   * the projections run as [32 x D] . [D x 4D] with the weights held in registers for the wave's whole life
+//     (D^2/16 registers per lane) and x read straight from HBM as the A operand (one 128-byte row per four lanes:
+//     the contraction index is permuted so that a lane's k are contiguous — k = (D/4) q + t);
+//   * Q | K | V | R land in the wave's private LDS slab [32][4D+4]: they never reach HBM (round 1 wrote and
+//     re-read 109 MB per layer and direction);
+//   * scores are formed TRANSPOSED, S^T[j][i] with the key index j on the accumulator registers and the query i on
+//     the lanes: the softmax over keys is then a lane-local loop plus two shuffles, and the probability registers
+//     ARE the A operand of P.V (step (J,r) <-> key 16J + 4q + r) — P never leaves registers;
+//   * the backward recomputes Q, K, V, R and the probabilities (both orientations: queries-on-lanes feeds dQ,
+//     keys-on-lanes feeds dV and dK), and leaves the gradient of the four pre-activation projections [B,F,4D] for
+//     the Dense backward (dt_dense_bwd: grad_x = dY Wcat^T, grad_W = x^T dY).
+// Attention-weight dropout (layers.py:141): keep-mask from a counter hash of (seed, row, head, query, key), the
+// same function in both kernels and in deeptables_amd/ops.py (tests rebuild the mask from it).
+#include "common.h"
+
+namespace dt {
+
+typedef float ai_f4 __attribute__((ext_vector_type(4)));
+constexpr int kAiPad = 4;
+
+__host__ __device__ inline unsigned ai_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j) {
+    unsigned x = seed ^ (b * 0x9E3779B1u) ^ ((h * 64u * 64u + i * 64u + j) * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+// keep-probability threshold: keep iff hash >= thr, thr = rate * 2^32
+__host__ __device__ inline float ai_keep(unsigned seed, unsigned thr, unsigned b, unsigned h, unsigned i, unsigned j,
+                                         float inv_keep) {
+    return ai_hash(seed, b, h, i, j) >= thr ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ void ai_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int D, int DH>
+struct AiCfg {
+    static constexpr int H = D / DH;
+    static constexpr int TK = D / 4;        // MFMA steps of a projection (k = TK q + t)
+    static constexpr int SK = DH / 4;       // MFMA steps of a score tile  (d = SK q + t)
+    static constexpr int YS = 4 * D + kAiPad;
+};
+
+// x rows of batch row b as the A operand of both row tiles: xa[T][t] = x[b][16T + n][TK q + t]  (rows >= F: row F-1)
+template <int D>
+__device__ __forceinline__ void ai_load_x(const float* __restrict__ x, int64_t b, int F, int n, int q, float (&xa)[2][D / 4]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int row = min(16 * T + n, F - 1);
+        const float* p = x + ((int64_t)b * F + row) * D + (D / 4) * q;
+#pragma unroll
+        for (int t = 0; t < D / 4; t += 4) {
+            const ai_f4 v = *reinterpret_cast<const ai_f4*>(p + t);
+            xa[T][t] = v.x; xa[T][t + 1] = v.y; xa[T][t + 2] = v.z; xa[T][t + 3] = v.w;
+        }
+    }
+}
+
+// Y = relu(x Wcat + b) -> the wave's LDS slab ys[32][YS]   (NP = 3 or 4 projections: q | k | v [| residual])
+template <int D>
+__device__ __forceinline__ void ai_project(const float (&xa)[2][D / 4], const float (&wr)[D / 4][D / 4],
+                                           const float (&br)[D / 4], int NP, float* ys, int n, int q) {
+    constexpr int TK = D / 4, YS = 4 * D + kAiPad;
+#pragma unroll
+    for (int ct = 0; ct < D / 4; ++ct) {                  // 4D / 16 column tiles
+        if (ct * 16 >= NP * D) break;
+        ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int t = 0; t < TK; ++t) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][t], wr[ct][t], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][t], wr[ct][t], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ys[(4 * q + r) * YS + 16 * ct + n] = fmaxf(c0[r] + br[ct], 0.f);
+            ys[(16 + 4 * q + r) * YS + 16 * ct + n] = fmaxf(c1[r] + br[ct], 0.f);
+        }
+    }
+}
+
+// the same with the weights read from the block's LDS copy wl[D][WS] (B operand of step t: W[TK q + t][16 ct + n])
+template <int D>
+__device__ __forceinline__ void ai_project_lds(const float (&xa)[2][D / 4], const float* wl, int WS,
+                                               const float (&br)[D / 4], int NP, float* ys, int n, int q) {
+    constexpr int TK = D / 4, YS = 4 * D + kAiPad;
+#pragma unroll
+    for (int ct = 0; ct < D / 4; ++ct) {
+        if (ct * 16 >= NP * D) break;
+        float wv[TK];
+#pragma unroll
+        for (int t = 0; t < TK; ++t) wv[t] = wl[(TK * q + t) * WS + 16 * ct + n];
+        ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int t = 0; t < TK; ++t) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][t], wv[t], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][t], wv[t], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ys[(4 * q + r) * YS + 16 * ct + n] = fmaxf(c0[r] + br[ct], 0.f);
+            ys[(16 + 4 * q + r) * YS + 16 * ct + n] = fmaxf(c1[r] + br[ct], 0.f);
+        }
+    }
+}
+
+// S^T tiles of head h in the queries-on-lanes orientation: st[J][I][r] = sum_d A[16J + 4q + r][d] B[16I + n][d]
+// (A = K, B = Q for the scores; A = V, B = dO for dP).  acol / bcol: first column of the head inside the slab.
+template <int DH>
+__device__ __forceinline__ void ai_tiles(const float* ys, int YS, int acol, int bcol, int n, int q, ai_f4 (&st)[2][2]) {
+    constexpr int SK = DH / 4;
+    float av[2][SK], bv[2][SK];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int t = 0; t < SK; ++t) {
+            av[T][t] = ys[(16 * T + n) * YS + acol + SK * q + t];
+            bv[T][t] = ys[(16 * T + n) * YS + bcol + SK * q + t];
+        }
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            ai_f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < SK; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[J][t], bv[I][t], c, 0, 0, 0);
+            st[J][I] = c;
+        }
+}
+
+// out[I][r] (row 16I + 4q + r, column n) = sum over the 32 "register-side" indices of p[J][I][r'] * M[16J + 4q + r'][col0 + (n % DH)]
+template <int DH>
+__device__ __forceinline__ void ai_apply(const ai_f4 (&p)[2][2], const float* ys, int YS, int col0, int n, int q,
+                                         ai_f4 (&out)[2]) {
+    float bv[2][4];
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[J][r] = ys[(16 * J + 4 * q + r) * YS + col0 + (n & (DH - 1))];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        ai_f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(p[J][I][r], bv[J][r], c, 0, 0, 0);
+        out[I] = c;
+    }
+}
+
+template <int D, int DH>
+__global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, const float* __restrict__ Wcat,
+                                                     const float* __restrict__ bcat, int B, int F, int NP,
+                                                     float* __restrict__ out_a, float* __restrict__ lse_out,
+                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
+    using C = AiCfg<D, DH>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    float* ys = lds + wave * 32 * C::YS;
+    const int M = NP * D;                                   // columns of Wcat
+    float wr[D / 4][C::TK], br[D / 4];
+#pragma unroll
+    for (int ct = 0; ct < D / 4; ++ct) {
+        const int col = min(16 * ct + n, M - 1);
+        br[ct] = bcat[col];
+#pragma unroll
+        for (int t = 0; t < C::TK; ++t) wr[ct][t] = Wcat[(int64_t)(C::TK * q + t) * M + col];
+    }
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int nwaves = gridDim.x * 4;
+    float xa[2][C::TK];
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
+    for (; b < B; b += nwaves) {
+        ai_project<D>(xa, wr, br, NP, ys, n, q);
+        if (b + nwaves < B) ai_load_x<D>(x, b + nwaves, F, n, q, xa);      // next row's operand while this one is attended
+        ai_fence();
+#pragma unroll
+        for (int h = 0; h < C::H; ++h) {
+            ai_f4 st[2][2];
+            ai_tiles<DH>(ys, C::YS, D + DH * h, DH * h, n, q, st);         // A = K_h, B = Q_h
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = 16 * J + 4 * q + r < F;
+                        st[J][I][r] = ok ? st[J][I][r] * scale : -3.0e38f;
+                        m = fmaxf(m, st[J][I][r]);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = 16 * J + 4 * q + r < F ? expf(st[J][I][r] - m) : 0.f;
+                        st[J][I][r] = e;
+                        l += e;
+                    }
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
+                const int i = 16 * I + n;
+                if (lse_out && q == 0 && i < F) lse_out[((int64_t)b * C::H + h) * F + i] = m + logf(l);
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = st[J][I][r] * inv;
+                        if (drop_thr) pv *= ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep);
+                        st[J][I][r] = pv;
+                    }
+            }
+            ai_f4 o[2];
+            ai_apply<DH>(st, ys, C::YS, 2 * D + DH * h, n, q, o);          // O_h = P V_h
+            if (n < DH) {
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * I + 4 * q + r;
+                        const float res = NP == 4 ? ys[i * C::YS + 3 * D + DH * h + n] : 0.f;
+                        ys[i * C::YS + DH * h + n] = fmaxf(o[I][r] + res, 0.f);    // over Q_h, which is dead now
+                    }
+            }
+        }
+        ai_fence();
+        // the row block [F][D] leaves as whole rows
+        for (int e = lane; e < F * (D / 4); e += 64) {
+            const int i = e / (D / 4), c4 = e - i * (D / 4);
+            *reinterpret_cast<ai_f4*>(out_a + ((int64_t)b * F + i) * D + 4 * c4) =
+                *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+        }
+        ai_fence();
+    }
+}
+
+// Backward.  g = gradient w.r.t. a = relu(O + R) (after the BatchNormalization backward), a = the saved forward output.
+// dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of q | k | v [| residual] (the weight gradient x^T dY is a
+// batch reduction and stays dt_dense_bwd's); dX [B,F,D] = dY Wcat^T is formed here, from the slab.
+// 8 waves per block (two per SIMD); the weights live ONCE per block in LDS (wl [D][NP*D+4]), not in registers.
+template <int D, int DH>
+__global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, const float* __restrict__ Wcat,
+                                                     const float* __restrict__ bcat, const float* __restrict__ a,
+                                                     const float* __restrict__ g, int B, int F, int NP,
+                                                     float* __restrict__ dY, float* __restrict__ dX,
+                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
+    using C = AiCfg<D, DH>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    float* wl = lds;                                       // [D][WS] Wcat, shared by the block's 8 waves
+    constexpr int WS = 4 * D + kAiPad;
+    float* ys = lds + D * WS + wave * (32 * C::YS + 96);
+    float* gs = ys + 3 * D;                                // dZ = g * (a > 0) (= dO of every head) replaces R in the slab
+    float* stat = ys + 32 * C::YS;                         // [32] m | [32] 1/l | [32] delta  of the current head
+    constexpr int GS = C::YS;
+    const int M = NP * D;
+    for (int e = threadIdx.x; e < D * M; e += blockDim.x) wl[(e / M) * WS + (e % M)] = Wcat[e];
+    float br[D / 4];
+#pragma unroll
+    for (int ct = 0; ct < D / 4; ++ct) br[ct] = bcat[min(16 * ct + n, M - 1)];
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int nwaves = gridDim.x * 8;
+    float xa[2][C::TK];
+    int64_t b = (int64_t)blockIdx.x * 8 + wave;
+    if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
+    for (; b < B; b += nwaves) {
+        // dZ rows -> LDS (rows >= F: zero), issued before the projections so the loads fly under them
+        ai_f4 gz[(32 * (D / 4) + 63) / 64];
+#pragma unroll
+        for (int u = 0; u < (32 * (D / 4) + 63) / 64; ++u) {
+            const int e = lane + 64 * u;
+            const int i = e / (D / 4), c4 = e - i * (D / 4);
+            gz[u] = ai_f4{0.f, 0.f, 0.f, 0.f};
+            if (i < F) {
+                const ai_f4 gv = *reinterpret_cast<const ai_f4*>(g + ((int64_t)b * F + i) * D + 4 * c4);
+                const ai_f4 av = *reinterpret_cast<const ai_f4*>(a + ((int64_t)b * F + i) * D + 4 * c4);
+                gz[u] = ai_f4{av.x > 0.f ? gv.x : 0.f, av.y > 0.f ? gv.y : 0.f, av.z > 0.f ? gv.z : 0.f,
+                              av.w > 0.f ? gv.w : 0.f};
+            }
+        }
+        ai_project_lds<D>(xa, wl, WS, br, NP, ys, n, q);
+        ai_fence();
+        // residual branch: d(pre-activation of R) = dZ * (R > 0), straight to HBM
+        unsigned rmask = 0;                                  // relu mask of this lane's R elements, 4 bits per float4
+        if (NP == 4) {
+#pragma unroll
+            for (int u = 0; u < (32 * (D / 4) + 63) / 64; ++u) {
+                const int e = lane + 64 * u;
+                const int i = e / (D / 4), c4 = e - i * (D / 4);
+                if (i < F) {
+                    const ai_f4 rv = *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 3 * D + 4 * c4);
+                    const ai_f4 gv = gz[u];
+                    rmask |= ((rv.x > 0.f ? 1u : 0u) | (rv.y > 0.f ? 2u : 0u) | (rv.z > 0.f ? 4u : 0u) | (rv.w > 0.f ? 8u : 0u)) << (4 * u);
+                    *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 3 * D + 4 * c4) =
+                        ai_f4{rv.x > 0.f ? gv.x : 0.f, rv.y > 0.f ? gv.y : 0.f, rv.z > 0.f ? gv.z : 0.f,
+                              rv.w > 0.f ? gv.w : 0.f};
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < (32 * (D / 4) + 63) / 64; ++u) {
+            const int e = lane + 64 * u;
+            const int i = e / (D / 4), c4 = e - i * (D / 4);
+            if (i < 32) *reinterpret_cast<ai_f4*>(gs + i * GS + 4 * c4) = gz[u];
+        }
+        ai_fence();
+#pragma unroll 1
+        for (int h = 0; h < C::H; ++h) {        // not unrolled: the heads' live ranges must not overlap (256 registers)
+            const int qc = DH * h, kc = D + DH * h, vc = 2 * D + DH * h;
+            // ---- queries on lanes: P^T, dP^T -> delta, dS^T -> dQ ----
+            ai_f4 pt[2][2], dpt[2][2];
+            ai_tiles<DH>(ys, C::YS, kc, qc, n, q, pt);                     // S^T = K Q^T
+            {
+                // dP^T[j][i] = V_j . dO_i: A = V_h rows (slab), B = dO rows (gs slab, other stride): inline variant
+                constexpr int SK = DH / 4;
+                float av[2][SK], bv[2][SK];
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int t = 0; t < SK; ++t) {
+                        av[T][t] = ys[(16 * T + n) * C::YS + vc + SK * q + t];
+                        bv[T][t] = gs[(16 * T + n) * GS + qc + SK * q + t];
+                    }
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int I = 0; I < 2; ++I) {
+                        ai_f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int t = 0; t < SK; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[J][t], bv[I][t], c, 0, 0, 0);
+                        dpt[J][I] = c;
+                    }
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = 16 * J + 4 * q + r < F;
+                        pt[J][I][r] = ok ? pt[J][I][r] * scale : -3.0e38f;
+                        m = fmaxf(m, pt[J][I][r]);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = 16 * J + 4 * q + r < F ? expf(pt[J][I][r] - m) : 0.f;
+                        pt[J][I][r] = e;
+                        l += e;
+                    }
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
+                const int i = 16 * I + n;
+                float delta = 0.f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = pt[J][I][r] * inv;
+                        const float keep = drop_thr ? ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep) : 1.f;
+                        dpt[J][I][r] *= keep;                               // gradient w.r.t. the un-dropped probability
+                        pt[J][I][r] = pv;
+                        delta += pv * dpt[J][I][r];
+                    }
+                delta += __shfl_xor(delta, 16, 64);
+                delta += __shfl_xor(delta, 32, 64);
+                if (q == 0) { stat[i] = m; stat[32 + i] = inv; stat[64 + i] = delta; }
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[J][I][r] = pt[J][I][r] * (dpt[J][I][r] - delta) * scale;   // dS^T
+            }
+            ai_f4 dq[2];
+            ai_apply<DH>(pt, ys, C::YS, kc, n, q, dq);                     // dQ_h = dS K_h
+            ai_fence();
+            // ---- keys on lanes: P, dP -> dS -> dV = P'^T dO, dK = dS^T Q ----
+            ai_f4 pn[2][2], dpn[2][2];
+            {
+                constexpr int SK = DH / 4;
+                float qa[2][SK], kb[2][SK], ga[2][SK], vb[2][SK];
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int t = 0; t < SK; ++t) {
+                        qa[T][t] = ys[(16 * T + n) * C::YS + qc + SK * q + t];
+                        kb[T][t] = ys[(16 * T + n) * C::YS + kc + SK * q + t];
+                        ga[T][t] = gs[(16 * T + n) * GS + qc + SK * q + t];
+                        vb[T][t] = ys[(16 * T + n) * C::YS + vc + SK * q + t];
+                    }
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) {
+                        ai_f4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+#pragma unroll
+                        for (int t = 0; t < SK; ++t) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[I][t], kb[J][t], c, 0, 0, 0);   // S[i][j], i = 16I+4q+r, j = 16J+n
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[I][t], vb[J][t], d, 0, 0, 0);   // dP[i][j]
+                        }
+                        pn[I][J] = c;
+                        dpn[I][J] = d;
+                    }
+            }
+            ai_f4 pdrop[2][2];                                              // dropped probabilities (A operand of dV)
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + 4 * q + r;
+                    const float m = stat[i], inv = stat[32 + i], delta = stat[64 + i];
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) {
+                        const int j = 16 * J + n;
+                        const float pv = j < F ? expf(pn[I][J][r] * scale - m) * inv : 0.f;
+                        const float keep = drop_thr ? ai_keep(seed, drop_thr, (unsigned)b, h, i, j, inv_keep) : 1.f;
+                        pdrop[I][J][r] = i < F ? pv * keep : 0.f;
+                        pn[I][J][r] = i < F ? pv * (dpn[I][J][r] * keep - delta) * scale : 0.f;            // dS[i][j]
+                    }
+                }
+            // dV[j][d] = sum_i P'[i][j] dO[i][d];  dK[j][d] = sum_i dS[i][j] Q[i][d]: the register-side index is the query i
+            ai_f4 dv[2], dk[2];
+            {
+                float gb[2][4], qb[2][4];
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gb[I][r] = gs[(16 * I + 4 * q + r) * GS + qc + (n & (DH - 1))];
+                        qb[I][r] = ys[(16 * I + 4 * q + r) * C::YS + qc + (n & (DH - 1))];
+                    }
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    ai_f4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+#pragma unroll
+                    for (int I = 0; I < 2; ++I)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(pdrop[I][J][r], gb[I][r], c, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[I][J][r], qb[I][r], d, 0, 0, 0);
+                        }
+                    dv[J] = c;
+                    dk[J] = d;
+                }
+            }
+            ai_fence();
+            // relu masks of the projections, gradients over the head's own (now dead) Q / K / V columns
+            if (n < DH) {
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * T + 4 * q + r;
+                        float* yr = ys + row * C::YS;
+                        const float qv = yr[qc + n], kv = yr[kc + n], vv = yr[vc + n];
+                        yr[qc + n] = qv > 0.f ? dq[T][r] : 0.f;
+                        yr[kc + n] = kv > 0.f ? dk[T][r] : 0.f;
+                        yr[vc + n] = vv > 0.f ? dv[T][r] : 0.f;
+                    }
+            }
+            ai_fence();
+        }
+        // dQ | dK | dV rows [F][3D] leave as whole rows
+        for (int e = lane; e < F * (3 * D / 4); e += 64) {
+            const int i = e / (3 * D / 4), c4 = e - i * (3 * D / 4);
+            *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 4 * c4) =
+                *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+        }
+        if (b + nwaves < B) ai_load_x<D>(x, b + nwaves, F, n, q, xa);      // next row's operand flies under the dX product
+        if (dX) {
+            // the residual block of the slab becomes d(pre-activation of R) = dZ * (R > 0): the slab row is now dY
+            if (NP == 4) {
+#pragma unroll
+                for (int u = 0; u < (32 * (D / 4) + 63) / 64; ++u) {
+                    const int e = lane + 64 * u;
+                    const int i = e / (D / 4), c4 = e - i * (D / 4);
+                    if (i < 32) {
+                        const unsigned mk = rmask >> (4 * u);
+                        const ai_f4 zv = *reinterpret_cast<const ai_f4*>(gs + i * GS + 4 * c4);
+                        *reinterpret_cast<ai_f4*>(gs + i * GS + 4 * c4) =
+                            ai_f4{mk & 1u ? zv.x : 0.f, mk & 2u ? zv.y : 0.f, mk & 4u ? zv.z : 0.f, mk & 8u ? zv.w : 0.f};
+                    }
+                }
+            }
+            ai_fence();
+            // dX[i][k] = sum_m dY[i][m] W[k][m]; the contraction index is permuted so that a lane's m are contiguous
+            // (m = (M/4) q + t): A and B operands are 16-byte LDS reads
+            ai_f4 dx[2][D / 16];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int ct = 0; ct < D / 16; ++ct) dx[T][ct] = ai_f4{0.f, 0.f, 0.f, 0.f};
+            const int MQ = M / 4;                            // 24 or 32 (D = 32), 12 or 16 (D = 16): multiples of 4
+            for (int t = 0; t < MQ; t += 4) {
+                const ai_f4 a0 = *reinterpret_cast<const ai_f4*>(ys + n * C::YS + MQ * q + t);
+                const ai_f4 a1 = *reinterpret_cast<const ai_f4*>(ys + (16 + n) * C::YS + MQ * q + t);
+#pragma unroll
+                for (int ct = 0; ct < D / 16; ++ct) {
+                    const ai_f4 w = *reinterpret_cast<const ai_f4*>(wl + (16 * ct + n) * WS + MQ * q + t);
+                    dx[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, dx[0][ct], 0, 0, 0);
+                    dx[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, dx[1][ct], 0, 0, 0);
+                    dx[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, dx[0][ct], 0, 0, 0);
+                    dx[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, dx[1][ct], 0, 0, 0);
+                    dx[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, dx[0][ct], 0, 0, 0);
+                    dx[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, dx[1][ct], 0, 0, 0);
+                    dx[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, dx[0][ct], 0, 0, 0);
+                    dx[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, dx[1][ct], 0, 0, 0);
+                }
+            }
+            ai_fence();
+            // stage over the (dead) first D columns of the slab, leave as whole rows
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int ct = 0; ct < D / 16; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ys[(16 * T + 4 * q + r) * C::YS + 16 * ct + n] = dx[T][ct][r];
+            ai_fence();
+            for (int e = lane; e < F * (D / 4); e += 64) {
+                const int i = e / (D / 4), c4 = e - i * (D / 4);
+                *reinterpret_cast<ai_f4*>(dX + ((int64_t)b * F + i) * D + 4 * c4) =
+                    *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+            }
+        }
+        ai_fence();
+    }
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" int dt_autoint_supported(int F, int D, int H) {
+    if (F < 1 || F > 32 || H < 1 || D % H) return 0;
+    const int dh = D / H;
+    return ((D == 32 && (dh == 8 || dh == 16)) || (D == 16 && (dh == 4 || dh == 8 || dh == 16))) ? 1 : 0;
+}
+
+extern "C" unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j) {
+    return ai_hash(seed, b, h, i, j);
+}
+
+#define DT_AI_DISPATCH(KERNEL, WAVES, LDS_FLOATS, ...)                                                             \
+    do {                                                                                                           \
+        const int dh = D / H;                                                                                      \
+        int blocks = (int)((B + (WAVES) - 1) / (WAVES));                                                           \
+        if (blocks > 2048 / (WAVES)) blocks = 2048 / (WAVES);                                                      \
+        const size_t lds = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
+        if (D == 32 && dh == 8) {                                                                                  \
+            hipFuncSetAttribute((const void*)KERNEL<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((KERNEL<32, 8>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
+        } else if (D == 32 && dh == 16) {                                                                          \
+            hipFuncSetAttribute((const void*)KERNEL<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
+            hipLaunchKernelGGL((KERNEL<32, 16>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                   \
+        } else if (D == 16 && dh == 4) {                                                                           \
+            hipFuncSetAttribute((const void*)KERNEL<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((KERNEL<16, 4>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
+        } else if (D == 16 && dh == 8) {                                                                           \
+            hipFuncSetAttribute((const void*)KERNEL<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((KERNEL<16, 8>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
+        } else {                                                                                                   \
+            hipFuncSetAttribute((const void*)KERNEL<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
+            hipLaunchKernelGGL((KERNEL<16, 16>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                   \
+        }                                                                                                          \
+    } while (0)
+
+static bool ai_drop(float rate, unsigned* thr, float* inv_keep) {
+    *thr = 0; *inv_keep = 1.f;
+    if (rate <= 0.f) return true;
+    if (rate >= 1.f) return false;
+    double t = (double)rate * 4294967296.0;
+    *thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (*thr == 0) *thr = 1;
+    *inv_keep = 1.0f / (1.0f - rate);
+    return true;
+}
+
+extern "C" int dt_autoint_fwd(const float* x, const float* Wcat, const float* bcat, int64_t B, int F, int D, int H,
+                              int use_residual, float dropout_rate, unsigned seed, float* out_a, float* lse,
+                              void* stream) {
+    DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd: unsupported shape F=%d D=%d H=%d", F, D, H);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && Wcat && bcat && out_a && B > 0 && B < (1LL << 31), "dt_autoint_fwd: null pointer / bad batch");
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_fwd: dropout_rate %f", dropout_rate);
+    hipStream_t st = as_stream(stream);
+    const int NP = use_residual ? 4 : 3;
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, Wcat, bcat, (int)B, F, NP, out_a, lse, thr, inv_keep, seed);
+    return launch_status("dt_autoint_fwd");
+}
+
+extern "C" int dt_autoint_bwd(const float* x, const float* Wcat, const float* bcat, const float* a, const float* g,
+                              int64_t B, int F, int D, int H, int use_residual, float dropout_rate, unsigned seed,
+                              float* dY, float* dX, void* stream) {
+    DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x && Wcat && bcat && a && g && dY && B > 0 && B < (1LL << 31), "dt_autoint_bwd: null pointer / bad batch");
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_bwd: dropout_rate %f", dropout_rate);
+    hipStream_t st = as_stream(stream);
+    const int NP = use_residual ? 4 : 3;
+    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, Wcat, bcat, a, g, (int)B, F,
+                   NP, dY, dX, thr, inv_keep, seed);
+    return launch_status("dt_autoint_bwd");
+}

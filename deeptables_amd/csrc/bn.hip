@@ -11,6 +11,7 @@
 // segments.  Per column the block accumulates SHIFTED sums (shift = first row of the chunk) so
 // the M2 it reports does not suffer E[x^2]-E[x]^2 cancellation; chunk results are merged with
 // Chan's parallel formula in a one-thread-per-column finalize kernel.
+#include <initializer_list>
 #include "common.h"
 
 namespace dt {
@@ -225,6 +226,156 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(
     }
 }
 
+// ---- 16-byte variants for C % 4 == 0 (the [batch*fields, embedding] normalisations of the AutoInt layers: C = 16 / 32).
+// A thread owns 4 adjacent columns; a wave-load covers whole 128-byte (C = 32) rows instead of 4-byte elements, the
+// row loop is unrolled 4x so four independent 16-byte loads per thread are in flight, and the element-wise passes
+// index with 32-bit arithmetic (the scalar versions spend most of their time in a 64-bit modulo).
+typedef float bn_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBnThreads) void k_bn_stats_v4(const float* __restrict__ x, int N, int C, int CW4,
+                                                            int rows_per_chunk, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][RS][CW4] float4
+    const int C4 = C >> 2, RS = kBnThreads / CW4;
+    const int tx = threadIdx.x % CW4, ty = threadIdx.x / CW4;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    bn_f4* ps = reinterpret_cast<bn_f4*>(lds);
+    bn_f4* pq = ps + RS * CW4;
+    for (int c0 = 0; c0 < C4; c0 += CW4) {
+        const int c4 = c0 + tx;
+        bn_f4 s = {0.f, 0.f, 0.f, 0.f}, q = s, K = s;
+        if (c4 < C4 && r0 < r1) {
+            const bn_f4* xp = reinterpret_cast<const bn_f4*>(x) + c4;
+            K = xp[(int64_t)r0 * C4];
+            int r = r0 + ty;
+            for (; r + 3 * RS < r1; r += 4 * RS) {
+                const bn_f4 v0 = xp[(int64_t)r * C4], v1 = xp[(int64_t)(r + RS) * C4],
+                            v2 = xp[(int64_t)(r + 2 * RS) * C4], v3 = xp[(int64_t)(r + 3 * RS) * C4];
+                const bn_f4 d0 = v0 - K, d1 = v1 - K, d2 = v2 - K, d3 = v3 - K;
+                s += (d0 + d1) + (d2 + d3);
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            for (; r < r1; r += RS) {
+                const bn_f4 d = xp[(int64_t)r * C4] - K;
+                s += d;
+                q += d * d;
+            }
+        }
+        ps[ty * CW4 + tx] = s;
+        pq[ty * CW4 + tx] = q;
+        __syncthreads();
+        if (ty == 0 && c4 < C4) {
+            for (int k = 1; k < RS; ++k) {
+                s += ps[k * CW4 + tx];
+                q += pq[k * CW4 + tx];
+            }
+            const float n = (float)max(r1 - r0, 0);
+            float* p = partial + (int64_t)blockIdx.x * 3 * C + 4 * c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float mean = 0.f, m2 = 0.f;
+                if (n > 0.f) {
+                    mean = K[e] + s[e] / n;
+                    m2 = fmaxf(q[e] - s[e] * s[e] / n, 0.f);
+                }
+                p[e] = n;
+                p[C + e] = mean;
+                p[2 * C + e] = m2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply_v4(const float* __restrict__ x, int total4, int C4,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ y) {
+    const bn_f4* xp = reinterpret_cast<const bn_f4*>(x);
+    bn_f4* yp = reinterpret_cast<bn_f4*>(y);
+    const bn_f4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += gridDim.x * blockDim.x) {
+        const int c4 = t % C4;
+        const bn_f4 g = gamma ? reinterpret_cast<const bn_f4*>(gamma)[c4] : one;
+        const bn_f4 bb = beta ? reinterpret_cast<const bn_f4*>(beta)[c4] : zero;
+        const bn_f4 m = reinterpret_cast<const bn_f4*>(mean)[c4], rs = reinterpret_cast<const bn_f4*>(rstd)[c4];
+        yp[t] = (xp[t] - m) * rs * g + bb;
+    }
+}
+
+__global__ __launch_bounds__(kBnThreads) void k_bn_bwd_stats_v4(
+    const float* __restrict__ x, const float* __restrict__ gy, int N, int C, int CW4, int rows_per_chunk,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int C4 = C >> 2, RS = kBnThreads / CW4;
+    const int tx = threadIdx.x % CW4, ty = threadIdx.x / CW4;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    bn_f4* ps = reinterpret_cast<bn_f4*>(lds);
+    bn_f4* pq = ps + RS * CW4;
+    for (int c0 = 0; c0 < C4; c0 += CW4) {
+        const int c4 = c0 + tx;
+        bn_f4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+        if (c4 < C4) {
+            const bn_f4 m = reinterpret_cast<const bn_f4*>(mean)[c4], rs = reinterpret_cast<const bn_f4*>(rstd)[c4];
+            const bn_f4* xp = reinterpret_cast<const bn_f4*>(x) + c4;
+            const bn_f4* gp = reinterpret_cast<const bn_f4*>(gy) + c4;
+            int r = r0 + ty;
+            for (; r + RS < r1; r += 2 * RS) {
+                const bn_f4 g0 = gp[(int64_t)r * C4], x0 = xp[(int64_t)r * C4];
+                const bn_f4 g1 = gp[(int64_t)(r + RS) * C4], x1 = xp[(int64_t)(r + RS) * C4];
+                s += g0 + g1;
+                q += g0 * ((x0 - m) * rs) + g1 * ((x1 - m) * rs);
+            }
+            for (; r < r1; r += RS) {
+                const bn_f4 g = gp[(int64_t)r * C4];
+                s += g;
+                q += g * ((xp[(int64_t)r * C4] - m) * rs);
+            }
+        }
+        ps[ty * CW4 + tx] = s;
+        pq[ty * CW4 + tx] = q;
+        __syncthreads();
+        if (ty == 0 && c4 < C4) {
+            for (int k = 1; k < RS; ++k) {
+                s += ps[k * CW4 + tx];
+                q += pq[k * CW4 + tx];
+            }
+            float* p = partial + (int64_t)blockIdx.x * 2 * C + 4 * c4;
+            *reinterpret_cast<bn_f4*>(p) = s;
+            *reinterpret_cast<bn_f4*>(p + C) = q;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_v4(
+    const float* __restrict__ x, const float* __restrict__ gy, int total4, int C4, float inv_n,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ gx) {
+    const bn_f4 one = {1.f, 1.f, 1.f, 1.f};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += gridDim.x * blockDim.x) {
+        const int c4 = t % C4;
+        const bn_f4 m = reinterpret_cast<const bn_f4*>(mean)[c4], rs = reinterpret_cast<const bn_f4*>(rstd)[c4];
+        const bn_f4 g = gamma ? reinterpret_cast<const bn_f4*>(gamma)[c4] : one;
+        const bn_f4 sg = reinterpret_cast<const bn_f4*>(sum_g)[c4], sgx = reinterpret_cast<const bn_f4*>(sum_gx)[c4];
+        const bn_f4 xhat = (reinterpret_cast<const bn_f4*>(x)[t] - m) * rs;
+        reinterpret_cast<bn_f4*>(gx)[t] = g * rs * (reinterpret_cast<const bn_f4*>(gy)[t] - sg * inv_n - xhat * (sgx * inv_n));
+    }
+}
+
+static bool bn_vec4(int N, int C, std::initializer_list<const void*> ptrs) {
+    if (C % 4 || C > 1024 || (int64_t)N * C / 4 >= (1LL << 31)) return false;
+    for (const void* p : ptrs)
+        if (p && ((uintptr_t)p & 15)) return false;
+    return true;
+}
+static int bn_col_width4(int C) {  // power of two >= C/4, <= 256
+    int w = 1;
+    while (w < C / 4 && w < kBnThreads) w <<= 1;
+    return w;
+}
+
 static int elementwise_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -254,13 +405,23 @@ extern "C" int dt_bn_train_fwd(const float* x, int N, int C, const float* gamma,
     const int CW = bn_col_width(C);
     const size_t lds = 2 * kBnThreads * sizeof(float);
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(k_bn_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, N, C, CW, rpc,
-                       partial);
+    const bool v4 = bn_vec4(N, C, {x, y, gamma, beta, save_mean, save_rstd, ws});
+    if (v4) {
+        const int CW4 = bn_col_width4(C);
+        hipLaunchKernelGGL(k_bn_stats_v4, dim3(chunks), dim3(kBnThreads), 8 * kBnThreads * sizeof(float), st, x, N, C, CW4,
+                           rpc, partial);
+    } else {
+        hipLaunchKernelGGL(k_bn_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, N, C, CW, rpc, partial);
+    }
     hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, chunks, C,
                        eps, momentum, moving_mean, moving_var, save_mean, save_rstd);
     const int64_t total = (int64_t)N * C;
-    hipLaunchKernelGGL(k_bn_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, total, C,
-                       gamma, beta, save_mean, save_rstd, y);
+    if (v4)
+        hipLaunchKernelGGL(k_bn_apply_v4, dim3(elementwise_blocks(total / 4)), dim3(256), 0, st, x, (int)(total / 4), C / 4,
+                           gamma, beta, save_mean, save_rstd, y);
+    else
+        hipLaunchKernelGGL(k_bn_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, total, C,
+                           gamma, beta, save_mean, save_rstd, y);
     return launch_status("dt_bn_train_fwd");
 }
 
@@ -290,13 +451,23 @@ extern "C" int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C
     const size_t lds = 2 * kBnThreads * sizeof(float);
     float* partial = reinterpret_cast<float*>(ws);
     float* sums = partial + (int64_t)kBnMaxChunks * 3 * C;
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, grad_y, N, C, CW,
-                       rpc, save_mean, save_rstd, partial);
+    const bool v4 = bn_vec4(N, C, {x, grad_y, gamma, save_mean, save_rstd, grad_x, ws}) &&
+                    (((int64_t)kBnMaxChunks * 3 * C) & 3) == 0;
+    if (v4)
+        hipLaunchKernelGGL(k_bn_bwd_stats_v4, dim3(chunks), dim3(kBnThreads), 8 * kBnThreads * sizeof(float), st, x, grad_y,
+                           N, C, bn_col_width4(C), rpc, save_mean, save_rstd, partial);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3(chunks), dim3(kBnThreads), lds, st, x, grad_y, N, C, CW,
+                           rpc, save_mean, save_rstd, partial);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, chunks,
                        C, sums, sums + C, grad_gamma, grad_beta);
     const int64_t total = (int64_t)N * C;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, grad_y,
-                       total, C, 1.0f / (float)N, gamma, save_mean, save_rstd, sums, sums + C,
-                       grad_x);
+    if (v4)
+        hipLaunchKernelGGL(k_bn_bwd_apply_v4, dim3(elementwise_blocks(total / 4)), dim3(256), 0, st, x, grad_y,
+                           (int)(total / 4), C / 4, 1.0f / (float)N, gamma, save_mean, save_rstd, sums, sums + C, grad_x);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(elementwise_blocks(total)), dim3(256), 0, st, x, grad_y,
+                           total, C, 1.0f / (float)N, gamma, save_mean, save_rstd, sums, sums + C,
+                           grad_x);
     return launch_status("dt_bn_train_bwd");
 }

@@ -157,29 +157,84 @@ __global__ __launch_bounds__(256) void k_dense1_fwd(const float* __restrict__ x,
 }
 
 // grad_x[n,k] = G[n] w[k];  grad_w[k] += sum_n G[n] x[n,k];  grad_b += sum_n G[n]
+// A block owns `rows_per_block` (<= 64) rows: their G sit in LDS, a thread owns 4 adjacent columns (16-byte lanes)
+// and walks the rows 4 at a time; the block's column sums go to part[block][K] (no atomics: every block of the
+// grid would otherwise hit the same K addresses) and k_dense1_reduce adds the blocks up.
+constexpr int kD1Rows = 64;
+typedef float d1_f4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_dense1_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ y, const float* __restrict__ gy,
                                                     int act, int N, int K, int rows_per_block,
-                                                    float* __restrict__ gx, float* __restrict__ gw,
-                                                    float* __restrict__ gb) {
+                                                    float* __restrict__ gx, float* __restrict__ part, int vec4) {
+    __shared__ float gs[kD1Rows];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = min((int64_t)N, r0 + rows_per_block);
-    float bsum = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const float wk = w[k];
-        float acc = 0.f;
-        for (int64_t n = r0; n < r1; ++n) {
-            const float g = dact(gy[n], y[n], act);
-            if (gx) gx[n * K + k] = g * wk;
-            acc += g * x[n * K + k];
+    const int nr = (int)(min((int64_t)N, r0 + rows_per_block) - r0);
+    if ((int)threadIdx.x < kD1Rows)
+        gs[threadIdx.x] = (int)threadIdx.x < nr ? dact(gy[r0 + threadIdx.x], y[r0 + threadIdx.x], act) : 0.f;
+    __syncthreads();
+    float* prow = part + (int64_t)blockIdx.x * (K + 4);
+    if (vec4) {
+        const int K4 = K >> 2;
+        for (int k4 = threadIdx.x; k4 < K4; k4 += blockDim.x) {
+            const d1_f4 wk = reinterpret_cast<const d1_f4*>(w)[k4];
+            const d1_f4* xp = reinterpret_cast<const d1_f4*>(x) + r0 * K4 + k4;
+            d1_f4* gp = gx ? reinterpret_cast<d1_f4*>(gx) + r0 * K4 + k4 : nullptr;
+            d1_f4 acc = {0.f, 0.f, 0.f, 0.f};
+            int n = 0;
+            for (; n + 3 < nr; n += 4) {
+                const d1_f4 x0 = xp[(int64_t)n * K4], x1 = xp[(int64_t)(n + 1) * K4], x2 = xp[(int64_t)(n + 2) * K4],
+                            x3 = xp[(int64_t)(n + 3) * K4];
+                const float g0 = gs[n], g1 = gs[n + 1], g2 = gs[n + 2], g3 = gs[n + 3];
+                if (gp) {
+                    gp[(int64_t)n * K4] = wk * g0; gp[(int64_t)(n + 1) * K4] = wk * g1;
+                    gp[(int64_t)(n + 2) * K4] = wk * g2; gp[(int64_t)(n + 3) * K4] = wk * g3;
+                }
+                acc += (x0 * g0 + x1 * g1) + (x2 * g2 + x3 * g3);
+            }
+            for (; n < nr; ++n) {
+                const float g = gs[n];
+                if (gp) gp[(int64_t)n * K4] = wk * g;
+                acc += xp[(int64_t)n * K4] * g;
+            }
+            reinterpret_cast<d1_f4*>(prow)[k4] = acc;
         }
-        atomicAdd(gw + k, acc);
+    } else {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float wk = w[k];
+            float acc = 0.f;
+            for (int n = 0; n < nr; ++n) {
+                const float g = gs[n];
+                if (gx) gx[(r0 + n) * K + k] = g * wk;
+                acc += g * x[(r0 + n) * K + k];
+            }
+            prow[k] = acc;
+        }
     }
-    if (gb && threadIdx.x < 64) {
-        for (int64_t n = r0 + threadIdx.x; n < r1; n += 64) bsum += dact(gy[n], y[n], act);
+    if (threadIdx.x < 64) {
+        float bsum = gs[threadIdx.x];
         bsum = wave_sum(bsum);
-        if (threadIdx.x == 0) atomicAdd(gb, bsum);
+        if (threadIdx.x == 0) prow[K] = bsum;
     }
+}
+
+// grad_w[k] += sum_blocks part[block][k]  (k == K: the bias)
+__global__ __launch_bounds__(256) void k_dense1_reduce(const float* __restrict__ part, int blocks, int K,
+                                                       float* __restrict__ gw, float* __restrict__ gb) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > K) return;
+    const float* p = part + k;
+    const int64_t stride = K + 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 3 < blocks; i += 4) {
+        a0 += p[(int64_t)i * stride]; a1 += p[(int64_t)(i + 1) * stride];
+        a2 += p[(int64_t)(i + 2) * stride]; a3 += p[(int64_t)(i + 3) * stride];
+    }
+    for (; i < blocks; ++i) a0 += p[(int64_t)i * stride];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (k < K) gw[k] += v;
+    else if (gb) gb[0] += v;
 }
 
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ W, int K, int M,
@@ -280,7 +335,15 @@ extern "C" int dt_dense_supported(int N, int K, int M) {
     return dense_lds(K, dense_nbw(M)) <= 150 * 1024 && dense_lds(M, dense_nbw(K)) <= 150 * 1024;
 }
 
+static int dense1_rows(int N) {          // rows per block of the Dense(1) backward: ~1024 blocks, 32..64 rows each
+    int rpb = ceil_div(N, 1024);
+    if (rpb < 32) rpb = 32;
+    if (rpb > kD1Rows) rpb = kD1Rows;
+    return rpb;
+}
+
 extern "C" int64_t dt_dense_workspace_bytes(int N, int K, int M) {
+    if (M == 1) return (int64_t)sizeof(float) * ceil_div(N > 0 ? N : 1, dense1_rows(N)) * (K + 4);   // per-block column sums
     return (int64_t)sizeof(float) * K * M;   // W^T for grad_x
 }
 
@@ -313,10 +376,14 @@ extern "C" int dt_dense_bwd(const float* x, const float* W, const float* y, cons
     DT_REQUIRE(x && W && y && grad_y && grad_W, "dt_dense_bwd: null pointer");
     hipStream_t st = as_stream(stream);
     if (M == 1) {
-        int rpb = ceil_div(N, 256);
-        if (rpb < 32) rpb = 32;
-        hipLaunchKernelGGL(k_dense1_bwd, dim3(ceil_div(N, rpb)), dim3(256), 0, st, x, W, y, grad_y, act, N, K, rpb,
-                           grad_x, grad_W, grad_b);
+        DT_REQUIRE(ws, "dt_dense_bwd: null workspace");
+        const int rpb = dense1_rows(N), blocks = ceil_div(N, rpb);
+        const int vec4 = (K % 4 == 0) && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)grad_x | (uintptr_t)ws) % 16 == 0);
+        float* part = reinterpret_cast<float*>(ws);
+        hipLaunchKernelGGL(k_dense1_bwd, dim3(blocks), dim3(256), 0, st, x, W, y, grad_y, act, N, K, rpb, grad_x, part,
+                           vec4);
+        hipLaunchKernelGGL(k_dense1_reduce, dim3(ceil_div(K + 1, 256)), dim3(256), 0, st, part, blocks, K, grad_W,
+                           grad_b);
         return launch_status("dt_dense_bwd(gemv)");
     }
     if (grad_x) {

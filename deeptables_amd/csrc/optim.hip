@@ -542,7 +542,11 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
         mk = nullptr;                                      // rows are already distinct: no dedupe pass
     } else {
         DT_REQUIRE(mark, "dt_adam_rows_step: null mark");
-        const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2;
+        // field-local LDS hashes run one workgroup per field: with few fields and a large batch they leave most of
+        // the chip idle (26 fields x 8192 lookups: 41 us against ~15 us for the global hash), so that case takes the
+        // global hash when the caller provided one
+        const bool few_blocks = fields < 64 && n_rows >= 65536 && slots && n_slots >= 2 * n_rows;
+        const bool field_local = fields > 0 && n_rows % fields == 0 && n_rows / fields <= kFieldSlots / 2 && !few_blocks;
         if (field_local) {
             const size_t lds = (size_t)kFieldSlots * 8 + kHotBytes;
             DT_UNSUPPORTED(D + 1 > kHotBytes / 4, "dt_adam_rows_step: D=%d too large", D);

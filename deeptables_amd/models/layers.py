@@ -77,14 +77,20 @@ class MultiheadAttention(Layer):
 
     def call(self, x, **kwargs):
         _ndim_check(x, 3)
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError('attention-weight dropout > 0 is not implemented in the HIP attention '
-                                      'kernel (the probabilities are never materialised); use dropout_rate=0.')
-        # The four projections read the same [B,F,D] block: one [D, 4D] GEMM (relu and bias fused) instead of four
-        # reads x once and quarters the launches; the Keras variables stay separate (dense_Q/K/V/residual).
+        rate = float(self.dropout_rate) if self.training else 0.0
+        # The four projections read the same [B,F,D] block: one [D, 4D] operand (relu and bias fused); the Keras
+        # variables stay separate (dense_Q/K/V/residual).
         projs = [self.dense_Q, self.dense_K, self.dense_V] + ([self.dense_residual] if self.use_residual else [])
         W_cat = torch.cat([p.kernel for p in projs], dim=1)
         b_cat = torch.cat([p.bias for p in projs], dim=0)
+        if ops.autoint_supported(x, self.num_heads):
+            # projections + attention + dropout + residual + relu in one launch per direction (csrc/autoint.hip)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rate > 0 else 0
+            outputs = ops.autoint_layer(x, W_cat, b_cat, self.num_heads, self.use_residual, rate, seed)
+            return self.batch_normalize(outputs)
+        if rate > 0:
+            raise NotImplementedError('attention-weight dropout > 0 needs the fused AutoInt layer kernel '
+                                      '(F <= 32 fields, embedding size 16 or 32, head width 4 / 8 / 16)')
         if x.is_cuda and ops.dense_supported(x, W_cat):
             y = ops.dense(x, W_cat, b_cat, 'relu')
             parts = list(ops.split_cols(y, self.num_units))  # column blocks of y: the attention kernel reads them in place

@@ -437,6 +437,72 @@ def mha_core(q, k, v, num_heads, grad_cols=3):
     return _MhaCore.apply(q, k, v, int(num_heads), int(grad_cols))
 
 
+# ------------------------------------------------------------------------------------------------
+# AutoInt interacting layer without its BatchNormalization — MultiheadAttention.call layers.py:119-150, one forward and
+# one backward launch on the fp32 matrix cores (csrc/autoint.hip); Q/K/V/residual never reach HBM
+# ------------------------------------------------------------------------------------------------
+def autoint_dropout_keep(seed, B, H, F, rate, device='cpu'):
+    """[B,H,F,F] keep-scale of the attention-weight dropout (0 or 1/(1-rate)) for `seed`: the counter hash of
+    csrc/autoint.hip restated with torch integer ops (tests rebuild the kernel's mask from it)."""
+    M32 = 0xFFFFFFFF
+    b = torch.arange(B, dtype=torch.int64, device=device).view(B, 1, 1, 1)
+    h = torch.arange(H, dtype=torch.int64, device=device).view(1, H, 1, 1)
+    i = torch.arange(F, dtype=torch.int64, device=device).view(1, 1, F, 1)
+    j = torch.arange(F, dtype=torch.int64, device=device).view(1, 1, 1, F)
+    x = (int(seed) & M32) ^ ((b * 0x9E3779B1) & M32) ^ (((h * 4096 + i * 64 + j) * 0x85EBCA77) & M32)
+    x = x ^ (x >> 16); x = (x * 0x7FEB352D) & M32; x = x ^ (x >> 15); x = (x * 0x846CA68B) & M32; x = x ^ (x >> 16)
+    thr = min(max(int(float(rate) * 4294967296.0), 1), 4294967295)
+    return (x >= thr).to(torch.float32) / (1.0 - float(rate))
+
+
+class _AutoIntLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wcat, bcat, num_heads, use_residual, dropout_rate, seed):
+        require_cuda(x, Wcat, bcat)
+        x, Wcat, bcat = _f32c(x), _f32c(Wcat), _f32c(bcat)
+        B, F, D = x.shape
+        a = torch.empty_like(x)
+        check(lib().dt_autoint_fwd(ptr(x), ptr(Wcat), ptr(bcat), B, F, D, num_heads, 1 if use_residual else 0,
+                                   float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, stream_ptr()),
+              'dt_autoint_fwd')
+        ctx.save_for_backward(x, Wcat, bcat, a)
+        ctx.cfg = (num_heads, use_residual, float(dropout_rate), int(seed) & 0xFFFFFFFF)
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wcat, bcat, a = ctx.saved_tensors
+        H, use_res, rate, seed = ctx.cfg
+        B, F, D = x.shape
+        M = Wcat.shape[1]
+        g = _f32c(g)
+        dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.empty((B * F, D), dtype=torch.float32, device=x.device) if need_x else None
+        check(lib().dt_autoint_bwd(ptr(x), ptr(Wcat), ptr(bcat), ptr(a), ptr(g), B, F, D, H, 1 if use_res else 0,
+                                   rate, seed, ptr(dY), ptr(gx), stream_ptr()), 'dt_autoint_bwd')
+        # grad_W = x^T dY and grad_b = colsum(dY) (batch reductions) on the Dense weight-gradient kernel; grad_x came
+        # out of the layer kernel
+        buf = torch.zeros(D * M + M, dtype=torch.float32, device=x.device)
+        gW, gb = buf[:D * M].view(D, M), buf[D * M:]
+        nbytes = lib().dt_dense_workspace_bytes(B * F, D, M)
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+        check(lib().dt_dense_bwd(ptr(x), ptr(Wcat), ptr(dY), ptr(dY), _lib.DT_ACT_LINEAR, B * F, D, M, None, ptr(gW),
+                                 ptr(gb), ptr(ws), stream_ptr()), 'dt_dense_bwd')
+        return (gx.view(B, F, D) if need_x else None), gW, gb, None, None, None, None
+
+
+def autoint_supported(x, num_heads):
+    return x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and \
+        bool(lib().dt_autoint_supported(int(x.shape[1]), int(x.shape[2]), int(num_heads)))
+
+
+def autoint_layer(x, Wcat, bcat, num_heads, use_residual=True, dropout_rate=0.0, seed=0):
+    """a = relu(multi-head field attention(relu-projections of x) [+ relu residual projection]) — layers.py:123-150.
+    Wcat [D, NP*D] = dense_Q | dense_K | dense_V [| dense_residual] kernels side by side, bcat their biases."""
+    return _AutoIntLayer.apply(x, Wcat, bcat, int(num_heads), bool(use_residual), float(dropout_rate), int(seed))
+
+
 class _SplitCols(torch.autograd.Function):
     """y [.., n*D] -> n column blocks [.., D] (views).  Backward: if the first incoming gradient already is column
     block 0 of a buffer laid out like y (what mha_core(grad_cols=n) hands back for q), the other blocks are copied

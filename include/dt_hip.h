@@ -242,6 +242,24 @@ int dt_dense_fwd(const float* x, const float* W, const float* bias, int act, int
 int dt_dense_bwd(const float* x, const float* W, const float* y, const float* grad_y, int act, int N, int K,
                  int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
 
+/* ---- AutoInt interacting layer (MultiheadAttention.call, layers.py:119-153) minus its BatchNormalization -------- *
+ * x [B,F,D]; Wcat [D, NP*D] = the kernels of dense_Q | dense_K | dense_V [| dense_residual] side by side, bcat [NP*D]
+ * their biases (NP = 4 with use_residual, else 3).  Forward: a [B,F,D] = relu(concat_h(softmax(Q_h K_h^T/sqrt(d_h)) V_h)
+ * + R) with Q,K,V,R = relu(x W + b); nothing else is written (lse may be NULL; [B,H,F] log-sum-exp when given).
+ * Backward: g = gradient w.r.t. a, a = the forward output; dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of the
+ * projections (dt_dense_bwd(x, Wcat, ., dY, DT_ACT_LINEAR, ..., grad_x = NULL) finishes grad_W / grad_b), and dX [B,F,D] =
+ * dY Wcat^T (may be NULL).  dropout_rate: Dropout on the
+ * attention weights (layers.py:141), keep-mask = dt_autoint_dropout_hash(seed, b, h, query, key) >= rate * 2^32,
+ * kept weights scaled by 1/(1-rate); pass 0 at inference.  fp32 MFMA (16x16x4); F <= 32, D in {16, 32}, d_h in {4, 8, 16}
+ * (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.                                           */
+int dt_autoint_supported(int F, int D, int H);
+unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j);
+int dt_autoint_fwd(const float* x, const float* Wcat, const float* bcat, int64_t B, int F, int D, int H,
+                   int use_residual, float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream);
+int dt_autoint_bwd(const float* x, const float* Wcat, const float* bcat, const float* a, const float* g, int64_t B,
+                   int F, int D, int H, int use_residual, float dropout_rate, unsigned seed, float* dY, float* dX,
+                   void* stream);
+
 /* ---- model-parallel tables: owner-side gather (parallel.ShardedEmbeddingStrategy; the role the sharded
  *      embedding_lookup of a parameter-server strategy plays) ------------------------------------------- *
  * idx_all [W,B,F] ids of all W minibatches; this rank owns fields [f_begin, f_end) of the packed table.

@@ -1,0 +1,86 @@
+# -*- coding:utf-8 -*-
+"""GPU: the fused AutoInt interacting layer (csrc/autoint.hip: projections + multi-head field attention + dropout on
+the attention weights + residual + relu in one launch per direction, fp32 MFMA) against a float64 torch restatement of
+MultiheadAttention.call, deeptables/models/layers.py:119-150 (the BatchNormalization of :151 is bn.hip's job and is
+covered by the layer / model tests)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(x, Wcat, bcat, H, use_residual, keep=None):
+    """layers.py:123-150 in float64.  keep [B,H,F,F]: scale of the attention-weight dropout (0 or 1/(1-rate))"""
+    B, F, D = x.shape
+    y = torch.relu(x @ Wcat + bcat)                                  # :123-127 (relu Dense Q | K | V | residual)
+    Q, K, V = y[..., :D], y[..., D:2 * D], y[..., 2 * D:3 * D]
+    dh = D // H
+    sp = lambda t: t.reshape(B, F, H, dh).permute(0, 2, 1, 3)        # :129-132 split heads
+    w = sp(Q) @ sp(K).transpose(-1, -2) / (dh ** 0.5)                # :134-137
+    w = torch.softmax(w, dim=-1)                                     # :139
+    if keep is not None:
+        w = w * keep                                                 # :141 Dropout on the weights
+    o = (w @ sp(V)).permute(0, 2, 1, 3).reshape(B, F, D)             # :143-145 merge heads
+    if use_residual:
+        o = o + y[..., 3 * D:]                                       # :147-148
+    return torch.relu(o)                                             # :150
+
+
+@pytest.mark.parametrize('B,F,D,H,res,rate', [(5, 26, 32, 4, True, 0.0), (64, 26, 32, 4, True, 0.0),
+                                              (33, 7, 16, 2, True, 0.0), (17, 32, 16, 4, False, 0.0),
+                                              (9, 1, 16, 1, True, 0.0), (40, 26, 32, 2, True, 0.0),
+                                              (31, 26, 32, 4, True, 0.3), (12, 13, 16, 4, False, 0.5)])
+def test_autoint_layer_matches_float64_reference(dev, B, F, D, H, res, rate):
+    from deeptables_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + F)
+    NP = 4 if res else 3
+    x = torch.randn(B, F, D, generator=g) * 0.7
+    W = torch.randn(D, NP * D, generator=g) * (1.5 / D ** 0.5)
+    b = torch.randn(NP * D, generator=g) * 0.2
+    go = torch.randn(B, F, D, generator=g)
+    seed = 12345 + B
+    assert ops.autoint_supported(x.to(dev), H)
+    xd, Wd, bd = (t.to(dev).requires_grad_(True) for t in (x, W, b))
+    a = ops.autoint_layer(xd, Wd, bd, H, res, rate, seed)
+    a.backward(go.to(dev))
+    keep = ops.autoint_dropout_keep(seed, B, H, F, rate).double() if rate > 0 else None
+    if keep is not None:           # the mask really drops about `rate` of the weights
+        assert abs(float((keep == 0).double().mean()) - rate) < 0.05
+    xr, Wr, br = (t.double().requires_grad_(True) for t in (x, W, b))
+    ar = reference(xr, Wr, br, H, res, keep)
+    ar.backward(go.double())
+
+    def rel(u, v):
+        return (u.detach().double().cpu() - v.detach()).abs().max().item() / max(v.detach().abs().max().item(), 1e-30)
+    assert rel(a, ar) < 1e-5, rel(a, ar)
+    assert rel(xd.grad, xr.grad) < 1e-4, rel(xd.grad, xr.grad)
+    assert rel(Wd.grad, Wr.grad) < 1e-4, rel(Wd.grad, Wr.grad)
+    assert rel(bd.grad, br.grad) < 1e-4, rel(bd.grad, br.grad)
+
+
+def test_dropout_hash_is_the_kernels(dev):
+    from deeptables_amd import ops
+    from deeptables_amd._lib import lib
+    k = ops.autoint_dropout_keep(77, 3, 2, 5, 0.25)
+    thr = int(0.25 * 4294967296.0)
+    for (b, h, i, j) in [(0, 0, 0, 0), (2, 1, 4, 3), (1, 0, 2, 4)]:
+        hv = lib().dt_autoint_dropout_hash(77, b, h, i, j)
+        assert (hv >= thr) == bool(k[b, h, i, j] > 0)
+
+
+def test_layer_with_dropout_trains_and_is_identity_at_inference(dev):
+    """MultiheadAttention with dropout_rate > 0 (layers.py:141) no longer raises; inference ignores the dropout"""
+    from deeptables_amd import functional
+    from deeptables_amd.models import layers as dl
+    functional.set_seed(3)
+    layer = dl.MultiheadAttention({'num_heads': 4, 'dropout_rate': 0.4, 'use_residual': True}, name='mha')
+    layer.build((None, 26, 32))
+    layer.to(dev)
+    x = torch.randn(16, 26, 32, device=dev, requires_grad=True)
+    layer.train()
+    y = layer(x)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    layer.eval()
+    y1, y2 = layer(x), layer(x)
+    assert torch.equal(y1, y2)
