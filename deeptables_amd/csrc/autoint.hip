@@ -40,6 +40,38 @@ __host__ __device__ inline float ai_keep(unsigned seed, unsigned thr, unsigned b
 
 __device__ __forceinline__ void ai_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// the kernels / biases of dense_Q | dense_K | dense_V [| dense_residual]: separate Keras variables ([D,D] and [D] each);
+// "Wcat[k][m]" below = W[m / D][k][m % D]
+struct AiW {
+    const float* W[4];
+    const float* b[4];
+};
+// optional BatchNormalization backward folded into the load of the incoming gradient (layers.py:151: the layer's output
+// is BN(a)): g_a = c1 (g_y - c2 - (a - mean) c3) with c1 = gamma rstd, c2 = sum_g / N, c3 = rstd sum_gx / N
+struct AiBn {
+    const float *gamma, *mean, *rstd, *sum_g, *sum_gx;   // gamma may be NULL (scale = False); mean == NULL: no BN
+    float inv_n;
+};
+template <int D>
+__device__ __forceinline__ float ai_w(const AiW& w, int k, int m) { return w.W[m / D][k * D + (m % D)]; }
+template <int D>
+__device__ __forceinline__ float ai_b(const AiW& w, int m) { return w.b[m / D][m % D]; }
+
+// reductions over the four lanes l, l^16, l^32, l^48 (the q groups of a 16x16x4 accumulator column) without LDS:
+// v_permlane16_swap exchanges odd 16-lane rows of one register with even rows of another, v_permlane32_swap the halves
+__device__ __forceinline__ float ai_qsum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float ai_qmax(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <int D, int DH>
 struct AiCfg {
     static constexpr int H = D / DH;
@@ -155,8 +187,7 @@ __device__ __forceinline__ void ai_apply(const ai_f4 (&p)[2][2], const float* ys
 }
 
 template <int D, int DH>
-__global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, const float* __restrict__ Wcat,
-                                                     const float* __restrict__ bcat, int B, int F, int NP,
+__global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, AiW w4, int B, int F, int NP,
                                                      float* __restrict__ out_a, float* __restrict__ lse_out,
                                                      unsigned drop_thr, float inv_keep, unsigned seed) {
     using C = AiCfg<D, DH>;
@@ -169,9 +200,9 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) {
         const int col = min(16 * ct + n, M - 1);
-        br[ct] = bcat[col];
+        br[ct] = ai_b<D>(w4, col);
 #pragma unroll
-        for (int t = 0; t < C::TK; ++t) wr[ct][t] = Wcat[(int64_t)(C::TK * q + t) * M + col];
+        for (int t = 0; t < C::TK; ++t) wr[ct][t] = ai_w<D>(w4, C::TK * q + t, col);
     }
     const float scale = 1.0f / sqrtf((float)DH);
     const int nwaves = gridDim.x * 4;
@@ -197,19 +228,17 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
                         st[J][I][r] = ok ? st[J][I][r] * scale : -3.0e38f;
                         m = fmaxf(m, st[J][I][r]);
                     }
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = ai_qmax(m);
                 float l = 0.f;
 #pragma unroll
                 for (int J = 0; J < 2; ++J)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = 16 * J + 4 * q + r < F ? expf(st[J][I][r] - m) : 0.f;
+                        const float e = 16 * J + 4 * q + r < F ? __expf(st[J][I][r] - m) : 0.f;
                         st[J][I][r] = e;
                         l += e;
                     }
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
+                l = ai_qsum(l);
                 const float inv = 1.0f / l;
                 const int i = 16 * I + n;
                 if (lse_out && q == 0 && i < F) lse_out[((int64_t)b * C::H + h) * F + i] = m + logf(l);
@@ -250,11 +279,13 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
 // dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of q | k | v [| residual] (the weight gradient x^T dY is a
 // batch reduction and stays dt_dense_bwd's); dX [B,F,D] = dY Wcat^T is formed here, from the slab.
 // 8 waves per block (two per SIMD); the weights live ONCE per block in LDS (wl [D][NP*D+4]), not in registers.
+// (Tried and dropped: x^T dY accumulated in-kernel — 64 accumulator registers per wave do not fit beside the head
+// loop at two waves per SIMD, and a block-shared LDS accumulator fed by ds_add_f32 ran at ~1 lane-atomic per 3 cycles:
+// 358 us against 189 + 42 us for this kernel + the Dense weight-gradient kernel.)
 template <int D, int DH>
-__global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, const float* __restrict__ Wcat,
-                                                     const float* __restrict__ bcat, const float* __restrict__ a,
+__global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                      const float* __restrict__ g, int B, int F, int NP,
-                                                     float* __restrict__ dY, float* __restrict__ dX,
+                                                     float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
                                                      unsigned drop_thr, float inv_keep, unsigned seed) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -267,11 +298,22 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
     float* stat = ys + 32 * C::YS;                         // [32] m | [32] 1/l | [32] delta  of the current head
     constexpr int GS = C::YS;
     const int M = NP * D;
-    for (int e = threadIdx.x; e < D * M; e += blockDim.x) wl[(e / M) * WS + (e % M)] = Wcat[e];
+    for (int e = threadIdx.x; e < D * M; e += blockDim.x) wl[(e / M) * WS + (e % M)] = ai_w<D>(w4, e / M, e % M);
     float br[D / 4];
 #pragma unroll
-    for (int ct = 0; ct < D / 4; ++ct) br[ct] = bcat[min(16 * ct + n, M - 1)];
+    for (int ct = 0; ct < D / 4; ++ct) br[ct] = ai_b<D>(w4, min(16 * ct + n, M - 1));
     __syncthreads();
+    // BN-backward constants of this lane's 4 channels (the float4 column of the g / a loads below is lane % (D/4))
+    ai_f4 bc1 = {1.f, 1.f, 1.f, 1.f}, bc2 = {0.f, 0.f, 0.f, 0.f}, bc3 = bc2, bmu = bc2;
+    if (bn.mean) {
+        const int c4 = lane % (D / 4);
+        const ai_f4 rs = *reinterpret_cast<const ai_f4*>(bn.rstd + 4 * c4);
+        const ai_f4 ga = bn.gamma ? *reinterpret_cast<const ai_f4*>(bn.gamma + 4 * c4) : bc1;
+        bmu = *reinterpret_cast<const ai_f4*>(bn.mean + 4 * c4);
+        bc1 = ga * rs;
+        bc2 = *reinterpret_cast<const ai_f4*>(bn.sum_g + 4 * c4) * bn.inv_n;
+        bc3 = rs * *reinterpret_cast<const ai_f4*>(bn.sum_gx + 4 * c4) * bn.inv_n;
+    }
     const float scale = 1.0f / sqrtf((float)DH);
     const int nwaves = gridDim.x * 8;
     float xa[2][C::TK];
@@ -286,8 +328,9 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
             const int i = e / (D / 4), c4 = e - i * (D / 4);
             gz[u] = ai_f4{0.f, 0.f, 0.f, 0.f};
             if (i < F) {
-                const ai_f4 gv = *reinterpret_cast<const ai_f4*>(g + ((int64_t)b * F + i) * D + 4 * c4);
+                ai_f4 gv = *reinterpret_cast<const ai_f4*>(g + ((int64_t)b * F + i) * D + 4 * c4);
                 const ai_f4 av = *reinterpret_cast<const ai_f4*>(a + ((int64_t)b * F + i) * D + 4 * c4);
+                if (bn.mean) gv = bc1 * (gv - bc2 - (av - bmu) * bc3);
                 gz[u] = ai_f4{av.x > 0.f ? gv.x : 0.f, av.y > 0.f ? gv.y : 0.f, av.z > 0.f ? gv.z : 0.f,
                               av.w > 0.f ? gv.w : 0.f};
             }
@@ -305,9 +348,10 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
                     const ai_f4 rv = *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 3 * D + 4 * c4);
                     const ai_f4 gv = gz[u];
                     rmask |= ((rv.x > 0.f ? 1u : 0u) | (rv.y > 0.f ? 2u : 0u) | (rv.z > 0.f ? 4u : 0u) | (rv.w > 0.f ? 8u : 0u)) << (4 * u);
-                    *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 3 * D + 4 * c4) =
-                        ai_f4{rv.x > 0.f ? gv.x : 0.f, rv.y > 0.f ? gv.y : 0.f, rv.z > 0.f ? gv.z : 0.f,
-                              rv.w > 0.f ? gv.w : 0.f};
+                    if (dY)
+                        *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 3 * D + 4 * c4) =
+                            ai_f4{rv.x > 0.f ? gv.x : 0.f, rv.y > 0.f ? gv.y : 0.f, rv.z > 0.f ? gv.z : 0.f,
+                                  rv.w > 0.f ? gv.w : 0.f};
                 }
             }
         }
@@ -356,19 +400,17 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
                         pt[J][I][r] = ok ? pt[J][I][r] * scale : -3.0e38f;
                         m = fmaxf(m, pt[J][I][r]);
                     }
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = ai_qmax(m);
                 float l = 0.f;
 #pragma unroll
                 for (int J = 0; J < 2; ++J)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = 16 * J + 4 * q + r < F ? expf(pt[J][I][r] - m) : 0.f;
+                        const float e = 16 * J + 4 * q + r < F ? __expf(pt[J][I][r] - m) : 0.f;
                         pt[J][I][r] = e;
                         l += e;
                     }
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
+                l = ai_qsum(l);
                 const float inv = 1.0f / l;
                 const int i = 16 * I + n;
                 float delta = 0.f;
@@ -382,8 +424,7 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
                         pt[J][I][r] = pv;
                         delta += pv * dpt[J][I][r];
                     }
-                delta += __shfl_xor(delta, 16, 64);
-                delta += __shfl_xor(delta, 32, 64);
+                delta = ai_qsum(delta);
                 if (q == 0) { stat[i] = m; stat[32 + i] = inv; stat[64 + i] = delta; }
 #pragma unroll
                 for (int J = 0; J < 2; ++J)
@@ -431,7 +472,7 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
 #pragma unroll
                     for (int J = 0; J < 2; ++J) {
                         const int j = 16 * J + n;
-                        const float pv = j < F ? expf(pn[I][J][r] * scale - m) * inv : 0.f;
+                        const float pv = j < F ? __expf(pn[I][J][r] * scale - m) * inv : 0.f;
                         const float keep = drop_thr ? ai_keep(seed, drop_thr, (unsigned)b, h, i, j, inv_keep) : 1.f;
                         pdrop[I][J][r] = i < F ? pv * keep : 0.f;
                         pn[I][J][r] = i < F ? pv * (dpn[I][J][r] * keep - delta) * scale : 0.f;            // dS[i][j]
@@ -479,8 +520,8 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
             }
             ai_fence();
         }
-        // dQ | dK | dV rows [F][3D] leave as whole rows
-        for (int e = lane; e < F * (3 * D / 4); e += 64) {
+        // dQ | dK | dV rows [F][3D] leave as whole rows (when the caller wants dY)
+        for (int e = lane; dY && e < F * (3 * D / 4); e += 64) {
             const int i = e / (3 * D / 4), c4 = e - i * (3 * D / 4);
             *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 4 * c4) =
                 *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
@@ -594,31 +635,52 @@ static bool ai_drop(float rate, unsigned* thr, float* inv_keep) {
     return true;
 }
 
-extern "C" int dt_autoint_fwd(const float* x, const float* Wcat, const float* bcat, int64_t B, int F, int D, int H,
-                              int use_residual, float dropout_rate, unsigned seed, float* out_a, float* lse,
-                              void* stream) {
+static bool ai_weights(const float* const* W, const float* const* b, int NP, AiW* w) {
+    for (int i = 0; i < 4; ++i) {
+        w->W[i] = i < NP ? W[i] : W[0];
+        w->b[i] = i < NP ? b[i] : b[0];
+        if (i < NP && (!W[i] || !b[i])) return false;
+    }
+    return true;
+}
+
+extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
+                              const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
+                              int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream) {
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
-    DT_REQUIRE(x && Wcat && bcat && out_a && B > 0 && B < (1LL << 31), "dt_autoint_fwd: null pointer / bad batch");
+    DT_REQUIRE(x && out_a && B > 0 && B < (1LL << 31), "dt_autoint_fwd: null pointer / bad batch");
+    const int NP = Wr ? 4 : 3;
+    const float* Ws[4] = {Wq, Wk, Wv, Wr};
+    const float* bs[4] = {bq, bk, bv, br};
+    AiW w4;
+    DT_REQUIRE(ai_weights(Ws, bs, NP, &w4), "dt_autoint_fwd: null weight pointer");
     unsigned thr; float inv_keep;
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_fwd: dropout_rate %f", dropout_rate);
     hipStream_t st = as_stream(stream);
-    const int NP = use_residual ? 4 : 3;
-    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, Wcat, bcat, (int)B, F, NP, out_a, lse, thr, inv_keep, seed);
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed);
     return launch_status("dt_autoint_fwd");
 }
 
-extern "C" int dt_autoint_bwd(const float* x, const float* Wcat, const float* bcat, const float* a, const float* g,
-                              int64_t B, int F, int D, int H, int use_residual, float dropout_rate, unsigned seed,
+extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
+                              const float* bq, const float* bk, const float* bv, const float* br, const float* a,
+                              const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
+                              const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
                               float* dY, float* dX, void* stream) {
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
-    DT_REQUIRE(x && Wcat && bcat && a && g && dY && B > 0 && B < (1LL << 31), "dt_autoint_bwd: null pointer / bad batch");
+    DT_REQUIRE(x && a && g && B > 0 && B < (1LL << 31), "dt_autoint_bwd: null pointer / bad batch");
+    const int NP = Wr ? 4 : 3;
+    const float* Ws[4] = {Wq, Wk, Wv, Wr};
+    const float* bs[4] = {bq, bk, bv, br};
+    AiW w4;
+    DT_REQUIRE(ai_weights(Ws, bs, NP, &w4), "dt_autoint_bwd: null weight pointer");
     unsigned thr; float inv_keep;
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_bwd: dropout_rate %f", dropout_rate);
     hipStream_t st = as_stream(stream);
-    const int NP = use_residual ? 4 : 3;
-    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, Wcat, bcat, a, g, (int)B, F,
-                   NP, dY, dX, thr, inv_keep, seed);
+    DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd: incomplete BatchNormalization arguments");
+    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
+    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, w4, a, g, (int)B, F, NP, dY,
+                   dX, bn, thr, inv_keep, seed);
     return launch_status("dt_autoint_bwd");
 }

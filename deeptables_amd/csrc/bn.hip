@@ -471,3 +471,26 @@ extern "C" int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C
                            grad_x);
     return launch_status("dt_bn_train_bwd");
 }
+
+/* The reduction half of dt_bn_train_bwd: sum_g[c] = sum_n grad_y, sum_gx[c] = sum_n grad_y * xhat (= grad_beta, grad_gamma),
+ * for a consumer that applies  grad_x = gamma rstd (grad_y - sum_g / N - xhat sum_gx / N)  itself while it reads
+ * grad_y anyway (dt_autoint_bwd).  sums: [2*C] = sum_g | sum_gx. */
+extern "C" int dt_bn_train_bwd_stats(const float* x, const float* grad_y, int N, int C, const float* save_mean,
+                                     const float* save_rstd, float* sums, float* grad_gamma, float* grad_beta, void* ws,
+                                     void* stream) {
+    DT_REQUIRE(N > 0 && C > 0, "dt_bn_train_bwd_stats: bad sizes");
+    DT_REQUIRE(x && grad_y && save_mean && save_rstd && sums && ws, "dt_bn_train_bwd_stats: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int chunks = bn_chunks(N);
+    const int rpc = ceil_div(N, chunks);
+    float* partial = reinterpret_cast<float*>(ws);
+    if (bn_vec4(N, C, {x, grad_y, save_mean, save_rstd, ws}))
+        hipLaunchKernelGGL(k_bn_bwd_stats_v4, dim3(chunks), dim3(kBnThreads), 8 * kBnThreads * sizeof(float), st, x, grad_y,
+                           N, C, bn_col_width4(C), rpc, save_mean, save_rstd, partial);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3(chunks), dim3(kBnThreads), 2 * kBnThreads * sizeof(float), st, x, grad_y, N,
+                           C, bn_col_width(C), rpc, save_mean, save_rstd, partial);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, chunks, C, sums, sums + C,
+                       grad_gamma, grad_beta);
+    return launch_status("dt_bn_train_bwd_stats");
+}

@@ -78,16 +78,21 @@ class MultiheadAttention(Layer):
     def call(self, x, **kwargs):
         _ndim_check(x, 3)
         rate = float(self.dropout_rate) if self.training else 0.0
-        # The four projections read the same [B,F,D] block: one [D, 4D] operand (relu and bias fused); the Keras
-        # variables stay separate (dense_Q/K/V/residual).
         projs = [self.dense_Q, self.dense_K, self.dense_V] + ([self.dense_residual] if self.use_residual else [])
+        if ops.autoint_supported(x, self.num_heads):
+            # projections + attention + dropout + residual + relu in one launch per direction (csrc/autoint.hip); the
+            # four Dense layers' variables are passed as they are (no concatenated copy, no gradient split)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rate > 0 else 0
+            bnl = self.batch_normalize
+            if self.training:        # BN with batch statistics rides along: its backward is folded into the layer's
+                return ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
+                                         batch_norm=(bnl.gamma, bnl.beta, bnl.moving_mean, bnl.moving_variance,
+                                                     bnl.epsilon, bnl.momentum))
+            outputs = ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed)
+            return bnl(outputs)
+        # generic shapes: one [D, 4D] GEMM (relu and bias fused) for the four projections + the attention core kernel
         W_cat = torch.cat([p.kernel for p in projs], dim=1)
         b_cat = torch.cat([p.bias for p in projs], dim=0)
-        if ops.autoint_supported(x, self.num_heads):
-            # projections + attention + dropout + residual + relu in one launch per direction (csrc/autoint.hip)
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rate > 0 else 0
-            outputs = ops.autoint_layer(x, W_cat, b_cat, self.num_heads, self.use_residual, rate, seed)
-            return self.batch_normalize(outputs)
         if rate > 0:
             raise NotImplementedError('attention-weight dropout > 0 needs the fused AutoInt layer kernel '
                                       '(F <= 32 fields, embedding size 16 or 32, head width 4 / 8 / 16)')

@@ -456,40 +456,77 @@ def autoint_dropout_keep(seed, B, H, F, rate, device='cpu'):
 
 
 class _AutoIntLayer(torch.autograd.Function):
+    """forward(x, num_heads, dropout_rate, seed, bn, *wb): wb = Wq, Wk, Wv[, Wr], bq, bk, bv[, br] (the Keras variables,
+    never concatenated).  bn = None -> returns a = relu(attention + residual); bn = (gamma, beta, moving_mean,
+    moving_var, eps, momentum) -> returns BatchNormalization(a) with batch statistics (layers.py:151), and the BN
+    backward is applied inside the layer's backward kernel while it reads the incoming gradient."""
+
     @staticmethod
-    def forward(ctx, x, Wcat, bcat, num_heads, use_residual, dropout_rate, seed):
-        require_cuda(x, Wcat, bcat)
-        x, Wcat, bcat = _f32c(x), _f32c(Wcat), _f32c(bcat)
+    def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, *wb):
+        require_cuda(x, *wb)
+        x = _f32c(x)
+        wb = [_f32c(t) for t in wb]
+        NP = len(wb) // 2
+        Ws, bs = wb[:NP] + [None] * (4 - NP), wb[NP:] + [None] * (4 - NP)
         B, F, D = x.shape
         a = torch.empty_like(x)
-        check(lib().dt_autoint_fwd(ptr(x), ptr(Wcat), ptr(bcat), B, F, D, num_heads, 1 if use_residual else 0,
+        check(lib().dt_autoint_fwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
                                    float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, stream_ptr()),
               'dt_autoint_fwd')
-        ctx.save_for_backward(x, Wcat, bcat, a)
-        ctx.cfg = (num_heads, use_residual, float(dropout_rate), int(seed) & 0xFFFFFFFF)
-        return a
+        ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, bn is not None)
+        if bn is None:
+            ctx.save_for_backward(x, a, *wb)
+            return a
+        moving_mean, moving_var, eps, momentum = bn
+        N = B * F
+        y = torch.empty_like(a)
+        mean = torch.empty((D,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((D,), dtype=torch.float32, device=x.device)
+        ws = _bn_ws(N, D, x.device)
+        check(lib().dt_bn_train_fwd(ptr(a), N, D, ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(moving_mean),
+                                    ptr(moving_var), ptr(y), ptr(mean), ptr(rstd), ptr(ws), stream_ptr()),
+              'dt_bn_train_fwd')
+        ctx.save_for_backward(x, a, *wb, mean, rstd, *([gamma] if gamma is not None else []))
+        ctx.has_affine = (gamma is not None, beta is not None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, Wcat, bcat, a = ctx.saved_tensors
-        H, use_res, rate, seed = ctx.cfg
+        H, NP, rate, seed, has_bn = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        x, a = saved[0], saved[1]
+        wb = saved[2:2 + 2 * NP]
+        Ws, bs = list(wb[:NP]) + [None] * (4 - NP), list(wb[NP:]) + [None] * (4 - NP)
         B, F, D = x.shape
-        M = Wcat.shape[1]
         g = _f32c(g)
-        dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
+        gamma = mean = rstd = sums = ggamma = gbeta = None
+        if has_bn:
+            mean, rstd = saved[2 + 2 * NP], saved[3 + 2 * NP]
+            gamma = saved[4 + 2 * NP] if ctx.has_affine[0] else None
+            sums = torch.empty((2 * D,), dtype=torch.float32, device=x.device)
+            ggamma = torch.empty((D,), dtype=torch.float32, device=x.device)
+            gbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+            ws = _bn_ws(B * F, D, x.device)
+            check(lib().dt_bn_train_bwd_stats(ptr(a), ptr(g), B * F, D, ptr(mean), ptr(rstd), ptr(sums), ptr(ggamma),
+                                              ptr(gbeta), ptr(ws), stream_ptr()), 'dt_bn_train_bwd_stats')
         need_x = ctx.needs_input_grad[0]
-        gx = torch.empty((B * F, D), dtype=torch.float32, device=x.device) if need_x else None
-        check(lib().dt_autoint_bwd(ptr(x), ptr(Wcat), ptr(bcat), ptr(a), ptr(g), B, F, D, H, 1 if use_res else 0,
-                                   rate, seed, ptr(dY), ptr(gx), stream_ptr()), 'dt_autoint_bwd')
-        # grad_W = x^T dY and grad_b = colsum(dY) (batch reductions) on the Dense weight-gradient kernel; grad_x came
-        # out of the layer kernel
+        gx = torch.empty_like(x) if need_x else None
+        M = NP * D
+        dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
+        check(lib().dt_autoint_bwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
+                                   rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dY), ptr(gx),
+                                   stream_ptr()), 'dt_autoint_bwd')
+        # kernel / bias gradients = x^T dY, colsum(dY): batch reductions on the Dense weight-gradient kernel (its W / y
+        # arguments are unused for a linear layer without grad_x)
         buf = torch.zeros(D * M + M, dtype=torch.float32, device=x.device)
-        gW, gb = buf[:D * M].view(D, M), buf[D * M:]
-        nbytes = lib().dt_dense_workspace_bytes(B * F, D, M)
-        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
-        check(lib().dt_dense_bwd(ptr(x), ptr(Wcat), ptr(dY), ptr(dY), _lib.DT_ACT_LINEAR, B * F, D, M, None, ptr(gW),
-                                 ptr(gb), ptr(ws), stream_ptr()), 'dt_dense_bwd')
-        return (gx.view(B, F, D) if need_x else None), gW, gb, None, None, None, None
+        gWc, gbc = buf[:D * M].view(D, M), buf[D * M:]
+        check(lib().dt_dense_bwd(ptr(x), ptr(dY), ptr(dY), ptr(dY), _lib.DT_ACT_LINEAR, B * F, D, M, None, ptr(gWc),
+                                 ptr(gbc), None, stream_ptr()), 'dt_dense_bwd')
+        gWs = gWc.view(D, NP, D).permute(1, 0, 2).contiguous()           # one copy: [NP][D][D], per-variable views
+        gW = [gWs[i] for i in range(NP)]
+        gb = [gbc[i * D:(i + 1) * D] for i in range(NP)]
+        return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
+                gbeta if has_bn and ctx.has_affine[1] else None, *gW, *gb)
 
 
 def autoint_supported(x, num_heads):
@@ -497,10 +534,18 @@ def autoint_supported(x, num_heads):
         bool(lib().dt_autoint_supported(int(x.shape[1]), int(x.shape[2]), int(num_heads)))
 
 
-def autoint_layer(x, Wcat, bcat, num_heads, use_residual=True, dropout_rate=0.0, seed=0):
+def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None):
     """a = relu(multi-head field attention(relu-projections of x) [+ relu residual projection]) — layers.py:123-150.
-    Wcat [D, NP*D] = dense_Q | dense_K | dense_V [| dense_residual] kernels side by side, bcat their biases."""
-    return _AutoIntLayer.apply(x, Wcat, bcat, int(num_heads), bool(use_residual), float(dropout_rate), int(seed))
+    kernels / biases: those of dense_Q, dense_K, dense_V[, dense_residual] (3 or 4 of each; [D,D] and [D]).
+    batch_norm = (gamma, beta, moving_mean, moving_var, eps, momentum): also applies the layer's training-mode
+    BatchNormalization (layers.py:151) and returns BN(a)."""
+    assert len(kernels) == len(biases) and len(kernels) in (3, 4)
+    if batch_norm is None:
+        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None,
+                                   *kernels, *biases)
+    gamma, beta, mm, mv, eps, momentum = batch_norm
+    return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), (mm, mv, float(eps), float(momentum)),
+                               gamma, beta, *kernels, *biases)
 
 
 class _SplitCols(torch.autograd.Function):

@@ -120,6 +120,9 @@ int dt_bn_infer_fwd(const float* x, int N, int C, const float* gamma, const floa
 int dt_bn_train_bwd(const float* x, const float* grad_y, int N, int C, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* grad_x,
                     float* grad_gamma, float* grad_beta, void* ws, void* stream);
+/* reduction half of dt_bn_train_bwd only: sums [2C] = sum_n grad_y | sum_n grad_y * xhat (also grad_beta / grad_gamma) */
+int dt_bn_train_bwd_stats(const float* x, const float* grad_y, int N, int C, const float* save_mean,
+                          const float* save_rstd, float* sums, float* grad_gamma, float* grad_beta, void* ws, void* stream);
 
 /* ---- a8  Cross.call  (models/layers.py:428-436) ------------------------------------------ *
  *   x [B,C]; w,b [L,C] (kernels_l / bias_l, each (C,1) in Keras, stacked)
@@ -243,22 +246,27 @@ int dt_dense_bwd(const float* x, const float* W, const float* y, const float* gr
                  int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
 
 /* ---- AutoInt interacting layer (MultiheadAttention.call, layers.py:119-153) minus its BatchNormalization -------- *
- * x [B,F,D]; Wcat [D, NP*D] = the kernels of dense_Q | dense_K | dense_V [| dense_residual] side by side, bcat [NP*D]
- * their biases (NP = 4 with use_residual, else 3).  Forward: a [B,F,D] = relu(concat_h(softmax(Q_h K_h^T/sqrt(d_h)) V_h)
- * + R) with Q,K,V,R = relu(x W + b); nothing else is written (lse may be NULL; [B,H,F] log-sum-exp when given).
- * Backward: g = gradient w.r.t. a, a = the forward output; dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of the
- * projections (dt_dense_bwd(x, Wcat, ., dY, DT_ACT_LINEAR, ..., grad_x = NULL) finishes grad_W / grad_b), and dX [B,F,D] =
- * dY Wcat^T (may be NULL).  dropout_rate: Dropout on the
- * attention weights (layers.py:141), keep-mask = dt_autoint_dropout_hash(seed, b, h, query, key) >= rate * 2^32,
- * kept weights scaled by 1/(1-rate); pass 0 at inference.  fp32 MFMA (16x16x4); F <= 32, D in {16, 32}, d_h in {4, 8, 16}
- * (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.                                           */
+ * x [B,F,D]; Wq/Wk/Wv/Wr [D,D] and bq/bk/bv/br [D]: kernels / biases of dense_Q, dense_K, dense_V, dense_residual
+ * (Wr = br = NULL: use_residual False).  Forward: a [B,F,D] = relu(concat_h(softmax(Q_h K_h^T/sqrt(d_h)) V_h) + R) with
+ * Q,K,V,R = relu(x W + b); nothing else is written (lse may be NULL; [B,H,F] log-sum-exp when given).
+ * Backward: g = gradient w.r.t. a, a = the forward output.  Outputs, each optional (NULL = not produced):
+ *   dX [B,F,D]; dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of q | k | v [| residual] (NP = 4 or 3), from which
+ *   dt_dense_bwd(x, ., ., dY, DT_ACT_LINEAR, .., grad_x = NULL) forms the kernel / bias gradients (batch reductions).
+ * bn_mean != NULL: g is the gradient w.r.t. the layer's BatchNormalization output y = BN(a) (layers.py:151) and the BN
+ * backward is applied while g is read: bn_gamma [D] (NULL = 1), bn_mean / bn_rstd [D] the saved batch statistics, bn_sums
+ * [2D] = sum_g | sum_gx from dt_bn_train_bwd_stats.
+ * dropout_rate: Dropout on the attention weights (layers.py:141), keep-mask = dt_autoint_dropout_hash(seed, b, h,
+ * query, key) >= rate * 2^32, kept weights scaled by 1/(1-rate); pass 0 at inference.  fp32 MFMA (16x16x4); F <= 32,
+ * D in {16, 32}, d_h in {4, 8, 16} (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.            */
 int dt_autoint_supported(int F, int D, int H);
 unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j);
-int dt_autoint_fwd(const float* x, const float* Wcat, const float* bcat, int64_t B, int F, int D, int H,
-                   int use_residual, float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream);
-int dt_autoint_bwd(const float* x, const float* Wcat, const float* bcat, const float* a, const float* g, int64_t B,
-                   int F, int D, int H, int use_residual, float dropout_rate, unsigned seed, float* dY, float* dX,
-                   void* stream);
+int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
+                   const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
+                   float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream);
+int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
+                   const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
+                   int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
+                   const float* bn_rstd, const float* bn_sums, float* dY, float* dX, void* stream);
 
 /* ---- model-parallel tables: owner-side gather (parallel.ShardedEmbeddingStrategy; the role the sharded
  *      embedding_lookup of a parameter-server strategy plays) ------------------------------------------- *

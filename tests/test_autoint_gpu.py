@@ -40,9 +40,13 @@ def test_autoint_layer_matches_float64_reference(dev, B, F, D, H, res, rate):
     go = torch.randn(B, F, D, generator=g)
     seed = 12345 + B
     assert ops.autoint_supported(x.to(dev), H)
-    xd, Wd, bd = (t.to(dev).requires_grad_(True) for t in (x, W, b))
-    a = ops.autoint_layer(xd, Wd, bd, H, res, rate, seed)
+    xd = x.to(dev).requires_grad_(True)
+    Ws = [W[:, i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+    bs = [b[i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+    a = ops.autoint_layer(xd, Ws, bs, H, rate, seed)
     a.backward(go.to(dev))
+    Wd_grad = torch.cat([w.grad for w in Ws], 1)
+    bd_grad = torch.cat([v.grad for v in bs], 0)
     keep = ops.autoint_dropout_keep(seed, B, H, F, rate).double() if rate > 0 else None
     if keep is not None:           # the mask really drops about `rate` of the weights
         assert abs(float((keep == 0).double().mean()) - rate) < 0.05
@@ -54,8 +58,8 @@ def test_autoint_layer_matches_float64_reference(dev, B, F, D, H, res, rate):
         return (u.detach().double().cpu() - v.detach()).abs().max().item() / max(v.detach().abs().max().item(), 1e-30)
     assert rel(a, ar) < 1e-5, rel(a, ar)
     assert rel(xd.grad, xr.grad) < 1e-4, rel(xd.grad, xr.grad)
-    assert rel(Wd.grad, Wr.grad) < 1e-4, rel(Wd.grad, Wr.grad)
-    assert rel(bd.grad, br.grad) < 1e-4, rel(bd.grad, br.grad)
+    assert rel(Wd_grad, Wr.grad) < 1e-4, rel(Wd_grad, Wr.grad)
+    assert rel(bd_grad, br.grad) < 1e-4, rel(bd_grad, br.grad)
 
 
 def test_dropout_hash_is_the_kernels(dev):
@@ -84,3 +88,30 @@ def test_layer_with_dropout_trains_and_is_identity_at_inference(dev):
     layer.eval()
     y1, y2 = layer(x), layer(x)
     assert torch.equal(y1, y2)
+
+
+def test_layer_with_fused_batchnorm_backward_equals_separate_kernels(dev):
+    """training mode: BN(a) with the BN backward folded into the layer's backward kernel == autoint_layer followed by
+    ops.batchnorm_train (bn.hip's three-kernel backward)"""
+    from deeptables_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, F, D, H = 48, 26, 32, 4
+    x = (torch.randn(B, F, D, generator=g) * 0.6).to(dev)
+    Ws = [(torch.randn(D, D, generator=g) * 0.25).to(dev) for _ in range(4)]
+    bs = [(torch.randn(D, generator=g) * 0.1).to(dev) for _ in range(4)]
+    gamma = (torch.rand(D, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(D, generator=g) * 0.1).to(dev)
+    go = torch.randn(B, F, D, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in [x] + Ws + bs + [gamma, beta]]
+        xx, W4, b4, ga, be = leaves[0], leaves[1:5], leaves[5:9], leaves[9], leaves[10]
+        mm, mv = torch.zeros(D, device=dev), torch.ones(D, device=dev)
+        if fused:
+            y = ops.autoint_layer(xx, W4, b4, H, 0.0, 0, batch_norm=(ga, be, mm, mv, 1e-3, 0.99))
+        else:
+            y = ops.batchnorm_train(ops.autoint_layer(xx, W4, b4, H, 0.0, 0), ga, be, mm, mv, 1e-3, 0.99)
+        y.backward(go)
+        res.append([y.detach()] + [t.grad for t in leaves] + [mm, mv])
+    for u, v in zip(*res):
+        assert (u - v).abs().max().item() <= 2e-5 * max(v.abs().max().item(), 1e-6) + 1e-7
