@@ -41,15 +41,38 @@ inline int launch_status(const char* what) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// ---- wave-level reductions (64 lanes, butterfly via DPP-lowered shuffles) -------------------
+// ---- wave-level reductions (64 lanes) without LDS -------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip per step; six dependent ones per wave_sum).  DPP
+// moves cover the steps inside a 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950) the two across rows.
+#define DT_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xf, 0xf, true))
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7 - i inside groups of 8
+constexpr int kDppMirror = 0x140;       // lane i <-> 15 - i inside rows of 16
+
+__device__ __forceinline__ float row_pair16(float v, bool is_max) {   // combine across the 16-lane rows and the halves
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = is_max ? fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])) : __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return is_max ? fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) : __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += DT_DPP_F(v, kDppXor1);
+    v += DT_DPP_F(v, kDppXor2);
+    v += DT_DPP_F(v, kDppHalfMirror);     // quads hold equal values: pairing quad 0 with quad 1 (mirrored) is enough
+    v += DT_DPP_F(v, kDppMirror);
+    return row_pair16(v, false);
 }
 // sum over the lanes that share (lane % group), i.e. strides group, 2*group, ... 32
 template <int GROUP>
 __device__ __forceinline__ float wave_sum_strided(float v) {
+    if (GROUP <= 16) {
+        // strides >= 16 first (exact lane pairing through the permlane swaps), then xor 8 / 4 / ... inside the row
+        v = row_pair16(v, false);
+#pragma unroll
+        for (int o = 8; o >= GROUP; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
 #pragma unroll
     for (int o = 32; o >= GROUP; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -57,14 +80,20 @@ __device__ __forceinline__ float wave_sum_strided(float v) {
 // sum inside aligned groups of GROUP consecutive lanes
 template <int GROUP>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (GROUP >= 2) v += DT_DPP_F(v, kDppXor1);
+    if (GROUP >= 4) v += DT_DPP_F(v, kDppXor2);
+    if (GROUP >= 8) v += DT_DPP_F(v, kDppHalfMirror);
+    if (GROUP >= 16) v += DT_DPP_F(v, kDppMirror);
+    if (GROUP == 32) v += __shfl_xor(v, 16, 64);
+    if (GROUP == 64) v = row_pair16(v, false);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, DT_DPP_F(v, kDppXor1));
+    v = fmaxf(v, DT_DPP_F(v, kDppXor2));
+    v = fmaxf(v, DT_DPP_F(v, kDppHalfMirror));
+    v = fmaxf(v, DT_DPP_F(v, kDppMirror));
+    return row_pair16(v, true);
 }
 
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() lowers to

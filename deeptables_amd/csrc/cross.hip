@@ -119,15 +119,17 @@ __global__ __launch_bounds__(256) void k_cross_bwd(
 
 // Register-accumulating variant for L <= LMAX: each wave keeps its grad_w / grad_b contributions in registers
 // across all of its rows and touches LDS once at the end (the generic kernel above does 2 LDS atomics per
-// (row, layer, column)).
+// (row, layer, column)).  x_0 .. x_{L-1} of a row are rebuilt ONCE, in forward order, into registers (LMAX * PER of
+// them) — round 1 rebuilt x_l from x_0 for every l (O(L^2) passes with an LDS bias read per element: 95 us at
+// B = 8192, C = 429, L = 6).
 template <int PER, int LMAX>
 __global__ __launch_bounds__(256) void k_cross_bwd_reg(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ save_s, const float* __restrict__ gout, int B, int C, int L,
     float* __restrict__ gx, float* __restrict__ partial /* [grid][2][L][C] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][L][C] accumulators, then [2][L][C] w|bias
-    float* wl = lds + (int64_t)2 * L * C;     // weights staged once per block: the layer loops below would
-    float* bl = wl + (int64_t)L * C;          // otherwise issue L^2 * PER global loads per row
+    float* wl = lds + (int64_t)2 * L * C;
+    float* bl = wl + (int64_t)L * C;
     for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) lds[i] = 0.f;
     for (int i = threadIdx.x; i < L * C; i += blockDim.x) { wl[i] = w[i]; bl[i] = bias[i]; }
     __syncthreads();
@@ -139,39 +141,37 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
 #pragma unroll
         for (int k = 0; k < PER; ++k) { gwa[l][k] = 0.f; gba[l][k] = 0.f; }
     for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
-        float x0[PER], g[PER], acc[PER], xl[PER], sv[LMAX];
+        float xs[LMAX][PER], g[PER], acc[PER], sv[LMAX];          // xs[l] = x_l (xs[0] = x_0)
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int col = k * 64 + lane;
-            x0[k] = col < C ? x[(int64_t)b * C + col] : 0.f;
+            xs[0][k] = col < C ? x[(int64_t)b * C + col] : 0.f;
             g[k] = col < C ? gout[(int64_t)b * C + col] : 0.f;
             acc[k] = 0.f;
         }
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) sv[l] = l < L ? save_s[(int64_t)b * L + l] : 0.f;
 #pragma unroll
+        for (int l = 1; l < LMAX; ++l) {
+            if (l >= L) break;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int col = k * 64 + lane;
+                xs[l][k] = col < C ? xs[0][k] * sv[l - 1] + xs[l - 1][k] + bl[(l - 1) * C + col] : 0.f;   // the forward's arithmetic
+            }
+        }
+#pragma unroll
         for (int l = LMAX - 1; l >= 0; --l) {
             if (l >= L) continue;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) xl[k] = x0[k];
-#pragma unroll
-            for (int m = 0; m < LMAX; ++m) {
-                if (m >= l) continue;
-#pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int col = k * 64 + lane;
-                    if (col < C) xl[k] = x0[k] * sv[m] + xl[k] + bl[m * C + col];
-                }
-            }
             float p = 0.f;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) p += g[k] * x0[k];
+            for (int k = 0; k < PER; ++k) p += g[k] * xs[0][k];
             const float t = wave_sum(p);
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int col = k * 64 + lane;
                 if (col < C) {
-                    gwa[l][k] += xl[k] * t;
+                    gwa[l][k] += xs[l][k] * t;
                     gba[l][k] += g[k];
                     acc[k] += g[k] * sv[l];
                     g[k] += wl[l * C + col] * t;
@@ -184,19 +184,26 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reg(
             if (col < C) gx[(int64_t)b * C + col] = g[k] + acc[k];
         }
     }
+    // the block's waves add their registers into the LDS accumulator ONE WAVE AT A TIME with plain read-modify-writes
+    // (LDS float atomics run at about one lane-atomic per three cycles on gfx950: 84 of them per lane cost more than
+    // the rows themselves)
+    for (int turn = 0; turn < wpb; ++turn) {
+        if ((int)(threadIdx.x >> 6) == turn) {
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-        if (l >= L) continue;
+            for (int l = 0; l < LMAX; ++l) {
+                if (l >= L) continue;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int col = k * 64 + lane;
-            if (col < C) {
-                atomicAdd(&lds[(int64_t)l * C + col], gwa[l][k]);
-                atomicAdd(&lds[(int64_t)(L + l) * C + col], gba[l][k]);
+                for (int k = 0; k < PER; ++k) {
+                    const int col = k * 64 + lane;
+                    if (col < C) {
+                        lds[(int64_t)l * C + col] += gwa[l][k];
+                        lds[(int64_t)(L + l) * C + col] += gba[l][k];
+                    }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* pp = partial + (int64_t)blockIdx.x * 2 * L * C;
     for (int i = threadIdx.x; i < 2 * L * C; i += blockDim.x) pp[i] = lds[i];
 }
@@ -230,9 +237,11 @@ static int cross_blocks(int B) {
     if (g > kCrossMaxBlocks) g = kCrossMaxBlocks;
     return g < 1 ? 1 : g;
 }
-static int cross_per(int C) {
-    int per = 1;
-    while (per * 64 < C) per <<= 1;
+static int cross_per(int C) {          // 64-column register slices per row: exact up to 8, powers of two beyond
+    const int need = ceil_div(C, 64);
+    if (need <= 8) return need;
+    int per = 16;
+    while (per < need) per <<= 1;
     return per;
 }
 
@@ -261,8 +270,8 @@ extern "C" int dt_cross_fwd(const float* x, const float* w, const float* b, int 
         hipLaunchKernelGGL((k_cross_fwd<P>), grid, block, 0, st, x, w, b, B, C, L, out, save_s); \
         break;
     switch (per) {
-        DT_CROSS_FWD(1) DT_CROSS_FWD(2) DT_CROSS_FWD(4) DT_CROSS_FWD(8) DT_CROSS_FWD(16)
-        DT_CROSS_FWD(32)
+        DT_CROSS_FWD(1) DT_CROSS_FWD(2) DT_CROSS_FWD(3) DT_CROSS_FWD(4) DT_CROSS_FWD(5) DT_CROSS_FWD(6) DT_CROSS_FWD(7)
+        DT_CROSS_FWD(8) DT_CROSS_FWD(16) DT_CROSS_FWD(32)
     }
 #undef DT_CROSS_FWD
     return launch_status("dt_cross_fwd");
@@ -286,7 +295,10 @@ extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, cons
     float* partial = reinterpret_cast<float*>(ws);
 #define DT_CROSS_BWD(P)                                                                               \
     case P:                                                                                           \
-        if (L <= 8 && P <= 8 && 2 * lds <= 64 * 1024)                                                 \
+        if (L <= 4 && P <= 8 && 2 * lds <= 64 * 1024)                                                 \
+            hipLaunchKernelGGL((k_cross_bwd_reg<(P <= 8 ? P : 8), 4>), grid, block, 2 * lds, st, x, w, b, \
+                               save_s, grad_out, B, C, L, grad_x, partial);                           \
+        else if (L <= 8 && P <= 8 && 2 * lds <= 64 * 1024)                                            \
             hipLaunchKernelGGL((k_cross_bwd_reg<(P <= 8 ? P : 8), 8>), grid, block, 2 * lds, st, x, w, b, \
                                save_s, grad_out, B, C, L, grad_x, partial);                           \
         else                                                                                          \
@@ -294,8 +306,8 @@ extern "C" int dt_cross_bwd(const float* x, const float* w, const float* b, cons
                                C, L, grad_x, partial);                                                \
         break;
     switch (per) {
-        DT_CROSS_BWD(1) DT_CROSS_BWD(2) DT_CROSS_BWD(4) DT_CROSS_BWD(8) DT_CROSS_BWD(16)
-        DT_CROSS_BWD(32)
+        DT_CROSS_BWD(1) DT_CROSS_BWD(2) DT_CROSS_BWD(3) DT_CROSS_BWD(4) DT_CROSS_BWD(5) DT_CROSS_BWD(6) DT_CROSS_BWD(7)
+        DT_CROSS_BWD(8) DT_CROSS_BWD(16) DT_CROSS_BWD(32)
     }
 #undef DT_CROSS_BWD
     if (L > 0 && (grad_w || grad_b))

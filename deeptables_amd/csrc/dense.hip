@@ -218,21 +218,28 @@ __global__ __launch_bounds__(256) void k_dense1_bwd(const float* __restrict__ x,
     }
 }
 
-// grad_w[k] += sum_blocks part[block][k]  (k == K: the bias)
+// grad_w[k] += sum_blocks part[block][k]  (k == K: the bias).  64 columns x 4 block-groups per workgroup, 16 loads in
+// flight per thread
 __global__ __launch_bounds__(256) void k_dense1_reduce(const float* __restrict__ part, int blocks, int K,
                                                        float* __restrict__ gw, float* __restrict__ gb) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > K) return;
-    const float* p = part + k;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
     const int64_t stride = K + 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = 0;
-    for (; i + 3 < blocks; i += 4) {
-        a0 += p[(int64_t)i * stride]; a1 += p[(int64_t)(i + 1) * stride];
-        a2 += p[(int64_t)(i + 2) * stride]; a3 += p[(int64_t)(i + 3) * stride];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k <= K) {
+        const float* p = part + k;
+        int i = grp;
+        for (; i + 60 < blocks; i += 64) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u & 3] += p[(int64_t)(i + 4 * u) * stride];
+        }
+        for (; i < blocks; i += 4) a[0] += p[(int64_t)i * stride];
     }
-    for (; i < blocks; ++i) a0 += p[(int64_t)i * stride];
-    const float v = (a0 + a1) + (a2 + a3);
+    red[grp][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (grp != 0 || k > K) return;
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     if (k < K) gw[k] += v;
     else if (gb) gb[0] += v;
 }
@@ -382,7 +389,7 @@ extern "C" int dt_dense_bwd(const float* x, const float* W, const float* y, cons
         float* part = reinterpret_cast<float*>(ws);
         hipLaunchKernelGGL(k_dense1_bwd, dim3(blocks), dim3(256), 0, st, x, W, y, grad_y, act, N, K, rpb, grad_x, part,
                            vec4);
-        hipLaunchKernelGGL(k_dense1_reduce, dim3(ceil_div(K + 1, 256)), dim3(256), 0, st, part, blocks, K, grad_W,
+        hipLaunchKernelGGL(k_dense1_reduce, dim3(ceil_div(K + 1, 64)), dim3(256), 0, st, part, blocks, K, grad_W,
                            grad_b);
         return launch_status("dt_dense_bwd(gemv)");
     }
