@@ -55,9 +55,10 @@ SIGNATURES = {
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr]),
     'dt_cin_layer_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32, _ptr,
+                                 _ptr, _ptr]),
     'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                 _ptr, _ptr, _ptr, _ptr]),
+                                 _c_f32, ctypes.c_uint32, _ptr, _ptr, _ptr, _ptr]),
     'dt_autoint_supported': (_c_int, [_c_int, _c_int, _c_int]),
     'dt_autoint_dropout_hash': (ctypes.c_uint32, [ctypes.c_uint32] * 5),
     'dt_autoint_fwd': (_c_int, [_ptr] * 9 + [_c_i64, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32, _ptr, _ptr, _ptr]),
@@ -105,6 +106,15 @@ SIGNATURES = {
 
 DT_IDX_F32, DT_IDX_I32 = 0, 1
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
+# keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)
+ACT_CODES = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3, 'elu': 4, 'selu': 5, 'softplus': 6, 'softsign': 7,
+             'exponential': 8}
+
+
+def act_code(name, what):
+    if name not in ACT_CODES:
+        raise ValueError(f'{what} activation {name!r}: the HIP kernels fuse {sorted(k for k in ACT_CODES if k)}')
+    return ACT_CODES[name]
 DT_OP_KERNEL = {'mat': 0, 'vec': 1, 'num': 2}
 
 _lib = None

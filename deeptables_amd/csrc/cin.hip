@@ -38,9 +38,6 @@ __host__ __device__ inline int cin_nb(int D) {  // batch rows an m-tile of 128 (
     return (kCinTileM % D == 0) ? kCinTileM / D : kCinTileM / D + 2;
 }
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    return act == DT_ACT_RELU ? fmaxf(v, 0.f) : v;
-}
 
 // copy the [nb] batch rows starting at b_first of x[B, F, D] (b stride `bstride`) into LDS slabs
 __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t bstride, int B, int F,
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
         if (mvalid && l < L) {
             const int64_t o = (b * L + l) * D + d;
             g = gy[o];
-            if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+            g *= act_grad_from_y(y[o], act);
         }
         G[t] = g;
     }
@@ -336,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
             if (r < rows && n0 + l < L) {
                 const int64_t o = ((b0 + bq) * L + n0 + l) * D + dq;
                 g = gy[o];
-                if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+                g *= act_grad_from_y(y[o], act);
             }
             gT[r * LPAD + l] = g;
         }
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(256) void k_cin_bias_grad(const float* __restrict__
         const int d = (int)(e % D);
         const int64_t o = (b * L + l) * D + d;
         float g = gy[o];
-        if (act == DT_ACT_RELU && !(y[o] > 0.f)) g = 0.f;
+        g *= act_grad_from_y(y[o], act);
         sacc += g;
     }
     sacc = wave_sum(sacc);
@@ -413,7 +410,7 @@ extern "C" int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W
     if (rc) return rc;
     if (B == 0) return DT_OK;
     DT_REQUIRE(x0 && xk && W && y, "dt_cin_layer_fwd: null pointer");
-    DT_REQUIRE(act == DT_ACT_LINEAR || act == DT_ACT_RELU, "dt_cin_layer_fwd: act %d", act);
+    DT_REQUIRE(act >= 0 && act < DT_ACT_COUNT, "dt_cin_layer_fwd: act %d", act);
     const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
                         2 * kCinKC * kCinTileN) * sizeof(float);
     DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd: tiles need %zu B of LDS (> 160 KiB)", lds);

@@ -96,6 +96,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return row_pair16(v, true);
 }
 
+// ---- keras.activations fused by the CIN / AFM kernels (codes: include/dt_hip.h) ----------------------------------
+constexpr float kSeluAlpha = 1.6732632423543772f, kSeluScale = 1.0507009873554805f;
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case DT_ACT_RELU: return fmaxf(v, 0.f);
+        case DT_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case DT_ACT_TANH: return tanhf(v);
+        case DT_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case DT_ACT_SELU: return kSeluScale * (v > 0.f ? v : kSeluAlpha * expm1f(v));
+        case DT_ACT_SOFTPLUS: return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+        case DT_ACT_SOFTSIGN: return v / (1.0f + fabsf(v));
+        case DT_ACT_EXPONENTIAL: return expf(v);
+        default: return v;
+    }
+}
+// d act / d pre-activation as a function of the OUTPUT y = act(v)
+__device__ __forceinline__ float act_grad_from_y(float y, int act) {
+    switch (act) {
+        case DT_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case DT_ACT_SIGMOID: return y * (1.f - y);
+        case DT_ACT_TANH: return 1.f - y * y;
+        case DT_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case DT_ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
+        case DT_ACT_SOFTPLUS: return 1.f - expf(-y);
+        case DT_ACT_SOFTSIGN: { const float t = 1.f - fabsf(y); return t * t; }
+        case DT_ACT_EXPONENTIAL: return y;
+        default: return 1.f;
+    }
+}
+
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() lowers to
 // `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e. it also drains every global load in flight; this form waits
 // for the LDS traffic alone, so operand prefetches issued before the barrier stay in flight across it.

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
             afm_att_preact<HMAX>(xr + pi[p] * D, xr + pj[p] * D, wa, bb, D, acc);
             float lg = 0.f;
 #pragma unroll
-            for (int h = 0; h < HMAX; ++h) lg += (act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h]) * pp[h];
+            for (int h = 0; h < HMAX; ++h) lg += act_apply(acc[h], act) * pp[h];
             sc[p] = lg;
             lmax = fmaxf(lmax, lg);
         }
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, co
             const float dlogit = sp * (ds - S);
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) {
-                const float a = act == DT_ACT_RELU ? fmaxf(acc[h], 0.f) : acc[h];
-                const float da = (act == DT_ACT_RELU && !(acc[h] > 0.f)) ? 0.f : dlogit * pp[h];
+                const float a = act_apply(acc[h], act);
+                const float da = dlogit * pp[h] * act_grad_from_y(a, act);
                 my_dp[h] += dlogit * a;
                 my_db[h] += da;
                 acc[h] = da;

@@ -13,6 +13,14 @@
 
 namespace dt {
 
+// attention-weight dropout (layers.py:141): the keep-mask hash of csrc/autoint.hip (same function, same seeds)
+__device__ __forceinline__ float mha_keep(unsigned seed, unsigned thr, unsigned b, unsigned h, unsigned i, unsigned j,
+                                          float inv_keep) {
+    unsigned x = seed ^ (b * 0x9E3779B1u) ^ ((h * 64u * 64u + i * 64u + j) * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >= thr ? inv_keep : 0.f;
+}
+
 template <int DHMAX, bool VEC4>
 struct RowIO {
     // load d_h floats of row `p` into r[]
@@ -58,7 +66,8 @@ __global__ __launch_bounds__(256) void k_mha_fwd(const float* __restrict__ q,
                                                  const float* __restrict__ k,
                                                  const float* __restrict__ v, int B, int F, int D,
                                                  int H, int ld, float scale, float* __restrict__ out,
-                                                 float* __restrict__ lse) {
+                                                 float* __restrict__ lse, unsigned drop_thr, float inv_keep,
+                                                 unsigned seed) {
     const int dh = D / H;
     const int64_t total = (int64_t)B * H * F;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,10 +91,11 @@ __global__ __launch_bounds__(256) void k_mha_fwd(const float* __restrict__ q,
         RowIO<DHMAX, VEC4>::load(k + ib + (int64_t)j * ld, dh, kr);
         const float p = expf(dotn<DHMAX>(qi, kr, dh) * scale - m);
         l += p;
+        const float pk = drop_thr ? p * mha_keep(seed, drop_thr, (unsigned)b, h, i, j, inv_keep) : p;
         RowIO<DHMAX, VEC4>::load(v + ib + (int64_t)j * ld, dh, kr);
 #pragma unroll
         for (int d = 0; d < DHMAX; ++d)
-            if (d < dh) acc[d] += p * kr[d];
+            if (d < dh) acc[d] += pk * kr[d];
     }
     const float inv = 1.0f / l;
 #pragma unroll
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ gout,
     int B, int F, int D, int H, int ld, int ldg, float scale, float* __restrict__ gq, float* __restrict__ gk,
-    float* __restrict__ gv) {
+    float* __restrict__ gv, unsigned drop_thr, float inv_keep, unsigned seed) {
     const int dh = D / H;
     const int64_t total = (int64_t)B * H * F;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,7 +136,8 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
         IO::load(k + ib + (int64_t)j * ld, dh, a0);
         IO::load(v + ib + (int64_t)j * ld, dh, a1);
         const float p = expf(dotn<DHMAX>(r0, a0, dh) * scale - lse_r);
-        const float ds = p * (dotn<DHMAX>(r1, a1, dh) - delta_r) * scale;
+        const float kp = drop_thr ? mha_keep(seed, drop_thr, (unsigned)b, h, r, j, inv_keep) : 1.f;
+        const float ds = p * (dotn<DHMAX>(r1, a1, dh) * kp - delta_r) * scale;
 #pragma unroll
         for (int d = 0; d < DHMAX; ++d)
             if (d < dh) a2[d] += ds * a0[d];
@@ -142,10 +153,11 @@ __global__ __launch_bounds__(256) void k_mha_bwd(
         IO::load(q + ib + (int64_t)i * ld, dh, a0);     // q_i
         IO::load(gout + base + (int64_t)i * D, dh, a1);  // dO_i
         const float p = expf(dotn<DHMAX>(a0, r0, dh) * scale - lse[lbase + i]);
-        const float dP = dotn<DHMAX>(a1, r1, dh);
+        const float kp = drop_thr ? mha_keep(seed, drop_thr, (unsigned)b, h, i, r, inv_keep) : 1.f;
+        const float dP = dotn<DHMAX>(a1, r1, dh) * kp;
 #pragma unroll
         for (int d = 0; d < DHMAX; ++d)
-            if (d < dh) r2[d] += p * a1[d];
+            if (d < dh) r2[d] += p * kp * a1[d];
         // delta_i = dO_i . O_i
         float oi[DHMAX];
 #pragma unroll
@@ -172,8 +184,23 @@ using namespace dt;
             hipLaunchKernelGGL((KERNEL<DHM, false>), grid, dim3(256), 0, st, __VA_ARGS__);        \
     } while (0)
 
+static bool mha_drop(float rate, unsigned* thr, float* inv_keep) {
+    *thr = 0; *inv_keep = 1.f;
+    if (rate <= 0.f) return true;
+    if (rate >= 1.f) return false;
+    double t = (double)rate * 4294967296.0;
+    *thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (*thr == 0) *thr = 1;
+    *inv_keep = 1.0f / (1.0f - rate);
+    return true;
+}
+
 extern "C" int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D,
-                               int H, int ld, float* out, float* lse, void* stream) {
+                               int H, int ld, float dropout_rate, unsigned seed, float* out, float* lse,
+                               void* stream) {
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(mha_drop(dropout_rate, &thr, &inv_keep), "dt_mha_core_fwd: dropout_rate %f", dropout_rate);
+    DT_REQUIRE(thr == 0 || F <= 64, "dt_mha_core_fwd: attention dropout supports up to 64 fields");
     DT_REQUIRE(ld >= D, "dt_mha_core_fwd: row stride %d < D=%d", ld, D);
     DT_REQUIRE(B >= 0 && F > 0 && D > 0 && H > 0 && D % H == 0,
                "dt_mha_core_fwd: bad sizes B=%d F=%d D=%d H=%d", B, F, D, H);
@@ -186,17 +213,20 @@ extern "C" int dt_mha_core_fwd(const float* q, const float* k, const float* v, i
     const int64_t total = (int64_t)B * H * F;
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = as_stream(stream);
-    if (dh <= 4) DT_MHA_LAUNCH(k_mha_fwd, 4, q, k, v, B, F, D, H, ld, scale, out, lse);
-    else if (dh <= 8) DT_MHA_LAUNCH(k_mha_fwd, 8, q, k, v, B, F, D, H, ld, scale, out, lse);
-    else if (dh <= 16) DT_MHA_LAUNCH(k_mha_fwd, 16, q, k, v, B, F, D, H, ld, scale, out, lse);
-    else if (dh <= 32) DT_MHA_LAUNCH(k_mha_fwd, 32, q, k, v, B, F, D, H, ld, scale, out, lse);
-    else DT_MHA_LAUNCH(k_mha_fwd, 64, q, k, v, B, F, D, H, ld, scale, out, lse);
+    if (dh <= 4) DT_MHA_LAUNCH(k_mha_fwd, 4, q, k, v, B, F, D, H, ld, scale, out, lse, thr, inv_keep, seed);
+    else if (dh <= 8) DT_MHA_LAUNCH(k_mha_fwd, 8, q, k, v, B, F, D, H, ld, scale, out, lse, thr, inv_keep, seed);
+    else if (dh <= 16) DT_MHA_LAUNCH(k_mha_fwd, 16, q, k, v, B, F, D, H, ld, scale, out, lse, thr, inv_keep, seed);
+    else if (dh <= 32) DT_MHA_LAUNCH(k_mha_fwd, 32, q, k, v, B, F, D, H, ld, scale, out, lse, thr, inv_keep, seed);
+    else DT_MHA_LAUNCH(k_mha_fwd, 64, q, k, v, B, F, D, H, ld, scale, out, lse, thr, inv_keep, seed);
     return launch_status("dt_mha_core_fwd");
 }
 
 extern "C" int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float* out,
                                const float* lse, const float* grad_out, int B, int F, int D, int H, int ld,
-                               int ldg, float* grad_q, float* grad_k, float* grad_v, void* stream) {
+                               int ldg, float dropout_rate, unsigned seed, float* grad_q, float* grad_k,
+                               float* grad_v, void* stream) {
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(mha_drop(dropout_rate, &thr, &inv_keep), "dt_mha_core_bwd: dropout_rate %f", dropout_rate);
     DT_REQUIRE(B >= 0 && F > 0 && D > 0 && H > 0 && D % H == 0 && ld >= D && ldg >= D, "dt_mha_core_bwd: bad sizes");
     if (B == 0) return DT_OK;
     DT_REQUIRE(q && k && v && out && lse && grad_out && grad_q && grad_k && grad_v,
@@ -209,12 +239,12 @@ extern "C" int dt_mha_core_bwd(const float* q, const float* k, const float* v, c
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = as_stream(stream);
     if (dh <= 4)
-        DT_MHA_LAUNCH(k_mha_bwd, 4, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 4, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v, thr, inv_keep, seed);
     else if (dh <= 8)
-        DT_MHA_LAUNCH(k_mha_bwd, 8, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 8, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v, thr, inv_keep, seed);
     else if (dh <= 16)
-        DT_MHA_LAUNCH(k_mha_bwd, 16, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 16, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v, thr, inv_keep, seed);
     else
-        DT_MHA_LAUNCH(k_mha_bwd, 32, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v);
+        DT_MHA_LAUNCH(k_mha_bwd, 32, q, k, v, out, lse, grad_out, B, F, D, H, ld, ldg, scale, grad_q, grad_k, grad_v, thr, inv_keep, seed);
     return launch_status("dt_mha_core_bwd");
 }

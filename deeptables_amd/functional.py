@@ -115,7 +115,7 @@ def get_activation(name):
     table = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid,
              'softmax': lambda t: torch.softmax(t, dim=-1), 'selu': torch.selu, 'elu': torch.nn.functional.elu,
              'softplus': torch.nn.functional.softplus, 'gelu': torch.nn.functional.gelu,
-             'swish': torch.nn.functional.silu}
+             'swish': torch.nn.functional.silu, 'softsign': torch.nn.functional.softsign, 'exponential': torch.exp}
     if name not in table:
         raise ValueError(f'Unknown activation: {name}')
     return table[name]

@@ -93,16 +93,14 @@ class MultiheadAttention(Layer):
         # generic shapes: one [D, 4D] GEMM (relu and bias fused) for the four projections + the attention core kernel
         W_cat = torch.cat([p.kernel for p in projs], dim=1)
         b_cat = torch.cat([p.bias for p in projs], dim=0)
-        if rate > 0:
-            raise NotImplementedError('attention-weight dropout > 0 needs the fused AutoInt layer kernel '
-                                      '(F <= 32 fields, embedding size 16 or 32, head width 4 / 8 / 16)')
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rate > 0 else 0
         if x.is_cuda and ops.dense_supported(x, W_cat):
             y = ops.dense(x, W_cat, b_cat, 'relu')
             parts = list(ops.split_cols(y, self.num_units))  # column blocks of y: the attention kernel reads them in place
         else:
             parts = [p(x) for p in projs]
         q, k, v = parts[0], parts[1], parts[2]
-        outputs = ops.mha_core(q, k, v, self.num_heads, grad_cols=len(parts))
+        outputs = ops.mha_core(q, k, v, self.num_heads, grad_cols=len(parts), dropout_rate=rate, seed=seed)
         if self.use_residual:
             outputs = outputs + parts[3]
         outputs = torch.relu(outputs)
@@ -292,8 +290,6 @@ class CIN(Layer):
 
     def call(self, x, **kwargs):
         _ndim_check(x, 3)
-        if self.activation not in ('relu', 'linear', None):
-            raise NotImplementedError(f'CIN activation {self.activation!r}: the HIP kernel fuses relu/linear only')
         hidden = x
         final_result = []
         n = len(self.cross_layer_size)
@@ -499,8 +495,6 @@ class AFM(Layer):
 
     def call(self, x, **kwargs):
         _ndim_check(x[0], 3)
-        if self.activation_function not in ('relu', 'linear', None):
-            raise NotImplementedError(f'AFM activation {self.activation_function!r}: the HIP kernel fuses relu/linear')
         xs = _stack_fields(x)
         attention_out = ops.afm_pool(xs, self.dense_attention.kernel, self.dense_attention.bias, self.attention_p,
                                      self.activation_function)

@@ -377,9 +377,7 @@ class _CinLayer(torch.autograd.Function):
 
 def cin_layer(x0, xk, W, bias=None, activation='relu'):
     """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias)."""
-    act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}.get(activation)
-    if act is None:
-        raise ValueError(f'CIN activation {activation!r} is not supported by the HIP kernel (relu/linear).')
+    act = _lib.act_code(activation, 'CIN')
     return _CinLayer.apply(x0, xk, W, bias, act)
 
 
@@ -399,7 +397,7 @@ def _row_stride(t, D):
 
 class _MhaCore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, H, grad_cols):
+    def forward(ctx, q, k, v, H, grad_cols, rate, seed):
         require_cuda(q, k, v)
         B, F, D = q.shape
         ctx.grad_cols = max(int(grad_cols), 3)
@@ -411,10 +409,10 @@ class _MhaCore(torch.autograd.Function):
             ld = lds.pop()
         out = torch.empty((B, F, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, H, F), dtype=torch.float32, device=q.device)
-        check(lib().dt_mha_core_fwd(ptr(q), ptr(k), ptr(v), B, F, D, H, ld, ptr(out), ptr(lse), stream_ptr()),
-              'dt_mha_core_fwd')
+        check(lib().dt_mha_core_fwd(ptr(q), ptr(k), ptr(v), B, F, D, H, ld, float(rate), int(seed) & 0xFFFFFFFF,
+                                    ptr(out), ptr(lse), stream_ptr()), 'dt_mha_core_fwd')
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.H, ctx.ld = H, ld
+        ctx.H, ctx.ld, ctx.drop = H, ld, (float(rate), int(seed) & 0xFFFFFFFF)
         return out
 
     @staticmethod
@@ -428,13 +426,15 @@ class _MhaCore(torch.autograd.Function):
         G = torch.empty((B, F, W), dtype=torch.float32, device=out.device)
         gq, gk, gv = G[..., :D], G[..., D:2 * D], G[..., 2 * D:3 * D]
         check(lib().dt_mha_core_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), B, F, D, ctx.H, ctx.ld,
-                                    W, ptr(gq), ptr(gk), ptr(gv), stream_ptr()), 'dt_mha_core_bwd')
-        return gq, gk, gv, None, None
+                                    W, ctx.drop[0], ctx.drop[1], ptr(gq), ptr(gk), ptr(gv), stream_ptr()),
+              'dt_mha_core_bwd')
+        return gq, gk, gv, None, None, None, None
 
 
-def mha_core(q, k, v, num_heads, grad_cols=3):
-    """grad_cols: width (in blocks of D) of the buffer the q/k/v gradients are laid out in (see split_cols)."""
-    return _MhaCore.apply(q, k, v, int(num_heads), int(grad_cols))
+def mha_core(q, k, v, num_heads, grad_cols=3, dropout_rate=0.0, seed=0):
+    """grad_cols: width (in blocks of D) of the buffer the q/k/v gradients are laid out in (see split_cols).
+    dropout_rate / seed: Dropout on the attention weights (layers.py:141), mask = autoint_dropout_keep(seed, ...)."""
+    return _MhaCore.apply(q, k, v, int(num_heads), int(grad_cols), float(dropout_rate), int(seed))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -678,7 +678,7 @@ class _AfmPool(torch.autograd.Function):
 
 def afm_pool(x, Wa, ba, pv, activation='relu'):
     """x [B,F,D] -> attention-pooled pair interactions [B,D]; Wa [D,H], ba [H]|None, pv [H] or [H,1]."""
-    act = {'relu': _lib.DT_ACT_RELU, 'linear': _lib.DT_ACT_LINEAR, None: _lib.DT_ACT_LINEAR}[activation]
+    act = _lib.act_code(activation, 'AFM')
     return _AfmPool.apply(x, Wa, ba, pv.reshape(-1), act)
 
 

@@ -42,6 +42,16 @@ extern "C" {
 
 #define DT_ACT_LINEAR 0
 #define DT_ACT_RELU 1
+/* keras.activations the CIN / AFM kernels also fuse (layers.py:709, :783 `Activation(name)`); each derivative is a
+ * function of the OUTPUT, so the backward needs no pre-activation: */
+#define DT_ACT_SIGMOID 2      /* y (1 - y) */
+#define DT_ACT_TANH 3         /* 1 - y^2 */
+#define DT_ACT_ELU 4          /* alpha = 1: y > 0 ? 1 : y + 1 */
+#define DT_ACT_SELU 5         /* y > 0 ? scale : y + scale alpha */
+#define DT_ACT_SOFTPLUS 6     /* 1 - exp(-y) */
+#define DT_ACT_SOFTSIGN 7     /* (1 - |y|)^2 */
+#define DT_ACT_EXPONENTIAL 8  /* y */
+#define DT_ACT_COUNT 9
 
 #define DT_OP_KERNEL_MAT 0
 #define DT_OP_KERNEL_VEC 1
@@ -179,12 +189,14 @@ int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const flo
  * lse [B,H,F] (log-sum-exp of each scaled score row) and the backward recomputes the
  * probabilities from q,k,lse and uses `out` for delta = rowsum(dO * O).
  * ld: distance in floats between consecutive field rows of q/k/v (D when contiguous; 4D when they are column
- * blocks of one fused [B,F,4D] projection output); ldg: the same for grad_q/grad_k/grad_v.        */
+ * blocks of one fused [B,F,4D] projection output); ldg: the same for grad_q/grad_k/grad_v.
+ * dropout_rate / seed: Dropout on the attention weights (layers.py:141) with the keep-mask of dt_autoint_dropout_hash
+ * (F <= 64 then); 0 at inference.                                                                   */
 int dt_mha_core_fwd(const float* q, const float* k, const float* v, int B, int F, int D, int H, int ld,
-                    float* out, float* lse, void* stream);
+                    float dropout_rate, unsigned seed, float* out, float* lse, void* stream);
 int dt_mha_core_bwd(const float* q, const float* k, const float* v, const float* out,
                     const float* lse, const float* grad_out, int B, int F, int D, int H, int ld, int ldg,
-                    float* grad_q, float* grad_k, float* grad_v, void* stream);
+                    float dropout_rate, unsigned seed, float* grad_q, float* grad_k, float* grad_v, void* stream);
 
 /* ---- a13 optimizer step (Keras Adam, models/deepmodel.py:321-322) ------------------------- *
  * Keras semantics: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).

@@ -130,6 +130,18 @@ def _activation(name):
         return torch.tanh
     if name == 'sigmoid':
         return torch.sigmoid
+    # keras.activations (keras/src/activations/activations.py) — the other names `Activation(name)` accepts in
+    # CIN (layers.py:709) / AFM (layers.py:783)
+    if name == 'elu':
+        return torch.nn.functional.elu                                  # alpha = 1
+    if name == 'selu':
+        return torch.selu                                               # scale 1.0507.., alpha 1.6733..
+    if name == 'softplus':
+        return torch.nn.functional.softplus                             # log(exp(x) + 1)
+    if name == 'softsign':
+        return torch.nn.functional.softsign                             # x / (|x| + 1)
+    if name == 'exponential':
+        return torch.exp
     raise ValueError(name)
 
 

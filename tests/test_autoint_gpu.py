@@ -115,3 +115,29 @@ def test_layer_with_fused_batchnorm_backward_equals_separate_kernels(dev):
         res.append([y.detach()] + [t.grad for t in leaves] + [mm, mv])
     for u, v in zip(*res):
         assert (u - v).abs().max().item() <= 2e-5 * max(v.abs().max().item(), 1e-6) + 1e-7
+
+
+@pytest.mark.parametrize('B,F,D,H,rate', [(21, 40, 24, 3, 0.3), (10, 26, 64, 4, 0.5), (7, 5, 12, 2, 0.0)])
+def test_generic_attention_core_with_dropout(dev, B, F, D, H, rate):
+    """shapes the fused layer kernel does not take (F > 32, D not 16/32) run Dense + the VALU attention core, which
+    applies the same keep-mask (layers.py:141)"""
+    from deeptables_amd import ops
+    g = torch.Generator().manual_seed(F)
+    q, k, v = (torch.relu(torch.randn(B, F, D, generator=g)) for _ in range(3))
+    go = torch.randn(B, F, D, generator=g)
+    assert not ops.autoint_supported(q.to(dev), H)
+    seed = 991
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.mha_core(qd, kd, vd, H, dropout_rate=rate, seed=seed)
+    out.backward(go.to(dev))
+    keep = ops.autoint_dropout_keep(seed, B, H, F, rate).double() if rate > 0 else None
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    dh = D // H
+    sp = lambda t: t.reshape(B, F, H, dh).permute(0, 2, 1, 3)
+    w = torch.softmax(sp(qr) @ sp(kr).transpose(-1, -2) / dh ** 0.5, dim=-1)
+    if keep is not None:
+        w = w * keep
+    ref = (w @ sp(vr)).permute(0, 2, 1, 3).reshape(B, F, D)
+    ref.backward(go.double())
+    for a, b_ in ((out, ref), (qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        assert (a.detach().double().cpu() - b_.detach()).abs().max().item() < 1e-4 * max(b_.detach().abs().max().item(), 1.0)

@@ -25,7 +25,10 @@ def maxerr(a, b):
 # kernels through the C-ABI wrappers
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B,F,D,H,act', [(64, 5, 8, 16, 'relu'), (300, 26, 16, 16, 'relu'), (33, 7, 12, 4, 'linear'),
-                                         (17, 3, 64, 40, 'relu'), (1, 2, 4, 1, 'relu')])
+                                         (17, 3, 64, 40, 'relu'), (1, 2, 4, 1, 'relu'), (40, 6, 8, 12, 'tanh'),
+                                         (40, 6, 8, 12, 'sigmoid'), (40, 6, 8, 12, 'elu'), (40, 6, 8, 12, 'selu'),
+                                         (40, 6, 8, 12, 'softplus'), (40, 6, 8, 12, 'softsign'),
+                                         (40, 6, 8, 12, 'exponential')])
 def test_afm_pool(dev, B, F, D, H, act):
     from deeptables_amd import ops
     from oracle import reference_layers as R

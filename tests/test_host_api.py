@@ -39,7 +39,7 @@ def test_argument_validation_without_a_gpu():
     assert b'dt_fm_fwd' in h.dt_last_error()
     assert h.dt_fm_fwd(None, 0, 3, 4, None, None) == 0            # empty batch is a no-op
     assert h.dt_embedding_fwd(None, 7, None, None, None, 4, 2, 8, None, None, None, None) == -1
-    assert h.dt_mha_core_fwd(None, None, None, 4, 3, 10, 3, 10, None, None, None) == -1    # D % H != 0
+    assert h.dt_mha_core_fwd(None, None, None, 4, 3, 10, 3, 10, 0.0, 0, None, None, None) == -1    # D % H != 0
     assert h.dt_bn_workspace_bytes(8192, 429) > 0 and h.dt_cross_workspace_bytes(8192, 429, 6) > 0
 
 

@@ -218,7 +218,11 @@ def test_outer_product(dev, B, F, D, kt):
 
 @pytest.mark.parametrize('B,F0,Hk,L,D,bias,act', [(5, 4, 4, 6, 3, False, 'relu'), (64, 26, 26, 128, 16, False, 'relu'),
                                                  (40, 26, 64, 128, 16, True, 'relu'), (9, 5, 7, 33, 8, True, 'linear'),
-                                                 (20, 6, 100, 200, 4, False, 'relu'), (16, 3, 2, 10, 10, False, 'relu')])
+                                                 (20, 6, 100, 200, 4, False, 'relu'), (16, 3, 2, 10, 10, False, 'relu'),
+                                                 (12, 5, 6, 40, 8, True, 'tanh'), (12, 5, 6, 40, 8, True, 'sigmoid'),
+                                                 (12, 5, 6, 40, 8, False, 'elu'), (12, 5, 6, 40, 8, True, 'selu'),
+                                                 (12, 5, 6, 40, 8, True, 'softplus'), (12, 5, 6, 40, 8, False, 'softsign'),
+                                                 (12, 5, 6, 40, 8, True, 'exponential')])
 def test_cin_layer(dev, B, F0, Hk, L, D, bias, act):
     from deeptables_amd import ops
     from oracle import closed_form as C
@@ -232,10 +236,12 @@ def test_cin_layer(dev, B, F0, Hk, L, D, bias, act):
     y = torch.einsum('bid,bjd,ijl->bld', x0r, xkr, Wr.reshape(F0, Hk, L))
     if bias:
         y = y + bvr[None, :, None]
-    ref = torch.relu(y) if act == 'relu' else y
-    np.testing.assert_allclose(ref.detach().numpy(),
-                               C.cin_layer(x0.numpy(), xk.numpy(), W.numpy(), None if bv is None else bv.numpy(), act == 'relu'),
-                               atol=1e-10)
+    from oracle import reference_layers as R
+    ref = R._activation(act)(y)        # keras `Activation(name)`, layers.py:709
+    if act in ('relu', 'linear'):
+        np.testing.assert_allclose(ref.detach().numpy(),
+                                   C.cin_layer(x0.numpy(), xk.numpy(), W.numpy(), None if bv is None else bv.numpy(),
+                                               act == 'relu'), atol=1e-10)
     (ref * up).sum().backward()
     x0d, xkd, Wd = (t.float().to(dev).requires_grad_(True) for t in (x0, xk, W))
     bd = bv.float().to(dev).requires_grad_(True) if bias else None
