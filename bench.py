@@ -106,8 +106,10 @@ class GraphedStep:
         self.graphs = {}
         self.use_graph = use_graph
         self.strategy = dm.config.distribute_strategy
-        self._dp = self.strategy is not None and self.strategy.world_size > 1
+        self._dp = self.strategy is not None and (self.strategy.world_size > 1 or getattr(self.strategy, 'force_dp', False))
         self.sparse_refs = {}
+        self._opt_graph = None      # data parallel: the optimizer step is a second captured graph, after the exchange
+        self._dp_steps = 0
 
     def _body(self, b):
         dm = self.dm
@@ -151,9 +153,23 @@ class GraphedStep:
         else:
             self._body(b)
         if self._dp:
+            # data parallel = two captured halves around the (eager) RCCL collectives: [fwd+bwd graph] -> dense
+            # all-reduce + sparse all-gather into persistent buffers -> [optimizer graph]
             self.strategy.exchange_gradients(self.dm.model, self.dm.optimizer if self.with_optimizer else None)
             if self.with_optimizer:
-                self.dm.optimizer.step()     # data parallel: after the gradient exchange, eager launches
+                sharded = getattr(self.dm.model, '_dt_sharded_step', False)
+                if self._opt_graph is not None:
+                    self._opt_graph.replay()
+                elif self.use_graph and not sharded and self._dp_steps >= 2:
+                    torch.cuda.synchronize()
+                    gopt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gopt):
+                        self.dm.optimizer.step()
+                    self._opt_graph = gopt
+                    gopt.replay()
+                else:
+                    self.dm.optimizer.step()     # first steps (slot buffers get allocated) and the sharded-table step
+            self._dp_steps += 1
 
 
 def time_steps(step, batches, steps, warmup, barrier):
@@ -329,15 +345,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the benchmarked configuration')
     ap.add_argument('--no-extras', action='store_true')
-    ap.add_argument('--tables', default='sharded', choices=['sharded', 'replicated'],
-                    help='N>1: embedding rows owned per field by one rank (all-to-all exchange) or replicated '
-                         'tables with a sparse all-gather')
+    ap.add_argument('--tables', default='replicated', choices=['replicated', 'sharded'],
+                    help='N>1: replicated tables + dense all-reduce + deduped sparse all-gather (the reference\'s '
+                         'MirroredStrategy shape, default) or embedding rows owned per field by one rank (all-to-all)')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='N=1: run the data-parallel step structure anyway (world size 1: collectives are no-ops)')
     ap.add_argument('--force-sharded', action='store_true', help='N=1: run the sharded-table step anyway (eager)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     strategy = None
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.force_dp:
         from deeptables_amd.parallel import DataParallelStrategy, ShardedEmbeddingStrategy
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -348,6 +366,8 @@ def main():
         strategy.assume_uniform_batches = True      # fixed batch per rank: no count exchange / host sync
         if args.force_sharded:
             strategy.force = True
+        if args.force_dp:
+            strategy.force_dp = True
         device = strategy.device
         rank = strategy.rank
     else:

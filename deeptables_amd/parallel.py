@@ -52,6 +52,41 @@ class DataParallelStrategy:
             dist.init_process_group(backend=backend, **kwargs)
         return cls(device=device)
 
+    # -- collectives that also work for device tensors under the gloo backend (staged through the host): lets the
+    #    whole train step be exercised with several processes on ONE GPU (tests/test_parallel_gpu.py) ------------
+    def _stage(self, t):
+        if not hasattr(self, '_host_staged'):
+            self._host_staged = dist.get_backend(self.group) == 'gloo'
+        return self._host_staged and t.is_cuda
+
+    def _all_reduce(self, t, async_op=False):
+        if self._stage(t):
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _all_gather_into(self, out, t):
+        if self._stage(t):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, t.detach().cpu().contiguous(), group=self.group)
+            out.copy_(h)
+            return
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+
+    def _persistent(self, tag, shape, dtype, device):
+        """a buffer that keeps its address from step to step (so the optimizer step that consumes the gathered
+        gradients can be captured in a hipGraph and replayed)"""
+        if not hasattr(self, '_bufs'):
+            self._bufs = {}
+        key = (tag, tuple(shape), dtype, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = b
+        return b
+
     # -- data ------------------------------------------------------------------------------------
     def shard(self, X, y):
         """AutoShardPolicy.DATA: rank r keeps rows r, r+W, r+2W, ... (deepmodel.py:92-95), truncated to the SAME
@@ -90,7 +125,7 @@ class DataParallelStrategy:
         if not grads or self.world_size == 1:
             return 0
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(flat)
         flat.div_(self.world_size)
         o = 0
         for g in grads:
@@ -99,19 +134,24 @@ class DataParallelStrategy:
             o += n
         return flat.numel()
 
-    def allgather_sparse(self, grad):
-        """SparseRowGrad -> SparseRowGrad of all ranks' rows (values pre-divided by world size)."""
+    def allgather_sparse(self, grad, tag=0):
+        """SparseRowGrad -> SparseRowGrad of all ranks' rows (values pre-divided by world size).  With
+        assume_uniform_batches the results live in persistent buffers (one set per `tag`)."""
         W = self.world_size
         if W == 1:
             return grad
         if self.assume_uniform_batches:
-            all_rows = torch.empty((W * grad.rows.numel(),), dtype=torch.int64, device=grad.rows.device)
-            all_vals = torch.empty((W * grad.values.shape[0], grad.values.shape[1]), dtype=grad.values.dtype,
-                                   device=grad.values.device)
-            dist.all_gather_into_tensor(all_rows, grad.rows.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(all_vals, (grad.values / W).contiguous(), group=self.group)
+            n, D = grad.rows.numel(), grad.values.shape[1]
+            dev = grad.rows.device
+            all_rows = self._persistent(('rows', tag), (W * n,), torch.int64, dev)
+            all_vals = self._persistent(('vals', tag), (W * n, D), grad.values.dtype, dev)
+            mine = self._persistent(('mine', tag), (n, D), grad.values.dtype, dev)
+            torch.div(grad.values.reshape(n, D), W, out=mine)
+            self._all_gather_into(all_rows, grad.rows.reshape(-1))
+            self._all_gather_into(all_vals, mine)
             return SparseRowGrad(all_rows, all_vals)
-        n = torch.tensor([grad.rows.numel()], dtype=torch.int64, device=grad.rows.device)
+        cdev = 'cpu' if dist.get_backend(self.group) == 'gloo' else grad.rows.device
+        n = torch.tensor([grad.rows.numel()], dtype=torch.int64, device=cdev)
         counts = [torch.zeros_like(n) for _ in range(W)]
         dist.all_gather(counts, n, group=self.group)
         counts = [int(c.item()) for c in counts]
@@ -123,8 +163,8 @@ class DataParallelStrategy:
         vals[:counts[self.rank]] = grad.values / W
         all_rows = torch.empty((W * nmax,), dtype=torch.int64, device=rows.device)
         all_vals = torch.empty((W * nmax, D), dtype=vals.dtype, device=vals.device)
-        dist.all_gather_into_tensor(all_rows, rows, group=self.group)
-        dist.all_gather_into_tensor(all_vals, vals, group=self.group)
+        self._all_gather_into(all_rows, rows)
+        self._all_gather_into(all_vals, vals)
         return SparseRowGrad(all_rows, all_vals)     # padded entries carry row -1 and are skipped
 
     def exchange_gradients(self, model, optimizer=None):
@@ -136,7 +176,7 @@ class DataParallelStrategy:
         if flat is not None:
             # the fused train step already keeps every dense gradient in ONE contiguous buffer: all-reduce it in
             # place (async, overlapped with the sparse all-gathers below), no bucket copy in or out
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = self._all_reduce(flat, async_op=True)
             base = flat.untyped_storage().data_ptr()
             rest = [p for p in model.parameters() if p.requires_grad and p.grad is not None and
                     p.grad.untyped_storage().data_ptr() != base]     # e.g. a small table's dense gradient
@@ -144,12 +184,18 @@ class DataParallelStrategy:
                 self.allreduce_dense(rest)
         else:
             self.allreduce_dense([p for p in model.parameters() if p.requires_grad])
+        tag = 0
         for layer in model.modules():
             if isinstance(layer, MultiColumnEmbedding):
                 for key, grads in list(layer.sparse_grads.items()):
-                    layer.sparse_grads[key] = [self.allgather_sparse(g) for g in grads]
+                    out = []
+                    for g in grads:
+                        out.append(self.allgather_sparse(g, tag))
+                        tag += 1
+                    layer.sparse_grads[key] = out
         if work is not None:
             work.wait()
+        if flat is not None:
             flat.div_(self.world_size)
 
 
