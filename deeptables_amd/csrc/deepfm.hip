@@ -66,6 +66,28 @@ __host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F,
 //      flags[owner], zeroes the owner's gradient row and reports row -1.
 //   G: owners without duplicates store their gradient row; owners with duplicates and the duplicates themselves
 //      atomicAdd into the owner's row; owners clear their hash slot and flag, so the workspace is all-zero again.
+// embedding_dropout (config.py:84; SpatialDropout1D on every [B,1,D] embedding, layers.py:878-880 = element dropout with
+// 1/(1-p) scaling): keep-mask from a counter hash of (seed, batch row, packed column f*D+d), the same in kernel A
+// (values) and kernel D (gradients).  The seed lives on the device and is advanced by kernel D, so a captured graph of
+// the step draws a new mask at every replay.
+struct EmbDrop {
+    unsigned thr;            // drop iff hash < thr; 0 = no dropout
+    float inv_keep;
+    unsigned* seed;          // device word
+};
+__host__ __device__ inline unsigned emb_drop_hash(unsigned seed, unsigned b, unsigned col) {
+    unsigned x = seed ^ (b * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float4 emb_drop4(float4 v, unsigned seed, unsigned thr, float inv_keep, unsigned b, unsigned col) {
+    v.x = emb_drop_hash(seed, b, col) >= thr ? v.x * inv_keep : 0.f;
+    v.y = emb_drop_hash(seed, b, col + 1) >= thr ? v.y * inv_keep : 0.f;
+    v.z = emb_drop_hash(seed, b, col + 2) >= thr ? v.z * inv_keep : 0.f;
+    v.w = emb_drop_hash(seed, b, col + 3) >= thr ? v.w * inv_keep : 0.f;
+    return v;
+}
+
 struct DedupeWs {
     unsigned long long* slots;   // [1 << slots_log2], zero outside a step
     int slots_log2;
@@ -87,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
     int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial, DedupeWs dd,
-    float* __restrict__ grad_rows, float* __restrict__ S_out) {
+    float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop) {
     __shared__ __attribute__((aligned(16))) float rowbuf[kRowsPerBlockA][kMaxC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & (LPR - 1);
@@ -138,6 +160,14 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
                     rows_out[occ] = row_w;
                     if (!ok && oob) atomicAdd(oob, 1);
                 }
+            }
+        }
+        if (drop.thr) {
+            const unsigned seed = *drop.seed;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = lane + 64 * t;
+                if (j < NV) v[t] = emb_drop4(v[t], seed, drop.thr, drop.inv_keep, (unsigned)b, (unsigned)(4 * j));
             }
         }
         const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
@@ -913,7 +943,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
                                                        MlpParams p, const float* __restrict__ wlin, DeepFmDims dm,
                                                        const float* __restrict__ accum, DeepFmAccum al,
                                                        float* __restrict__ grad_rows, DedupeWs dd, float grad_scale,
-                                                       int field_major, unsigned long long* stamps) {
+                                                       int field_major, EmbDrop drop, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
     constexpr int HS = kH1 + kPad, NT = 512;
@@ -1088,6 +1118,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
 
     // ---- the tile's row gradients leave as whole rows (16-byte lanes); duplicates of the step's row dedupe add
     //      into their owner's row, owners clear their hash slot and flag ----
+    const unsigned dseed = drop.thr ? *drop.seed : 0u;
     const int fq = FD >> 2;                                       // float4 per row
     float* tile_rows = grad_rows + (int64_t)m0 * FD;
     for (int e = tid; e < kTM * fq; e += NT) {
@@ -1096,6 +1127,11 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         if (b >= dm.B) continue;
         const int col = 4 * q, f = col >> dshift, d = col & (dm.D - 1);
         floatx4 o = ld4(xs + row * XS + col);
+        if (drop.thr) {          // gradient through the dropped embedding: the same keep-mask as the forward
+            float4 t4 = make_float4(o.x, o.y, o.z, o.w);
+            t4 = emb_drop4(t4, dseed, drop.thr, drop.inv_keep, (unsigned)b, (unsigned)col);
+            o = floatx4{t4.x, t4.y, t4.z, t4.w};
+        }
         if (field_major) {       // model-parallel tables: [F,B,D], already divided by the world size
             st4(grad_rows + (((int64_t)f * dm.B + b) << dshift) + d, o * grad_scale);
             continue;
@@ -1123,6 +1159,9 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     }
     DT_STAMP(stamps, 3);
 }
+
+// advances the dropout seed once per step (after kernel D: every reader of this step's value has finished)
+__global__ void k_emb_drop_advance(unsigned* seed) { *seed = *seed * 1664525u + 1013904223u; }
 
 }  // namespace dt
 
@@ -1203,6 +1242,8 @@ extern "C" int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11) {
     return DT_OK;
 }
 
+extern "C" unsigned dt_deepfm_dropout_hash(unsigned seed, unsigned b, unsigned col) { return emb_drop_hash(seed, b, col); }
+
 extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
     int64_t s = 1024;
     while (s < 8LL * B * F) s <<= 1;   // load <= 1/8 keeps the serialised probe chains short
@@ -1221,7 +1262,7 @@ extern "C" int dt_deepfm_train_step(
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
-    void* stream) {
+    float embedding_dropout, unsigned* dropout_seed, void* stream) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
@@ -1259,6 +1300,15 @@ extern "C" int dt_deepfm_train_step(
         hipMemsetAsync(ws + wl.X + (int64_t)B * dm.CP, 0, (size_t)pad * dm.CP * sizeof(float), st);
         hipMemsetAsync(ws + wl.dH1 + (int64_t)B * kH1, 0, (size_t)pad * kH1 * sizeof(float), st);
     }
+    EmbDrop drop{0u, 1.f, dropout_seed};
+    if (embedding_dropout > 0.f) {
+        DT_REQUIRE(embedding_dropout < 1.f && dropout_seed, "dt_deepfm_train_step: embedding_dropout %f needs a rate < 1 and "
+                                                             "the device seed word", embedding_dropout);
+        const double t = (double)embedding_dropout * 4294967296.0;
+        drop.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        if (drop.thr == 0) drop.thr = 1;
+        drop.inv_keep = 1.0f / (1.0f - embedding_dropout);
+    }
     static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
     unsigned long long* stamps = stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
 
@@ -1266,7 +1316,7 @@ extern "C" int dt_deepfm_train_step(
 #define DT_A(KIND, L)                                                                                        \
     hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), 0, st, idx, (const float4*)table, \
                        row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, rows_out,    \
-                       oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S)
+                       oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S, drop)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
@@ -1323,8 +1373,9 @@ extern "C" int dt_deepfm_train_step(
                              ((F + 3) & ~3) + 2 * kTM * F) * sizeof(float);
         hipFuncSetAttribute((const void*)k_dx_sparse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
         hipLaunchKernelGGL(k_dx_sparse_bwd, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz, ws + wl.S,
-                           mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
+                           mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major, drop,
                            stamps ? stamps + (int64_t)tiles * 16 : nullptr);
+        if (drop.thr) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else {
         // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
         hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,

@@ -37,7 +37,9 @@ class FusedDeepFM:
                 return False
             if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
                 return False
-            if c.stacking_op != consts.STACKING_OP_ADD or c.embedding_dropout or c.dense_dropout:
+            if c.stacking_op != consts.STACKING_OP_ADD or c.dense_dropout:
+                return False
+            if not (0 <= float(c.embedding_dropout or 0) < 1):
                 return False
             hu = tuple(tuple(h) for h in c.dnn_params.get('hidden_units', ()))
             if hu != ((128, 0, False), (64, 0, False)) or c.dnn_params.get('activation', 'relu') != 'relu':
@@ -55,7 +57,7 @@ class FusedDeepFM:
             D = emb.groups[0][0]
             F = len(emb.input_dims)
             Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
-            return bool(lib().dt_deepfm_supported(8192, F, D, Nd, 128, 64))
+            return bool(lib().dt_deepfm_supported(max(int(getattr(dm, '_batch_hint', 0) or 0), 1), F, D, Nd, 128, 64))
         except Exception:
             return False
 
@@ -96,6 +98,11 @@ class FusedDeepFM:
         if self.out.bias is not None:
             self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
         self.loss_view = a[o['loss']:o['loss'] + 1]
+        # embedding_dropout (config.py:84): element dropout inside the step's kernels; the seed word lives on the device
+        # and is advanced by the step (a captured graph draws a new mask at every replay)
+        self.emb_dropout = float(dm.config.embedding_dropout or 0)
+        seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+        self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         # duplicate lookups are resolved inside the step (kernels A and G) unless DT_AMD_FUSED_DEDUPE=0
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
         # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
@@ -183,7 +190,8 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 1.0 / W, 1, 2, stream_ptr()), 'dt_deepfm_train_step')
+            None, None, 0, 1.0 / W, 1, 2, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
         # the loss is a mean over the LOCAL minibatch, the global objective the mean over W of them: kernel G already
@@ -221,7 +229,8 @@ class FusedDeepFM:
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
             ptr(buf['dedupe']) if (backward and self.dedupe) else None, buf['dedupe_slots'], 1.0, 0,
-            2 if backward else 1, stream_ptr()), 'dt_deepfm_train_step')
+            2 if backward else 1, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g

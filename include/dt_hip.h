@@ -355,7 +355,13 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
                          const float* w3, const float* w_out, const float* b_out, float* logit_out,
                          int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
                          int* oob_count, void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale,
-                         int grad_rows_field_major, int phases, void* stream);
+                         int grad_rows_field_major, int phases, float embedding_dropout, unsigned* dropout_seed,
+                         void* stream);
+/* embedding_dropout > 0 (ModelConfig.embedding_dropout, config.py:84: SpatialDropout1D on every [B,1,D] embedding =
+ * element dropout scaled by 1/(1-p)): element (b, f, d) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b, f*D+d) >=
+ * p * 2^32.  *dropout_seed is a DEVICE word, advanced by the step itself (so a captured graph draws a fresh mask at every
+ * replay); pass 0 / NULL at inference. */
+unsigned dt_deepfm_dropout_hash(unsigned seed, unsigned b, unsigned col);
 
 #ifdef __cplusplus
 }

@@ -200,3 +200,69 @@ def test_sharded_embedding_step_single_rank_equals_plain(dev):
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
         dist.destroy_process_group()
+
+
+def _emb_keep(seed, B, F, D, rate):
+    """the keep-scale [B, F*D] of the fused step's embedding dropout for `seed` (csrc/deepfm.hip emb_drop_hash, numpy)"""
+    b = np.arange(B, dtype=np.uint64)[:, None]
+    col = np.arange(F * D, dtype=np.uint64)[None, :]
+    M = np.uint64(0xFFFFFFFF)
+    x = (np.uint64(seed) ^ ((b * np.uint64(0x9E3779B1)) & M) ^ ((col * np.uint64(0x85EBCA77)) & M)) & M
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M
+    x ^= x >> np.uint64(16)
+    thr = np.uint64(int(rate * 4294967296.0))
+    return (x >= thr).astype(np.float64) / (1.0 - rate)
+
+
+def test_fused_step_with_embedding_dropout_matches_oracle_with_the_same_mask(dev):
+    """ModelConfig.embedding_dropout = 0.3 is the REFERENCE DEFAULT (config.py:84): the graph stays on the fused plan;
+    SpatialDropout1D on (B,1,D) (layers.py:878-880, :900-902) = element dropout with 1/(1-p) scaling"""
+    from deeptables_amd import functional
+    from deeptables_amd._lib import lib
+    from deeptables_amd.models import ModelConfig, DeepModel, deepnets
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    from oracle import bridge, reference_layers as R
+    F, Nd, D, B, rate = 26, 13, 16, 96, 0.3
+    functional.set_seed(5)
+    conf = ModelConfig(nets=deepnets.DeepFM, fixed_embedding_dim=True, embeddings_output_dim=D, embedding_dropout=rate,
+                       metrics=['AUC'])
+    cats = [CategoricalColumn(f'C{i}', 40 + i, D) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])]
+    dm = DeepModel('binary', 2, conf, cats, conts)
+    dm.build()
+    plan = dm.fused_plan()
+    assert plan is not None, 'the reference-default embedding_dropout must stay on the fused plan'
+    idx, dense, y = batch(cats, Nd, B)
+    seed = 0x1234567
+    plan.drop_seed.fill_(seed)
+    thr = int(0.5 * 4294967296.0)
+    assert (lib().dt_deepfm_dropout_hash(seed, 3, 17) >= thr) == bool(_emb_keep(seed, 4, 2, 16, 0.5)[3, 17] > 0)
+    keep = torch.from_numpy(_emb_keep(seed, B, F, D, rate)).reshape(B, F, D)
+    assert abs(float((keep == 0).double().mean()) - rate) < 0.03
+
+    class Masked:               # tables[f][ids] -> looked-up rows times this field's keep-scale
+        def __init__(self, t, f):
+            self.t, self.f = t, f
+
+        def __getitem__(self, ids):
+            return self.t[ids] * keep[:, self.f].reshape(B, 1, D)
+
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    tabs = w['emb_categorical_vars_all']
+    w['emb_categorical_vars_all'] = [Masked(t, f) for f, t in enumerate(tabs)]
+    ref_logit, _ = R.model_forward(w, idx.float(), dense.double(), dm.config.nets, bridge.oracle_config(dm), training=True)
+    ref_loss = R.binary_crossentropy_from_logits(ref_logit, y.double())
+    ref_loss.backward()
+    dm.model.train()
+    loss, logit = dm.forward_backward([idx.int().to(dev), dense.to(dev)], y.to(dev))
+    torch.cuda.synchronize()
+    assert (logit.double().cpu() - ref_logit.detach()).abs().max().item() < 1e-4
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-5
+    L = dm.model.layers_by_name
+    assert rel(L['dnn_dense_1'].kernel.grad, w['dnn'][0][0].grad) < 2e-4
+    assert rel(L['linear_logit'].kernel.grad, w['linear_logit'].grad) < 2e-4
+    table = L['emb_categorical_vars_all'].tables[f'd{D}']
+    assert rel(table.grad, torch.cat([t.grad for t in tabs], 0)) < 2e-4
+    # the step advanced the device seed: the next step draws another mask
+    assert int(plan.drop_seed.item()) & 0xFFFFFFFF == (seed * 1664525 + 1013904223) & 0xFFFFFFFF
