@@ -1,4 +1,4 @@
-// deepfm.hip — the whole DeepFM train step (forward + BCE + backward) as SEVEN fused launches.
+// deepfm.hip — the whole DeepFM train step (forward + BCE + backward) as SIX fused launches.
 //
 // DeepFM = nets ['linear','fm_nets','dnn_nets'] (deeptables/models/deepnets.py:15) assembled by
 // DeepModel.__build_model (deeptables/models/deepmodel.py:259-317):
@@ -11,8 +11,8 @@
 //   logit = Dense(1, bias)(Add([lin, fm, dnn]))  (sigmoid applied by the loss)   deepmodel.py:296-297,455
 // The reference runs this as ~100 small TF ops per step; the generic path of this repo as ~60 launches.  Here:
 //   A  k_sparse_fwd     gather + FM + linear + concat row X + field sums S + per-block BN statistics   (HBM-bound)
-//   B  k_prep + k_bn_final   two-level BN reduction (mean/rstd, moving stats), MFMA operand layouts of W1 / W2 / W2^T
-//   C  k_mlp_fwd3       X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit + the top of the backward
+//   B  k_prep           level 1 of the BN reduction (16 slices per column) + MFMA operand layouts of W1 / W2 / W2^T
+//   C  k_mlp_fwd3       BN level 2 (mean/rstd, moving stats) -> X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit + the top of the backward
 //   E  k_wgrad4         Xhat^T dH1 and H1^T dH2 (split over batch slices) + reduction of C's per-tile partial sums
 //   E' k_bn_grads2      slices added up; dgamma, dbeta, dW1, dW2, d w_lin finished
 //   D  k_dx_sparse_bwd  dXn = dH1 W1^T with BN backward + FM/linear terms + embedding row-gradients as its epilogue
@@ -317,24 +317,16 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
     }
 }
 
-// level 2: merge the kBnSlices per-column results, publish mean / rstd / scale / beta (padded) + moving stats
-__global__ __launch_bounds__(256) void k_bn_final(DeepFmDims dm, float eps, float momentum,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                                  PrepOut o) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= dm.CP) return;
-    if (col >= dm.C) {  // pad columns
-        o.mean[col] = 0.f; o.rstd[col] = 0.f; o.sc[col] = 0.f; o.beta[col] = 0.f;
-        return;
-    }
+// level-2 merge of one column's kBnSlices partial results -> (mean, biased variance)
+__device__ __forceinline__ void bn_merge_slices(const float* __restrict__ bn2, int C, int col, float& mean, float& var) {
     float nb[kBnSlices], mb[kBnSlices], qb[kBnSlices];
 #pragma unroll
     for (int w = 0; w < kBnSlices; ++w) {
-        const float* q = o.bn2 + (int64_t)w * 3 * dm.C + col;
-        nb[w] = q[0]; mb[w] = q[dm.C]; qb[w] = q[2 * dm.C];
+        const float* q = bn2 + (int64_t)w * 3 * C + col;
+        nb[w] = q[0]; mb[w] = q[C]; qb[w] = q[2 * C];
     }
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+    float n = 0.f, m2 = 0.f;
+    mean = 0.f;
 #pragma unroll
     for (int w = 0; w < kBnSlices; ++w) {
         if (nb[w] <= 0.f) continue;
@@ -344,19 +336,18 @@ __global__ __launch_bounds__(256) void k_bn_final(DeepFmDims dm, float eps, floa
         m2 += qb[w] + delta * delta * (n * nb[w] / nt);
         n = nt;
     }
-    const float var = n > 0.f ? m2 / n : 0.f;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    o.mean[col] = mean;
-    o.rstd[col] = rstd;
-    o.sc[col] = rstd * gamma[col];
-    o.beta[col] = beta[col];
-    if (moving_mean) moving_mean[col] = moving_mean[col] * momentum + mean * (1.f - momentum);
-    if (moving_var) moving_var[col] = moving_var[col] * momentum + var * (1.f - momentum);
+    var = n > 0.f ? m2 / n : 0.f;
 }
+
 
 struct MlpParams {
     const float *b1, *W2, *b2, *w3, *wo, *bo, *gamma, *mean, *rstd, *sc, *betap;
     const float *W1, *W1L, *W2L, *W2TL;   // original W1 [C][128]; lane-major operand layouts written by k_prep (see k_mlp_fwd3)
+    // BN level-2 merge inside kernel C (k_bn_final folded in): level-1 results, the layer's beta, eps / momentum, the
+    // moving statistics (updated by block 0, may be NULL) and the padded vectors C publishes for kernels E and D
+    const float *bn2, *beta;
+    float eps, momentum;
+    float *moving_mean, *moving_var, *mean_w, *rstd_w, *sc_w, *betap_w;
 };
 
 // phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
@@ -439,15 +430,28 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     const Part3 pl = part3_layout(dm.CP);
     float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
-    // ---- prologue loads: BN parameters, chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
+    // ---- prologue: the BN level-2 merge (mean / rstd of this thread's columns from the 16 level-1 slices; every block
+    //      does it for itself — 16 x 3 L2-resident loads per column — instead of waiting for one more tiny kernel),
+    //      chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
     float bnv[3][(CP + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
         const int col = tid + 256 * i;
-        const bool ok = col < CP;
-        bnv[0][i] = ok ? p.mean[col] : 0.f;
-        bnv[1][i] = ok ? p.sc[col] : 0.f;
-        bnv[2][i] = ok ? p.betap[col] : 0.f;
+        bnv[0][i] = 0.f; bnv[1][i] = 0.f; bnv[2][i] = 0.f;
+        float rstd = 0.f, var = 0.f;
+        if (col < dm.C) {
+            bn_merge_slices(p.bn2, dm.C, col, bnv[0][i], var);
+            rstd = 1.0f / sqrtf(var + p.eps);
+            bnv[1][i] = rstd * p.gamma[col];
+            bnv[2][i] = p.beta[col];
+        }
+        if (blockIdx.x == 0 && col < CP) {         // published for kernels E / D (launched after this one) + moving statistics
+            p.mean_w[col] = bnv[0][i]; p.rstd_w[col] = rstd; p.sc_w[col] = bnv[1][i]; p.betap_w[col] = bnv[2][i];
+            if (col < dm.C) {
+                if (p.moving_mean) p.moving_mean[col] = p.moving_mean[col] * p.momentum + bnv[0][i] * (1.f - p.momentum);
+                if (p.moving_var) p.moving_var[col] = p.moving_var[col] * p.momentum + var * (1.f - p.momentum);
+            }
+        }
     }
     const int qcol = 4 * (tid & 15), srow = tid >> 4;      // staging: this thread owns 4 columns of rows srow, srow + 16
     floatx4 xv[NCH][2];                                    // raw X, kept to the end (d w_lin partial sums)
@@ -1276,7 +1280,9 @@ extern "C" int dt_deepfm_train_step(
     const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd);
     float* ws = reinterpret_cast<float*>(workspace);
     MlpParams mp{b1, W2, b2, w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
-                 W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL};
+                 W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
+                 ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
+                 ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap};
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)w3 | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int blocksA = ceil_div(B, kRowsPerBlockA);
@@ -1332,8 +1338,6 @@ extern "C" int dt_deepfm_train_step(
                ws + wl.W2TL, W2};
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56), dim3(1024), 0, st, ws + wl.bnp, blocksA, dm, bn_eps, bn_momentum,
                        bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks);
-    hipLaunchKernelGGL(k_bn_final, dim3(ceil_div(dm.CP, 256)), dim3(256), 0, st, dm, bn_eps, bn_momentum, bn_gamma,
-                       bn_beta, bn_moving_mean, bn_moving_var, po);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
         const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 3 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM) * sizeof(float);
