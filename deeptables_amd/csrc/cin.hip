@@ -39,6 +39,12 @@ __host__ __device__ inline int cin_nb(int D) {  // batch rows an m-tile of 128 (
 }
 
 
+template <bool kAnyAct>
+__device__ __forceinline__ float cin_act(float v, int act) {
+    if (kAnyAct) return act_apply(v, act);
+    return act == DT_ACT_RELU ? fmaxf(v, 0.f) : v;
+}
+
 // copy the [nb] batch rows starting at b_first of x[B, F, D] (b stride `bstride`) into LDS slabs
 __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t bstride, int B, int F,
                                            int D, int b_first, int nb, int slab, float* lds) {
@@ -53,6 +59,9 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// kAnyAct = false: only linear / relu reach the epilogue (no libm code next to the 64 accumulators; with the full
+// activation switch inlined there the kernel spills the accumulators and runs 7x slower)
+template <bool kAnyAct>
 __global__ __launch_bounds__(256, 2) void k_cin_fwd(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ W, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
@@ -143,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd(
             const int64_t b = mr / D;
             const int dd = (int)(mr % D);
             float4 o;
-            o.x = act_apply(acc[nb][g * 4 + 0] + bv, act);
-            o.y = act_apply(acc[nb][g * 4 + 1] + bv, act);
-            o.z = act_apply(acc[nb][g * 4 + 2] + bv, act);
-            o.w = act_apply(acc[nb][g * 4 + 3] + bv, act);
+            o.x = cin_act<kAnyAct>(acc[nb][g * 4 + 0] + bv, act);
+            o.y = cin_act<kAnyAct>(acc[nb][g * 4 + 1] + bv, act);
+            o.z = cin_act<kAnyAct>(acc[nb][g * 4 + 2] + bv, act);
+            o.w = cin_act<kAnyAct>(acc[nb][g * 4 + 3] + bv, act);
             if (vec_ok) {
                 *reinterpret_cast<float4*>(y + (b * L + n) * D + dd) = o;
             } else {
@@ -416,9 +425,15 @@ extern "C" int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W
     DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd: tiles need %zu B of LDS (> 160 KiB)", lds);
     const int64_t M = (int64_t)B * D;
     dim3 grid((unsigned)((M + kCinTileM - 1) / kCinTileM), (unsigned)ceil_div(L, kCinTileN));
-    hipFuncSetAttribute((const void*)k_cin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cin_fwd, grid, dim3(256), lds, as_stream(stream), x0, x0_bstride, xk,
-                       xk_bstride, W, bias, act, B, F0, Hk, L, D, y);
+    if (act == DT_ACT_LINEAR || act == DT_ACT_RELU) {
+        hipFuncSetAttribute((const void*)k_cin_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_fwd<false>, grid, dim3(256), lds, as_stream(stream), x0, x0_bstride, xk,
+                           xk_bstride, W, bias, act, B, F0, Hk, L, D, y);
+    } else {
+        hipFuncSetAttribute((const void*)k_cin_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_fwd<true>, grid, dim3(256), lds, as_stream(stream), x0, x0_bstride, xk,
+                           xk_bstride, W, bias, act, B, F0, Hk, L, D, y);
+    }
     return launch_status("dt_cin_layer_fwd");
 }
 

@@ -1,0 +1,527 @@
+// cin_bf16.hip — the CIN layer of cin.hip in bf16-MFMA mode (north_star "1e-2 bf16"): v_mfma_f32_32x32x16_bf16, bf16
+// operands, fp32 accumulation.  Same math and interface as cin.hip (CIN.call, deeptables/models/layers.py:689-710):
+//     Y[(b,d), l] = act( sum_{k=(i,j)} x0[b,i,d] xk[b,j,d] W[k, l] + bias[l] )
+// An OPT-IN precision mode (cin_params['mfma_dtype'] = 'bf16'): results are within 1e-2 of the float64 oracle instead of
+// 1e-4; the fp32 kernels of cin.hip stay the default and the benchmark headline never uses this file.
+//
+// A bf16 MFMA consumes 8 consecutive k per lane and instruction (K = 16), so the operands are laid out for 16-byte
+// LDS reads:
+//   * k' = i * Hp + j with Hp = Hk rounded up to 8 (zero columns): a lane's 8 k' share one i -> ONE x0 value times
+//     eight consecutive xk values (two ds_read_b128 from an [m][j] tile), rounded once to bf16;
+//   * the filter is re-laid once per call by k_cin_pack_w: WT [L][K'] (forward: B operand rows = filters, 8 k' per
+//     read) and WN [(i, 32-j block)][L] (dgrad: A operand rows = (i,j), 8 l per read), both bf16, zero padded;
+//   * wgrad contracts over the rows m = (b,d): x0 / xk / G are staged [i][m], [j][m], [l][m] so that 8 consecutive m
+//     are one read.
+// Tile shapes, the T-never-stored dgrad and the batch-split wgrad follow cin.hip.
+#include "common.h"
+
+namespace dt {
+
+typedef float cb_f16v __attribute__((ext_vector_type(16)));
+typedef float cb_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cb_b8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBM = 128;     // (b,d) rows per block tile
+constexpr int kBN = 128;     // filters per block tile
+constexpr int kBK = 32;      // k' per LDS chunk of W^T (forward)
+constexpr int kBWS = kBK + 8;    // bf16 row stride of a W^T chunk: 80 B -> 16 rows' 16-byte reads hit distinct banks
+constexpr int kBMC = 64;     // rows m per wgrad LDS chunk
+constexpr int kBKT = 2;      // 32-row k sub-tiles per wave (wgrad)
+
+__device__ __forceinline__ cb_b8 cb_pack(const cb_f4& lo, const cb_f4& hi) {
+    cb_b8 r;
+    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    return r;
+}
+__device__ __forceinline__ cb_b8 cb_zero() {
+    cb_b8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)0.f;
+    return r;
+}
+__host__ __device__ inline int cb_hp(int Hk) { return (Hk + 7) & ~7; }
+__host__ __device__ inline int cb_lq(int L) { return (L + 15) & ~15; }
+
+// W [F0*Hk][L] fp32 -> WT [Lp][Kp] bf16 (Lp = L rounded up to 128, Kp = F0*Hp, k' = i*Hp + j) and
+//                      WN [F0*njb*32][Lq] bf16 (row (i*njb + jb)*32 + r <-> j = 32 jb + r), zero padded
+__global__ __launch_bounds__(256) void k_cin_pack_w(const float* __restrict__ W, int F0, int Hk, int L,
+                                                    __bf16* __restrict__ WT, __bf16* __restrict__ WN) {
+    const int Hp = cb_hp(Hk), Kp = F0 * Hp, Lp = (L + kBN - 1) / kBN * kBN, Lq = cb_lq(L), njb = (Hk + 31) / 32;
+    const int64_t nT = (int64_t)Lp * Kp, nN = (int64_t)F0 * njb * 32 * Lq;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nT + nN; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < nT) {
+            const int n = (int)(e / Kp), kp = (int)(e - (int64_t)n * Kp);
+            const int i = kp / Hp, j = kp - i * Hp;
+            WT[e] = (__bf16)((n < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + n] : 0.f);
+        } else {
+            const int64_t q = e - nT;
+            const int row = (int)(q / Lq), l = (int)(q - (int64_t)row * Lq);
+            const int ib = row >> 5, r = row & 31;
+            const int i = ib / njb, j = (ib - i * njb) * 32 + r;
+            WN[q] = (__bf16)((l < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + l] : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <bool kAnyAct>  // false: linear / relu only (see k_cin_fwd)
+__global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const __bf16* __restrict__ WT, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L, int D,
+    float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Hp = cb_hp(Hk), Kp = F0 * Hp;
+    const int F0S = F0 | 1, HS = Hp + 4;
+    const int64_t M = (int64_t)B * D;
+    float* x0T = lds;                    // [kBM][F0S]
+    float* xkT = x0T + kBM * F0S;        // [kBM][HS], zero beyond Hk
+    __bf16* wtb = reinterpret_cast<__bf16*>(xkT + kBM * HS);     // [2][kBN][kBWS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * kBN;
+
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t m = m0 + r;
+        x0T[r * F0S + i] = m < M ? x0[(m / D) * x0_bs + (int64_t)i * D + (m % D)] : 0.f;
+    }
+    for (int e = threadIdx.x; e < kBM * Hp; e += 256) {
+        const int j = e / kBM, r = e - j * kBM;
+        const int64_t m = m0 + r;
+        xkT[r * HS + j] = (m < M && j < Hk) ? xk[(m / D) * xk_bs + (int64_t)j * D + (m % D)] : 0.f;
+    }
+    // W^T chunk loader: 128 filters x 32 k' bf16 = 512 x 16 B, two per thread
+    const int Lp = (L + kBN - 1) / kBN * kBN;
+    (void)Lp;
+    cb_f4 wreg[2];
+    auto load_w = [&](int chunk) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = threadIdx.x + 256 * u, n = e >> 2, pc = e & 3;
+            const int kp = chunk * kBK + 8 * pc;
+            wreg[u] = kp < Kp ? *reinterpret_cast<const cb_f4*>(WT + (int64_t)(n0 + n) * Kp + kp) : cb_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = threadIdx.x + 256 * u, n = e >> 2, pc = e & 3;
+            *reinterpret_cast<cb_f4*>(wtb + (buf * kBN + n) * kBWS + 8 * pc) = wreg[u];
+        }
+    };
+    cb_f16v acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int nchunks = (Kp + kBK - 1) / kBK;
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    const int row = wave * 32 + c;
+    const float* x0r = x0T + row * F0S;
+    const float* xkr = xkT + row * HS;
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) load_w(chunk + 1);
+#pragma unroll
+        for (int st = 0; st < kBK / 16; ++st) {
+            const int kp = chunk * kBK + 16 * st + 8 * s;
+            cb_b8 a = cb_zero();
+            if (kp < Kp) {
+                const int i = kp / Hp, j0 = kp - i * Hp;
+                const float xv = x0r[i];
+                const cb_f4 lo = *reinterpret_cast<const cb_f4*>(xkr + j0), hi = *reinterpret_cast<const cb_f4*>(xkr + j0 + 4);
+                a = cb_pack(lo * xv, hi * xv);
+            }
+            const __bf16* wrow = wtb + (buf * kBN + c) * kBWS + 16 * st + 8 * s;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (nb < nblocks_n) {
+                    const cb_b8 b = *reinterpret_cast<const cb_b8*>(wrow + nb * 32 * kBWS);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+                }
+        }
+        if (chunk + 1 < nchunks) store_w(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue (as cin.hip): row = (r&3) + 8*(r>>2) + 4*s, col = c
+    const bool vec_ok = (D % 4 == 0);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nblocks_n) continue;
+        const int n = n0 + nb * 32 + c;
+        if (n >= L) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t mr = m0 + wave * 32 + 8 * g + 4 * s;
+            if (mr >= M) continue;
+            const int64_t b = mr / D;
+            const int dd = (int)(mr % D);
+            float ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = kAnyAct ? act_apply(acc[nb][g * 4 + r] + bv, act)
+                                : (act == DT_ACT_RELU ? fmaxf(acc[nb][g * 4 + r] + bv, 0.f) : acc[nb][g * 4 + r] + bv);
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(y + (b * L + n) * D + dd) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t mm = mr + r;
+                    if (mm < M) y[((mm / D) * L + n) * D + (mm % D)] = ov[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad: grad_x0 (+=), grad_xk (=).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
+// lane that owns column m against xk / x0; grad_x0 is gathered in LDS and flushed once.
+// ------------------------------------------------------------------------------------------
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */>
+__global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const __bf16* __restrict__ WN, const float* __restrict__ y, const float* __restrict__ gy, int act,
+    int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int64_t M = (int64_t)B * D;
+    const int F0S = F0 | 1, Lq = cb_lq(L), WS = 16 * LSTEPS + 8;
+    float* x0T = lds;                    // [kBM][F0S]
+    float* g0T = x0T + kBM * F0S;        // [kBM][F0S] grad_x0 of the tile
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + kBM * F0S);   // [2][32][WS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t mm = m0 + r;
+        x0T[r * F0S + i] = mm < M ? x0[(mm / D) * x0_bs + (int64_t)i * D + (mm % D)] : 0.f;
+        g0T[r * F0S + i] = 0.f;
+    }
+    const int row = wave * 32 + c;
+    const int64_t m = m0 + row;          // the column of T^T this lane owns
+    const bool mvalid = m < M;
+    const int64_t b = mvalid ? m / D : 0;
+    const int d = mvalid ? (int)(m % D) : 0;
+
+    // G[m][l] for l = 16 st + 8 s + e as the B operand, kept in registers for the whole tile
+    cb_b8 G[LSTEPS];
+#pragma unroll
+    for (int st = 0; st < LSTEPS; ++st) {
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 16 * st + 8 * s + e;
+            float g = 0.f;
+            if (mvalid && l < L) {
+                const int64_t o = (b * L + l) * D + d;
+                g = gy[o] * act_grad_from_y(y[o], act);
+            }
+            gv[e] = g;
+        }
+        G[st] = cb_pack(cb_f4{gv[0], gv[1], gv[2], gv[3]}, cb_f4{gv[4], gv[5], gv[6], gv[7]});
+    }
+    // xk values this lane needs: j = jb*32 + (r&3) + 8*(r>>2) + 4*s
+    float xkv[JB][16], gxk_acc[JB][16];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+            xkv[jb][r] = (mvalid && j < Hk) ? xk[b * xk_bs + (int64_t)j * D + d] : 0.f;
+            gxk_acc[jb][r] = 0.f;
+        }
+    const int njb = (Hk + 31) / 32;
+    const int nchunks = F0 * njb;
+    // W chunk (i, jb): 32 rows x Lq bf16, contiguous in WN
+    auto stage_w = [&](int chunk, int buf) {
+        const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
+        const int pieces = Lq / 8;                      // 16-byte pieces per row
+        for (int e = threadIdx.x; e < 32 * pieces; e += 256) {
+            const int r = e / pieces, pc = e - r * pieces;
+            *reinterpret_cast<cb_f4*>(wtl + (buf * 32 + r) * WS + 8 * pc) = *reinterpret_cast<const cb_f4*>(src + r * Lq + 8 * pc);
+        }
+    };
+    const int lsteps = Lq / 16;
+    stage_w(0, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const int i = chunk / njb, jb = chunk - i * njb;
+        if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
+        const __bf16* wrow = wtl + (buf * 32 + c) * WS + 8 * s;
+        cb_f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < LSTEPS; ++st)
+            if (st < lsteps)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cb_b8*>(wrow + 16 * st), G[st], acc, 0, 0, 0);
+        // contract T^T[j, m] (16 j's in this lane) against xk and x0
+        const float x0v = x0T[row * F0S + i];
+        float p = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+            if (jj == jb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p += xkv[jj][r] * acc[r];
+                    gxk_acc[jj][r] += x0v * acc[r];
+                }
+            }
+        p += __shfl_xor(p, 32, 64);
+        if (s == 0) g0T[row * F0S + i] += p;  // unique owner of (m, i)
+        __syncthreads();
+    }
+    if (mvalid) {
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (j < Hk) gxk[(b * Hk + j) * D + d] = gxk_acc[jb][r];
+            }
+    }
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t mm = m0 + r;
+        if (mm < M) gx0[((mm / D) * F0 + i) * D + (mm % D)] += g0T[r * F0S + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: grad_W[k, l] += sum_m Z[m,k] G[m,l]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
+    int D, int64_t rows_per_split, float* __restrict__ gW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    constexpr int XS = kBMC + 4, GS = kBMC + 8;
+    float* x0s = lds;                    // [F0][XS]  (rows m contiguous)
+    float* xks = x0s + F0 * XS;          // [Hk][XS]
+    __bf16* gsb = reinterpret_cast<__bf16*>(xks + Hk * XS);     // [kBN][GS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int kbase = blockIdx.x * (128 * kBKT) + wave * (32 * kBKT);
+    int ki[kBKT], kj[kBKT];
+    bool kvalid[kBKT];
+#pragma unroll
+    for (int u = 0; u < kBKT; ++u) {
+        const int k = kbase + 32 * u + c;   // this lane's A row (i,j) in sub-tile u
+        kvalid[u] = k < K;
+        ki[u] = kvalid[u] ? k / Hk : 0;
+        kj[u] = kvalid[u] ? k % Hk : 0;
+    }
+    const int n0 = blockIdx.z * kBN;
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(M, m_begin + rows_per_split);
+    cb_f16v acc[kBKT][4];
+#pragma unroll
+    for (int u = 0; u < kBKT; ++u)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.f;
+
+    for (int64_t mc = m_begin; mc < m_end; mc += kBMC) {
+        __syncthreads();
+        const int64_t b0 = mc / D;
+        const int d0 = (int)(mc - b0 * D);
+        const int rows = (int)min((int64_t)kBMC, m_end - mc);
+        for (int e = threadIdx.x; e < kBMC * F0; e += 256) {
+            const int i = e / kBMC, r = e - i * kBMC;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
+            x0s[i * XS + r] = r < rows ? x0[(b0 + bq) * x0_bs + i * D + dq] : 0.f;
+        }
+        for (int e = threadIdx.x; e < kBMC * Hk; e += 256) {
+            const int j = e / kBMC, r = e - j * kBMC;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
+            xks[j * XS + r] = r < rows ? xk[(b0 + bq) * xk_bs + j * D + dq] : 0.f;
+        }
+        for (int e = threadIdx.x; e < kBMC * kBN; e += 256) {
+            const int l = e / kBMC, r = e - l * kBMC;
+            const int q = d0 + r, bq = q / D, dq = q - bq * D;
+            float g = 0.f;
+            if (r < rows && n0 + l < L) {
+                const int64_t o = ((b0 + bq) * L + n0 + l) * D + dq;
+                g = gy[o] * act_grad_from_y(y[o], act);
+            }
+            gsb[l * GS + r] = (__bf16)g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < kBMC / 16; ++st) {
+            const int r0 = 16 * st + 8 * s;
+            cb_b8 a[kBKT];
+#pragma unroll
+            for (int u = 0; u < kBKT; ++u) {
+                a[u] = cb_zero();
+                if (kvalid[u]) {
+                    const float* xp = x0s + ki[u] * XS + r0;
+                    const float* kp = xks + kj[u] * XS + r0;
+                    a[u] = cb_pack(*reinterpret_cast<const cb_f4*>(xp) * *reinterpret_cast<const cb_f4*>(kp),
+                                   *reinterpret_cast<const cb_f4*>(xp + 4) * *reinterpret_cast<const cb_f4*>(kp + 4));
+                }
+            }
+            const __bf16* grow = gsb + c * GS + r0;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (nb < nblocks_n) {
+                    const cb_b8 g = *reinterpret_cast<const cb_b8*>(grow + nb * 32 * GS);
+#pragma unroll
+                    for (int u = 0; u < kBKT; ++u)
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], g, acc[u][nb], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kBKT; ++u)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb >= nblocks_n) continue;
+            const int l = n0 + nb * 32 + c;
+            if (l >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[u][nb][r]);
+            }
+        }
+}
+
+// grad_bias[l] += sum_{b,d} G[b,l,d]   (fp32, as cin.hip)
+__global__ __launch_bounds__(256) void k_cin_bias_grad_b(const float* __restrict__ y, const float* __restrict__ gy,
+                                                         int act, int B, int L, int D, float* __restrict__ gbias) {
+    const int l = blockIdx.x;
+    float sacc = 0.f;
+    const int64_t n = (int64_t)B * D;
+    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t b = e / D;
+        const int d = (int)(e % D);
+        const int64_t o = (b * L + l) * D + d;
+        sacc += gy[o] * act_grad_from_y(y[o], act);
+    }
+    sacc = wave_sum(sacc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&gbias[l], sacc);
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+static int cinb_check(const char* who, int B, int F0, int Hk, int L, int D) {
+    DT_REQUIRE(B >= 0 && F0 > 0 && Hk > 0 && L > 0 && D > 0, "%s: bad sizes B=%d F0=%d Hk=%d L=%d D=%d", who, B, F0, Hk, L, D);
+    DT_UNSUPPORTED(L > 256 || Hk > 128 || F0 > 128, "%s: the bf16 mode takes L <= 256, Hk <= 128, F0 <= 128 (L=%d Hk=%d F0=%d)",
+                   who, L, Hk, F0);
+    return DT_OK;
+}
+
+// workspace: WT [Lp][Kp] + WN [F0*njb*32][Lq], bf16
+extern "C" int64_t dt_cin_bf16_workspace_bytes(int F0, int Hk, int L) {
+    if (F0 <= 0 || Hk <= 0 || L <= 0) return 0;
+    const int64_t Kp = (int64_t)F0 * cb_hp(Hk), Lp = (L + kBN - 1) / kBN * kBN;
+    const int64_t nN = (int64_t)F0 * ((Hk + 31) / 32) * 32 * cb_lq(L);
+    return 2 * (Lp * Kp + nN) + 64;
+}
+
+static void cinb_pack(const float* W, int F0, int Hk, int L, void* ws, __bf16** WT, __bf16** WN, hipStream_t st) {
+    const int64_t Kp = (int64_t)F0 * cb_hp(Hk), Lp = (L + kBN - 1) / kBN * kBN;
+    *WT = reinterpret_cast<__bf16*>(ws);
+    *WN = *WT + ((Lp * Kp + 7) & ~(int64_t)7);
+    hipLaunchKernelGGL(k_cin_pack_w, dim3(512), dim3(256), 0, st, W, F0, Hk, L, *WT, *WN);
+}
+
+extern "C" int dt_cin_layer_fwd_bf16(const float* x0, const float* xk, const float* W, const float* bias, int act, int B,
+                                     int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y,
+                                     void* ws, void* stream) {
+    int rc = cinb_check("dt_cin_layer_fwd_bf16", B, F0, Hk, L, D);
+    if (rc) return rc;
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x0 && xk && W && y && ws, "dt_cin_layer_fwd_bf16: null pointer");
+    DT_REQUIRE(act >= 0 && act < DT_ACT_COUNT, "dt_cin_layer_fwd_bf16: act %d", act);
+    hipStream_t st = as_stream(stream);
+    __bf16 *WT, *WN;
+    cinb_pack(W, F0, Hk, L, ws, &WT, &WN, st);
+    const size_t lds = ((size_t)kBM * ((F0 | 1) + cb_hp(Hk) + 4)) * sizeof(float) + (size_t)2 * kBN * kBWS * 2;
+    DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
+    const int64_t M = (int64_t)B * D;
+    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
+    if (act == DT_ACT_LINEAR || act == DT_ACT_RELU) {
+        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_fwd_bf16<false>, grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT, bias, act,
+                           B, F0, Hk, L, D, y);
+    } else {
+        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_fwd_bf16<true>, grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT, bias, act,
+                           B, F0, Hk, L, D, y);
+    }
+    return launch_status("dt_cin_layer_fwd_bf16");
+}
+
+template <int LSTEPS, int JB>
+static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, const float* y,
+                          const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
+                          hipStream_t st) {
+    const size_t lds = (size_t)2 * kBM * (F0 | 1) * sizeof(float) + (size_t)2 * 32 * (16 * LSTEPS + 8) * 2;
+    if (lds > 160 * 1024) {
+        set_error("dt_cin_layer_bwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
+        return DT_ERR_UNSUPPORTED;
+    }
+    const int64_t M = (int64_t)B * D;
+    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB>), dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, x0, x0_bs,
+                       xk, xk_bs, WN, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
+    return launch_status("dt_cin_layer_bwd_bf16(dgrad)");
+}
+
+extern "C" int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y,
+                                     int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride,
+                                     float* grad_x0, float* grad_xk, float* grad_W, float* grad_bias, void* ws,
+                                     void* stream) {
+    int rc = cinb_check("dt_cin_layer_bwd_bf16", B, F0, Hk, L, D);
+    if (rc) return rc;
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x0 && xk && W && y && grad_y && grad_x0 && grad_xk && grad_W && ws, "dt_cin_layer_bwd_bf16: null pointer");
+    hipStream_t st = as_stream(stream);
+    __bf16 *WT, *WN;
+    cinb_pack(W, F0, Hk, L, ws, &WT, &WN, st);
+    const int jb = ceil_div(Hk, 32);
+#define DT_DGRAD_B(LS, JBV)                                                                                          \
+    rc = launch_dgrad_b<LS, JBV>(x0, x0_bstride, xk, xk_bstride, WN, y, grad_y, act, B, F0, Hk, L, D, grad_x0, grad_xk, st)
+    if (L <= 128) {
+        if (jb <= 1) DT_DGRAD_B(8, 1);
+        else if (jb <= 2) DT_DGRAD_B(8, 2);
+        else DT_DGRAD_B(8, 4);
+    } else {
+        if (jb <= 1) DT_DGRAD_B(16, 1);
+        else if (jb <= 2) DT_DGRAD_B(16, 2);
+        else DT_DGRAD_B(16, 4);
+    }
+#undef DT_DGRAD_B
+    if (rc) return rc;
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    const int kblocks = ceil_div(K, 128 * kBKT), nblocks = ceil_div(L, kBN);
+    int splits = 512 / (kblocks * nblocks);
+    if (splits < 1) splits = 1;
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + kBMC - 1) / kBMC * kBMC;
+    splits = (int)((M + rps - 1) / rps);
+    const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)kBN * (kBMC + 8) * 2;
+    hipFuncSetAttribute((const void*)k_cin_wgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cin_wgrad_bf16, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride,
+                       y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
+    if (grad_bias)
+        hipLaunchKernelGGL(k_cin_bias_grad_b, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D, grad_bias);
+    return launch_status("dt_cin_layer_bwd_bf16(wgrad)");
+}

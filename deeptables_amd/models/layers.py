@@ -7,6 +7,8 @@ instead of a chain of TF ops.  Weight names/shapes follow the Keras layer so che
 import itertools
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -223,6 +225,8 @@ class CIN(Layer):
         self.params = params
         self.cross_layer_size = params.get('cross_layer_size', (128, 128,))
         self.activation = params.get('activation', 'relu')
+        # extension of cin_params (config.py:120-127): 'mfma_dtype': 'bf16' selects the bf16-MFMA kernels (1e-2 mode)
+        self.mfma_dtype = params.get('mfma_dtype', os.environ.get('DT_AMD_CIN_DTYPE', 'float32'))
         self.use_residual = params.get('use_residual', False)
         self.use_bias = params.get('use_bias', False)
         self.direct = params.get('direct', False)
@@ -295,7 +299,7 @@ class CIN(Layer):
         n = len(self.cross_layer_size)
         for idx, layer_size in enumerate(self.cross_layer_size):
             bias = self.bias[idx] if self.use_bias else None
-            curr_out = ops.cin_layer(x, hidden, self._filter(idx, layer_size), bias, self.activation)  # [B,L,D]
+            curr_out = ops.cin_layer(x, hidden, self._filter(idx, layer_size), bias, self.activation, self.mfma_dtype)  # [B,L,D]
             if self.direct:
                 direct_connect, hidden = curr_out, curr_out
             elif idx != n - 1:

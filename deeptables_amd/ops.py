@@ -338,7 +338,7 @@ def outer_product(x, kernel, kernel_type='mat'):
 # ------------------------------------------------------------------------------------------------
 class _CinLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, xk, W, bias, act):
+    def forward(ctx, x0, xk, W, bias, act, bf16):
         require_cuda(x0, xk, W)
         x0, W = _f32c(x0), _f32c(W)
         if xk.dtype != torch.float32:
@@ -351,8 +351,14 @@ class _CinLayer(torch.autograd.Function):
         L = W.shape[1]
         y = torch.empty((B, L, D), dtype=torch.float32, device=x0.device)
         bias_c = None if bias is None else _f32c(bias)
-        check(lib().dt_cin_layer_fwd(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
-                                     F0 * D, xk.stride(0), ptr(y), stream_ptr()), 'dt_cin_layer_fwd')
+        ctx.bf16 = bool(bf16)
+        if ctx.bf16:     # opt-in bf16-MFMA mode (csrc/cin_bf16.hip): 1e-2 instead of 1e-4 against the float64 oracle
+            ws = torch.empty((lib().dt_cin_bf16_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
+            check(lib().dt_cin_layer_fwd_bf16(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
+                                              F0 * D, xk.stride(0), ptr(y), ptr(ws), stream_ptr()), 'dt_cin_layer_fwd_bf16')
+        else:
+            check(lib().dt_cin_layer_fwd(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
+                                         F0 * D, xk.stride(0), ptr(y), stream_ptr()), 'dt_cin_layer_fwd')
         ctx.save_for_backward(x0, xk, W, y)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -369,16 +375,25 @@ class _CinLayer(torch.autograd.Function):
         gxk = torch.zeros((B, Hk, D), dtype=torch.float32, device=x0.device)
         gW = torch.zeros_like(W)
         gb = torch.zeros((L,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
-        check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
-                                     F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
-                                     stream_ptr()), 'dt_cin_layer_bwd')
-        return gx0, gxk, gW, gb, None
+        if ctx.bf16:
+            ws = torch.empty((lib().dt_cin_bf16_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
+            check(lib().dt_cin_layer_bwd_bf16(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                              F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb), ptr(ws),
+                                              stream_ptr()), 'dt_cin_layer_bwd_bf16')
+        else:
+            check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                         F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
+                                         stream_ptr()), 'dt_cin_layer_bwd')
+        return gx0, gxk, gW, gb, None, None
 
 
-def cin_layer(x0, xk, W, bias=None, activation='relu'):
-    """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias)."""
+def cin_layer(x0, xk, W, bias=None, activation='relu', mfma_dtype='float32'):
+    """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias).
+    mfma_dtype: 'float32' (exact fp32 MFMA, the default) or 'bf16' (bf16 operands, fp32 accumulation: ~1e-2)."""
     act = _lib.act_code(activation, 'CIN')
-    return _CinLayer.apply(x0, xk, W, bias, act)
+    if mfma_dtype not in ('float32', 'fp32', 'f32', 'bf16', 'bfloat16'):
+        raise ValueError(f'CIN mfma_dtype {mfma_dtype!r}: expected float32 or bf16')
+    return _CinLayer.apply(x0, xk, W, bias, act, mfma_dtype in ('bf16', 'bfloat16'))
 
 
 # ------------------------------------------------------------------------------------------------

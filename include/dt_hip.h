@@ -257,6 +257,17 @@ int dt_dense_fwd(const float* x, const float* W, const float* bias, int act, int
 int dt_dense_bwd(const float* x, const float* W, const float* y, const float* grad_y, int act, int N, int K,
                  int M, float* grad_x, float* grad_W, float* grad_b, void* ws, void* stream);
 
+/* ---- CIN layer, bf16-MFMA mode (opt-in; north_star "logits within 1e-2 bf16") --------------------------------------- *
+ * Same contract as dt_cin_layer_fwd / dt_cin_layer_bwd, computed on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32
+ * accumulation): results within 1e-2 of the float64 oracle instead of 1e-4.  ws: dt_cin_bf16_workspace_bytes(F0, Hk, L)
+ * bytes (bf16 re-layouts of W, rebuilt by every call).  L <= 256, Hk <= 128, F0 <= 128.                            */
+int64_t dt_cin_bf16_workspace_bytes(int F0, int Hk, int L);
+int dt_cin_layer_fwd_bf16(const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
+                          int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y, void* ws, void* stream);
+int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y, int act,
+                          int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* grad_x0,
+                          float* grad_xk, float* grad_W, float* grad_bias, void* ws, void* stream);
+
 /* ---- AutoInt interacting layer (MultiheadAttention.call, layers.py:119-153) minus its BatchNormalization -------- *
  * x [B,F,D]; Wq/Wk/Wv/Wr [D,D] and bq/bk/bv/br [D]: kernels / biases of dense_Q, dense_K, dense_V, dense_residual
  * (Wr = br = NULL: use_residual False).  Forward: a [B,F,D] = relu(concat_h(softmax(Q_h K_h^T/sqrt(d_h)) V_h) + R) with
