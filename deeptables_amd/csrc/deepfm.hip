@@ -61,11 +61,16 @@ __host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F,
 
 // Optional row dedupe inside the step (dt_deepfm_train_step, dedupe_ws != NULL): the sparse gradient leaves the step
 // with every table row appearing ONCE, so the row-sparse optimizer needs no dedupe pass of its own.
-//   A: every valid lookup inserts (row+1) << 32 | occurrence into an open-addressing hash with a 64-bit CAS.  The
-//      winner owns the row (mark = its slot); a later lookup of the same row is a duplicate: mark = -(owner)-2, it sets
-//      flags[owner], zeroes the owner's gradient row and reports row -1.
-//   G: owners without duplicates store their gradient row; owners with duplicates and the duplicates themselves
-//      atomicAdd into the owner's row; owners clear their hash slot and flag, so the workspace is all-zero again.
+//   A: writes the looked-up rows a second time, field-major (rows_fm [F][B]; a block's 16 batch rows fill whole lines).
+//   B (extra blocks of k_prep, one per (field, hash partition)): the partition's lookups are inserted into an LDS hash
+//      ((row+1) << 24 | occurrence, 64-bit LDS CAS).  The winner owns the row; a later lookup of the same row is a
+//      duplicate: mark = -(owner)-2, it sets mark[owner] = 1, zeroes the owner's gradient row and reports row -1.
+//      Unique rows (the normal case) cost NO global write: mark stays 0.
+//   D: owners without duplicates store their gradient row; owners with duplicates and the duplicates themselves
+//      atomicAdd into the owner's row; every non-zero mark is cleared, so the workspace is all-zero again.
+// History (bench numbers in DESIGN.md): a global hash filled with 64-bit CAS inside kernel A cost ~10 us of device-scope
+// round trips in the gather's dependency chain; a direct-mapped election table (one plain store per lookup, cleared by
+// D) cost ~15 us spread over A / D / the optimizer: 2 x 213K partial-line write-backs per step.
 // embedding_dropout (config.py:84; SpatialDropout1D on every [B,1,D] embedding, layers.py:878-880 = element dropout with
 // 1/(1-p) scaling): keep-mask from a counter hash of (seed, batch row, packed column f*D+d), the same in kernel A
 // (values) and kernel D (gradients).  The seed lives on the device and is advanced by kernel D, so a captured graph of
@@ -88,12 +93,20 @@ __device__ __forceinline__ float4 emb_drop4(float4 v, unsigned seed, unsigned th
     return v;
 }
 
+constexpr int kElectSlots = 8192;     // LDS hash of one election block (64 KB); also the largest batch the in-step dedupe takes
 struct DedupeWs {
-    unsigned long long* slots;   // [1 << slots_log2], zero outside a step
-    int slots_log2;
-    int* mark;                   // [B*F]
-    int* flags;                  // [B*F], zero outside a step
+    int* mark;                   // [B*F], zero outside a step (NULL: no dedupe)
+    int64_t* rows_fm;            // [F][B] scratch
+    int parts_log2;              // hash partitions per field
 };
+
+// phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
+// read back by tools/phase_times.py; costs one scalar load + store per phase
+#define DT_STAMP(buf, slot)                                                            \
+    do {                                                                               \
+        if ((buf) && threadIdx.x == 0)                                                 \
+            (buf)[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // A: sparse forward.  One wave = one batch row, 16 waves (16 rows) per block: 8192 waves at B = 8192, all
@@ -103,19 +116,20 @@ struct DedupeWs {
 constexpr int kRowsPerBlockA = 16;
 constexpr int kMaxC = 544;
 
-template <int KIND, int LPR>
-__global__ __launch_bounds__(1024) void k_sparse_fwd(
+template <int KIND, int LPR, int RPB>
+__global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     const void* __restrict__ idx, const float4* __restrict__ table, const int64_t* __restrict__ row_offset,
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
     int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial, DedupeWs dd,
-    float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop) {
-    __shared__ __attribute__((aligned(16))) float rowbuf[kRowsPerBlockA][kMaxC];
+    float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop, unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) float rowbuf[RPB][kMaxC];
+    DT_STAMP(stamps, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & (LPR - 1);
     const int NV = dm.F * LPR;  // float4 per row (<= 128)
     const int D = 4 * LPR;
-    const int b = blockIdx.x * kRowsPerBlockA + wave;
+    const int b = blockIdx.x * RPB + wave;
     if (b < dm.B) {
         float4 v[2];
 #pragma unroll
@@ -130,38 +144,13 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
                 if (ok) v[t] = table[row * LPR + c];
                 if (c == 0) {
                     const int64_t occ = (int64_t)b * dm.F + f;
-                    int64_t row_w = row;
-                    if (dd.slots) {
-                        // ownership of the row for this step (see DedupeWs): the first lookup to claim the hash
-                        // slot owns it, later ones become duplicates that G folds into the owner's gradient row
-                        int mk = -1;
-                        if (ok) {
-                            const unsigned mask = (1u << dd.slots_log2) - 1u;
-                            unsigned h = hash_row((unsigned)row, 32 - dd.slots_log2);
-                            const unsigned long long mine =
-                                ((unsigned long long)(row + 1) << 32) | (unsigned long long)(unsigned)occ;
-                            for (;;) {
-                                const unsigned long long prev = atomicCAS(&dd.slots[h], 0ULL, mine);
-                                if (prev == 0ULL) { mk = (int)h; break; }
-                                if ((prev >> 32) == (unsigned long long)(row + 1)) {
-                                    const int64_t owner = (int64_t)(prev & 0xffffffffULL);
-                                    mk = -(int)owner - 2;
-                                    dd.flags[owner] = 1;                     // the owner's row is accumulated atomically:
-                                    float4* z = reinterpret_cast<float4*>(grad_rows + owner * D);   // start it from 0
-                                    for (int q = 0; q < LPR; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                    row_w = -1;                              // not a separate row of the gradient
-                                    break;
-                                }
-                                h = (h + 1) & mask;
-                            }
-                        }
-                        dd.mark[occ] = mk;
-                    }
-                    rows_out[occ] = row_w;
+                    if (dd.mark) dd.rows_fm[(int64_t)f * dm.B + b] = row;     // for the election blocks of k_prep (see DedupeWs)
+                    rows_out[occ] = row;
                     if (!ok && oob) atomicAdd(oob, 1);
                 }
             }
         }
+        DT_STAMP(stamps, 1);
         if (drop.thr) {
             const unsigned seed = *drop.seed;
 #pragma unroll
@@ -186,6 +175,7 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
             S.x += x.x; S.y += x.y; S.z += x.z; S.w += x.w;
             Q.x += x.x * x.x; Q.y += x.y * x.y; Q.z += x.z * x.z; Q.w += x.w * x.w;
         }
+        DT_STAMP(stamps, 2);
         for (int k = lane; k < dm.CP - dm.F * D; k += 64)   // dense columns, then zero padding up to CP
             xrow[dm.F * D + k] = k < dm.Nd ? dv : 0.f;
         if (lane < dm.Nd) rowbuf[wave][dm.F * D + lane] = dv;
@@ -201,10 +191,12 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
             fm_out[b] = 0.5f * ts;
             lin_out[b] = lp;
         }
+        DT_STAMP(stamps, 3);
     }
     __syncthreads();
+    DT_STAMP(stamps, 4);
     // ---- BN statistics of this block's rows: exact two-pass {n, mean, M2} per column ----
-    const int nrows = min(kRowsPerBlockA, dm.B - (int)blockIdx.x * kRowsPerBlockA);
+    const int nrows = min(RPB, dm.B - (int)blockIdx.x * RPB);
     for (int col = threadIdx.x; col < dm.C; col += blockDim.x) {
         float sum = 0.f;
         for (int w = 0; w < nrows; ++w) sum += rowbuf[w][col];
@@ -219,6 +211,7 @@ __global__ __launch_bounds__(1024) void k_sparse_fwd(
         p[dm.C + col] = mean;
         p[2 * dm.C + col] = m2;
     }
+    DT_STAMP(stamps, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,13 +228,79 @@ struct PrepOut {
     const float* W2;
 };
 
+// Merge of K partial results {n_i, mean_i, M2_i} of one column, all K at once (no running recurrence, ONE division):
+//   N = sum n_i,  mean = sum n_i mean_i / N,  M2 = sum [M2_i + n_i (mean_i - mean)^2]
+// (the pairwise Chan update costs two divisions per partial on a serial chain: 10K cycles for 16 slices x 2 columns).
+template <int K>
+__device__ __forceinline__ void bn_merge(const float (&nb)[K], const float (&mb)[K], const float (&qb)[K], float& n,
+                                         float& mean, float& m2) {
+    float ns = 0.f, ms = 0.f;
+#pragma unroll
+    for (int w = 0; w < K; ++w) { ns += nb[w]; ms += nb[w] * mb[w]; }
+    n = ns;
+    mean = ns > 0.f ? ms / ns : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < K; ++w) {
+        const float d = mb[w] - mean;
+        q += qb[w] + nb[w] * d * d;
+    }
+    m2 = q;
+}
+
+// level-2 merge of one column's kBnSlices partial results -> (mean, biased variance)
+__device__ __forceinline__ void bn_merge_slices(const float* __restrict__ bn2, int C, int col, float& mean, float& var) {
+    float nb[kBnSlices], mb[kBnSlices], qb[kBnSlices];
+#pragma unroll
+    for (int w = 0; w < kBnSlices; ++w) {
+        const float* q = bn2 + (int64_t)w * 3 * C + col;
+        nb[w] = q[0]; mb[w] = q[C]; qb[w] = q[2 * C];
+    }
+    float n, m2;
+    bn_merge<kBnSlices>(nb, mb, qb, n, mean, m2);
+    var = n > 0.f ? m2 / n : 0.f;
+}
+
 __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
                                                float eps, float momentum, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ moving_mean,
                                                float* __restrict__ moving_var, const float* __restrict__ W1,
-                                               PrepOut o, int bn_blocks) {
+                                               PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
+                                               int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
+    if ((int)blockIdx.x >= bn_blocks + layout_blocks) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
+        extern __shared__ unsigned long long eslots[];    // [kElectSlots]
+        const int e = (int)blockIdx.x - bn_blocks - layout_blocks;
+        const int f = e >> dd.parts_log2, part = e & ((1 << dd.parts_log2) - 1);
+        for (int i = threadIdx.x; i < kElectSlots; i += blockDim.x) eslots[i] = 0ULL;
+        __syncthreads();
+        const int64_t* rf = dd.rows_fm + (int64_t)f * dm.B;
+        for (int b = threadIdx.x; b < dm.B; b += blockDim.x) {
+            const int64_t row = rf[b];
+            if (row < 0) continue;
+            const unsigned h = ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u;
+            if ((int)((h >> 13) >> (19 - dd.parts_log2)) != part) continue;          // top bits of h: the partition
+            const int64_t occ = (int64_t)b * dm.F + f;
+            const unsigned long long mine = ((unsigned long long)(row + 1) << 24) | (unsigned long long)occ;
+            unsigned slot = h & (kElectSlots - 1);
+            for (int probe = 0; probe < kElectSlots; ++probe) {
+                const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, mine);
+                if (prev == 0ULL) break;                                             // owner (mark stays 0 unless a duplicate turns up)
+                if ((prev >> 24) == (unsigned long long)(row + 1)) {                 // duplicate of an earlier lookup
+                    const int64_t owner = (int64_t)(prev & 0xffffffULL);
+                    dd.mark[occ] = -(int)owner - 2;
+                    dd.mark[owner] = 1;                                              // the owner's row is accumulated atomically:
+                    float4* z = reinterpret_cast<float4*>(grad_rows + owner * dm.D);  // start it from 0
+                    for (int q = 0; q < dm.D / 4; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rows_out[occ] = -1;                                              // not a separate row of the gradient
+                    break;
+                }
+                slot = (slot + 1) & (kElectSlots - 1);
+            }
+        }
+        return;
+    }
     if ((int)blockIdx.x >= bn_blocks) {  // weight layouts
-        const int wb = (int)blockIdx.x - bn_blocks, nwb = gridDim.x - bn_blocks;
+        const int wb = (int)blockIdx.x - bn_blocks, nwb = layout_blocks;
         // W1L: float4 j of lane (c = l%32, s = l/32) of wave w in k-group g = W1[8g + 4s + j][32w + c]  (k_mlp_fwd3 GEMM1)
         floatx4_t* w1l = reinterpret_cast<floatx4_t*>(o.W1L);
         const int n4 = dm.CP * kH1 / 4;
@@ -284,9 +343,13 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
     const bool cok = col < dm.C;
     const int per = (chunks + kBnSlices - 1) / kBnSlices;
     const int k0 = slice * per, k1 = min(chunks, k0 + per);
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    constexpr int UB = 16;
-    for (int kb = k0; kb < k1; kb += UB) {
+    // the slice's partials in batches of UB, each batch merged at once (bn_merge), the batches by the same formula
+    constexpr int UB = 16, NBATCH = 4;                         // <= 64 chunks per slice (B <= 16,384 at 16 rows per chunk), more: serial tail
+    float bn_[NBATCH], bm_[NBATCH], bq_[NBATCH];
+#pragma unroll
+    for (int t = 0; t < NBATCH; ++t) { bn_[t] = 0.f; bm_[t] = 0.f; bq_[t] = 0.f; }
+    int batch = 0;
+    for (int kb = k0; kb < k1; kb += UB, ++batch) {
         float nb[UB], mb[UB], qb[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -299,16 +362,19 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             mb[u] = ok ? v1 : 0.f;
             qb[u] = ok ? v2 : 0.f;
         }
+        float bn, bm, bq;
+        bn_merge<UB>(nb, mb, qb, bn, bm, bq);
+        const int t = batch < NBATCH - 1 ? batch : NBATCH - 1;
+        if (batch < NBATCH) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (nb[u] <= 0.f) continue;
-            const float nt = n + nb[u];
-            const float delta = mb[u] - mean;
-            mean += delta * (nb[u] / nt);
-            m2 += qb[u] + delta * delta * (n * nb[u] / nt);
-            n = nt;
+            for (int tt = 0; tt < NBATCH; ++tt) if (tt == t) { bn_[tt] = bn; bm_[tt] = bm; bq_[tt] = bq; }
+        } else {                                               // very large batches: fold into the last register slot
+            const float pn[2] = {bn_[NBATCH - 1], bn}, pm[2] = {bm_[NBATCH - 1], bm}, pq[2] = {bq_[NBATCH - 1], bq};
+            bn_merge<2>(pn, pm, pq, bn_[NBATCH - 1], bm_[NBATCH - 1], bq_[NBATCH - 1]);
         }
     }
+    float n, mean, m2;
+    bn_merge<NBATCH>(bn_, bm_, bq_, n, mean, m2);
     if (cok) {
         float* q = o.bn2 + (int64_t)slice * 3 * dm.C;
         q[col] = n;
@@ -316,29 +382,6 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
         q[2 * dm.C + col] = m2;
     }
 }
-
-// level-2 merge of one column's kBnSlices partial results -> (mean, biased variance)
-__device__ __forceinline__ void bn_merge_slices(const float* __restrict__ bn2, int C, int col, float& mean, float& var) {
-    float nb[kBnSlices], mb[kBnSlices], qb[kBnSlices];
-#pragma unroll
-    for (int w = 0; w < kBnSlices; ++w) {
-        const float* q = bn2 + (int64_t)w * 3 * C + col;
-        nb[w] = q[0]; mb[w] = q[C]; qb[w] = q[2 * C];
-    }
-    float n = 0.f, m2 = 0.f;
-    mean = 0.f;
-#pragma unroll
-    for (int w = 0; w < kBnSlices; ++w) {
-        if (nb[w] <= 0.f) continue;
-        const float nt = n + nb[w];
-        const float delta = mb[w] - mean;
-        mean += delta * (nb[w] / nt);
-        m2 += qb[w] + delta * delta * (n * nb[w] / nt);
-        n = nt;
-    }
-    var = n > 0.f ? m2 / n : 0.f;
-}
-
 
 struct MlpParams {
     const float *b1, *W2, *b2, *w3, *wo, *bo, *gamma, *mean, *rstd, *sc, *betap;
@@ -350,13 +393,6 @@ struct MlpParams {
     float *moving_mean, *moving_var, *mean_w, *rstd_w, *sc_w, *betap_w;
 };
 
-// phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
-// read back by tools/phase_times.py; costs one scalar load + store per phase
-#define DT_STAMP(buf, slot)                                                            \
-    do {                                                                               \
-        if ((buf) && threadIdx.x == 0)                                                 \
-            (buf)[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();    \
-    } while (0)
 
 
 // =============================================================================================
@@ -430,9 +466,25 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     const Part3 pl = part3_layout(dm.CP);
     float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
-    // ---- prologue: the BN level-2 merge (mean / rstd of this thread's columns from the 16 level-1 slices; every block
-    //      does it for itself — 16 x 3 L2-resident loads per column — instead of waiting for one more tiny kernel),
-    //      chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
+    // ---- prologue: chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
+    const int qcol = 4 * (tid & 15), srow = tid >> 4;      // staging: this thread owns 4 columns of rows srow, srow + 16
+    floatx4 xv[NCH][2];                                    // raw X, kept to the end (d w_lin partial sums)
+    auto xload1 = [&](int j, int u) {       // unconditional: the workspace rows of a ragged last tile are zero (host memset)
+        xv[j][u] = ld4(X + (int64_t)(m0 + srow + 16 * u) * CP + 64 * j + qcol);
+    };
+    const floatx4* w1l = reinterpret_cast<const floatx4*>(p.W1L) + wave * 64 + lane;     // + 256 per k-group g
+    floatx4 bq[3][8];
+    xload1(0, 0); xload1(0, 1);
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) bq[0][g8] = w1l[g8 * 256];
+    if (NCH > 1) {
+        xload1(NCH > 1 ? 1 : 0, 0); xload1(NCH > 1 ? 1 : 0, 1);
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) bq[1][g8] = w1l[(8 + g8) * 256];
+    }
+    DT_STAMP(stamps, 6);
+    // BN level 2 behind the loads just issued: mean / rstd of this thread's columns from the 16 level-1 slices (every
+    // block for itself: 48 L2-resident loads and ~100 flops per column)
     float bnv[3][(CP + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
@@ -453,22 +505,6 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             }
         }
     }
-    const int qcol = 4 * (tid & 15), srow = tid >> 4;      // staging: this thread owns 4 columns of rows srow, srow + 16
-    floatx4 xv[NCH][2];                                    // raw X, kept to the end (d w_lin partial sums)
-    auto xload1 = [&](int j, int u) {       // unconditional: the workspace rows of a ragged last tile are zero (host memset)
-        xv[j][u] = ld4(X + (int64_t)(m0 + srow + 16 * u) * CP + 64 * j + qcol);
-    };
-    const floatx4* w1l = reinterpret_cast<const floatx4*>(p.W1L) + wave * 64 + lane;     // + 256 per k-group g
-    floatx4 bq[3][8];
-    xload1(0, 0); xload1(0, 1);
-#pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8) bq[0][g8] = w1l[g8 * 256];
-    if (NCH > 1) {
-        xload1(NCH > 1 ? 1 : 0, 0); xload1(NCH > 1 ? 1 : 0, 1);
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) bq[1][g8] = w1l[(8 + g8) * 256];
-    }
-    DT_STAMP(stamps, 6);
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
         const int col = tid + 256 * i;
@@ -960,7 +996,6 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     float* dzs = cv + 4 * FD16;
     float* wls = dzs + kTM;                              // [F] linear_logit kernel rows of the fields
     int* marks = reinterpret_cast<int*>(wls + ((dm.F + 3) & ~3));   // [32][F] (dedupe only)
-    int* flg = marks + kTM * dm.F;                       // [32][F]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves: two per SIMD
     const int n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
@@ -1009,13 +1044,12 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     floatx4 sv = {0.f, 0.f, 0.f, 0.f};
     const int s4n = kTM * dm.D / 4;                               // float4 of the S tile (<= 512: D <= 64)
     if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
-    int mkv[2], flv[2];
-    if (dd.slots) {
+    int mkv[2];
+    if (dd.mark) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t occ = min((int64_t)m0 * dm.F + tid + NT * u, (int64_t)dm.B * dm.F - 1);
             mkv[u] = dd.mark[occ];
-            flv[u] = dd.flags[occ];
         }
     }
     DT_STAMP(stamps, 6);
@@ -1054,11 +1088,11 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         if (tid < kTM) dzs[tid] = m0 + tid < dm.B ? dzv : 0.f;
         if (tid >= 64 && tid < 64 + dm.F) wls[tid - 64] = wlv;
         if (tid < s4n) st4(Ss + 4 * tid, sv);
-        if (dd.slots) {
+        if (dd.mark) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + NT * u;
-                if (e < kTM * dm.F) { marks[e] = mkv[u]; flg[e] = flv[u]; }
+                if (e < kTM * dm.F) marks[e] = mkv[u];
             }
         }
     };
@@ -1121,7 +1155,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     DT_STAMP(stamps, 8);
 
     // ---- the tile's row gradients leave as whole rows (16-byte lanes); duplicates of the step's row dedupe add
-    //      into their owner's row, owners clear their hash slot and flag ----
+    //      into their owner's row; non-zero marks are cleared ----
     const unsigned dseed = drop.thr ? *drop.seed : 0u;
     const int fq = FD >> 2;                                       // float4 per row
     float* tile_rows = grad_rows + (int64_t)m0 * FD;
@@ -1142,18 +1176,15 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         }
         float* dst = tile_rows + row * FD + col;
         bool atomic = false;
-        if (dd.slots) {
+        if (dd.mark) {
             const int mk = marks[row * dm.F + f];
-            if (mk >= 0) {                       // owner
-                atomic = flg[row * dm.F + f] != 0;
-                if (d == 0) {
-                    dd.slots[mk] = 0ULL;
-                    if (atomic) dd.flags[(int64_t)b * dm.F + f] = 0;
-                }
+            if (mk == 1) {                       // owner of a row that has duplicates
+                atomic = true;
             } else if (mk <= -2) {               // duplicate: into the owner's (zero-started) row
                 dst = grad_rows + (((int64_t)(-mk - 2)) << dshift) + d;
                 atomic = true;
             }
+            if (mk != 0 && d == 0) dd.mark[(int64_t)b * dm.F + f] = 0;
         }
         if (atomic) {
             atomicAdd(dst, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
@@ -1214,7 +1245,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
     w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
     w.part = take((int64_t)tiles * part3_layout(dm.CP).stride);
-    w.stamps = take((int64_t)3 * tiles * 16 * 2);   // u64 [3 kernels][tiles][16]
+    w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
     w.total = o;
     return w;
 }
@@ -1249,13 +1280,11 @@ extern "C" int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11) {
 extern "C" unsigned dt_deepfm_dropout_hash(unsigned seed, unsigned b, unsigned col) { return emb_drop_hash(seed, b, col); }
 
 extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
-    int64_t s = 1024;
-    while (s < 8LL * B * F) s <<= 1;   // load <= 1/8 keeps the serialised probe chains short
-    return s;
+    return (int64_t)B * F;          // one mark per lookup
 }
 
 extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) {
-    return dt_deepfm_dedupe_slots(B, F) * 8 + 2LL * B * F * 4;
+    return (int64_t)B * F * 4 + 8 + (int64_t)B * F * 8;      // mark (zero between steps) | pad | rows_fm (scratch)
 }
 
 extern "C" int dt_deepfm_train_step(
@@ -1285,21 +1314,18 @@ extern "C" int dt_deepfm_train_step(
                  ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap};
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)w3 | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
-    const int blocksA = ceil_div(B, kRowsPerBlockA);
     const int tiles = ceil_div(B, kTM);
-    DedupeWs dd{nullptr, 0, nullptr, nullptr};
+    DedupeWs dd{nullptr, nullptr, 0};
     DT_REQUIRE(!(dedupe_ws && grad_rows_field_major), "dt_deepfm_train_step: dedupe and field-major row gradients "
                                                       "are mutually exclusive");
-    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach D, which empties the hash again
-        int lg = 0;
-        while ((1LL << lg) < dedupe_slots) ++lg;
-        DT_REQUIRE((1LL << lg) == dedupe_slots && dedupe_slots >= 2LL * B * F && lg <= 31 &&
-                       (int64_t)B * F < (1LL << 31),
-                   "dt_deepfm_train_step: dedupe_slots=%lld must be a power of two >= 2*B*F", (long long)dedupe_slots);
-        dd.slots = reinterpret_cast<unsigned long long*>(dedupe_ws);
-        dd.slots_log2 = lg;
-        dd.mark = reinterpret_cast<int*>(dd.slots + dedupe_slots);
-        dd.flags = dd.mark + (int64_t)B * F;
+    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach D, which zeroes the marks again
+        DT_REQUIRE(dedupe_slots == (int64_t)B * F, "dt_deepfm_train_step: dedupe_slots=%lld must be "
+                   "dt_deepfm_dedupe_slots(B, F)", (long long)dedupe_slots);
+        DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
+                       "dt_deepfm_train_step: the in-step dedupe takes batches up to %d rows (B=%d)", kElectSlots, B);
+        dd.mark = reinterpret_cast<int*>(dedupe_ws);
+        dd.rows_fm = reinterpret_cast<int64_t*>(((uintptr_t)(dd.mark + (int64_t)B * F) + 7) & ~(uintptr_t)7);
+        while ((1024 << dd.parts_log2) < B) ++dd.parts_log2;       // ~1024 lookups per election block
     }
     if (B % kTM) {       // ragged last tile: its workspace rows beyond B are read (unmasked) by the tile kernels -> keep them zero
         const int64_t pad = (int64_t)tiles * kTM - B;
@@ -1319,10 +1345,12 @@ extern "C" int dt_deepfm_train_step(
     unsigned long long* stamps = stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
 
     // A
+    const int blocksA = ceil_div(B, kRowsPerBlockA);
 #define DT_A(KIND, L)                                                                                        \
-    hipLaunchKernelGGL((k_sparse_fwd<KIND, L>), dim3(blocksA), dim3(1024), 0, st, idx, (const float4*)table, \
-                       row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, rows_out,    \
-                       oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S, drop)
+    hipLaunchKernelGGL((k_sparse_fwd<KIND, L, kRowsPerBlockA>), dim3(blocksA), dim3(64 * kRowsPerBlockA), 0, st, idx, \
+                       (const float4*)table, row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, \
+                       rows_out, oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S, drop,                     \
+                       stamps ? stamps + (int64_t)tiles * 48 : nullptr)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
@@ -1336,8 +1364,12 @@ extern "C" int dt_deepfm_train_step(
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2};
-    hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56), dim3(1024), 0, st, ws + wl.bnp, blocksA, dm, bn_eps, bn_momentum,
-                       bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks);
+    const int elect_blocks = dd.mark ? (F << dd.parts_log2) : 0;
+    const size_t ldsB = dd.mark ? (size_t)kElectSlots * 8 : 0;
+    if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+    hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,
+                       bn_momentum, bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, 56, dd, rows_out,
+                       grad_rows);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
         const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 3 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM) * sizeof(float);

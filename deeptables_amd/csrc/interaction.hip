@@ -39,6 +39,17 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // Persistent blocks, one batch row at a time in LDS.  The attention weights live in LDS padded to a compile-time
 // stride HMAX (zeros beyond H), so the inner loops are guard-free and read 16 bytes at a time.
 // ---------------------------------------------------------------------------------------------
+template <bool kAnyAct>
+__device__ __forceinline__ float afm_act(float v, int act) {
+    if (kAnyAct) return act_apply(v, act);
+    return act == DT_ACT_RELU ? fmaxf(v, 0.f) : v;
+}
+template <bool kAnyAct>
+__device__ __forceinline__ float afm_act_grad(float y, int act) {
+    if (kAnyAct) return act_grad_from_y(y, act);
+    return (act == DT_ACT_RELU && !(y > 0.f)) ? 0.f : 1.f;
+}
+
 template <int HMAX>
 __device__ __forceinline__ void afm_att_preact(const float* __restrict__ xi, const float* __restrict__ xj,
                                                const float* __restrict__ wa, const float* __restrict__ bb, int D,
@@ -57,7 +68,7 @@ __device__ __forceinline__ void afm_att_preact(const float* __restrict__ xi, con
     }
 }
 
-template <int HMAX>
+template <int HMAX, bool kAnyAct>  // kAnyAct = false: linear / relu only (keeps libm code out of the unrolled loops)
 __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, const float* __restrict__ Wa,
                                                  const float* __restrict__ ba, const float* __restrict__ pv,
                                                  int act, int B, int F, int D, int H, float* __restrict__ out,
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
             afm_att_preact<HMAX>(xr + pi[p] * D, xr + pj[p] * D, wa, bb, D, acc);
             float lg = 0.f;
 #pragma unroll
-            for (int h = 0; h < HMAX; ++h) lg += act_apply(acc[h], act) * pp[h];
+            for (int h = 0; h < HMAX; ++h) lg += afm_act<kAnyAct>(acc[h], act) * pp[h];
             sc[p] = lg;
             lmax = fmaxf(lmax, lg);
         }
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void k_afm_fwd(const float* __restrict__ x, co
 // Backward.  Per row: (1) S = sum_p score_p dscore_p; (2) per pair: recompute the attention pre-activations, form
 // datt[p,:] and dbi[p,:] in LDS; (3) grad_Wa += bi^T datt as 4x4 register blocks — thread = (d-block, h-block, pair
 // group), accumulators persist over the block's rows; (4) grad_x from dbi.  grad_pv / grad_ba accumulate per thread.
-template <int HMAX>
+template <int HMAX, bool kAnyAct>
 __global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, const float* __restrict__ Wa,
                                                  const float* __restrict__ ba, const float* __restrict__ pv,
                                                  const float* __restrict__ score, const float* __restrict__ gout,
@@ -224,8 +235,8 @@ __global__ __launch_bounds__(256) void k_afm_bwd(const float* __restrict__ x, co
             const float dlogit = sp * (ds - S);
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) {
-                const float a = act_apply(acc[h], act);
-                const float da = dlogit * pp[h] * act_grad_from_y(a, act);
+                const float a = afm_act<kAnyAct>(acc[h], act);
+                const float da = dlogit * pp[h] * afm_act_grad<kAnyAct>(a, act);
                 my_dp[h] += dlogit * a;
                 my_db[h] += da;
                 acc[h] = da;
@@ -695,11 +706,13 @@ extern "C" int dt_afm_fwd(const float* x, const float* Wa, const float* ba, cons
     DT_UNSUPPORTED(lds > 150 * 1024, "dt_afm_fwd: needs %zu B of LDS", lds);
     int blocks = B < 2048 ? B : 2048;
     hipStream_t st = as_stream(stream);
+    const bool simple_act = act == DT_ACT_LINEAR || act == DT_ACT_RELU;
 #define DT_AFM_F(HM)                                                                                          \
     do {                                                                                                      \
-        hipFuncSetAttribute((const void*)k_afm_fwd<HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_afm_fwd<HM>), dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, act, B, F, D, H, \
-                           out, score);                                                                       \
+        auto kern = simple_act ? k_afm_fwd<HM, false> : k_afm_fwd<HM, true>;                                  \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, act, B, F, D, H, out,       \
+                           score);                                                                            \
     } while (0)
     if (H <= 16) DT_AFM_F(16); else if (H <= 32) DT_AFM_F(32); else DT_AFM_F(64);
 #undef DT_AFM_F
@@ -717,11 +730,13 @@ extern "C" int dt_afm_bwd(const float* x, const float* Wa, const float* ba, cons
     DT_UNSUPPORTED(lds > 150 * 1024, "dt_afm_bwd: needs %zu B of LDS", lds);
     int blocks = B < 512 ? B : 512;
     hipStream_t st = as_stream(stream);
+    const bool simple_act = act == DT_ACT_LINEAR || act == DT_ACT_RELU;
 #define DT_AFM_B(HM)                                                                                          \
     do {                                                                                                      \
-        hipFuncSetAttribute((const void*)k_afm_bwd<HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_afm_bwd<HM>), dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, score, grad_out,  \
-                           act, B, F, D, H, grad_x, grad_Wa, grad_ba, grad_pv);                               \
+        auto kern = simple_act ? k_afm_bwd<HM, false> : k_afm_bwd<HM, true>;                                  \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, x, Wa, ba, pv, score, grad_out, act, B, F, \
+                           D, H, grad_x, grad_Wa, grad_ba, grad_pv);                                          \
     } while (0)
     if (H <= 16) DT_AFM_B(16); else if (H <= 32) DT_AFM_B(32); else DT_AFM_B(64);
 #undef DT_AFM_B

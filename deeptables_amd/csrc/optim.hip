@@ -12,6 +12,7 @@
 //    this step are touched (m/v of other rows do not decay — a documented deviation from
 //    Keras' dense semantics).  Duplicate lookups of a row are merged through a small
 //    hash of the step's row ids (see below); each distinct row is updated exactly once.
+#include <stdlib.h>
 #include "common.h"
 
 namespace dt {
@@ -70,24 +71,37 @@ __device__ __forceinline__ void adam_dense_range(const DenseTail& d, int64_t fir
     }
 }
 
-// call from every thread at the end of a step's LAST kernel: the last block to arrive advances the state
-__device__ __forceinline__ void adam_advance_by_last_block(AdamState* st, float lr, float b1, float b2) {
-    __syncthreads();
+// Every block reads lr_t once (thread 0, broadcast through LDS).  In the step's LAST launch (advance != 0) thread 0 of
+// every block takes an arrival ticket at the block's end; the block whose ticket completes the count advances the
+// state — every other block has read lr_t by then.
+//   no fence: nothing a block WROTE has to be seen by the advancing block; a device-wide fence here writes back the
+//   whole L2 (+4 us).  Arrivals on ONE address serialise (~6 ns each when they stream, ~350 ns when blocks queue on the
+//   returned value): two levels, 64 addresses.  Measured alternatives (DeepFM step, 3.6K-block row update): ticket taken
+//   right after the lr_t read 32.6 us, at the block's end 28.1-30.2 us, no ticket + a one-thread kernel 29.0 + 4.0 us.
+constexpr unsigned kNoTicket = 0xffffffffu;
+__device__ __forceinline__ float adam_read_lr(AdamState* st, float lr_host, int advance, unsigned& ticket) {
+    __shared__ float s_lr;
+    ticket = kNoTicket;
+    if (!st) return lr_host;
     if (threadIdx.x == 0) {
-        // no fence: nothing this block WROTE has to be seen by the advancing block, and its read of lr_t has
-        // completed (the value was consumed); a device-wide fence here writes back the whole L2 (+4 us)
-        // thousands of blocks arriving on ONE address serialise (a 3,600-block launch took +23 us): two levels
-        const unsigned k = blockIdx.x % kAdamSub;
-        const unsigned expect = (gridDim.x + kAdamSub - 1 - k) / kAdamSub;       // blocks with this residue
-        if (atomicAdd(&st->sub[k], 1u) == expect - 1) {
-            st->sub[k] = 0u;
-            const unsigned groups = gridDim.x < (unsigned)kAdamSub ? gridDim.x : (unsigned)kAdamSub;
-            if (atomicAdd(&st->done, 1u) == groups - 1) {
-                st->done = 0u;
-                const int t = st->t + 1;
-                st->t = t;
-                st->lr_t = adam_lr_t(lr, b1, b2, t);
-            }
+        s_lr = st->lr_t;
+        if (advance) ticket = 0u;                 // taken in adam_finish
+    }
+    __syncthreads();
+    return s_lr;
+}
+__device__ __forceinline__ void adam_finish(AdamState* st, unsigned ticket, float lr, float b1, float b2) {
+    if (ticket == kNoTicket) return;              // threads other than 0, or a launch that does not advance
+    const unsigned k = blockIdx.x % kAdamSub;
+    const unsigned expect = (gridDim.x + kAdamSub - 1 - k) / kAdamSub;       // blocks with this residue
+    if (atomicAdd(&st->sub[k], 1u) == expect - 1) {
+        st->sub[k] = 0u;
+        const unsigned groups = gridDim.x < (unsigned)kAdamSub ? gridDim.x : (unsigned)kAdamSub;
+        if (atomicAdd(&st->done, 1u) == groups - 1) {
+            st->done = 0u;
+            const int t = st->t + 1;
+            st->t = t;
+            st->lr_t = adam_lr_t(lr, b1, b2, t);
         }
     }
 }
@@ -96,11 +110,12 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                     float lr_host, AdamState* __restrict__ st, float b1, float b2,
                                                     float eps, int advance, float lr) {
-    const float lr_t = st ? st->lr_t : lr_host;
+    unsigned ticket;
+    const float lr_t = adam_read_lr(st, lr_host, advance, ticket);
     const DenseTail d{p, g, m, v, n};
     adam_dense_range(d, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, lr_t, b1, b2,
                      eps);
-    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+    adam_finish(st, ticket, lr, b1, b2);
 }
 
 // Several parameter tensors in ONE launch (the layer-by-layer path has one small tensor per Dense / BN / Cross
@@ -120,7 +135,8 @@ struct AdamMulti {
 
 __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti d, float lr_host, AdamState* __restrict__ st, float b1,
                                                     float b2, float eps, int advance, float lr) {
-    const float lr_t = st ? st->lr_t : lr_host;
+    unsigned ticket;
+    const float lr_t = adam_read_lr(st, lr_host, advance, ticket);
     int t = 0;
     while (t + 1 < d.count && (int)blockIdx.x >= d.block_start[t + 1]) ++t;
     const DenseTail tail{d.p[t], d.g[t], d.m[t], d.v[t], (int64_t)d.n[t]};
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti d, float lr_host, 
         tail.v[i] = vi;
         tail.p[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
-    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+    adam_finish(st, ticket, lr, b1, b2);
 }
 
 // ---- row-sparse ("lazy") Adam on (rows, values) pairs --------------------------------------------------------
@@ -316,17 +332,18 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
                                                          AdamState* __restrict__ st, float b1, float b2, float eps,
                                                          int row_blocks, DenseTail tail, int advance, float lr,
                                                          int sstride) {
-    const float lr_t = st ? st->lr_t : lr_host;
+    unsigned ticket;
+    const float lr_t = adam_read_lr(st, lr_host, advance, ticket);
     if ((int)blockIdx.x >= row_blocks) {      // trailing blocks: the model's dense parameters (one flat buffer)
         adam_dense_range(tail, (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x,
                          (int64_t)(gridDim.x - row_blocks) * blockDim.x, lr_t, b1, b2, eps);
-        if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
-        return;
+    } else {
+        adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
     }
-    adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
-    if (advance && st) adam_advance_by_last_block(st, lr, b1, b2);
+    adam_finish(st, ticket, lr, b1, b2);
 }
 
+constexpr int kAdamPieces = 1;   // pieces per thread: 4 measured slower (29-32 us vs 28 us on the DeepFM step)
 template <int VW>
 __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, float* __restrict__ m,
                                                      float* __restrict__ v, const int64_t* __restrict__ rows,
@@ -334,43 +351,62 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
                                                      unsigned long long* __restrict__ slots,
                                                      const int* __restrict__ mark, float lr_t, float b1, float b2,
                                                      float eps, int sstride) {
+    // kAdamPieces pieces (VW floats of one row) per thread, the loads of all of them in flight before the first update:
+    // 4x fewer blocks take the state's arrival ticket (each ~350 ns when they queue on one address) and every lane has
+    // up to 16 independent loads outstanding
     const int lpr = D / VW;
-    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t occ = gt / lpr;
-    const int part = (int)(gt - occ * lpr);
-    if (occ >= n) return;
-    const int slot = mark ? mark[occ] : (rows[occ] >= 0 ? 0 : -1);   // no mark: rows are already distinct
-    if (slot < 0) return;
-    const int64_t i0 = rows[occ] * D + part * VW;
-    const int64_t s0 = rows[occ] * sstride + part * VW;      // the row's slot record: m | v interleaved (sstride = 2D) or separate (D)
-    const float* gsrc = values + occ * D + part * VW;
-    float gi[VW], mi[VW], vi[VW], pi[VW];
-    if (VW == 4) {
-        typedef float nt_f4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<nt_f4*>(gi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(gsrc));
-        *reinterpret_cast<nt_f4*>(mi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m + s0));
-        *reinterpret_cast<nt_f4*>(vi) = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v + s0));
-        *reinterpret_cast<float4*>(pi) = *reinterpret_cast<const float4*>(table + i0);
-    } else {
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x * kAdamPieces + threadIdx.x;
+    float gi[kAdamPieces][VW], mi[kAdamPieces][VW], vi[kAdamPieces][VW], pi[kAdamPieces][VW];
+    int64_t i0[kAdamPieces], s0[kAdamPieces];
+    int slot[kAdamPieces];
+    bool lead[kAdamPieces];
 #pragma unroll
-        for (int k = 0; k < VW; ++k) { gi[k] = gsrc[k]; mi[k] = m[s0 + k]; vi[k] = v[s0 + k]; pi[k] = table[i0 + k]; }
+    for (int q = 0; q < kAdamPieces; ++q) {
+        const int64_t gt = base + (int64_t)q * blockDim.x;
+        const int64_t occ = gt / lpr;
+        const int part = (int)(gt - occ * lpr);
+        slot[q] = -1;
+        lead[q] = part == 0;
+        if (occ < n) {
+            const int64_t row = rows[occ];
+            slot[q] = mark ? mark[occ] : (row >= 0 ? 0 : -1);   // no mark: rows are already distinct
+            if (slot[q] >= 0) {
+                i0[q] = row * D + part * VW;
+                s0[q] = row * sstride + part * VW;      // the row's slot record: m | v interleaved (sstride = 2D) or separate (D)
+                const float* gsrc = values + occ * D + part * VW;
+                if (VW == 4) {
+                    *reinterpret_cast<float4*>(gi[q]) = *reinterpret_cast<const float4*>(gsrc);
+                    *reinterpret_cast<float4*>(mi[q]) = *reinterpret_cast<const float4*>(m + s0[q]);
+                    *reinterpret_cast<float4*>(vi[q]) = *reinterpret_cast<const float4*>(v + s0[q]);
+                    *reinterpret_cast<float4*>(pi[q]) = *reinterpret_cast<const float4*>(table + i0[q]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) {
+                        gi[q][k] = gsrc[k]; mi[q][k] = m[s0[q] + k]; vi[q][k] = v[s0[q] + k]; pi[q][k] = table[i0[q] + k];
+                    }
+                }
+            }
+        }
     }
 #pragma unroll
-    for (int k = 0; k < VW; ++k) {
-        mi[k] = b1 * mi[k] + (1.f - b1) * gi[k];
-        vi[k] = b2 * vi[k] + (1.f - b2) * gi[k] * gi[k];
-        pi[k] -= lr_t * mi[k] / (sqrtf(vi[k]) + eps);
-    }
-    if (VW == 4) {
-        typedef float nt_f4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(mi), reinterpret_cast<nt_f4*>(m + s0));
-        __builtin_nontemporal_store(*reinterpret_cast<nt_f4*>(vi), reinterpret_cast<nt_f4*>(v + s0));
-        *reinterpret_cast<float4*>(table + i0) = *reinterpret_cast<float4*>(pi);
-    } else {
+    for (int q = 0; q < kAdamPieces; ++q) {
+        if (slot[q] < 0) continue;
 #pragma unroll
-        for (int k = 0; k < VW; ++k) { m[s0 + k] = mi[k]; v[s0 + k] = vi[k]; table[i0 + k] = pi[k]; }
+        for (int k = 0; k < VW; ++k) {
+            mi[q][k] = b1 * mi[q][k] + (1.f - b1) * gi[q][k];
+            vi[q][k] = b2 * vi[q][k] + (1.f - b2) * gi[q][k] * gi[q][k];
+            pi[q][k] -= lr_t * mi[q][k] / (sqrtf(vi[q][k]) + eps);
+        }
+        if (VW == 4) {
+            *reinterpret_cast<float4*>(m + s0[q]) = *reinterpret_cast<float4*>(mi[q]);
+            *reinterpret_cast<float4*>(v + s0[q]) = *reinterpret_cast<float4*>(vi[q]);
+            *reinterpret_cast<float4*>(table + i0[q]) = *reinterpret_cast<float4*>(pi[q]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VW; ++k) { m[s0[q] + k] = mi[q][k]; v[s0[q] + k] = vi[q][k]; table[i0[q] + k] = pi[q][k]; }
+        }
+        if (lead[q] && slots) slots[slot[q]] = 0ULL;   // global-hash variant: leave the hash empty for the next step
     }
-    if (part == 0 && slots) slots[slot] = 0ULL;   // global-hash variant: leave the hash empty for the next step
 }
 
 // ---- BinaryCrossentropy from logits (the loss Keras evaluates for a sigmoid output in graph mode, deepmodel.py:326-328):
@@ -565,12 +601,12 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
         }
     }
     if (D % 4 == 0) {
-        const int row_blocks = (int)((n_rows * (D / 4) + 255) / 256);
+        const int row_blocks = (int)((n_rows * (D / 4) + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
         hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
                            lr, sstride);
     } else {
-        const int row_blocks = (int)((n_rows * D + 255) / 256);
+        const int row_blocks = (int)((n_rows * D + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
         hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
                            lr, sstride);

@@ -132,6 +132,7 @@ class FusedDeepFM:
                  'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
                  'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
                  'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),
+                 # marks of the in-step dedupe (zero between steps) + its field-major row scratch
                  'dedupe': torch.zeros((lib().dt_deepfm_dedupe_bytes(B, self.F) + 7) // 8, dtype=torch.int64,
                                        device=dev),
                  'dedupe_slots': lib().dt_deepfm_dedupe_slots(B, self.F)}
@@ -228,7 +229,7 @@ class FusedDeepFM:
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
-            ptr(buf['dedupe']) if (backward and self.dedupe) else None, buf['dedupe_slots'], 1.0, 0,
+            ptr(buf['dedupe']) if (backward and self.dedupe and B <= 8192) else None, buf['dedupe_slots'], 1.0, 0,
             2 if backward else 1, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
             'dt_deepfm_train_step')
         if backward:
@@ -236,7 +237,7 @@ class FusedDeepFM:
                 p.grad = g
             # with the in-step dedupe every table row appears once (duplicates report row -1, the owner holds the sum)
             self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
-                                                             fields=-1 if self.dedupe else None)]
+                                                             fields=-1 if (self.dedupe and B <= 8192) else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)

@@ -344,10 +344,11 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * and the mean loss at the offsets reported by dt_deepfm_accum_offsets() in the order
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
  * phases: 1 = forward only (logits + loss), 2 = forward + backward.
- * dedupe_ws (may be NULL): dt_deepfm_dedupe_bytes(B,F) bytes, ALL ZERO on entry and left all zero on return, with
- * dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step resolves duplicate lookups
- * itself: each table row appears once in rows_out (later lookups of it report -1) and its grad_rows entry holds the
- * SUM over all its lookups — dt_adam_rows_step can then be called with fields = -1 (no dedupe pass).
+ * dedupe_ws (may be NULL; B <= 8192): dt_deepfm_dedupe_bytes(B,F) bytes whose first dt_deepfm_dedupe_slots(B,F) 32-bit
+ * words are ALL ZERO on entry and left all zero on return; dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given
+ * (and phases == 2) the step resolves duplicate lookups itself: each table row appears once in rows_out (other lookups
+ * of it report -1) and its grad_rows entry holds the SUM over all its lookups — dt_adam_rows_step can then be called
+ * with fields = -1 (no dedupe pass).
  * grad_rows_field_major != 0 (model-parallel tables, no dedupe_ws): grad_rows is written as [F,B,D] and multiplied
  * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.                              */
 int64_t dt_deepfm_dedupe_slots(int B, int F);

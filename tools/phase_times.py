@@ -17,19 +17,21 @@ plan = dm.fused_plan()
 ws = plan._bufs[8192]['ws']
 off = lib().dt_deepfm_stamps_offset_floats(8192, plan.F, plan.D, plan.Nd)
 tiles = 256
-raw = ws[off: off + 3 * tiles * 16 * 2].cpu().numpy().view(np.uint64).reshape(3, tiles, 16).astype(np.float64)
+flat = ws[off: off + 5 * tiles * 16 * 2].cpu().numpy().view(np.uint64).astype(np.float64)
+raw = list(flat[:3 * tiles * 16].reshape(3, tiles, 16)) + [flat[3 * tiles * 16:].reshape(2 * tiles, 16)]
 v1 = 'DT_DEEPFM_V1' in os.environ
 labels = [{0: 'entry', 1: 'staged', 2: 'gemm1', 3: 'h1 stored', 4: 'gemm2+h2', 5: 'end'},
           {0: 'entry', 1: 'prologue', 2: 'dH1', 3: 'end(dXn)'}] if v1 else \
     [{0: 'entry', 6: 'prologue loads issued', 7: 'bn params in LDS', 1: 'chunk0 staged', 2: 'gemm1 done',
       3: 'h1 in LDS', 4: 'gemm2 + partial logits', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)'},
      {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'},
-     {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)'}]
-for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad'])):
+     {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)'},
+     {0: 'entry', 1: 'ids + hash insert done, row loads issued', 2: 'rows arrived, X stores issued', 3: 'row sums done', 4: 'block barrier', 5: 'end (BN partials)'}]
+for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad', 'k_sparse_fwd'])):
     st = raw[k]
     rel = st - st[:, :1]
     order = sorted(labels[k], key=lambda sl: rel[:, sl].mean())
-    print(kn, 'stamps of wave 0 (shader cycles since entry; mean / min / max over the 256 blocks, and the step from the previous stamp):')
+    print(kn, 'stamps of wave 0 (shader cycles since entry; mean / min / max over the blocks, and the step from the previous stamp):')
     prev = 0.0
     for sl in order:
         m = rel[:, sl].mean()
