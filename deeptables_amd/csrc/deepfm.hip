@@ -945,6 +945,14 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
     const bool w2 = col >= dm.C;
     const int mac = w2 ? (dm.CP >> 6) : (col >> 6), row = w2 ? col - dm.C : (col & 63);
     const float* src = wpart + (int64_t)mac * row_blocks * 8192 + row * 128 + 2 * lane;
+    // wave 0's operands of the final formulas travel with the slices (one memory round trip per block, not two)
+    floatx2 w = {0.f, 0.f}, d = {0.f, 0.f};
+    float ga = 0.f, be = 0.f;
+    if (wave == 0 && !w2) {
+        w = *reinterpret_cast<const floatx2*>(W1 + (int64_t)col * kH1 + 2 * lane);
+        d = *reinterpret_cast<const floatx2*>(accum + al.db1 + 2 * lane);
+        ga = gamma[col]; be = beta[col];
+    }
     floatx2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -963,11 +971,8 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
         accum[al.dW2 + (int64_t)(2 * lane + 1) * kH2 + row] = m.y;
         return;
     }
-    const floatx2 w = *reinterpret_cast<const floatx2*>(W1 + (int64_t)col * kH1 + 2 * lane);
-    const floatx2 d = *reinterpret_cast<const floatx2*>(accum + al.db1 + 2 * lane);
     const float dg = wave_sum(w.x * m.x + w.y * m.y);
     const float db = wave_sum(w.x * d.x + w.y * d.y);
-    const float ga = gamma[col], be = beta[col];
     *reinterpret_cast<floatx2*>(accum + al.dW1 + (int64_t)col * kH1 + 2 * lane) =
         floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
     if (lane == 0) { accum[al.dgamma + col] = dg; accum[al.dbeta + col] = db; }
