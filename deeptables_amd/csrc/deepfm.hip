@@ -38,23 +38,32 @@ struct DeepFmDims {
 // accumulator buffer layout (floats), zeroed once per step by one memset
 struct DeepFmAccum {
     int64_t dW1, dW2, db1, db2, dw3, dwo, dbo, loss, dgamma, dbeta, dwlin, slin, total;
+    // DCN (cross layers L > 0; see dt_dcn_train_step): dw3 then holds the [C + 64] kernel applied to Concatenate([cross, dnn]) (cross
+    // part first, Concatenate([cross, dnn]) order) and dw3d points at its dnn part; cross kernels / biases [L][C];
+    // scratch: the cross path's two BN-backward column sums
+    int64_t dw3d, dcw, dcb, sumc, sumcx;
 };
-__host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F, int Nd) {
+__host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F, int Nd, int L = 0) {
     DeepFmAccum a;
     int64_t o = 0;
     a.dW1 = o; o += (int64_t)C * kH1;
     a.dW2 = o; o += (int64_t)kH1 * kH2;
     a.db1 = o; o += kH1;
     a.db2 = o; o += kH2;
-    a.dw3 = o; o += kH2;
+    a.dw3 = o; o += (L > 0 ? C : 0);
+    a.dw3d = o; o += kH2;
     a.dwo = o; o += 1;
     a.dbo = o; o += 1;
     a.loss = o; o += 2;
     a.dgamma = o; o += CP;   // = sum_b dXn * xhat   (also the BN-backward column sum)
     a.dbeta = o; o += CP;    // = sum_b dXn
-    a.dwlin = o; o += F + Nd;
+    a.dwlin = o; o += (L > 0 ? 0 : F + Nd);
+    a.dcw = o; o += (int64_t)L * C;
+    a.dcb = o; o += (int64_t)L * C;
     o = (o + 3) & ~(int64_t)3;
-    a.slin = o; o += CP;     // scratch: sum_b dz * X per column (field-reduced into dwlin by kernel G)
+    a.slin = o; o += (L > 0 ? 0 : CP);     // scratch: sum_b dz * X per column (field-reduced into dwlin by kernel E')
+    a.sumc = o; o += (L > 0 ? CP : 0);
+    a.sumcx = o; o += (L > 0 ? CP : 0);
     a.total = (o + 3) & ~(int64_t)3;
     return a;
 }
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             }
         }
         const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
-        float lp = dv * (lane < dm.Nd ? wlin[dm.F + lane] : 0.f);
+        float lp = (wlin && lane < dm.Nd) ? dv * wlin[dm.F + lane] : 0.f;
         float4 S = make_float4(0.f, 0.f, 0.f, 0.f), Q = S;
         float* xrow = X + (int64_t)b * dm.CP;
 #pragma unroll
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             if (j < NV) {
                 *reinterpret_cast<float4*>(xrow + 4 * j) = x;
                 *reinterpret_cast<float4*>(&rowbuf[wave][4 * j]) = x;
-                lp += ((x.x + x.y) + (x.z + x.w)) * wlin[j / LPR];
+                if (wlin) lp += ((x.x + x.y) + (x.z + x.w)) * wlin[j / LPR];
             }
             S.x += x.x; S.y += x.y; S.z += x.z; S.w += x.w;
             Q.x += x.x * x.x; Q.y += x.y * x.y; Q.z += x.z * x.z; Q.w += x.w * x.w;
@@ -429,41 +438,57 @@ constexpr int kH2S = kH2 + kPad;
 __device__ __forceinline__ floatx4 ld4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
 __device__ __forceinline__ void st4(float* p, floatx4 v) { *reinterpret_cast<floatx4*>(p) = v; }
 
-// per-tile partial sums written by C and reduced by E (layout of one tile's record, floats; contiguous)
+// per-tile partial sums written by C and reduced by E (layout of one tile's record, floats; contiguous).  DCN (L > 0
+// cross layers): no slin; sumc | sumcx | dw3c | dcw[L] | dcb[L] follow, CP floats each.
 struct Part3 {
-    int slin, db1, db2, dw3, dwo, dbo, loss, n, stride;
+    int slin, db1, db2, dw3, dwo, dbo, loss, cross, n, stride;
 };
-__host__ __device__ inline Part3 part3_layout(int CP) {
+__host__ __device__ inline Part3 part3_layout(int CP, int L = 0) {
     Part3 l;
-    l.slin = 0; l.db1 = CP; l.db2 = l.db1 + kH1; l.dw3 = l.db2 + kH2;
+    l.slin = 0; l.db1 = L > 0 ? 0 : CP; l.db2 = l.db1 + kH1; l.dw3 = l.db2 + kH2;
     l.dwo = l.dw3 + kH2; l.dbo = l.dwo + 1; l.loss = l.dbo + 1;
-    l.n = l.loss + 1;
+    l.cross = (l.loss + 1 + 3) & ~3;
+    l.n = L > 0 ? l.cross + (3 + 2 * L) * CP : l.loss + 1;
     l.stride = (l.n + 3) & ~3;
     return l;
 }
 
+// DCN arguments of the tile kernels (cw == NULL: DeepFM)
+struct DcnArgs {
+    const float *cw, *cb;        // Cross kernels / biases [L][C] (layers.py:423-426, stacked)
+    const float* w3c;            // cross part [C] of the kernel applied to Concatenate([cross, dnn])
+    int L;
+    float* dXc;                  // [B][CP] d loss / d Xn through the cross network (kernel C -> kernel D)
+};
+constexpr int kCrossMax = 8;     // cross layers the fused DCN step takes
+
 // C: MLP forward + top of the backward on a 32-row tile; NCH = CP / 64 column chunks.
-template <int NCH>
+// LC = 0: DeepFM (z = linear + fm + dnn).  LC = kCrossMax: DCN (z = w3c . cross(Xn) + dnn): the Cross network's forward and
+// backward run on the Xn tile in LDS, one wave per row (lanes along the columns), between the tower's phases.
+template <int NCH, int LC>
 __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
                                                   const float* __restrict__ lin, const float* __restrict__ fm,
                                                   const float* __restrict__ y, float* __restrict__ H1,
                                                   float* __restrict__ dH1, float* __restrict__ dH2,
                                                   float* __restrict__ z_out, float* __restrict__ logit_out,
                                                   float* __restrict__ dlogit, float* __restrict__ dz_out,
-                                                  float* __restrict__ part, unsigned long long* stamps) {
+                                                  float* __restrict__ part, unsigned long long* stamps, DcnArgs dc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
     constexpr int CP = 64 * NCH, XS = CP + kPad, HS = kH1 + kPad;
     float* xs = lds;                   // [32][XS] Xn tile; reused for the 4 waves' d w_lin partials at the end
-    float* bnp = xs + kTM * XS;        // [3][CP]  mean | gamma*rstd | beta
-    float* h1s = bnp + 3 * CP;         // [32][HS] H1, later dH1
+    float* bnp = xs + kTM * XS;        // [4][CP]  mean | gamma*rstd | beta | rstd
+    float* h1s = bnp + 4 * CP;         // [32][HS] H1, later dH1
     float* dh2s = h1s + kTM * HS;      // [32][kH2S] dH2
     float* zp = dh2s + kTM * kH2S;     // [4][32]  per-wave partial dnn logits
     float* dzs = zp + 4 * kTM;         // [32]
+    float* zcs = dzs + kTM;            // DCN: [32] w3c . cross(Xn) per row
+    float* sL = zcs + kTM;             // DCN: [32][kCrossMax] the rows' x_l . w_l
+    float* cwL = sL + kTM * kCrossMax; // DCN: [L][CP] cross kernels | [L][CP] cross biases | [CP] w3c, zero beyond C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 5, c = lane & 31, n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
-    const Part3 pl = part3_layout(dm.CP);
+    const Part3 pl = part3_layout(dm.CP, LC ? dc.L : 0);
     float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
     // ---- prologue: chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
@@ -485,17 +510,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     DT_STAMP(stamps, 6);
     // BN level 2 behind the loads just issued: mean / rstd of this thread's columns from the 16 level-1 slices (every
     // block for itself: 48 L2-resident loads and ~100 flops per column)
-    float bnv[3][(CP + 255) / 256];
+    float bnv[4][(CP + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
         const int col = tid + 256 * i;
-        bnv[0][i] = 0.f; bnv[1][i] = 0.f; bnv[2][i] = 0.f;
+        bnv[0][i] = 0.f; bnv[1][i] = 0.f; bnv[2][i] = 0.f; bnv[3][i] = 0.f;
         float rstd = 0.f, var = 0.f;
         if (col < dm.C) {
             bn_merge_slices(p.bn2, dm.C, col, bnv[0][i], var);
             rstd = 1.0f / sqrtf(var + p.eps);
             bnv[1][i] = rstd * p.gamma[col];
             bnv[2][i] = p.beta[col];
+            bnv[3][i] = rstd;
         }
         if (blockIdx.x == 0 && col < CP) {         // published for kernels E / D (launched after this one) + moving statistics
             p.mean_w[col] = bnv[0][i]; p.rstd_w[col] = rstd; p.sc_w[col] = bnv[1][i]; p.betap_w[col] = bnv[2][i];
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
         const int col = tid + 256 * i;
-        if (col < CP) { bnp[col] = bnv[0][i]; bnp[CP + col] = bnv[1][i]; bnp[2 * CP + col] = bnv[2][i]; }
+        if (col < CP) { bnp[col] = bnv[0][i]; bnp[CP + col] = bnv[1][i]; bnp[2 * CP + col] = bnv[2][i]; bnp[3 * CP + col] = bnv[3][i]; }
     }
     lds_barrier();
     DT_STAMP(stamps, 7);
@@ -590,7 +616,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     if (wave == 0) {
         wov = p.wo[0];
         bov = p.bo ? p.bo[0] : 0.f;
-        if (lane < 32 && m0 + lane < dm.B) { linv = lin[m0 + lane]; fmv = fm[m0 + lane]; yv = y[m0 + lane]; }
+        if (lane < 32 && m0 + lane < dm.B) {
+            if (LC == 0) { linv = lin[m0 + lane]; fmv = fm[m0 + lane]; }
+            yv = y[m0 + lane];
+        }
     }
     float h1r[16];
 #pragma unroll
@@ -640,6 +669,43 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             if (n16 == 0) zp[wave * kTM + row] = v;
         }
     }
+    if constexpr (LC > 0) {
+        // ---- Cross forward (layers.py:428-436): x_{l+1} = x0 (x_l . w_l) + b_l + x_l on the wave's 8 rows; the
+        //      layer's scalars s_l are kept for the backward, the output only meets w3c ----
+        const int nv = (2 * dc.L + 1) * CP;
+        for (int e = tid; e < nv; e += 256) {
+            const int v = e / CP, col = e - v * CP;
+            float t = 0.f;
+            if (col < dm.C) t = v < dc.L ? dc.cw[(int64_t)v * dm.C + col] : v < 2 * dc.L ? dc.cb[(int64_t)(v - dc.L) * dm.C + col] : dc.w3c[col];
+            cwL[e] = t;
+        }
+        lds_barrier();
+        const float* cbL = cwL + dc.L * CP;
+        const float* w3cL = cwL + 2 * dc.L * CP;
+        for (int i = 0; i < kTM / 4; ++i) {
+            const int row = wave * (kTM / 4) + i;
+            float x0[NCH], xl[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { x0[k] = xs[row * XS + 64 * k + lane]; xl[k] = x0[k]; }
+#pragma unroll
+            for (int l = 0; l < LC; ++l) {
+                if (l < dc.L) {
+                    float pd = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) pd += xl[k] * cwL[l * CP + 64 * k + lane];
+                    const float sl = wave_sum(pd);
+                    if (lane == 0) sL[row * kCrossMax + l] = sl;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) xl[k] = x0[k] * sl + xl[k] + cbL[l * CP + 64 * k + lane];
+                }
+            }
+            float pz = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) pz += xl[k] * w3cL[64 * k + lane];
+            pz = wave_sum(pz);
+            if (lane == 0) zcs[row] = pz;
+        }
+    }
     lds_barrier();
     DT_STAMP(stamps, 4);
 
@@ -649,7 +715,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         float loss = 0.f, dl = 0.f, zz = 0.f;
         if (m < dm.B) {
             const float pt = (zp[c] + zp[kTM + c]) + (zp[2 * kTM + c] + zp[3 * kTM + c]);
-            zz = (linv + fmv) + pt;                  // Add([linear, fm, dnn]) order
+            zz = LC ? zcs[c] + pt                   // Dense(1)(Concatenate([cross, dnn])) (deepnets.py:194-207)
+                    : (linv + fmv) + pt;             // Add([linear, fm, dnn]) order
             const float lg = zz * wov + bov;
             const float pr = 1.0f / (1.0f + expf(-lg));
             loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
@@ -722,7 +789,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     }
     // d linear_logit kernel: sum_rows dz * X (raw) for this thread's 4 columns of every chunk, rows srow and srow+16;
     // the 4 row groups of a wave meet by shuffles, the 4 waves in LDS (the Xn tile is dead)
-    {
+    if constexpr (LC == 0) {
         const float dza = dzs[srow], dzb = dzs[srow + 16];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -743,8 +810,100 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         const int r = (tid >> 5) + 8 * u;
         if (m0 + r < dm.B) st4(dH1 + (int64_t)(m0 + r) * kH1 + 4 * (tid & 31), ld4(h1s + r * HS + 4 * (tid & 31)));
     }
-    for (int col = tid; col < CP; col += 256)
-        prec[pl.slin + col] = (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]);
+    if constexpr (LC == 0) {
+        for (int col = tid; col < CP; col += 256)
+            prec[pl.slin + col] = (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]);
+    } else {
+        // ---- Cross backward on the wave's 8 rows, g_L = dz w3c (t_l = g_{l+1} . x0):
+        //        g_l = g_{l+1} + w_l t_l,  d w_l += x_l t_l,  d b_l += g_{l+1},  dXn_cross = g_0 + sum_l g_{l+1} s_l
+        //      dXn_cross leaves for HBM (kernel D adds it to dH1 . W1^T); its two BN-backward column sums, d w3c and the
+        //      cross gradients are summed over the rows in registers, over the waves in LDS ----
+        const float* cbL = cwL + dc.L * CP;
+        const float* w3cL = cwL + 2 * dc.L * CP;
+        float mu[NCH], rs[NCH];
+        float a_sc[NCH], a_scx[NCH], a_w3[NCH], a_cw[LC][NCH], a_cb[LC][NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            mu[k] = bnp[64 * k + lane];
+            rs[k] = bnp[3 * CP + 64 * k + lane];
+            a_sc[k] = 0.f; a_scx[k] = 0.f; a_w3[k] = 0.f;
+#pragma unroll
+            for (int l = 0; l < LC; ++l) { a_cw[l][k] = 0.f; a_cb[l][k] = 0.f; }
+        }
+        for (int i = 0; i < kTM / 4; ++i) {
+            const int row = wave * (kTM / 4) + i;
+            const int64_t m = m0 + row;
+            const float dzv = dzs[row];
+            float x0[NCH], xr[NCH], xc[LC + 1][NCH], g[NCH], gx0[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                xr[k] = X[m * CP + 64 * k + lane];            // raw row (the workspace rows of a ragged tile are zero)
+                x0[k] = xs[row * XS + 64 * k + lane];
+                xc[0][k] = x0[k];
+            }
+#pragma unroll
+            for (int l = 0; l < LC; ++l) {
+                if (l < dc.L) {
+                    const float sl = sL[row * kCrossMax + l];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) xc[l + 1][k] = x0[k] * sl + xc[l][k] + cbL[l * CP + 64 * k + lane];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) xc[l + 1][k] = xc[l][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                g[k] = dzv * w3cL[64 * k + lane];
+                a_w3[k] += dzv * xc[LC][k];
+                gx0[k] = 0.f;
+            }
+#pragma unroll
+            for (int l = LC - 1; l >= 0; --l) {
+                if (l < dc.L) {
+                    float pt = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) pt += g[k] * x0[k];
+                    const float tl = wave_sum(pt);
+                    const float sl = sL[row * kCrossMax + l];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        a_cb[l][k] += g[k];
+                        a_cw[l][k] += xc[l][k] * tl;
+                        gx0[k] += g[k] * sl;
+                        g[k] += cwL[l * CP + 64 * k + lane] * tl;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const float dx = g[k] + gx0[k];
+                if (m < dm.B) dc.dXc[m * CP + 64 * k + lane] = dx;
+                a_sc[k] += dx;
+                a_scx[k] += dx * ((xr[k] - mu[k]) * rs[k]);
+            }
+        }
+        // the 4 waves' sums meet in the (now dead) Xn tile: [(3 + 2 L)][CP], wave by wave
+        lds_barrier();
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+                auto put = [&](int v, const float (&a)[NCH]) {
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        float* q = xs + v * CP + 64 * k + lane;
+                        *q = w == 0 ? a[k] : *q + a[k];
+                    }
+                };
+                put(0, a_sc); put(1, a_scx); put(2, a_w3);
+#pragma unroll
+                for (int l = 0; l < LC; ++l)
+                    if (l < dc.L) { put(3 + l, a_cw[l]); put(3 + dc.L + l, a_cb[l]); }
+            }
+            lds_barrier();
+        }
+        const int nrec = (3 + 2 * dc.L) * CP;
+        for (int e = tid; e < nrec; e += 256) prec[pl.cross + e] = xs[e];
+    }
     DT_STAMP(stamps, 8);
 }
 
@@ -764,10 +923,10 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
                                                 const float* __restrict__ dH2, int nred_blocks, int row_blocks,
                                                 int rows_per_block, const float* __restrict__ part, int nparts,
                                                 float* __restrict__ accum, DeepFmAccum al, float* __restrict__ wpart,
-                                                unsigned long long* stamps_all) {
+                                                unsigned long long* stamps_all, int Lc) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128] (heavy) / [4][64] (reducers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Part3 pl = part3_layout(dm.CP);
+    const Part3 pl = part3_layout(dm.CP, Lc);
     if ((int)blockIdx.x < nred_blocks) {
         // record entries in the order slin | db1 | db2 | dw3 | dwo | dbo | loss
         const int e = (int)blockIdx.x * 64 + lane;
@@ -787,15 +946,25 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
         __syncthreads();
         if (wave == 0 && e < pl.n) {
             const float v = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-            int64_t dst;
+            int64_t dst = -1;
             if (e < pl.db1) dst = al.slin + e;
             else if (e < pl.db2) dst = al.db1 + (e - pl.db1);
             else if (e < pl.dw3) dst = al.db2 + (e - pl.db2);
-            else if (e < pl.dwo) dst = al.dw3 + (e - pl.dw3);
+            else if (e < pl.dwo) dst = al.dw3d + (e - pl.dw3);
             else if (e == pl.dwo) dst = al.dwo;
             else if (e == pl.dbo) dst = al.dbo;
-            else dst = al.loss;
-            accum[dst] = v;
+            else if (e == pl.loss) dst = al.loss;
+            else if (e >= pl.cross) {                    // DCN: sumc | sumcx | dw3c | dcw[L] | dcb[L], CP floats each
+                const int vec = (e - pl.cross) / dm.CP, col = (e - pl.cross) - vec * dm.CP;
+                if (vec == 0) dst = al.sumc + col;
+                else if (vec == 1) dst = al.sumcx + col;
+                else if (col < dm.C) {
+                    if (vec == 2) dst = al.dw3 + col;
+                    else if (vec < 3 + Lc) dst = al.dcw + (int64_t)(vec - 3) * dm.C + col;
+                    else dst = al.dcb + (int64_t)(vec - 3 - Lc) * dm.C + col;
+                }
+            }
+            if (dst >= 0) accum[dst] = v;
         }
         return;
     }
@@ -926,10 +1095,11 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
 // d linear_logit kernel: field f = its D columns, dense k = one column.
 __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, DeepFmDims dm, float* accum,
-                                                   DeepFmAccum al, const float* __restrict__ wpart, int row_blocks) {
+                                                   DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
+                                                   int Lc) {
     __shared__ floatx2 sm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && Lc == 0) {
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
             float v = 0.f;
             if (q < dm.F) {
@@ -975,7 +1145,10 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
     const float db = wave_sum(w.x * d.x + w.y * d.y);
     *reinterpret_cast<floatx2*>(accum + al.dW1 + (int64_t)col * kH1 + 2 * lane) =
         floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
-    if (lane == 0) { accum[al.dgamma + col] = dg; accum[al.dbeta + col] = db; }
+    if (lane == 0) {       // DCN: + the cross path's share of the two sums (reduced by kernel E from C's tile records)
+        accum[al.dgamma + col] = dg + (Lc ? accum[al.sumcx + col] : 0.f);
+        accum[al.dbeta + col] = db + (Lc ? accum[al.sumc + col] : 0.f);
+    }
 }
 
 // D: dXn = dH1 . W1^T on 16x16x4 tiles, one 16-column block (x both 16-row halves, sharing the W1 operand) at a
@@ -983,12 +1156,14 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
 //   dX[c]  = gamma rstd (dXn - mean_b(dXn) - xhat mean_b(dXn xhat))
 //   grad_rows[b,f,d] = dX[b,f*D+d] + dz[b] w_lin[f] + dz[b] (S[b,d] - E[b,f,d])
 // Only the F*D embedding columns are computed (the dense inputs need no gradient).
+template <bool DCN>      // DCN: + dXn through the cross network (dXc, written by kernel C), no FM / linear terms
 __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__ X, const float* __restrict__ dH1,
                                                        const float* __restrict__ dz, const float* __restrict__ S,
                                                        MlpParams p, const float* __restrict__ wlin, DeepFmDims dm,
                                                        const float* __restrict__ accum, DeepFmAccum al,
                                                        float* __restrict__ grad_rows, DedupeWs dd, float grad_scale,
-                                                       int field_major, EmbDrop drop, unsigned long long* stamps) {
+                                                       int field_major, EmbDrop drop, unsigned long long* stamps,
+                                                       const float* __restrict__ dXc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
     constexpr int HS = kH1 + kPad, NT = 512;
@@ -1001,6 +1176,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     float* dzs = cv + 4 * FD16;
     float* wls = dzs + kTM;                              // [F] linear_logit kernel rows of the fields
     int* marks = reinterpret_cast<int*>(wls + ((dm.F + 3) & ~3));   // [32][F] (dedupe only)
+    float* xcs = reinterpret_cast<float*>(marks + 2 * kTM * dm.F);  // DCN: [32][XS] dXn through the cross network
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves: two per SIMD
     const int n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
@@ -1032,6 +1208,16 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         const int r = e / q4, q = e - r * q4;
         if (NT * u < total) xv[u] = ld4(X + (int64_t)(m0 + r) * dm.CP + 4 * q);
     }
+    floatx4 xcv[DCN ? 9 : 1];
+    if (DCN) {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int e = min(tid + NT * u, total - 1);
+            const int r = e / q4, q = e - r * q4;
+            const int64_t m = min((int64_t)m0 + r, (int64_t)dm.B - 1);    // dXc has exactly B rows
+            if (NT * u < total) xcv[DCN ? u : 0] = ld4(dXc + m * dm.CP + 4 * q);
+        }
+    }
     float cvv[4][2];                                              // FD16 <= 544: two columns per thread
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1044,11 +1230,13 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         }
     }
     float dzv = 0.f, wlv = 0.f;
-    if (tid < kTM) dzv = dz[min(m0 + tid, dm.B - 1)];
-    if (tid >= 64 && tid < 64 + dm.F) wlv = wlin[tid - 64];
     floatx4 sv = {0.f, 0.f, 0.f, 0.f};
     const int s4n = kTM * dm.D / 4;                               // float4 of the S tile (<= 512: D <= 64)
-    if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
+    if (!DCN) {
+        if (tid < kTM) dzv = dz[min(m0 + tid, dm.B - 1)];
+        if (tid >= 64 && tid < 64 + dm.F) wlv = wlin[tid - 64];
+        if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
+    }
     int mkv[2];
     if (dd.mark) {
 #pragma unroll
@@ -1077,7 +1265,10 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         for (int u = 0; u < 9; ++u) {
             const int e = tid + NT * u;
             const int r = e / q4, q = e - r * q4;
-            if (e < total) st4(xs + r * XS + 4 * q, xv[u]);
+            if (e < total) {
+                st4(xs + r * XS + 4 * q, xv[u]);
+                if (DCN) st4(xcs + r * XS + 4 * q, xcv[DCN ? u : 0]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1139,7 +1330,8 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
             for (int q = 0; q < 8; ++q) {
                 const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
                 const float gx = (q >> 2) ? c1[q & 3] : c0[q & 3];
-                xs[row * XS + col] = ca * (gx - cm1 - (xr[q] - cmu) * cm2) + dzr[q] * wl + dzr[q] * (sr[q] - xr[q]);
+                if (DCN) xs[row * XS + col] = ca * ((gx + xcs[row * XS + col]) - cm1 - (xr[q] - cmu) * cm2);
+                else xs[row * XS + col] = ca * (gx - cm1 - (xr[q] - cmu) * cm2) + dzr[q] * wl + dzr[q] * (sr[q] - xr[q]);
             }
         }
         if (blk < 8) DT_STAMP(stamps, 5);
@@ -1227,9 +1419,9 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 
 // workspace layout (floats)
 struct DeepFmWs {
-    int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, total;
+    int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, dXc, total;
 };
-static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
+static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
@@ -1249,8 +1441,9 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm) {
     w.wpart = take((int64_t)256 * 8192);            // k_wgrad4's per-slice partial macro tiles (<= 256 heavy blocks)
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
     w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
-    w.part = take((int64_t)tiles * part3_layout(dm.CP).stride);
+    w.part = take((int64_t)tiles * part3_layout(dm.CP, L).stride);
     w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
+    w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.total = o;
     return w;
 }
@@ -1292,7 +1485,9 @@ extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) {
     return (int64_t)B * F * 4 + 8 + (int64_t)B * F * 8;      // mark (zero between steps) | pad | rows_fm (scratch)
 }
 
-extern "C" int dt_deepfm_train_step(
+// the step both entry points run: DeepFM (cross == NULL) or DCN (cross kernels / biases [Lc][C]; w3 = the [C + 64] kernel
+// applied to Concatenate([cross, dnn]), w_lin unused)
+static int tower_train_step(
     const void* idx, int idx_kind, const float* table, const int64_t* row_offset, const int32_t* vocab,
     const float* dense, const float* y, int B, int F, int D, int Nd,
     const float* w_lin, const float* bn_gamma, const float* bn_beta, float* bn_moving_mean,
@@ -1300,24 +1495,26 @@ extern "C" int dt_deepfm_train_step(
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
-    float embedding_dropout, unsigned* dropout_seed, void* stream) {
+    float embedding_dropout, unsigned* dropout_seed, void* stream, const float* cross_w, const float* cross_b, int Lc) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
-    DT_REQUIRE(idx && table && row_offset && vocab && y && w_lin && bn_gamma && bn_beta && W1 && b1 && W2 && b2 &&
+    const bool dcn = Lc > 0;
+    DT_REQUIRE(idx && table && row_offset && vocab && y && (dcn || w_lin) && bn_gamma && bn_beta && W1 && b1 && W2 && b2 &&
                    w3 && w_out && logit_out && rows_out && grad_rows && accum && workspace,
                "dt_deepfm_train_step: null pointer");
     DT_REQUIRE(Nd == 0 || dense, "dt_deepfm_train_step: dense is null");
     DT_REQUIRE(idx_kind == DT_IDX_F32 || idx_kind == DT_IDX_I32, "dt_deepfm_train_step: idx_kind %d", idx_kind);
     hipStream_t st = as_stream(stream);
-    const DeepFmWs wl = deepfm_ws_layout(dm);
-    const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd);
+    const DeepFmWs wl = deepfm_ws_layout(dm, Lc);
+    const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd, Lc);
     float* ws = reinterpret_cast<float*>(workspace);
-    MlpParams mp{b1, W2, b2, w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
+    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc};
+    MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
                  ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap};
-    DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)w3 | (uintptr_t)accum) % 16 == 0,
+    DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)(dcn ? W2 : w3) | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int tiles = ceil_div(B, kTM);
     DedupeWs dd{nullptr, nullptr, 0};
@@ -1377,18 +1574,27 @@ extern "C" int dt_deepfm_train_step(
                        grad_rows);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
-        const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 3 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM) * sizeof(float);
+        const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
+                             (dcn ? kTM + kTM * kCrossMax + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
+        DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
 #define DT_C(N)                                                                                                     \
     case N:                                                                                                         \
-        hipFuncSetAttribute((const void*)k_mlp_fwd3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC);     \
-        hipLaunchKernelGGL(k_mlp_fwd3<N>, dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin,         \
-                           ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,               \
-                           ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps);                                       \
+        if (dcn) {                                                                                                  \
+            hipFuncSetAttribute((const void*)k_mlp_fwd3<N, kCrossMax>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
+            hipLaunchKernelGGL((k_mlp_fwd3<N, kCrossMax>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm,     \
+                               ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
+                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca);                   \
+        } else {                                                                                                    \
+            hipFuncSetAttribute((const void*)k_mlp_fwd3<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
+            hipLaunchKernelGGL((k_mlp_fwd3<N, 0>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin, \
+                               ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,           \
+                               ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca);                              \
+        }                                                                                                           \
         break;
         switch (dm.CP >> 6) { DT_C(1) DT_C(2) DT_C(3) DT_C(4) DT_C(5) DT_C(6) DT_C(7) DT_C(8) DT_C(9) }
 #undef DT_C
     }
-    const Part3 pl3 = part3_layout(dm.CP);
+    const Part3 pl3 = part3_layout(dm.CP, Lc);
     const int nred3 = (ceil_div(pl3.n, 64) + 7) & ~7;        // k_wgrad4 reducer blocks (a multiple of 8, see the kernel)
     if (phases >= 2) {
         // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
@@ -1404,23 +1610,98 @@ extern "C" int dt_deepfm_train_step(
         hipFuncSetAttribute((const void*)k_wgrad4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
         hipLaunchKernelGGL(k_wgrad4, dim3(nred3 + nmac * row_blocks), dim3(256), ldsE, st, ws + wl.X, mp, dm,
                            ws + wl.H1, ws + wl.dH1, ws + wl.dH2, nred3, row_blocks, rows_per_block, ws + wl.part,
-                           tiles, accum, al, ws + wl.wpart, stamps ? stamps + (int64_t)tiles * 32 : nullptr);
+                           tiles, accum, al, ws + wl.wpart, stamps ? stamps + (int64_t)tiles * 32 : nullptr, Lc);
         // E'
         hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, row_blocks);
+                           accum, al, ws + wl.wpart, row_blocks, Lc);
         // D
         const int FD16 = ((F * D + 15) >> 4) << 4;
         const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM +
-                             ((F + 3) & ~3) + 2 * kTM * F) * sizeof(float);
-        hipFuncSetAttribute((const void*)k_dx_sparse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
-        hipLaunchKernelGGL(k_dx_sparse_bwd, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz, ws + wl.S,
-                           mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major, drop,
-                           stamps ? stamps + (int64_t)tiles * 16 : nullptr);
+                             ((F + 3) & ~3) + 2 * kTM * F + (dcn ? kTM * (dm.CP + kPad) : 0)) * sizeof(float);
+        DT_UNSUPPORTED(ldsD > 160 * 1024, "dt_dcn_train_step: the row-gradient kernel needs %zu B of LDS", ldsD);
+        if (dcn) {
+            hipFuncSetAttribute((const void*)k_dx_sparse_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
+            hipLaunchKernelGGL(k_dx_sparse_bwd<true>, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz,
+                               ws + wl.S, mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
+                               drop, stamps ? stamps + (int64_t)tiles * 16 : nullptr, ws + wl.dXc);
+        } else {
+            hipFuncSetAttribute((const void*)k_dx_sparse_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
+            hipLaunchKernelGGL(k_dx_sparse_bwd<false>, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz,
+                               ws + wl.S, mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
+                               drop, stamps ? stamps + (int64_t)tiles * 16 : nullptr, nullptr);
+        }
         if (drop.thr) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else {
         // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
         hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
-                           ws + wl.dH2, nred3, 1, 8, ws + wl.part, tiles, accum, al, ws + wl.wpart, nullptr);
+                           ws + wl.dH2, nred3, 1, 8, ws + wl.part, tiles, accum, al, ws + wl.wpart, nullptr, Lc);
     }
-    return launch_status("dt_deepfm_train_step");
+    return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
+}
+
+extern "C" int dt_deepfm_train_step(
+    const void* idx, int idx_kind, const float* table, const int64_t* row_offset, const int32_t* vocab,
+    const float* dense, const float* y, int B, int F, int D, int Nd,
+    const float* w_lin, const float* bn_gamma, const float* bn_beta, float* bn_moving_mean,
+    float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1, const float* W2,
+    const float* b2, const float* w3, const float* w_out, const float* b_out,
+    float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
+    void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
+    float embedding_dropout, unsigned* dropout_seed, void* stream) {
+    DT_REQUIRE(w_lin, "dt_deepfm_train_step: null pointer");
+    return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, w_lin, bn_gamma, bn_beta,
+                            bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
+                            rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, grad_rows_scale,
+                            grad_rows_field_major, phases, embedding_dropout, dropout_seed, stream, nullptr, nullptr, 0);
+}
+
+// ---- DCN (nets ['dcn_nets'], deepnets.py:194-207): the same step with the Cross network (layers.py:428-436) in place of
+//      the linear + FM terms ----
+extern "C" int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int L) {
+    DeepFmDims dm; int lpr;
+    if (!dt_deepfm_supported(B, F, D, Nd, H1, H2) || L < 1 || L > kCrossMax) return 0;
+    if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return 0;
+    const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM + kTM +
+                         kTM * kCrossMax + (2 * L + 1) * dm.CP) * sizeof(float);
+    const int FD16 = ((F * D + 15) >> 4) << 4;
+    const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + 2 * kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM + ((F + 3) & ~3) +
+                         2 * kTM * F) * sizeof(float);
+    return ldsC <= 160 * 1024 && ldsD <= 160 * 1024;
+}
+
+extern "C" int64_t dt_dcn_workspace_bytes(int B, int F, int D, int Nd, int L) {
+    DeepFmDims dm; int lpr;
+    if (!deepfm_dims(B, F, D, Nd, &dm, &lpr) || L < 1 || L > kCrossMax) return -1;
+    return deepfm_ws_layout(dm, L).total * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t dt_dcn_accum_floats(int F, int D, int Nd, int L) {
+    const int C = F * D + Nd, CP = (C + 63) & ~63;
+    return deepfm_accum_layout(C, CP, F, Nd, L).total;
+}
+
+// offsets (floats) inside the accumulator buffer, in the order:
+// dW1, dW2, db1, db2, dw3 [C + 64], dwo, dbo, loss, dgamma, dbeta, d cross kernels [L][C], d cross biases [L][C]
+extern "C" int dt_dcn_accum_offsets(int F, int D, int Nd, int L, int64_t* out12) {
+    const int C = F * D + Nd, CP = (C + 63) & ~63;
+    const DeepFmAccum a = deepfm_accum_layout(C, CP, F, Nd, L);
+    const int64_t v[12] = {a.dW1, a.dW2, a.db1, a.db2, a.dw3, a.dwo, a.dbo, a.loss, a.dgamma, a.dbeta, a.dcw, a.dcb};
+    for (int i = 0; i < 12; ++i) out12[i] = v[i];
+    return DT_OK;
+}
+
+extern "C" int dt_dcn_train_step(
+    const void* idx, int idx_kind, const float* table, const int64_t* row_offset, const int32_t* vocab,
+    const float* dense, const float* y, int B, int F, int D, int Nd,
+    const float* cross_w, const float* cross_b, int L, const float* bn_gamma, const float* bn_beta,
+    float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1,
+    const float* W2, const float* b2, const float* w3, const float* w_out, const float* b_out,
+    float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
+    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, void* stream) {
+    DT_REQUIRE(cross_w && cross_b, "dt_dcn_train_step: null pointer");
+    DT_UNSUPPORTED(L < 1 || L > kCrossMax, "dt_dcn_train_step: %d cross layers (1..%d)", L, kCrossMax);
+    return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, nullptr, bn_gamma, bn_beta,
+                            bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
+                            rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
+                            embedding_dropout, dropout_seed, stream, cross_w, cross_b, L);
 }

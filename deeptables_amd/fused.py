@@ -248,9 +248,172 @@ class FusedDeepFM:
         return self.loss_view, buf['logit']
 
 
+_DCN_ACC_NAMES = ['dW1', 'dW2', 'db1', 'db2', 'dw3', 'dwo', 'dbo', 'loss', 'dgamma', 'dbeta', 'dcw', 'dcb']
+
+
+class FusedDCN(FusedDeepFM):
+    """Whole-step executor for the DCN graph (nets ['dcn_nets'], deepnets.py:194-207): the DeepFM kernel sequence with the
+    Cross network (layers.py:428-436) running on the BN'd tile inside the tower kernel -> `dt_dcn_train_step`."""
+
+    NETS = {'dcn_nets'}
+
+    @classmethod
+    def eligible(cls, dm):
+        c = dm.config
+        try:
+            if list(c.nets) != ['dcn_nets'] or dm.var_len_categorical_columns:
+                return False
+            if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
+                return False
+            if c.dense_dropout or not (0 <= float(c.embedding_dropout or 0) < 1):
+                return False
+            st = c.distribute_strategy
+            if getattr(st, 'sharded_embeddings', False) and getattr(st, 'active', False):
+                return False                      # row-owned tables: the layer-by-layer path
+            hu = tuple(tuple(h) for h in c.dnn_params.get('hidden_units', ()))
+            if hu != ((128, 0, False), (64, 0, False)) or c.dnn_params.get('activation', 'relu') != 'relu':
+                return False
+            if c.dnn_params.get('custom_dnn_fn') is not None:
+                return False
+            L = dm.model.layers_by_name
+            # a single net: Concatenate([cross, dnn]) feeds task_output directly (deepmodel.py:286-301), no dense_logit_*
+            need = ['emb_categorical_vars_all', 'bn_concat_emb_dense', 'dcn_cross_layer', 'dcn_dense_1', 'dcn_dense_2',
+                    'task_output']
+            if 'dense_logit_dcn_nets' in L:
+                return False
+            if any(n not in L for n in need):
+                return False
+            emb = L['emb_categorical_vars_all']
+            if len(emb.groups) != 1 or len(dm.continuous_columns or []) > 1:
+                return False
+            D = emb.groups[0][0]
+            F = len(emb.input_dims)
+            Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
+            nl = int(L['dcn_cross_layer'].num_cross_layer)
+            return bool(lib().dt_dcn_supported(max(int(getattr(dm, '_batch_hint', 0) or 0), 1), F, D, Nd, 128, 64, nl))
+        except Exception:
+            return False
+
+    def __init__(self, dm):
+        self.dm = dm
+        L = dm.model.layers_by_name
+        self.emb = L['emb_categorical_vars_all']
+        self.bn = L['bn_concat_emb_dense']
+        self.cross = L['dcn_cross_layer']
+        self.nl = int(self.cross.num_cross_layer)
+        self.d1, self.d2 = L['dcn_dense_1'], L['dcn_dense_2']
+        self.out = L['task_output']        # kernel [C + 64, 1]: the step's w3; its w_out is the constant 1
+        self.D = self.emb.groups[0][0]
+        self.F = len(self.emb.input_dims)
+        self.Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
+        self.C = self.F * self.D + self.Nd
+        self.key = f'd{self.D}'
+        self.device = self.emb.tables[self.key].device
+        self.one = torch.ones(4, dtype=torch.float32, device=self.device)
+        n_acc = lib().dt_dcn_accum_floats(self.F, self.D, self.Nd, self.nl)
+        offs = (ctypes.c_int64 * 12)()
+        check(lib().dt_dcn_accum_offsets(self.F, self.D, self.Nd, self.nl, ctypes.cast(offs, ctypes.c_void_p)),
+              'dt_dcn_accum_offsets')
+        self.off = dict(zip(_DCN_ACC_NAMES, [int(v) for v in offs]))
+        self.accum = torch.zeros(n_acc, dtype=torch.float32, device=self.device)
+        self._bufs = {}
+        a, o, C, nl = self.accum, self.off, self.C, self.nl
+        self.grad_views = [
+            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * 128].view(C, 128)),
+            (self.d2.kernel, a[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)),
+            (self.d1.bias, a[o['db1']:o['db1'] + 128]),
+            (self.d2.bias, a[o['db2']:o['db2'] + 64]),
+            (self.out.kernel, a[o['dw3']:o['dw3'] + C + 64].view(C + 64, 1)),
+            (self.bn.gamma, a[o['dgamma']:o['dgamma'] + C]),
+            (self.bn.beta, a[o['dbeta']:o['dbeta'] + C]),
+            (self.cross.kernel_stack, a[o['dcw']:o['dcw'] + nl * C].view(nl, C)),
+            (self.cross.bias_stack, a[o['dcb']:o['dcb'] + nl * C].view(nl, C)),
+        ]
+        if self.out.bias is not None:
+            self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
+        self.loss_view = a[o['loss']:o['loss'] + 1]
+        self.emb_dropout = float(dm.config.embedding_dropout or 0)
+        seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+        self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
+        self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
+        # parameters mirror the gradient layout in one flat buffer (one optimizer launch, see FusedDeepFM); W1 / W2 precede
+        # the [C + 64] output kernel, so they keep their 16-byte alignment whatever C is (the kernels read w3 with scalar loads)
+        self.flat_params = torch.zeros_like(self.accum)
+        members = []
+        for p, gview in self.grad_views:
+            off = (gview.data_ptr() - a.data_ptr()) // 4
+            n = p.numel()
+            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_params[off:off + n].view(p.shape)
+            members.append((p, off, n))
+        n_flat = o['dcb'] + nl * C
+        opt = getattr(dm, 'optimizer', None)
+        if opt is not None and hasattr(opt, 'register_flat_group'):
+            opt.register_flat_group(self.flat_params, self.accum, members, n_flat)
+        dm.model._dt_flat_grad = self.accum
+
+    def _buffers(self, B):
+        b = self._bufs.get(B)
+        if b is None:
+            nbytes = lib().dt_dcn_workspace_bytes(B, self.F, self.D, self.Nd, self.nl)
+            if nbytes < 0:
+                raise _lib.DtHipError('fused DCN step: unsupported shape')
+            dev = self.device
+            b = {'ws': torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev),
+                 'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
+                 'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
+                 'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),
+                 'dedupe': torch.zeros((lib().dt_deepfm_dedupe_bytes(B, self.F) + 7) // 8, dtype=torch.int64,
+                                       device=dev),
+                 'dedupe_slots': lib().dt_deepfm_dedupe_slots(B, self.F)}
+            self._bufs[B] = b
+        return b
+
+    def run(self, idx, dense, y, backward=True):
+        self.dm.model._dt_sharded_step = False
+        B = idx.shape[0]
+        buf = self._buffers(B)
+        idx = idx.contiguous()
+        kind = _lib.DT_IDX_F32 if idx.dtype == torch.float32 else _lib.DT_IDX_I32
+        if idx.dtype not in (torch.float32, torch.int32):
+            idx = idx.to(torch.int32)
+        dense = None if dense is None else dense.contiguous()
+        y = y.reshape(-1).contiguous()
+        table = self.emb.tables[self.key]
+        training = self.dm.model.training
+        dedupe = backward and self.dedupe and B <= 8192
+        check(lib().dt_dcn_train_step(
+            ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
+            ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
+            ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),
+            ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
+            float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
+            ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.out.kernel), ptr(self.one), ptr(self.out.bias),
+            ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+            ptr(self.emb.oob_count) if self.emb.check_oob else None,
+            ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'],
+            2 if backward else 1, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            'dt_dcn_train_step')
+        if backward:
+            for p, g in self.grad_views:
+                p.grad = g
+            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
+                                                             fields=-1 if dedupe else None)]
+            if self.emb.uses_dense_grad(self.D):
+                # small tables keep exact dense-Adam semantics: densify the row gradients
+                g = torch.zeros_like(table)
+                check(lib().dt_embedding_bwd_dense(ptr(buf['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
+                                                   ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
+                table.grad = g
+                self.emb.sparse_grads.pop(self.key, None)
+        return self.loss_view, buf['logit']
+
+
 def make_fused_plan(dm):
     if not fused_enabled() or dm.model is None:
         return None
     if FusedDeepFM.eligible(dm):
         return FusedDeepFM(dm)
+    if FusedDCN.eligible(dm):
+        return FusedDCN(dm)
     return None

@@ -354,6 +354,28 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
+
+/* ---- fused DCN train step (nets ['dcn_nets']: Cross || DNN on BN(concat(embeddings, dense)), deepnets.py:194-207;
+ * Cross.call layers.py:428-436; the reference runs it as ~120 TF ops per step).  The same launches as
+ * dt_deepfm_train_step with the Cross network's forward and backward inside the tile kernel:
+ *   z = Dense(1, no bias)(Concatenate([cross(xn), relu(Dense64(relu(Dense128(xn))))])),  logit = Dense(1)(z).
+ * cross_w / cross_b [L][C] = the layer's L kernels / biases stacked (L <= 8); w3 [C + 64] = the kernel applied to
+ * Concatenate([cross, dnn]) (cross part first).  With 'dcn_nets' as the ONLY net the reference feeds the concatenation
+ * straight into task_output (deepmodel.py:286-301): pass its kernel as w3, a constant 1 as w_out and its bias as b_out.  accum: dt_dcn_accum_floats() floats, offsets from dt_dcn_accum_offsets()
+ * in the order dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, d cross_w, d cross_b.  Everything else as
+ * dt_deepfm_train_step (workspace: dt_dcn_workspace_bytes).                                                        */
+int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int L);
+int64_t dt_dcn_workspace_bytes(int B, int F, int D, int Nd, int L);
+int64_t dt_dcn_accum_floats(int F, int D, int Nd, int L);
+int dt_dcn_accum_offsets(int F, int D, int Nd, int L, int64_t* out12_host);
+int dt_dcn_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,
+                      const int32_t* vocab, const float* dense, const float* y, int B, int F, int D, int Nd,
+                      const float* cross_w, const float* cross_b, int L, const float* bn_gamma, const float* bn_beta,
+                      float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1,
+                      const float* b1, const float* W2, const float* b2, const float* w3, const float* w_out,
+                      const float* b_out, float* logit_out, int64_t* rows_out, float* grad_rows, float* accum,
+                      void* workspace, int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
+                      float embedding_dropout, unsigned* dropout_seed, void* stream);
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
 int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
 /* debugging aid: offset (floats) of the per-block phase timestamps written when DT_DEEPFM_STAMPS is set */

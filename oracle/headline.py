@@ -52,7 +52,11 @@ def oracle_train_step(dm, idx, dense, y, dtype=torch.float64, tables_cpu=None):
     w['emb_categorical_vars_all'] = [_RowTable(t, dtype, log) for t in tables_cpu]
     idx_c = idx.detach().cpu()
     dn = None if dense is None else dense.detach().cpu().to(dtype)
-    logit, _ = R.model_forward(w, idx_c.to(torch.float32), dn, dm.config.nets, bridge.oracle_config(dm), training=True)
+    R.RELU_PROBE = probe = []
+    try:
+        logit, _ = R.model_forward(w, idx_c.to(torch.float32), dn, dm.config.nets, bridge.oracle_config(dm), training=True)
+    finally:
+        R.RELU_PROBE = None
     loss = R.binary_crossentropy_from_logits(logit, y.detach().cpu().to(dtype))
     loss.backward()
     B, F = idx_c.shape
@@ -65,7 +69,8 @@ def oracle_train_step(dm, idx, dense, y, dtype=torch.float64, tables_cpu=None):
     for f, (ids, r, ok) in enumerate(log):
         rows[:, f] = torch.where(ok.reshape(-1), ids.reshape(-1).long() + offs[f], torch.full((B,), -1, dtype=torch.int64))
         grads.append(r.grad.reshape(B, 1, -1))
-    return {'logit': logit.detach(), 'loss': float(loss.detach()), 'weights': w, 'rows': rows,
+    return {'min_abs_relu_input': min(probe) if probe else float('inf'),
+            'logit': logit.detach(), 'loss': float(loss.detach()), 'weights': w, 'rows': rows,
             'row_grads': torch.cat(grads, 1), 'tables_cpu': tables_cpu, 'row_offsets': offs}
 
 
@@ -114,16 +119,48 @@ def oracle_dense_grads(dm, w):
                 add(d.bias, w[key][i - 1][1].grad)
             i += 1
     if 'dcn_cross_layer' in L and 'dcn_cross_kernels' in w:
-        for k, kw in zip(L['dcn_cross_layer'].kernels, w['dcn_cross_kernels']):
-            add(k, kw.grad)
-        for b_, bw in zip(L['dcn_cross_layer'].bias, w['dcn_cross_bias']):
-            add(b_, bw.grad)
+        # the product keeps the L (C,1) kernels / biases as the rows of two stacked parameters (models/layers.py Cross)
+        cr = L['dcn_cross_layer']
+        if all(kw.grad is not None for kw in w['dcn_cross_kernels']):
+            add(cr.kernel_stack, torch.stack([kw.grad.reshape(-1) for kw in w['dcn_cross_kernels']], 0))
+            add(cr.bias_stack, torch.stack([bw.grad.reshape(-1) for bw in w['dcn_cross_bias']], 0))
     return out
 
 
-def check_train_step(dm, batch, adam=True, lr=1e-3):
+def check_train_step(dm, batch, adam=True, lr=1e-3, grad_tol=2e-4):
     """Run ONE product train step (forward_backward [+ optimizer.step]) on `batch` = (idx, dense, y) device tensors and
-    compare everything it produced with the oracle.  -> dict of error figures (see keys below).  The caller asserts."""
+    compare everything it produced with the oracle.  -> dict of error figures (see keys below).  The caller asserts.
+
+    relu'(0): a unit whose float64 input lies within fp32 rounding (~1e-7 here) of zero has no derivative the two
+    precisions can agree on, and with 1.5 M relu units per batch one such unit turns up every few batches; it moves
+    db1 / dW1 / the row gradients by one full term (seen: batch seed 1234 on the DCN model, |input| = 4e-7 -> dW1 off
+    by 7.6e-3 of its max, everything else 2e-7; both sides agree to 2e-7 once the bias is 3e-6 away).  So: when the
+    gradient comparison fails AND the oracle saw a relu input below 1e-5, every bias of the Dense layers feeding a relu is
+    shifted by +2e-5 on the product model and the comparison (forward + backward, no optimizer step yet) is repeated, at
+    most twice.  `relu_kink_retries` and `first_attempt` (the failed figures) record it."""
+    first = None
+    for attempt in range(3):
+        last = attempt == 2
+        res = _check_once(dm, batch, adam, lr, (lambda r: last or (r['dense_grad_rel_err'] < grad_tol and
+                                                                    r.get('rows_grad_rel_err', 0.0) < grad_tol) or
+                                                r['min_abs_relu_input'] >= 1e-5))
+        if res.pop('_final'):
+            res['relu_kink_retries'] = attempt
+            if first is not None:
+                res['first_attempt'] = first
+            return res
+        if first is None:
+            first = {k: res[k] for k in ('dense_grad_rel_err', 'rows_grad_rel_err', 'min_abs_relu_input') if k in res}
+        with torch.no_grad():
+            for name, layer in dm.model.layers_by_name.items():
+                if (name.startswith('dnn_dense_') or name.startswith('dcn_dense_')) and getattr(layer, 'bias', None) is not None:
+                    layer.bias.add_(2e-5)
+        dm.optimizer.zero_grad()
+
+
+def _check_once(dm, batch, adam, lr, accept):
+    """one comparison; `accept(res)` decides after the gradient checks whether this attempt is final (only then does the
+    optimizer step run)"""
     import numpy as np
     from deeptables_amd import ops
     idx, dense, y = batch
@@ -133,6 +170,7 @@ def check_train_step(dm, batch, adam=True, lr=1e-3):
     table = emb.tables[key]
     ref = oracle_train_step(dm, idx, dense, y)
     res = {}
+    res['min_abs_relu_input'] = ref['min_abs_relu_input']
     # (1) the gather itself, bit for bit (float32 ids = reference contract, int32 ids = fast path)
     rows_ref32 = torch.cat([t[idx[:, f].long().cpu().clamp(0, t.shape[0] - 1)].unsqueeze(1)
                             for f, t in enumerate(ref['tables_cpu'])], 1)          # [B,F,D] float32
@@ -151,11 +189,14 @@ def check_train_step(dm, batch, adam=True, lr=1e-3):
     torch.cuda.synchronize()
     res['fused_plan'] = type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None
     res['max_abs_logit_err'] = (logit.double().cpu().reshape(-1) - ref['logit'].reshape(-1)).abs().max().item()
+    res['max_abs_logit'] = ref['logit'].abs().max().item()
     res['loss_abs_err'] = abs(float(loss) - ref['loss'])
     worst = 0.0
     pairs = oracle_dense_grads(dm, ref['weights'])
+    own_grads = {}
     for p, g in pairs:
         worst = max(worst, _rel(p.grad.reshape(g.shape), g))
+        own_grads[id(p)] = p.grad.detach().double().cpu().reshape(g.shape).clone()
     res['dense_grad_rel_err'] = worst
     res['dense_grads_checked'] = len(pairs)
     # (3) the sparse gradient, merged per table row on both sides
@@ -177,7 +218,13 @@ def check_train_step(dm, batch, adam=True, lr=1e-3):
         res['rows_grad_per_lookup_rel_err'] = (per_lookup - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
     else:
         res['rows_grad_rel_err'] = float('inf')
-    # (4) one Keras-Adam step
+    res['_final'] = bool(accept(res))
+    if not res['_final']:
+        return res
+    # (4) one Keras-Adam step: the oracle's update rule applied to the gradient the PRODUCT holds (the gradients themselves
+    #     were compared above).  Keras Adam divides by sqrt(v) + 1e-7, so wherever |g| <~ 1e-7 the update is g / eps:
+    #     feeding it the oracle's gradient would turn a 2e-7 (of the tensor max) gradient difference into a difference the
+    #     size of the whole step — an arithmetic property of the rule, not of either implementation.
     if adam:
         t_rows_before = table.detach()[u_ref.to(table.device)].double().cpu()
         st = opt.state.get(id(table))
@@ -186,12 +233,13 @@ def check_train_step(dm, batch, adam=True, lr=1e-3):
         torch.cuda.synchronize()
         t = t_before + 1
         if fresh:       # m = v = 0 before the step: the update is a closed form of the gradient
-            p_new, _, _ = R.keras_adam_step(t_rows_before, v_ref, torch.zeros_like(v_ref), torch.zeros_like(v_ref), t, lr=lr)
+            v_own = v_got if res['rows_identical'] else v_ref
+            p_new, _, _ = R.keras_adam_step(t_rows_before, v_own, torch.zeros_like(v_own), torch.zeros_like(v_own), t, lr=lr)
             got = table.detach()[u_ref.to(table.device)].double().cpu()
             step = (p_new - t_rows_before).abs().max().item()
             res['adam_rows_rel_err'] = (got - p_new).abs().max().item() / max(step, 1e-30)
             worst = 0.0
-            by_id = {id(p): g for p, g in pairs}
+            by_id = own_grads
             for n, before in dense_before:
                 p = dict(dense_parameters(dm))[n]
                 g = by_id.get(id(p))

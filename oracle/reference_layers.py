@@ -121,10 +121,19 @@ def outer_product(xs, kernel, kernel_type='mat'):
     return kp
 
 
+# set to a list by oracle/headline.py: every relu evaluation appends min |input|
+RELU_PROBE = None
+
+
 def _activation(name):
     if name is None or name == 'linear':
         return lambda t: t
     if name == 'relu':
+        if RELU_PROBE is not None:              # test infrastructure: how close does a relu input come to its kink?
+            def probed_relu(t):
+                RELU_PROBE.append(float(t.detach().abs().min())) if t.numel() else None
+                return torch.relu(t)
+            return probed_relu
         return torch.relu
     if name == 'tanh':
         return torch.tanh
