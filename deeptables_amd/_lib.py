@@ -110,6 +110,7 @@ SIGNATURES = {
     'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
     'dt_dcn_supported': (_c_int, [_c_int] * 7),
     'dt_dcn_workspace_bytes': (_c_i64, [_c_int] * 5),
+    'dt_dcn_stamps_offset_floats': (_c_i64, [_c_int] * 5),
     'dt_dcn_accum_floats': (_c_i64, [_c_int] * 4),
     'dt_dcn_accum_offsets': (_c_int, [_c_int, _c_int, _c_int, _c_int, _ptr]),
     'dt_dcn_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,

@@ -612,6 +612,19 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     }
     const float bias1 = p.b1[32 * wave + c];
     const float b2v = p.b2[16 * wave + n16], w3v = p.w3[16 * wave + n16];
+    // DCN: this thread's share of the cross vectors (kernels | biases | w3c), on its way to LDS behind GEMM2
+    constexpr int kStage = LC ? ((2 * LC + 1) * CP + 255) / 256 : 1;
+    float cst[kStage];
+    if constexpr (LC > 0) {
+        const int nv = (2 * dc.L + 1) * CP;
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+            const int e = min(tid + 256 * u, nv - 1);
+            const int v = e / CP, col = min(e - v * CP, dm.C - 1);
+            const float* src = v < dc.L ? dc.cw + (int64_t)v * dm.C : v < 2 * dc.L ? dc.cb + (int64_t)(v - dc.L) * dm.C : dc.w3c;
+            cst[u] = src[col];
+        }
+    }
     float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f;
     if (wave == 0) {
         wov = p.wo[0];
@@ -672,38 +685,82 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     if constexpr (LC > 0) {
         // ---- Cross forward (layers.py:428-436): x_{l+1} = x0 (x_l . w_l) + b_l + x_l on the wave's 8 rows; the
         //      layer's scalars s_l are kept for the backward, the output only meets w3c ----
-        const int nv = (2 * dc.L + 1) * CP;
-        for (int e = tid; e < nv; e += 256) {
-            const int v = e / CP, col = e - v * CP;
-            float t = 0.f;
-            if (col < dm.C) t = v < dc.L ? dc.cw[(int64_t)v * dm.C + col] : v < 2 * dc.L ? dc.cb[(int64_t)(v - dc.L) * dm.C + col] : dc.w3c[col];
-            cwL[e] = t;
+        // the layer vectors: L2 -> LDS once per block (every thread's ~23 loads in flight together: a load-store loop takes
+        // one L2 round trip PER ITERATION, 17K cycles; they are issued before GEMM2, see `cst`), then LDS -> registers once per wave and phase (lane-major: column
+        // 64 k + lane).  FOUR rows advance in lockstep: a wave issues in order, so the only way to hide the latency of a
+        // row's serial chain (dot -> wave reduction -> update, per layer) is another row's independent chain.
+        {
+            const int nv = (2 * dc.L + 1) * CP;
+#pragma unroll
+            for (int u = 0; u < kStage; ++u) {
+                const int e = tid + 256 * u;
+                if (e < nv) cwL[e] = (e % CP) < dm.C ? cst[u] : 0.f;
+            }
         }
         lds_barrier();
-        const float* cbL = cwL + dc.L * CP;
-        const float* w3cL = cwL + 2 * dc.L * CP;
-        for (int i = 0; i < kTM / 4; ++i) {
-            const int row = wave * (kTM / 4) + i;
-            float x0[NCH], xl[NCH];
+        // a lane's NCH columns (64 k + lane) travel as P float pairs: the elementwise work is v_pk_fma_f32 / v_pk_add_f32
+        // (two columns per instruction; a wave64 VALU instruction takes 4 cycles whatever it does, and this phase is bound
+        // by exactly that)
+        constexpr int P = (NCH + 1) / 2;
+        auto ldpair = [&](const float* base, int j) {           // columns 64 (2j) + lane, 64 (2j+1) + lane of an LDS row
+            floatx2 v;
+            v.x = base[128 * j + lane];
+            v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
+            return v;
+        };
+        floatx2 cwr[LC][P], cbr[LC][P], w3r[P];
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) { x0[k] = xs[row * XS + 64 * k + lane]; xl[k] = x0[k]; }
+        for (int j = 0; j < P; ++j) {
+            w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
+#pragma unroll
+            for (int l = 0; l < LC; ++l) {
+                cwr[l][j] = l < dc.L ? ldpair(cwL + l * CP, j) : floatx2{0.f, 0.f};
+                cbr[l][j] = l < dc.L ? ldpair(cwL + (dc.L + l) * CP, j) : floatx2{0.f, 0.f};
+            }
+        }
+        DT_STAMP(stamps, 9);
+        constexpr int RG = 4;
+        for (int i = 0; i < kTM / 4; i += RG) {
+            const int row0 = wave * (kTM / 4) + i;
+            floatx2 x0[RG][P], xl[RG][P];
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+#pragma unroll
+                for (int j = 0; j < P; ++j) { x0[r][j] = ldpair(xs + (row0 + r) * XS, j); xl[r][j] = x0[r][j]; }
 #pragma unroll
             for (int l = 0; l < LC; ++l) {
                 if (l < dc.L) {
-                    float pd = 0.f;
+                    float sl[RG];
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) pd += xl[k] * cwL[l * CP + 64 * k + lane];
-                    const float sl = wave_sum(pd);
-                    if (lane == 0) sL[row * kCrossMax + l] = sl;
+                    for (int r = 0; r < RG; ++r) {
+                        floatx2 pd = {0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) xl[k] = x0[k] * sl + xl[k] + cbL[l * CP + 64 * k + lane];
+                        for (int j = 0; j < P; ++j) pd += xl[r][j] * cwr[l][j];
+                        sl[r] = pd.x + pd.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) sl[r] = wave_sum(sl[r]);
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) {
+                        if (lane == 0) sL[(row0 + r) * kCrossMax + l] = sl[r];
+                        const floatx2 s2 = {sl[r], sl[r]};
+#pragma unroll
+                        for (int j = 0; j < P; ++j) xl[r][j] = x0[r][j] * s2 + (xl[r][j] + cbr[l][j]);
+                    }
                 }
             }
-            float pz = 0.f;
+            float pz[RG];
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) pz += xl[k] * w3cL[64 * k + lane];
-            pz = wave_sum(pz);
-            if (lane == 0) zcs[row] = pz;
+            for (int r = 0; r < RG; ++r) {
+                floatx2 t = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < P; ++j) t += xl[r][j] * w3r[j];
+                pz[r] = t.x + t.y;
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r) pz[r] = wave_sum(pz[r]);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) if (lane == 0) zcs[row0 + r] = pz[r];
         }
     }
     lds_barrier();
@@ -818,81 +875,130 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         //        g_l = g_{l+1} + w_l t_l,  d w_l += x_l t_l,  d b_l += g_{l+1},  dXn_cross = g_0 + sum_l g_{l+1} s_l
         //      dXn_cross leaves for HBM (kernel D adds it to dH1 . W1^T); its two BN-backward column sums, d w3c and the
         //      cross gradients are summed over the rows in registers, over the waves in LDS ----
-        const float* cbL = cwL + dc.L * CP;
-        const float* w3cL = cwL + 2 * dc.L * CP;
-        float mu[NCH], rs[NCH];
-        float a_sc[NCH], a_scx[NCH], a_w3[NCH], a_cw[LC][NCH], a_cb[LC][NCH];
+        // TWO rows in lockstep (see the forward); x_l is walked BACK from x_L (x_l = x_{l+1} - x0 s_l - b_l) instead of being
+        // kept for every layer: 5 row vectors live per row, not L + 6
+        constexpr int P = (NCH + 1) / 2;                      // column pairs, see the forward
+        auto ldpair = [&](const float* base, int j) {
+            floatx2 v;
+            v.x = base[128 * j + lane];
+            v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
+            return v;
+        };
+        floatx2 cwr[LC][P], cbr[LC][P], w3r[P], mu[P], rs[P];
+        floatx2 a_sc[P], a_scx[P], a_w3[P], a_cw[LC][P], a_cb[LC][P];
+        const floatx2 zero2 = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            mu[k] = bnp[64 * k + lane];
-            rs[k] = bnp[3 * CP + 64 * k + lane];
-            a_sc[k] = 0.f; a_scx[k] = 0.f; a_w3[k] = 0.f;
-#pragma unroll
-            for (int l = 0; l < LC; ++l) { a_cw[l][k] = 0.f; a_cb[l][k] = 0.f; }
-        }
-        for (int i = 0; i < kTM / 4; ++i) {
-            const int row = wave * (kTM / 4) + i;
-            const int64_t m = m0 + row;
-            const float dzv = dzs[row];
-            float x0[NCH], xr[NCH], xc[LC + 1][NCH], g[NCH], gx0[NCH];
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                xr[k] = X[m * CP + 64 * k + lane];            // raw row (the workspace rows of a ragged tile are zero)
-                x0[k] = xs[row * XS + 64 * k + lane];
-                xc[0][k] = x0[k];
-            }
+        for (int j = 0; j < P; ++j) {
+            w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
+            mu[j] = ldpair(bnp, j);
+            rs[j] = ldpair(bnp + 3 * CP, j);
+            a_sc[j] = zero2; a_scx[j] = zero2; a_w3[j] = zero2;
 #pragma unroll
             for (int l = 0; l < LC; ++l) {
-                if (l < dc.L) {
-                    const float sl = sL[row * kCrossMax + l];
+                cwr[l][j] = l < dc.L ? ldpair(cwL + l * CP, j) : zero2;
+                cbr[l][j] = l < dc.L ? ldpair(cwL + (dc.L + l) * CP, j) : zero2;
+                a_cw[l][j] = zero2; a_cb[l][j] = zero2;
+            }
+        }
+        DT_STAMP(stamps, 10);
+        constexpr int RG = 2;
+        for (int i = 0; i < kTM / 4; i += RG) {
+            const int row0 = wave * (kTM / 4) + i;
+            floatx2 x0[RG][P], xr[RG][P], xc[RG][P], g[RG][P], gx0[RG][P];
+            float dzv[RG];
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) xc[l + 1][k] = x0[k] * sl + xc[l][k] + cbL[l * CP + 64 * k + lane];
-                } else {
+            for (int r = 0; r < RG; ++r) {
+                const int64_t m = m0 + row0 + r;
+                dzv[r] = dzs[row0 + r];
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) xc[l + 1][k] = xc[l][k];
+                for (int j = 0; j < P; ++j) {
+                    const float* xg = X + m * CP + 128 * j + lane;     // raw row (the workspace rows of a ragged tile are zero)
+                    xr[r][j].x = xg[0];
+                    xr[r][j].y = (2 * j + 1 < NCH) ? xg[64] : 0.f;
+                    x0[r][j] = ldpair(xs + (row0 + r) * XS, j);
+                    xc[r][j] = x0[r][j];
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                g[k] = dzv * w3cL[64 * k + lane];
-                a_w3[k] += dzv * xc[LC][k];
-                gx0[k] = 0.f;
+            for (int l = 0; l < LC; ++l) {                       // forward again, with the saved scalars: x_L
+                if (l < dc.L) {
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) {
+                        const float sl = sL[(row0 + r) * kCrossMax + l];
+                        const floatx2 s2 = {sl, sl};
+#pragma unroll
+                        for (int j = 0; j < P; ++j) xc[r][j] = x0[r][j] * s2 + (xc[r][j] + cbr[l][j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const floatx2 d2 = {dzv[r], dzv[r]};
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    g[r][j] = d2 * w3r[j];
+                    a_w3[j] += d2 * xc[r][j];
+                    gx0[r][j] = zero2;
+                }
             }
 #pragma unroll
             for (int l = LC - 1; l >= 0; --l) {
                 if (l < dc.L) {
-                    float pt = 0.f;
+                    float tl[RG], sl[RG];
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) pt += g[k] * x0[k];
-                    const float tl = wave_sum(pt);
-                    const float sl = sL[row * kCrossMax + l];
+                    for (int r = 0; r < RG; ++r) {
+                        floatx2 pt = zero2;
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) {
-                        a_cb[l][k] += g[k];
-                        a_cw[l][k] += xc[l][k] * tl;
-                        gx0[k] += g[k] * sl;
-                        g[k] += cwL[l * CP + 64 * k + lane] * tl;
+                        for (int j = 0; j < P; ++j) pt += g[r][j] * x0[r][j];
+                        tl[r] = pt.x + pt.y;
+                        sl[r] = sL[(row0 + r) * kCrossMax + l];
+                    }
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) tl[r] = wave_sum(tl[r]);
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) {
+                        const floatx2 t2 = {tl[r], tl[r]}, s2 = {sl[r], sl[r]};
+#pragma unroll
+                        for (int j = 0; j < P; ++j) {
+                            xc[r][j] = (xc[r][j] - cbr[l][j]) - x0[r][j] * s2;        // x_l from x_{l+1}
+                            a_cb[l][j] += g[r][j];
+                            a_cw[l][j] += xc[r][j] * t2;
+                            gx0[r][j] += g[r][j] * s2;
+                            g[r][j] += cwr[l][j] * t2;
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const float dx = g[k] + gx0[k];
-                if (m < dm.B) dc.dXc[m * CP + 64 * k + lane] = dx;
-                a_sc[k] += dx;
-                a_scx[k] += dx * ((xr[k] - mu[k]) * rs[k]);
+            for (int r = 0; r < RG; ++r) {
+                const int64_t m = m0 + row0 + r;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const floatx2 dx = g[r][j] + gx0[r][j];
+                    if (m < dm.B) {
+                        dc.dXc[m * CP + 128 * j + lane] = dx.x;
+                        if (2 * j + 1 < NCH) dc.dXc[m * CP + 128 * j + 64 + lane] = dx.y;
+                    }
+                    a_sc[j] += dx;
+                    a_scx[j] += dx * ((xr[r][j] - mu[j]) * rs[j]);
+                }
             }
         }
-        // the 4 waves' sums meet in the (now dead) Xn tile: [(3 + 2 L)][CP], wave by wave
+        // the 4 waves' sums meet in LDS (every other region is dead): waves 0 / 1 store their [(3 + 2 L)][CP] sums into two
+        // slabs with plain stores, waves 2 / 3 then add theirs (one vector = 7 reads, 7 adds, 7 writes in flight), and the
+        // record written below is slab 0 + slab 1.  (Four read-modify-write passes over one slab cost 28K cycles.)
+        DT_STAMP(stamps, 11);
         lds_barrier();
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-                auto put = [&](int v, const float (&a)[NCH]) {
+        const int nrec0 = (3 + 2 * dc.L) * CP;
+        float* slab = lds + (wave & 1) * nrec0;
+        for (int round = 0; round < 2; ++round) {
+            if ((wave >> 1) == round) {
+                auto put = [&](int v, const floatx2 (&a)[P]) {
+                    float t[NCH];
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) {
-                        float* q = xs + v * CP + 64 * k + lane;
-                        *q = w == 0 ? a[k] : *q + a[k];
-                    }
+                    for (int k = 0; k < NCH; ++k) t[k] = round ? slab[v * CP + 64 * k + lane] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) slab[v * CP + 64 * k + lane] = t[k] + ((k & 1) ? a[k >> 1].y : a[k >> 1].x);
                 };
                 put(0, a_sc); put(1, a_scx); put(2, a_w3);
 #pragma unroll
@@ -901,8 +1007,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             }
             lds_barrier();
         }
-        const int nrec = (3 + 2 * dc.L) * CP;
-        for (int e = tid; e < nrec; e += 256) prec[pl.cross + e] = xs[e];
+        DT_STAMP(stamps, 12);
+        for (int e = tid; e < nrec0; e += 256) prec[pl.cross + e] = lds[e] + lds[nrec0 + e];
     }
     DT_STAMP(stamps, 8);
 }
@@ -1574,8 +1680,9 @@ static int tower_train_step(
                        grad_rows);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
-        const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
-                             (dcn ? kTM + kTM * kCrossMax + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
+        size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
+                       (dcn ? kTM + kTM * kCrossMax + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
+        if (dcn) ldsC = max(ldsC, 2 * (size_t)(3 + 2 * Lc) * dm.CP * sizeof(float));      // the two reduction slabs
         DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
 #define DT_C(N)                                                                                                     \
     case N:                                                                                                         \
@@ -1661,8 +1768,9 @@ extern "C" int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int
     DeepFmDims dm; int lpr;
     if (!dt_deepfm_supported(B, F, D, Nd, H1, H2) || L < 1 || L > kCrossMax) return 0;
     if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return 0;
-    const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM + kTM +
-                         kTM * kCrossMax + (2 * L + 1) * dm.CP) * sizeof(float);
+    size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM + kTM +
+                   kTM * kCrossMax + (2 * L + 1) * dm.CP) * sizeof(float);
+    ldsC = max(ldsC, 2 * (size_t)(3 + 2 * L) * dm.CP * sizeof(float));        // the tile kernel's two reduction slabs
     const int FD16 = ((F * D + 15) >> 4) << 4;
     const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + 2 * kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM + ((F + 3) & ~3) +
                          2 * kTM * F) * sizeof(float);
@@ -1673,6 +1781,12 @@ extern "C" int64_t dt_dcn_workspace_bytes(int B, int F, int D, int Nd, int L) {
     DeepFmDims dm; int lpr;
     if (!deepfm_dims(B, F, D, Nd, &dm, &lpr) || L < 1 || L > kCrossMax) return -1;
     return deepfm_ws_layout(dm, L).total * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t dt_dcn_stamps_offset_floats(int B, int F, int D, int Nd, int L) {
+    DeepFmDims dm; int lpr;
+    if (!deepfm_dims(B, F, D, Nd, &dm, &lpr) || L < 1 || L > kCrossMax) return -1;
+    return deepfm_ws_layout(dm, L).stamps;
 }
 
 extern "C" int64_t dt_dcn_accum_floats(int F, int D, int Nd, int L) {

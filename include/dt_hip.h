@@ -366,6 +366,7 @@ int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
  * dt_deepfm_train_step (workspace: dt_dcn_workspace_bytes).                                                        */
 int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int L);
 int64_t dt_dcn_workspace_bytes(int B, int F, int D, int Nd, int L);
+int64_t dt_dcn_stamps_offset_floats(int B, int F, int D, int Nd, int L);   /* DT_DEEPFM_STAMPS diagnostics */
 int64_t dt_dcn_accum_floats(int F, int D, int Nd, int L);
 int dt_dcn_accum_offsets(int F, int D, int Nd, int L, int64_t* out12_host);
 int dt_dcn_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,

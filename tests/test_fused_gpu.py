@@ -115,7 +115,7 @@ def test_fused_dcn_matches_oracle_and_generic_path(dev, B, F, Nd, D, L, idt):
     ins = [idx.to(getattr(torch, idt)).to(dev)] + ([dense.to(dev)] if Nd else [])
     loss, logit = dm.forward_backward(ins, y.to(dev))
     torch.cuda.synchronize()
-    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4
+    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4 * max(1.0, ref_logit.abs().max().item())
     assert abs(float(loss) - float(ref_loss)) < 1e-5
     Ly = dm.model.layers_by_name
     cr = Ly['dcn_cross_layer']
@@ -137,7 +137,8 @@ def test_fused_dcn_matches_oracle_and_generic_path(dev, B, F, Nd, D, L, idt):
     fused = [a.clone() for a, _ in pairs]
     dm._fused_plan = None
     loss2, logit2 = dm.forward_backward(ins, y.to(dev))
-    assert (logit2 - logit).abs().max().item() < 1e-4
+    # two fp32 evaluation orders of an L-layer cross network: 1e-4 of the logit scale
+    assert (logit2 - logit).abs().max().item() < 1e-4 * max(1.0, logit.abs().max().item())
     assert rel(Ly['dcn_dense_1'].kernel.grad, fused[4]) < 2e-4
     assert rel(cr.kernel_stack.grad, fused[8]) < 2e-4
     # and a whole train step (Adam on the flat buffer incl. the cross parameters) runs

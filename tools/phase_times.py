@@ -7,7 +7,8 @@ import bench
 from deeptables_amd.models import deepnets
 from deeptables_amd._lib import lib
 dev = torch.device('cuda', 0)
-dm = bench.build_model(deepnets.DeepFM, dev)
+model = os.environ.get('MODEL', 'DeepFM')
+dm = bench.build_model(getattr(deepnets, model), dev, None, bench.D, bench.MODEL_PARAMS.get(model))
 batches = bench.make_batches(8192, dev, 1)
 dm.model.train()
 for i in range(5):
@@ -15,7 +16,8 @@ for i in range(5):
 torch.cuda.synchronize()
 plan = dm.fused_plan()
 ws = plan._bufs[8192]['ws']
-off = lib().dt_deepfm_stamps_offset_floats(8192, plan.F, plan.D, plan.Nd)
+off = lib().dt_dcn_stamps_offset_floats(8192, plan.F, plan.D, plan.Nd, plan.nl) if model == 'DCN' else \
+    lib().dt_deepfm_stamps_offset_floats(8192, plan.F, plan.D, plan.Nd)
 tiles = 256
 flat = ws[off: off + 5 * tiles * 16 * 2].cpu().numpy().view(np.uint64).astype(np.float64)
 raw = list(flat[:3 * tiles * 16].reshape(3, tiles, 16)) + [flat[3 * tiles * 16:].reshape(2 * tiles, 16)]
@@ -23,14 +25,14 @@ v1 = 'DT_DEEPFM_V1' in os.environ
 labels = [{0: 'entry', 1: 'staged', 2: 'gemm1', 3: 'h1 stored', 4: 'gemm2+h2', 5: 'end'},
           {0: 'entry', 1: 'prologue', 2: 'dH1', 3: 'end(dXn)'}] if v1 else \
     [{0: 'entry', 6: 'prologue loads issued', 7: 'bn params in LDS', 1: 'chunk0 staged', 2: 'gemm1 done',
-      3: 'h1 in LDS', 4: 'gemm2 + partial logits', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)'},
+      3: 'h1 in LDS', 4: 'gemm2 + partial logits', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)', 9: 'DCN: cross vectors in LDS', 10: 'DCN: bwd registers loaded', 11: 'DCN: bwd rows done', 12: 'DCN: wave sums merged'},
      {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'},
      {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)'},
      {0: 'entry', 1: 'ids + hash insert done, row loads issued', 2: 'rows arrived, X stores issued', 3: 'row sums done', 4: 'block barrier', 5: 'end (BN partials)'}]
 for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad', 'k_sparse_fwd'])):
     st = raw[k]
     rel = st - st[:, :1]
-    order = sorted(labels[k], key=lambda sl: rel[:, sl].mean())
+    order = sorted([sl for sl in labels[k] if st[:, sl].max() > 0], key=lambda sl: rel[:, sl].mean())
     print(kn, 'stamps of wave 0 (shader cycles since entry; mean / min / max over the blocks, and the step from the previous stamp):')
     prev = 0.0
     for sl in order:
