@@ -48,6 +48,28 @@ def algorithmic_bytes_per_row(n_dense_params, batch, dim=D, optimizer=True):
     return fwd_bwd + 6 * 4 * F * dim
 
 
+MFMA_PEAK_F32_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense (MI355X_MICROARCH.md)
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16, dense
+
+
+def mfma_flops_per_row(model, dim):
+    """Matrix-core flops of one train step per batch row for the two MFMA-bound graphs (north_star: CIN and the AutoInt
+    attention are the MFMA paths), forward + backward = 3x the forward contraction count (dgrad + wgrad):
+      xDeepFM: CIN layer k contracts Z[b,d,(i,j)] W[(i,j),l]: 2 D F0 H_{k-1} H_k flops per row (layers.py:692-710)
+      AutoInt: per interacting layer 4 projections 2 F D D each + scores / context 2 * 2 F F D (layers.py:119-153)"""
+    if model == 'xDeepFM':
+        sizes = MODEL_PARAMS['xDeepFM']['cin_params']['cross_layer_size']
+        h, fl = F, 0
+        for size in sizes:
+            fl += 2 * dim * F * h * size
+            h = size
+        return 3.0 * fl
+    if model == 'AutoInt':
+        n = MODEL_PARAMS['AutoInt']['autoint_params']['num_attention']
+        return 3.0 * n * (4 * 2 * F * dim * dim + 2 * 2 * F * F * dim)
+    return None
+
+
 # BASELINE.json configs[2..4]: the non-default layer parameters of the other benchmarked graphs
 MODEL_PARAMS = {
     'xDeepFM': dict(cin_params={'cross_layer_size': (128, 128, 128), 'activation': 'relu', 'use_residual': False,
@@ -440,6 +462,20 @@ def main():
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
             'step_us': step_stats,
         }
+        fpr = mfma_flops_per_row(args.model, dim)
+        if fpr is not None:      # CIN / attention graphs: the matrix cores bound the step, not HBM
+            bf16 = args.model == 'xDeepFM' and os.environ.get('DT_AMD_CIN_DTYPE') == 'bf16'
+            peak = MFMA_PEAK_BF16_TFLOPS if bf16 else MFMA_PEAK_F32_TFLOPS
+            tf = args.batch * fpr / step_s / 1e12
+            result['roofline_hbm'] = result['roofline']
+            result['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+                                  'traffic': None, 'mfma_dtype': 'bf16 (fp32 accumulate)' if bf16 else 'f32',
+                                  'flops_per_row': fpr, 'launch_us': step_s * 1e6,
+                                  'launch': 'one hipGraph replay = one train step; flops = the CIN / attention contractions, '
+                                            'fwd + dgrad + wgrad'}
+            if bf16:
+                result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
+
         if parity is not None:
             result['parity'] = parity
         if not args.no_extras and world == 1:

@@ -1,6 +1,6 @@
 """Builds profiles/deepfm_traffic.json (stamped with the source hash of the kernels it was measured on) from the two rocprofv3 PMC passes (tools_pmc.sh):
-    python tools/make_traffic.py gpurun_out/r01_pmc_fetch/r01_pmc_fetch_counter_collection.csv \
-                                 gpurun_out/r01_pmc_write/r01_pmc_write_counter_collection.csv
+    python tools/make_traffic.py gpurun_out/r02_pmc_fetch/r02_pmc_fetch_counter_collection.csv \
+                                 gpurun_out/r02_pmc_write/r02_pmc_write_counter_collection.csv
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Correction (MI355X_MICROARCH.md §HBM): on gfx950
 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced STREAMING read -> doubled for the kernels whose
 reads are float4 streams; everything else is left as reported (uncalibrated)."""
@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-WIDE = {'k_mlp_fwd': 'X tile streamed as float4', 'k_sparse_bwd': 'X and dXn rows streamed as float4'}
+WIDE = {'k_mlp_fwd3': 'X tile streamed as float4', 'k_dx_sparse_bwd': 'X and dH1 tiles streamed as float4'}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,7 +44,7 @@ def main():
     opt = B * 6 * 4 * F * D                      # p, m, v of the looked-up rows, read + write
     out = {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py '
-                  '--steps 20 --warmup 3 --no-extras --no-cpu-baseline (tools_pmc.sh), averages per launch, KB -> bytes '
+                  '--steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-parity (tools_pmc.sh), averages per launch, KB -> bytes '
                   'x1024; built by tools/make_traffic.py',
         'step': 'fwd + bwd + Adam (the timed region of bench.py)',
         'per_kernel_KB': per,
