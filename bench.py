@@ -495,7 +495,7 @@ def main():
                 result['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(result))
     barrier()
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
