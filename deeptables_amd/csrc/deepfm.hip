@@ -278,8 +278,12 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
                                                int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
     if ((int)blockIdx.x >= bn_blocks + layout_blocks) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots[];    // [kElectSlots]
+        // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
+        // so the field's row list is fetched into ONE L2 instead of eight
         const int e = (int)blockIdx.x - bn_blocks - layout_blocks;
-        const int f = e >> dd.parts_log2, part = e & ((1 << dd.parts_log2) - 1);
+        const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
+        const int f = 8 * (j >> dd.parts_log2) + ((int)blockIdx.x & 7);
+        if (f >= dm.F) return;
         for (int i = threadIdx.x; i < kElectSlots; i += blockDim.x) eslots[i] = 0ULL;
         __syncthreads();
         const int64_t* rf = dd.rows_fm + (int64_t)f * dm.B;
@@ -1672,7 +1676,7 @@ static int tower_train_step(
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2};
-    const int elect_blocks = dd.mark ? (F << dd.parts_log2) : 0;
+    const int elect_blocks = dd.mark ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = dd.mark ? (size_t)kElectSlots * 8 : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,

@@ -257,9 +257,10 @@ class DeepModel:
             self._fused_plan = make_fused_plan(self)
         return self._fused_plan
 
-    def forward_backward(self, inputs, y):
-        """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads."""
-        plan = self.fused_plan() if self.model.training else None
+    def forward_backward(self, inputs, y, sample_weight=None):
+        """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
+        sample_weight [B] (Keras fit's sample_weight x class_weight): the weighted loss runs on the layer-by-layer path."""
+        plan = self.fused_plan() if (self.model.training and sample_weight is None) else None
         self.optimizer.zero_grad(flat=plan is None) if hasattr(self.optimizer, 'register_flat_group') \
             else self.optimizer.zero_grad()
         if plan is not None:
@@ -272,13 +273,14 @@ class DeepModel:
         self.model._dt_flat_grad = getattr(self, '_generic_flat_grad', None)
         self.model._dt_sharded_step = False
         logit = self.model(inputs)
-        loss = self._loss(logit, y)
+        loss = self._loss(logit, y) if sample_weight is None else \
+            training.weighted_loss(self.loss_name, logit, y, sample_weight)
         loss.backward()
         return loss.detach(), logit.detach()
 
-    def train_step(self, inputs, y):
+    def train_step(self, inputs, y, sample_weight=None):
         """forward -> loss -> backward -> (data-parallel gradient exchange) -> optimizer step."""
-        loss, logit = self.forward_backward(inputs, y)
+        loss, logit = self.forward_backward(inputs, y, sample_weight)
         strategy = self.config.distribute_strategy
         if strategy is not None:
             strategy.exchange_gradients(self.model, self.optimizer)
@@ -309,6 +311,19 @@ class DeepModel:
             X_val, y_val = validation_data[0], validation_data[1]
         if batch_size is None:
             batch_size = 128
+        # Keras fit: class_weight {label: w} maps to a per-row weight and multiplies sample_weight (binary / multiclass
+        # labels; reference deeptable.py:354-365 passes both through to keras)
+        weights = None
+        if class_weight is not None or sample_weight is not None:
+            weights = np.ones(len(X), dtype=np.float32) if sample_weight is None else \
+                np.asarray(sample_weight, dtype=np.float32).reshape(-1).copy()
+            if validation_data is None and validation_split and len(weights) != len(X):
+                weights = weights[tr_i]                 # the caller's weights follow the rows kept for training
+            if class_weight is not None:
+                yl = np.asarray(y)
+                yl = yl.argmax(-1) if yl.ndim > 1 and yl.shape[-1] > 1 else yl.reshape(-1)
+                cw = {int(k): float(v) for k, v in dict(class_weight).items()}
+                weights = weights * np.array([cw.get(int(v), 1.0) for v in yl], dtype=np.float32)
         strategy = self.config.distribute_strategy
         if strategy is not None and not hasattr(strategy, 'exchange_gradients'):
             raise ValueError('[distribute_strategy] in ModelConfig must be a deeptables_amd.parallel.'
@@ -317,11 +332,14 @@ class DeepModel:
             self.build(strategy.device if strategy is not None else None)
         if strategy is not None:
             strategy.broadcast_parameters(self.model)
-            X, y = strategy.shard(X, y)
+            if weights is not None:
+                (X, y), weights = strategy.shard(X, y), strategy.shard(weights, weights)[0]
+            else:
+                X, y = strategy.shard(X, y)
         train = training.TableBatches(X, y, self.categorical_columns, self.continuous_columns, self.device,
                                       self.task, self.num_classes,
                                       var_len_categorical_columns=self.var_len_categorical_columns,
-                                      resident=getattr(self, 'feed_resident', None))
+                                      resident=getattr(self, 'feed_resident', None), sample_weight=weights)
         val = None
         if X_val is not None and len(X_val) > 0:
             val = training.TableBatches(X_val, y_val, self.categorical_columns, self.continuous_columns,
@@ -344,7 +362,10 @@ class DeepModel:
             while step < steps_per_epoch:
                 progressed = False
                 for ins, yb in train.iterate(min(batch_size, train.n), shuffle, drop_remainder=True):
-                    loss, logit = self.train_step(ins, yb)
+                    wb = None
+                    if train.weighted:
+                        wb, yb = yb[:, -1].contiguous(), yb[:, :-1].contiguous()
+                    loss, logit = self.train_step(ins, yb, wb)
                     losses.append(loss)
                     probs.append(self._activate(logit))
                     ys.append(yb)

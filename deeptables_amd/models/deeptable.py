@@ -153,13 +153,25 @@ class DeepTable:
                                     self.preprocessor.categorical_columns, self.preprocessor.continuous_columns,
                                     var_categorical_len_columns=getattr(self.preprocessor,
                                                                         'var_len_categorical_columns', None))
+        if class_weight is None and self.config.apply_class_weight and self.task != consts.TASK_REGRESSION:
+            class_weight = self.get_class_weight(y_t)               # reference deeptable.py:354-355
         history = model.fit(X_t, y_t, batch_size=batch_size, epochs=epochs, verbose=verbose, callbacks=callbacks,
                             validation_split=validation_split, validation_data=validation_data, shuffle=shuffle,
+                            class_weight=class_weight, sample_weight=sample_weight,
                             initial_epoch=initial_epoch, steps_per_epoch=steps_per_epoch,
                             validation_steps=validation_steps, validation_freq=validation_freq)
         self.model = model
         self._models['dt-1'] = model
         return model, history
+
+    def get_class_weight(self, y):
+        """'balanced' class weights n / (classes * count) over the encoded labels (reference deeptable.py:651-668:
+        sklearn compute_class_weight('balanced'))."""
+        yl = np.asarray(y)
+        yl = yl.argmax(-1) if yl.ndim > 1 and yl.shape[-1] > 1 else yl.reshape(-1).astype(np.int64)
+        n_cls = len(self.classes_) if self.classes_ is not None else int(yl.max()) + 1
+        counts = np.bincount(yl, minlength=n_cls).astype(np.float64)
+        return {k: float(len(yl) / (n_cls * c)) if c > 0 else 0.0 for k, c in enumerate(counts)}
 
     def _require_model(self):
         if self.model is None:

@@ -42,6 +42,24 @@ def bce_from_logits(logit, y):
     return (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-z.abs()))).mean()
 
 
+def weighted_loss(loss_name, logit, y, w):
+    """Keras `sample_weight` / `class_weight` semantics (keras Model.fit -> compile loss with reduction
+    SUM_OVER_BATCH_SIZE): per-sample loss times its weight, summed, divided by the batch size.  Element-wise torch on
+    [B, outputs] — not on the hot path (the fused steps and the one-launch BCE are used only without weights)."""
+    B = y.shape[0]
+    z = logit.reshape(B, -1)
+    t = y.reshape(B, -1).to(z.dtype)
+    if loss_name == 'binary_crossentropy':
+        per = (torch.clamp(z, min=0) - z * t + torch.log1p(torch.exp(-z.abs()))).mean(-1)
+    elif loss_name == 'categorical_crossentropy':
+        per = -(torch.log_softmax(z, dim=-1) * t).sum(-1)
+    elif loss_name in ('mse', 'mean_squared_error'):
+        per = ((z - t) ** 2).mean(-1)
+    else:
+        raise ValueError(f'sample / class weights with loss {loss_name!r}')
+    return (per * w.reshape(B).to(z.dtype)).sum() / B
+
+
 def categorical_ce_from_logits(logit, y_onehot):
     return -(torch.log_softmax(logit, dim=-1) * y_onehot).sum(-1).mean()
 
@@ -380,8 +398,9 @@ class TableBatches:
 
     def __init__(self, X, y, categorical_columns, continuous_columns, device, task=None, num_classes=None,
                  cat_dtype=torch.int32, var_len_categorical_columns=None, resident=None,
-                 max_resident_bytes=32 << 30, ring=3):
+                 max_resident_bytes=32 << 30, ring=3, sample_weight=None):
         self.n = len(X)
+        self.weighted = sample_weight is not None      # per-row loss weights ride as the LAST column of y
         self.device = torch.device(device)
         get = (lambda cols: X[cols].values) if hasattr(X, 'columns') else None
         host = []          # [(kind, host tensor)] in model input order: cat, var-len..., dense... (deepmodel.py:310)
@@ -402,6 +421,11 @@ class TableBatches:
             if task == consts.TASK_MULTICLASS and y.ndim == 1:
                 y = np.eye(num_classes, dtype=np.float32)[y.astype(np.int64)]
             y_host = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32))
+            if sample_weight is not None:
+                w = torch.as_tensor(np.ascontiguousarray(np.asarray(sample_weight).reshape(-1), dtype=np.float32))
+                if w.shape[0] != y_host.shape[0]:
+                    raise ValueError(f'sample_weight has {w.shape[0]} entries for {y_host.shape[0]} rows')
+                y_host = torch.cat([y_host.reshape(y_host.shape[0], -1), w[:, None]], 1).contiguous()
         nbytes = sum(t.numel() * t.element_size() for _, t in host) + (0 if y_host is None else y_host.numel() * 4)
         self.resident = (nbytes <= max_resident_bytes) if resident is None else bool(resident)
         self.kinds = [k for k, _ in host]
@@ -503,8 +527,13 @@ class TableBatches:
                 sizes[nxt] = self._stage(nxt % self._ring, starts[nxt], min(starts[nxt] + batch_size, self.n),
                                          perm_host)
             yb = outs.pop() if self.y is not None else None
-            yield outs, yb
-            if ev is not None:                                         # mark where the consumer finished with it
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream(self.device))
-                consumed[0] = done
+            try:
+                yield outs, yb
+            finally:
+                # mark where the consumer finished with the slot — also when it stops at this batch and closes the
+                # generator (fit breaks out at steps_per_epoch): the next iterate() must not restage the slot against a
+                # stale event while this step's kernels may still read the device buffers
+                if ev is not None:
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                    consumed[0] = done
