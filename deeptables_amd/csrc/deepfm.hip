@@ -712,18 +712,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
             return v;
         };
-        floatx2 cwr[LC][P], cbr[LC][P], w3r[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
-#pragma unroll
-            for (int l = 0; l < LC; ++l) {
-                cwr[l][j] = l < dc.L ? ldpair(cwL + l * CP, j) : floatx2{0.f, 0.f};
-                cbr[l][j] = l < dc.L ? ldpair(cwL + (dc.L + l) * CP, j) : floatx2{0.f, 0.f};
-            }
-        }
         DT_STAMP(stamps, 9);
-        constexpr int RG = 4;
+        // all EIGHT rows of the wave advance in lockstep; the layer vectors are read from LDS where they are used (two
+        // columns per ds_read2) — holding 2L+1 of them in registers pushed the accumulators of the backward into AGPRs
+        constexpr int RG = kTM / 4;
+        floatx2 w3r[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
         for (int i = 0; i < kTM / 4; i += RG) {
             const int row0 = wave * (kTM / 4) + i;
             floatx2 x0[RG][P], xl[RG][P];
@@ -731,26 +726,27 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             for (int r = 0; r < RG; ++r)
 #pragma unroll
                 for (int j = 0; j < P; ++j) { x0[r][j] = ldpair(xs + (row0 + r) * XS, j); xl[r][j] = x0[r][j]; }
+#pragma unroll 1
+            for (int l = 0; l < dc.L; ++l) {
+                floatx2 cw[P], cb[P];
 #pragma unroll
-            for (int l = 0; l < LC; ++l) {
-                if (l < dc.L) {
-                    float sl[RG];
+                for (int j = 0; j < P; ++j) { cw[j] = ldpair(cwL + l * CP, j); cb[j] = ldpair(cwL + (dc.L + l) * CP, j); }
+                float sl[RG];
 #pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        floatx2 pd = {0.f, 0.f};
+                for (int r = 0; r < RG; ++r) {
+                    floatx2 pd = {0.f, 0.f};
 #pragma unroll
-                        for (int j = 0; j < P; ++j) pd += xl[r][j] * cwr[l][j];
-                        sl[r] = pd.x + pd.y;
-                    }
+                    for (int j = 0; j < P; ++j) pd += xl[r][j] * cw[j];
+                    sl[r] = pd.x + pd.y;
+                }
 #pragma unroll
-                    for (int r = 0; r < RG; ++r) sl[r] = wave_sum(sl[r]);
+                for (int r = 0; r < RG; ++r) sl[r] = wave_sum(sl[r]);
 #pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        if (lane == 0) sL[(row0 + r) * kCrossMax + l] = sl[r];
-                        const floatx2 s2 = {sl[r], sl[r]};
+                for (int r = 0; r < RG; ++r) {
+                    if (lane == 0) sL[(row0 + r) * kCrossMax + l] = sl[r];
+                    const floatx2 s2 = {sl[r], sl[r]};
 #pragma unroll
-                        for (int j = 0; j < P; ++j) xl[r][j] = x0[r][j] * s2 + (xl[r][j] + cbr[l][j]);
-                    }
+                    for (int j = 0; j < P; ++j) xl[r][j] = x0[r][j] * s2 + (xl[r][j] + cb[j]);
                 }
             }
             float pz[RG];
@@ -888,7 +884,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
             return v;
         };
-        floatx2 cwr[LC][P], cbr[LC][P], w3r[P], mu[P], rs[P];
+        floatx2 w3r[P], mu[P], rs[P];
         floatx2 a_sc[P], a_scx[P], a_w3[P], a_cw[LC][P], a_cb[LC][P];
         const floatx2 zero2 = {0.f, 0.f};
 #pragma unroll
@@ -898,14 +894,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             rs[j] = ldpair(bnp + 3 * CP, j);
             a_sc[j] = zero2; a_scx[j] = zero2; a_w3[j] = zero2;
 #pragma unroll
-            for (int l = 0; l < LC; ++l) {
-                cwr[l][j] = l < dc.L ? ldpair(cwL + l * CP, j) : zero2;
-                cbr[l][j] = l < dc.L ? ldpair(cwL + (dc.L + l) * CP, j) : zero2;
-                a_cw[l][j] = zero2; a_cb[l][j] = zero2;
-            }
+            for (int l = 0; l < LC; ++l) { a_cw[l][j] = zero2; a_cb[l][j] = zero2; }
         }
         DT_STAMP(stamps, 10);
-        constexpr int RG = 2;
+        constexpr int RG = 4;
         for (int i = 0; i < kTM / 4; i += RG) {
             const int row0 = wave * (kTM / 4) + i;
             floatx2 x0[RG][P], xr[RG][P], xc[RG][P], g[RG][P], gx0[RG][P];
@@ -923,16 +915,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                     xc[r][j] = x0[r][j];
                 }
             }
+#pragma unroll 1
+            for (int l = 0; l < dc.L; ++l) {                     // forward again, with the saved scalars: x_L
+                floatx2 cb[P];
 #pragma unroll
-            for (int l = 0; l < LC; ++l) {                       // forward again, with the saved scalars: x_L
-                if (l < dc.L) {
+                for (int j = 0; j < P; ++j) cb[j] = ldpair(cwL + (dc.L + l) * CP, j);
 #pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        const float sl = sL[(row0 + r) * kCrossMax + l];
-                        const floatx2 s2 = {sl, sl};
+                for (int r = 0; r < RG; ++r) {
+                    const float sl = sL[(row0 + r) * kCrossMax + l];
+                    const floatx2 s2 = {sl, sl};
 #pragma unroll
-                        for (int j = 0; j < P; ++j) xc[r][j] = x0[r][j] * s2 + (xc[r][j] + cbr[l][j]);
-                    }
+                    for (int j = 0; j < P; ++j) xc[r][j] = x0[r][j] * s2 + (xc[r][j] + cb[j]);
                 }
             }
 #pragma unroll
@@ -946,8 +939,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                 }
             }
 #pragma unroll
-            for (int l = LC - 1; l >= 0; --l) {
+            for (int l = LC - 1; l >= 0; --l) {                  // unrolled: a_cw / a_cb are indexed by the layer
                 if (l < dc.L) {
+                    floatx2 cw[P], cb[P];
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { cw[j] = ldpair(cwL + l * CP, j); cb[j] = ldpair(cwL + (dc.L + l) * CP, j); }
                     float tl[RG], sl[RG];
 #pragma unroll
                     for (int r = 0; r < RG; ++r) {
@@ -964,11 +960,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                         const floatx2 t2 = {tl[r], tl[r]}, s2 = {sl[r], sl[r]};
 #pragma unroll
                         for (int j = 0; j < P; ++j) {
-                            xc[r][j] = (xc[r][j] - cbr[l][j]) - x0[r][j] * s2;        // x_l from x_{l+1}
+                            xc[r][j] = (xc[r][j] - cb[j]) - x0[r][j] * s2;            // x_l from x_{l+1}
                             a_cb[l][j] += g[r][j];
                             a_cw[l][j] += xc[r][j] * t2;
                             gx0[r][j] += g[r][j] * s2;
-                            g[r][j] += cwr[l][j] * t2;
+                            g[r][j] += cw[j] * t2;
                         }
                     }
                 }

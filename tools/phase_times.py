@@ -39,4 +39,11 @@ for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad', '
         m = rel[:, sl].mean()
         print(f'   {labels[k][sl]:>22s}  {m:9.0f}  {rel[:, sl].min():9.0f}  {rel[:, sl].max():9.0f}   +{m - prev:8.0f}')
         prev = m
-    print('   entry skew over blocks (cycles):', st[:, 0].max() - st[:, 0].min())
+    # s_memtime counters differ between XCDs: skew and makespan per XCD (workgroups go round-robin over the 8 XCDs)
+    last = max(order, key=lambda sl: rel[:, sl].mean())
+    sk, mk = [], []
+    for x in range(8):
+        blk = st[x::8]
+        sk.append(blk[:, 0].max() - blk[:, 0].min())
+        mk.append(blk[:, last].max() - blk[:, 0].min())
+    print(f'   per XCD: entry skew over its blocks {np.mean(sk):.0f} (max {np.max(sk):.0f}) cycles; first entry -> last end {np.mean(mk):.0f} (max {np.max(mk):.0f}) cycles')
