@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
 //    BN blocks: 64 columns x 16 waves; lanes run along the columns (256-byte coalesced partial rows), every
 //    wave Chan-merges a slice of the chunk list, the 16 slices meet in LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBnSlices = 16;   // level-1 BN reduction blocks per 64-column group
+constexpr int kBnSlices = 4;    // level-1 BN reduction blocks per 64-column group (each: 16 waves)
 
 struct PrepOut {
     float *mean, *rstd, *sc, *beta;               // all padded to CP
@@ -345,27 +345,26 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
         }
         return;
     }
-    // level 1 of the BN reduction: block = (64-column group, slice of the chunk list), ONE wave, lanes along the
-    // columns (256-byte coalesced partial rows).  A CU pulls only ~20 GB/s from HBM, so the 2.6 MB of partials
-    // must be spread over >= 100 CUs; level 2 (k_bn_final) merges the kBnSlices results per column.
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x >= 64) return;
+    // level 1 of the BN reduction: block = (64-column group, slice of the chunk list); lanes along the columns (256-byte
+    // coalesced partial rows), the block's 16 waves split the slice's chunks so that every partial is loaded in ONE
+    // round trip (<= kBnPerWave per wave; one wave walking the slice in batches paid a round trip per batch: 7 us).
+    // The waves' merged triples meet in LDS, wave 0 merges them.  kBnSlices slices per column group keep ~30 CUs
+    // pulling the 2.6 MB of partials; kernel C merges the kBnSlices results per column in its prologue (level 2).
+    __shared__ float wtri[16][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cgroups = (dm.C + 63) >> 6;
     const int cg = blockIdx.x % cgroups, slice = blockIdx.x / cgroups;
     const int col = cg * 64 + lane;
     const bool cok = col < dm.C;
     const int per = (chunks + kBnSlices - 1) / kBnSlices;
     const int k0 = slice * per, k1 = min(chunks, k0 + per);
-    // the slice's partials in batches of UB, each batch merged at once (bn_merge), the batches by the same formula
-    constexpr int UB = 16, NBATCH = 4;                         // <= 64 chunks per slice (B <= 16,384 at 16 rows per chunk), more: serial tail
-    float bn_[NBATCH], bm_[NBATCH], bq_[NBATCH];
+    const int nw = (int)(blockDim.x >> 6);
+    constexpr int kBnPerWave = 8;                 // 16 waves x 8 = 128 chunks per slice in one round; more: further rounds
+    float an = 0.f, am = 0.f, aq = 0.f;
+    for (int kb = k0 + wave * kBnPerWave; kb < k1; kb += nw * kBnPerWave) {
+        float nb[kBnPerWave], mb[kBnPerWave], qb[kBnPerWave];
 #pragma unroll
-    for (int t = 0; t < NBATCH; ++t) { bn_[t] = 0.f; bm_[t] = 0.f; bq_[t] = 0.f; }
-    int batch = 0;
-    for (int kb = k0; kb < k1; kb += UB, ++batch) {
-        float nb[UB], mb[UB], qb[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
+        for (int u = 0; u < kBnPerWave; ++u) {
             const int k = kb + u;
             const bool ok = cok && k < k1;
             const float* p = partial + (int64_t)(ok ? k : 0) * 3 * dm.C + (cok ? col : 0);
@@ -376,18 +375,22 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             qb[u] = ok ? v2 : 0.f;
         }
         float bn, bm, bq;
-        bn_merge<UB>(nb, mb, qb, bn, bm, bq);
-        const int t = batch < NBATCH - 1 ? batch : NBATCH - 1;
-        if (batch < NBATCH) {
+        bn_merge<kBnPerWave>(nb, mb, qb, bn, bm, bq);
+        const float pn[2] = {an, bn}, pm[2] = {am, bm}, pq[2] = {aq, bq};
+        bn_merge<2>(pn, pm, pq, bn, bm, bq);
+        an = bn; am = bm; aq = bq;
+    }
+    wtri[wave][0][lane] = an; wtri[wave][1][lane] = am; wtri[wave][2][lane] = aq;
+    __syncthreads();
+    if (wave != 0) return;
+    float nb[16], mb[16], qb[16];
 #pragma unroll
-            for (int tt = 0; tt < NBATCH; ++tt) if (tt == t) { bn_[tt] = bn; bm_[tt] = bm; bq_[tt] = bq; }
-        } else {                                               // very large batches: fold into the last register slot
-            const float pn[2] = {bn_[NBATCH - 1], bn}, pm[2] = {bm_[NBATCH - 1], bm}, pq[2] = {bq_[NBATCH - 1], bq};
-            bn_merge<2>(pn, pm, pq, bn_[NBATCH - 1], bm_[NBATCH - 1], bq_[NBATCH - 1]);
-        }
+    for (int w = 0; w < 16; ++w) {
+        const bool ok = w < nw;
+        nb[w] = ok ? wtri[w][0][lane] : 0.f; mb[w] = ok ? wtri[w][1][lane] : 0.f; qb[w] = ok ? wtri[w][2][lane] : 0.f;
     }
     float n, mean, m2;
-    bn_merge<NBATCH>(bn_, bm_, bq_, n, mean, m2);
+    bn_merge<16>(nb, mb, qb, n, mean, m2);
     if (cok) {
         float* q = o.bn2 + (int64_t)slice * 3 * dm.C;
         q[col] = n;
@@ -463,6 +466,7 @@ struct DcnArgs {
     const float* w3c;            // cross part [C] of the kernel applied to Concatenate([cross, dnn])
     int L;
     float* dXc;                  // [B][CP] d loss / d Xn through the cross network (kernel C -> kernel D)
+    int mse;                     // loss: 0 = BinaryCrossentropy on the sigmoid output, 1 = MeanSquaredError on the linear output
 };
 constexpr int kCrossMax = 8;     // cross layers the fused DCN step takes
 
@@ -775,9 +779,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             zz = LC ? zcs[c] + pt                   // Dense(1)(Concatenate([cross, dnn])) (deepnets.py:194-207)
                     : (linv + fmv) + pt;             // Add([linear, fm, dnn]) order
             const float lg = zz * wov + bov;
-            const float pr = 1.0f / (1.0f + expf(-lg));
-            loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
-            dl = (pr - yv) / (float)dm.B;
+            if (dc.mse) {        // regression task (deepmodel.py:130-131, 216): 'mse' on the linear task_output
+                const float df = lg - yv;
+                loss = df * df;
+                dl = 2.0f * df / (float)dm.B;
+            } else {
+                const float pr = 1.0f / (1.0f + expf(-lg));
+                loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
+                dl = (pr - yv) / (float)dm.B;
+            }
             if (s == 0) {
                 z_out[m] = zz;
                 logit_out[m] = lg;
@@ -1615,7 +1625,9 @@ static int tower_train_step(
     const DeepFmWs wl = deepfm_ws_layout(dm, Lc);
     const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd, Lc);
     float* ws = reinterpret_cast<float*>(workspace);
-    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc};
+    const int mse = (phases & DT_STEP_LOSS_MSE) ? 1 : 0;
+    phases &= 0xf;
+    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,

@@ -20,6 +20,17 @@ from .utils import consts
 _ACC_NAMES = ['dW1', 'dW2', 'db1', 'db2', 'dw3', 'dwo', 'dbo', 'loss', 'dgamma', 'dbeta', 'dwlin']
 
 
+def _step_loss(dm):
+    """loss flag of the fused steps: 0 = binary task with BinaryCrossentropy, DT_STEP_LOSS_MSE = regression task with
+    'mse' (deepmodel.py:126-141), None = a task / loss the steps do not take"""
+    ln = getattr(dm, 'loss_name', None)
+    if dm.task == consts.TASK_BINARY and ln == 'binary_crossentropy':
+        return 0
+    if dm.task == consts.TASK_REGRESSION and ln in ('mse', 'mean_squared_error'):
+        return _lib.DT_STEP_LOSS_MSE
+    return None
+
+
 def fused_enabled():
     return os.environ.get('DT_AMD_FUSED', '1') != '0'
 
@@ -35,7 +46,7 @@ class FusedDeepFM:
         try:
             if set(c.nets) != cls.NETS or len(c.nets) != 3 or dm.var_len_categorical_columns:
                 return False
-            if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
+            if _step_loss(dm) is None:
                 return False
             if c.stacking_op != consts.STACKING_OP_ADD or c.dense_dropout:
                 return False
@@ -191,7 +202,8 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 1.0 / W, 1, 2, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            None, None, 0, 1.0 / W, 1, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+            stream_ptr()),
             'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
@@ -230,7 +242,7 @@ class FusedDeepFM:
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
             ptr(buf['dedupe']) if (backward and self.dedupe and B <= 8192) else None, buf['dedupe_slots'], 1.0, 0,
-            2 if backward else 1, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
             'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
@@ -263,7 +275,7 @@ class FusedDCN(FusedDeepFM):
         try:
             if list(c.nets) != ['dcn_nets'] or dm.var_len_categorical_columns:
                 return False
-            if dm.task != consts.TASK_BINARY or getattr(dm, 'loss_name', None) != 'binary_crossentropy':
+            if _step_loss(dm) is None:
                 return False
             if c.dense_dropout or not (0 <= float(c.embedding_dropout or 0) < 1):
                 return False
@@ -392,7 +404,7 @@ class FusedDCN(FusedDeepFM):
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
             ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'],
-            2 if backward else 1, self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
+            (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
             'dt_dcn_train_step')
         if backward:
             for p, g in self.grad_views:

@@ -343,7 +343,8 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * (IndexedSlices indices/values); accum: dt_deepfm_accum_floats() floats holding every dense gradient
  * and the mean loss at the offsets reported by dt_deepfm_accum_offsets() in the order
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
- * phases: 1 = forward only (logits + loss), 2 = forward + backward.
+ * phases: 1 = forward only (logits + loss), 2 = forward + backward; OR-ed with DT_STEP_LOSS_MSE the loss is
+ * MeanSquaredError on the linear output (regression task, deepmodel.py:130-131) instead of BinaryCrossentropy.
  * dedupe_ws (may be NULL; B <= 8192): dt_deepfm_dedupe_bytes(B,F) bytes whose first dt_deepfm_dedupe_slots(B,F) 32-bit
  * words are ALL ZERO on entry and left all zero on return; dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given
  * (and phases == 2) the step resolves duplicate lookups itself: each table row appears once in rows_out (other lookups
@@ -351,6 +352,7 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * with fields = -1 (no dedupe pass).
  * grad_rows_field_major != 0 (model-parallel tables, no dedupe_ws): grad_rows is written as [F,B,D] and multiplied
  * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.                              */
+#define DT_STEP_LOSS_MSE 0x10
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);

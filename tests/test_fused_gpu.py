@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(F, Nd, D, vocab, seed=3, use_bias=True, nets=None, **extra):
+def build(F, Nd, D, vocab, seed=3, use_bias=True, nets=None, task='binary', **extra):
     from deeptables_amd import functional
     from deeptables_amd.models import ModelConfig, DeepModel, deepnets
     from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
@@ -17,7 +17,7 @@ def build(F, Nd, D, vocab, seed=3, use_bias=True, nets=None, **extra):
                        embedding_dropout=0, metrics=['AUC'], output_use_bias=use_bias, **extra)
     cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
     conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])] if Nd else []
-    dm = DeepModel('binary', 2, conf, cats, conts)
+    dm = DeepModel(task, 2 if task == 'binary' else 1, conf, cats, conts)
     dm.build()
     g = torch.Generator().manual_seed(9)
     with torch.no_grad():
@@ -146,6 +146,43 @@ def test_fused_dcn_matches_oracle_and_generic_path(dev, B, F, Nd, D, L, idt):
     k0 = cr.kernel_stack.detach().clone()
     dm.train_step(ins, y.to(dev))
     assert (cr.kernel_stack.detach() - k0).abs().max().item() > 0
+
+
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+def test_fused_steps_take_the_regression_task(dev, net):
+    """task 'regression' -> loss 'mse' on the linear task_output (deepmodel.py:126-141, 216): DT_STEP_LOSS_MSE"""
+    from oracle import bridge
+    from deeptables_amd.models import deepnets
+    from deeptables_amd.fused import FusedDCN, FusedDeepFM
+    extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+    dm, cats = build(9, 4, 8, vocab=30, nets=getattr(deepnets, net), task='regression',
+                     dnn_params={'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu'}, **extra)
+    assert dm.loss_name == 'mse'
+    assert isinstance(dm.fused_plan(), FusedDCN if net == 'DCN' else FusedDeepFM)
+    idx, dense, _ = batch(cats, 4, 200)
+    y = torch.randn(200, 1, generator=torch.Generator().manual_seed(3)) * 2
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_out, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    ref_loss = ((ref_out - y.double()) ** 2).mean()
+    ref_loss.backward()
+    dm.model.train()
+    ins = [idx.int().to(dev), dense.to(dev)]
+    loss, out = dm.forward_backward(ins, y.to(dev))
+    torch.cuda.synchronize()
+    assert (out.double().cpu() - ref_out).abs().max().item() < 1e-4 * max(1.0, ref_out.abs().max().item())
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * max(1.0, float(ref_loss))
+    Ly = dm.model.layers_by_name
+    pre = 'dcn' if net == 'DCN' else 'dnn'
+    key = 'dcn_dnn' if net == 'DCN' else 'dnn'
+    assert rel(Ly[f'{pre}_dense_1'].kernel.grad, w[key][0][0].grad) < 2e-4
+    assert rel(Ly['task_output'].kernel.grad, w['task_output'][0].grad) < 2e-4
+    assert rel(Ly['bn_concat_emb_dense'].gamma.grad, w['bn_concat_emb_dense'][0].grad) < 2e-4
+    table = Ly['emb_categorical_vars_all'].tables['d8']
+    assert rel(table.grad, torch.cat([t.grad for t in w['emb_categorical_vars_all']], 0)) < 2e-4
+    # same through the layer-by-layer path
+    dm._fused_plan = None
+    loss2, out2 = dm.forward_backward(ins, y.to(dev))
+    assert abs(float(loss2) - float(loss)) < 1e-5 * max(1.0, float(loss))
 
 
 def test_fused_sparse_gradient_rows(dev):
