@@ -79,6 +79,9 @@ SIGNATURES = {
     'dt_adam_rows_step': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
                                    _c_f32, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32,
                                    _ptr]),
+    'dt_adam_rows_step_seg': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
+                                   _c_f32, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32,
+                                   _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     'dt_bce_logits': (_c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     'dt_sgd_dense_step': (_c_int, [_ptr, _ptr, _c_i64, _c_f32, _ptr]),
     'dt_sgd_rows_step': (_c_int, [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr]),
@@ -108,6 +111,7 @@ SIGNATURES = {
                                            _c_int, _ptr, _ptr, _ptr, _ptr]),
     'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
+    'dt_deepfm_dedupe_segments': (_c_int, [_c_int, _c_int, _ptr]),
     'dt_dcn_supported': (_c_int, [_c_int] * 7),
     'dt_dcn_workspace_bytes': (_c_i64, [_c_int] * 5),
     'dt_dcn_stamps_offset_floats': (_c_i64, [_c_int] * 5),

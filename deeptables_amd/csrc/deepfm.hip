@@ -68,18 +68,22 @@ __host__ __device__ inline DeepFmAccum deepfm_accum_layout(int C, int CP, int F,
     return a;
 }
 
-// Optional row dedupe inside the step (dt_deepfm_train_step, dedupe_ws != NULL): the sparse gradient leaves the step
-// with every table row appearing ONCE, so the row-sparse optimizer needs no dedupe pass of its own.
+// Optional row dedupe inside the step (dt_deepfm_train_step, dedupe_ws != NULL): the sparse gradient leaves the step as
+//   * (rows_out, grad_rows) entries for the rows looked up ONCE in the batch, and
+//   * SEGMENTS for the rows looked up several times: (table row, offset, count) + a list of the lookups (occurrences)
+//     whose gradient rows have to be summed; every member of a segment reports row -1 in rows_out,
+// so the row-sparse optimizer needs no dedupe pass and nothing in the step adds into a shared row: kernel D stores
+// every lookup's gradient row plainly, the optimizer's segment waves sum a row's members (one wave per row, 16 rows
+// per load) and update the row (dt_adam_rows_step_seg).
 //   A: writes the looked-up rows a second time, field-major (rows_fm [F][B]; a block's 16 batch rows fill whole lines).
-//   B (extra blocks of k_prep, one per (field, hash partition)): the partition's lookups are inserted into an LDS hash
-//      ((row+1) << 24 | occurrence, 64-bit LDS CAS).  The winner owns the row; a later lookup of the same row is a
-//      duplicate: mark = -(owner)-2, it sets mark[owner] = 1, zeroes the owner's gradient row and reports row -1.
-//      Unique rows (the normal case) cost NO global write: mark stays 0.
-//   D: owners without duplicates store their gradient row; owners with duplicates and the duplicates themselves
-//      atomicAdd into the owner's row; every non-zero mark is cleared, so the workspace is all-zero again.
-// History (bench numbers in DESIGN.md): a global hash filled with 64-bit CAS inside kernel A cost ~10 us of device-scope
-// round trips in the gather's dependency chain; a direct-mapped election table (one plain store per lookup, cleared by
-// D) cost ~15 us spread over A / D / the optimizer: 2 x 213K partial-line write-backs per step.
+//   B (extra blocks of k_prep, one per (field, hash partition), all partitions of a field on one XCD): an LDS hash of
+//      8192 64-bit slots (row+1) << 24 | count — CAS to claim, atomicAdd to count; B <= 8192 lookups per field always
+//      fit.  Slots with count >= 2 become segments in the block's private region of the segment / list arrays (a block
+//      scan places them), then every member appends itself through the slot's cursor.
+// History (numbers in DESIGN.md): a global hash filled with 64-bit CAS inside kernel A (~10 us of device-scope round
+// trips in the gather's chain); a direct-mapped election table (2 x 213K partial-line write-backs per step, ~15 us);
+// LDS election with the duplicates atomically added into an owner's row by kernel D — fine for uniform ids, but under
+// Zipf ids the hot rows serialised on their owner's 16 addresses (D 20 -> 68 us).
 // embedding_dropout (config.py:84; SpatialDropout1D on every [B,1,D] embedding, layers.py:878-880 = element dropout with
 // 1/(1-p) scaling): keep-mask from a counter hash of (seed, batch row, packed column f*D+d), the same in kernel A
 // (values) and kernel D (gradients).  The seed lives on the device and is advanced by kernel D, so a captured graph of
@@ -104,10 +108,19 @@ __device__ __forceinline__ float4 emb_drop4(float4 v, unsigned seed, unsigned th
 
 constexpr int kElectSlots = 8192;     // LDS hash of one election block (64 KB); also the largest batch the in-step dedupe takes
 struct DedupeWs {
-    int* mark;                   // [B*F], zero outside a step (NULL: no dedupe)
+    int* mark;                   // [B*F] zero (kept for kernel D's atomic path; no kernel writes it any more) (NULL: no dedupe)
     int64_t* rows_fm;            // [F][B] scratch
     int parts_log2;              // hash partitions per field
+    // segments of the rows looked up more than once (see above), one private region per election block e (no global
+    // counter: a device-scope atomicAdd in the middle of the block cost ~2 us): nseg[e] segments at seg_*[e * kSegCap ..],
+    // their lookups at seg_list[e * B ..]
+    int* nseg;                   // [elect blocks]
+    int64_t* seg_row;            // [elect blocks][kSegCap]
+    int* seg_off;                // first entry in seg_list (absolute)
+    int* seg_cnt;
+    int* seg_list;               // [elect blocks][B] lookups (b*F + f)
 };
+constexpr int kSegCap = kElectSlots / 2;     // a block's rows with >= 2 lookups: at most B / 2
 
 // phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
 // read back by tools/phase_times.py; costs one scalar load + store per phase
@@ -277,38 +290,104 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
                                                PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
                                                int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
     if ((int)blockIdx.x >= bn_blocks + layout_blocks) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
-        extern __shared__ unsigned long long eslots[];    // [kElectSlots]
+        extern __shared__ unsigned long long eslots[];    // [kElectSlots] + bitmap of the slots with >= 2 lookups + scan scratch
+        unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
+        int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]
         // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
         // so the field's row list is fetched into ONE L2 instead of eight
         const int e = (int)blockIdx.x - bn_blocks - layout_blocks;
         const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
         const int f = 8 * (j >> dd.parts_log2) + ((int)blockIdx.x & 7);
-        if (f >= dm.F) return;
-        for (int i = threadIdx.x; i < kElectSlots; i += blockDim.x) eslots[i] = 0ULL;
-        __syncthreads();
+        if (f >= dm.F) {
+            if (threadIdx.x == 0) dd.nseg[e] = 0;
+            return;
+        }
+        const int tid = threadIdx.x;
         const int64_t* rf = dd.rows_fm + (int64_t)f * dm.B;
-        for (int b = threadIdx.x; b < dm.B; b += blockDim.x) {
-            const int64_t row = rf[b];
-            if (row < 0) continue;
+        constexpr int kMine = kElectSlots / 1024;             // lookups a thread can meet (B <= kElectSlots, 1024 threads)
+        int myslot[kMine];
+        int64_t rowv[kMine];
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {                     // all of the thread's row loads in flight, the LDS clear below them
+            const int b = tid + 1024 * u;
+            rowv[u] = rf[min(b, dm.B - 1)];
+        }
+        for (int i = tid; i < kElectSlots; i += blockDim.x) eslots[i] = 0ULL;
+        if (tid < kElectSlots / 32) multi[tid] = 0u;
+        __syncthreads();
+        // pass 1: claim (CAS) / count (atomicAdd); the SECOND lookup of a row flags its slot in the bitmap
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {
+            myslot[u] = -1;
+            const int64_t row = rowv[u];
+            if (tid + 1024 * u >= dm.B || row < 0) continue;
             const unsigned h = ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u;
             if ((int)((h >> 13) >> (19 - dd.parts_log2)) != part) continue;          // top bits of h: the partition
-            const int64_t occ = (int64_t)b * dm.F + f;
-            const unsigned long long mine = ((unsigned long long)(row + 1) << 24) | (unsigned long long)occ;
+            const unsigned long long key = (unsigned long long)(row + 1) << 24;
             unsigned slot = h & (kElectSlots - 1);
-            for (int probe = 0; probe < kElectSlots; ++probe) {
-                const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, mine);
-                if (prev == 0ULL) break;                                             // owner (mark stays 0 unless a duplicate turns up)
-                if ((prev >> 24) == (unsigned long long)(row + 1)) {                 // duplicate of an earlier lookup
-                    const int64_t owner = (int64_t)(prev & 0xffffffULL);
-                    dd.mark[occ] = -(int)owner - 2;
-                    dd.mark[owner] = 1;                                              // the owner's row is accumulated atomically:
-                    float4* z = reinterpret_cast<float4*>(grad_rows + owner * dm.D);  // start it from 0
-                    for (int q = 0; q < dm.D / 4; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    rows_out[occ] = -1;                                              // not a separate row of the gradient
+            for (;;) {                                        // at most B <= kElectSlots distinct rows: always terminates
+                const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, key | 1ULL);
+                if (prev == 0ULL) break;
+                if ((prev >> 24) == (unsigned long long)(row + 1)) {
+                    const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
+                    if ((old & 0xffffffULL) == 1ULL) atomicOr(&multi[slot >> 5], 1u << (slot & 31));
                     break;
                 }
                 slot = (slot + 1) & (kElectSlots - 1);
             }
+            myslot[u] = (int)slot;
+        }
+        __syncthreads();
+        // pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one
+        // exclusive scan over those 256 threads of (segments << 16 | list entries): shuffles inside a wave, the wave
+        // totals through LDS.  (Walking all 8192 slots instead cost 2.6 us per block; with uniform ids ~2 are flagged.)
+        const int lane = tid & 63, wv = tid >> 6;
+        unsigned word = tid < kElectSlots / 32 ? multi[tid] : 0u;
+        int mine = 0;
+        for (unsigned w = word; w; w &= w - 1) {
+            const int slot = 32 * tid + (__ffs((int)w) - 1);
+            mine += (1 << 16) + (int)(eslots[slot] & 0xffffffULL);
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63 && wv < 4) scan[wv] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int t = scan[w];
+            if (w < wv) before += t;
+            total += t;
+        }
+        if (tid == 0) dd.nseg[e] = total >> 16;
+        const int base0 = e * kSegCap, base1 = e * dm.B;
+        const int excl = before + incl - mine;
+        int sidx = base0 + (excl >> 16), lrel = excl & 0xffff;
+        for (unsigned w = word; w; w &= w - 1) {
+            const int slot = 32 * tid + (__ffs((int)w) - 1);
+            const unsigned long long v = eslots[slot];
+            const int c = (int)(v & 0xffffffULL);
+            dd.seg_row[sidx] = (int64_t)(v >> 24) - 1;
+            dd.seg_off[sidx] = base1 + lrel;
+            dd.seg_cnt[sidx] = c;
+            eslots[slot] = (v & ~0xffffffULL) | 0x800000ULL | (unsigned long long)lrel;    // flag + cursor
+            ++sidx; lrel += c;
+        }
+        __syncthreads();
+        // pass 3: the members of a segment append themselves and leave rows_out
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {
+            if (myslot[u] < 0) continue;
+            if (!(eslots[myslot[u]] & 0x800000ULL)) continue;
+            const int b = tid + 1024 * u;
+            const int64_t occ = (int64_t)b * dm.F + f;
+            const unsigned long long old = atomicAdd(&eslots[myslot[u]], 1ULL);
+            dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
+            rows_out[occ] = -1;
         }
         return;
     }
@@ -1597,8 +1676,32 @@ extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
     return (int64_t)B * F;          // one mark per lookup
 }
 
-extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) {
-    return (int64_t)B * F * 4 + 8 + (int64_t)B * F * 8;      // mark (zero between steps) | pad | rows_fm (scratch)
+// byte offsets inside dedupe_ws: mark | rows_fm | nseg | seg_row | seg_off | seg_cnt | seg_list | total
+struct DedupeLayout { int64_t mark, rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, total; int eblocks, parts_log2; };
+static DedupeLayout dedupe_layout(int B, int F) {
+    const int64_t n = (int64_t)B * F;
+    DedupeLayout l;
+    l.parts_log2 = 0;
+    while ((1024 << l.parts_log2) < B) ++l.parts_log2;       // ~1024 lookups per election block
+    l.eblocks = (((F + 7) >> 3) << 3) << l.parts_log2;       // fields padded to 8 (XCD-aware ids)
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 15) & ~(int64_t)15; return r; };
+    l.mark = take(n * 4); l.rows_fm = take(n * 8); l.nseg = take((int64_t)l.eblocks * 4);
+    l.seg_row = take((int64_t)l.eblocks * kSegCap * 8); l.seg_off = take((int64_t)l.eblocks * kSegCap * 4);
+    l.seg_cnt = take((int64_t)l.eblocks * kSegCap * 4); l.seg_list = take((int64_t)l.eblocks * B * 4);
+    l.total = o;
+    return l;
+}
+
+extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) { return dedupe_layout(B, F).total; }
+
+// what the optimizer consumes (dt_adam_rows_step_seg): byte offsets of nseg (int32 [regions]), seg_row (int64
+// [regions][cap]), seg_off, seg_cnt (int32 [regions][cap]), seg_list (int32), then regions and cap
+extern "C" int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7) {
+    const DedupeLayout l = dedupe_layout(B, F);
+    out7[0] = l.nseg; out7[1] = l.seg_row; out7[2] = l.seg_off; out7[3] = l.seg_cnt; out7[4] = l.seg_list;
+    out7[5] = l.eblocks; out7[6] = kSegCap;
+    return DT_OK;
 }
 
 // the step both entry points run: DeepFM (cross == NULL) or DCN (cross kernels / biases [Lc][C]; w3 = the [C + 64] kernel
@@ -1635,7 +1738,7 @@ static int tower_train_step(
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)(dcn ? W2 : w3) | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int tiles = ceil_div(B, kTM);
-    DedupeWs dd{nullptr, nullptr, 0};
+    DedupeWs dd{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     DT_REQUIRE(!(dedupe_ws && grad_rows_field_major), "dt_deepfm_train_step: dedupe and field-major row gradients "
                                                       "are mutually exclusive");
     if (dedupe_ws && phases >= 2) {          // forward-only calls never reach D, which zeroes the marks again
@@ -1643,9 +1746,17 @@ static int tower_train_step(
                    "dt_deepfm_dedupe_slots(B, F)", (long long)dedupe_slots);
         DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
                        "dt_deepfm_train_step: the in-step dedupe takes batches up to %d rows (B=%d)", kElectSlots, B);
-        dd.mark = reinterpret_cast<int*>(dedupe_ws);
-        dd.rows_fm = reinterpret_cast<int64_t*>(((uintptr_t)(dd.mark + (int64_t)B * F) + 7) & ~(uintptr_t)7);
-        while ((1024 << dd.parts_log2) < B) ++dd.parts_log2;       // ~1024 lookups per election block
+        DT_REQUIRE((uintptr_t)dedupe_ws % 16 == 0, "dt_deepfm_train_step: dedupe_ws must be 16-byte aligned");
+        const DedupeLayout dl = dedupe_layout(B, F);
+        char* base = reinterpret_cast<char*>(dedupe_ws);
+        dd.mark = reinterpret_cast<int*>(base + dl.mark);
+        dd.rows_fm = reinterpret_cast<int64_t*>(base + dl.rows_fm);
+        dd.nseg = reinterpret_cast<int*>(base + dl.nseg);
+        dd.seg_row = reinterpret_cast<int64_t*>(base + dl.seg_row);
+        dd.seg_off = reinterpret_cast<int*>(base + dl.seg_off);
+        dd.seg_cnt = reinterpret_cast<int*>(base + dl.seg_cnt);
+        dd.seg_list = reinterpret_cast<int*>(base + dl.seg_list);
+        dd.parts_log2 = dl.parts_log2;
     }
     if (B % kTM) {       // ragged last tile: its workspace rows beyond B are read (unmasked) by the tile kernels -> keep them zero
         const int64_t pad = (int64_t)tiles * kTM - B;
@@ -1685,7 +1796,7 @@ static int tower_train_step(
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2};
     const int elect_blocks = dd.mark ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
-    const size_t ldsB = dd.mark ? (size_t)kElectSlots * 8 : 0;
+    const size_t ldsB = dd.mark ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,
                        bn_momentum, bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, 56, dd, rows_out,

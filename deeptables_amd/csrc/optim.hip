@@ -323,6 +323,77 @@ __device__ __forceinline__ void adam_rows_owner_body(float* __restrict__ table, 
                                                      const int* __restrict__ mark, float lr_t, float b1, float b2,
                                                      float eps, int sstride);
 
+// Segments (rows looked up several times in the step; built by the fused steps' election, csrc/deepfm.hip DedupeWs):
+// the waves of the launch's row blocks walk them after their own rows — a wave's lanes form 64 / (D/4) row groups, every group
+// sums every (64 / (D/4))-th member's gradient row (16-byte lanes), the groups meet by lane shuffles, and group 0 applies
+// the Adam update to the table row.  No lookup ever adds into a shared row: hot rows (Zipf ids, low-cardinality columns)
+// cost one wave a few loads instead of hundreds of same-address atomics.
+struct SegTail {
+    const int* nseg;             // [regions] segments per region (read on the device); NULL: no segments
+    const int64_t* row;          // [regions][cap]
+    const int *off, *cnt, *list;
+    int regions, cap;
+};
+__device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks, int nseg0, float* __restrict__ table,
+                                              float* __restrict__ m, float* __restrict__ v,
+                                              const float* __restrict__ values, int D, float lr_t, float b1, float b2,
+                                              float eps, int sstride) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = D >> 2;                               // lanes per row (a power of two <= 64: checked by the host)
+    const int groups = 64 / lpr, grp = lane / lpr, part = lane - grp * lpr;
+    const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int nw = row_blocks * (int)(blockDim.x >> 6);
+    // region e = gw % regions is shared by wpr waves (local index lw); fewer waves than regions: a wave walks several
+    const int wpr = nw >= sg.regions ? nw / sg.regions : 1, lw = nw >= sg.regions ? gw / sg.regions : 0;
+    if (lw >= wpr) return;
+    const int e0 = gw % sg.regions;
+    for (int e = e0; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw))
+    for (int sl = lw, nseg = (e == e0 ? nseg0 : sg.nseg[e]); sl < nseg; sl += wpr) {
+        const int s = e * sg.cap + sl;
+        const int64_t row = sg.row[s];
+        const int off = sg.off[s], cnt = sg.cnt[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int i = grp;
+        for (; i + 3 * groups < cnt; i += 4 * groups) {      // four members per group in flight
+            const int o0 = sg.list[off + i], o1 = sg.list[off + i + groups], o2 = sg.list[off + i + 2 * groups],
+                      o3 = sg.list[off + i + 3 * groups];
+            const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+            const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
+            const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
+            const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
+            acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
+            acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
+        }
+        for (; i < cnt; i += groups) {
+            const int o0 = sg.list[off + i];
+            const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+            acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
+        }
+        for (int o = lpr; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (grp == 0) {
+            const int64_t i0 = row * D + 4 * part, s0 = row * sstride + 4 * part;
+            float4 p = *reinterpret_cast<const float4*>(table + i0);
+            float4 mi = *reinterpret_cast<const float4*>(m + s0), vi = *reinterpret_cast<const float4*>(v + s0);
+            const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+            float* pp = reinterpret_cast<float*>(&p);
+            float* pm = reinterpret_cast<float*>(&mi);
+            float* pv = reinterpret_cast<float*>(&vi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pm[k] = b1 * pm[k] + (1.f - b1) * g[k];
+                pv[k] = b2 * pv[k] + (1.f - b2) * g[k] * g[k];
+                pp[k] -= lr_t * pm[k] / (sqrtf(pv[k]) + eps);
+            }
+            *reinterpret_cast<float4*>(m + s0) = mi;
+            *reinterpret_cast<float4*>(v + s0) = vi;
+            *reinterpret_cast<float4*>(table + i0) = p;
+        }
+    }
+}
+
 template <int VW>
 __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ table, float* __restrict__ m,
                                                          float* __restrict__ v, const int64_t* __restrict__ rows,
@@ -331,14 +402,19 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
                                                          const int* __restrict__ mark, float lr_host,
                                                          AdamState* __restrict__ st, float b1, float b2, float eps,
                                                          int row_blocks, DenseTail tail, int advance, float lr,
-                                                         int sstride) {
+                                                         int sstride, SegTail seg) {
     unsigned ticket;
     const float lr_t = adam_read_lr(st, lr_host, advance, ticket);
     if ((int)blockIdx.x >= row_blocks) {      // trailing blocks: the model's dense parameters (one flat buffer)
         adam_dense_range(tail, (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x,
                          (int64_t)(gridDim.x - row_blocks) * blockDim.x, lr_t, b1, b2, eps);
     } else {
+        // the segments of rows looked up several times ride on the row blocks' waves (extra blocks would each take the
+        // state's arrival ticket: +6 us for 1024 of them); a wave's region count is loaded before its own rows
+        int nseg0 = 0;
+        if (VW == 4 && seg.nseg) nseg0 = seg.nseg[((int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % seg.regions];
         adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
+        if (VW == 4 && seg.nseg) adam_segments(seg, row_blocks, nseg0, table, m, v, values, D, lr_t, b1, b2, eps, sstride);
     }
     adam_finish(st, ticket, lr, b1, b2);
 }
@@ -548,11 +624,13 @@ extern "C" int64_t dt_adam_rows_slots(int64_t n_rows) {
     return s;
 }
 
-extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
-                                 int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t,
-                                 float beta1, float beta2, float eps, void* state, float* dense_p,
-                                 const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int advance,
-                                 float lr, void* stream) {
+extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int64_t* rows, float* values,
+                                     int64_t n_rows, int D, int fields, void* slots, int64_t n_slots, int* mark,
+                                     float lr_t, float beta1, float beta2, float eps, void* state, float* dense_p,
+                                     const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int advance,
+                                     float lr, const int* seg_nseg, const int64_t* seg_row, const int* seg_off,
+                                     const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
+                                     void* stream) {
     DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -1 && dense_n >= 0, "dt_adam_rows_step: bad sizes");
     DT_REQUIRE(!advance || state, "dt_adam_rows_step: advance needs the device state");
     DT_REQUIRE(dense_n == 0 || (dense_p && dense_g && dense_m && dense_v), "dt_adam_rows_step: null dense tail");
@@ -569,6 +647,13 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
     DT_REQUIRE(table && m && v && rows && values, "dt_adam_rows_step: null pointer");
     DT_REQUIRE(n_rows < (1LL << 31), "dt_adam_rows_step: %lld occurrences do not fit the 32-bit slot field",
                (long long)n_rows);
+    SegTail seg{seg_nseg, seg_row, seg_off, seg_cnt, seg_list, seg_regions, seg_cap};
+    if (seg_nseg) {
+        DT_REQUIRE(seg_row && seg_off && seg_cnt && seg_list && seg_regions > 0 && seg_cap > 0,
+                   "dt_adam_rows_step_seg: bad segment arrays");
+        const int lpr = D / 4;
+        DT_UNSUPPORTED(D % 4 || lpr > 64 || (lpr & (lpr - 1)), "dt_adam_rows_step_seg: segments need D = 4 * 2^k <= 256 (D=%d)", D);
+    }
     // slot layout: two separate [V, D] arrays, or ONE [V, 2, D] array with m and v of a row side by side (v == m + D):
     // a row's m and v then share a 128-byte line and the update touches two random locations per row instead of three
     const int sstride = (v == m + D) ? 2 * D : D;
@@ -602,14 +687,24 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
     }
     if (D % 4 == 0) {
         const int row_blocks = (int)((n_rows * (D / 4) + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
-        hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
-                           v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
-                           lr, sstride);
+        hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st,
+                           table, m, v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail,
+                           advance, lr, sstride, seg);
     } else {
         const int row_blocks = (int)((n_rows * D + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
         hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
-                           lr, sstride);
+                           lr, sstride, seg);
     }
     return launch_status("dt_adam_rows_step");
+}
+
+extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows,
+                                 int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t,
+                                 float beta1, float beta2, float eps, void* state, float* dense_p,
+                                 const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int advance,
+                                 float lr, void* stream) {
+    return dt_adam_rows_step_seg(table, m, v, rows, values, n_rows, D, fields, slots, n_slots, mark, lr_t, beta1, beta2,
+                                 eps, state, dense_p, dense_g, dense_m, dense_v, dense_n, advance, lr, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, 0, 0, stream);
 }

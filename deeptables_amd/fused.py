@@ -31,6 +31,34 @@ def _step_loss(dm):
     return None
 
 
+def _dedupe_in_step(plan, B, backward):
+    """The in-step dedupe hands the rows looked up several times to the optimizer as SEGMENTS: only for an optimizer that
+    takes them, a single process (the data-parallel exchange gathers plain (rows, values)), and row-sparse tables."""
+    if not (backward and plan.dedupe and B <= 8192):
+        return False
+    opt = getattr(plan.dm, 'optimizer', None)
+    if not getattr(opt, 'supports_row_segments', False):
+        return False
+    st = plan.dm.config.distribute_strategy
+    if st is not None and int(getattr(st, 'world_size', 1)) > 1:
+        return False
+    return not plan.emb.uses_dense_grad(plan.D)
+
+
+def _segments(buf, B, F):
+    seg = buf.get('segments')
+    if seg is None:
+        offs = (ctypes.c_int64 * 7)()
+        check(lib().dt_deepfm_dedupe_segments(B, F, ctypes.cast(offs, ctypes.c_void_p)), 'dt_deepfm_dedupe_segments')
+        raw = buf['dedupe'].view(torch.uint8)
+        E, cap = int(offs[5]), int(offs[6])
+        seg = (raw[offs[0]:offs[0] + 4 * E].view(torch.int32), raw[offs[1]:offs[1] + 8 * E * cap].view(torch.int64),
+               raw[offs[2]:offs[2] + 4 * E * cap].view(torch.int32), raw[offs[3]:offs[3] + 4 * E * cap].view(torch.int32),
+               raw[offs[4]:offs[4] + 4 * E * B].view(torch.int32), E, cap)
+        buf['segments'] = seg
+    return seg
+
+
 def fused_enabled():
     return os.environ.get('DT_AMD_FUSED', '1') != '0'
 
@@ -232,6 +260,7 @@ class FusedDeepFM:
         y = y.reshape(-1).contiguous()
         table = self.emb.tables[self.key]
         training = self.dm.model.training
+        dedupe = _dedupe_in_step(self, B, backward)
         check(lib().dt_deepfm_train_step(
             ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
             ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
@@ -241,15 +270,16 @@ class FusedDeepFM:
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             ptr(self.emb.oob_count) if self.emb.check_oob else None,
-            ptr(buf['dedupe']) if (backward and self.dedupe and B <= 8192) else None, buf['dedupe_slots'], 1.0, 0,
+            ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'], 1.0, 0,
             (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
             'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
-            # with the in-step dedupe every table row appears once (duplicates report row -1, the owner holds the sum)
+            # with the in-step dedupe: rows looked up once keep their entry, the others travel as segments
             self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
-                                                             fields=-1 if (self.dedupe and B <= 8192) else None)]
+                                                             fields=-1 if dedupe else None,
+                                                             segments=_segments(buf, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)
@@ -393,7 +423,7 @@ class FusedDCN(FusedDeepFM):
         y = y.reshape(-1).contiguous()
         table = self.emb.tables[self.key]
         training = self.dm.model.training
-        dedupe = backward and self.dedupe and B <= 8192
+        dedupe = _dedupe_in_step(self, B, backward)
         check(lib().dt_dcn_train_step(
             ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
             ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
@@ -410,7 +440,8 @@ class FusedDCN(FusedDeepFM):
             for p, g in self.grad_views:
                 p.grad = g
             self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
-                                                             fields=-1 if dedupe else None)]
+                                                             fields=-1 if dedupe else None,
+                                                             segments=_segments(buf, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)

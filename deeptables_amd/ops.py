@@ -45,14 +45,35 @@ def _grad_target(p):
 class SparseRowGrad:
     """The (indices, values) pair TF calls IndexedSlices: gradient of a packed embedding table."""
 
-    __slots__ = ('rows', 'values', 'fields')
+    __slots__ = ('rows', 'values', 'fields', 'segments')
 
-    def __init__(self, rows, values, fields=None):
-        self.rows = rows        # int64 [n]   packed row ids, -1 = out-of-range lookup
+    def __init__(self, rows, values, fields=None, segments=None):
+        self.rows = rows        # int64 [n]   packed row ids, -1 = out-of-range lookup (or a member of a segment)
         self.values = values    # float32 [n, D]
         # layout promise for the optimizer's per-field dedupe: None = the owning layer's default ([.., F] lookups of
-        # a packed table), 0 = no field structure (use the global hash)
+        # a packed table), 0 = no field structure (use the global hash), -1 = every row >= 0 appears once
         self.fields = fields
+        # rows looked up several times, as the fused steps hand them over (csrc/deepfm.hip DedupeWs): device tensors
+        # (nseg int32 [regions], seg_row int64, seg_off, seg_cnt, seg_list int32, regions, cap); the members' entries of
+        # `rows` are -1 and the
+        # optimizer's segment waves sum their `values` rows (dt_adam_rows_step_seg)
+        self.segments = segments
+
+    def expanded(self):
+        """(rows, values) with the segment members' row ids restored — one entry per lookup again (host sync; for
+        consumers that do not take segments, and for tests)."""
+        if self.segments is None:
+            return self.rows, self.values
+        nseg, srow, soff, scnt, slist, regions, cap = self.segments
+        rows = self.rows.reshape(-1).clone()
+        valid = (torch.arange(cap, device=rows.device)[None, :] < nseg.long()[:, None]).reshape(-1)
+        if bool(valid.any()):
+            cnt, off, srow_v = scnt[:regions * cap][valid].long(), soff[:regions * cap][valid].long(), srow[:regions * cap][valid]
+            start = torch.cumsum(cnt, 0) - cnt
+            pos = torch.arange(int(cnt.sum().item()), device=rows.device) - torch.repeat_interleave(start, cnt)
+            occ = slist[(torch.repeat_interleave(off, cnt) + pos)].long()
+            rows[occ] = torch.repeat_interleave(srow_v, cnt)
+        return rows, self.values
 
 
 class _EmbeddingLookup(torch.autograd.Function):

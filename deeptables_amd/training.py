@@ -72,6 +72,8 @@ def mse(pred, y):
 # Keras Adam
 # ---------------------------------------------------------------------------------------------
 class KerasAdam:
+    supports_row_segments = True      # takes SparseRowGrad.segments (dt_adam_rows_step_seg)
+
     """keras.optimizers.Adam(learning_rate=1e-3, beta_1=.9, beta_2=.999, epsilon=1e-7):
         lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
     Dense parameters: one fused HIP launch each — or ONE launch for a whole registered flat group (the fused
@@ -255,10 +257,15 @@ class KerasAdam:
                 slots, mark, n_slots = s['slots'], s['mark'], s['n_slots']
             is_last = i == len(sparse) - 1 and not (dense_after and dense)
             tl = tail if (is_last and tail is not None) else (None, None, None, None, 0)
-            check(lib().dt_adam_rows_step(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
-                                          D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
-                                          self.b1, self.b2, self.eps, sp, ptr(tl[0]), ptr(tl[1]), ptr(tl[2]),
-                                          ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, st), 'dt_adam_rows_step')
+            seg = grads[0].segments if (len(grads) == 1 and getattr(grads[0], 'segments', None) is not None) else None
+            if seg is None and any(getattr(g, 'segments', None) is not None for g in grads):
+                raise ValueError('a segmented sparse gradient cannot be concatenated with other pieces')
+            sg = [ptr(t) for t in seg[:5]] + [int(seg[5]), int(seg[6])] if seg is not None else [None] * 5 + [0, 0]
+            check(lib().dt_adam_rows_step_seg(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
+                                              D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
+                                              self.b1, self.b2, self.eps, sp, ptr(tl[0]), ptr(tl[1]), ptr(tl[2]),
+                                              ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, *sg, st),
+                  'dt_adam_rows_step_seg')
         if dense_after:
             hook()
             self._dense_launch(dense, sp, st, advance=True)

@@ -232,6 +232,17 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
                       int D, int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1,
                       float beta2, float eps, void* state, float* dense_p, const float* dense_g, float* dense_m,
                       float* dense_v, int64_t dense_n, int advance, float lr, void* stream);
+/* dt_adam_rows_step + SEGMENTS (seg_nseg != NULL; D = 4 * 2^k): rows looked up several times arrive in seg_regions
+ * regions of seg_cap slots: region e holds seg_nseg[e] segments (read on the device) at index s = e * seg_cap + i:
+ * (seg_row[s], seg_off[s], seg_cnt[s]) with seg_list[seg_off .. +seg_cnt) naming the `values` rows to sum.  Their
+ * entries of `rows` must be -1.  The waves of the same launch sum a segment's members and apply the update to its table
+ * row: no lookup adds into a shared gradient row.                                                                   */
+int dt_adam_rows_step_seg(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows, int D,
+                          int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1, float beta2,
+                          float eps, void* state, float* dense_p, const float* dense_g, float* dense_m, float* dense_v,
+                          int64_t dense_n, int advance, float lr, const int* seg_nseg, const int64_t* seg_row,
+                          const int* seg_off, const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
+                          void* stream);
 
 /* BinaryCrossentropy on a sigmoid output, evaluated from the logits as Keras does in graph mode (deepmodel.py:326-328;
  * the `task_output` activation, deepmodel.py:436-457): loss [1] = mean(max(z,0) - z*y + log1p(exp(-|z|))) and
@@ -345,16 +356,20 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
  * phases: 1 = forward only (logits + loss), 2 = forward + backward; OR-ed with DT_STEP_LOSS_MSE the loss is
  * MeanSquaredError on the linear output (regression task, deepmodel.py:130-131) instead of BinaryCrossentropy.
- * dedupe_ws (may be NULL; B <= 8192): dt_deepfm_dedupe_bytes(B,F) bytes whose first dt_deepfm_dedupe_slots(B,F) 32-bit
- * words are ALL ZERO on entry and left all zero on return; dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given
- * (and phases == 2) the step resolves duplicate lookups itself: each table row appears once in rows_out (other lookups
- * of it report -1) and its grad_rows entry holds the SUM over all its lookups — dt_adam_rows_step can then be called
- * with fields = -1 (no dedupe pass).
+ * dedupe_ws (may be NULL; B <= 8192; 16-byte aligned): dt_deepfm_dedupe_bytes(B,F) bytes whose first
+ * dt_deepfm_dedupe_slots(B,F) 32-bit words are ALL ZERO on entry and stay zero; dedupe_slots =
+ * dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step resolves duplicate lookups itself: a table row
+ * looked up ONCE keeps its (rows_out, grad_rows) entry; a row looked up several times becomes a SEGMENT — every one of
+ * its lookups reports -1 in rows_out (their grad_rows entries still hold the per-lookup gradients) and the segment
+ * arrays inside dedupe_ws (dt_deepfm_dedupe_segments -> byte offsets of nseg, seg_row, seg_off, seg_cnt, seg_list,
+ * then the number of regions and their capacity) say which grad_rows entries to sum for which row.
+ * dt_adam_rows_step_seg consumes exactly that (fields = -1: no dedupe pass).
  * grad_rows_field_major != 0 (model-parallel tables, no dedupe_ws): grad_rows is written as [F,B,D] and multiplied
  * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.                              */
 #define DT_STEP_LOSS_MSE 0x10
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
+int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7_host);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
 
 /* ---- fused DCN train step (nets ['dcn_nets']: Cross || DNN on BN(concat(embeddings, dense)), deepnets.py:194-207;

@@ -201,8 +201,11 @@ def _check_once(dm, batch, adam, lr, accept):
     res['dense_grads_checked'] = len(pairs)
     # (3) the sparse gradient, merged per table row on both sides
     sg = emb.sparse_grads[key]
-    g_rows = torch.cat([s.rows.reshape(-1) for s in sg]).cpu()
-    g_vals = torch.cat([s.values.reshape(-1, D) for s in sg]).double().cpu()
+    # rows looked up several times travel as segments (ops.SparseRowGrad.segments): one entry per lookup again
+    exp = [s.expanded() if hasattr(s, 'expanded') else (s.rows, s.values) for s in sg]
+    res['segments'] = int(sum(int(s.segments[0].sum().item()) for s in sg if getattr(s, 'segments', None) is not None))
+    g_rows = torch.cat([r.reshape(-1) for r, _ in exp]).cpu()
+    g_vals = torch.cat([v.reshape(-1, D) for _, v in exp]).double().cpu()
     u_got, v_got = merge_rows(g_rows, g_vals)
     u_ref, v_ref = merge_rows(ref['rows'], ref['row_grads'].double())
     res['rows_identical'] = bool(torch.equal(u_got, u_ref))

@@ -201,16 +201,30 @@ def test_fused_sparse_gradient_rows(dev):
         offs = np.concatenate([[0], np.cumsum([c.vocabulary_size for c in cats])[:-1]])
         want_rows = idx.numpy() + offs[None, :]
         got_rows = sg.rows.cpu().numpy().reshape(128, 26)
-        # the fused step dedupes: each looked-up row appears exactly once, later lookups of it report -1
+        # the fused step dedupes: a row looked up once keeps its entry, rows looked up several times become segments
+        # (all their lookups report -1)
         kept = got_rows >= 0
         assert np.array_equal(got_rows[kept], want_rows[kept]) and sg.fields == -1
-        assert sorted(got_rows[kept].tolist()) == sorted(set(want_rows.reshape(-1).tolist()))
+        flat = want_rows.reshape(-1)
+        uniq, counts = np.unique(flat, return_counts=True)
+        assert sorted(got_rows[kept].tolist()) == sorted(uniq[counts == 1].tolist())
+        nseg_r, srow, soff, scnt, slist, regions, cap = sg.segments
+        valid = (torch.arange(cap, device=srow.device)[None, :] < nseg_r.long()[:, None]).reshape(-1)
+        srow_v, soff_v, scnt_v = srow[valid].cpu(), soff[valid].cpu(), scnt[valid].cpu()
+        assert len(srow_v) == int((counts > 1).sum()) and int(scnt_v.sum()) == int(counts[counts > 1].sum())
+        assert sorted(srow_v.tolist()) == sorted(uniq[counts > 1].tolist())
+        slist_c = slist.cpu().numpy()
+        for s_ in range(len(srow_v)):        # every segment lists exactly the lookups of its row
+            members = slist_c[int(soff_v[s_]):int(soff_v[s_]) + int(scnt_v[s_])]
+            assert np.all(flat[members] == int(srow_v[s_])) and len(set(members.tolist())) == int(scnt_v[s_])
+        assert np.array_equal(sg.expanded()[0].cpu().numpy().reshape(128, 26), want_rows)
         V = emb.tables['d16'].shape[0]
 
         def densify(g):
             d = torch.zeros(V, 16, device=dev)
-            ok = g.rows.reshape(-1) >= 0
-            d.index_add_(0, g.rows.reshape(-1)[ok], g.values.reshape(-1, 16)[ok])
+            rows, values = g.expanded()
+            ok = rows.reshape(-1) >= 0
+            d.index_add_(0, rows.reshape(-1)[ok], values.reshape(-1, 16)[ok])
             return d
         dense_fused = densify(sg)
         # same per-row sums from the generic path (which keeps one entry per lookup)

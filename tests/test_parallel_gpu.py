@@ -105,8 +105,9 @@ def _emulate():
             for a, p in zip(gsum, dense_params):
                 a += p.grad
             for sg in emb.sparse_grads['d16']:
-                rows.append(sg.rows.reshape(-1).clone())
-                vals.append(sg.values.reshape(-1, D).clone() / W)
+                r_, v_ = sg.expanded()            # rows looked up several times travel as segments in one process
+                rows.append(r_.reshape(-1).clone())
+                vals.append(v_.reshape(-1, D).clone() / W)
             if r == 0:
                 mm_keep, mv_keep = bn.moving_mean.clone(), bn.moving_variance.clone()
         bn.moving_mean.copy_(mm_keep); bn.moving_variance.copy_(mv_keep)
