@@ -108,8 +108,7 @@ __device__ __forceinline__ float4 emb_drop4(float4 v, unsigned seed, unsigned th
 
 constexpr int kElectSlots = 8192;     // LDS hash of one election block (64 KB); also the largest batch the in-step dedupe takes
 struct DedupeWs {
-    int* mark;                   // [B*F] zero (kept for kernel D's atomic path; no kernel writes it any more) (NULL: no dedupe)
-    int64_t* rows_fm;            // [F][B] scratch
+    int64_t* rows_fm;            // [F][B] scratch (NULL: no dedupe)
     int parts_log2;              // hash partitions per field
     // segments of the rows looked up more than once (see above), one private region per election block e (no global
     // counter: a device-scope atomicAdd in the middle of the block cost ~2 us): nseg[e] segments at seg_*[e * kSegCap ..],
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
                 if (ok) v[t] = table[row * LPR + c];
                 if (c == 0) {
                     const int64_t occ = (int64_t)b * dm.F + f;
-                    if (dd.mark) dd.rows_fm[(int64_t)f * dm.B + b] = row;     // for the election blocks of k_prep (see DedupeWs)
+                    if (dd.rows_fm) dd.rows_fm[(int64_t)f * dm.B + b] = row;     // for the election blocks of k_prep (see DedupeWs)
                     rows_out[occ] = row;
                     if (!ok && oob) atomicAdd(oob, 1);
                 }
@@ -1370,8 +1369,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     float* cv = Ss + kTM * dm.D;          // [4][FD16]: gamma*rstd | mean | mean_b(dXn) | rstd mean_b(dXn xhat)
     float* dzs = cv + 4 * FD16;
     float* wls = dzs + kTM;                              // [F] linear_logit kernel rows of the fields
-    int* marks = reinterpret_cast<int*>(wls + ((dm.F + 3) & ~3));   // [32][F] (dedupe only)
-    float* xcs = reinterpret_cast<float*>(marks + 2 * kTM * dm.F);  // DCN: [32][XS] dXn through the cross network
+    float* xcs = wls + ((dm.F + 3) & ~3);                           // DCN: [32][XS] dXn through the cross network
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves: two per SIMD
     const int n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
@@ -1432,14 +1430,6 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         if (tid >= 64 && tid < 64 + dm.F) wlv = wlin[tid - 64];
         if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
     }
-    int mkv[2];
-    if (dd.mark) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t occ = min((int64_t)m0 * dm.F + tid + NT * u, (int64_t)dm.B * dm.F - 1);
-            mkv[u] = dd.mark[occ];
-        }
-    }
     DT_STAMP(stamps, 6);
     // dH1 (the A operand) first: the MFMAs of every wave's first block start as soon as it is in LDS; X and the
     // per-column / per-row constants (needed by the epilogues only) land behind those MFMAs
@@ -1479,13 +1469,6 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
         if (tid < kTM) dzs[tid] = m0 + tid < dm.B ? dzv : 0.f;
         if (tid >= 64 && tid < 64 + dm.F) wls[tid - 64] = wlv;
         if (tid < s4n) st4(Ss + 4 * tid, sv);
-        if (dd.mark) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = tid + NT * u;
-                if (e < kTM * dm.F) marks[e] = mkv[u];
-            }
-        }
     };
 
     auto mm = [&](int buf, int blk, bool more, floatx4& c0, floatx4& c1) {
@@ -1546,8 +1529,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
     __syncthreads();
     DT_STAMP(stamps, 8);
 
-    // ---- the tile's row gradients leave as whole rows (16-byte lanes); duplicates of the step's row dedupe add
-    //      into their owner's row; non-zero marks are cleared ----
+    // ---- the tile's row gradients leave as whole rows (16-byte lanes) ----
     const unsigned dseed = drop.thr ? *drop.seed : 0u;
     const int fq = FD >> 2;                                       // float4 per row
     float* tile_rows = grad_rows + (int64_t)m0 * FD;
@@ -1566,23 +1548,7 @@ __global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__
             st4(grad_rows + (((int64_t)f * dm.B + b) << dshift) + d, o * grad_scale);
             continue;
         }
-        float* dst = tile_rows + row * FD + col;
-        bool atomic = false;
-        if (dd.mark) {
-            const int mk = marks[row * dm.F + f];
-            if (mk == 1) {                       // owner of a row that has duplicates
-                atomic = true;
-            } else if (mk <= -2) {               // duplicate: into the owner's (zero-started) row
-                dst = grad_rows + (((int64_t)(-mk - 2)) << dshift) + d;
-                atomic = true;
-            }
-            if (mk != 0 && d == 0) dd.mark[(int64_t)b * dm.F + f] = 0;
-        }
-        if (atomic) {
-            atomicAdd(dst, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
-        } else {
-            st4(dst, o);
-        }
+        st4(tile_rows + row * FD + col, o);      // every lookup's own row: duplicates are summed by the optimizer (segments)
     }
     DT_STAMP(stamps, 3);
 }
@@ -1673,11 +1639,11 @@ extern "C" int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11) {
 extern "C" unsigned dt_deepfm_dropout_hash(unsigned seed, unsigned b, unsigned col) { return emb_drop_hash(seed, b, col); }
 
 extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
-    return (int64_t)B * F;          // one mark per lookup
+    return (int64_t)B * F;          // lookups per step (the value dt_*_train_step expects as dedupe_slots)
 }
 
-// byte offsets inside dedupe_ws: mark | rows_fm | nseg | seg_row | seg_off | seg_cnt | seg_list | total
-struct DedupeLayout { int64_t mark, rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, total; int eblocks, parts_log2; };
+// byte offsets inside dedupe_ws: rows_fm | nseg | seg_row | seg_off | seg_cnt | seg_list | total
+struct DedupeLayout { int64_t rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, total; int eblocks, parts_log2; };
 static DedupeLayout dedupe_layout(int B, int F) {
     const int64_t n = (int64_t)B * F;
     DedupeLayout l;
@@ -1686,7 +1652,7 @@ static DedupeLayout dedupe_layout(int B, int F) {
     l.eblocks = (((F + 7) >> 3) << 3) << l.parts_log2;       // fields padded to 8 (XCD-aware ids)
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 15) & ~(int64_t)15; return r; };
-    l.mark = take(n * 4); l.rows_fm = take(n * 8); l.nseg = take((int64_t)l.eblocks * 4);
+    l.rows_fm = take(n * 8); l.nseg = take((int64_t)l.eblocks * 4);
     l.seg_row = take((int64_t)l.eblocks * kSegCap * 8); l.seg_off = take((int64_t)l.eblocks * kSegCap * 4);
     l.seg_cnt = take((int64_t)l.eblocks * kSegCap * 4); l.seg_list = take((int64_t)l.eblocks * B * 4);
     l.total = o;
@@ -1738,10 +1704,10 @@ static int tower_train_step(
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)(dcn ? W2 : w3) | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int tiles = ceil_div(B, kTM);
-    DedupeWs dd{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DedupeWs dd{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     DT_REQUIRE(!(dedupe_ws && grad_rows_field_major), "dt_deepfm_train_step: dedupe and field-major row gradients "
                                                       "are mutually exclusive");
-    if (dedupe_ws && phases >= 2) {          // forward-only calls never reach D, which zeroes the marks again
+    if (dedupe_ws && phases >= 2) {          // forward-only calls have no sparse gradient to dedupe
         DT_REQUIRE(dedupe_slots == (int64_t)B * F, "dt_deepfm_train_step: dedupe_slots=%lld must be "
                    "dt_deepfm_dedupe_slots(B, F)", (long long)dedupe_slots);
         DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
@@ -1749,7 +1715,6 @@ static int tower_train_step(
         DT_REQUIRE((uintptr_t)dedupe_ws % 16 == 0, "dt_deepfm_train_step: dedupe_ws must be 16-byte aligned");
         const DedupeLayout dl = dedupe_layout(B, F);
         char* base = reinterpret_cast<char*>(dedupe_ws);
-        dd.mark = reinterpret_cast<int*>(base + dl.mark);
         dd.rows_fm = reinterpret_cast<int64_t*>(base + dl.rows_fm);
         dd.nseg = reinterpret_cast<int*>(base + dl.nseg);
         dd.seg_row = reinterpret_cast<int64_t*>(base + dl.seg_row);
@@ -1795,8 +1760,8 @@ static int tower_train_step(
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2};
-    const int elect_blocks = dd.mark ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
-    const size_t ldsB = dd.mark ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
+    const int elect_blocks = dd.rows_fm ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
+    const size_t ldsB = dd.rows_fm ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,
                        bn_momentum, bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, 56, dd, rows_out,
@@ -1847,7 +1812,7 @@ static int tower_train_step(
         // D
         const int FD16 = ((F * D + 15) >> 4) << 4;
         const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM +
-                             ((F + 3) & ~3) + 2 * kTM * F + (dcn ? kTM * (dm.CP + kPad) : 0)) * sizeof(float);
+                             ((F + 3) & ~3) + (dcn ? kTM * (dm.CP + kPad) : 0)) * sizeof(float);
         DT_UNSUPPORTED(ldsD > 160 * 1024, "dt_dcn_train_step: the row-gradient kernel needs %zu B of LDS", ldsD);
         if (dcn) {
             hipFuncSetAttribute((const void*)k_dx_sparse_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
@@ -1895,8 +1860,8 @@ extern "C" int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int
                    kTM * kCrossMax + (2 * L + 1) * dm.CP) * sizeof(float);
     ldsC = max(ldsC, 2 * (size_t)(3 + 2 * L) * dm.CP * sizeof(float));        // the tile kernel's two reduction slabs
     const int FD16 = ((F * D + 15) >> 4) << 4;
-    const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + 2 * kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM + ((F + 3) & ~3) +
-                         2 * kTM * F) * sizeof(float);
+    const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + 2 * kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM + ((F + 3) & ~3)) *
+                        sizeof(float);
     return ldsC <= 160 * 1024 && ldsD <= 160 * 1024;
 }
 

@@ -171,7 +171,7 @@ class FusedDeepFM:
                  'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
                  'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
                  'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),
-                 # marks of the in-step dedupe (zero between steps) + its field-major row scratch
+                 # scratch of the in-step dedupe: field-major rows + the segment arrays (csrc/deepfm.hip DedupeWs)
                  'dedupe': torch.zeros((lib().dt_deepfm_dedupe_bytes(B, self.F) + 7) // 8, dtype=torch.int64,
                                        device=dev),
                  'dedupe_slots': lib().dt_deepfm_dedupe_slots(B, self.F)}

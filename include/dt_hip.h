@@ -345,7 +345,7 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
  * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,
  * the per-net Dense(1) logits, Add, Dense(1) output, BinaryCrossentropy (from logits, mean over B)
- * — forward AND backward in seven launches (csrc/deepfm.hip).  Hidden sizes are fixed to the
+ * — forward AND backward in six launches (csrc/deepfm.hip).  Hidden sizes are fixed to the
  * ModelConfig default dnn_params ((128,0,False),(64,0,False)), relu; dt_deepfm_supported() says
  * whether a shape is covered (else the host uses the per-layer entry points above).
  *   W1 [C,128] b1 [128] W2 [128,64] b2 [64] w3 [64] (dense_logit_dnn_nets) w_out [1] b_out [1]|NULL
@@ -356,9 +356,9 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
  * phases: 1 = forward only (logits + loss), 2 = forward + backward; OR-ed with DT_STEP_LOSS_MSE the loss is
  * MeanSquaredError on the linear output (regression task, deepmodel.py:130-131) instead of BinaryCrossentropy.
- * dedupe_ws (may be NULL; B <= 8192; 16-byte aligned): dt_deepfm_dedupe_bytes(B,F) bytes whose first
- * dt_deepfm_dedupe_slots(B,F) 32-bit words are ALL ZERO on entry and stay zero; dedupe_slots =
- * dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step resolves duplicate lookups itself: a table row
+ * dedupe_ws (may be NULL; B <= 8192; 16-byte aligned): dt_deepfm_dedupe_bytes(B,F) bytes of scratch (no
+ * initialisation needed); dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step
+ * resolves duplicate lookups itself: a table row
  * looked up ONCE keeps its (rows_out, grad_rows) entry; a row looked up several times becomes a SEGMENT — every one of
  * its lookups reports -1 in rows_out (their grad_rows entries still hold the per-lookup gradients) and the segment
  * arrays inside dedupe_ws (dt_deepfm_dedupe_segments -> byte offsets of nseg, seg_row, seg_off, seg_cnt, seg_list,

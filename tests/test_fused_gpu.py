@@ -238,9 +238,6 @@ def test_fused_sparse_gradient_rows(dev):
         t0 = emb.tables['d16'].detach().clone()
         dm.train_step(ins, y.to(dev))
         assert (emb.tables['d16'].detach() - t0).abs().max().item() > 0
-        # the in-step dedupe leaves its marks empty for the next step
-        buf = dm.fused_plan()._bufs[128]
-        assert int(buf['dedupe'].view(torch.int32)[:buf['dedupe_slots']].abs().sum()) == 0
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
 
