@@ -321,30 +321,29 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 
     for (int64_t mc = m_begin; mc < m_end; mc += kCinMC) {
         __syncthreads();
-        // stage transposed tiles: rows mm = mc + r ; (b, d) of a row in 32-bit arithmetic
+        // stage transposed tiles: rows mm = mc + r.  A thread always stages the same r = tid % 64 (256 threads, 64 rows per
+        // chunk), so its (batch row, d) offset is computed once per chunk, not once per element
         const int64_t b0 = mc / D;
         const int d0 = (int)(mc - b0 * D);
         const int rows = (int)min((int64_t)kCinMC, m_end - mc);
-        for (int e = threadIdx.x; e < kCinMC * F0; e += 256) {
-            const int i = e / kCinMC, r = e - i * kCinMC;  // r fastest -> d fastest in global
-            const int q = d0 + r, bq = q / D, dq = q - bq * D;
-            x0T[r * F0P + i] = r < rows ? x0[(b0 + bq) * x0_bs + i * D + dq] : 0.f;
-        }
-        for (int e = threadIdx.x; e < kCinMC * Hk; e += 256) {
-            const int j = e / kCinMC, r = e - j * kCinMC;
-            const int q = d0 + r, bq = q / D, dq = q - bq * D;
-            xkT[r * HkP + j] = r < rows ? xk[(b0 + bq) * xk_bs + j * D + dq] : 0.f;
-        }
-        for (int e = threadIdx.x; e < kCinMC * kCinTileN; e += 256) {
-            const int l = e / kCinMC, r = e - l * kCinMC;
-            const int q = d0 + r, bq = q / D, dq = q - bq * D;
-            float g = 0.f;
-            if (r < rows && n0 + l < L) {
-                const int64_t o = ((b0 + bq) * L + n0 + l) * D + dq;
-                g = gy[o];
-                g *= act_grad_from_y(y[o], act);
+        const int r_ = threadIdx.x & (kCinMC - 1), i_first = threadIdx.x / kCinMC;        // element e = i * 64 + r, i = i_first + 4 k
+        const int q_ = d0 + r_, bq_ = q_ / D, dq_ = q_ - bq_ * D;
+        const bool rok = r_ < rows;
+        const float* x0p = x0 + (b0 + bq_) * x0_bs + dq_;
+        const float* xkp = xk + (b0 + bq_) * xk_bs + dq_;
+        for (int i = i_first; i < F0; i += 256 / kCinMC) x0T[r_ * F0P + i] = rok ? x0p[i * D] : 0.f;
+        for (int j = i_first; j < Hk; j += 256 / kCinMC) xkT[r_ * HkP + j] = rok ? xkp[j * D] : 0.f;
+        {
+            const int64_t ob = ((b0 + bq_) * L + n0) * D + dq_;
+            for (int l = i_first; l < kCinTileN; l += 256 / kCinMC) {
+                float g = 0.f;
+                if (rok && n0 + l < L) {
+                    const int64_t o = ob + (int64_t)l * D;
+                    g = gy[o];
+                    g *= act_grad_from_y(y[o], act);
+                }
+                gT[r_ * LPAD + l] = g;
             }
-            gT[r * LPAD + l] = g;
         }
         __syncthreads();
 #pragma unroll 4
