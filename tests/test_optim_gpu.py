@@ -79,6 +79,64 @@ def test_rows_adam_merges_duplicates(dev, D, F, B, vocab, use_fields):
         assert int(st['slots'].abs().sum().item()) == 0                     # global hash left empty for the next step
 
 
+@pytest.mark.parametrize('D,n,vocab,regions,hot', [(16, 4096, 500, 4, 0), (16, 20000, 3000, 256, 700), (32, 3000, 200, 3, 50),
+                                                    (4, 500, 40, 1, 0), (64, 2000, 100, 8, 300)])
+def test_rows_adam_takes_row_segments(dev, D, n, vocab, regions, hot):
+    """dt_adam_rows_step_seg: rows looked up once arrive as (rows, values) entries, rows looked up several times as
+    SEGMENTS (region e: nseg[e] x (row, offset, count) + a list of the `values` rows to sum; their `rows` entries are -1),
+    the way the fused steps hand them over (csrc/deepfm.hip DedupeWs).  A hot row with `hot` lookups included."""
+    from deeptables_amd.ops import SparseRowGrad
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(D + n)
+    t0 = torch.randn(vocab, D, generator=g) * 0.05
+    table = torch.nn.Parameter(t0.clone().to(dev))
+    emb = _FakeEmb(table, 0)
+    opt = _adam(dev, [table], [emb])
+    rp = t0.double()
+    rm, rv = torch.zeros_like(rp), torch.zeros_like(rp)
+    cap = n // 2 + 1
+    for t in range(1, 4):
+        ids = torch.randint(0, vocab, (n,), generator=g)
+        if hot:
+            ids[torch.randperm(n, generator=g)[:hot]] = 7
+        ids[torch.rand(n, generator=g) < 0.02] = -1
+        vals = torch.randn(n, D, generator=g)
+        # host-side segment construction: rows with >= 2 lookups, dealt to the regions round-robin
+        rows = ids.clone()
+        uniq, counts = torch.unique(ids[ids >= 0], return_counts=True)
+        multi = uniq[counts > 1].tolist()
+        nseg = torch.zeros(regions, dtype=torch.int32)
+        seg_row = torch.zeros(regions * cap, dtype=torch.int64)
+        seg_off = torch.zeros(regions * cap, dtype=torch.int32)
+        seg_cnt = torch.zeros(regions * cap, dtype=torch.int32)
+        seg_list = torch.zeros(n, dtype=torch.int32)
+        cursor = 0
+        for k, r in enumerate(multi):
+            members = torch.nonzero(ids == r).reshape(-1)
+            e = k % regions
+            sidx = e * cap + int(nseg[e])
+            seg_row[sidx], seg_off[sidx], seg_cnt[sidx] = r, cursor, len(members)
+            seg_list[cursor:cursor + len(members)] = members.int()
+            cursor += len(members)
+            nseg[e] += 1
+            rows[members] = -1
+        seg = (nseg.to(dev), seg_row.to(dev), seg_off.to(dev), seg_cnt.to(dev), seg_list.to(dev), regions, cap)
+        sg = SparseRowGrad(rows.to(dev), vals.clone().to(dev), fields=-1, segments=seg)
+        assert torch.equal(sg.expanded()[0].cpu(), ids)                  # the per-lookup view restores every row id
+        emb.sparse_grads = {f'd{D}': [sg]}
+        opt.step()
+        dense = torch.zeros(vocab, D, dtype=torch.float64)
+        ok = ids >= 0
+        dense.index_add_(0, ids[ok], vals.double()[ok])
+        touched = torch.zeros(vocab, dtype=torch.bool)
+        touched[ids[ok]] = True
+        np_, nm, nv = R.keras_adam_step(rp, dense, rm, rv, t)
+        rp = torch.where(touched[:, None], np_, rp)
+        rm = torch.where(touched[:, None], nm, rm)
+        rv = torch.where(touched[:, None], nv, rv)
+        assert (table.detach().cpu().double() - rp).abs().max().item() < 2e-6, t
+
+
 def test_two_gradient_pieces_and_dp_sized_input(dev):
     """Several SparseRowGrad pieces for one table (what the data-parallel all-gather hands over): rows repeat across
     pieces; more than 8192 lookups per field falls back to the global hash."""
