@@ -57,6 +57,32 @@ __global__ __launch_bounds__(256) void k_adamlike(float4* __restrict__ table, fl
     table[row * 4 + c] = p; mv[row * 8 + c] = m; mv[row * 8 + 4 + c] = v;
 }
 
+// the same update on ONE interleaved record per row: p | m | v = 192 contiguous bytes (one random location, not two)
+__global__ __launch_bounds__(256) void k_adamlike3(float4* __restrict__ pmv, const int* __restrict__ rows,
+                                                   const float4* __restrict__ grad, int64_t n) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int c = threadIdx.x & 3;
+    if (g >= n) return;
+    const int64_t row = rows[g];
+    float4 gr = grad[g * 4 + c];
+    float4 p = pmv[row * 12 + c], m = pmv[row * 12 + 4 + c], v = pmv[row * 12 + 8 + c];
+    m.x = 0.9f * m.x + 0.1f * gr.x; m.y = 0.9f * m.y + 0.1f * gr.y; m.z = 0.9f * m.z + 0.1f * gr.z; m.w = 0.9f * m.w + 0.1f * gr.w;
+    v.x = 0.99f * v.x + 0.01f * gr.x * gr.x; v.y = 0.99f * v.y + 0.01f * gr.y * gr.y;
+    v.z = 0.99f * v.z + 0.01f * gr.z * gr.z; v.w = 0.99f * v.w + 0.01f * gr.w * gr.w;
+    p.x -= 1e-3f * m.x / (sqrtf(v.x) + 1e-7f); p.y -= 1e-3f * m.y / (sqrtf(v.y) + 1e-7f);
+    p.z -= 1e-3f * m.z / (sqrtf(v.z) + 1e-7f); p.w -= 1e-3f * m.w / (sqrtf(v.w) + 1e-7f);
+    pmv[row * 12 + c] = p; pmv[row * 12 + 4 + c] = m; pmv[row * 12 + 8 + c] = v;
+}
+
+// gather of the 64-byte p part out of 192-byte records (what the forward gather would see with that layout)
+__global__ __launch_bounds__(256) void k_gather3(const float4* __restrict__ pmv, const int* __restrict__ rows,
+                                                 int64_t n, float4* __restrict__ out) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int c = threadIdx.x & 3;
+    if (g >= n) return;
+    out[g * 4 + c] = pmv[(int64_t)rows[g] * 12 + c];
+}
+
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
@@ -80,8 +106,8 @@ static float time_us(F launch, int reps = 16) {
 int main() {
     const int64_t V = 26LL * 1000 * 1000;   // table rows of 64 bytes: 1.66 GB
     float4 *table, *mv, *out, *grad;
-    CK(hipMalloc(&table, V * 64)); CK(hipMalloc(&mv, V * 128));
-    CK(hipMemset(table, 0, V * 64)); CK(hipMemset(mv, 0, V * 128));
+    CK(hipMalloc(&table, V * 64)); CK(hipMalloc(&mv, V * 192));
+    CK(hipMemset(table, 0, V * 64)); CK(hipMemset(mv, 0, V * 192));
     const int64_t NMAX = 1 << 24;
     CK(hipMalloc(&out, NMAX * 64)); CK(hipMalloc(&grad, NMAX * 64));
     CK(hipMemset(grad, 0, NMAX * 64));
@@ -99,6 +125,9 @@ int main() {
         float t4 = time_us([&](int i) { hipLaunchKernelGGL(k_gather<4>, dim3((blocks1 + 3) / 4), dim3(256), 0, 0, table, rows + i * n, n, out); });
         float tr = time_us([&](int i) { hipLaunchKernelGGL(k_rmw, dim3(blocks1), dim3(256), 0, 0, table, rows + i * n, n); });
         float ta = time_us([&](int i) { hipLaunchKernelGGL(k_adamlike, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + i * n, grad, n); });
+        float ta3 = time_us([&](int i) { hipLaunchKernelGGL(k_adamlike3, dim3(blocks1), dim3(256), 0, 0, mv, rows + i * n, grad, n); });
+        float tg3 = time_us([&](int i) { hipLaunchKernelGGL(k_gather3, dim3(blocks1), dim3(256), 0, 0, mv, rows + i * n, n, out); });
+        printf("n=%8lld  interleaved p|m|v records (192 B): adam-like %7.1f us, gather of the p part %7.1f us\n", (long long)n, ta3, tg3);
         printf("n=%8lld  gather R=1 %7.1f us (%5.2f TB/s gathered+written)  R=2 %7.1f us  R=4 %7.1f us | rmw %7.1f us (%5.2f TB/s r+w) | adam-like %7.1f us (%5.2f TB/s)\n",
                (long long)n, t1, n * 128 / t1 / 1e6, t2, t4, tr, n * 128 / tr / 1e6, ta, n * 448 / ta / 1e6);
     }
