@@ -1,0 +1,92 @@
+# -*- coding:utf-8 -*-
+"""CPU: host-side logic added in round 2 that needs no kernel — the per-lookup view of a segmented sparse gradient
+(ops.SparseRowGrad.expanded), Keras' sample / class weighting of the loss (training.weighted_loss), the feed carrying
+per-row weights through a shuffle (training.TableBatches), balanced class weights (DeepTable.get_class_weight)."""
+import numpy as np
+import torch
+
+
+def test_segmented_sparse_grad_expands_to_one_entry_per_lookup():
+    from deeptables_amd.ops import SparseRowGrad
+    ids = torch.tensor([5, 9, 5, 2, 9, 9, 7, -1, 2], dtype=torch.int64)
+    vals = torch.arange(9 * 4, dtype=torch.float32).reshape(9, 4)
+    # rows 5 (lookups 0, 2), 9 (1, 4, 5) and 2 (3, 8) are looked up several times -> segments in 2 regions of capacity 3
+    regions, cap = 2, 3
+    nseg = torch.tensor([2, 1], dtype=torch.int32)
+    seg_row = torch.tensor([5, 2, 0, 9, 0, 0], dtype=torch.int64)
+    seg_off = torch.tensor([0, 2, 0, 4, 0, 0], dtype=torch.int32)
+    seg_cnt = torch.tensor([2, 2, 0, 3, 0, 0], dtype=torch.int32)
+    seg_list = torch.tensor([0, 2, 3, 8, 1, 4, 5, 0, 0], dtype=torch.int32)
+    rows = ids.clone()
+    rows[[0, 2, 3, 8, 1, 4, 5]] = -1
+    sg = SparseRowGrad(rows, vals, fields=-1, segments=(nseg, seg_row, seg_off, seg_cnt, seg_list, regions, cap))
+    got_rows, got_vals = sg.expanded()
+    assert torch.equal(got_rows, ids) and got_vals is vals
+    assert torch.equal(rows[[0, 2]], torch.tensor([-1, -1]))        # the stored rows are untouched
+    plain = SparseRowGrad(ids, vals)
+    assert plain.expanded()[0] is ids
+    empty = SparseRowGrad(ids, vals, segments=(torch.zeros(2, dtype=torch.int32), seg_row, seg_off, seg_cnt, seg_list, 2, 3))
+    assert torch.equal(empty.expanded()[0], ids)
+
+
+def test_weighted_loss_follows_keras_sample_weight_semantics():
+    from deeptables_amd import training
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(17, 1, generator=g, dtype=torch.float64)
+    y = (torch.rand(17, 1, generator=g) < 0.4).double()
+    w = torch.rand(17, generator=g, dtype=torch.float64) * 3
+    p = torch.sigmoid(z)
+    per = -(y * torch.log(p) + (1 - y) * torch.log(1 - p)).reshape(-1)
+    assert abs(float(training.weighted_loss('binary_crossentropy', z, y, w)) - float((per * w).sum() / 17)) < 1e-12
+    # all-ones weights = the unweighted mean
+    assert abs(float(training.weighted_loss('binary_crossentropy', z, y, torch.ones(17, dtype=torch.float64))) -
+               float(training.bce_from_logits(z, y))) < 1e-12
+    zc = torch.randn(9, 4, generator=g, dtype=torch.float64)
+    yc = torch.eye(4, dtype=torch.float64)[torch.randint(0, 4, (9,), generator=g)]
+    wc = torch.rand(9, generator=g, dtype=torch.float64)
+    per_c = -(torch.log_softmax(zc, -1) * yc).sum(-1)
+    assert abs(float(training.weighted_loss('categorical_crossentropy', zc, yc, wc)) - float((per_c * wc).sum() / 9)) < 1e-12
+    yr = torch.randn(17, 1, generator=g, dtype=torch.float64)
+    assert abs(float(training.weighted_loss('mse', z, yr, w)) - float((((z - yr) ** 2).reshape(-1) * w).sum() / 17)) < 1e-12
+
+
+def test_feed_carries_row_weights_through_the_shuffle():
+    from deeptables_amd import training
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    n = 50
+    X = {'cat': np.arange(n * 2).reshape(n, 2) % 7, 'input_continuous_all': np.arange(n, dtype=np.float32).reshape(n, 1)}
+
+    class XF:
+        def __init__(self, d):
+            self.d = d
+
+        def __len__(self):
+            return n
+
+        def __getitem__(self, k):
+            return self.d[k]
+    y = (np.arange(n) % 3 == 0).astype(np.float32)
+    w = np.arange(n, dtype=np.float32) + 0.5                        # weight i+0.5 belongs to the row whose dense value is i
+    cats = [CategoricalColumn('C0', 7, 4), CategoricalColumn('C1', 7, 4)]
+    conts = [ContinuousColumn('input_continuous_all', ['I0'])]
+    tb = training.TableBatches(XF(X), y, cats, conts, 'cpu', 'binary', 2, sample_weight=w)
+    assert tb.weighted
+    seen = 0
+    for ins, yb in tb.iterate(16, True, drop_remainder=False):
+        dense = ins[-1].reshape(-1)
+        assert yb.shape[1] == 2
+        assert torch.allclose(yb[:, -1], dense + 0.5)               # the weight travelled with its row
+        assert torch.allclose(yb[:, 0], (dense.long() % 3 == 0).float())
+        seen += len(dense)
+    assert seen == n
+    assert not training.TableBatches(XF(X), y, cats, conts, 'cpu', 'binary', 2).weighted
+
+
+def test_balanced_class_weights():
+    from deeptables_amd.models.deeptable import DeepTable
+
+    class Stub:
+        classes_ = [0, 1, 2]
+    y = np.array([0] * 6 + [1] * 3 + [2] * 1)
+    cw = DeepTable.get_class_weight(Stub(), y)
+    assert cw == {0: 10 / (3 * 6), 1: 10 / (3 * 3), 2: 10 / (3 * 1)}      # sklearn 'balanced': n / (classes * count)
