@@ -9,12 +9,16 @@ order), not a simplified closed form; `oracle/closed_form.py` holds the independ
 forms, and `tests/test_oracle.py` checks the two against each other and against the golden
 vectors in `tests/golden/`.
 
-PARITY UNPINNED: the reference ships no golden vectors / known-answer tests for this path
-(all its assertions are `AUC >= 0` or shapes: deeptables/tests/models/nets_test.py:43-44,
-layers_test.py:28-29) and TensorFlow/Keras — where the arithmetic lives (requirements.txt:1
-`tensorflow>=2.4`, CI pins 2.16.2-2.18.0) — is not installable in this environment.  The oracle
-is therefore anchored on the reference's own call sites and on the published semantics of the
-TF/Keras ops they call; every Keras default assumed is written down in KERAS_DEFAULTS below.
+PARITY STATUS — pinned to the reference's SOURCE, unpinned against TensorFlow's arithmetic.  The reference ships no
+golden vectors / known-answer tests for this path (all its assertions are `AUC >= 0` or shapes:
+deeptables/tests/models/nets_test.py:43-44, layers_test.py:28-29) and TensorFlow/Keras (requirements.txt:1
+`tensorflow>=2.4`, CI pins 2.16.2-2.18.0) is not installable in this environment.  What IS checked: the reference's
+own `layers.py` and `deepnets.py`, imported unmodified from /root/reference onto an in-process shim of the ~40
+TF / Keras primitives they call (tests/golden/make_reference_golden.py), produce outputs this oracle reproduces to
+1e-12 for every hot-path layer and net function (24 fixtures, tests/golden/reference_code_*.npz, replayed on every
+CPU run by tests/test_oracle_reference_code.py): op order, axes, splits, transposes and weight shapes are the
+reference's.  What is NOT checked: float32 rounding / reduction order inside a TensorFlow primitive, and the Keras
+defaults listed in KERAS_DEFAULTS below (BatchNormalization epsilon / momentum, initializers, Adam, BCE clipping).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 Gradients of the oracle come from torch.autograd on these functions.
@@ -254,6 +258,12 @@ def multihead_attention(x, w, num_heads=1, use_residual=True, training=True):
     return outputs
 
 
+def _mha_from_parts(x, parts, names, num_heads=1, use_residual=True, training=True):
+    """multihead_attention with its weight dict given as parallel lists (tests/golden/make_reference_golden.py stores
+    tensors, not dicts): names[i] in {'Q','K','V','R','bn'}, parts[i] = the tuple of that entry."""
+    return multihead_attention(x, {n: tuple(p) for n, p in zip(names, parts)}, num_heads, use_residual, training)
+
+
 # ---------------------------------------------------------------------------------------------
 # deepnets.py net functions + deepmodel.py graph (explicit-weights functional form)
 # ---------------------------------------------------------------------------------------------
@@ -289,6 +299,31 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
     weights: dict keyed with the Keras layer/weight names (see tests/golden/make_golden.py).
     cat_idx [B,F] float32 (reference input contract), dense [B,Nd] or None.
     Returns the LOGIT fed to the sigmoid of `task_output` ([B,1]) and the probability."""
+    outs, concat_emb_dense = model_nets(weights, cat_idx, dense, nets, config, training)
+    if len(outs) > 1:                                                # :286-297
+        logits = []
+        for name, out in outs.items():
+            if out.shape[-1] > 1:
+                out = out @ weights[f'dense_logit_{name}']           # Dense(1, no bias)
+            logits.append(out)
+        xs = logits[0]
+        for t in logits[1:]:
+            xs = xs + t                                              # Add()
+    else:
+        xs = next(iter(outs.values()))
+    k, b = weights['task_output']                                    # :455 Dense(1, sigmoid)
+    logit = xs @ k
+    if b is not None:
+        logit = logit + b
+    prob = torch.sigmoid(logit)
+    if return_parts:
+        return logit, prob, outs, concat_emb_dense
+    return logit, prob
+
+
+def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
+    """the front of DeepModel.__build_model: embeddings, concat + BatchNormalization, and the output of every net
+    function of `nets` (deepmodel.py:259-285, deepnets.py) -> (OrderedDict net -> output, concat_emb_dense)"""
     config = config or {}
     tables = weights['emb_categorical_vars_all']                     # list of (V_f, D)
     embeddings = multi_column_embedding(cat_idx, tables)             # :264 / :388-404
@@ -384,25 +419,25 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
                 raise ValueError(net)
         else:
             raise ValueError(net)
-    if len(outs) > 1:                                                # :286-297
-        logits = []
-        for name, out in outs.items():
-            if out.shape[-1] > 1:
-                out = out @ weights[f'dense_logit_{name}']           # Dense(1, no bias)
-            logits.append(out)
-        xs = logits[0]
-        for t in logits[1:]:
-            xs = xs + t                                              # Add()
-    else:
-        xs = next(iter(outs.values()))
-    k, b = weights['task_output']                                    # :455 Dense(1, sigmoid)
-    logit = xs @ k
-    if b is not None:
-        logit = logit + b
-    prob = torch.sigmoid(logit)
-    if return_parts:
-        return logit, prob, outs, concat_emb_dense
-    return logit, prob
+    return outs, concat_emb_dense
+
+
+def _nets_from_parts(cat_idx, dense, tables, bn, names, parts, nets, config, net):
+    """model_forward's per-net output `outs[net]` with the weight dict given as parallel lists
+    (tests/golden/make_reference_golden.py stores tensors, not dicts).  names[i] is a key of the weights dict and
+    parts[i] its value; 'autoint_layers' is a list of [Q, K, V, R|None, bn] lists."""
+    w = {'emb_categorical_vars_all': list(tables), 'bn_concat_emb_dense': tuple(bn)}
+    for n, p in zip(names, parts):
+        if n == 'autoint_layers':
+            w[n] = [{k: tuple(v) for k, v in zip(('Q', 'K', 'V', 'R', 'bn'), lw) if v is not None} for lw in p]
+        elif n in ('dnn', 'dcn_dnn'):
+            w[n] = [tuple(kb) for kb in p]
+        elif n == 'cin_exFM_out':
+            w[n] = tuple(p)
+        else:
+            w[n] = p
+    outs, _ = model_nets(w, cat_idx, dense, [net], config, training=True)
+    return outs[net]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,560 @@
+# -*- coding:utf-8 -*-
+"""Pins the oracle to the REFERENCE'S OWN LAYER CODE.
+
+TensorFlow / Keras cannot be installed here, so the reference cannot run as it is.  But its hot-path layers
+(/root/reference/deeptables/models/layers.py) are short compositions of a few dozen primitive tensor ops
+(tf.reduce_sum, tf.split, tf.concat, tf.matmul, tf.tensordot, tf.nn.conv1d, tf.nn.softmax, Dense, ...), and the
+PRIMITIVES have unambiguous published semantics.  This script
+
+  1. installs an in-process shim of exactly those primitives on torch float64 (modules `tensorflow`, `keras`, ... in
+     sys.modules; nothing is written anywhere),
+  2. imports the reference's layers.py UNMODIFIED from /root/reference (read-only) on top of the shim,
+  3. runs the reference's own `build` / `call` code of FM, Cross, InnerProduct, OuterProduct (mat / vec / num), CIN
+     (direct / split, with / without residual and bias; reduce_D = False, the branch every BASELINE config takes),
+     MultiheadAttention (training-mode BatchNormalization), MultiColumnEmbedding, AFM, BilinearInteraction (3 types)
+     and SENET (mean / max) on seeded inputs and weights,
+  4. checks the oracle (oracle/reference_layers.py) against those outputs to 1e-12, and
+  5. writes inputs, weights and the reference code's outputs to tests/golden/reference_code_*.npz.
+
+What this pins: the op ORDER and every shape / axis / split / transpose decision of the reference's layer code — the part a
+restatement can get wrong.  What it cannot pin: TensorFlow's own arithmetic inside a primitive (float32 rounding,
+reduction order), which no restatement controls either.  tests/test_oracle_reference_code.py compares the oracle
+with the committed vectors on every CPU run; this script only runs where /root/reference exists.
+
+    python tests/golden/make_reference_golden.py          # regenerates the fixtures (deterministic)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+DT = torch.float64
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1. the shim: tensors are torch tensors; TensorShape-style accessors the reference uses are added to torch.Tensor
+# ---------------------------------------------------------------------------------------------------------------
+class _Shape(tuple):
+    def as_list(self):
+        return list(self)
+
+
+def _install_tensor_accessors():
+    torch.Tensor.get_shape = lambda self: _Shape(int(s) for s in self.shape)
+    torch.Tensor.numpy_ = lambda self: self.detach().cpu().numpy()
+
+
+def _t(x):
+    if isinstance(x, (list, tuple)) and len(x) and isinstance(x[0], torch.Tensor):
+        return torch.stack(list(x), 0)          # TF converts a list of tensors to one stacked tensor
+    if isinstance(x, torch.Tensor):
+        return x
+    return torch.as_tensor(x, dtype=DT)
+
+
+def _axis(a):
+    return tuple(a) if isinstance(a, (list, tuple)) else a
+
+
+def tf_reduce_sum(x, axis=None, keepdims=False, keep_dims=None):
+    kd = keepdims if keep_dims is None else keep_dims
+    return _t(x).sum() if axis is None else _t(x).sum(dim=_axis(axis), keepdim=kd)
+
+
+def tf_reduce_mean(x, axis=None, keepdims=False):
+    return _t(x).mean() if axis is None else _t(x).mean(dim=_axis(axis), keepdim=keepdims)
+
+
+def tf_reduce_max(x, axis=None, keepdims=False):
+    return _t(x).max() if axis is None else _t(x).amax(dim=_axis(axis), keepdim=keepdims)
+
+
+def tf_split(value, num_or_size_splits, axis=0):
+    value = _t(value)
+    if isinstance(num_or_size_splits, int):
+        assert value.shape[axis] % num_or_size_splits == 0
+        return list(torch.split(value, value.shape[axis] // num_or_size_splits, dim=axis))
+    return list(torch.split(value, list(num_or_size_splits), dim=axis))
+
+
+def tf_matmul(a, b, transpose_a=False, transpose_b=False):
+    a, b = _t(a), _t(b)
+    if transpose_a:
+        a = a.transpose(-1, -2)
+    if transpose_b:
+        b = b.transpose(-1, -2)
+    return torch.matmul(a, b)
+
+
+def tf_tensordot(a, b, axes):
+    a, b = _t(a), _t(b)
+    if isinstance(axes, int):
+        return torch.tensordot(a, b, dims=axes)
+    ax_a, ax_b = axes
+    ax_a = [ax_a] if isinstance(ax_a, int) else list(ax_a)
+    ax_b = [ax_b] if isinstance(ax_b, int) else list(ax_b)
+    return torch.tensordot(a, b, dims=(ax_a, ax_b))
+
+
+def tf_conv1d(input, filters, stride=1, padding='VALID'):
+    """tf.nn.conv1d, NWC input [batch, width, in_ch], filters [k, in_ch, out_ch], VALID."""
+    assert padding == 'VALID'
+    x = _t(input).permute(0, 2, 1)                       # -> [batch, in_ch, width]
+    w = _t(filters).permute(2, 1, 0)                     # -> [out_ch, in_ch, k]
+    return torch.nn.functional.conv1d(x, w, stride=stride).permute(0, 2, 1)
+
+
+def _make_tf():
+    tf = types.ModuleType('tensorflow')
+    tf.float32, tf.int32, tf.int64 = 'float32', 'int32', 'int64'
+    tf.reduce_sum, tf.reduce_mean, tf.reduce_max = tf_reduce_sum, tf_reduce_mean, tf_reduce_max
+    tf.expand_dims = lambda x, axis: _t(x).unsqueeze(axis)
+    tf.split = tf_split
+    tf.concat = lambda values, axis: torch.cat([_t(v) for v in values], dim=axis)
+    tf.transpose = lambda a, perm=None: _t(a).permute(*perm) if perm is not None else _t(a).t()
+    tf.tensordot = tf_tensordot
+    tf.reshape = lambda x, shape: _t(x).reshape(*[int(s) for s in shape])
+    tf.matmul = tf_matmul
+    tf.multiply = lambda a, b: _t(a) * _t(b)
+    tf.square = lambda x: _t(x) * _t(x)
+    tf.sigmoid = lambda x: torch.sigmoid(_t(x))
+    tf.identity = lambda x: x
+    tf.zeros_like = lambda x: torch.zeros_like(_t(x))
+    tf.ones_like = lambda x: torch.ones_like(_t(x))
+    tf.shape = lambda x: _t(x).shape
+    tf.constant = lambda v, dtype=None: torch.as_tensor(v, dtype=DT)
+    tf.where = lambda c, a, b: torch.where(c, _t(a), _t(b))
+    tf.equal = lambda a, b: _t(a) == _t(b)
+    tf.greater = lambda a, b: _t(a) > _t(b)
+    tf.greater_equal = lambda a, b: _t(a) >= _t(b)
+    tf.less = lambda a, b: _t(a) < _t(b)
+    tf.logical_and = lambda a, b: a & b
+    nn = types.ModuleType('tensorflow.nn')
+    nn.softmax = lambda x, axis=-1: torch.softmax(_t(x), dim=axis)
+    nn.relu = lambda x: torch.relu(_t(x))
+    nn.conv1d = tf_conv1d
+    nn.bias_add = lambda x, b: _t(x) + _t(b)
+    nn.sigmoid = lambda x: torch.sigmoid(_t(x))
+    tf.nn = nn
+    return tf
+
+
+# ---- keras.layers.* the reference's layers instantiate -----------------------------------------------------------------
+_RNG = None
+
+
+def _init(shape, kind):
+    """deterministic weights (the VALUES do not matter for pinning the op sequence; zeros would hide terms)"""
+    shape = tuple(int(s) for s in shape)
+    return torch.as_tensor(_RNG.uniform(-0.5, 0.5, size=shape), dtype=DT)
+
+
+def _act(name):
+    if name is None or name == 'linear':
+        return lambda t: t
+    if callable(name):
+        return name
+    return {'relu': torch.relu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh,
+            'softmax': lambda t: torch.softmax(t, -1)}[name]
+
+
+_REGISTRY = []          # every shim layer in creation order (the net functions create theirs internally)
+
+
+class Layer:
+    def __init__(self, name=None, **kwargs):
+        self.name = name
+        self.built = False
+        self._weights = []
+        _REGISTRY.append(self)
+
+    def add_weight(self, name=None, shape=None, initializer=None, dtype=None, trainable=True, regularizer=None,
+                   constraint=None, **kw):
+        w = _init(shape, initializer)
+        self._weights.append((name, w))
+        return w
+
+    def build(self, input_shape):
+        self.built = True
+
+    def __call__(self, x, **kwargs):
+        if not self.built:
+            if isinstance(x, (list, tuple)):
+                self.build([_Shape(int(s) for s in t.shape) for t in x])
+            else:
+                self.build(_Shape(int(s) for s in x.shape))
+            self.built = True
+        return self.call(x, **kwargs)
+
+    def get_config(self):
+        return {}
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+
+class Dense(Layer):
+    def __init__(self, units, activation=None, use_bias=True, kernel_initializer=None, **kw):
+        super().__init__(**kw)
+        self.units, self.activation, self.use_bias = units, activation, use_bias
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight('kernel', (input_shape[-1], self.units))
+        self.bias = self.add_weight('bias', (self.units,)) if self.use_bias else None
+
+    def call(self, x):
+        y = torch.matmul(x, self.kernel)
+        if self.bias is not None:
+            y = y + self.bias
+        return _act(self.activation)(y)
+
+
+class Dropout(Layer):                       # inference / rate 0: identity
+    def __init__(self, rate=0.0, **kw):
+        super().__init__(**kw)
+        self.rate = rate
+
+    def call(self, x, training=None):
+        assert not self.rate, 'the fixtures use dropout rate 0'
+        return x
+
+
+SpatialDropout1D = Dropout
+
+
+class BatchNormalization(Layer):
+    """keras.layers.BatchNormalization() in TRAINING mode: batch statistics over all axes but the last, biased variance,
+    epsilon 1e-3, gamma ones / beta zeros at build (they are replaced by seeded values so the affine part is visible)."""
+
+    def __init__(self, epsilon=1e-3, momentum=0.99, **kw):
+        super().__init__(**kw)
+        self.epsilon = epsilon
+
+    def build(self, input_shape):
+        self.gamma = self.add_weight('gamma', (input_shape[-1],)) + 1.0
+        self.beta = self.add_weight('beta', (input_shape[-1],))
+
+    def call(self, x, training=None):
+        red = tuple(range(x.dim() - 1))
+        mean = x.mean(dim=red, keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=red, keepdim=True)
+        return (x - mean) / torch.sqrt(var + self.epsilon) * self.gamma + self.beta
+
+
+class Activation(Layer):
+    def __init__(self, activation, **kw):
+        super().__init__(**kw)
+        self.fn = _act(activation)
+
+    def call(self, x):
+        return self.fn(x)
+
+
+class Concatenate(Layer):
+    def __init__(self, axis=-1, **kw):
+        super().__init__(**kw)
+        self.axis = axis
+
+    def call(self, xs):
+        return torch.cat(list(xs), dim=self.axis)
+
+
+class Flatten(Layer):
+    def call(self, x):
+        return x.reshape(x.shape[0], -1)
+
+
+class Add(Layer):
+    def call(self, xs):
+        out = xs[0]
+        for t in xs[1:]:
+            out = out + t
+        return out
+
+
+class _Unused(Layer):
+    def __init__(self, *a, **kw):
+        super().__init__()
+
+
+def _stub_module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    return m
+
+
+class _Any:
+    """attribute sink for names the layer code only touches in paths the fixtures do not take"""
+
+    def __init__(self, *a, **kw):
+        pass
+
+    def __getattr__(self, k):
+        return _Any()
+
+    def __call__(self, *a, **kw):
+        return _Any()
+
+
+def install_shim():
+    _install_tensor_accessors()
+    tf = _make_tf()
+    layers = _stub_module('keras.api.layers', Layer=Layer, Dense=Dense, Dropout=Dropout, BatchNormalization=BatchNormalization,
+                          Activation=Activation, Concatenate=Concatenate, Flatten=Flatten, Input=_Unused, Embedding=_Unused,
+                          Lambda=_Unused, Add=Add, Conv2D=_Unused, MaxPooling2D=_Unused, SpatialDropout1D=SpatialDropout1D)
+    kops = _stub_module('keras.ops', ndim=lambda x: (_t(x)).dim(), sum=tf_reduce_sum,
+                        cast=lambda x, dtype: _t(x).to({'int32': torch.int32, 'int64': torch.int64,
+                                                       'float32': DT}.get(dtype, dtype)),
+                        log=lambda x: torch.log(_t(x)), clip=lambda x, a, b: torch.clamp(_t(x), a, b),
+                        power=lambda x, p: torch.pow(_t(x), p), not_equal=lambda a, b: _t(a) != b)
+    backend = _stub_module('keras.backend', epsilon=lambda: 1e-7, floatx=lambda: 'float32')
+
+    class _Getter(types.ModuleType):
+        def get(self, x):
+            return x
+
+        def serialize(self, x):
+            return x
+    losses = _stub_module('keras.losses', Loss=object)
+    keras = _stub_module('keras', ops=kops, backend=backend, layers=layers, initializers=_Getter('keras.initializers'),
+                         regularizers=_Getter('keras.regularizers'), constraints=_Getter('keras.constraints'), losses=losses)
+    tf.keras = _stub_module('tensorflow.keras', layers=layers)
+    ctx = _stub_module('tensorflow.python.eager.context', executing_eagerly=lambda: False, context=lambda: _Any())
+    emb_ops = _stub_module('tensorflow.python.ops.embedding_ops',
+                           embedding_lookup=lambda params, ids: params[_t(ids).long()])
+    mods = {
+        'tensorflow': tf, 'tensorflow.nn': tf.nn, 'tensorflow.keras': tf.keras,
+        'tensorflow.python': _stub_module('tensorflow.python'),
+        'tensorflow.python.eager': _stub_module('tensorflow.python.eager', context=ctx),
+        'tensorflow.python.eager.context': ctx,
+        'tensorflow.python.framework': _stub_module('tensorflow.python.framework', ops=_Any()),
+        'tensorflow.python.framework.ops': _stub_module('tensorflow.python.framework.ops'),
+        'tensorflow.python.keras': _stub_module('tensorflow.python.keras'),
+        'tensorflow.python.keras.utils': _stub_module('tensorflow.python.keras.utils', tf_utils=_Any()),
+        'tensorflow.python.ops': _stub_module('tensorflow.python.ops', embedding_ops=emb_ops, math_ops=_Any()),
+        'tensorflow.python.ops.embedding_ops': emb_ops,
+        'keras': keras, 'keras.ops': kops, 'keras.backend': backend, 'keras.api': _stub_module('keras.api', layers=layers),
+        'keras.api.layers': layers, 'keras.api.metrics': _stub_module('keras.api.metrics', RootMeanSquaredError=_Any),
+        'keras.initializers': keras.initializers, 'keras.regularizers': keras.regularizers,
+        'keras.constraints': keras.constraints, 'keras.losses': losses,
+        'keras.src': _stub_module('keras.src'), 'keras.src.legacy': _stub_module('keras.src.legacy'),
+        'keras.src.legacy.losses': _stub_module('keras.src.legacy.losses', Reduction=_Any()),
+    }
+    sys.modules.update(mods)
+
+
+def load_reference_layers():
+    """the reference's layers.py, unmodified, as module `deeptables.models.layers` (its package __init__ files pull in
+    hypernets / pandas pipelines and are not executed)"""
+    logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, warn=lambda *a, **k: None,
+                                   debug=lambda *a, **k: None, error=lambda *a, **k: None)
+    utils = _stub_module('deeptables.utils', dt_logging=types.SimpleNamespace(get_logger=lambda n: logger),
+                         consts=_Any(), gpu=_Any())
+    utils.__path__ = []
+    pkg = _stub_module('deeptables')
+    pkg.__path__ = []
+    models = _stub_module('deeptables.models')
+    models.__path__ = []
+    sys.modules.update({'deeptables': pkg, 'deeptables.utils': utils, 'deeptables.models': models})
+    spec = importlib.util.spec_from_file_location('deeptables.models.layers', os.path.join(REF, 'deeptables/models/layers.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['deeptables.models.layers'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference_deepnets():
+    """the reference's deepnets.py (net functions: which layers on which of the four input tensors), unmodified"""
+    sys.modules['tensorflow.python.keras.utils.generic_utils'] = _stub_module(
+        'tensorflow.python.keras.utils.generic_utils', deserialize_keras_object=_Any(), serialize_keras_object=_Any())
+    sys.modules['deeptables.utils'].counter = _Any()
+    spec = importlib.util.spec_from_file_location('deeptables.models.deepnets', os.path.join(REF, 'deeptables/models/deepnets.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['deeptables.models.deepnets'] = mod
+    sys.modules['deeptables.models'].layers = sys.modules['deeptables.models.layers']
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2. cases: (reference layer code run on the shim) vs (the oracle's restatement), same inputs and weights.
+#    A case = the oracle function's name + its tensor arguments + its static arguments; the fixture stores exactly
+#    that plus the reference code's output, so tests/test_oracle_reference_code.py can replay it without /root/reference.
+# ---------------------------------------------------------------------------------------------------------------
+def pack(prefix, v, out):
+    """nested lists / tuples of tensors -> flat {key: ndarray}; None -> marker"""
+    if v is None:
+        out[prefix + '@none'] = np.zeros(0)
+    elif isinstance(v, (list, tuple)):
+        out[prefix + '@len'] = np.array(len(v))
+        for k, e in enumerate(v):
+            pack(f'{prefix}#{k}', e, out)
+    else:
+        out[prefix] = v.detach().cpu().numpy()
+
+
+def main():
+    global _RNG
+    import json
+    sys.path.insert(0, ROOT)
+    install_shim()
+    L = load_reference_layers()
+    from oracle import reference_layers as R
+    rng = np.random.RandomState(20250924)
+    _RNG = rng
+    written = []
+
+    def rand(*shape):
+        return torch.as_tensor(rng.randn(*shape), dtype=DT)
+
+    def case(name, ref_out, fn, tensors, static=None, post=None):
+        static = static or {}
+        got = getattr(R, fn)(**tensors, **static)
+        if post == 'cat1':
+            got, ref_out = torch.cat(list(got), 1), torch.cat(list(ref_out), 1)
+        ref_out = _t(ref_out)
+        assert ref_out.shape == got.shape, (name, tuple(ref_out.shape), tuple(got.shape))
+        err = (ref_out - got).abs().max().item()
+        assert err < 1e-12 * max(1.0, ref_out.abs().max().item()), (name, err)
+        d = {'out': ref_out.detach().cpu().numpy(),
+             'meta': np.array(json.dumps({'fn': fn, 'static': static, 'post': post, 'args': sorted(tensors)}))}
+        for k, v in tensors.items():
+            pack('arg:' + k, v, d)
+        np.savez(os.path.join(HERE, f'reference_code_{name}.npz'), **d)
+        written.append(name)
+        print(f'{name:30s} reference code == oracle.{fn:24s} max|diff| = {err:.1e}   out {tuple(ref_out.shape)}')
+
+    B, F, D = 7, 5, 4
+    # FM (layers.py:53-62)
+    x = rand(B, F, D)
+    case('fm', L.FM()(x), 'fm', {'x': x})
+    # Cross (layers.py:421-436), 3 layers; zeros-initialised biases get seeded values from the shim
+    xc = rand(B, 11)
+    cr = L.Cross(params={'num_cross_layer': 3})
+    case('cross', cr(xc), 'cross', {'x': xc, 'kernels': list(cr.kernels), 'biases': list(cr.bias)})
+    # InnerProduct / OuterProduct (layers.py:473-487, :543-581): list of F x [B,1,D]
+    xs = [rand(B, 1, D) for _ in range(F)]
+    case('inner_product', L.InnerProduct()(xs), 'inner_product', {'xs': xs})
+    for kt in ('mat', 'vec', 'num'):
+        op = L.OuterProduct(params={'outer_product_kernel_type': kt})
+        out = op(xs)
+        case(f'outer_product_{kt}', out, 'outer_product', {'xs': xs, 'kernel': op.kernel}, {'kernel_type': kt})
+    # CIN (layers.py:638-734), reduce_D = False (the oracle restates that branch; BASELINE configs use it)
+    xcin = rand(B, F, D)
+    for tag, params in (('split_bias', dict(cross_layer_size=(6, 4, 3), activation='relu', use_residual=False, use_bias=True,
+                                            direct=False, reduce_D=False)),
+                        ('direct_residual', dict(cross_layer_size=(4, 5), activation='sigmoid', use_residual=True,
+                                                 use_bias=False, direct=True, reduce_D=False)),
+                        ('split_linear', dict(cross_layer_size=(4, 2), activation='linear', use_residual=False, use_bias=False,
+                                              direct=False, reduce_D=False))):
+        cin = L.CIN(params=params)
+        out = cin(xcin)
+        tensors = {'x': xcin, 'filters': list(cin.f_), 'biases': list(cin.bias) if params['use_bias'] else None,
+                   'dense_out': (cin.exFM_out.kernel, cin.exFM_out.bias),
+                   'dense_out0': (cin.exFM_out0.kernel, cin.exFM_out0.bias) if params['use_residual'] else None}
+        case(f'cin_{tag}', out, 'cin', tensors, {'cross_layer_size': list(params['cross_layer_size']),
+                                                 'activation': params['activation'], 'direct': params['direct']})
+    # MultiheadAttention (layers.py:104-153), training-mode BatchNormalization, dropout_rate 0
+    xa = rand(B, F, 8)
+    for heads, res in ((2, True), (4, False)):
+        mha = L.MultiheadAttention(params={'num_heads': heads, 'dropout_rate': 0, 'use_residual': res})
+        out = mha(xa)
+        w = {'Q': (mha.dense_Q.kernel, mha.dense_Q.bias), 'K': (mha.dense_K.kernel, mha.dense_K.bias),
+             'V': (mha.dense_V.kernel, mha.dense_V.bias), 'bn': (mha.batch_normalize.gamma, mha.batch_normalize.beta)}
+        if res:
+            w['R'] = (mha.dense_residual.kernel, mha.dense_residual.bias)
+        # the oracle takes the weights as ONE dict argument: stored as separate tensors, rebuilt by the replay
+        names = sorted(w)
+        case(f'mha_h{heads}_res{int(res)}', out, '_mha_from_parts',
+             {'x': xa, 'parts': [list(w[n]) for n in names]}, {'names': names, 'num_heads': heads, 'use_residual': res})
+    # MultiColumnEmbedding (layers.py:853-904): float ids are cast (truncated) to int32, one table per column
+    dims = [5, 9, 3]
+    mce = L.MultiColumnEmbedding(input_dims=dims, output_dims=[D] * 3)
+    ids = torch.as_tensor(np.stack([rng.randint(0, d, size=B) for d in dims], 1).astype(np.float32) + 0.4, dtype=torch.float32)
+    outs = mce(ids)
+    case('multi_column_embedding', outs, 'multi_column_embedding', {'inputs': ids, 'tables': list(mce.embeddings)}, post='cat1')
+    # AFM (layers.py:742-812)
+    afm = L.AFM(params={'hidden_factor': 3, 'dropout_rate': 0})
+    out = afm(xs)
+    case('afm', out, 'afm', {'xs': xs, 'att_kernel': afm.dense_attention.kernel, 'att_bias': afm.dense_attention.bias,
+                             'projection_h': afm.attention_p, 'out_kernel': afm.dense_out.kernel}, {'activation': 'relu'})
+    # BilinearInteraction (layers.py:311-382) and SENET (:245-308) take the stacked [B,F,D] block
+    x3 = rand(B, F, D)
+    for bt in ('field_all', 'field_each', 'field_interaction'):
+        bi = L.BilinearInteraction(bilinear_type=bt)
+        out = bi(x3)
+        case(f'bilinear_{bt}', out, 'bilinear_interaction', {'x': x3, 'W_list': [bi.W] if bt == 'field_all' else list(bi.W_list)},
+             {'bilinear_type': bt})
+    for pool in ('mean', 'max'):
+        se = L.SENET(pooling_op=pool, reduction_ratio=2)
+        out = se(x3)
+        case(f'senet_{pool}', out, 'senet', {'x': x3, 'att1': (se.dense_att1.kernel, se.dense_att1.bias),
+                                             'att2': (se.dense_att2.kernel, se.dense_att2.bias)}, {'pooling_op': pool})
+    # ---- the net functions of deepnets.py (which layers read which of the four graph tensors, in which order) against
+    #      the oracle's model_nets — the part of DeepModel.__build_model that feeds them (embedding lookup, Flatten /
+    #      Concatenate, BatchNormalization of concat[flatten_emb, dense], deepmodel.py:259-274, 348-361) is formed here
+    #      with the same shim layers, since that method cannot be imported without the reference's whole package
+    N = load_reference_deepnets()
+    Bn, Fn, Dn, Nd = 9, 4, 6, 3
+    dims = [7, 5, 11, 4]
+    mce = L.MultiColumnEmbedding(input_dims=dims, output_dims=[Dn] * Fn)
+    idx = torch.as_tensor(np.stack([rng.randint(0, d, size=Bn) for d in dims], 1).astype(np.float32), dtype=torch.float32)
+    embeddings = mce(idx)                                                        # list of F x [B,1,D]
+    dense = rand(Bn, Nd)
+    flatten_emb = Flatten()(Concatenate(axis=-1)(embeddings))                    # deepmodel.py:269-274
+    bn = BatchNormalization(name='bn_concat_emb_dense')
+    concat_emb_dense = bn(Concatenate()([flatten_emb, dense]))                   # deepmodel.py:348-361
+    config = types.SimpleNamespace(
+        dnn_params={'hidden_units': ((16, 0, False), (8, 0, False)), 'activation': 'relu'},
+        cross_params={'num_cross_layer': 3},
+        cin_params={'cross_layer_size': (6, 4), 'activation': 'relu', 'use_residual': False, 'use_bias': False,
+                    'direct': False, 'reduce_D': False},
+        autoint_params={'num_attention': 2, 'num_heads': 2, 'dropout_rate': 0, 'use_residual': True})
+    desc = types.SimpleNamespace(add_net=lambda *a, **k: None)
+    ocfg = {'cin_params': dict(config.cin_params, cross_layer_size=list(config.cin_params['cross_layer_size'])),
+            'autoint_params': config.autoint_params, 'dnn_activation': 'relu'}
+
+    def by_name(layers, name):
+        return next(l for l in layers if l.name == name)
+
+    def run_net(net):
+        start = len(_REGISTRY)
+        out = getattr(N, net)(embeddings, flatten_emb, dense, concat_emb_dense, config, desc)
+        new = _REGISTRY[start:]
+        names, parts = [], []
+        if net == 'linear':
+            names, parts = ['linear_logit'], [by_name(new, 'linear_logit').kernel]
+        elif net in ('dnn_nets', 'dcn_nets'):
+            pre = 'dnn' if net == 'dnn_nets' else 'dcn'
+            ds = [by_name(new, f'{pre}_dense_{i}') for i in (1, 2)]
+            names, parts = ['dnn' if net == 'dnn_nets' else 'dcn_dnn'], [[[d.kernel, d.bias] for d in ds]]
+            if net == 'dcn_nets':
+                cr_ = by_name(new, 'dcn_cross_layer')
+                names += ['dcn_cross_kernels', 'dcn_cross_bias']
+                parts += [list(cr_.kernels), list(cr_.bias)]
+        elif net == 'cin_nets':
+            c = next(l for l in new if isinstance(l, L.CIN))
+            names, parts = ['cin_filters', 'cin_exFM_out'], [list(c.f_), [c.exFM_out.kernel, c.exFM_out.bias]]
+        elif net == 'autoint_nets':
+            ms = [l for l in new if isinstance(l, L.MultiheadAttention)]
+            names = ['autoint_layers']
+            parts = [[[[m.dense_Q.kernel, m.dense_Q.bias], [m.dense_K.kernel, m.dense_K.bias],
+                       [m.dense_V.kernel, m.dense_V.bias], [m.dense_residual.kernel, m.dense_residual.bias],
+                       [m.batch_normalize.gamma, m.batch_normalize.beta]] for m in ms]]
+        case(f'net_{net}', out, '_nets_from_parts',
+             {'cat_idx': idx, 'dense': dense, 'tables': list(mce.embeddings), 'bn': [bn.gamma, bn.beta], 'parts': parts},
+             {'names': names, 'nets': [net], 'config': ocfg, 'net': net})
+
+    for net in ('linear', 'fm_nets', 'dnn_nets', 'dcn_nets', 'cin_nets', 'autoint_nets'):
+        run_net(net)
+    print(f'{len(written)} fixtures written to tests/golden/reference_code_*.npz')
+
+
+if __name__ == '__main__':
+    main()
