@@ -13,10 +13,13 @@ PARITY STATUS — pinned to the reference's SOURCE, unpinned against TensorFlow'
 golden vectors / known-answer tests for this path (all its assertions are `AUC >= 0` or shapes:
 deeptables/tests/models/nets_test.py:43-44, layers_test.py:28-29) and TensorFlow/Keras (requirements.txt:1
 `tensorflow>=2.4`, CI pins 2.16.2-2.18.0) is not installable in this environment.  What IS checked: the reference's
-own `layers.py` and `deepnets.py`, imported unmodified from /root/reference onto an in-process shim of the ~40
-TF / Keras primitives they call (tests/golden/make_reference_golden.py), produce outputs this oracle reproduces to
-1e-12 for every hot-path layer and net function (24 fixtures, tests/golden/reference_code_*.npz, replayed on every
-CPU run by tests/test_oracle_reference_code.py): op order, axes, splits, transposes and weight shapes are the
+own `layers.py`, `deepnets.py`, `config.py`, `metainfo.py` and `deepmodel.py`, imported unmodified from /root/reference
+onto an in-process shim of the TF / Keras primitives they call (tests/golden/make_reference_golden.py), produce outputs
+this oracle reproduces to 1e-12: every layer / loss class of layers.py, every net function of deepnets.py, and WHOLE
+MODELS built by the reference's DeepModel.__build_model with the reference's ModelConfig defaults — the five BASELINE.json
+configurations (FM, DeepFM, xDeepFM, AutoInt, DCN), every other preset, stacking add / concat, binary / regression /
+multiclass heads, BatchNormalization towers (53 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
+tests/test_oracle_reference_code.py): op order, axes, splits, transposes, weight shapes and the graph wiring are the
 reference's.  What is NOT checked: float32 rounding / reduction order inside a TensorFlow primitive, and the Keras
 defaults listed in KERAS_DEFAULTS below (BatchNormalization epsilon / momentum, initializers, Adam, BCE clipping).
 
@@ -267,15 +270,21 @@ def _mha_from_parts(x, parts, names, num_heads=1, use_residual=True, training=Tr
 # ---------------------------------------------------------------------------------------------
 # deepnets.py net functions + deepmodel.py graph (explicit-weights functional form)
 # ---------------------------------------------------------------------------------------------
-def dnn(x, layers_w, activation='relu'):
-    """deepnets.dnn — deepnets.py:401-427 with (units, dropout=0, batch_norm=False) cells:
-    Dense(bias) -> Activation.  layers_w: list of (kernel, bias)."""
+def dnn(x, layers_w, activation='relu', training=True):
+    """deepnets.dnn — deepnets.py:401-427 with (units, dropout=0, batch_norm) cells:
+    Dense(use_bias = not batch_norm) -> [BatchNormalization] -> Activation.
+    layers_w: list of (kernel, bias) or, for a batch_norm cell, (kernel, None, (gamma, beta[, moving_mean, moving_var]))."""
     act = _activation(activation)
-    for k, b in layers_w:
-        x = x @ k
+    for cell in layers_w:
+        k, b = cell[0], cell[1]
+        x = x @ k                                                      # :414
         if b is not None:
             x = x + b
-        x = act(x)
+        if len(cell) > 2 and cell[2] is not None:                      # :420-421
+            bn = cell[2]
+            x, _, _ = keras_batchnorm(x, bn[0], bn[1], bn[2] if len(bn) > 2 else None,
+                                      bn[3] if len(bn) > 3 else None, training=training)
+        x = act(x)                                                     # :422
     return x
 
 
@@ -295,27 +304,50 @@ def linear_net(embeddings, dense, kernel):
 
 
 def model_forward(weights, cat_idx, dense, nets, config=None, training=True, return_parts=False):
-    """DeepModel.__build_model — deepmodel.py:259-317, binary task, stacking 'add', dropout 0.
+    """DeepModel.__build_model — deepmodel.py:259-317, dropout 0.  config keys read here: 'stacking_op' ('add' |
+    'concat', default 'add'), 'task' ('binary' | 'regression' | 'multiclass' | 'multilabel', default 'binary').
     weights: dict keyed with the Keras layer/weight names (see tests/golden/make_golden.py).
     cat_idx [B,F] float32 (reference input contract), dense [B,Nd] or None.
-    Returns the LOGIT fed to the sigmoid of `task_output` ([B,1]) and the probability."""
+    Returns the pre-activation of `task_output` (the LOGIT, [B,units]) and its activation (sigmoid probability for
+    binary / multilabel, softmax for multiclass, the value itself for regression)."""
+    config = config or {}
     outs, concat_emb_dense = model_nets(weights, cat_idx, dense, nets, config, training)
-    if len(outs) > 1:                                                # :286-297
+    if len(outs) > 1:                                                # :286-301
         logits = []
         for name, out in outs.items():
+            if out.dim() > 2:
+                out = out.reshape(out.shape[0], -1)                  # :289-290 Flatten
             if out.shape[-1] > 1:
-                out = out @ weights[f'dense_logit_{name}']           # Dense(1, no bias)
+                out = out @ weights[f'dense_logit_{name}']           # :291-292 Dense(1, no bias)
             logits.append(out)
-        xs = logits[0]
-        for t in logits[1:]:
-            xs = xs + t                                              # Add()
-    else:
+        stacking = config.get('stacking_op', 'add')
+        if stacking == 'add':                                        # :296-297
+            xs = logits[0]
+            for t in logits[1:]:
+                xs = xs + t
+        elif stacking == 'concat':                                   # :298-299
+            xs = torch.cat(logits, dim=-1)
+        else:
+            raise ValueError(f'Unsupported stacking_op:{stacking}.')
+    elif len(outs) == 1:                                             # :302-307
         xs = next(iter(outs.values()))
-    k, b = weights['task_output']                                    # :455 Dense(1, sigmoid)
+        if xs.dim() > 2:
+            xs = xs.reshape(xs.shape[0], -1)
+    else:
+        raise ValueError(f'Unexpected logit output.{outs}')
+    k, b = weights['task_output']                                    # :436-457 Dense(units, activation)
     logit = xs @ k
     if b is not None:
         logit = logit + b
-    prob = torch.sigmoid(logit)
+    task = config.get('task', 'binary')
+    if task in ('binary', 'multilabel'):
+        prob = torch.sigmoid(logit)
+    elif task == 'multiclass':
+        prob = torch.softmax(logit, dim=-1)
+    elif task == 'regression':
+        prob = logit
+    else:
+        raise ValueError(f'Unknown task type:{task}')
     if return_parts:
         return logit, prob, outs, concat_emb_dense
     return logit, prob
@@ -325,6 +357,7 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
     """the front of DeepModel.__build_model: embeddings, concat + BatchNormalization, and the output of every net
     function of `nets` (deepmodel.py:259-285, deepnets.py) -> (OrderedDict net -> output, concat_emb_dense)"""
     config = config or {}
+    act_name = config.get('dnn_activation', 'relu')
     tables = weights['emb_categorical_vars_all']                     # list of (V_f, D)
     embeddings = multi_column_embedding(cat_idx, tables)             # :264 / :388-404
     flatten_emb = None
@@ -342,13 +375,17 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
         concat_emb_dense, _, _ = keras_batchnorm(x, bn[0], bn[1], bn[2] if len(bn) > 2 else None,
                                                  bn[3] if len(bn) > 3 else None, training=training)
     outs = {}
+    cursor = {'fgcnn': 0, 'afm': 0}          # weights['fgcnn'] / ['afm'] list the layers of ALL nets in creation order
+    if len([n for n in nets if n in ('cin_nets', 'fgcnn_cin_nets')]) > 1 or \
+            len([n for n in nets if n in ('fibi_nets', 'fibi_dnn_nets')]) > 1:
+        raise ValueError('the weights dict holds one CIN and one SENET / Bilinear set')
     for net in nets:                                                 # :281-285
         if net == 'linear':
             outs[net] = linear_net(embeddings, dense, weights['linear_logit'])
         elif net == 'fm_nets':
             outs[net] = fm(torch.cat(embeddings, dim=1))             # deepnets.py:88-94
         elif net == 'dnn_nets':
-            outs[net] = dnn(concat_emb_dense, weights['dnn'], config.get('dnn_activation', 'relu'))
+            outs[net] = dnn(concat_emb_dense, weights['dnn'], act_name, training)
         elif net == 'cin_nets':
             cp = config['cin_params']
             outs[net] = cin(torch.cat(embeddings, dim=1), weights['cin_filters'], weights.get('cin_bias'),
@@ -356,7 +393,7 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
                             dense_out=weights['cin_exFM_out'])       # deepnets.py:75-80
         elif net == 'dcn_nets':                                      # deepnets.py:194-207
             cross_out = cross(concat_emb_dense, weights['dcn_cross_kernels'], weights['dcn_cross_bias'])
-            dnn_out = dnn(concat_emb_dense, weights['dcn_dnn'], config.get('dnn_activation', 'relu'))
+            dnn_out = dnn(concat_emb_dense, weights['dcn_dnn'], act_name, training)
             outs[net] = torch.cat([cross_out, dnn_out], dim=-1)
         elif net == 'autoint_nets':                                  # deepnets.py:210-224
             ap = config['autoint_params']
@@ -365,8 +402,25 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
                 o = multihead_attention(o, lw, ap.get('num_heads', 1), ap.get('use_residual', True),
                                         training=training)
             outs[net] = o.reshape(o.shape[0], -1)
+        elif net == 'cross_nets':                                    # deepnets.py:172-178
+            outs[net] = cross(concat_emb_dense, weights['cross_kernels'], weights['cross_bias'])
+        elif net == 'cross_dnn_nets':                                # deepnets.py:181-191
+            c = cross(concat_emb_dense, weights['cross_dnn_kernels'], weights['cross_dnn_bias'])
+            outs[net] = dnn(c, weights['cross_dnn'], act_name, training)
+        elif net in ('opnn_nets', 'ipnn_nets', 'pnn_nets'):          # deepnets.py:110-160
+            if len(embeddings) < 2:
+                continue                                             # the net function returns None: dropped (:284)
+            kt = config.get('pnn_params', {}).get('outer_product_kernel_type', 'mat')
+            if net == 'opnn_nets':
+                parts = [outer_product(embeddings, weights['opnn_kernel'], kt)]
+            elif net == 'ipnn_nets':
+                parts = [inner_product(embeddings)]
+            else:
+                parts = [inner_product(embeddings), outer_product(embeddings, weights['pnn_kernel'], kt)]
+            outs[net] = dnn(torch.cat(parts + [concat_emb_dense], dim=-1), weights[net[:-5]], act_name, training)
         elif net == 'afm_nets':                                      # deepnets.py:99-107
-            a = weights['afm'][0]
+            a = weights['afm'][cursor['afm']]
+            cursor['afm'] += 1
             outs[net] = afm(embeddings, a['att_kernel'], a['att_bias'], a['projection_h'], a['out_kernel'],
                             a.get('activation', 'relu'))
         elif net in ('fibi_nets', 'fibi_dnn_nets'):                  # deepnets.py:344-386
@@ -383,20 +437,25 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
                 outs[net] = fibi
             else:
                 outs[net] = dnn(torch.cat([fibi.reshape(fibi.shape[0], -1), dense], dim=-1), weights['fibi_dnn'],
-                                config.get('dnn_activation', 'relu'))
-        elif net.startswith('fgcnn_'):                               # deepnets.py:227-341
+                                act_name, training)
+        elif net.startswith('fgcnn_') or net == 'fg_nets':           # deepnets.py:227-341
             gp = config.get('fgcnn_params', {})
             e = torch.cat(embeddings, dim=1)
             fg_inputs = e.unsqueeze(-1)
             new_features = []
-            for lw, pool, nf in zip(weights['fgcnn'], gp.get('fg_pool_heights', (2, 2)),
-                                    gp.get('fg_new_feat_filters', (2, 2))):
+            pools, nfs = gp.get('fg_pool_heights', (2, 2)), gp.get('fg_new_feat_filters', (2, 2))
+            depth = min(len(gp.get('fg_filters', (14, 16))), len(gp.get('fg_heights', (7, 7))), len(pools), len(nfs))
+            mine = weights['fgcnn'][cursor['fgcnn']:cursor['fgcnn'] + depth]     # every fg_nets call builds its own
+            cursor['fgcnn'] += depth                                             # FGCNN layers (deepnets.py:251-258)
+            for lw, pool, nf in zip(mine, pools, nfs):
                 fg_inputs, nfeat = fgcnn(fg_inputs, lw['conv_kernel'], lw['conv_bias'], lw['dense_kernel'],
                                          lw['dense_bias'], pool, nf)
                 new_features.append(nfeat)
             fg_output = torch.cat(new_features + [e], dim=1)
             flat = fg_output.reshape(fg_output.shape[0], -1)
-            if net == 'fgcnn_fm_nets':
+            if net == 'fg_nets':
+                outs[net] = fg_output
+            elif net == 'fgcnn_fm_nets':
                 outs[net] = fm(fg_output)
             elif net == 'fgcnn_cin_nets':
                 cp = config['cin_params']
@@ -404,17 +463,18 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
                                 cp.get('activation', 'relu'), cp.get('direct', False),
                                 dense_out=weights['cin_exFM_out'])
             elif net == 'fgcnn_afm_nets':
-                a = weights['afm'][0]
+                a = weights['afm'][cursor['afm']]
+                cursor['afm'] += 1
                 outs[net] = afm(list(torch.split(fg_output, 1, dim=1)), a['att_kernel'], a['att_bias'],
                                 a['projection_h'], a['out_kernel'], a.get('activation', 'relu'))
             elif net == 'fgcnn_ipnn_nets':
                 parts = [flat, inner_product(list(torch.split(fg_output, 1, dim=1)))]
                 if dense is not None:
                     parts.append(dense)
-                outs[net] = dnn(torch.cat(parts, dim=-1), weights['fgcnn_ipnn'], config.get('dnn_activation', 'relu'))
+                outs[net] = dnn(torch.cat(parts, dim=-1), weights['fgcnn_ipnn'], act_name, training)
             elif net == 'fgcnn_dnn_nets':
                 x_in = torch.cat([flat, dense], dim=-1) if dense is not None else flat
-                outs[net] = dnn(x_in, weights['fgcnn_dnn'], config.get('dnn_activation', 'relu'))
+                outs[net] = dnn(x_in, weights['fgcnn_dnn'], act_name, training)
             else:
                 raise ValueError(net)
         else:
@@ -438,6 +498,26 @@ def _nets_from_parts(cat_idx, dense, tables, bn, names, parts, nets, config, net
             w[n] = p
     outs, _ = model_nets(w, cat_idx, dense, [net], config, training=True)
     return outs[net]
+
+
+def _model_from_parts(cat_idx, dense, weights, nets, config):
+    """model_forward in training mode -> [logit | activation] side by side (tests/golden/make_reference_golden.py stores
+    the reference's `task_output` pre-activation and output the same way).  Lists that stand for (kernel, bias) pairs
+    arrive as lists; the restatement only indexes them."""
+    logit, prob = model_forward(weights, cat_idx, dense, nets, config, training=True)
+    return torch.cat([logit, prob], dim=-1)
+
+
+def _ghmc_from_parts(input, target, acc_sum, bins=10, momentum=0.75):
+    """ghmc_loss -> [loss, updated acc_sum...] as one vector"""
+    loss, acc = ghmc_loss(input, target, acc_sum, bins, momentum)
+    return torch.cat([loss.reshape(1), acc.reshape(-1)])
+
+
+def _fgcnn_from_parts(x, conv_kernel, conv_bias, dense_kernel, dense_bias, pool_height, new_filters, activation='tanh'):
+    """fgcnn -> [pooled | new_features] flattened side by side"""
+    pooled, feats = fgcnn(x, conv_kernel, conv_bias, dense_kernel, dense_bias, pool_height, new_filters, activation)
+    return torch.cat([pooled.reshape(pooled.shape[0], -1), feats.reshape(feats.shape[0], -1)], dim=-1)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,29 +1,33 @@
 # -*- coding:utf-8 -*-
-"""Pins the oracle to the REFERENCE'S OWN LAYER CODE.
+"""Pins the oracle to the REFERENCE'S OWN CODE.
 
-TensorFlow / Keras cannot be installed here, so the reference cannot run as it is.  But its hot-path layers
-(/root/reference/deeptables/models/layers.py) are short compositions of a few dozen primitive tensor ops
-(tf.reduce_sum, tf.split, tf.concat, tf.matmul, tf.tensordot, tf.nn.conv1d, tf.nn.softmax, Dense, ...), and the
-PRIMITIVES have unambiguous published semantics.  This script
+TensorFlow / Keras cannot be installed here, so the reference cannot run as it is.  But its hot path
+(/root/reference/deeptables/models/layers.py, deepnets.py, deepmodel.py) is a composition of a few dozen primitive
+tensor ops and stock Keras layers (tf.reduce_sum, tf.split, tf.concat, tf.matmul, tf.tensordot, tf.nn.conv1d,
+tf.nn.softmax, Dense, BatchNormalization, Conv2D, ...), and the PRIMITIVES have unambiguous published semantics.
+This script
 
   1. installs an in-process shim of exactly those primitives on torch float64 (modules `tensorflow`, `keras`, ... in
      sys.modules; nothing is written anywhere),
-  2. imports the reference's layers.py UNMODIFIED from /root/reference (read-only) on top of the shim,
-  3. runs the reference's own `build` / `call` code of FM, Cross, InnerProduct, OuterProduct (mat / vec / num), CIN
-     (direct / split, with / without residual and bias; reduce_D = False, the branch every BASELINE config takes),
-     MultiheadAttention (training-mode BatchNormalization), MultiColumnEmbedding, AFM, BilinearInteraction (3 types)
-     and SENET (mean / max) on seeded inputs and weights,
+  2. imports the reference's layers.py, deepnets.py, config.py, metainfo.py, utils/consts.py, utils/counter.py and
+     deepmodel.py UNMODIFIED from /root/reference (read-only) on top of the shim,
+  3. runs the reference's own code on seeded inputs and weights: `build` / `call` of every layer and loss class of
+     layers.py; the net functions of deepnets.py; and whole models through DeepModel.__build_model with the reference's
+     ModelConfig defaults (the five BASELINE.json configurations, every preset, stacking / head variants),
   4. checks the oracle (oracle/reference_layers.py) against those outputs to 1e-12, and
   5. writes inputs, weights and the reference code's outputs to tests/golden/reference_code_*.npz.
 
-What this pins: the op ORDER and every shape / axis / split / transpose decision of the reference's layer code — the part a
-restatement can get wrong.  What it cannot pin: TensorFlow's own arithmetic inside a primitive (float32 rounding,
-reduction order), which no restatement controls either.  tests/test_oracle_reference_code.py compares the oracle
-with the committed vectors on every CPU run; this script only runs where /root/reference exists.
+What this pins: the op ORDER and every shape / axis / split / transpose / wiring decision of the reference's code — the
+part a restatement can get wrong.  What it cannot pin: TensorFlow's own arithmetic inside a primitive (float32 rounding,
+reduction order) and the stock Keras layers' defaults (BatchNormalization epsilon, initializers), which the shim states
+the same way the oracle does.  tests/test_oracle_reference_code.py compares the oracle with the committed vectors on
+every CPU run; this script only runs where /root/reference exists.
 
     python tests/golden/make_reference_golden.py          # regenerates the fixtures (deterministic)
 """
+import contextlib
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -124,7 +128,6 @@ def _make_tf():
     tf.multiply = lambda a, b: _t(a) * _t(b)
     tf.square = lambda x: _t(x) * _t(x)
     tf.sigmoid = lambda x: torch.sigmoid(_t(x))
-    tf.identity = lambda x: x
     tf.zeros_like = lambda x: torch.zeros_like(_t(x))
     tf.ones_like = lambda x: torch.ones_like(_t(x))
     tf.shape = lambda x: _t(x).shape
@@ -135,12 +138,25 @@ def _make_tf():
     tf.greater_equal = lambda a, b: _t(a) >= _t(b)
     tf.less = lambda a, b: _t(a) < _t(b)
     tf.logical_and = lambda a, b: a & b
+    tf.abs = lambda x: torch.abs(_t(x))
+    tf.maximum = lambda a, b: torch.clamp(_t(a), min=b) if not isinstance(b, torch.Tensor) else torch.maximum(_t(a), b)
+    tf.cast = lambda x, dtype=None: (x.to(DT) if isinstance(x, torch.Tensor) else torch.as_tensor(float(x), dtype=DT))
+    tf.Variable = lambda v, trainable=True, **kw: torch.as_tensor(v, dtype=DT).clone()
+    tf.identity = lambda x, name=None: x
+    tf.control_dependencies = lambda deps: contextlib.nullcontext()
+
+    def assign(var, value):
+        var.copy_(value)
+        return var
+    tf.compat = types.SimpleNamespace(v1=types.SimpleNamespace(assign=assign))
     nn = types.ModuleType('tensorflow.nn')
     nn.softmax = lambda x, axis=-1: torch.softmax(_t(x), dim=axis)
     nn.relu = lambda x: torch.relu(_t(x))
     nn.conv1d = tf_conv1d
     nn.bias_add = lambda x, b: _t(x) + _t(b)
     nn.sigmoid = lambda x: torch.sigmoid(_t(x))
+    nn.sigmoid_cross_entropy_with_logits = lambda labels=None, logits=None: \
+        torch.nn.functional.binary_cross_entropy_with_logits(_t(logits), _t(labels), reduction='none')
     tf.nn = nn
     return tf
 
@@ -212,6 +228,7 @@ class Dense(Layer):
         y = torch.matmul(x, self.kernel)
         if self.bias is not None:
             y = y + self.bias
+        self.last_preact = y
         return _act(self.activation)(y)
 
 
@@ -278,6 +295,93 @@ class Add(Layer):
         return out
 
 
+def _tf_same_pad(size, k, stride):
+    """TensorFlow 'SAME': out = ceil(size / stride), the odd padding element goes after"""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return total // 2, total - total // 2
+
+
+class Conv2D(Layer):
+    """keras.layers.Conv2D, channels_last [B,H,W,C], kernel [kh,kw,C,filters]; via torch's conv2d (NCHW)"""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', activation=None, use_bias=True,
+                 kernel_initializer=None, **kw):
+        super().__init__(**kw)
+        assert tuple(strides) == (1, 1)
+        self.filters, self.kernel_size, self.padding, self.activation, self.use_bias = \
+            filters, tuple(kernel_size), padding, activation, use_bias
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight('kernel', self.kernel_size + (input_shape[-1], self.filters))
+        self.bias = self.add_weight('bias', (self.filters,)) if self.use_bias else None
+
+    def call(self, x):
+        xt = x.permute(0, 3, 1, 2)
+        if self.padding == 'same':
+            (t, b), (l, r) = _tf_same_pad(xt.shape[2], self.kernel_size[0], 1), _tf_same_pad(xt.shape[3], self.kernel_size[1], 1)
+            xt = torch.nn.functional.pad(xt, (l, r, t, b))
+        y = torch.nn.functional.conv2d(xt, self.kernel.permute(3, 2, 0, 1), self.bias)
+        return _act(self.activation)(y.permute(0, 2, 3, 1))
+
+
+class MaxPooling2D(Layer):
+    """keras.layers.MaxPooling2D, channels_last, strides = pool_size; 'same' padding never wins the max"""
+
+    def __init__(self, pool_size=(2, 2), strides=None, padding='valid', **kw):
+        super().__init__(**kw)
+        self.pool_size, self.padding = tuple(pool_size), padding
+        assert strides is None
+
+    def call(self, x):
+        xt = x.permute(0, 3, 1, 2)
+        if self.padding == 'same':
+            (t, b), (l, r) = (_tf_same_pad(xt.shape[2], self.pool_size[0], self.pool_size[0]),
+                              _tf_same_pad(xt.shape[3], self.pool_size[1], self.pool_size[1]))
+            xt = torch.nn.functional.pad(xt, (l, r, t, b), value=float('-inf'))
+        return torch.nn.functional.max_pool2d(xt, self.pool_size, self.pool_size).permute(0, 2, 3, 1)
+
+
+class Embedding(Layer):
+    def __init__(self, input_dim, output_dim, **kw):
+        super().__init__(name=kw.get('name'))
+        self.input_dim, self.output_dim = input_dim, output_dim
+
+    def build(self, input_shape):
+        self.embeddings = self.add_weight('embeddings', (self.input_dim, self.output_dim))
+
+    def call(self, ids):
+        return self.embeddings[_t(ids).long()]
+
+
+_BOUND = {}             # keras.Input(name=...) -> the concrete seeded tensor bound to that name: the graph runs eagerly
+
+
+def Input(shape=None, name=None, dtype=None, **kw):
+    t = _BOUND[name]
+    assert tuple(t.shape[1:]) == tuple(shape), (name, t.shape, shape)
+    return t
+
+
+class Model:
+    def __init__(self, inputs=None, outputs=None, **kw):
+        self.inputs, self.outputs = inputs, outputs
+
+    def compile(self, *a, **kw):
+        pass
+
+
+class Loss:
+    def __init__(self, reduction=None, name=None):
+        self.reduction, self.name = reduction, name
+
+    def __call__(self, y_true, y_pred):
+        return self.call(y_true, y_pred)
+
+    def get_config(self):
+        return {}
+
+
 class _Unused(Layer):
     def __init__(self, *a, **kw):
         super().__init__()
@@ -306,13 +410,14 @@ def install_shim():
     _install_tensor_accessors()
     tf = _make_tf()
     layers = _stub_module('keras.api.layers', Layer=Layer, Dense=Dense, Dropout=Dropout, BatchNormalization=BatchNormalization,
-                          Activation=Activation, Concatenate=Concatenate, Flatten=Flatten, Input=_Unused, Embedding=_Unused,
-                          Lambda=_Unused, Add=Add, Conv2D=_Unused, MaxPooling2D=_Unused, SpatialDropout1D=SpatialDropout1D)
+                          Activation=Activation, Concatenate=Concatenate, Flatten=Flatten, Input=Input, Embedding=Embedding,
+                          Lambda=_Unused, Add=Add, Conv2D=Conv2D, MaxPooling2D=MaxPooling2D, SpatialDropout1D=SpatialDropout1D)
     kops = _stub_module('keras.ops', ndim=lambda x: (_t(x)).dim(), sum=tf_reduce_sum,
                         cast=lambda x, dtype: _t(x).to({'int32': torch.int32, 'int64': torch.int64,
                                                        'float32': DT}.get(dtype, dtype)),
                         log=lambda x: torch.log(_t(x)), clip=lambda x, a, b: torch.clamp(_t(x), a, b),
-                        power=lambda x, p: torch.pow(_t(x), p), not_equal=lambda a, b: _t(a) != b)
+                        power=lambda x, p: torch.pow(_t(x), p), not_equal=lambda a, b: _t(a) != b,
+                        mean=tf_reduce_mean, expand_dims=lambda x, axis: _t(x).unsqueeze(axis), split=tf_split)
     backend = _stub_module('keras.backend', epsilon=lambda: 1e-7, floatx=lambda: 'float32')
 
     class _Getter(types.ModuleType):
@@ -321,9 +426,12 @@ def install_shim():
 
         def serialize(self, x):
             return x
-    losses = _stub_module('keras.losses', Loss=object)
+    losses = _stub_module('keras.losses', Loss=Loss, BinaryCrossentropy=_Any, MeanSquaredError=_Any,
+                          CategoricalCrossentropy=_Any)
+    kmodels = _stub_module('keras.api.models', Model=Model, load_model=_Any(), save_model=_Any())
     keras = _stub_module('keras', ops=kops, backend=backend, layers=layers, initializers=_Getter('keras.initializers'),
-                         regularizers=_Getter('keras.regularizers'), constraints=_Getter('keras.constraints'), losses=losses)
+                         regularizers=_Getter('keras.regularizers'), constraints=_Getter('keras.constraints'), losses=losses,
+                         optimizers=_Any())
     tf.keras = _stub_module('tensorflow.keras', layers=layers)
     ctx = _stub_module('tensorflow.python.eager.context', executing_eagerly=lambda: False, context=lambda: _Any())
     emb_ops = _stub_module('tensorflow.python.ops.embedding_ops',
@@ -339,7 +447,8 @@ def install_shim():
         'tensorflow.python.keras.utils': _stub_module('tensorflow.python.keras.utils', tf_utils=_Any()),
         'tensorflow.python.ops': _stub_module('tensorflow.python.ops', embedding_ops=emb_ops, math_ops=_Any()),
         'tensorflow.python.ops.embedding_ops': emb_ops,
-        'keras': keras, 'keras.ops': kops, 'keras.backend': backend, 'keras.api': _stub_module('keras.api', layers=layers),
+        'keras': keras, 'keras.ops': kops, 'keras.backend': backend,
+        'keras.api': _stub_module('keras.api', layers=layers, models=kmodels), 'keras.api.models': kmodels,
         'keras.api.layers': layers, 'keras.api.metrics': _stub_module('keras.api.metrics', RootMeanSquaredError=_Any),
         'keras.initializers': keras.initializers, 'keras.regularizers': keras.regularizers,
         'keras.constraints': keras.constraints, 'keras.losses': losses,
@@ -349,37 +458,59 @@ def install_shim():
     sys.modules.update(mods)
 
 
+def _load_file(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_reference_layers():
     """the reference's layers.py, unmodified, as module `deeptables.models.layers` (its package __init__ files pull in
-    hypernets / pandas pipelines and are not executed)"""
+    hypernets / pandas pipelines and are not executed; utils/consts.py and utils/counter.py are the reference's files,
+    consts on a stub of the five TASK_* names it star-imports from hypernets.utils.const)"""
     logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, warn=lambda *a, **k: None,
-                                   debug=lambda *a, **k: None, error=lambda *a, **k: None)
+                                   debug=lambda *a, **k: None, error=lambda *a, **k: None, is_info_enabled=lambda: False)
+    hconst = _stub_module('hypernets.utils.const', TASK_AUTO='auto', TASK_BINARY='binary', TASK_MULTICLASS='multiclass',
+                          TASK_REGRESSION='regression', TASK_MULTILABEL='multilabel')
+    sys.modules.update({'hypernets': _stub_module('hypernets'), 'hypernets.utils': _stub_module('hypernets.utils', const=hconst),
+                        'hypernets.utils.const': hconst,
+                        'hypernets.tabular': _stub_module('hypernets.tabular', get_tool_box=_Any())})
     utils = _stub_module('deeptables.utils', dt_logging=types.SimpleNamespace(get_logger=lambda n: logger),
-                         consts=_Any(), gpu=_Any())
+                         gpu=_Any(), to_dataset=_Any())
     utils.__path__ = []
     pkg = _stub_module('deeptables')
     pkg.__path__ = []
     models = _stub_module('deeptables.models')
     models.__path__ = []
     sys.modules.update({'deeptables': pkg, 'deeptables.utils': utils, 'deeptables.models': models})
-    spec = importlib.util.spec_from_file_location('deeptables.models.layers', os.path.join(REF, 'deeptables/models/layers.py'))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules['deeptables.models.layers'] = mod
-    spec.loader.exec_module(mod)
-    return mod
+    utils.consts = _load_file('deeptables.utils.consts', 'deeptables/utils/consts.py')
+    utils.counter = _load_file('deeptables.utils.counter', 'deeptables/utils/counter.py')
+    return _load_file('deeptables.models.layers', 'deeptables/models/layers.py')
 
 
 def load_reference_deepnets():
     """the reference's deepnets.py (net functions: which layers on which of the four input tensors), unmodified"""
     sys.modules['tensorflow.python.keras.utils.generic_utils'] = _stub_module(
-        'tensorflow.python.keras.utils.generic_utils', deserialize_keras_object=_Any(), serialize_keras_object=_Any())
-    sys.modules['deeptables.utils'].counter = _Any()
-    spec = importlib.util.spec_from_file_location('deeptables.models.deepnets', os.path.join(REF, 'deeptables/models/deepnets.py'))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules['deeptables.models.deepnets'] = mod
+        'tensorflow.python.keras.utils.generic_utils', serialize_keras_object=_Any(),
+        deserialize_keras_object=lambda name, module_objects=None, custom_objects=None, printable_module_name=None:
+        module_objects[name])
     sys.modules['deeptables.models'].layers = sys.modules['deeptables.models.layers']
-    spec.loader.exec_module(mod)
+    mod = _load_file('deeptables.models.deepnets', 'deeptables/models/deepnets.py')
+    sys.modules['deeptables.models'].deepnets = mod
     return mod
+
+
+def load_reference_deepmodel():
+    """the reference's metainfo.py, config.py and deepmodel.py, unmodified: ModelConfig (its defaults), the column
+    descriptors and DeepModel, whose private __build_model (deepmodel.py:259-317) wires inputs -> embeddings -> concat ->
+    BatchNormalization -> net functions -> stacking -> task_output.  keras.Input returns the tensor bound to its name
+    (_BOUND), so building the graph evaluates it."""
+    metainfo = _load_file('deeptables.models.metainfo', 'deeptables/models/metainfo.py')
+    config = _load_file('deeptables.models.config', 'deeptables/models/config.py')
+    deepmodel = _load_file('deeptables.models.deepmodel', 'deeptables/models/deepmodel.py')
+    return metainfo, config, deepmodel
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -388,9 +519,13 @@ def load_reference_deepnets():
 #    that plus the reference code's output, so tests/test_oracle_reference_code.py can replay it without /root/reference.
 # ---------------------------------------------------------------------------------------------------------------
 def pack(prefix, v, out):
-    """nested lists / tuples of tensors -> flat {key: ndarray}; None -> marker"""
+    """nested dicts / lists / tuples of tensors -> flat {key: ndarray}; None -> marker"""
     if v is None:
         out[prefix + '@none'] = np.zeros(0)
+    elif isinstance(v, dict):
+        out[prefix + '@keys'] = np.array(json.dumps(list(v)))
+        for k, e in v.items():
+            pack(f'{prefix}/{k}', e, out)
     elif isinstance(v, (list, tuple)):
         out[prefix + '@len'] = np.array(len(v))
         for k, e in enumerate(v):
@@ -401,7 +536,6 @@ def pack(prefix, v, out):
 
 def main():
     global _RNG
-    import json
     sys.path.insert(0, ROOT)
     install_shim()
     L = load_reference_layers()
@@ -553,6 +687,171 @@ def main():
 
     for net in ('linear', 'fm_nets', 'dnn_nets', 'dcn_nets', 'cin_nets', 'autoint_nets'):
         run_net(net)
+    # ---- the remaining layer types of layers.py: FGCNN (:161-242), VarLenColumnEmbedding (:925-980), the losses (:983-1163)
+    x4 = rand(B, 6, D, 1)
+    fg = L.FGCNN(filters=3, kernel_height=4, new_filters=2, pool_height=2)
+    pooled, feats = fg(x4)
+    case('fgcnn', torch.cat([pooled.reshape(B, -1), feats.reshape(B, -1)], -1), '_fgcnn_from_parts',
+         {'x': x4, 'conv_kernel': fg.conv2d.kernel, 'conv_bias': fg.conv2d.bias, 'dense_kernel': fg.dense_output.kernel,
+          'dense_bias': fg.dense_output.bias}, {'pool_height': 2, 'new_filters': 2})
+    fg2 = L.FGCNN(filters=2, kernel_height=7, new_filters=1, pool_height=3, activation='relu')   # taller than the 5 fields
+    x5 = rand(B, 5, D, 2)
+    pooled, feats = fg2(x5)
+    case('fgcnn_tall_kernel', torch.cat([pooled.reshape(B, -1), feats.reshape(B, -1)], -1), '_fgcnn_from_parts',
+         {'x': x5, 'conv_kernel': fg2.conv2d.kernel, 'conv_bias': fg2.conv2d.bias, 'dense_kernel': fg2.dense_output.kernel,
+          'dense_bias': fg2.dense_output.bias}, {'pool_height': 3, 'new_filters': 1, 'activation': 'relu'})
+    vl = L.VarLenColumnEmbedding(emb_vocab_size=11, emb_output_dim=3, embeddings_initializer='uniform',
+                                 embeddings_regularizer=None, activity_regularizer=None, dropout_rate=0.)
+    vids = torch.as_tensor(rng.randint(0, 11, size=(B, 4)).astype(np.float32))
+    case('var_len_column_embedding', vl(vids), 'var_len_embedding', {'inputs': vids, 'table': vl.emb_layer.embeddings})
+    y01 = torch.as_tensor((rng.rand(B, 1) < 0.4).astype(np.float64))
+    pr = torch.as_tensor(rng.uniform(0.02, 0.98, size=(B, 1)))
+    pr[0, 0], pr[1, 0] = 0.0, 1.0                                                  # the clip to [eps, 1 - eps]
+    case('binary_focal_loss', L.BinaryFocalLoss(gamma=1.5, alpha=0.3).call(y01, pr.clone()), 'binary_focal_loss',
+         {'y_true': y01, 'y_pred': pr}, {'gamma': 1.5, 'alpha': 0.3})
+    yc = torch.as_tensor(np.eye(3)[rng.randint(0, 3, size=B)])
+    pc = torch.as_tensor(rng.uniform(0.05, 1.0, size=(B, 3)))                      # not normalised: the loss rescales
+    case('categorical_focal_loss', L.CategoricalFocalLoss().call(yc, pc.clone()), 'categorical_focal_loss',
+         {'y_true': yc, 'y_pred': pc})
+    gh = L.GHMCLoss(bins=6, momentum=0.6)
+    zin, tgt = rand(B, 2) * 2, torch.as_tensor((rng.rand(B, 2) < 0.5).astype(np.float64))
+    acc0 = gh.acc_sum.clone()
+    loss1 = gh.calc(zin, tgt)
+    case('ghmc_loss_step1', torch.cat([loss1.reshape(1), gh.acc_sum.reshape(-1)]), '_ghmc_from_parts',
+         {'input': zin, 'target': tgt, 'acc_sum': acc0}, {'bins': 6, 'momentum': 0.6})
+    acc1, zin2 = gh.acc_sum.clone(), rand(B, 2)
+    loss2 = gh.calc(zin2, tgt)                                                    # second call: the moving bin counts
+    case('ghmc_loss_step2', torch.cat([loss2.reshape(1), gh.acc_sum.reshape(-1)]), '_ghmc_from_parts',
+         {'input': zin2, 'target': tgt, 'acc_sum': acc1}, {'bins': 6, 'momentum': 0.6})
+    gh0 = L.GHMCLoss(bins=5, momentum=0)
+    loss0 = gh0.calc(zin, tgt)
+    case('ghmc_loss_no_momentum', torch.cat([loss0.reshape(1), torch.zeros(5, dtype=DT)]), '_ghmc_from_parts',
+         {'input': zin, 'target': tgt, 'acc_sum': torch.zeros(5, dtype=DT)}, {'bins': 5, 'momentum': 0})
+
+    # ---- whole models: the reference's DeepModel.__build_model (deepmodel.py:259-317), ModelConfig defaults (config.py) and
+    #      column descriptors (metainfo.py), all unmodified.  `nets` is handed to __build_model in list order (ModelConfig
+    #      passes it through set(), whose order changes from process to process; the order only matters for 'concat').
+    M, C, DM = load_reference_deepmodel()
+
+    def reference_weights(layers):
+        by = {l.name: l for l in layers if getattr(l, 'name', None)}
+        w = {}
+        mce_ = next((l for l in layers if isinstance(l, L.MultiColumnEmbedding)), None)
+        w['emb_categorical_vars_all'] = list(mce_.embeddings) if mce_ is not None else []
+        if 'bn_concat_emb_dense' in by:
+            w['bn_concat_emb_dense'] = [by['bn_concat_emb_dense'].gamma, by['bn_concat_emb_dense'].beta]
+        if 'linear_logit' in by:
+            w['linear_logit'] = by['linear_logit'].kernel
+
+        def cells(prefix):
+            out, i = [], 1
+            while f'{prefix}_dense_{i}' in by:
+                d_, bn_ = by[f'{prefix}_dense_{i}'], by.get(f'{prefix}_bn_{i}')
+                out.append([d_.kernel, d_.bias] if bn_ is None else [d_.kernel, None, [bn_.gamma, bn_.beta]])
+                i += 1
+            return out
+        for prefix, key in (('dnn', 'dnn'), ('dcn', 'dcn_dnn'), ('opnn', 'opnn'), ('ipnn', 'ipnn'), ('pnn', 'pnn'),
+                            ('cross_dnn', 'cross_dnn'), ('fibi_dnn', 'fibi_dnn'), ('fgcnn_dnn', 'fgcnn_dnn'),
+                            ('fgcnn_ipnn', 'fgcnn_ipnn')):
+            if f'{prefix}_dense_1' in by:
+                w[key] = cells(prefix)
+        for l in layers:
+            n = getattr(l, 'name', None) or ''
+            if n.startswith('dense_logit_'):
+                w[n] = l.kernel
+            if isinstance(l, L.CIN):
+                w['cin_filters'], w['cin_exFM_out'] = list(l.f_), [l.exFM_out.kernel, l.exFM_out.bias]
+                if l.use_bias:
+                    w['cin_bias'] = list(l.bias)
+            elif isinstance(l, L.Cross):
+                key = {'dcn_cross_layer': 'dcn_cross', 'cross_layer': 'cross', 'cross_dnn_layer': 'cross_dnn'}[n]
+                w[key + '_kernels'], w[key + '_bias'] = list(l.kernels), list(l.bias)
+            elif isinstance(l, L.OuterProduct):
+                w[{'outer_product_layer': 'opnn_kernel', 'pnn_outer_product_layer': 'pnn_kernel'}[n]] = l.kernel
+            elif isinstance(l, L.AFM):
+                w.setdefault('afm', []).append({'att_kernel': l.dense_attention.kernel, 'att_bias': l.dense_attention.bias,
+                                                'projection_h': l.attention_p, 'out_kernel': l.dense_out.kernel})
+            elif isinstance(l, L.SENET):
+                w.setdefault('senet', []).append({'att1': [l.dense_att1.kernel, l.dense_att1.bias],
+                                                  'att2': [l.dense_att2.kernel, l.dense_att2.bias]})
+            elif isinstance(l, L.BilinearInteraction):
+                Ws = [l.W] if l.bilinear_type == 'field_all' else list(l.W_list)
+                w.setdefault('bilinear', {})['senet' if n.startswith('senet_bilinear') else 'embedding'] = torch.stack(Ws)
+            elif isinstance(l, L.FGCNN):
+                w.setdefault('fgcnn', []).append({'conv_kernel': l.conv2d.kernel, 'conv_bias': l.conv2d.bias,
+                                                  'dense_kernel': l.dense_output.kernel, 'dense_bias': l.dense_output.bias})
+            elif isinstance(l, L.MultiheadAttention):
+                lw = {'Q': [l.dense_Q.kernel, l.dense_Q.bias], 'K': [l.dense_K.kernel, l.dense_K.bias],
+                      'V': [l.dense_V.kernel, l.dense_V.bias], 'bn': [l.batch_normalize.gamma, l.batch_normalize.beta]}
+                if l.use_residual:
+                    lw['R'] = [l.dense_residual.kernel, l.dense_residual.bias]
+                w.setdefault('autoint_layers', []).append(lw)
+        to = by['task_output']
+        w['task_output'] = [to.kernel, to.bias]
+        return w
+
+    def run_model(tag, nets, task='binary', num_classes=2, vocab=(7, 5, 11, 4, 6), emb_dim=4, n_dense=3, batch=8, **conf):
+        conf.setdefault('embedding_dropout', 0)                 # config.py:84 default 0.3: dropout is outside a value pin
+        config = C.ModelConfig(nets=nets, embeddings_output_dim=emb_dim, **conf)
+        assert sorted(config.nets) == sorted(nets)
+        cats = [M.CategoricalColumn(f'C{i}', v, emb_dim) for i, v in enumerate(vocab)]
+        conts = [M.ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(n_dense)], input_dim=n_dense)] \
+            if n_dense else []
+        ids = torch.as_tensor(np.stack([rng.randint(0, v, size=batch) for v in vocab], 1).astype(np.float32))
+        dn = rand(batch, n_dense) if n_dense else None
+        _BOUND.clear()
+        _BOUND['input_categorical_vars_all'] = ids
+        if n_dense:
+            _BOUND['input_continuous_all'] = dn
+        start = len(_REGISTRY)
+        dm = DM.DeepModel(task, num_classes, config, cats, conts)
+        model = dm._DeepModel__build_model(task=task, num_classes=num_classes, nets=list(nets), categorical_columns=cats,
+                                           continuous_columns=conts, var_len_categorical_columns=None, config=config)
+        layers_ = _REGISTRY[start:]
+        head = next(l for l in layers_ if l.name == 'task_output')
+        ocfg = {'cin_params': dict(config.cin_params, cross_layer_size=list(config.cin_params['cross_layer_size'])),
+                'autoint_params': config.autoint_params, 'fibinet_params': config.fibinet_params,
+                'fgcnn_params': {k: list(v) for k, v in config.fgcnn_params.items()}, 'pnn_params': config.pnn_params,
+                'dnn_activation': config.dnn_params.get('activation', 'relu'), 'stacking_op': config.stacking_op,
+                'task': task}
+        case(f'model_{tag}', torch.cat([head.last_preact, model.outputs], -1), '_model_from_parts',
+             {'cat_idx': ids, 'dense': dn, 'weights': reference_weights(layers_)}, {'nets': list(nets), 'config': ocfg})
+
+    small = {'hidden_units': ((12, 0, False), (6, 0, False)), 'activation': 'relu'}
+    # the five BASELINE.json configurations, at fixture size
+    run_model('fm', ['linear', 'fm_nets'])                                                         # configs[0]
+    run_model('deepfm', N.DeepFM)                                                                  # configs[1], default 128-64 tower
+    run_model('xdeepfm', N.xDeepFM, dnn_params=small,
+              cin_params={'cross_layer_size': (8, 8, 8), 'activation': 'relu', 'use_residual': False, 'use_bias': False,
+                          'direct': False, 'reduce_D': False})                                     # configs[2]
+    run_model('autoint', N.AutoInt, emb_dim=8,
+              autoint_params={'num_attention': 3, 'num_heads': 4, 'dropout_rate': 0, 'use_residual': True})   # configs[3]
+    run_model('dcn', N.DCN, dnn_params=small, cross_params={'num_cross_layer': 6})                 # configs[4]
+    # the other presets of deepnets.py:14-23 and every remaining net function
+    run_model('widedeep', N.WideDeep, dnn_params=small)
+    run_model('pnn', N.PNN, dnn_params=small)
+    run_model('afm', N.AFM)
+    run_model('fibinet', N.FiBiNet, dnn_params=small)
+    run_model('fgcnn', N.FGCNN, dnn_params=small)
+    run_model('opnn_ipnn_vec', ['opnn_nets', 'ipnn_nets'], dnn_params=small, pnn_params={'outer_product_kernel_type': 'vec'})
+    run_model('cross_and_cross_dnn', ['cross_nets', 'cross_dnn_nets'], dnn_params=small, cross_params={'num_cross_layer': 2})
+    run_model('fibi_nets_flattened', ['fibi_nets', 'linear'],
+              fibinet_params={'senet_pooling_op': 'max', 'senet_reduction_ratio': 2, 'bilinear_type': 'field_each'})
+    run_model('fibi_nets_alone', ['fibi_nets'],
+              fibinet_params={'senet_pooling_op': 'mean', 'senet_reduction_ratio': 3, 'bilinear_type': 'field_all'})
+    run_model('fgcnn_cin_fm', ['fgcnn_cin_nets', 'fgcnn_fm_nets'],                     # two fg_nets calls: two FGCNN stacks
+              cin_params={'cross_layer_size': (6, 4), 'activation': 'relu', 'use_residual': False, 'use_bias': False,
+                          'direct': False, 'reduce_D': False},
+              fgcnn_params={'fg_filters': (3, 2), 'fg_heights': (3, 2), 'fg_pool_heights': (2, 2), 'fg_new_feat_filters': (2, 1)})
+    run_model('fgcnn_afm_ipnn', ['fgcnn_afm_nets', 'fgcnn_ipnn_nets'], dnn_params=small,
+              fgcnn_params={'fg_filters': (2,), 'fg_heights': (3,), 'fg_pool_heights': (2,), 'fg_new_feat_filters': (2,)})
+    # the rest of __build_model / __output_layer: stacking 'concat', no output bias, regression and multiclass heads,
+    # a tower with BatchNormalization cells (Dense without bias -> BN -> activation), no continuous inputs
+    run_model('deepfm_concat_nobias', N.DeepFM, dnn_params=small, stacking_op='concat', output_use_bias=False)
+    run_model('deepfm_regression', N.DeepFM, task='regression', num_classes=None, dnn_params=small)
+    run_model('dnn_multiclass', ['dnn_nets'], task='multiclass', num_classes=3, dnn_params=small)
+    run_model('deepfm_bn_tower', N.DeepFM, dnn_params={'hidden_units': ((12, 0, True), (6, 0, True)), 'activation': 'tanh'})
+    run_model('deepfm_no_dense', N.DeepFM, n_dense=0, dnn_params=small)
     print(f'{len(written)} fixtures written to tests/golden/reference_code_*.npz')
 
 

@@ -2,10 +2,11 @@
 """CPU: the oracle against outputs of the REFERENCE'S OWN LAYER CODE.
 
 tests/golden/reference_code_*.npz were produced by tests/golden/make_reference_golden.py, which imports the reference's
-layers.py unmodified (from /root/reference, in the build container) on an in-process shim of the ~40 TensorFlow / Keras
-primitives it calls, runs `build` / `call` of each hot-path layer on seeded inputs and weights, and stores inputs,
-weights and outputs.  Here every fixture is replayed through oracle/reference_layers.py: the restatement must reproduce
-the reference code's output to 1e-12 (float64).  This pins the oracle's op order, axes, splits and transposes to the
+layers.py, deepnets.py, config.py, metainfo.py and deepmodel.py unmodified (from /root/reference, in the build container)
+on an in-process shim of the TensorFlow / Keras primitives they call, runs `build` / `call` of every layer class, every
+net function and DeepModel.__build_model (whole models: the five BASELINE.json configurations, every preset, the
+stacking / head variants) on seeded inputs and weights, and stores inputs, weights and outputs.  Here every fixture is
+replayed through oracle/reference_layers.py: the restatement must reproduce the reference code's output to 1e-12 (float64).  This pins the oracle's op order, axes, splits and transposes to the
 reference source; TensorFlow's float32 arithmetic inside a primitive is outside what any restatement controls."""
 import glob
 import json
@@ -22,6 +23,8 @@ FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, 'reference_code_*.npz')))
 def _unpack(prefix, d):
     if prefix + '@none' in d:
         return None
+    if prefix + '@keys' in d:
+        return {k: _unpack(f'{prefix}/{k}', d) for k in json.loads(str(d[prefix + '@keys']))}
     if prefix + '@len' in d:
         return [_unpack(f'{prefix}#{k}', d) for k in range(int(d[prefix + '@len']))]
     a = d[prefix]
@@ -34,7 +37,33 @@ def test_fixture_set_is_complete():
             'cin_split_bias', 'cin_direct_residual', 'cin_split_linear', 'mha_h2_res1', 'mha_h4_res0',
             'multi_column_embedding', 'afm', 'bilinear_field_all', 'bilinear_field_each', 'bilinear_field_interaction',
             'senet_mean', 'senet_max', 'net_linear', 'net_fm_nets', 'net_dnn_nets', 'net_dcn_nets', 'net_cin_nets',
-            'net_autoint_nets'} <= names
+            'net_autoint_nets',
+            # the other layer types of layers.py
+            'fgcnn', 'fgcnn_tall_kernel', 'var_len_column_embedding', 'binary_focal_loss', 'categorical_focal_loss',
+            'ghmc_loss_step1', 'ghmc_loss_step2', 'ghmc_loss_no_momentum',
+            # whole models through the reference's DeepModel.__build_model: the five BASELINE.json configurations ...
+            'model_fm', 'model_deepfm', 'model_xdeepfm', 'model_autoint', 'model_dcn',
+            # ... the other presets and net functions, and the stacking / head variants
+            'model_widedeep', 'model_pnn', 'model_afm', 'model_fibinet', 'model_fgcnn', 'model_opnn_ipnn_vec',
+            'model_cross_and_cross_dnn', 'model_fibi_nets_flattened', 'model_fibi_nets_alone', 'model_fgcnn_cin_fm',
+            'model_fgcnn_afm_ipnn', 'model_deepfm_concat_nobias', 'model_deepfm_regression', 'model_dnn_multiclass',
+            'model_deepfm_bn_tower', 'model_deepfm_no_dense'} <= names
+
+
+def test_every_reference_layer_class_and_net_function_has_a_fixture():
+    """layers.py defines 15 layer / loss classes, deepnets.py 21 net functions: each is executed by at least
+    one fixture (a net function either directly, net_*, or inside a whole model, model_*)"""
+    metas = [json.loads(str(np.load(f)['meta'])) for f in FIXTURES]
+    nets = set()
+    for m in metas:
+        nets.update(m['static'].get('nets', []))
+    assert nets >= {'linear', 'cin_nets', 'fm_nets', 'afm_nets', 'opnn_nets', 'ipnn_nets', 'pnn_nets', 'dnn_nets',
+                    'cross_nets', 'cross_dnn_nets', 'dcn_nets', 'autoint_nets', 'fgcnn_cin_nets', 'fgcnn_fm_nets',
+                    'fgcnn_afm_nets', 'fgcnn_ipnn_nets', 'fgcnn_dnn_nets', 'fibi_nets', 'fibi_dnn_nets'}
+    fns = {m['fn'] for m in metas}
+    assert fns >= {'fm', 'cross', 'inner_product', 'outer_product', 'cin', '_mha_from_parts', 'multi_column_embedding', 'afm',
+                   'bilinear_interaction', 'senet', '_fgcnn_from_parts', 'var_len_embedding', 'binary_focal_loss',
+                   'categorical_focal_loss', '_ghmc_from_parts', '_model_from_parts'}
 
 
 @pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(f)[len('reference_code_'):-4] for f in FIXTURES])
@@ -68,7 +97,7 @@ def test_generator_still_agrees_with_the_reference_tree(tmp_path, monkeypatch):
     finally:
         import sys
         for k in list(sys.modules):
-            if k not in saved and (k.startswith('tensorflow') or k.startswith('keras') or k.startswith('deeptables.')
+            if k not in saved and (k.startswith('tensorflow') or k.startswith('keras') or k.startswith('hypernets') or k.startswith('deeptables.')
                                    or k == 'deeptables'):
                 del sys.modules[k]
     for f in FIXTURES:
