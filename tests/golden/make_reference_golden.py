@@ -813,7 +813,11 @@ def main():
                 'autoint_params': config.autoint_params, 'fibinet_params': config.fibinet_params,
                 'fgcnn_params': {k: list(v) for k, v in config.fgcnn_params.items()}, 'pnn_params': config.pnn_params,
                 'dnn_activation': config.dnn_params.get('activation', 'relu'), 'stacking_op': config.stacking_op,
-                'task': task}
+                'task': task,
+                # not read by the oracle: what a caller needs to build the same model through the ModelConfig API
+                'build': {'num_classes': num_classes, 'embeddings_output_dim': emb_dim, 'output_use_bias': config.output_use_bias,
+                          'dnn_params': dict(config.dnn_params, hidden_units=[list(h) for h in config.dnn_params['hidden_units']]),
+                          'cross_params': config.cross_params, 'afm_params': config.afm_params}}
         case(f'model_{tag}', torch.cat([head.last_preact, model.outputs], -1), '_model_from_parts',
              {'cat_idx': ids, 'dense': dn, 'weights': reference_weights(layers_)}, {'nets': list(nets), 'config': ocfg})
 

@@ -81,6 +81,51 @@ def test_oracle_reproduces_the_reference_layer_code(path):
     assert err <= 1e-12 * max(1.0, want.abs().max().item()), (meta['fn'], err)
 
 
+MODEL_FIXTURES = [f for f in FIXTURES if os.path.basename(f).startswith('reference_code_model_')]
+
+
+def load_model_fixture(path):
+    d = dict(np.load(path, allow_pickle=False))
+    meta = json.loads(str(d['meta']))
+    return meta, {k: _unpack('arg:' + k, d) for k in meta['args']}, torch.as_tensor(d['out'])
+
+
+def _count(v):
+    if v is None:
+        return 0
+    if isinstance(v, dict):
+        return sum(_count(e) for e in v.values())
+    if isinstance(v, (list, tuple)):
+        return sum(_count(e) for e in v)
+    return v.numel()
+
+
+@pytest.mark.parametrize('path', MODEL_FIXTURES, ids=[os.path.basename(f)[len('reference_code_model_'):-4] for f in MODEL_FIXTURES])
+def test_drop_in_model_has_the_reference_models_parameters(path):
+    """The graph deeptables_amd builds for the same ModelConfig holds exactly the reference model's weights: same Keras
+    layer names, same shapes, same count (the fixture's weights are those of the graph the reference's own
+    DeepModel.__build_model created).  Weights in (float32), weights out, oracle on them == the reference code's output.
+    Builds on CPU; nothing is computed by the product here (its forward needs the HIP library — the GPU twin of this
+    test is tests/test_reference_models_gpu.py)."""
+    from oracle import bridge
+    meta, tensors, want = load_model_fixture(path)
+    dm, ids, dense = bridge.model_from_reference_fixture(meta['static'], tensors, 'cpu')
+    assert list(dm.config.nets) == meta['static']['nets']
+    n_model = sum(p.numel() for p in dm.model.parameters())
+    weights = dict(tensors['weights'])
+    readers = {'dnn_nets', 'dcn_nets', 'cross_nets', 'cross_dnn_nets', 'opnn_nets', 'ipnn_nets', 'pnn_nets'}
+    if 'bn_concat_emb_dense' not in dm.model.layers_by_name:
+        # deepmodel.py:359 always CALLS this BatchNormalization; keras.Model keeps only layers on a path to the output,
+        # so a model none of whose nets reads concat_emb_dense has no such weights (the eager shim created them anyway)
+        assert not readers & set(meta['static']['nets'])
+        weights.pop('bn_concat_emb_dense')
+    assert n_model == _count(weights), 'the two graphs differ in their trainable weights'
+    logit, act = bridge.oracle_forward(dm, ids, dense, training=True)
+    got = torch.cat([logit, act], -1)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())     # float32 storage of the weights
+
+
 @pytest.mark.skipif(not os.path.exists('/root/reference/deeptables/models/layers.py'),
                     reason='the reference tree exists only in the build container')
 def test_generator_still_agrees_with_the_reference_tree(tmp_path, monkeypatch):

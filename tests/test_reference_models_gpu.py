@@ -1,0 +1,48 @@
+# -*- coding:utf-8 -*-
+"""GPU: the HIP path against outputs of the REFERENCE'S OWN CODE for whole models.
+
+tests/golden/reference_code_model_*.npz hold, for 21 model configurations (the five of BASELINE.json, every preset of
+deepnets.py, every net function, stacking add / concat, binary / regression / multiclass heads, a BatchNormalization
+tower, no continuous inputs), the inputs, the weights and the output of the reference's DeepModel.__build_model graph as
+the reference's own source computes it (tests/golden/make_reference_golden.py: deepmodel.py / deepnets.py / layers.py
+imported unmodified on a shim of the TF / Keras primitives, float64).  Here the same ModelConfig is built through the
+drop-in API, the fixture's weights are copied in, the forward runs on the GPU through libdt_hip.so, and the logit and the
+output must match the reference code's within north_star's tolerance (1e-4, relative to the logit scale above 1).
+No oracle arithmetic takes part: fixture -> HIP."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_oracle_reference_code import MODEL_FIXTURES, load_model_fixture  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('idx_dtype', ['float32', 'int32'])
+@pytest.mark.parametrize('path', MODEL_FIXTURES, ids=[os.path.basename(f)[len('reference_code_model_'):-4] for f in MODEL_FIXTURES])
+def test_hip_forward_matches_the_reference_codes_output(dev, path, idx_dtype):
+    from oracle import bridge          # only its weight loader (no oracle arithmetic below)
+    meta, tensors, want = load_model_fixture(path)
+    dm, ids, dense = bridge.model_from_reference_fixture(meta['static'], tensors, dev)
+    dm.model.train()                   # the fixtures are training-mode forwards (batch statistics in every BatchNormalization)
+    inputs = [ids.to(getattr(torch, idx_dtype)).to(dev)] + ([] if dense is None else [dense.to(dev)])
+    logit = dm.model(inputs)
+    out = dm._activate(logit)
+    got = torch.cat([logit, out], -1).detach().double().cpu()
+    assert tuple(got.shape) == tuple(want.shape)
+    tol = 1e-4 * max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err < tol, f'{os.path.basename(path)}: |HIP - reference code| = {err:.3e} (tolerance {tol:.1e})'
+
+
+def test_the_fixture_set_covers_the_baseline_configurations():
+    names = {os.path.basename(f)[len('reference_code_model_'):-4] for f in MODEL_FIXTURES}
+    assert {'fm', 'deepfm', 'xdeepfm', 'autoint', 'dcn'} <= names
+    for f in MODEL_FIXTURES:
+        meta = json.loads(str(np.load(f)['meta']))
+        assert meta['fn'] == '_model_from_parts'
