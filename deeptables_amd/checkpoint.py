@@ -71,6 +71,8 @@ def named_weights(model):
 def _slot_piece(slot, off, t):
     """the part of an optimizer slot that belongs to variable `t`, which starts `off` elements into the parameter the
     slot mirrors — as a VIEW (slots of packed tables can be row-strided, so no reshape(-1) which would copy)"""
+    if off == 0 and tuple(slot.shape) == tuple(t.shape):
+        return slot
     if slot.dim() == 2 and t.dim() == 2 and off % slot.shape[1] == 0 and t.shape[1] == slot.shape[1]:
         r0 = off // slot.shape[1]
         return slot[r0:r0 + t.shape[0]]
@@ -109,7 +111,13 @@ def save_model(model, path, optimizer=None, metadata=None):
     return list(tensors)
 
 
+def _same_view(a, b):
+    return a.data_ptr() == b.data_ptr() and tuple(a.shape) == tuple(b.shape) and a.stride() == b.stride()
+
+
 def _inside(view, base):
+    if _same_view(view, base):          # the variable IS the parameter (possibly a strided block of a fused plan's slab)
+        return view.is_floating_point()
     lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * base.element_size()
     return view.is_floating_point() and lo <= view.data_ptr() < hi and view.is_contiguous()
 

@@ -31,6 +31,41 @@ def _step_loss(dm):
     return None
 
 
+TILE_H1, TILE_H2 = 128, 64         # the tower widths the step's kernels are compiled for (csrc/deepfm.hip kH1 / kH2)
+
+
+def _tower_widths(dnn_params):
+    """(H1, H2) when the tower is one the fused steps take — two Dense(bias) -> relu cells without dropout / batch norm
+    whose widths fit the compiled 128 x 64 tile (deepnets.py:401-427) — else None.  Narrower towers run on the same
+    kernels: the plan stores W1 / b1 / W2 / b2 / w3 inside zero-padded [C,128] / [128] / [128,64] / [64] / [64] slabs and
+    the model's parameters are the leading blocks of those slabs (views).  A padded unit has zero weights and bias, so
+    its activation, every gradient that touches it and its Adam moments stay exactly zero."""
+    hu = tuple(tuple(h) for h in dnn_params.get('hidden_units', ()))
+    if len(hu) != 2 or any(len(h) != 3 for h in hu):
+        return None
+    (h1, d1, bn1), (h2, d2, bn2) = hu
+    if d1 or d2 or bn1 or bn2 or not (1 <= int(h1) <= TILE_H1 and 1 <= int(h2) <= TILE_H2):
+        return None
+    if dnn_params.get('activation', 'relu') != 'relu' or dnn_params.get('custom_dnn_fn') is not None:
+        return None
+    return int(h1), int(h2)
+
+
+def _mirror_in_flat(flat_params, accum, grad_views):
+    """Moves every parameter of `grad_views` [(param, view of accum)] to the same place of `flat_params` (same offset,
+    shape and strides as its gradient view) -> members for KerasAdam.register_flat_group."""
+    members = []
+    for p, gview in grad_views:
+        off = (gview.data_ptr() - accum.data_ptr()) // 4
+        assert tuple(gview.shape) == tuple(p.shape), (tuple(gview.shape), tuple(p.shape))
+        pview = torch.as_strided(flat_params, tuple(gview.shape), tuple(gview.stride()), off)
+        with torch.no_grad():
+            pview.copy_(p.data)
+        p.data = pview
+        members.append((p, off, p.numel(), (tuple(gview.shape), tuple(gview.stride()))))
+    return members
+
+
 def _dedupe_in_step(plan, B, backward):
     """The in-step dedupe hands the rows looked up several times to the optimizer as SEGMENTS: only for an optimizer that
     takes them, a single process (the data-parallel exchange gathers plain (rows, values)), and row-sparse tables."""
@@ -80,10 +115,7 @@ class FusedDeepFM:
                 return False
             if not (0 <= float(c.embedding_dropout or 0) < 1):
                 return False
-            hu = tuple(tuple(h) for h in c.dnn_params.get('hidden_units', ()))
-            if hu != ((128, 0, False), (64, 0, False)) or c.dnn_params.get('activation', 'relu') != 'relu':
-                return False
-            if c.dnn_params.get('custom_dnn_fn') is not None:
+            if _tower_widths(c.dnn_params) is None:
                 return False
             L = dm.model.layers_by_name
             need = ['emb_categorical_vars_all', 'bn_concat_emb_dense', 'linear_logit', 'dnn_dense_1', 'dnn_dense_2',
@@ -123,12 +155,13 @@ class FusedDeepFM:
         self.accum = torch.zeros(n_acc, dtype=torch.float32, device=self.device)
         self._bufs = {}
         a, o, C = self.accum, self.off, self.C
+        H1, H2 = _tower_widths(dm.config.dnn_params)       # <= the compiled tile: the slabs are zero padded
         self.grad_views = [
-            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * 128].view(C, 128)),
-            (self.d2.kernel, a[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)),
-            (self.d1.bias, a[o['db1']:o['db1'] + 128]),
-            (self.d2.bias, a[o['db2']:o['db2'] + 64]),
-            (self.dl.kernel, a[o['dw3']:o['dw3'] + 64].view(64, 1)),
+            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * TILE_H1].view(C, TILE_H1)[:, :H1]),
+            (self.d2.kernel, a[o['dW2']:o['dW2'] + TILE_H1 * TILE_H2].view(TILE_H1, TILE_H2)[:H1, :H2]),
+            (self.d1.bias, a[o['db1']:o['db1'] + H1]),
+            (self.d2.bias, a[o['db2']:o['db2'] + H2]),
+            (self.dl.kernel, a[o['dw3']:o['dw3'] + H2].view(H2, 1)),
             (self.out.kernel, a[o['dwo']:o['dwo'] + 1].view(1, 1)),
             (self.bn.gamma, a[o['dgamma']:o['dgamma'] + C]),
             (self.bn.beta, a[o['dbeta']:o['dbeta'] + C]),
@@ -147,13 +180,7 @@ class FusedDeepFM:
         # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
         # the model with ONE launch over (flat_params, accum) instead of one launch per tensor.
         self.flat_params = torch.zeros_like(self.accum)
-        members = []
-        for p, gview in self.grad_views:
-            off = (gview.data_ptr() - a.data_ptr()) // 4
-            n = p.numel()
-            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat_params[off:off + n].view(p.shape)
-            members.append((p, off, n))
+        members = _mirror_in_flat(self.flat_params, a, self.grad_views)
         n_flat = o['dwlin'] + self.F + self.Nd
         opt = getattr(dm, 'optimizer', None)
         if opt is not None and hasattr(opt, 'register_flat_group'):
@@ -312,10 +339,7 @@ class FusedDCN(FusedDeepFM):
             st = c.distribute_strategy
             if getattr(st, 'sharded_embeddings', False) and getattr(st, 'active', False):
                 return False                      # row-owned tables: the layer-by-layer path
-            hu = tuple(tuple(h) for h in c.dnn_params.get('hidden_units', ()))
-            if hu != ((128, 0, False), (64, 0, False)) or c.dnn_params.get('activation', 'relu') != 'relu':
-                return False
-            if c.dnn_params.get('custom_dnn_fn') is not None:
+            if _tower_widths(c.dnn_params) is None:
                 return False
             L = dm.model.layers_by_name
             # a single net: Concatenate([cross, dnn]) feeds task_output directly (deepmodel.py:286-301), no dense_logit_*
@@ -344,7 +368,7 @@ class FusedDCN(FusedDeepFM):
         self.cross = L['dcn_cross_layer']
         self.nl = int(self.cross.num_cross_layer)
         self.d1, self.d2 = L['dcn_dense_1'], L['dcn_dense_2']
-        self.out = L['task_output']        # kernel [C + 64, 1]: the step's w3; its w_out is the constant 1
+        self.out = L['task_output']        # kernel [C + H2, 1]: the step's w3; its w_out is the constant 1
         self.D = self.emb.groups[0][0]
         self.F = len(self.emb.input_dims)
         self.Nd = sum(col.input_dim for col in (dm.continuous_columns or []))
@@ -360,12 +384,13 @@ class FusedDCN(FusedDeepFM):
         self.accum = torch.zeros(n_acc, dtype=torch.float32, device=self.device)
         self._bufs = {}
         a, o, C, nl = self.accum, self.off, self.C, self.nl
+        H1, H2 = _tower_widths(dm.config.dnn_params)
         self.grad_views = [
-            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * 128].view(C, 128)),
-            (self.d2.kernel, a[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)),
-            (self.d1.bias, a[o['db1']:o['db1'] + 128]),
-            (self.d2.bias, a[o['db2']:o['db2'] + 64]),
-            (self.out.kernel, a[o['dw3']:o['dw3'] + C + 64].view(C + 64, 1)),
+            (self.d1.kernel, a[o['dW1']:o['dW1'] + C * TILE_H1].view(C, TILE_H1)[:, :H1]),
+            (self.d2.kernel, a[o['dW2']:o['dW2'] + TILE_H1 * TILE_H2].view(TILE_H1, TILE_H2)[:H1, :H2]),
+            (self.d1.bias, a[o['db1']:o['db1'] + H1]),
+            (self.d2.bias, a[o['db2']:o['db2'] + H2]),
+            (self.out.kernel, a[o['dw3']:o['dw3'] + C + H2].view(C + H2, 1)),      # [w3c | w3d], w3d's pad at the end
             (self.bn.gamma, a[o['dgamma']:o['dgamma'] + C]),
             (self.bn.beta, a[o['dbeta']:o['dbeta'] + C]),
             (self.cross.kernel_stack, a[o['dcw']:o['dcw'] + nl * C].view(nl, C)),
@@ -381,13 +406,7 @@ class FusedDCN(FusedDeepFM):
         # parameters mirror the gradient layout in one flat buffer (one optimizer launch, see FusedDeepFM); W1 / W2 precede
         # the [C + 64] output kernel, so they keep their 16-byte alignment whatever C is (the kernels read w3 with scalar loads)
         self.flat_params = torch.zeros_like(self.accum)
-        members = []
-        for p, gview in self.grad_views:
-            off = (gview.data_ptr() - a.data_ptr()) // 4
-            n = p.numel()
-            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat_params[off:off + n].view(p.shape)
-            members.append((p, off, n))
+        members = _mirror_in_flat(self.flat_params, a, self.grad_views)
         n_flat = o['dcb'] + nl * C
         opt = getattr(dm, 'optimizer', None)
         if opt is not None and hasattr(opt, 'register_flat_group'):

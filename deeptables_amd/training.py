@@ -138,22 +138,30 @@ class KerasAdam:
         return s
 
     def register_flat_group(self, flat_param, flat_grad, members, n, grad_views=False):
-        """members: [(param, offset, numel)] whose .data are views of flat_param and whose fused-plan gradients
-        are the matching views of flat_grad.  Their m/v become views of one flat m/v (existing state is kept).
+        """members: [(param, offset, numel[, (shape, strides)])] whose .data are views of flat_param and whose fused-plan
+        gradients are the matching views of flat_grad (contiguous unless shape / strides are given: a fused plan keeps
+        narrow towers inside zero-padded slabs).  Their m/v become the same views of one flat m/v (existing state is kept).
         grad_views=True: `zero_grad()` zeroes flat_grad and hands its views out as `.grad` (generic autograd path)."""
         m = torch.zeros_like(flat_param)
         v = torch.zeros_like(flat_param)
-        for p, off, cnt in members:
+
+        def view_of(flat, p, off, cnt, layout):
+            if layout is None:
+                return flat[off:off + cnt].view(p.shape)
+            return torch.as_strided(flat, layout[0], layout[1], off)
+        members = [(mb[0], mb[1], mb[2], mb[3] if len(mb) > 3 else None) for mb in members]
+        for p, off, cnt, layout in members:
             old = self.state.get(id(p))
+            mv, vv = view_of(m, p, off, cnt, layout), view_of(v, p, off, cnt, layout)
             if old is not None:
-                m[off:off + cnt].copy_(old['m'].reshape(-1))
-                v[off:off + cnt].copy_(old['v'].reshape(-1))
-            self.state[id(p)] = {'m': m[off:off + cnt].view(p.shape), 'v': v[off:off + cnt].view(p.shape)}
-        self._flat = (flat_param, flat_grad, m, v, int(n), {id(p): off for p, off, _ in members})
-        self._flat_views = [(p, flat_grad[off:off + cnt].view(p.shape)) for p, off, cnt in members] \
+                mv.copy_(old['m'].reshape(p.shape))
+                vv.copy_(old['v'].reshape(p.shape))
+            self.state[id(p)] = {'m': mv, 'v': vv}
+        self._flat = (flat_param, flat_grad, m, v, int(n), {id(p): off for p, off, _, _ in members})
+        self._flat_views = [(p, view_of(flat_grad, p, off, cnt, layout)) for p, off, cnt, layout in members] \
             if grad_views else None
-        for p, off, cnt in members:
-            p._dt_grad_view = flat_grad[off:off + cnt].view(p.shape) if grad_views else None
+        for p, off, cnt, layout in members:
+            p._dt_grad_view = None
         if grad_views:                       # same tensor objects in both places (`p.grad is p._dt_grad_view`)
             for p, view in self._flat_views:
                 p._dt_grad_view = view

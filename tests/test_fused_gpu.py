@@ -246,12 +246,111 @@ def test_ineligible_graphs_fall_back_to_layer_kernels(dev):
     from deeptables_amd import functional
     from deeptables_amd.models import ModelConfig, DeepModel
     from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    for hu in (((256, 0, False), (64, 0, False)),          # wider than the compiled 128 x 64 tile
+               ((64, 0, True), (32, 0, False)),            # a BatchNormalization cell
+               ((64, 0.1, False), (32, 0, False)),         # tower dropout
+               ((64, 0, False), (1, 0, False)),            # a width-1 tower output gets no dense_logit_* layer (deepmodel.py:291)
+               ((64, 0, False),), ((64, 0, False), (32, 0, False), (16, 0, False))):
+        conf = ModelConfig(nets=['linear', 'fm_nets', 'dnn_nets'], embeddings_output_dim=8, embedding_dropout=0,
+                           dnn_params={'hidden_units': hu, 'activation': 'relu'})
+        dm = DeepModel('binary', 2, conf, [CategoricalColumn(f'C{i}', 10, 8) for i in range(4)],
+                       [ContinuousColumn('input_continuous_all', ['a', 'b'])])
+        dm.build()
+        assert dm.fused_plan() is None, hu
     conf = ModelConfig(nets=['linear', 'fm_nets', 'dnn_nets'], embeddings_output_dim=8, embedding_dropout=0,
-                       dnn_params={'hidden_units': ((64, 0, False), (32, 0, False)), 'activation': 'relu'})
+                       dnn_params={'hidden_units': ((64, 0, False), (32, 0, False)), 'activation': 'tanh'})
     dm = DeepModel('binary', 2, conf, [CategoricalColumn(f'C{i}', 10, 8) for i in range(4)],
                    [ContinuousColumn('input_continuous_all', ['a', 'b'])])
     dm.build()
     assert dm.fused_plan() is None
+
+
+@pytest.mark.parametrize('net,H1,H2', [('DeepFM', 100, 40), ('DeepFM', 64, 32), ('DeepFM', 128, 17), ('DeepFM', 3, 2),
+                                       ('DCN', 100, 40), ('DCN', 32, 64)])
+def test_fused_steps_take_narrower_towers(dev, tmp_path, net, H1, H2):
+    """hidden_units narrower than the compiled 128 x 64 tile (deepnets.py:401-427) run on the same kernels: the plan keeps
+    W1 / b1 / W2 / b2 / w3 inside zero-padded slabs and the model's parameters are views of their leading blocks.
+    Gradients vs the oracle, three Adam steps vs the layer-by-layer path, the pads stay exactly zero, and a checkpoint
+    with optimizer slots round-trips through the strided views."""
+    from oracle import bridge, reference_layers as R
+    from deeptables_amd import checkpoint
+    from deeptables_amd.models import deepnets
+    from deeptables_amd.fused import FusedDCN, FusedDeepFM
+    F, Nd, D, B = 11, 5, 8, 300
+    extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+    hu = {'hidden_units': ((H1, 0, False), (H2, 0, False)), 'activation': 'relu'}
+    dm, cats = build(F, Nd, D, vocab=30, nets=getattr(deepnets, net), dnn_params=hu, **extra)
+    plan = dm.fused_plan()
+    assert isinstance(plan, FusedDCN if net == 'DCN' else FusedDeepFM)
+    pre, key = ('dcn', 'dcn_dnn') if net == 'DCN' else ('dnn', 'dnn')
+    Ly = dm.model.layers_by_name
+    d1, d2 = Ly[f'{pre}_dense_1'], Ly[f'{pre}_dense_2']
+    assert tuple(d1.kernel.shape) == (F * D + Nd, H1) and tuple(d2.kernel.shape) == (H1, H2)
+    idx, dense, y = batch(cats, Nd, B)
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    ref_loss = R.binary_crossentropy_from_logits(ref_logit, y.double())
+    ref_loss.backward()
+    dm.model.train()
+    ins = [idx.int().to(dev), dense.to(dev)]
+    loss, logit = dm.forward_backward(ins, y.to(dev))
+    torch.cuda.synchronize()
+    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4 * max(1.0, ref_logit.abs().max().item())
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    for i, (a, b) in enumerate([(d1.kernel.grad, w[key][0][0].grad), (d1.bias.grad, w[key][0][1].grad),
+                                (d2.kernel.grad, w[key][1][0].grad), (d2.bias.grad, w[key][1][1].grad),
+                                (Ly['task_output'].kernel.grad, w['task_output'][0].grad),
+                                (Ly['bn_concat_emb_dense'].gamma.grad, w['bn_concat_emb_dense'][0].grad)]):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert rel(a, b) < 2e-4, f'grad {i}: {rel(a, b)}'
+    if net == 'DeepFM':
+        assert rel(Ly['dense_logit_dnn_nets'].kernel.grad, w['dense_logit_dnn_nets'].grad) < 2e-4
+    table = Ly['emb_categorical_vars_all'].tables[f'd{D}']
+    assert rel(table.grad, torch.cat([t.grad for t in w['emb_categorical_vars_all']], 0)) < 2e-4
+    # three optimizer steps: fused (padded slabs, one flat Adam launch) vs a twin model on the layer-by-layer path
+    twin, _ = build(F, Nd, D, vocab=30, nets=getattr(deepnets, net), dnn_params=hu, **extra)
+    twin._fused_plan = None
+    with torch.no_grad():
+        for (n1, p1), (n2, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+            assert n1 == n2
+            p2.copy_(p1)
+        for (n1, b1), (n2, b2) in zip(dm.model.named_buffers(), twin.model.named_buffers()):
+            assert n1 == n2
+            b2.copy_(b1)                       # BatchNormalization's moving statistics (one update ahead by now)
+    twin.model.train()
+    for step in range(3):
+        idx_s, dense_s, y_s = batch(cats, Nd, B, seed=20 + step)
+        ins_s = [idx_s.int().to(dev), dense_s.to(dev)]
+        l1, _ = dm.train_step(ins_s, y_s.to(dev))
+        l2, _ = twin.train_step(ins_s, y_s.to(dev))
+        assert abs(float(l1) - float(l2)) < 1e-5
+    assert dm._fused_plan is plan and twin._fused_plan is None
+    for (n1, p1), (_, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+        assert rel(p1, p2) < 5e-4, n1
+    # the pads of the slabs: weights, gradients and Adam moments exactly zero
+    C = F * D + Nd
+    o = plan.off
+    st = dm.optimizer._flat
+    for flat in (plan.flat_params, plan.accum, st[2], st[3]):
+        W1 = flat[o['dW1']:o['dW1'] + C * 128].view(C, 128)
+        W2 = flat[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)
+        assert W1[:, H1:].abs().sum().item() == 0 and W2[H1:].abs().sum().item() == 0 and W2[:, H2:].abs().sum().item() == 0
+        assert flat[o['db1'] + H1:o['db1'] + 128].abs().sum().item() == 0
+        assert flat[o['db2'] + H2:o['db2'] + 64].abs().sum().item() == 0
+    # checkpoint round trip through the strided parameter views, optimizer slots included
+    path = str(tmp_path / 'narrow.safetensors')
+    checkpoint.save_model(dm.model, path, optimizer=dm.optimizer)
+    k1, m1 = d1.kernel.detach().clone(), dm.optimizer.state[id(d1.kernel)]['m'].clone()
+    assert m1.abs().max().item() > 0
+    with torch.no_grad():
+        d1.kernel.zero_()
+        dm.optimizer.state[id(d1.kernel)]['m'].zero_()
+    checkpoint.load_model(dm.model, path, optimizer=dm.optimizer)
+    assert torch.equal(d1.kernel.detach(), k1) and torch.equal(dm.optimizer.state[id(d1.kernel)]['m'], m1)
+    # predict (layer-by-layer forward on the strided views) agrees with the step's logits
+    dm.model.eval()
+    twin.model.eval()
+    assert (dm.model(ins) - twin.model(ins)).abs().max().item() < 1e-4
 
 
 def test_sharded_embedding_step_single_rank_equals_plain(dev):
