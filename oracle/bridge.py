@@ -111,96 +111,100 @@ def oracle_forward(dm, cat, dense, dtype=torch.float64, training=True, weights=N
     return R.model_forward(w, cat_f, dn, dm.config.nets, oracle_config(dm), training=training)
 
 
-def load_weights(dm, w):
-    """Inverse of oracle_weights: copy an oracle weights dict (numpy/torch, any float dtype) into the DeepModel.
-    Every entry of `w` that names a layer of the model is written; a layer whose weights `w` does not hold keeps its
-    initial values (callers that need completeness compare oracle_weights(dm) with `w` afterwards)."""
-    import numpy as np
+def param_pairs(dm, w):
+    """Walks an oracle weights dict `w` (or a dict of the same structure holding gradients) along the DeepModel's layers ->
+    [(parameter of the model, entry of w)], embedding tables excluded (they are one packed parameter per dimension:
+    `emb.set_embeddings` / `emb.tables`).  Entries of `w` the model has no layer for are skipped."""
     L = dm.model.layers_by_name
+    out = []
 
-    def put(param, value):
-        v = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
-        with torch.no_grad():
-            param.copy_(torch.as_tensor(v, dtype=torch.float32).reshape(param.shape))
-
-    def put_dense(layer, kb):
-        put(layer.kernel, kb[0])
+    def dense(layer, kb):
+        out.append((layer.kernel, kb[0]))
         if layer.bias is not None and len(kb) > 1 and kb[1] is not None:
-            put(layer.bias, kb[1])
+            out.append((layer.bias, kb[1]))
 
-    emb = L.get('emb_categorical_vars_all')
-    if emb is not None:
-        emb.set_embeddings(w['emb_categorical_vars_all'])
     if 'bn_concat_emb_dense' in L:
         bn = L['bn_concat_emb_dense']
-        put(bn.gamma, w['bn_concat_emb_dense'][0])
-        put(bn.beta, w['bn_concat_emb_dense'][1])
+        out.append((bn.gamma, w['bn_concat_emb_dense'][0]))
+        out.append((bn.beta, w['bn_concat_emb_dense'][1]))
     if 'linear_logit' in L:
-        put(L['linear_logit'].kernel, w['linear_logit'])
+        out.append((L['linear_logit'].kernel, w['linear_logit']))
     for prefix, key in (('dnn', 'dnn'), ('dcn', 'dcn_dnn'), ('opnn', 'opnn'), ('ipnn', 'ipnn'), ('pnn', 'pnn'),
                         ('cross_dnn', 'cross_dnn'), ('fibi_dnn', 'fibi_dnn'), ('fgcnn_dnn', 'fgcnn_dnn'),
                         ('fgcnn_ipnn', 'fgcnn_ipnn')):
         i = 1
         while f'{prefix}_dense_{i}' in L and key in w:
             cell = w[key][i - 1]
-            put_dense(L[f'{prefix}_dense_{i}'], cell)
+            dense(L[f'{prefix}_dense_{i}'], cell)
             if len(cell) > 2 and cell[2] is not None:                      # batch_norm cell (deepnets.py:420-421)
                 bn = L[f'{prefix}_bn_{i}']
-                put(bn.gamma, cell[2][0])
-                put(bn.beta, cell[2][1])
+                out.append((bn.gamma, cell[2][0]))
+                out.append((bn.beta, cell[2][1]))
             i += 1
     seen = {'att': 0, 'afm': 0, 'senet': 0, 'fgcnn': 0}
     cross_keys = {'dcn_cross_layer': 'dcn_cross', 'cross_layer': 'cross', 'cross_dnn_layer': 'cross_dnn'}
     for name, layer in L.items():
         cls = layer.__class__.__name__
         if name.startswith('dense_logit_'):
-            put(layer.kernel, w[name])
+            out.append((layer.kernel, w[name]))
         elif cls == 'CIN':
-            for p, v in zip(layer.f_, w['cin_filters']):
-                put(p, v)
+            out.extend(zip(layer.f_, w['cin_filters']))
             if layer.use_bias and w.get('cin_bias') is not None:
-                for p, v in zip(layer.bias, w['cin_bias']):
-                    put(p, v)
-            put_dense(layer.exFM_out, w['cin_exFM_out'])
+                out.extend(zip(layer.bias, w['cin_bias']))
+            dense(layer.exFM_out, w['cin_exFM_out'])
         elif cls == 'Cross' and name in cross_keys:
             key = cross_keys[name]
-            for p, v in zip(layer.kernels, w[key + '_kernels']):
-                put(p, v)
-            for p, v in zip(layer.bias, w[key + '_bias']):
-                put(p, v)
+            out.append((layer.kernel_stack, torch.stack([torch.as_tensor(k).reshape(-1) for k in w[key + '_kernels']])))
+            out.append((layer.bias_stack, torch.stack([torch.as_tensor(b).reshape(-1) for b in w[key + '_bias']])))
         elif cls == 'OuterProduct':
             key = {'outer_product_layer': 'opnn_kernel', 'pnn_outer_product_layer': 'pnn_kernel'}.get(name)
             if key in w:
-                put(layer.kernel, w[key])
+                out.append((layer.kernel, w[key]))
         elif cls == 'AFM':
             a = w['afm'][seen['afm']]
             seen['afm'] += 1
-            put_dense(layer.dense_attention, (a['att_kernel'], a.get('att_bias')))
-            put(layer.attention_p, a['projection_h'])
-            put(layer.dense_out.kernel, a['out_kernel'])
+            dense(layer.dense_attention, (a['att_kernel'], a.get('att_bias')))
+            out.append((layer.attention_p, a['projection_h']))
+            out.append((layer.dense_out.kernel, a['out_kernel']))
         elif cls == 'SENET':
             se = w['senet'][seen['senet']]
             seen['senet'] += 1
-            put_dense(layer.dense_att1, se['att1'])
-            put_dense(layer.dense_att2, se['att2'])
+            dense(layer.dense_att1, se['att1'])
+            dense(layer.dense_att2, se['att2'])
         elif cls == 'BilinearInteraction':
-            put(layer.W, w['bilinear']['senet' if name.startswith('senet_bilinear') else 'embedding'])
+            Wv = w['bilinear']['senet' if name.startswith('senet_bilinear') else 'embedding']
+            out.append((layer.W, torch.stack([torch.as_tensor(t) for t in Wv]) if isinstance(Wv, (list, tuple)) else Wv))
         elif cls == 'FGCNN':
             fw = w['fgcnn'][seen['fgcnn']]
             seen['fgcnn'] += 1
-            put(layer.conv_kernel, fw['conv_kernel'])
-            put(layer.conv_bias, fw['conv_bias'])
-            put_dense(layer.dense_output, (fw['dense_kernel'], fw['dense_bias']))
+            out.append((layer.conv_kernel, fw['conv_kernel']))
+            out.append((layer.conv_bias, fw['conv_bias']))
+            dense(layer.dense_output, (fw['dense_kernel'], fw['dense_bias']))
         elif cls == 'MultiheadAttention':
             lw = w['autoint_layers'][seen['att']]
             seen['att'] += 1
             for dn, key in ((layer.dense_Q, 'Q'), (layer.dense_K, 'K'), (layer.dense_V, 'V'),
                             (layer.dense_residual, 'R')):
                 if dn is not None and key in lw:
-                    put_dense(dn, lw[key])
-            put(layer.batch_normalize.gamma, lw['bn'][0])
-            put(layer.batch_normalize.beta, lw['bn'][1])
-    put_dense(L['task_output'], w['task_output'])
+                    dense(dn, lw[key])
+            out.append((layer.batch_normalize.gamma, lw['bn'][0]))
+            out.append((layer.batch_normalize.beta, lw['bn'][1]))
+    dense(L['task_output'], w['task_output'])
+    return out
+
+
+def load_weights(dm, w):
+    """Inverse of oracle_weights: copy an oracle weights dict (numpy/torch, any float dtype) into the DeepModel.
+    Every entry of `w` that names a layer of the model is written; a layer whose weights `w` does not hold keeps its
+    initial values (callers that need completeness compare oracle_weights(dm) with `w` afterwards)."""
+    import numpy as np
+    emb = dm.model.layers_by_name.get('emb_categorical_vars_all')
+    if emb is not None:
+        emb.set_embeddings(w['emb_categorical_vars_all'])
+    for param, value in param_pairs(dm, w):
+        v = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+        with torch.no_grad():
+            param.copy_(torch.as_tensor(v, dtype=torch.float32).reshape(param.shape))
 
 
 def model_from_reference_fixture(static, tensors, device):

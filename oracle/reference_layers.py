@@ -18,8 +18,9 @@ onto an in-process shim of the TF / Keras primitives they call (tests/golden/mak
 this oracle reproduces to 1e-12: every layer / loss class of layers.py, every net function of deepnets.py, and WHOLE
 MODELS built by the reference's DeepModel.__build_model with the reference's ModelConfig defaults — the five BASELINE.json
 configurations (FM, DeepFM, xDeepFM, AutoInt, DCN), every other preset, stacking add / concat, binary / regression /
-multiclass heads, BatchNormalization towers (53 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
-tests/test_oracle_reference_code.py): op order, axes, splits, transposes, weight shapes and the graph wiring are the
+multiclass heads, BatchNormalization towers — forward AND the gradients of the task loss with respect to every weight
+(autograd through the reference's graph) (74 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
+tests/test_oracle_reference_code.py; tests/test_reference_models_gpu.py compares the HIP path with the same files): op order, axes, splits, transposes, weight shapes and the graph wiring are the
 reference's.  What is NOT checked: float32 rounding / reduction order inside a TensorFlow primitive, and the Keras
 defaults listed in KERAS_DEFAULTS below (BatchNormalization epsilon / momentum, initializers, Adam, BCE clipping).
 
@@ -41,7 +42,11 @@ KERAS_DEFAULTS = {
     'add_weight_default_initializer': 'glorot_uniform',   # OuterProduct.kernel etc.
     'he_uniform_limit': 'sqrt(6/fan_in)',
     'adam': dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7),
-    'bce': 'computed from logits in graph mode; probabilities clipped to [1e-7, 1-1e-7] otherwise',
+    # tf.keras 2 recovers the logits of a sigmoid output in graph mode; Keras 3 (`import keras`, the reference's CI pins)
+    # always clips the probabilities to [1e-7, 1 - 1e-7] and takes logs.  The two agree to ~1e-7 unless |logit| > 16.1,
+    # where the clipped form has loss 16.1 and gradient 0; this oracle (and the product) use the logits form.  The
+    # gradient fixtures (reference_code_modelgrad_*) apply the clipped Keras-3 formula at |logit| < 12.
+    'bce': 'from the logits (stable form); Keras 3 clips probabilities to [1e-7, 1-1e-7]: same below |logit| = 16.1',
     'float_to_int_cast': 'truncation toward zero',
     'oob_embedding_index': 'TF-CPU raises InvalidArgument; TF-GPU returns a zero row',
 }
@@ -430,8 +435,8 @@ def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
             senet_embedding = senet(e, se['att1'], se['att2'], fp.get('senet_pooling_op', 'mean'))
             btype = fp.get('bilinear_type', 'field_interaction')
             Ws, We = weights['bilinear']['senet'], weights['bilinear']['embedding']
-            senet_bilinear_out = bilinear_interaction(senet_embedding, [Ws[i] for i in range(Ws.shape[0])], btype)
-            bilinear_out = bilinear_interaction(e, [We[i] for i in range(We.shape[0])], btype)
+            senet_bilinear_out = bilinear_interaction(senet_embedding, [Ws[i] for i in range(len(Ws))], btype)
+            bilinear_out = bilinear_interaction(e, [We[i] for i in range(len(We))], btype)
             fibi = torch.cat([senet_bilinear_out, bilinear_out], dim=1)
             if net == 'fibi_nets':
                 outs[net] = fibi
@@ -506,6 +511,53 @@ def _model_from_parts(cat_idx, dense, weights, nets, config):
     arrive as lists; the restatement only indexes them."""
     logit, prob = model_forward(weights, cat_idx, dense, nets, config, training=True)
     return torch.cat([logit, prob], dim=-1)
+
+
+def _leaves(nest):
+    """tensors of a nested dict / list / tuple in traversal order (dict: key order as stored), None skipped"""
+    if nest is None or isinstance(nest, str):
+        return []
+    if isinstance(nest, dict):
+        return [t for v in nest.values() for t in _leaves(v)]
+    if isinstance(nest, (list, tuple)):
+        return [t for v in nest for t in _leaves(v)]
+    return [nest]
+
+
+def _map_leaves(nest, fn):
+    if nest is None or isinstance(nest, str):
+        return nest
+    if isinstance(nest, dict):
+        return {k: _map_leaves(v, fn) for k, v in nest.items()}
+    if isinstance(nest, (list, tuple)):
+        return [_map_leaves(v, fn) for v in nest]
+    return fn(nest)
+
+
+def model_loss(weights, cat_idx, dense, y, nets, config=None, training=True):
+    """the loss DeepModel.__compile_model selects for the task (deepmodel.py:319-346): BinaryCrossentropy (from the
+    logits), MeanSquaredError, CategoricalCrossentropy — each the mean over the batch (Keras SUM_OVER_BATCH_SIZE)"""
+    config = config or {}
+    logit, out = model_forward(weights, cat_idx, dense, nets, config, training=training)
+    task = config.get('task', 'binary')
+    if task in ('binary', 'multilabel'):
+        z, t = logit, y.reshape(logit.shape).to(logit.dtype)
+        return (torch.clamp(z, min=0) - z * t + torch.log1p(torch.exp(-torch.abs(z)))).mean()
+    if task == 'regression':
+        return ((out - y.reshape(out.shape).to(out.dtype)) ** 2).mean()
+    if task == 'multiclass':
+        return -(torch.log_softmax(logit, dim=-1) * y.to(logit.dtype)).sum(-1).mean()
+    raise ValueError(task)
+
+
+def _model_grads_from_parts(cat_idx, dense, weights, y, nets, config):
+    """d model_loss / d every tensor of `weights` (traversal order of _leaves), flattened into one vector; a weight the
+    graph does not use (the concat BatchNormalization of a model none of whose nets reads it) contributes zeros"""
+    w = _map_leaves(weights, lambda t: t.detach().clone().requires_grad_(True))
+    leaves = _leaves(w)
+    loss = model_loss(w, cat_idx, dense, y, nets, config, training=True)
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    return torch.cat([(torch.zeros_like(t) if g is None else g).reshape(-1) for t, g in zip(leaves, grads)])
 
 
 def _ghmc_from_parts(input, target, acc_sum, bins=10, momentum=0.75):

@@ -163,12 +163,13 @@ def _make_tf():
 
 # ---- keras.layers.* the reference's layers instantiate -----------------------------------------------------------------
 _RNG = None
+_INIT_SCALE = 1.0       # run_model(init_scale=...): deep cross stacks saturate the sigmoid with +-0.5 weights
 
 
 def _init(shape, kind):
     """deterministic weights (the VALUES do not matter for pinning the op sequence; zeros would hide terms)"""
     shape = tuple(int(s) for s in shape)
-    return torch.as_tensor(_RNG.uniform(-0.5, 0.5, size=shape), dtype=DT)
+    return torch.as_tensor(_RNG.uniform(-0.5, 0.5, size=shape) * _INIT_SCALE, dtype=DT).requires_grad_(True)   # (the gradient fixtures)
 
 
 def _act(name):
@@ -776,7 +777,7 @@ def main():
                                                   'att2': [l.dense_att2.kernel, l.dense_att2.bias]})
             elif isinstance(l, L.BilinearInteraction):
                 Ws = [l.W] if l.bilinear_type == 'field_all' else list(l.W_list)
-                w.setdefault('bilinear', {})['senet' if n.startswith('senet_bilinear') else 'embedding'] = torch.stack(Ws)
+                w.setdefault('bilinear', {})['senet' if n.startswith('senet_bilinear') else 'embedding'] = Ws
             elif isinstance(l, L.FGCNN):
                 w.setdefault('fgcnn', []).append({'conv_kernel': l.conv2d.kernel, 'conv_bias': l.conv2d.bias,
                                                   'dense_kernel': l.dense_output.kernel, 'dense_bias': l.dense_output.bias})
@@ -790,7 +791,10 @@ def main():
         w['task_output'] = [to.kernel, to.bias]
         return w
 
-    def run_model(tag, nets, task='binary', num_classes=2, vocab=(7, 5, 11, 4, 6), emb_dim=4, n_dense=3, batch=8, **conf):
+    def run_model(tag, nets, task='binary', num_classes=2, vocab=(7, 5, 11, 4, 6), emb_dim=4, n_dense=3, batch=8,
+                  init_scale=1.0, **conf):
+        global _INIT_SCALE
+        _INIT_SCALE = init_scale
         conf.setdefault('embedding_dropout', 0)                 # config.py:84 default 0.3: dropout is outside a value pin
         config = C.ModelConfig(nets=nets, embeddings_output_dim=emb_dim, **conf)
         assert sorted(config.nets) == sorted(nets)
@@ -818,8 +822,30 @@ def main():
                 'build': {'num_classes': num_classes, 'embeddings_output_dim': emb_dim, 'output_use_bias': config.output_use_bias,
                           'dnn_params': dict(config.dnn_params, hidden_units=[list(h) for h in config.dnn_params['hidden_units']]),
                           'cross_params': config.cross_params, 'afm_params': config.afm_params}}
+        wnest = reference_weights(layers_)
         case(f'model_{tag}', torch.cat([head.last_preact, model.outputs], -1), '_model_from_parts',
-             {'cat_idx': ids, 'dense': dn, 'weights': reference_weights(layers_)}, {'nets': list(nets), 'config': ocfg})
+             {'cat_idx': ids, 'dense': dn, 'weights': wnest}, {'nets': list(nets), 'config': ocfg})
+        # the gradients of the task's Keras loss (deepmodel.py:319-346; the documented formulas on the model OUTPUT, with
+        # Keras' clip of the probabilities to [1e-7, 1 - 1e-7]) through the reference's graph, by autograd on the shim's ops
+        out = model.outputs
+        if task == 'binary':
+            yv = torch.as_tensor((rng.rand(batch, 1) < 0.3).astype(np.float64))
+            pc = torch.clamp(out, 1e-7, 1 - 1e-7)
+            loss = -(yv * torch.log(pc) + (1 - yv) * torch.log(1 - pc)).mean()
+        elif task == 'regression':
+            yv = rand(batch, 1) * 2
+            loss = ((out - yv) ** 2).mean()
+        else:
+            yv = torch.as_tensor(np.eye(num_classes)[rng.randint(0, num_classes, size=batch)])
+            pc = torch.clamp(out / out.sum(-1, keepdim=True), 1e-7, 1 - 1e-7)
+            loss = -(yv * torch.log(pc)).sum(-1).mean()
+        leaves = R._leaves(wnest)
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        flat = torch.cat([(torch.zeros_like(t) if g is None else g).reshape(-1) for t, g in zip(leaves, grads)])
+        assert task != 'binary' or head.last_preact.abs().max().item() < 12, 'saturated sigmoid: Keras clips p at 1e-7'
+        case(f'modelgrad_{tag}', flat, '_model_grads_from_parts',
+             {'cat_idx': ids, 'dense': dn, 'weights': wnest, 'y': yv}, {'nets': list(nets), 'config': ocfg})
+        _INIT_SCALE = 1.0
 
     small = {'hidden_units': ((12, 0, False), (6, 0, False)), 'activation': 'relu'}
     # the five BASELINE.json configurations, at fixture size
@@ -830,7 +856,7 @@ def main():
                           'direct': False, 'reduce_D': False})                                     # configs[2]
     run_model('autoint', N.AutoInt, emb_dim=8,
               autoint_params={'num_attention': 3, 'num_heads': 4, 'dropout_rate': 0, 'use_residual': True})   # configs[3]
-    run_model('dcn', N.DCN, dnn_params=small, cross_params={'num_cross_layer': 6})                 # configs[4]
+    run_model('dcn', N.DCN, dnn_params=small, cross_params={'num_cross_layer': 6}, init_scale=0.4)                 # configs[4]
     # the other presets of deepnets.py:14-23 and every remaining net function
     run_model('widedeep', N.WideDeep, dnn_params=small)
     run_model('pnn', N.PNN, dnn_params=small)

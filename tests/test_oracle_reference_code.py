@@ -48,6 +48,8 @@ def test_fixture_set_is_complete():
             'model_cross_and_cross_dnn', 'model_fibi_nets_flattened', 'model_fibi_nets_alone', 'model_fgcnn_cin_fm',
             'model_fgcnn_afm_ipnn', 'model_deepfm_concat_nobias', 'model_deepfm_regression', 'model_dnn_multiclass',
             'model_deepfm_bn_tower', 'model_deepfm_no_dense'} <= names
+    # every whole model also has its loss gradients (autograd through the reference's graph)
+    assert {n.replace('model_', 'modelgrad_', 1) for n in names if n.startswith('model_')} <= names
 
 
 def test_every_reference_layer_class_and_net_function_has_a_fixture():
@@ -82,6 +84,7 @@ def test_oracle_reproduces_the_reference_layer_code(path):
 
 
 MODEL_FIXTURES = [f for f in FIXTURES if os.path.basename(f).startswith('reference_code_model_')]
+GRAD_FIXTURES = [f for f in FIXTURES if os.path.basename(f).startswith('reference_code_modelgrad_')]
 
 
 def load_model_fixture(path):
