@@ -524,7 +524,8 @@ __device__ __forceinline__ floatx4 ld4(const float* p) { return *reinterpret_cas
 __device__ __forceinline__ void st4(float* p, floatx4 v) { *reinterpret_cast<floatx4*>(p) = v; }
 
 // per-tile partial sums written by C and reduced by E (layout of one tile's record, floats; contiguous).  DCN (L > 0
-// cross layers): no slin; sumc | sumcx | dw3c | dcw[L] | dcb[L] follow, CP floats each.
+// cross layers): no slin; G[0..L] (CP floats each: G_l = Xhat^T coeff_l over the tile's rows, see the cross backward of
+// kernel C) and one CP-float block of scalars follow: [l] = sum_r coeff_l, [16 + l] = sum_r A_{l+1}, [31] = sum_r dz.
 struct Part3 {
     int slin, db1, db2, dw3, dwo, dbo, loss, cross, n, stride;
 };
@@ -533,7 +534,7 @@ __host__ __device__ inline Part3 part3_layout(int CP, int L = 0) {
     l.slin = 0; l.db1 = L > 0 ? 0 : CP; l.db2 = l.db1 + kH1; l.dw3 = l.db2 + kH2;
     l.dwo = l.dw3 + kH2; l.dbo = l.dwo + 1; l.loss = l.dbo + 1;
     l.cross = (l.loss + 1 + 3) & ~3;
-    l.n = L > 0 ? l.cross + (3 + 2 * L) * CP : l.loss + 1;
+    l.n = L > 0 ? l.cross + (L + 2) * CP : l.loss + 1;
     l.stride = (l.n + 3) & ~3;
     return l;
 }
@@ -547,6 +548,8 @@ struct DcnArgs {
     int mse;                     // loss: 0 = BinaryCrossentropy on the sigmoid output, 1 = MeanSquaredError on the linear output
 };
 constexpr int kCrossMax = 8;     // cross layers the fused DCN step takes
+constexpr int kCrossScal = 48 * 16;                                  // floats of the P / Gram block (k_mlp_fwd3 crP)
+constexpr int kCrossLds = kTM + kCrossScal + 2 * kTM * 16;          // DCN's LDS next to the layer vectors: zcs | crP | crA | crF
 
 // C: MLP forward + top of the backward on a 32-row tile; NCH = CP / 64 column chunks.
 // LC = 0: DeepFM (z = linear + fm + dnn).  LC = kCrossMax: DCN (z = w3c . cross(Xn) + dnn): the Cross network's forward and
@@ -569,8 +572,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     float* zp = dh2s + kTM * kH2S;     // [4][32]  per-wave partial dnn logits
     float* dzs = zp + 4 * kTM;         // [32]
     float* zcs = dzs + kTM;            // DCN: [32] w3c . cross(Xn) per row
-    float* sL = zcs + kTM;             // DCN: [32][kCrossMax] the rows' x_l . w_l
-    float* cwL = sL + kTM * kCrossMax; // DCN: [L][CP] cross kernels | [L][CP] cross biases | [CP] w3c, zero beyond C
+    float* crP = zcs + kTM;            // DCN: [48][16] P[r][l] = Xn[r] . Wc_l (rows 0..31), b_j . Wc_l (rows 32 + j); Wc_L = w3c
+    float* crA = crP + kCrossScal;     // DCN: [32][16] a_l of every row (x_l = a_l x0 + c_l)
+    float* crF = crA + kTM * 16;       // DCN: [32][16] coeff[r][l] = d loss / d P[r][l]
+    float* cwL = crF + kTM * 16;       // DCN: [L][CP] cross kernels | [L][CP] cross biases | [CP] w3c, zero beyond C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 5, c = lane & 31, n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
@@ -769,12 +774,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         }
     }
     if constexpr (LC > 0) {
-        // ---- Cross forward (layers.py:428-436): x_{l+1} = x0 (x_l . w_l) + b_l + x_l on the wave's 8 rows; the
-        //      layer's scalars s_l are kept for the backward, the output only meets w3c ----
-        // the layer vectors: L2 -> LDS once per block (every thread's ~23 loads in flight together: a load-store loop takes
-        // one L2 round trip PER ITERATION, 17K cycles; they are issued before GEMM2, see `cst`), then LDS -> registers once per wave and phase (lane-major: column
-        // 64 k + lane).  FOUR rows advance in lockstep: a wave issues in order, so the only way to hide the latency of a
-        // row's serial chain (dot -> wave reduction -> update, per layer) is another row's independent chain.
+        // ---- Cross forward (layers.py:428-436): x_{l+1} = x0 (x_l . w_l) + b_l + x_l.  By induction x_l = a_l x0 + c_l with
+        //      a per-row SCALAR a_l and a row-independent vector c_l = b_0 + .. + b_{l-1}:
+        //          s_l = x_l . w_l = a_l p_l + q_l,   p_l = x0 . w_l,   q_l = c_l . w_l,   a_{l+1} = a_l + s_l,  a_0 = 1
+        //      so the whole network is ONE skinny GEMM P = Xn [32 x CP] . [w_0 .. w_{L-1} w3c] (fp32 MFMA 16x16x4; a third row
+        //      tile holds the biases, giving the Gram entries b_j . w_l that make up q_l) and L scalar steps per row; the
+        //      output only meets w3c:  z_c = w3c . x_L = a_L (x0 . w3c) + c_L . w3c.  (Round 2's first version walked the
+        //      layers on the VALU with wave reductions per row and layer: 11.4 K cycles forward, 45 K backward.)
         {
             const int nv = (2 * dc.L + 1) * CP;
 #pragma unroll
@@ -784,65 +790,77 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             }
         }
         lds_barrier();
-        // a lane's NCH columns (64 k + lane) travel as P float pairs: the elementwise work is v_pk_fma_f32 / v_pk_add_f32
-        // (two columns per instruction; a wave64 VALU instruction takes 4 cycles whatever it does, and this phase is bound
-        // by exactly that)
-        constexpr int P = (NCH + 1) / 2;
-        auto ldpair = [&](const float* base, int j) {           // columns 64 (2j) + lane, 64 (2j+1) + lane of an LDS row
-            floatx2 v;
-            v.x = base[128 * j + lane];
-            v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
-            return v;
-        };
         DT_STAMP(stamps, 9);
-        // all EIGHT rows of the wave advance in lockstep; the layer vectors are read from LDS where they are used (two
-        // columns per ds_read2) — holding 2L+1 of them in registers pushed the accumulators of the backward into AGPRs
-        constexpr int RG = kTM / 4;
-        floatx2 w3r[P];
+        float* pb = h1s;                   // [4][48][16] K-quarter partials (H1's LDS copy is dead until the backward)
+        {
+            const int L = dc.L;
+            const float* brow = n16 < L ? cwL + n16 * CP : cwL + 2 * L * CP;      // B operand column n16: w_l, w3c, then zero
+            const float bmask = n16 <= L ? 1.f : 0.f;
+            const float* a2row = cwL + (L + min(n16, L - 1)) * CP;                // third row tile: the bias vectors
+            const float a2mask = n16 < L ? 1.f : 0.f;
+            floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+            const int kb = wave * (CP / 4);                                       // this wave's quarter of K (16 * NCH columns)
 #pragma unroll
-        for (int j = 0; j < P; ++j) w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
-        for (int i = 0; i < kTM / 4; i += RG) {
-            const int row0 = wave * (kTM / 4) + i;
-            floatx2 x0[RG][P], xl[RG][P];
-#pragma unroll
-            for (int r = 0; r < RG; ++r)
-#pragma unroll
-                for (int j = 0; j < P; ++j) { x0[r][j] = ldpair(xs + (row0 + r) * XS, j); xl[r][j] = x0[r][j]; }
-#pragma unroll 1
-            for (int l = 0; l < dc.L; ++l) {
-                floatx2 cw[P], cb[P];
-#pragma unroll
-                for (int j = 0; j < P; ++j) { cw[j] = ldpair(cwL + l * CP, j); cb[j] = ldpair(cwL + (dc.L + l) * CP, j); }
-                float sl[RG];
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    floatx2 pd = {0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < P; ++j) pd += xl[r][j] * cw[j];
-                    sl[r] = pd.x + pd.y;
-                }
-#pragma unroll
-                for (int r = 0; r < RG; ++r) sl[r] = wave_sum(sl[r]);
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    if (lane == 0) sL[(row0 + r) * kCrossMax + l] = sl[r];
-                    const floatx2 s2 = {sl[r], sl[r]};
-#pragma unroll
-                    for (int j = 0; j < P; ++j) xl[r][j] = x0[r][j] * s2 + (xl[r][j] + cb[j]);
-                }
-            }
-            float pz[RG];
-#pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                floatx2 t = {0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < P; ++j) t += xl[r][j] * w3r[j];
-                pz[r] = t.x + t.y;
+            for (int G = 0; G < NCH; ++G) {
+                const int k = kb + 16 * G + 4 * kq;
+                const floatx4 b = ld4(brow + k) * bmask;
+                const floatx4 a0 = ld4(xs + n16 * XS + k), a1 = ld4(xs + (16 + n16) * XS + k);
+                const floatx4 a2 = ld4(a2row + k) * a2mask;
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b.x, c2, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b.y, c2, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b.z, c2, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b.w, c2, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < RG; ++r) pz[r] = wave_sum(pz[r]);
+            for (int i = 0; i < 4; ++i) {                                          // C layout: row 4 kq + i, column n16
+                pb[wave * kCrossScal + (4 * kq + i) * 16 + n16] = c0[i];
+                pb[wave * kCrossScal + (16 + 4 * kq + i) * 16 + n16] = c1[i];
+                pb[wave * kCrossScal + (32 + 4 * kq + i) * 16 + n16] = c2[i];
+            }
+        }
+        lds_barrier();
+        for (int e = tid; e < kCrossScal; e += 256)
+            crP[e] = (pb[e] + pb[kCrossScal + e]) + (pb[2 * kCrossScal + e] + pb[3 * kCrossScal + e]);
+        lds_barrier();
+        if (wave == 0 && lane < kTM) {                         // the L scalar steps of row `lane`, everything in registers
+            const int L = dc.L;                                // (register arrays: compile-time indices only, L is a guard)
+            static_assert(LC + 1 <= 12, "three float4 per row of crP");
+            float pr[12], gq[LC][12];
+            {
+                const floatx4 t0 = ld4(crP + lane * 16), t1 = ld4(crP + lane * 16 + 4), t2 = ld4(crP + lane * 16 + 8);
 #pragma unroll
-            for (int r = 0; r < RG; ++r) if (lane == 0) zcs[row0 + r] = pz[r];
+                for (int e = 0; e < 4; ++e) { pr[e] = t0[e]; pr[4 + e] = t1[e]; pr[8 + e] = t2[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {                     // Gram rows b_j . Wc_l (the same address in every lane: broadcast)
+                const floatx4 t0 = ld4(crP + (32 + j) * 16), t1 = ld4(crP + (32 + j) * 16 + 4), t2 = ld4(crP + (32 + j) * 16 + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gq[j][e] = t0[e]; gq[j][4 + e] = t1[e]; gq[j][8 + e] = t2[e]; }
+            }
+            float a = 1.f, zc = 0.f;
+#pragma unroll
+            for (int l = 0; l <= LC; ++l) {
+                float q = 0.f;                                 // q_l = (b_0 + .. + b_{l-1}) . Wc_l
+#pragma unroll
+                for (int j = 0; j < LC; ++j)
+                    if (j < l) q += gq[j][l];
+                if (l < L) {
+                    crA[lane * 16 + l] = a;
+                    a += a * pr[l] + q;
+                } else if (l == L) {
+                    crA[lane * 16 + l] = a;
+                    zc = a * pr[l] + q;                        // z_c = w3c . x_L = a_L (x0 . w3c) + c_L . w3c
+                }
+            }
+            zcs[lane] = zc;
         }
     }
     lds_barrier();
@@ -959,144 +977,121 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         for (int col = tid; col < CP; col += 256)
             prec[pl.slin + col] = (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]);
     } else {
-        // ---- Cross backward on the wave's 8 rows, g_L = dz w3c (t_l = g_{l+1} . x0):
-        //        g_l = g_{l+1} + w_l t_l,  d w_l += x_l t_l,  d b_l += g_{l+1},  dXn_cross = g_0 + sum_l g_{l+1} s_l
-        //      dXn_cross leaves for HBM (kernel D adds it to dH1 . W1^T); its two BN-backward column sums, d w3c and the
-        //      cross gradients are summed over the rows in registers, over the waves in LDS ----
-        // TWO rows in lockstep (see the forward); x_l is walked BACK from x_L (x_l = x_{l+1} - x0 s_l - b_l) instead of being
-        // kept for every layer: 5 row vectors live per row, not L + 6
-        constexpr int P = (NCH + 1) / 2;                      // column pairs, see the forward
-        auto ldpair = [&](const float* base, int j) {
-            floatx2 v;
-            v.x = base[128 * j + lane];
-            v.y = (2 * j + 1 < NCH) ? base[128 * j + 64 + lane] : 0.f;
-            return v;
-        };
-        floatx2 w3r[P], mu[P], rs[P];
-        floatx2 a_sc[P], a_scx[P], a_w3[P], a_cw[LC][P], a_cb[LC][P];
-        const floatx2 zero2 = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            w3r[j] = ldpair(cwL + 2 * dc.L * CP, j);
-            mu[j] = ldpair(bnp, j);
-            rs[j] = ldpair(bnp + 3 * CP, j);
-            a_sc[j] = zero2; a_scx[j] = zero2; a_w3[j] = zero2;
-#pragma unroll
-            for (int l = 0; l < LC; ++l) { a_cw[l][j] = zero2; a_cb[l][j] = zero2; }
-        }
+        // ---- Cross backward in the closed form of the forward (x_L = a_L x0 + c_L, g = dz w3c):
+        //   per row, scalars only:  A_L = d/d a_L = g . x0 = dz P[r][L];  for l = L-1 .. 0:  coeff_l = d/d p_l = A_{l+1} a_l,
+        //                           A_l = A_{l+1} (1 + p_l);  coeff_L = dz a_L  (the weight of w3c in d/d x0)
+        //   dXn_cross[r] = sum_l coeff[r][l] Wc_l                      -> HBM, kernel D adds it to dH1 . W1^T
+        //   G_l = sum_r coeff[r][l] xhat[r]  (fp32 MFMA, K = the 32 rows)   -> the tile record, with the scalar sums
+        //         Sco_l = sum_r coeff[r][l],  SA_l = sum_r A_{l+1},  Sdz = sum_r dz   (ones^T . M on the MFMA as well)
+        //   Kernel E' finishes per column:  d w_l = gamma G_l + beta Sco_l + SA_l c_l,  d w3c likewise with Sdz c_L,
+        //   d b_j = Sdz w3c + sum_{l > j} SA_l w_l,  and the cross path's two BN-backward sums  sum_l Sco_l Wc_l,  sum_l Wc_l G_l.
+        const int L = dc.L;
+        float* rec = prec + pl.cross;
         DT_STAMP(stamps, 10);
-        constexpr int RG = 4;
-        for (int i = 0; i < kTM / 4; i += RG) {
-            const int row0 = wave * (kTM / 4) + i;
-            floatx2 x0[RG][P], xr[RG][P], xc[RG][P], g[RG][P], gx0[RG][P];
-            float dzv[RG];
+        float* crS = crA;                  // [32][16] A_{l+1} of every row (columns 0..L-1) and dz (column 15); a row's a_l are
+                                           // in registers before its lane overwrites them
+        if (wave == 0 && lane < kTM) {
+            const int r = lane;
+            float pr[12], av[12];
+            {
+                const floatx4 t0 = ld4(crP + r * 16), t1 = ld4(crP + r * 16 + 4), t2 = ld4(crP + r * 16 + 8);
+                const floatx4 u0 = ld4(crA + r * 16), u1 = ld4(crA + r * 16 + 4), u2 = ld4(crA + r * 16 + 8);
 #pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const int64_t m = m0 + row0 + r;
-                dzv[r] = dzs[row0 + r];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const float* xg = X + m * CP + 128 * j + lane;     // raw row (the workspace rows of a ragged tile are zero)
-                    xr[r][j].x = xg[0];
-                    xr[r][j].y = (2 * j + 1 < NCH) ? xg[64] : 0.f;
-                    x0[r][j] = ldpair(xs + (row0 + r) * XS, j);
-                    xc[r][j] = x0[r][j];
+                for (int e = 0; e < 4; ++e) {
+                    pr[e] = t0[e]; pr[4 + e] = t1[e]; pr[8 + e] = t2[e];
+                    av[e] = u0[e]; av[4 + e] = u1[e]; av[8 + e] = u2[e];
                 }
             }
-#pragma unroll 1
-            for (int l = 0; l < dc.L; ++l) {                     // forward again, with the saved scalars: x_L
-                floatx2 cb[P];
+            const float dzv = dzs[r];
+            float pL = 0.f, aL = 0.f;
 #pragma unroll
-                for (int j = 0; j < P; ++j) cb[j] = ldpair(cwL + (dc.L + l) * CP, j);
+            for (int l = 0; l <= LC; ++l) { pL = l == L ? pr[l] : pL; aL = l == L ? av[l] : aL; }
+            float cf[16], sa[16];
 #pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    const float sl = sL[(row0 + r) * kCrossMax + l];
-                    const floatx2 s2 = {sl, sl};
+            for (int l = 0; l < 16; ++l) { cf[l] = 0.f; sa[l] = 0.f; }
+            float A = dzv * pL;
 #pragma unroll
-                    for (int j = 0; j < P; ++j) xc[r][j] = x0[r][j] * s2 + (xc[r][j] + cb[j]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const floatx2 d2 = {dzv[r], dzv[r]};
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    g[r][j] = d2 * w3r[j];
-                    a_w3[j] += d2 * xc[r][j];
-                    gx0[r][j] = zero2;
+            for (int l = LC - 1; l >= 0; --l) {
+                if (l < L) {
+                    cf[l] = A * av[l];
+                    sa[l] = A;
+                    A *= 1.f + pr[l];
                 }
             }
 #pragma unroll
-            for (int l = LC - 1; l >= 0; --l) {                  // unrolled: a_cw / a_cb are indexed by the layer
-                if (l < dc.L) {
-                    floatx2 cw[P], cb[P];
+            for (int l = 0; l <= LC; ++l) cf[l] = l == L ? dzv * aL : cf[l];
+            sa[15] = dzv;
 #pragma unroll
-                    for (int j = 0; j < P; ++j) { cw[j] = ldpair(cwL + l * CP, j); cb[j] = ldpair(cwL + (dc.L + l) * CP, j); }
-                    float tl[RG], sl[RG];
+            for (int e = 0; e < 4; ++e) {
+                st4(crF + r * 16 + 4 * e, floatx4{cf[4 * e], cf[4 * e + 1], cf[4 * e + 2], cf[4 * e + 3]});
+                st4(crS + r * 16 + 4 * e, floatx4{sa[4 * e], sa[4 * e + 1], sa[4 * e + 2], sa[4 * e + 3]});
+            }
+        }
+        // xhat = (X - mean) rstd replaces Xn in the tile (every read of Xn lies before the barrier above)
 #pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        floatx2 pt = zero2;
+        for (int j = 0; j < NCH; ++j) {
+            const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
+            st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
+            st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
+        }
+        lds_barrier();
+        DT_STAMP(stamps, 11);
+        {   // dXn_cross: wave w owns rows 8 w .. 8 w + 7, lanes run along the columns (256-byte row segments to HBM)
+            float wc[LC + 1][NCH];
 #pragma unroll
-                        for (int j = 0; j < P; ++j) pt += g[r][j] * x0[r][j];
-                        tl[r] = pt.x + pt.y;
-                        sl[r] = sL[(row0 + r) * kCrossMax + l];
+            for (int l = 0; l <= LC; ++l) {
+                const float* src = l < L ? cwL + l * CP : cwL + 2 * L * CP;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) wc[l][k] = l <= L ? src[64 * k + lane] : 0.f;
+            }
+#pragma unroll 2
+            for (int r8 = 0; r8 < kTM / 4; ++r8) {
+                const int row = wave * (kTM / 4) + r8;
+                const int64_t m = m0 + row;
+                float acc[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
+#pragma unroll
+                for (int l = 0; l <= LC; ++l) {
+                    if (l <= L) {
+                        const float cf = crF[row * 16 + l];
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) acc[k] += cf * wc[l][k];
                     }
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) tl[r] = wave_sum(tl[r]);
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        const floatx2 t2 = {tl[r], tl[r]}, s2 = {sl[r], sl[r]};
-#pragma unroll
-                        for (int j = 0; j < P; ++j) {
-                            xc[r][j] = (xc[r][j] - cb[j]) - x0[r][j] * s2;            // x_l from x_{l+1}
-                            a_cb[l][j] += g[r][j];
-                            a_cw[l][j] += xc[r][j] * t2;
-                            gx0[r][j] += g[r][j] * s2;
-                            g[r][j] += cw[j] * t2;
-                        }
-                    }
                 }
-            }
+                if (m < dm.B) {
 #pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                const int64_t m = m0 + row0 + r;
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const floatx2 dx = g[r][j] + gx0[r][j];
-                    if (m < dm.B) {
-                        dc.dXc[m * CP + 128 * j + lane] = dx.x;
-                        if (2 * j + 1 < NCH) dc.dXc[m * CP + 128 * j + 64 + lane] = dx.y;
-                    }
-                    a_sc[j] += dx;
-                    a_scx[j] += dx * ((xr[r][j] - mu[j]) * rs[j]);
+                    for (int k = 0; k < NCH; ++k) dc.dXc[m * CP + 64 * k + lane] = acc[k];
                 }
             }
         }
-        // the 4 waves' sums meet in LDS (every other region is dead): waves 0 / 1 store their [(3 + 2 L)][CP] sums into two
-        // slabs with plain stores, waves 2 / 3 then add theirs (one vector = 7 reads, 7 adds, 7 writes in flight), and the
-        // record written below is slab 0 + slab 1.  (Four read-modify-write passes over one slab cost 28K cycles.)
-        DT_STAMP(stamps, 11);
-        lds_barrier();
-        const int nrec0 = (3 + 2 * dc.L) * CP;
-        float* slab = lds + (wave & 1) * nrec0;
-        for (int round = 0; round < 2; ++round) {
-            if ((wave >> 1) == round) {
-                auto put = [&](int v, const floatx2 (&a)[P]) {
-                    float t[NCH];
+        if (wave == 3) {   // the scalar sums over the tile's rows: ones^T . [coeff | A, dz] on the MFMA (every output row equal)
+            floatx4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) t[k] = round ? slab[v * CP + 64 * k + lane] : 0.f;
-#pragma unroll
-                    for (int k = 0; k < NCH; ++k) slab[v * CP + 64 * k + lane] = t[k] + ((k & 1) ? a[k >> 1].y : a[k >> 1].x);
-                };
-                put(0, a_sc); put(1, a_scx); put(2, a_w3);
-#pragma unroll
-                for (int l = 0; l < LC; ++l)
-                    if (l < dc.L) { put(3 + l, a_cw[l]); put(3 + dc.L + l, a_cb[l]); }
+            for (int st = 0; st < 8; ++st) {
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crF[(4 * st + kq) * 16 + n16], d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crS[(4 * st + kq) * 16 + n16], d2, 0, 0, 0);
             }
-            lds_barrier();
+            if (kq == 0) { rec[(L + 1) * CP + n16] = d1[0]; rec[(L + 1) * CP + 16 + n16] = d2[0]; }
+        }
+        {   // G = Xhat^T . coeff: wave w owns the 16-column tiles w, w + 4, ..; K = the tile's 32 rows (8 steps)
+            float bop[8];
+#pragma unroll
+            for (int st = 0; st < 8; ++st) bop[st] = crF[(4 * st + kq) * 16 + n16];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int ct = wave + 4 * t;
+                floatx4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kq) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
+                if (n16 <= L) {                                   // C layout: Xhat column 16 ct + 4 kq + i, coefficient n16
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rec[n16 * CP + 16 * ct + 4 * kq + i] = d[i];
+                }
+            }
         }
         DT_STAMP(stamps, 12);
-        for (int e = tid; e < nrec0; e += 256) prec[pl.cross + e] = lds[e] + lds[nrec0 + e];
     }
     DT_STAMP(stamps, 8);
 }
@@ -1148,15 +1143,10 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
             else if (e == pl.dwo) dst = al.dwo;
             else if (e == pl.dbo) dst = al.dbo;
             else if (e == pl.loss) dst = al.loss;
-            else if (e >= pl.cross) {                    // DCN: sumc | sumcx | dw3c | dcw[L] | dcb[L], CP floats each
+            else if (e >= pl.cross) {                    // DCN: G_0 .. G_L | scalars (finished per column by kernel E')
                 const int vec = (e - pl.cross) / dm.CP, col = (e - pl.cross) - vec * dm.CP;
-                if (vec == 0) dst = al.sumc + col;
-                else if (vec == 1) dst = al.sumcx + col;
-                else if (col < dm.C) {
-                    if (vec == 2) dst = al.dw3 + col;
-                    else if (vec < 3 + Lc) dst = al.dcw + (int64_t)(vec - 3) * dm.C + col;
-                    else dst = al.dcb + (int64_t)(vec - 3 - Lc) * dm.C + col;
-                }
+                if (vec == Lc + 1) { if (col < 32) dst = al.sumc + col; }
+                else if (col < dm.C) dst = vec < Lc ? al.dcw + (int64_t)vec * dm.C + col : al.dw3 + col;
             }
             if (dst >= 0) accum[dst] = v;
         }
@@ -1290,7 +1280,8 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
 __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                    DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
-                                                   int Lc) {
+                                                   int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
+                                                   const float* __restrict__ w3c) {
     __shared__ floatx2 sm[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && Lc == 0) {
@@ -1339,9 +1330,33 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
     const float db = wave_sum(w.x * d.x + w.y * d.y);
     *reinterpret_cast<floatx2*>(accum + al.dW1 + (int64_t)col * kH1 + 2 * lane) =
         floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
-    if (lane == 0) {       // DCN: + the cross path's share of the two sums (reduced by kernel E from C's tile records)
-        accum[al.dgamma + col] = dg + (Lc ? accum[al.sumcx + col] : 0.f);
-        accum[al.dbeta + col] = db + (Lc ? accum[al.sumc + col] : 0.f);
+    if (lane == 0) {
+        float sumc = 0.f, sumcx = 0.f;
+        if (Lc) {
+            // DCN: the cross gradients of this column from the reduced tile records (see the cross backward of kernel C):
+            // accum[dcw + l C + col] holds G_l, accum[dw3 + col] G_L, accum[sumc + ..] the scalar sums
+            const float* sc = accum + al.sumc;
+            const float sdz = sc[31];
+            float c = 0.f;                                        // c_l = b_0 + .. + b_{l-1}
+            for (int l = 0; l < Lc; ++l) {
+                const float G = accum[al.dcw + (int64_t)l * dm.C + col], w = cw[(int64_t)l * dm.C + col];
+                sumc += sc[l] * w;
+                sumcx += w * G;
+                accum[al.dcw + (int64_t)l * dm.C + col] = ga * G + be * sc[l] + sc[16 + l] * c;
+                c += cb[(int64_t)l * dm.C + col];
+            }
+            const float G = accum[al.dw3 + col], w = w3c[col];
+            sumc += sc[Lc] * w;
+            sumcx += w * G;
+            accum[al.dw3 + col] = ga * G + be * sc[Lc] + sdz * c;
+            float suffix = sdz * w;                               // d b_j = Sdz w3c + sum_{l > j} SA_l w_l
+            for (int j = Lc - 1; j >= 0; --j) {
+                accum[al.dcb + (int64_t)j * dm.C + col] = suffix;
+                suffix += sc[16 + j] * cw[(int64_t)j * dm.C + col];
+            }
+        }
+        accum[al.dgamma + col] = dg + sumcx;
+        accum[al.dbeta + col] = db + sumc;
     }
 }
 
@@ -1769,8 +1784,7 @@ static int tower_train_step(
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
         size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
-                       (dcn ? kTM + kTM * kCrossMax + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
-        if (dcn) ldsC = max(ldsC, 2 * (size_t)(3 + 2 * Lc) * dm.CP * sizeof(float));      // the two reduction slabs
+                       (dcn ? kCrossLds + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
         DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
 #define DT_C(N)                                                                                                     \
     case N:                                                                                                         \
@@ -1808,7 +1822,7 @@ static int tower_train_step(
                            tiles, accum, al, ws + wl.wpart, stamps ? stamps + (int64_t)tiles * 32 : nullptr, Lc);
         // E'
         hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, row_blocks, Lc);
+                           accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3);
         // D
         const int FD16 = ((F * D + 15) >> 4) << 4;
         const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM +
@@ -1856,9 +1870,8 @@ extern "C" int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int
     DeepFmDims dm; int lpr;
     if (!dt_deepfm_supported(B, F, D, Nd, H1, H2) || L < 1 || L > kCrossMax) return 0;
     if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return 0;
-    size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM + kTM +
-                   kTM * kCrossMax + (2 * L + 1) * dm.CP) * sizeof(float);
-    ldsC = max(ldsC, 2 * (size_t)(3 + 2 * L) * dm.CP * sizeof(float));        // the tile kernel's two reduction slabs
+    const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM + kCrossLds +
+                         (2 * L + 1) * dm.CP) * sizeof(float);
     const int FD16 = ((F * D + 15) >> 4) << 4;
     const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + 2 * kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM + ((F + 3) & ~3)) *
                         sizeof(float);
