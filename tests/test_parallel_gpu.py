@@ -122,7 +122,12 @@ def _emulate():
 
 @pytest.mark.parametrize('kind', ['replicated', 'sharded'])
 def test_two_process_train_steps_match_single_process_emulation(dev, kind):
-    want = _emulate()
+    from deeptables_amd.models import layers as dl
+    keep = dl.DENSE_GRAD_MAX_ELEMS
+    try:
+        want = _emulate()                 # (_model switches this process to row-sparse table gradients)
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = keep
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()

@@ -41,12 +41,14 @@ def test_hip_forward_matches_the_reference_codes_output(dev, path, idx_dtype):
 
 
 @pytest.mark.parametrize('path', GRAD_FIXTURES, ids=[os.path.basename(f)[len('reference_code_modelgrad_'):-4] for f in GRAD_FIXTURES])
-def test_hip_backward_matches_the_reference_codes_gradients(dev, path):
+def test_hip_backward_matches_the_reference_codes_gradients(dev, path, monkeypatch):
     """d loss / d every weight: the train step's forward + loss + backward on the GPU (the fused DeepFM / DCN steps where
     the graph is one they take, the layer kernels elsewhere) against autograd through the reference's own graph
     (reference_code_modelgrad_*.npz: Keras loss formulas on the model output, float64)."""
     from oracle import bridge
     from oracle.reference_layers import _leaves, _map_leaves          # nest bookkeeping only
+    from deeptables_amd.models import layers as dl
+    monkeypatch.setattr(dl, 'DENSE_GRAD_MAX_ELEMS', 1 << 22)          # tiny vocabularies: the exact dense table gradient
     meta, tensors, want = load_model_fixture(path)
     dm, ids, dense = bridge.model_from_reference_fixture(meta['static'], tensors, dev)
     dm.model.train()
