@@ -476,6 +476,12 @@ class DeepModel:
         """deepmodel.py:205-210 saves the Keras model as .h5; here: one safetensors file with the Keras weight
         names (deeptables_amd/checkpoint.py), optionally with the optimizer slots."""
         from .. import checkpoint
+        st = self.config.distribute_strategy
+        if include_optimizer and getattr(st, 'sharded_embeddings', False) and getattr(st, 'active', False):
+            # row-owned tables: a rank holds Adam moments only for the fields it owns (sync_tables restores the weights,
+            # not the slots), so one rank's file would reset every other rank's moments on resume
+            raise ValueError('save(include_optimizer=True) under ShardedEmbeddingStrategy: every rank holds the Adam '
+                             'moments of its own fields only; save without the optimizer, or train with replicated tables')
         os.makedirs(os.path.dirname(os.path.abspath(filepath)) or '.', exist_ok=True)
         checkpoint.save_model(self.model, filepath, optimizer=self.optimizer if include_optimizer else None,
                               metadata={'task': str(self.task), 'nets': [str(n) for n in self.config.nets]})

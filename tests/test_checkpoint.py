@@ -82,6 +82,22 @@ def test_safetensors_round_trip_cpu(tmp_path):
         checkpoint.import_keras_h5(m, str(tmp_path / 'x.h5'))
 
 
+def test_save_with_optimizer_refused_under_sharded_tables(tmp_path):
+    """a rank of ShardedEmbeddingStrategy holds Adam moments only for its own fields: one rank's file must not pass for
+    the whole optimizer state"""
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+
+    class FakeSharded:
+        sharded_embeddings, active, world_size, rank = True, True, 2, 0
+    conf = ModelConfig(nets=['dnn_nets'], embeddings_output_dim=4, embedding_dropout=0, distribute_strategy=FakeSharded())
+    dm = DeepModel('binary', 2, conf, [CategoricalColumn('C0', 10, 4)], [ContinuousColumn('input_continuous_all', ['a'])])
+    dm.build('cpu')
+    with pytest.raises(ValueError, match='ShardedEmbeddingStrategy'):
+        dm.save(str(tmp_path / 'm.safetensors'), include_optimizer=True)
+    dm.save(str(tmp_path / 'm.safetensors'))                       # weights only: fine
+
+
 @pytest.mark.gpu
 def test_deepmodel_save_load_with_optimizer(dev, tmp_path):
     """Train two steps, save (weights + Adam slots), load into a fresh model, one more step on both: identical."""
