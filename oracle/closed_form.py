@@ -24,6 +24,49 @@ def cross(x, w, b):              # layers.py:428-436 ; w,b [L,C]
     return xl
 
 
+def cross_scalar_form(xhat, gamma, beta, w, b, w3c, dz):
+    """The algebra the fused DCN step runs (csrc/deepfm.hip, kernels C and E'), in numpy float64, tile = the whole batch.
+    Inputs: xhat [B,C] = (X - mean) rstd, BN affine gamma / beta [C] (x0 = gamma xhat + beta), cross kernels / biases
+    w, b [L,C], w3c [C] (the part of the output kernel applied to the cross output), dz [B] = d loss / d z.
+    By induction on x_{l+1} = x0 (x_l . w_l) + x_l + b_l (layers.py:428-436):
+        x_l = a_l x0 + c_l,  a_0 = 1,  c_l = b_0 + .. + b_{l-1};   s_l = a_l p_l + q_l,  p_l = x0 . w_l,  q_l = c_l . w_l
+    Returns dict: z_c = w3c . x_L [B]; dXn = d loss / d x0 through the cross network [B,C]; dw [L,C], db [L,C], dw3c [C];
+    sum_dx = sum_b dXn and sum_dx_xhat = sum_b dXn * xhat (the cross path's share of BatchNormalization's backward sums)."""
+    L, C = w.shape
+    x0 = xhat * gamma + beta
+    Wc = np.concatenate([w, w3c[None]], 0)                    # [L+1, C]: w_0 .. w_{L-1}, w3c
+    P = x0 @ Wc.T                                             # kernel C: one skinny GEMM
+    BW = b @ Wc.T                                             # the Gram rows b_j . Wc_l (third row tile of that GEMM)
+    c = np.concatenate([np.zeros((1, C)), np.cumsum(b, 0)], 0)                         # c_0 .. c_L
+    q = np.array([BW[:l, l].sum() for l in range(L + 1)])                              # q_l = c_l . Wc_l
+    a = np.ones((x0.shape[0], L + 1))
+    for l in range(L):                                        # the L scalar steps per row
+        a[:, l + 1] = a[:, l] + a[:, l] * P[:, l] + q[l]
+    z_c = a[:, L] * P[:, L] + q[L]
+    # backward: scalars per row
+    coeff = np.zeros((x0.shape[0], L + 1))
+    A_next = np.zeros((x0.shape[0], L))
+    A = dz * P[:, L]
+    coeff[:, L] = dz * a[:, L]
+    for l in range(L - 1, -1, -1):
+        coeff[:, l] = A * a[:, l]
+        A_next[:, l] = A
+        A = A * (1.0 + P[:, l])
+    dXn = coeff @ Wc                                          # kernel C: rows to HBM
+    G = xhat.T @ coeff                                        # [C, L+1]: the tile record (MFMA, K = rows)
+    Sco, SA, Sdz = coeff.sum(0), A_next.sum(0), dz.sum()      # the record's scalar block (ones^T . M)
+    # kernel E': per column
+    dw = np.stack([gamma * G[:, l] + beta * Sco[l] + SA[l] * c[l] for l in range(L)])
+    dw3c = gamma * G[:, L] + beta * Sco[L] + Sdz * c[L]
+    db = np.zeros((L, C))
+    suffix = Sdz * w3c
+    for j in range(L - 1, -1, -1):
+        db[j] = suffix
+        suffix = suffix + SA[j] * w[j]
+    return {'z_c': z_c, 'dXn': dXn, 'dw': dw, 'db': db, 'dw3c': dw3c,
+            'sum_dx': (Sco[:, None] * Wc).sum(0), 'sum_dx_xhat': (Wc * G.T).sum(0)}
+
+
 def pair_index(F):
     return [(i, j) for i in range(F - 1) for j in range(i + 1, F)]
 
