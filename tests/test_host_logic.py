@@ -90,3 +90,67 @@ def test_balanced_class_weights():
     y = np.array([0] * 6 + [1] * 3 + [2] * 1)
     cw = DeepTable.get_class_weight(Stub(), y)
     assert cw == {0: 10 / (3 * 6), 1: 10 / (3 * 3), 2: 10 / (3 * 1)}      # sklearn 'balanced': n / (classes * count)
+
+
+def _cpu_model(nets, hidden, **extra):
+    from deeptables_amd.models import ModelConfig, DeepModel
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    conf = ModelConfig(nets=nets, fixed_embedding_dim=True, embeddings_output_dim=8, embedding_dropout=0,
+                       dnn_params={'hidden_units': hidden, 'activation': 'relu'}, **extra)
+    dm = DeepModel('binary', 2, conf, [CategoricalColumn(f'C{i}', 20 + i, 8) for i in range(6)],
+                   [ContinuousColumn('input_continuous_all', ['a', 'b', 'c'])])
+    dm.build('cpu')
+    return dm
+
+
+def test_fused_plan_eligibility_by_tower_shape():
+    """which dnn_params the whole-step plans take (fused._tower_widths): two relu cells without dropout / batch norm whose
+    widths fit the compiled 128 x 64 tile; everything else falls back to the per-layer kernels (plan None).  Host logic
+    only: the plan is constructed on CPU, nothing is launched."""
+    from deeptables_amd.fused import FusedDCN, FusedDeepFM, _tower_widths
+    assert _tower_widths({'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu'}) == (128, 64)
+    assert _tower_widths({'hidden_units': [[100, 0, False], [40, 0, False]]}) == (100, 40)
+    for bad in ({'hidden_units': ((129, 0, False), (64, 0, False))}, {'hidden_units': ((128, 0, False), (65, 0, False))},
+                {'hidden_units': ((64, 0, True), (32, 0, False))}, {'hidden_units': ((64, 0.2, False), (32, 0, False))},
+                {'hidden_units': ((64, 0, False),)}, {'hidden_units': ((64, 0, False), (32, 0, False), (16, 0, False))},
+                {'hidden_units': ((64, 0, False), (32, 0, False)), 'activation': 'tanh'},
+                {'hidden_units': ((64, 0, False), (32, 0, False)), 'custom_dnn_fn': lambda x, p, c: x}, {'hidden_units': ()}):
+        assert _tower_widths(bad) is None, bad
+    assert isinstance(_cpu_model(['linear', 'fm_nets', 'dnn_nets'], ((100, 0, False), (40, 0, False))).fused_plan(), FusedDeepFM)
+    assert isinstance(_cpu_model(['dcn_nets'], ((32, 0, False), (64, 0, False)), cross_params={'num_cross_layer': 3}).fused_plan(),
+                      FusedDCN)
+    assert _cpu_model(['linear', 'fm_nets', 'dnn_nets'], ((256, 0, False), (64, 0, False))).fused_plan() is None
+    assert _cpu_model(['linear', 'fm_nets', 'dnn_nets'], ((64, 0, False), (1, 0, False))).fused_plan() is None    # no dense_logit layer
+    assert _cpu_model(['linear', 'dnn_nets'], ((128, 0, False), (64, 0, False))).fused_plan() is None             # not DeepFM
+    assert _cpu_model(['linear', 'fm_nets', 'dnn_nets'], ((128, 0, False), (64, 0, False)), stacking_op='concat').fused_plan() is None
+
+
+def test_narrow_tower_parameters_are_views_of_zero_padded_slabs():
+    """the plan moves W1 / b1 / W2 / b2 / w3 into [C,128] / [128] / [128,64] / [64] / [64] slabs of its flat parameter
+    buffer: values kept, pads zero, the gradient views and the Adam moments laid out the same way"""
+    dm = _cpu_model(['linear', 'fm_nets', 'dnn_nets'], ((100, 0, False), (40, 0, False)))
+    L = dm.model.layers_by_name
+    before = {n: p.detach().clone() for n, p in dm.model.named_parameters()}
+    plan = dm.fused_plan()
+    for n, p in dm.model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n                      # moving the storage keeps every value
+    C = 6 * 8 + 3
+    d1, d2, dl = L['dnn_dense_1'], L['dnn_dense_2'], L['dense_logit_dnn_nets']
+    assert tuple(d1.kernel.shape) == (C, 100) and d1.kernel.stride() == (128, 1)
+    assert tuple(d2.kernel.shape) == (100, 40) and d2.kernel.stride() == (64, 1)
+    o, flat = plan.off, plan.flat_params
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    for p, g in plan.grad_views:
+        assert lo <= p.data_ptr() < hi and tuple(p.shape) == tuple(g.shape) and p.stride() == g.stride()
+        assert (p.data_ptr() - lo) == (g.data_ptr() - plan.accum.data_ptr())          # same offset in both buffers
+        st = dm.optimizer.state[id(p)]
+        assert tuple(st['m'].shape) == tuple(p.shape) and st['m'].stride() == p.stride()
+    W1 = flat[o['dW1']:o['dW1'] + C * 128].view(C, 128)
+    W2 = flat[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)
+    assert torch.equal(W1[:, :100], d1.kernel.detach()) and W1[:, 100:].abs().sum() == 0
+    assert torch.equal(W2[:100, :40], d2.kernel.detach()) and W2[100:].abs().sum() == 0 and W2[:, 40:].abs().sum() == 0
+    assert flat[o['db1'] + 100:o['db1'] + 128].abs().sum() == 0 and flat[o['db2'] + 40:o['db2'] + 64].abs().sum() == 0
+    assert torch.equal(flat[o['dw3']:o['dw3'] + 40], dl.kernel.detach().reshape(-1)) and flat[o['dw3'] + 40:o['dw3'] + 64].abs().sum() == 0
+    with torch.no_grad():                         # writes through the parameter land in the slab (the kernels read the slab)
+        d1.kernel[3, 7] = 42.0
+    assert W1[3, 7].item() == 42.0
