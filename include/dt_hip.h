@@ -345,12 +345,9 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
  * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,
  * the per-net Dense(1) logits, Add, Dense(1) output, BinaryCrossentropy (from logits, mean over B)
- * — forward AND backward in six launches (csrc/deepfm.hip).  The tile kernels are compiled for the
- * ModelConfig default dnn_params ((128,0,False),(64,0,False)), relu; a NARROWER two-cell relu tower (H1 <= 128,
- * H2 <= 64) runs on them with W1 / b1 / W2 / b2 / w3 zero-padded to these shapes by the caller (a padded unit's
- * activation and every gradient touching it are exactly zero; deeptables_amd/fused.py keeps the model's parameters
- * as views of such padded slabs).  dt_deepfm_supported() says whether a shape is covered (else the host uses the
- * per-layer entry points above).
+ * — forward AND backward in six launches (csrc/deepfm.hip).  Hidden sizes are fixed to the
+ * ModelConfig default dnn_params ((128,0,False),(64,0,False)), relu; dt_deepfm_supported() says
+ * whether a shape is covered (else the host uses the per-layer entry points above).
  *   W1 [C,128] b1 [128] W2 [128,64] b2 [64] w3 [64] (dense_logit_dnn_nets) w_out [1] b_out [1]|NULL
  *   w_lin [F+Nd] (linear_logit), bn_* [C] with C = F*D+Nd.
  * Outputs: logit_out [B]; rows_out [B,F] + grad_rows [B,F,D] = the embedding table's sparse gradient
@@ -377,9 +374,7 @@ int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
 
 /* ---- fused DCN train step (nets ['dcn_nets']: Cross || DNN on BN(concat(embeddings, dense)), deepnets.py:194-207;
  * Cross.call layers.py:428-436; the reference runs it as ~120 TF ops per step).  The same launches as
- * dt_deepfm_train_step with the Cross network's forward and backward inside the tile kernel, in closed form
- * (x_l = a_l x0 + c_l with a per-row scalar a_l and c_l = b_0 + .. + b_{l-1}: one skinny MFMA GEMM Xn.[w_l | w3c] and
- * L scalar steps per row instead of L dependent passes; same result up to fp32 re-association):
+ * dt_deepfm_train_step with the Cross network's forward and backward inside the tile kernel:
  *   z = Dense(1, no bias)(Concatenate([cross(xn), relu(Dense64(relu(Dense128(xn))))])),  logit = Dense(1)(z).
  * cross_w / cross_b [L][C] = the layer's L kernels / biases stacked (L <= 8); w3 [C + 64] = the kernel applied to
  * Concatenate([cross, dnn]) (cross part first).  With 'dcn_nets' as the ONLY net the reference feeds the concatenation
