@@ -267,3 +267,19 @@ def test_split_cols_backward_completes_the_shared_buffer():
     G[..., 0:D], G[..., D:2 * D], G[..., 2 * D:3 * D] = 1, 2, 3
     torch.autograd.backward([a, b, c, d], [G[..., 0:D], G[..., D:2 * D], G[..., 2 * D:3 * D], torch.full((3, 5, D), 4.)])
     assert torch.equal(y.grad, want) and y.grad.data_ptr() == G.data_ptr()
+
+
+def test_committed_traffic_json_names_the_sources_it_was_measured_on():
+    """profiles/deepfm_traffic.json (the PMC passes behind bench.py's roofline.traffic) carries the hash of csrc/ + include/
+    at measurement time; bench.py reports it only while that equals the running sources.  A stale stamp is not an error
+    (any kernel or header edit makes it stale until the two PMC passes are collected again) but it should be visible."""
+    import json
+    import warnings
+    import __graft_entry__ as ge
+    path = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
+    j = json.load(open(path))
+    assert {'source_hash', 'bytes_per_step_corrected', 'algorithmic_bytes_per_step', 'per_kernel_KB'} <= set(j)
+    assert len(j['source_hash']) == 16
+    if j['source_hash'] != ge.source_hash():
+        warnings.warn(f"profiles/deepfm_traffic.json was measured on sources {j['source_hash']}, the tree is at "
+                      f"{ge.source_hash()}: bench.py will print roofline.traffic = null until tools_pmc.sh is re-run")
