@@ -27,6 +27,7 @@ every CPU run; this script only runs where /root/reference exists.
 """
 import contextlib
 import importlib.util
+import inspect
 import json
 import os
 import sys
@@ -882,6 +883,64 @@ def main():
     run_model('dnn_multiclass', ['dnn_nets'], task='multiclass', num_classes=3, dnn_params=small)
     run_model('deepfm_bn_tower', N.DeepFM, dnn_params={'hidden_units': ((12, 0, True), (6, 0, True)), 'activation': 'tanh'})
     run_model('deepfm_no_dense', N.DeepFM, n_dense=0, dnn_params=small)
+    # ---- the plugin / configuration surface: what the reference's own config.py / metainfo.py / deepnets.py
+    #      answer, recorded as JSON for tests/test_oracle_reference_code.py::test_drop_in_api_answers_like_the_reference
+    def outcome(fn):
+        try:
+            return {'ok': jsonable(fn())}
+        except Exception as e:                      # the exception TYPE is the contract (messages are free text)
+            return {'raises': type(e).__name__}
+
+    def jsonable(v):
+        if isinstance(v, (list, tuple)):
+            return [jsonable(e) for e in v]
+        if isinstance(v, dict):
+            return {str(k): jsonable(e) for k, e in v.items()}
+        if callable(v):
+            return getattr(v, '__name__', 'callable')
+        return v if isinstance(v, (str, int, float, bool, type(None))) else repr(v)
+
+    def good_net(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+        return None
+
+    def bad_net(embeddings, dense_layer):
+        return None
+
+    cfg0 = C.ModelConfig()
+    api = {
+        'ModelConfig_fields': list(cfg0._fields),
+        'ModelConfig_defaults': {k: jsonable(getattr(cfg0, k)) for k in cfg0._fields if k != 'nets'},
+        'ModelConfig_default_nets': sorted(cfg0.nets),
+        'presets': {k: list(getattr(N, k)) for k in ('WideDeep', 'DeepFM', 'xDeepFM', 'AutoInt', 'DCN', 'FGCNN', 'FiBiNet', 'PNN', 'AFM')},
+        'net_functions': sorted(n for n in dir(N) if callable(getattr(N, n)) and not n.startswith('_') and
+                                getattr(getattr(N, n), '__module__', '') == N.__name__ and
+                                inspect.isfunction(getattr(N, n)) and
+                                inspect.signature(getattr(N, n)) == inspect.signature(N.linear)),
+        'CategoricalColumn': jsonable(M.CategoricalColumn('c', 10)._asdict()),
+        'VarLenCategoricalColumn': jsonable(M.VarLenCategoricalColumn('v', 10)._asdict()),
+        'ContinuousColumn': jsonable(M.ContinuousColumn('x', ['a', 'b'])._asdict()),
+        'behaviour': {
+            'get(None)': outcome(lambda: N.get(None)),
+            'get(123)': outcome(lambda: N.get(123)),
+            "get('dnn_nets')": outcome(lambda: N.get('dnn_nets')),
+            'get(callable with the plugin signature)': outcome(lambda: N.get(good_net)),
+            'get(callable with another signature)': outcome(lambda: N.get(bad_net)),
+            "register_nets('not callable')": outcome(lambda: N.register_nets('x')),
+            'register_nets(plugin)': outcome(lambda: N.register_nets(good_net)),
+            'get_nets(names + plugin), sorted': outcome(lambda: sorted(N.get_nets(['linear', good_net, 'linear']))),
+            'ModelConfig(var_len item of length 2)': outcome(lambda: C.ModelConfig(var_len_categorical_columns=[('g', '|')])),
+            'ModelConfig(var_len column also excluded)': outcome(
+                lambda: C.ModelConfig(exclude_columns=['g'], var_len_categorical_columns=[('g', '|', 'max')])),
+            'ModelConfig(var_len column also categorical)': outcome(
+                lambda: C.ModelConfig(categorical_columns=['g'], var_len_categorical_columns=[('g', '|', 'max')])),
+            'ModelConfig(var_len ok).var_len_categorical_columns': outcome(
+                lambda: C.ModelConfig(var_len_categorical_columns=[('g', '|', 'max')]).var_len_categorical_columns),
+            'hash(ModelConfig) == hash(name)': outcome(lambda: hash(C.ModelConfig(name='abc')) == hash('abc')),
+        },
+    }
+    with open(os.path.join(HERE, 'reference_code_api.json'), 'w') as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print('reference_code_api.json written')
     print(f'{len(written)} fixtures written to tests/golden/reference_code_*.npz')
 
 
