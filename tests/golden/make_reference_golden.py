@@ -938,6 +938,36 @@ def main():
             'hash(ModelConfig) == hash(name)': outcome(lambda: hash(C.ModelConfig(name='abc')) == hash('abc')),
         },
     }
+    def build_outcome(nets, task='binary', num_classes=2, n_cat=3, n_dense=2, **conf):
+        def go():
+            config = C.ModelConfig(nets=nets, embedding_dropout=0, **conf)
+            cats = [M.CategoricalColumn(f'C{i}', 5 + i, 4) for i in range(n_cat)]
+            conts = [M.ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(n_dense)], input_dim=n_dense)] \
+                if n_dense else []
+            _BOUND.clear()
+            _BOUND['input_categorical_vars_all'] = torch.zeros(4, n_cat, dtype=torch.float32)
+            _BOUND['input_continuous_all'] = rand(4, max(n_dense, 1))[:, :n_dense]
+            dm = DM.DeepModel(task, num_classes, config, cats, conts)
+            out = dm._DeepModel__build_model(task=task, num_classes=num_classes, nets=list(nets), categorical_columns=cats,
+                                             continuous_columns=conts, var_len_categorical_columns=None, config=config).outputs
+            return list(out.shape)
+        return outcome(go)
+    api['build'] = {
+        'DeepFM, binary': build_outcome(N.DeepFM),
+        'DeepFM, multiclass 3': build_outcome(N.DeepFM, task='multiclass', num_classes=3),
+        'DeepFM, multilabel 4': build_outcome(N.DeepFM, task='multilabel', num_classes=4),
+        'DeepFM, regression': build_outcome(N.DeepFM, task='regression', num_classes=None),
+        "stacking_op 'bogus'": build_outcome(N.DeepFM, stacking_op='bogus'),
+        "task 'weird'": build_outcome(N.DeepFM, task='weird'),
+        'multiclass without num_classes': build_outcome(N.DeepFM, task='multiclass', num_classes=None),
+        'no inputs at all': build_outcome(['dnn_nets'], n_cat=0, n_dense=0),
+        'fm_nets without categorical columns': build_outcome(['fm_nets'], n_cat=0),
+        'afm_nets with one categorical column': build_outcome(['afm_nets'], n_cat=1),
+        'pnn_nets with one categorical column, plus dnn_nets': build_outcome(['pnn_nets', 'dnn_nets'], n_cat=1),
+        'dnn_nets on continuous inputs only': build_outcome(['dnn_nets'], n_cat=0),
+        'dnn_nets on categorical inputs only': build_outcome(['dnn_nets'], n_dense=0),
+        'linear on continuous inputs only': build_outcome(['linear'], n_cat=0),
+    }
     with open(os.path.join(HERE, 'reference_code_api.json'), 'w') as f:
         json.dump(api, f, indent=1, sort_keys=True)
     print('reference_code_api.json written')

@@ -197,6 +197,40 @@ def test_drop_in_api_answers_like_the_reference():
     for k, fn in asked.items():
         assert outcome(fn) == api['behaviour'][k], k
 
+    # DeepModel.__build_model (deepmodel.py:259-317, 436-457): which configurations build, with how many output units, and
+    # which raise (a net function returning None is dropped, :284; no net left / no input / unknown task or stacking -> ValueError)
+    from deeptables_amd.models import DeepModel
+
+    def build_outcome(nets, task='binary', num_classes=2, n_cat=3, n_dense=2, **conf):
+        def go():
+            config = ModelConfig(nets=nets, embedding_dropout=0, **conf)
+            cats = [CategoricalColumn(f'C{i}', 5 + i, 4) for i in range(n_cat)]
+            conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(n_dense)], input_dim=n_dense)] \
+                if n_dense else []
+            dm = DeepModel(task, num_classes, config, cats, conts)
+            dm.build('cpu')
+            return [4, int(dm.model.layers_by_name['task_output'].kernel.shape[1])]
+        return outcome(go)
+    built = {
+        'DeepFM, binary': build_outcome(N.DeepFM),
+        'DeepFM, multiclass 3': build_outcome(N.DeepFM, task='multiclass', num_classes=3),
+        'DeepFM, multilabel 4': build_outcome(N.DeepFM, task='multilabel', num_classes=4),
+        'DeepFM, regression': build_outcome(N.DeepFM, task='regression', num_classes=None),
+        "stacking_op 'bogus'": build_outcome(N.DeepFM, stacking_op='bogus'),
+        "task 'weird'": build_outcome(N.DeepFM, task='weird'),
+        'multiclass without num_classes': build_outcome(N.DeepFM, task='multiclass', num_classes=None),
+        'no inputs at all': build_outcome(['dnn_nets'], n_cat=0, n_dense=0),
+        'fm_nets without categorical columns': build_outcome(['fm_nets'], n_cat=0),
+        'afm_nets with one categorical column': build_outcome(['afm_nets'], n_cat=1),
+        'pnn_nets with one categorical column, plus dnn_nets': build_outcome(['pnn_nets', 'dnn_nets'], n_cat=1),
+        'dnn_nets on continuous inputs only': build_outcome(['dnn_nets'], n_cat=0),
+        'dnn_nets on categorical inputs only': build_outcome(['dnn_nets'], n_dense=0),
+        'linear on continuous inputs only': build_outcome(['linear'], n_cat=0),
+    }
+    assert set(built) == set(api['build'])
+    for k, got in built.items():
+        assert got == api['build'][k], (k, got, api['build'][k])
+
 
 @pytest.mark.skipif(not os.path.exists('/root/reference/deeptables/models/layers.py'),
                     reason='the reference tree exists only in the build container')
