@@ -536,6 +536,55 @@ def pack(prefix, v, out):
         out[prefix] = v.detach().cpu().numpy()
 
 
+def layer_contract(L, outcome, zeros):
+    """bad-input behaviour of the layer classes of module L (the reference's layers.py here; tests replay the same calls on
+    deeptables_amd.models.layers) -> {case: {'raises': type name} | {'ok': ...}}"""
+    x2, x3 = zeros(4, 6), zeros(4, 3, 2)
+    mha = {'num_heads': 1, 'dropout_rate': 0, 'use_residual': True}
+    cin = {'cross_layer_size': (4, 4), 'activation': 'relu', 'use_residual': False, 'use_bias': False, 'direct': False, 'reduce_D': False}
+    return {
+        'FM on a 2-D tensor': outcome(lambda: L.FM()(x2)),
+        'MultiheadAttention on a 2-D tensor': outcome(lambda: L.MultiheadAttention(params=mha)(x2)),
+        'SENET on a 2-D tensor': outcome(lambda: L.SENET(pooling_op='mean', reduction_ratio=2)(x2)),
+        'BilinearInteraction on a 2-D tensor': outcome(lambda: L.BilinearInteraction(bilinear_type='field_all')(x2)),
+        'Cross on a 3-D tensor': outcome(lambda: L.Cross(params={'num_cross_layer': 2})(x3)),
+        'InnerProduct on 2-D embeddings': outcome(lambda: L.InnerProduct()([x2, x2])),
+        'OuterProduct on 2-D embeddings': outcome(lambda: L.OuterProduct(params={'outer_product_kernel_type': 'mat'})([x2, x2])),
+        'OuterProduct with an unknown kernel type': outcome(lambda: L.OuterProduct(params={'outer_product_kernel_type': 'xyz'})),
+        'CIN without layers': outcome(lambda: L.CIN(params=dict(cin, cross_layer_size=()))),
+        'CIN on a 2-D tensor': outcome(lambda: L.CIN(params=cin)(x2)),
+        'CIN split with an odd hidden layer': outcome(lambda: L.CIN(params=dict(cin, cross_layer_size=(5, 4)))(x3)),
+        'AFM on a single embedding': outcome(lambda: L.AFM(params={'dropout_rate': 0})([zeros(4, 1, 2)])),
+        'AFM on 2-D embeddings': outcome(lambda: L.AFM(params={'dropout_rate': 0})([x2, x2])),
+        'MultiColumnEmbedding(input_dims=5)': outcome(lambda: L.MultiColumnEmbedding(input_dims=5, output_dims=[4])),
+        'MultiColumnEmbedding(output_dims=4)': outcome(lambda: L.MultiColumnEmbedding(input_dims=[5], output_dims=4)),
+        'MultiColumnEmbedding with lists of different lengths': outcome(lambda: L.MultiColumnEmbedding(input_dims=[5, 6], output_dims=[4])),
+        'MultiColumnEmbedding called with the wrong number of columns': outcome(
+            lambda: L.MultiColumnEmbedding(input_dims=[5, 6], output_dims=[4, 4])(zeros(4, 3))),
+    }
+
+
+def layer_configs(L, jsonable):
+    """get_config() of every layer class, constructor arguments as the net functions pass them"""
+    mk = {
+        'FM': lambda: L.FM(),
+        'MultiheadAttention': lambda: L.MultiheadAttention(params={'num_heads': 2, 'dropout_rate': 0.1, 'use_residual': False}),
+        'FGCNN': lambda: L.FGCNN(filters=3, kernel_height=4, new_filters=2, pool_height=2),
+        'SENET': lambda: L.SENET(pooling_op='max', reduction_ratio=2),
+        'BilinearInteraction': lambda: L.BilinearInteraction(bilinear_type='field_each'),
+        'Cross': lambda: L.Cross(params={'num_cross_layer': 3}),
+        'InnerProduct': lambda: L.InnerProduct(),
+        'OuterProduct': lambda: L.OuterProduct(params={'outer_product_kernel_type': 'vec'}),
+        'CIN': lambda: L.CIN(params={'cross_layer_size': (6, 4), 'activation': 'tanh', 'use_residual': True, 'use_bias': True,
+                                     'direct': True, 'reduce_D': False}),
+        'AFM': lambda: L.AFM(params={'hidden_factor': 5, 'dropout_rate': 0}),
+    }
+    out = {}
+    for name, fn in mk.items():
+        out[name] = jsonable(fn().get_config())
+    return out
+
+
 def main():
     global _RNG
     sys.path.insert(0, ROOT)
@@ -968,6 +1017,11 @@ def main():
         'dnn_nets on categorical inputs only': build_outcome(['dnn_nets'], n_dense=0),
         'linear on continuous inputs only': build_outcome(['linear'], n_cat=0),
     }
+    # the layer classes' own contract (layers.py): dimension checks raise ValueError, get_config() carries the constructor
+    # arguments (what load_model(custom_objects=dt_custom_objects) rebuilds a layer from)
+    api['layer_errors'] = layer_contract(L, outcome, lambda *shape: torch.zeros(*shape, dtype=DT))
+    api['layer_get_config'] = layer_configs(L, jsonable)
+    api['dt_custom_objects'] = sorted(L.dt_custom_objects)
     with open(os.path.join(HERE, 'reference_code_api.json'), 'w') as f:
         json.dump(api, f, indent=1, sort_keys=True)
     print('reference_code_api.json written')

@@ -232,6 +232,46 @@ def test_drop_in_api_answers_like_the_reference():
         assert got == api['build'][k], (k, got, api['build'][k])
 
 
+def _generator_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_reference_golden', os.path.join(GOLDEN, 'make_reference_golden.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                    # defines functions only; the shim is installed by main()
+    return gen
+
+
+def test_drop_in_layers_keep_the_reference_layers_contract():
+    """layers.py's own contract, recorded from the reference classes: every dimension / argument check raises ValueError
+    (before anything is launched: the calls below run on CPU tensors), get_config() returns the constructor arguments,
+    and dt_custom_objects names the classes load_model needs."""
+    from deeptables_amd.models import layers as L
+    api = json.load(open(os.path.join(GOLDEN, 'reference_code_api.json')))
+    gen = _generator_module()
+
+    def jsonable(v):
+        if isinstance(v, (list, tuple)):
+            return [jsonable(e) for e in v]
+        if isinstance(v, dict):
+            return {str(k): jsonable(e) for k, e in v.items()}
+        return v if isinstance(v, (str, int, float, bool, type(None))) else repr(v)
+
+    def outcome(fn):
+        try:
+            return {'ok': jsonable(fn())}
+        except Exception as e:
+            return {'raises': type(e).__name__}
+
+    got = gen.layer_contract(L, outcome, lambda *shape: torch.zeros(*shape, dtype=torch.float32))
+    assert set(got) == set(api['layer_errors'])
+    for k, v in got.items():
+        assert v == api['layer_errors'][k], (k, v)
+    cfgs = gen.layer_configs(L, jsonable)
+    for name, want in api['layer_get_config'].items():
+        for key, value in want.items():                       # (a Keras base config adds name / trainable / dtype on top)
+            assert cfgs[name].get(key) == value, (name, key, cfgs[name].get(key), value)
+    assert set(api['dt_custom_objects']) <= set(L.dt_custom_objects)
+
+
 @pytest.mark.skipif(not os.path.exists('/root/reference/deeptables/models/layers.py'),
                     reason='the reference tree exists only in the build container')
 def test_generator_still_agrees_with_the_reference_tree(tmp_path, monkeypatch):
