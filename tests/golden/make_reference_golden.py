@@ -841,6 +841,8 @@ def main():
         w['task_output'] = [to.kernel, to.bias]
         return w
 
+    graph_names = {}
+
     def run_model(tag, nets, task='binary', num_classes=2, vocab=(7, 5, 11, 4, 6), emb_dim=4, n_dense=3, batch=8,
                   init_scale=1.0, **conf):
         global _INIT_SCALE
@@ -862,6 +864,7 @@ def main():
         model = dm._DeepModel__build_model(task=task, num_classes=num_classes, nets=list(nets), categorical_columns=cats,
                                            continuous_columns=conts, var_len_categorical_columns=None, config=config)
         layers_ = _REGISTRY[start:]
+        graph_names[tag] = [l.name for l in layers_ if l.name]          # the layers the reference names explicitly, in order
         head = next(l for l in layers_ if l.name == 'task_output')
         ocfg = {'cin_params': dict(config.cin_params, cross_layer_size=list(config.cin_params['cross_layer_size'])),
                 'autoint_params': config.autoint_params, 'fibinet_params': config.fibinet_params,
@@ -1019,6 +1022,7 @@ def main():
     }
     # the layer classes' own contract (layers.py): dimension checks raise ValueError, get_config() carries the constructor
     # arguments (what load_model(custom_objects=dt_custom_objects) rebuilds a layer from)
+    api['graph_layer_names'] = graph_names        # names with a per-process counter suffix (_0, _1, ..) are compared without it
     api['layer_errors'] = layer_contract(L, outcome, lambda *shape: torch.zeros(*shape, dtype=DT))
     api['layer_get_config'] = layer_configs(L, jsonable)
     api['dt_custom_objects'] = sorted(L.dt_custom_objects)

@@ -127,6 +127,18 @@ def test_drop_in_model_has_the_reference_models_parameters(path):
     got = torch.cat([logit, act], -1)
     assert tuple(got.shape) == tuple(want.shape)
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())     # float32 storage of the weights
+    # every layer the reference names explicitly exists under that name (DeepModel.apply(output_layers=[...]) and Keras
+    # weight files address layers by name); counters appended per process (concat_fgcnn_embedding_0) are ignored
+    import re
+    api = json.load(open(os.path.join(GOLDEN, 'reference_code_api.json')))
+    tag = os.path.basename(path)[len('reference_code_model_'):-4]
+    strip = lambda n: re.sub(r'_\d+$', '', n)
+    mine = {strip(n) for n in dm.model.layers_by_name} | \
+        {strip(m.name) for m in dm.model.modules() if isinstance(getattr(m, 'name', None), str)}      # + named sub-layers
+    pruned = {'bn_concat_emb_dense', 'concat_embedding_dense', 'flatten_embeddings', 'concat_embeddings_axis'} \
+        if 'bn_concat_emb_dense' not in dm.model.layers_by_name else set()     # not on a path to the output (see above)
+    missing = {strip(n) for n in api['graph_layer_names'][tag]} - mine - pruned
+    assert not missing, (tag, sorted(missing))
 
 
 def test_drop_in_api_answers_like_the_reference():
