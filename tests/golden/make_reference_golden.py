@@ -1022,6 +1022,20 @@ def main():
     }
     # the layer classes' own contract (layers.py): dimension checks raise ValueError, get_config() carries the constructor
     # arguments (what load_model(custom_objects=dt_custom_objects) rebuilds a layer from)
+    def loss_outcome(task, num_classes):
+        def go():
+            config = C.ModelConfig(nets=['dnn_nets'], embedding_dropout=0)
+            cats = [M.CategoricalColumn('C0', 5, 4)]
+            _BOUND.clear()
+            _BOUND['input_categorical_vars_all'] = torch.zeros(4, 1, dtype=torch.float32)
+            dm = DM.DeepModel(task, num_classes, config, cats, [])
+            dm._DeepModel__build_model(task=task, num_classes=num_classes, nets=['dnn_nets'], categorical_columns=cats,
+                                       continuous_columns=[], var_len_categorical_columns=None, config=config)
+            return dm.model_desc.loss
+        return outcome(go)
+    # DeepModel.__compile_model (deepmodel.py:319-346), loss='auto': which Keras loss a task gets
+    api['auto_loss'] = {f'{t}/{n}': loss_outcome(t, n) for t, n in (('binary', 2), ('multilabel', 3), ('regression', None),
+                                                                  ('multiclass', 3), ('multiclass', 2))}
     api['graph_layer_names'] = graph_names        # names with a per-process counter suffix (_0, _1, ..) are compared without it
     api['layer_errors'] = layer_contract(L, outcome, lambda *shape: torch.zeros(*shape, dtype=DT))
     api['layer_get_config'] = layer_configs(L, jsonable)

@@ -239,6 +239,15 @@ def test_drop_in_api_answers_like_the_reference():
         'dnn_nets on categorical inputs only': build_outcome(['dnn_nets'], n_dense=0),
         'linear on continuous inputs only': build_outcome(['linear'], n_cat=0),
     }
+    def loss_outcome(task, num_classes):
+        def go():
+            dm = DeepModel(task, num_classes, ModelConfig(nets=['dnn_nets'], embedding_dropout=0), [CategoricalColumn('C0', 5, 4)], [])
+            dm.build('cpu')
+            return dm.model_desc.loss
+        return outcome(go)
+    for key, want in api['auto_loss'].items():                 # DeepModel.__compile_model, loss='auto'
+        t, n = key.split('/')
+        assert loss_outcome(t, None if n == 'None' else int(n)) == want, key
     assert set(built) == set(api['build'])
     for k, got in built.items():
         assert got == api['build'][k], (k, got, api['build'][k])
