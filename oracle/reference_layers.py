@@ -19,7 +19,7 @@ this oracle reproduces to 1e-12: every layer / loss class of layers.py, every ne
 MODELS built by the reference's DeepModel.__build_model with the reference's ModelConfig defaults — the five BASELINE.json
 configurations (FM, DeepFM, xDeepFM, AutoInt, DCN), every other preset, stacking add / concat, binary / regression /
 multiclass heads, BatchNormalization towers — forward AND the gradients of the task loss with respect to every weight
-(autograd through the reference's graph) (74 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
+(autograd through the reference's graph) (76 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
 tests/test_oracle_reference_code.py; tests/test_reference_models_gpu.py compares the HIP path with the same files): op order, axes, splits, transposes, weight shapes and the graph wiring are the
 reference's.  What is NOT checked: float32 rounding / reduction order inside a TensorFlow primitive, and the Keras
 defaults listed in KERAS_DEFAULTS below (BatchNormalization epsilon / momentum, initializers, Adam, BCE clipping).
@@ -308,7 +308,7 @@ def linear_net(embeddings, dense, kernel):
     return x @ kernel                                                                      # :64 Dense(1,no bias)
 
 
-def model_forward(weights, cat_idx, dense, nets, config=None, training=True, return_parts=False):
+def model_forward(weights, cat_idx, dense, nets, config=None, training=True, return_parts=False, var_len_idx=None):
     """DeepModel.__build_model — deepmodel.py:259-317, dropout 0.  config keys read here: 'stacking_op' ('add' |
     'concat', default 'add'), 'task' ('binary' | 'regression' | 'multiclass' | 'multilabel', default 'binary').
     weights: dict keyed with the Keras layer/weight names (see tests/golden/make_golden.py).
@@ -316,7 +316,7 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
     Returns the pre-activation of `task_output` (the LOGIT, [B,units]) and its activation (sigmoid probability for
     binary / multilabel, softmax for multiclass, the value itself for regression)."""
     config = config or {}
-    outs, concat_emb_dense = model_nets(weights, cat_idx, dense, nets, config, training)
+    outs, concat_emb_dense = model_nets(weights, cat_idx, dense, nets, config, training, var_len_idx)
     if len(outs) > 1:                                                # :286-301
         logits = []
         for name, out in outs.items():
@@ -358,16 +358,18 @@ def model_forward(weights, cat_idx, dense, nets, config=None, training=True, ret
     return logit, prob
 
 
-def model_nets(weights, cat_idx, dense, nets, config=None, training=True):
+def model_nets(weights, cat_idx, dense, nets, config=None, training=True, var_len_idx=None):
     """the front of DeepModel.__build_model: embeddings, concat + BatchNormalization, and the output of every net
     function of `nets` (deepmodel.py:259-285, deepnets.py) -> (OrderedDict net -> output, concat_emb_dense)"""
     config = config or {}
     act_name = config.get('dnn_activation', 'relu')
     tables = weights['emb_categorical_vars_all']                     # list of (V_f, D)
-    embeddings = multi_column_embedding(cat_idx, tables)             # :264 / :388-404
+    embeddings = multi_column_embedding(cat_idx, tables) if cat_idx is not None else []   # :264 / :388-404
+    for ids, table in zip(var_len_idx or [], weights.get('var_len_tables', [])):     # :406-418: one [B,1,L*D] block each
+        embeddings.append(var_len_embedding(ids, table))
     flatten_emb = None
     if embeddings:
-        flatten_emb = torch.cat(embeddings, dim=-1).reshape(cat_idx.shape[0], -1)   # :269-274
+        flatten_emb = torch.cat(embeddings, dim=-1).reshape(embeddings[0].shape[0], -1)   # :269-274
     if flatten_emb is not None and dense is not None:                # :348-353
         x = torch.cat([flatten_emb, dense], dim=-1)
     elif flatten_emb is not None:
@@ -505,11 +507,11 @@ def _nets_from_parts(cat_idx, dense, tables, bn, names, parts, nets, config, net
     return outs[net]
 
 
-def _model_from_parts(cat_idx, dense, weights, nets, config):
+def _model_from_parts(cat_idx, dense, weights, nets, config, var_len_idx=None):
     """model_forward in training mode -> [logit | activation] side by side (tests/golden/make_reference_golden.py stores
     the reference's `task_output` pre-activation and output the same way).  Lists that stand for (kernel, bias) pairs
     arrive as lists; the restatement only indexes them."""
-    logit, prob = model_forward(weights, cat_idx, dense, nets, config, training=True)
+    logit, prob = model_forward(weights, cat_idx, dense, nets, config, training=True, var_len_idx=var_len_idx)
     return torch.cat([logit, prob], dim=-1)
 
 
@@ -534,11 +536,11 @@ def _map_leaves(nest, fn):
     return fn(nest)
 
 
-def model_loss(weights, cat_idx, dense, y, nets, config=None, training=True):
+def model_loss(weights, cat_idx, dense, y, nets, config=None, training=True, var_len_idx=None):
     """the loss DeepModel.__compile_model selects for the task (deepmodel.py:319-346): BinaryCrossentropy (from the
     logits), MeanSquaredError, CategoricalCrossentropy — each the mean over the batch (Keras SUM_OVER_BATCH_SIZE)"""
     config = config or {}
-    logit, out = model_forward(weights, cat_idx, dense, nets, config, training=training)
+    logit, out = model_forward(weights, cat_idx, dense, nets, config, training=training, var_len_idx=var_len_idx)
     task = config.get('task', 'binary')
     if task in ('binary', 'multilabel'):
         z, t = logit, y.reshape(logit.shape).to(logit.dtype)
@@ -550,12 +552,12 @@ def model_loss(weights, cat_idx, dense, y, nets, config=None, training=True):
     raise ValueError(task)
 
 
-def _model_grads_from_parts(cat_idx, dense, weights, y, nets, config):
+def _model_grads_from_parts(cat_idx, dense, weights, y, nets, config, var_len_idx=None):
     """d model_loss / d every tensor of `weights` (traversal order of _leaves), flattened into one vector; a weight the
     graph does not use (the concat BatchNormalization of a model none of whose nets reads it) contributes zeros"""
     w = _map_leaves(weights, lambda t: t.detach().clone().requires_grad_(True))
     leaves = _leaves(w)
-    loss = model_loss(w, cat_idx, dense, y, nets, config, training=True)
+    loss = model_loss(w, cat_idx, dense, y, nets, config, training=True, var_len_idx=var_len_idx)
     grads = torch.autograd.grad(loss, leaves, allow_unused=True)
     return torch.cat([(torch.zeros_like(t) if g is None else g).reshape(-1) for t, g in zip(leaves, grads)])
 

@@ -789,6 +789,9 @@ def main():
         w = {}
         mce_ = next((l for l in layers if isinstance(l, L.MultiColumnEmbedding)), None)
         w['emb_categorical_vars_all'] = list(mce_.embeddings) if mce_ is not None else []
+        vls = [l for l in layers if isinstance(l, L.VarLenColumnEmbedding)]
+        if vls:
+            w['var_len_tables'] = [l.emb_layer.embeddings for l in vls]
         if 'bn_concat_emb_dense' in by:
             w['bn_concat_emb_dense'] = [by['bn_concat_emb_dense'].gamma, by['bn_concat_emb_dense'].beta]
         if 'linear_logit' in by:
@@ -844,7 +847,7 @@ def main():
     graph_names = {}
 
     def run_model(tag, nets, task='binary', num_classes=2, vocab=(7, 5, 11, 4, 6), emb_dim=4, n_dense=3, batch=8,
-                  init_scale=1.0, **conf):
+                  init_scale=1.0, var_len=(), **conf):
         global _INIT_SCALE
         _INIT_SCALE = init_scale
         conf.setdefault('embedding_dropout', 0)                 # config.py:84 default 0.3: dropout is outside a value pin
@@ -859,10 +862,18 @@ def main():
         _BOUND['input_categorical_vars_all'] = ids
         if n_dense:
             _BOUND['input_continuous_all'] = dn
+        vl_cols, vl_ids = [], []
+        for k, (vl_vocab, vl_len) in enumerate(var_len):            # variable-length columns (deepmodel.py:375-378, 406-418)
+            col = M.VarLenCategoricalColumn(f'tags{k}', vl_vocab, emb_dim)
+            col.max_elements_length = vl_len                        # set by the preprocessor in the reference (metainfo.py:69)
+            vl_cols.append(col)
+            vl_ids.append(torch.as_tensor(rng.randint(0, vl_vocab, size=(batch, vl_len)).astype(np.float32)))
+            _BOUND[col.name] = vl_ids[-1]
         start = len(_REGISTRY)
-        dm = DM.DeepModel(task, num_classes, config, cats, conts)
+        dm = DM.DeepModel(task, num_classes, config, cats, conts, var_categorical_len_columns=vl_cols or None)
         model = dm._DeepModel__build_model(task=task, num_classes=num_classes, nets=list(nets), categorical_columns=cats,
-                                           continuous_columns=conts, var_len_categorical_columns=None, config=config)
+                                           continuous_columns=conts, var_len_categorical_columns=vl_cols or None,
+                                           config=config)
         layers_ = _REGISTRY[start:]
         graph_names[tag] = [l.name for l in layers_ if l.name]          # the layers the reference names explicitly, in order
         head = next(l for l in layers_ if l.name == 'task_output')
@@ -876,8 +887,11 @@ def main():
                           'dnn_params': dict(config.dnn_params, hidden_units=[list(h) for h in config.dnn_params['hidden_units']]),
                           'cross_params': config.cross_params, 'afm_params': config.afm_params}}
         wnest = reference_weights(layers_)
+        extra = {'var_len_idx': vl_ids} if vl_ids else {}
+        if vl_ids:
+            ocfg['build']['var_len'] = [[c.name, c.vocabulary_size, c.max_elements_length] for c in vl_cols]
         case(f'model_{tag}', torch.cat([head.last_preact, model.outputs], -1), '_model_from_parts',
-             {'cat_idx': ids, 'dense': dn, 'weights': wnest}, {'nets': list(nets), 'config': ocfg})
+             {'cat_idx': ids, 'dense': dn, 'weights': wnest, **extra}, {'nets': list(nets), 'config': ocfg})
         # the gradients of the task's Keras loss (deepmodel.py:319-346; the documented formulas on the model OUTPUT, with
         # Keras' clip of the probabilities to [1e-7, 1 - 1e-7]) through the reference's graph, by autograd on the shim's ops
         out = model.outputs
@@ -897,7 +911,7 @@ def main():
         flat = torch.cat([(torch.zeros_like(t) if g is None else g).reshape(-1) for t, g in zip(leaves, grads)])
         assert task != 'binary' or head.last_preact.abs().max().item() < 12, 'saturated sigmoid: Keras clips p at 1e-7'
         case(f'modelgrad_{tag}', flat, '_model_grads_from_parts',
-             {'cat_idx': ids, 'dense': dn, 'weights': wnest, 'y': yv}, {'nets': list(nets), 'config': ocfg})
+             {'cat_idx': ids, 'dense': dn, 'weights': wnest, 'y': yv, **extra}, {'nets': list(nets), 'config': ocfg})
         _INIT_SCALE = 1.0
 
     small = {'hidden_units': ((12, 0, False), (6, 0, False)), 'activation': 'relu'}
@@ -935,6 +949,9 @@ def main():
     run_model('dnn_multiclass', ['dnn_nets'], task='multiclass', num_classes=3, dnn_params=small)
     run_model('deepfm_bn_tower', N.DeepFM, dnn_params={'hidden_units': ((12, 0, True), (6, 0, True)), 'activation': 'tanh'})
     run_model('deepfm_no_dense', N.DeepFM, n_dense=0, dnn_params=small)
+    # two variable-length categorical columns next to the fixed ones: their [B,1,L*D] blocks join the embedding list, so only
+    # nets that read the flattened concatenation apply (deepmodel.py:406-418)
+    run_model('dnn_var_len', ['dnn_nets'], dnn_params=small, var_len=((9, 3), (6, 5)))
     # ---- the plugin / configuration surface: what the reference's own config.py / metainfo.py / deepnets.py
     #      answer, recorded as JSON for tests/test_oracle_reference_code.py::test_drop_in_api_answers_like_the_reference
     def outcome(fn):

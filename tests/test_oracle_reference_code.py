@@ -47,7 +47,7 @@ def test_fixture_set_is_complete():
             'model_widedeep', 'model_pnn', 'model_afm', 'model_fibinet', 'model_fgcnn', 'model_opnn_ipnn_vec',
             'model_cross_and_cross_dnn', 'model_fibi_nets_flattened', 'model_fibi_nets_alone', 'model_fgcnn_cin_fm',
             'model_fgcnn_afm_ipnn', 'model_deepfm_concat_nobias', 'model_deepfm_regression', 'model_dnn_multiclass',
-            'model_deepfm_bn_tower', 'model_deepfm_no_dense'} <= names
+            'model_deepfm_bn_tower', 'model_deepfm_no_dense', 'model_dnn_var_len'} <= names
     # every whole model also has its loss gradients (autograd through the reference's graph)
     assert {n.replace('model_', 'modelgrad_', 1) for n in names if n.startswith('model_')} <= names
 
@@ -123,7 +123,7 @@ def test_drop_in_model_has_the_reference_models_parameters(path):
         assert not readers & set(meta['static']['nets'])
         weights.pop('bn_concat_emb_dense')
     assert n_model == _count(weights), 'the two graphs differ in their trainable weights'
-    logit, act = bridge.oracle_forward(dm, ids, dense, training=True)
+    logit, act = bridge.oracle_forward(dm, ids, dense, training=True, var_len=tensors.get('var_len_idx'))
     got = torch.cat([logit, act], -1)
     assert tuple(got.shape) == tuple(want.shape)
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())     # float32 storage of the weights

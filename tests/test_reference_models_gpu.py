@@ -22,6 +22,11 @@ from test_oracle_reference_code import GRAD_FIXTURES, MODEL_FIXTURES, load_model
 
 pytestmark = pytest.mark.gpu
 
+# the variable-length-column model joined the fixture set after round 2's GPU budget was spent: it is replayed against the
+# oracle and the drop-in graph on CPU (tests/test_oracle_reference_code.py); its GPU replay starts with round 3
+MODEL_FIXTURES = [f for f in MODEL_FIXTURES if 'var_len' not in os.path.basename(f)]
+GRAD_FIXTURES = [f for f in GRAD_FIXTURES if 'var_len' not in os.path.basename(f)]
+
 
 @pytest.mark.parametrize('idx_dtype', ['float32', 'int32'])
 @pytest.mark.parametrize('path', MODEL_FIXTURES, ids=[os.path.basename(f)[len('reference_code_model_'):-4] for f in MODEL_FIXTURES])
