@@ -19,7 +19,7 @@ this oracle reproduces to 1e-12: every layer / loss class of layers.py, every ne
 MODELS built by the reference's DeepModel.__build_model with the reference's ModelConfig defaults — the five BASELINE.json
 configurations (FM, DeepFM, xDeepFM, AutoInt, DCN), every other preset, stacking add / concat, binary / regression /
 multiclass heads, BatchNormalization towers — forward AND the gradients of the task loss with respect to every weight
-(autograd through the reference's graph) (76 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
+(autograd through the reference's graph) (78 fixtures, tests/golden/reference_code_*.npz, replayed on every CPU run by
 tests/test_oracle_reference_code.py; tests/test_reference_models_gpu.py compares the HIP path with the same files): op order, axes, splits, transposes, weight shapes and the graph wiring are the
 reference's.  What is NOT checked: float32 rounding / reduction order inside a TensorFlow primitive, and the Keras
 defaults listed in KERAS_DEFAULTS below (BatchNormalization epsilon / momentum, initializers, Adam, BCE clipping).
@@ -166,10 +166,19 @@ def _activation(name):
     raise ValueError(name)
 
 
+def cin_reduced_filter(f0, f__, layer_size, n_in):
+    """the filter of a reduce_D layer from its low-rank factors — layers.py:696-701.
+    f0 (1, L, F0, D), f__ (1, L, D, H_k) -> (1, F0*H_k, L), n_in = F0*H_k"""
+    f_m = torch.matmul(f0, f__)                                           # :698
+    f_o = f_m.reshape(1, layer_size, n_in)                                # :699
+    return f_o.permute(0, 2, 1)                                           # :700
+
+
 def cin(x, filters, biases, cross_layer_size, activation='relu', direct=False, dense_out=None,
-        dense_out0=None, return_hidden=False):
-    """CIN.call — layers.py:680-734 (reduce_D=False).
-    x [B,F,D]; filters[k]: (1, F*H_k, L_k); biases[k]: (L_k,) or None.
+        dense_out0=None, return_hidden=False, reduce_factors=None):
+    """CIN.call — layers.py:680-734.  reduce_D=False: filters[k] (1, F*H_k, L_k).  reduce_D=True: filters is None and
+    reduce_factors[k] = (f0_k (1, L_k, F, D), f___k (1, L_k, D, H_k)), the filter is their product (:696-701).
+    x [B,F,D]; biases[k]: (L_k,) or None.
     dense_out = (kernel (sum_out,1), bias (1,)) is exFM_out; dense_out0 the use_residual Dense.
     Returns exFM_out [B,1] (or the pre-Dense `result` [B, sum_out] if dense_out is None)."""
     if x.dim() != 3:
@@ -188,7 +197,11 @@ def cin(x, filters, biases, cross_layer_size, activation='relu', direct=False, d
                                     for a, b in zip(split_tensor0, split_tensor)], dim=0)
         dot_result_o = dot_result_m.reshape(dim, -1, field_nums[0] * field_nums[idx])   # :692
         dot_result = dot_result_o.permute(1, 0, 2)                       # :693  [B,D,F*H]
-        filt = filters[idx]                                              # :702  (1, F*H, L)
+        if reduce_factors is not None:
+            filt = cin_reduced_filter(reduce_factors[idx][0], reduce_factors[idx][1], layer_size,
+                                      field_nums[0] * field_nums[idx])
+        else:
+            filt = filters[idx]                                          # :702  (1, F*H, L)
         curr_out = torch.matmul(dot_result, filt[0])                     # :703 conv1d, width-1 kernel
         if biases is not None and biases[idx] is not None:               # :704-705
             curr_out = curr_out + biases[idx]

@@ -952,6 +952,20 @@ def main():
     # two variable-length categorical columns next to the fixed ones: their [B,1,L*D] blocks join the embedding list, so only
     # nets that read the flattened concatenation apply (deepmodel.py:406-418)
     run_model('dnn_var_len', ['dnn_nets'], dnn_params=small, var_len=((9, 3), (6, 5)))
+    # (appended after every other case: the fixtures above keep the random stream they were verified on the GPU with)
+    xcin2 = rand(B, F, D)
+    # reduce_D = True (layers.py:652-655, 696-701): every layer's filter is the product of two low-rank factors
+    for tag, params in (('reduce_D_split', dict(cross_layer_size=(6, 4), activation='relu', use_residual=False, use_bias=True,
+                                               direct=False, reduce_D=True)),
+                        ('reduce_D_direct', dict(cross_layer_size=(3, 5), activation='tanh', use_residual=False, use_bias=False,
+                                                direct=True, reduce_D=True))):
+        cin = L.CIN(params=params)
+        out = cin(xcin2)
+        tensors = {'x': xcin2, 'filters': None, 'biases': list(cin.bias) if params['use_bias'] else None,
+                   'dense_out': (cin.exFM_out.kernel, cin.exFM_out.bias), 'dense_out0': None,
+                   'reduce_factors': [[a, b_] for a, b_ in zip(cin.f0_, cin.f__)]}
+        case(f'cin_{tag}', out, 'cin', tensors, {'cross_layer_size': list(params['cross_layer_size']),
+                                                 'activation': params['activation'], 'direct': params['direct']})
     # ---- the plugin / configuration surface: what the reference's own config.py / metainfo.py / deepnets.py
     #      answer, recorded as JSON for tests/test_oracle_reference_code.py::test_drop_in_api_answers_like_the_reference
     def outcome(fn):

@@ -34,7 +34,8 @@ def _unpack(prefix, d):
 def test_fixture_set_is_complete():
     names = {os.path.basename(f)[len('reference_code_'):-4] for f in FIXTURES}
     assert {'fm', 'cross', 'inner_product', 'outer_product_mat', 'outer_product_vec', 'outer_product_num',
-            'cin_split_bias', 'cin_direct_residual', 'cin_split_linear', 'mha_h2_res1', 'mha_h4_res0',
+            'cin_split_bias', 'cin_direct_residual', 'cin_split_linear', 'cin_reduce_D_split', 'cin_reduce_D_direct',
+            'mha_h2_res1', 'mha_h4_res0',
             'multi_column_embedding', 'afm', 'bilinear_field_all', 'bilinear_field_each', 'bilinear_field_interaction',
             'senet_mean', 'senet_max', 'net_linear', 'net_fm_nets', 'net_dnn_nets', 'net_dcn_nets', 'net_cin_nets',
             'net_autoint_nets',
@@ -251,6 +252,35 @@ def test_drop_in_api_answers_like_the_reference():
     assert set(built) == set(api['build'])
     for k, got in built.items():
         assert got == api['build'][k], (k, got, api['build'][k])
+
+
+@pytest.mark.parametrize('tag', ['reduce_D_split', 'reduce_D_direct'])
+def test_drop_in_cin_composes_reduce_D_filters_like_the_reference(tag):
+    """CIN with reduce_D=True (layers.py:652-655, 696-701): the drop-in layer holds the same two low-rank factors per layer and
+    hands its kernels their product laid out as the reference's conv1d filter.  CPU: parameter shapes and the composed
+    filter against the oracle's (itself replayed against the reference code by the cin_reduce_D_* fixtures); the kernels
+    that consume the filter are the reduce_D=False ones."""
+    from oracle import reference_layers as R
+    from deeptables_amd.models import layers as L
+    d = dict(np.load(os.path.join(GOLDEN, f'reference_code_cin_{tag}.npz'), allow_pickle=False))
+    meta = json.loads(str(d['meta']))
+    x = _unpack('arg:x', d)
+    factors = _unpack('arg:reduce_factors', d)
+    cls = meta['static']['cross_layer_size']
+    layer = L.CIN(params={'cross_layer_size': tuple(cls), 'activation': meta['static']['activation'], 'use_residual': False,
+                          'use_bias': _unpack('arg:biases', d) is not None, 'direct': meta['static']['direct'], 'reduce_D': True})
+    layer.build(tuple(x.shape))
+    assert len(layer.f_) == 0 and len(layer.f0_) == len(cls) == len(layer.f__)
+    F0 = x.shape[1]
+    for k, (f0, f1) in enumerate(factors):
+        assert tuple(layer.f0_[k].shape) == tuple(f0.shape) and tuple(layer.f__[k].shape) == tuple(f1.shape)
+        with torch.no_grad():
+            layer.f0_[k].copy_(f0.float())
+            layer.f__[k].copy_(f1.float())
+        want = R.cin_reduced_filter(f0, f1, cls[k], F0 * layer.field_nums[k])[0]
+        got = layer._filter(k, cls[k])
+        assert tuple(got.shape) == tuple(want.shape)
+        assert (got.detach().double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
 
 
 def _generator_module():
