@@ -1,5 +1,8 @@
 #!/bin/bash
-# final round-2 evidence run (one gpurun call): PMC passes -> traffic json -> bench lines -> kernel stats -> GPU tests
+# The round's evidence in ONE gpurun call (round 2 ran exactly this: 120 s on the box):
+#   PMC passes -> profiles/deepfm_traffic.json -> bench lines (the default one last-but-first so it carries the traffic) ->
+#   kernel stats -> DCN phase stamps -> the GPU test suite.  Outputs land in gpurun_out/ and are copied to profiles/ by hand.
+#   usage: gpurun --timeout 330 -- 'bash tools/collect_round_evidence.sh'
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 bash tools_pmc.sh r02_pmc_fetch FETCH_SIZE --steps 20 --warmup 3 --no-parity > gpurun_out/final_pmc_fetch.txt 2>&1
