@@ -42,11 +42,12 @@ KERAS_DEFAULTS = {
     'add_weight_default_initializer': 'glorot_uniform',   # OuterProduct.kernel etc.
     'he_uniform_limit': 'sqrt(6/fan_in)',
     'adam': dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7),
-    # tf.keras 2 recovers the logits of a sigmoid output in graph mode; Keras 3 (`import keras`, the reference's CI pins)
-    # always clips the probabilities to [1e-7, 1 - 1e-7] and takes logs.  The two agree to ~1e-7 unless |logit| > 16.1,
-    # where the clipped form has loss 16.1 and gradient 0; this oracle (and the product) use the logits form.  The
-    # gradient fixtures (reference_code_modelgrad_*) apply the clipped Keras-3 formula at |logit| < 12.
-    'bce': 'from the logits (stable form); Keras 3 clips probabilities to [1e-7, 1-1e-7]: same below |logit| = 16.1',
+    # under model.fit's tf.function Keras' TensorFlow backend recovers the logits of a sigmoid output (the output tensor's
+    # op is `Sigmoid`: backend/tensorflow/nn.py _get_logits) and evaluates sigmoid_cross_entropy_with_logits; run eagerly
+    # it clips the probabilities to [1e-7, 1 - 1e-7] and takes logs.  The two agree to ~1e-7 unless |logit| > 16.1, where
+    # the clipped form has loss 16.1 and gradient 0.  This oracle (and the product) use the logits form; the gradient
+    # fixtures (reference_code_modelgrad_*) apply the probability formula at |logit| < 12, where the forms coincide.
+    'bce': 'from the logits (graph mode); probabilities clipped to [1e-7, 1-1e-7] only when run eagerly',
     'float_to_int_cast': 'truncation toward zero',
     'oob_embedding_index': 'TF-CPU raises InvalidArgument; TF-GPU returns a zero row',
 }
