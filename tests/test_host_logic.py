@@ -154,3 +154,44 @@ def test_narrow_tower_parameters_are_views_of_zero_padded_slabs():
     with torch.no_grad():                         # writes through the parameter land in the slab (the kernels read the slab)
         d1.kernel[3, 7] = 42.0
     assert W1[3, 7].item() == 42.0
+
+
+def test_segmented_sparse_grad_expands_for_random_segment_layouts():
+    """property: whatever way duplicated rows are split into (region, segment) records — regions of different fill, segments
+    in any order inside a region, members in any order inside a segment — `expanded()` restores the row id of every lookup"""
+    from hypothesis import given, settings, strategies as st
+    from deeptables_amd.ops import SparseRowGrad
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40), st.integers(1, 4), st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+    def check(n, regions, cap, seed):
+        rng = np.random.RandomState(seed)
+        rows = rng.randint(0, max(2, n // 2), size=n).astype(np.int64)          # many duplicates
+        rows[rng.rand(n) < 0.1] = -1                                            # out-of-range lookups stay -1
+        reported = rows.copy()
+        nseg = np.zeros(regions, np.int32)
+        seg_row = np.zeros(regions * cap, np.int64)
+        seg_off = np.zeros(regions * cap, np.int32)
+        seg_cnt = np.zeros(regions * cap, np.int32)
+        seg_list = np.zeros((regions, n), np.int32)
+        fill = np.zeros(regions, np.int64)
+        for r in rng.permutation(np.unique(rows[rows >= 0])):
+            members = np.flatnonzero(rows == r)
+            if len(members) < 2:
+                continue
+            reg = int(rng.randint(regions))
+            if nseg[reg] == cap:                                                # region full: the row stays per-lookup
+                continue                                                        # (the kernels size cap so this cannot happen)
+            k = reg * cap + nseg[reg]
+            seg_row[k], seg_off[k], seg_cnt[k] = r, reg * n + fill[reg], len(members)
+            seg_list[reg, fill[reg]:fill[reg] + len(members)] = rng.permutation(members)
+            fill[reg] += len(members)
+            nseg[reg] += 1
+            reported[members] = -1
+        T = torch.as_tensor
+        sg = SparseRowGrad(T(reported), torch.zeros(n, 2), fields=-1,
+                           segments=(T(nseg), T(seg_row), T(seg_off), T(seg_cnt), T(seg_list.reshape(-1)), regions, cap))
+        got, _ = sg.expanded()
+        assert np.array_equal(got.numpy(), rows)
+        assert np.array_equal(sg.rows.numpy(), reported)                       # the stored gradient is not modified
+    check()
