@@ -58,11 +58,14 @@ def mfma_flops_per_row(model, dim):
       xDeepFM: CIN layer k contracts Z[b,d,(i,j)] W[(i,j),l]: 2 D F0 H_{k-1} H_k flops per row (layers.py:692-710)
       AutoInt: per interacting layer 4 projections 2 F D D each + scores / context 2 * 2 F F D (layers.py:119-153)"""
     if model == 'xDeepFM':
-        sizes = MODEL_PARAMS['xDeepFM']['cin_params']['cross_layer_size']
+        cp = MODEL_PARAMS['xDeepFM']['cin_params']
         h, fl = F, 0
-        for size in sizes:
+        for size in cp['cross_layer_size']:
             fl += 2 * dim * F * h * size
-            h = size
+            # direct=False: only the first half of a layer's channels feeds the next layer (layers.py:713-718), so
+            # H = [26, 64, 64] for 3 x 128 -> 49.2 MFLOP/row fwd+bwd (SURVEY §8(d)); round 2 advanced h = size and
+            # overcounted 1.83x
+            h = size if cp.get('direct', False) else size // 2
         return 3.0 * fl
     if model == 'AutoInt':
         n = MODEL_PARAMS['AutoInt']['autoint_params']['num_attention']
@@ -242,23 +245,28 @@ def parity_leg(args, device):
     before anything is timed and on its own model instance."""
     from oracle import headline
     from deeptables_amd.models import deepnets
-    nets = {'DeepFM': deepnets.DeepFM, 'DCN': deepnets.DCN}[args.model]
+    nets = {'DeepFM': deepnets.DeepFM, 'DCN': deepnets.DCN, 'xDeepFM': deepnets.xDeepFM,
+            'AutoInt': deepnets.AutoInt}[args.model]
+    dim = 32 if args.model == 'AutoInt' else D
     global N_BATCHES
     keep, out = N_BATCHES, {}
-    dm = build_model(nets, device, None, D, MODEL_PARAMS.get(args.model))
+    dm = build_model(nets, device, None, dim, MODEL_PARAMS.get(args.model))
+    ok, rules = True, set()
     try:
         N_BATCHES = 1
-        for kind in ('uniform', 'zipf'):
+        # the CIN / attention oracles cost tens of seconds per step in float64: one id distribution for those
+        for kind in (('uniform', 'zipf') if args.model in ('DeepFM', 'DCN') else (args.dist,)):
             b = make_batches(args.batch, device, seed=1234, dist_kind=kind)[0]
             r = headline.check_train_step(dm, b)
+            good, rule = headline.verdict(r)
+            ok = ok and good
+            rules.add(rule)
             out[kind] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in r.items()}
     finally:
         N_BATCHES = keep
-    ok = all(r['gather_bit_exact'] and r['rows_identical'] and
-             r['max_abs_logit_err'] < 1e-4 * max(1.0, r['max_abs_logit']) and
-             r['rows_grad_rel_err'] < 2e-4 and r['dense_grad_rel_err'] < 2e-4 for r in out.values())
     out['tolerance'] = ('gather bit-exact; logits 1e-4 (north_star) of max(1, max |logit|): a 6-layer Cross network puts '
-                        'logits far above 1; gradients 2e-4 of the tensor max; Adam 1e-3 of the step')
+                        'logits far above 1; gradients: ' + ' / '.join(sorted(rules)) + ' (oracle/headline.verdict); '
+                        'Adam 1e-3 of the step')
     out['ok'] = bool(ok)
     del dm
     torch.cuda.empty_cache()
@@ -415,7 +423,7 @@ def main():
             'PNN': deepnets.PNN}[args.model]
     dim = 32 if args.model == 'AutoInt' else D
     parity = None
-    if rank == 0 and world == 1 and not args.no_parity and args.model in ('DeepFM', 'DCN'):
+    if rank == 0 and world == 1 and not args.no_parity and args.model in ('DeepFM', 'DCN', 'xDeepFM', 'AutoInt'):
         try:
             parity = parity_leg(args, device)
         except Exception as e:      # the checker must not kill the contract line; the failure is reported in it

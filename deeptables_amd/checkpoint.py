@@ -148,8 +148,15 @@ def load_model(model, path, optimizer=None, strict=True):
                 by_ptr = {}
                 for name, t in targets.items():
                     by_ptr.setdefault(t.untyped_storage().data_ptr(), []).append((name, t))
+                row_sparse = {id(t) for layer in getattr(optimizer, 'embedding_layers', ())
+                              for t in layer.tables.values() if not layer.uses_dense_grad(t.shape[1])}
                 for p in optimizer.params:
-                    st = optimizer._st(p)
+                    # never convert a slot layout while loading: a table that already holds the interleaved [V,2,D] slot
+                    # record keeps it (captured graphs hold its address; `_slot_piece` reads through row-strided views),
+                    # and state created here for a packed 2-D table is created in the layout the row update uses
+                    st = optimizer.state.get(id(p))
+                    if st is None:
+                        st = optimizer._st(p, rows=id(p) in row_sparse)
                     for name, t in by_ptr.get(p.untyped_storage().data_ptr(), []):
                         if not _inside(t, p) or f'optimizer/{name}/m' not in keys:
                             continue

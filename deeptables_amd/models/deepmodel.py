@@ -263,6 +263,7 @@ class DeepModel:
         plan = self.fused_plan() if (self.model.training and sample_weight is None) else None
         self.optimizer.zero_grad(flat=plan is None) if hasattr(self.optimizer, 'register_flat_group') \
             else self.optimizer.zero_grad()
+        self._step_used_plan = plan is not None
         if plan is not None:
             cat = inputs[0]
             dense = inputs[1] if len(inputs) > 1 else None
@@ -285,12 +286,15 @@ class DeepModel:
         if strategy is not None:
             strategy.exchange_gradients(self.model, self.optimizer)
         self.optimizer.step()
-        return loss.detach(), logit.detach().clone() if self.fused_plan() is not None else logit.detach()
+        # a fused plan hands out its static logit buffer (overwritten by the next step): copy it.  Asked of THIS step, not
+        # of fused_plan(): a weighted step must not build the plan (it re-homes the tower parameters) as a side effect.
+        return loss.detach(), logit.detach().clone() if getattr(self, '_step_used_plan', False) else logit.detach()
 
     def fit(self, X=None, y=None, batch_size=128, epochs=1, verbose=1, callbacks=None, validation_split=0.2,
             validation_data=None, shuffle=True, class_weight=None, sample_weight=None, initial_epoch=0,
             steps_per_epoch=None, validation_steps=None, validation_freq=1, max_queue_size=10, workers=1,
             use_multiprocessing=False):
+        n_fit_rows, tr_i = len(X), None
         if validation_data is None:
             n = len(X)
             n_val = int(math.ceil(n * validation_split)) if validation_split else 0
@@ -317,8 +321,13 @@ class DeepModel:
         if class_weight is not None or sample_weight is not None:
             weights = np.ones(len(X), dtype=np.float32) if sample_weight is None else \
                 np.asarray(sample_weight, dtype=np.float32).reshape(-1).copy()
-            if validation_data is None and validation_split and len(weights) != len(X):
-                weights = weights[tr_i]                 # the caller's weights follow the rows kept for training
+            if sample_weight is not None:
+                # the caller's weights belong to the rows as passed in: checked against THAT length, then sliced with the
+                # rows kept for training (a weight vector that merely happens to have the post-split length is an error)
+                if len(weights) != n_fit_rows:
+                    raise ValueError(f'sample_weight has {len(weights)} entries for {n_fit_rows} rows')
+                if tr_i is not None:
+                    weights = weights[tr_i]
             if class_weight is not None:
                 yl = np.asarray(y)
                 yl = yl.argmax(-1) if yl.ndim > 1 and yl.shape[-1] > 1 else yl.reshape(-1)
@@ -365,6 +374,8 @@ class DeepModel:
                     wb = None
                     if train.weighted:
                         wb, yb = yb[:, -1].contiguous(), yb[:, :-1].contiguous()
+                        if train.y_ndim == 1:               # the metric buffers see y as an unweighted fit feeds it
+                            yb = yb.reshape(-1)
                     loss, logit = self.train_step(ins, yb, wb)
                     losses.append(loss)
                     probs.append(self._activate(logit))

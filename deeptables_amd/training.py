@@ -72,8 +72,6 @@ def mse(pred, y):
 # Keras Adam
 # ---------------------------------------------------------------------------------------------
 class KerasAdam:
-    supports_row_segments = True      # takes SparseRowGrad.segments (dt_adam_rows_step_seg)
-
     """keras.optimizers.Adam(learning_rate=1e-3, beta_1=.9, beta_2=.999, epsilon=1e-7):
         lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
     Dense parameters: one fused HIP launch each — or ONE launch for a whole registered flat group (the fused
@@ -84,6 +82,7 @@ class KerasAdam:
     The step counter and lr_t live on the device (dt_adam_advance), so a captured hipGraph of the step replays
     with the right bias correction."""
 
+    supports_row_segments = True      # takes SparseRowGrad.segments (dt_adam_rows_step_seg)
     _name = 'Adam'
 
     def __init__(self, params, embedding_layers=(), learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
@@ -166,6 +165,16 @@ class KerasAdam:
             for p, view in self._flat_views:
                 p._dt_grad_view = view
 
+    def _flat_member_views(self):
+        """{id(param): the parameter's view of the flat GRADIENT buffer} (same offset / shape / strides as its data)"""
+        fp, fg = self._flat[0], self._flat[1]
+        out = {}
+        for p in self.params:
+            if id(p) in self._flat[5]:
+                off = (p.data.data_ptr() - fp.data_ptr()) // 4
+                out[id(p)] = torch.as_strided(fg, tuple(p.data.shape), tuple(p.data.stride()), off)
+        return out
+
     def _dense_launch(self, dense, sp, st, advance):
         """All dense tensors of the step in one launch (dt_adam_multi_step; chunks of 32 tensors)."""
         if not dense:
@@ -215,11 +224,37 @@ class KerasAdam:
             if len(in_flat) == len(members):       # every member's gradient is its flat view: one launch
                 dense.append((fp, fg, fm, fv, n))
                 flat_done = set(members)
+            else:
+                # gradients that are NOT the flat views (the layer-by-layer path after a fused plan re-homed the
+                # parameters: a weighted step, DT_AMD_FUSED toggled, ...).  Members of a plan with a narrow tower are
+                # STRIDED views of zero-padded slabs (fused._mirror_in_flat), so the per-tensor kernels — which take
+                # (pointer, numel) — must not see them: scatter every member's gradient into its place of the flat
+                # gradient buffer and update the whole group with the one flat launch.  Pads have zero gradient and
+                # zero moments: they stay exactly zero.
+                with_grad = [p for p in self.params if id(p) in members and p.grad is not None]
+                if len(with_grad) == len(members):
+                    views = self._flat_member_views()
+                    if not in_flat:
+                        fg.zero_()
+                    flat_ids = {id(p) for p in in_flat}
+                    for p in with_grad:
+                        if id(p) not in flat_ids:
+                            views[id(p)].copy_(p.grad.reshape(views[id(p)].shape))
+                    dense.append((fp, fg, fm, fv, n))
+                    flat_done = set(members)
+        deferred = []                                     # (param, slots, contiguous copies) of strided tensors
         for p in self.params:
             if p.grad is None or id(p) in flat_done:
                 continue
             s = self._st(p)
-            dense.append((p.data, p.grad.contiguous(), s['m'], s['v'], p.numel()))
+            if p.data.is_contiguous() and s['m'].is_contiguous() and s['v'].is_contiguous():
+                dense.append((p.data, p.grad.contiguous(), s['m'], s['v'], p.numel()))
+            else:
+                # a strided parameter / slot on its own (only some members of a flat group carry a gradient): update
+                # contiguous copies and write them back after the launches below
+                pc, mc, vc = p.data.contiguous(), s['m'].contiguous(), s['v'].contiguous()
+                dense.append((pc, p.grad.contiguous(), mc, vc, p.numel()))
+                deferred.append((p, s, pc, mc, vc))
         sparse = []
         for layer in self.embedding_layers:
             for key, grads in layer.sparse_grads.items():
@@ -277,6 +312,10 @@ class KerasAdam:
         if dense_after:
             hook()
             self._dense_launch(dense, sp, st, advance=True)
+        for p, s, pc, mc, vc in deferred:
+            p.data.copy_(pc)
+            s['m'].copy_(mc)
+            s['v'].copy_(vc)
         for layer in self.embedding_layers:
             layer.sparse_grads.clear()
 
@@ -416,6 +455,7 @@ class TableBatches:
                  max_resident_bytes=32 << 30, ring=3, sample_weight=None):
         self.n = len(X)
         self.weighted = sample_weight is not None      # per-row loss weights ride as the LAST column of y
+        self.y_ndim = None
         self.device = torch.device(device)
         get = (lambda cols: X[cols].values) if hasattr(X, 'columns') else None
         host = []          # [(kind, host tensor)] in model input order: cat, var-len..., dense... (deepmodel.py:310)
@@ -436,6 +476,7 @@ class TableBatches:
             if task == consts.TASK_MULTICLASS and y.ndim == 1:
                 y = np.eye(num_classes, dtype=np.float32)[y.astype(np.int64)]
             y_host = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32))
+            self.y_ndim = y_host.dim()                 # weights ride as an extra column: remember y's own rank
             if sample_weight is not None:
                 w = torch.as_tensor(np.ascontiguousarray(np.asarray(sample_weight).reshape(-1), dtype=np.float32))
                 if w.shape[0] != y_host.shape[0]:

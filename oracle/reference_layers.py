@@ -136,6 +136,7 @@ def outer_product(xs, kernel, kernel_type='mat'):
 
 # set to a list by oracle/headline.py: every relu evaluation appends min |input|
 RELU_PROBE = None
+RELU_NEAR = None        # set to a list next to RELU_PROBE: per relu evaluation, how many inputs lie within 1e-6 rms of zero
 
 
 def _activation(name):
@@ -144,7 +145,11 @@ def _activation(name):
     if name == 'relu':
         if RELU_PROBE is not None:              # test infrastructure: how close does a relu input come to its kink?
             def probed_relu(t):
-                RELU_PROBE.append(float(t.detach().abs().min())) if t.numel() else None
+                if t.numel():
+                    a = t.detach().abs()
+                    RELU_PROBE.append(float(a.min()))
+                    if RELU_NEAR is not None:   # units within float32 rounding of the kink: |input| < 1e-6 of the tensor's rms
+                        RELU_NEAR.append(int(((a > 0) & (a < 1e-6 * float(a.pow(2).mean().sqrt()))).sum()))
                 return torch.relu(t)
             return probed_relu
         return torch.relu
@@ -255,11 +260,12 @@ def multihead_attention(x, w, num_heads=1, use_residual=True, training=True):
     w: dict with Q,K,V,(R): (kernel (D,D), bias (D,)), bn: (gamma, beta)."""
     if x.dim() != 3:
         raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {x.dim()}.')
-    q = torch.relu(x @ w['Q'][0] + w['Q'][1])                            # :123  Dense(relu)
-    k = torch.relu(x @ w['K'][0] + w['K'][1])                            # :124
-    v = torch.relu(x @ w['V'][0] + w['V'][1])                            # :125
+    relu = _activation('relu')                                           # torch.relu (probed under oracle/headline.py)
+    q = relu(x @ w['Q'][0] + w['Q'][1])                                  # :123  Dense(relu)
+    k = relu(x @ w['K'][0] + w['K'][1])                                  # :124
+    v = relu(x @ w['V'][0] + w['V'][1])                                  # :125
     if use_residual:
-        v_res = torch.relu(x @ w['R'][0] + w['R'][1])                    # :126-127
+        v_res = relu(x @ w['R'][0] + w['R'][1])                          # :126-127
     D = x.shape[-1]
     hs = D // num_heads
     Q_ = torch.cat(torch.split(q, hs, dim=2), dim=0)                     # :130
@@ -272,7 +278,8 @@ def multihead_attention(x, w, num_heads=1, use_residual=True, training=True):
     outputs = torch.cat(torch.split(outputs, x.shape[0], dim=0), dim=2)  # :145
     if use_residual:
         outputs = outputs + v_res                                        # :148-149
-    outputs = torch.relu(outputs)                                        # :150
+    outputs = torch.relu(outputs)                                        # :150 (a sum of non-negative terms: exactly 0 or
+                                                                         # positive in any precision, not a kink -> unprobed)
     gamma, beta = w['bn'][0], w['bn'][1]
     mm = w['bn'][2] if len(w['bn']) > 2 else None
     mv = w['bn'][3] if len(w['bn']) > 3 else None

@@ -966,6 +966,17 @@ def main():
                    'reduce_factors': [[a, b_] for a, b_ in zip(cin.f0_, cin.f__)]}
         case(f'cin_{tag}', out, 'cin', tensors, {'cross_layer_size': list(params['cross_layer_size']),
                                                  'activation': params['activation'], 'direct': params['direct']})
+    # (round 3, appended after everything above so earlier fixtures keep their random stream) whole models at the embedding
+    # widths the product's FAST kernels take: AutoInt at D = 16 and D = 32 lands on csrc/autoint.hip (the MFMA
+    # interacting-layer kernel; D = 8 above runs the VALU fallback of mha.hip), xDeepFM at D = 16 is replayed in the
+    # bf16-MFMA mode of the CIN (csrc/cin_bf16.hip) at north_star's 1e-2
+    run_model('autoint_d16', N.AutoInt, emb_dim=16, dnn_params=small,
+              autoint_params={'num_attention': 2, 'num_heads': 2, 'dropout_rate': 0, 'use_residual': True})
+    run_model('autoint_d32', N.AutoInt, emb_dim=32, dnn_params=small, vocab=(7, 5, 11, 4, 6, 9, 3),
+              autoint_params={'num_attention': 3, 'num_heads': 4, 'dropout_rate': 0, 'use_residual': True})
+    run_model('xdeepfm_d16', N.xDeepFM, emb_dim=16, dnn_params=small, batch=16,
+              cin_params={'cross_layer_size': (16, 12, 8), 'activation': 'relu', 'use_residual': False, 'use_bias': False,
+                          'direct': False, 'reduce_D': False})
     # ---- the plugin / configuration surface: what the reference's own config.py / metainfo.py / deepnets.py
     #      answer, recorded as JSON for tests/test_oracle_reference_code.py::test_drop_in_api_answers_like_the_reference
     def outcome(fn):

@@ -81,3 +81,53 @@ def test_xdeepfm_bf16_logits_within_1e2(dev):
     err = (logit.double().cpu() - ref_logit).abs().max().item()
     assert err < TOL, err
     assert torch.isfinite(loss).all()
+
+
+def test_xdeepfm_reference_code_fixture_in_bf16_mode(dev):
+    """The reference's OWN xDeepFM graph at D = 16 (tests/golden/reference_code_model_xdeepfm_d16.npz: deepmodel.py /
+    deepnets.py:69-81 / layers.py:638-734 imported unmodified, float64) replayed through the drop-in API with
+    cin_params['mfma_dtype'] = 'bf16': the bf16-MFMA CIN kernels against the reference code itself, not the oracle —
+    logit and output within north_star's 1e-2; the float32 default of the same fixture holds 1e-4
+    (tests/test_reference_models_gpu.py)."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_reference_code import GOLDEN as GOLDEN_DIR, load_model_fixture
+    from oracle import bridge          # only its weight loader
+    from oracle.reference_layers import _leaves, _map_leaves
+    meta, tensors, want = load_model_fixture(os.path.join(GOLDEN_DIR, 'reference_code_model_xdeepfm_d16.npz'))
+    static = copy.deepcopy(meta['static'])
+    static['config']['cin_params'] = dict(static['config']['cin_params'], mfma_dtype='bf16')
+    dm, ids, dense = bridge.model_from_reference_fixture(static, tensors, dev)
+    assert dm.config.cin_params['mfma_dtype'] == 'bf16'
+    dm.model.train()
+    logit = dm.model([ids.to(dev), dense.to(dev)])
+    got = torch.cat([logit, dm._activate(logit)], -1).detach().double().cpu()
+    err = (got - want).abs().max().item()
+    assert err < TOL * max(1.0, want.abs().max().item()), err
+    assert err > 1e-7          # and it is not the exact-fp32 path answering
+    # the train step's gradients in that mode against autograd through the reference's graph: relative L2 (a relu unit
+    # whose pre-activation lies within the bf16 error of zero takes the other derivative: rank-1 terms, see the layer test)
+    gmeta, gt, gwant = load_model_fixture(os.path.join(GOLDEN_DIR, 'reference_code_modelgrad_xdeepfm_d16.npz'))
+    gstatic = copy.deepcopy(gmeta['static'])
+    gstatic['config']['cin_params'] = dict(gstatic['config']['cin_params'], mfma_dtype='bf16')
+    from deeptables_amd.models import layers as dl
+    keep, dl.DENSE_GRAD_MAX_ELEMS = dl.DENSE_GRAD_MAX_ELEMS, 1 << 22
+    try:
+        dm, ids, dense = bridge.model_from_reference_fixture(gstatic, gt, dev)
+        dm.model.train()
+        dm.optimizer.zero_grad()
+        dm.forward_backward([ids.to(dev), dense.to(dev)], gt['y'].to(torch.float32).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = keep
+    leaves = _leaves(gt['weights'])
+    pieces = iter(torch.split(gwant, [t.numel() for t in leaves]))
+    grads = _map_leaves(gt['weights'], lambda t: next(pieces).reshape(t.shape))
+    num = den = 0.0
+    for p, g in bridge.param_pairs(dm, grads):
+        g = torch.as_tensor(g).double()
+        num += (p.grad.detach().double().cpu().reshape(g.shape) - g).pow(2).sum().item()
+        den += g.pow(2).sum().item()
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5

@@ -471,3 +471,53 @@ def test_fused_step_with_embedding_dropout_matches_oracle_with_the_same_mask(dev
     assert rel(table.grad, torch.cat([t.grad for t in tabs], 0)) < 2e-4
     # the step advanced the device seed: the next step draws another mask
     assert int(plan.drop_seed.item()) & 0xFFFFFFFF == (seed * 1664525 + 1013904223) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize('net,H1,H2', [('DeepFM', 100, 40), ('DCN', 32, 64)])
+def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2):
+    """once a fused plan with a narrow tower exists, the tower parameters and their Adam moments are
+    STRIDED views of zero-padded slabs.  A step with sample weights takes the layer-by-layer path and hands the optimizer
+    ordinary autograd gradients: the update must land on the right elements (and keep the pads zero), not treat the views
+    as contiguous.  Unweighted (fused) and weighted steps interleaved against a twin that never builds a plan; and a
+    weighted FIRST step does not build the plan as a side effect."""
+    from deeptables_amd.models import deepnets
+    F, Nd, D, B = 11, 5, 8, 300
+    extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+    hu = {'hidden_units': ((H1, 0, False), (H2, 0, False)), 'activation': 'relu'}
+    dm, cats = build(F, Nd, D, vocab=30, nets=getattr(deepnets, net), dnn_params=hu, **extra)
+    twin, _ = build(F, Nd, D, vocab=30, nets=getattr(deepnets, net), dnn_params=hu, **extra)
+    twin._fused_plan = None
+    with torch.no_grad():
+        for (n1, p1), (n2, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+            p2.copy_(p1)
+    dm.model.train(); twin.model.train()
+    g = torch.Generator().manual_seed(5)
+    # a weighted step first: no plan yet, and none is built by it
+    idx_s, dense_s, y_s = batch(cats, Nd, B, seed=40)
+    ins_s = [idx_s.int().to(dev), dense_s.to(dev)]
+    w0 = (torch.rand(B, generator=g) + 0.5).to(dev)
+    l1, _ = dm.train_step(ins_s, y_s.to(dev), w0)
+    l2, _ = twin.train_step(ins_s, y_s.to(dev), w0)
+    assert not hasattr(dm, '_fused_plan'), 'a weighted step built the fused plan'
+    assert abs(float(l1) - float(l2)) < 1e-5
+    for step in range(6):
+        idx_s, dense_s, y_s = batch(cats, Nd, B, seed=50 + step)
+        ins_s = [idx_s.int().to(dev), dense_s.to(dev)]
+        wts = (torch.rand(B, generator=g) + 0.5).to(dev) if step % 2 else None      # fused, weighted, fused, ...
+        l1, _ = dm.train_step(ins_s, y_s.to(dev), wts)
+        l2, _ = twin.train_step(ins_s, y_s.to(dev), wts)
+        assert abs(float(l1) - float(l2)) < 2e-5, step
+    plan = dm._fused_plan
+    assert plan is not None and twin._fused_plan is None
+    assert not dm.model.layers_by_name[('dcn' if net == 'DCN' else 'dnn') + '_dense_1'].kernel.data.is_contiguous() or H1 == 128
+    for (n1, p1), (_, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+        assert rel(p1, p2) < 5e-4, n1
+    C = F * D + Nd
+    o = plan.off
+    st = dm.optimizer._flat
+    for flat in (plan.flat_params, st[2], st[3]):
+        W1 = flat[o['dW1']:o['dW1'] + C * 128].view(C, 128)
+        W2 = flat[o['dW2']:o['dW2'] + 128 * 64].view(128, 64)
+        assert W1[:, H1:].abs().sum().item() == 0 and W2[H1:].abs().sum().item() == 0 and W2[:, H2:].abs().sum().item() == 0
+        assert flat[o['db1'] + H1:o['db1'] + 128].abs().sum().item() == 0
+        assert flat[o['db2'] + H2:o['db2'] + 64].abs().sum().item() == 0

@@ -22,6 +22,20 @@ def _check(res, tol_grad=2e-4, plan='FusedDeepFM'):
     assert res['untouched_rows_unchanged'], res
 
 
+def _check_layer_path(res, n_dense):
+    """xDeepFM / AutoInt run layer by layer (no whole-step plan): the same figures, gradients judged by
+    oracle/headline.verdict (relu kinks of the CIN filters / attention projections, see there)"""
+    from oracle import headline
+    assert res['gather_bit_exact'] and res['rows_identical'], res
+    assert res['max_abs_logit_err'] < 1e-4 * max(1.0, res['max_abs_logit']), res
+    assert res['loss_abs_err'] < 1e-5, res
+    assert res['dense_grads_checked'] == n_dense, res
+    good, rule = headline.verdict(res)
+    assert good, (rule, res)
+    assert res['adam_rows_rel_err'] < 1e-3 and res['adam_dense_rel_err'] < 1e-3, res
+    assert res['untouched_rows_unchanged'], res
+
+
 @pytest.mark.parametrize('dist', ['uniform', 'zipf'])
 def test_headline_config_matches_oracle(dev, dist):
     import bench
@@ -53,6 +67,39 @@ def test_dcn_config_matches_oracle(dev, dist):
         bench.N_BATCHES = keep
     res = headline.check_train_step(dm, batches[0])
     _check(res, plan='FusedDCN')
+
+
+def test_xdeepfm_config_matches_oracle(dev):
+    """bench.py --model xDeepFM (CIN 3 x 128, direct=False, deepnets.py:69-81, layers.py:638-734) at the size it is timed:
+    B = 8192, 26 x 1 M rows, row-sparse Adam.  Logits, the CIN filter / exFM_out / tower gradients, the per-lookup row
+    gradients and one Adam step against the float64 oracle."""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.xDeepFM, dev, None, bench.D, bench.MODEL_PARAMS.get('xDeepFM'))
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind='uniform')
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    _check_layer_path(res, n_dense=15)
+
+
+def test_autoint_config_matches_oracle(dev):
+    """bench.py --model AutoInt (3 interacting layers x 4 heads, D = 32, deepnets.py:210-224, layers.py:104-153) at
+    B = 8192: logits, every projection / BatchNormalization gradient (through autoint.hip), row gradients, one Adam step."""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.AutoInt, dev, None, 32, bench.MODEL_PARAMS.get('AutoInt'))
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind='uniform')
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    _check_layer_path(res, n_dense=32)
 
 
 def test_headline_config_float32_ids_second_step(dev):

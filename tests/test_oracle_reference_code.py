@@ -48,7 +48,9 @@ def test_fixture_set_is_complete():
             'model_widedeep', 'model_pnn', 'model_afm', 'model_fibinet', 'model_fgcnn', 'model_opnn_ipnn_vec',
             'model_cross_and_cross_dnn', 'model_fibi_nets_flattened', 'model_fibi_nets_alone', 'model_fgcnn_cin_fm',
             'model_fgcnn_afm_ipnn', 'model_deepfm_concat_nobias', 'model_deepfm_regression', 'model_dnn_multiclass',
-            'model_deepfm_bn_tower', 'model_deepfm_no_dense', 'model_dnn_var_len'} <= names
+            'model_deepfm_bn_tower', 'model_deepfm_no_dense', 'model_dnn_var_len',
+            # ... and (round 3) the embedding widths the product's fast kernels take: autoint.hip (D = 16 / 32), cin_bf16.hip
+            'model_autoint_d16', 'model_autoint_d32', 'model_xdeepfm_d16'} <= names
     # every whole model also has its loss gradients (autograd through the reference's graph)
     assert {n.replace('model_', 'modelgrad_', 1) for n in names if n.startswith('model_')} <= names
 

@@ -1,7 +1,7 @@
 # -*- coding:utf-8 -*-
 """GPU: the HIP path against outputs of the REFERENCE'S OWN CODE for whole models.
 
-tests/golden/reference_code_model_*.npz hold, for 21 model configurations (the five of BASELINE.json, every preset of
+tests/golden/reference_code_model_*.npz hold, for 25 model configurations (the five of BASELINE.json, every preset of
 deepnets.py, every net function, stacking add / concat, binary / regression / multiclass heads, a BatchNormalization
 tower, no continuous inputs), the inputs, the weights and the output of the reference's DeepModel.__build_model graph as
 the reference's own source computes it (tests/golden/make_reference_golden.py: deepmodel.py / deepnets.py / layers.py
@@ -22,10 +22,11 @@ from test_oracle_reference_code import GRAD_FIXTURES, MODEL_FIXTURES, load_model
 
 pytestmark = pytest.mark.gpu
 
-# the variable-length-column model joined the fixture set after round 2's GPU budget was spent: it is replayed against the
-# oracle and the drop-in graph on CPU (tests/test_oracle_reference_code.py); its GPU replay starts with round 3
-MODEL_FIXTURES = [f for f in MODEL_FIXTURES if 'var_len' not in os.path.basename(f)]
-GRAD_FIXTURES = [f for f in GRAD_FIXTURES if 'var_len' not in os.path.basename(f)]
+def _inputs(ids, dense, tensors, dev, idx_dtype=torch.float32):
+    """model inputs in the reference's order: categorical ids, the variable-length id blocks, the continuous block
+    (deepmodel.py:310-311, 363-385)"""
+    vl = [v.to(idx_dtype).to(dev) for v in (tensors.get('var_len_idx') or [])]
+    return [ids.to(idx_dtype).to(dev)] + vl + ([] if dense is None else [dense.to(dev)])
 
 
 @pytest.mark.parametrize('idx_dtype', ['float32', 'int32'])
@@ -35,7 +36,7 @@ def test_hip_forward_matches_the_reference_codes_output(dev, path, idx_dtype):
     meta, tensors, want = load_model_fixture(path)
     dm, ids, dense = bridge.model_from_reference_fixture(meta['static'], tensors, dev)
     dm.model.train()                   # the fixtures are training-mode forwards (batch statistics in every BatchNormalization)
-    inputs = [ids.to(getattr(torch, idx_dtype)).to(dev)] + ([] if dense is None else [dense.to(dev)])
+    inputs = _inputs(ids, dense, tensors, dev, getattr(torch, idx_dtype))
     logit = dm.model(inputs)
     out = dm._activate(logit)
     got = torch.cat([logit, out], -1).detach().double().cpu()
@@ -57,7 +58,7 @@ def test_hip_backward_matches_the_reference_codes_gradients(dev, path, monkeypat
     meta, tensors, want = load_model_fixture(path)
     dm, ids, dense = bridge.model_from_reference_fixture(meta['static'], tensors, dev)
     dm.model.train()
-    inputs = [ids.to(dev)] + ([] if dense is None else [dense.to(dev)])
+    inputs = _inputs(ids, dense, tensors, dev)
     y = tensors['y'].to(torch.float32).to(dev)
     dm.optimizer.zero_grad()
     loss, _ = dm.forward_backward(inputs, y)
