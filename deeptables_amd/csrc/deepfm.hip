@@ -152,23 +152,40 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     const int D = 4 * LPR;
     const int b = blockIdx.x * RPB + wave;
     if (b < dm.B) {
-        float4 v[2];
+        // two dependent memory round trips for BOTH of the lane's float4 slots: (ids, vocabulary sizes, row offsets), then
+        // the two table rows.  Every load is unconditional from a clamped (valid) address and zeroed afterwards: guarded
+        // loads made the compiler close each slot's region with s_waitcnt vmcnt(0) — six round trips in a row (round 2's
+        // ISA reading).
+        int id[2], voc[2], fld[2];
+        int64_t roff[2];
+        bool in[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = lane + 64 * t;
-            v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < NV) {
-                const int f = j / LPR;
-                const int id = load_id<KIND>(idx, (int64_t)b * dm.F + f);
-                const bool ok = (unsigned)id < (unsigned)vocab[f];
-                const int64_t row = ok ? row_offset[f] + id : (int64_t)-1;
-                if (ok) v[t] = table[row * LPR + c];
-                if (c == 0) {
-                    const int64_t occ = (int64_t)b * dm.F + f;
-                    if (dd.rows_fm) dd.rows_fm[(int64_t)f * dm.B + b] = row;     // for the election blocks of k_prep (see DedupeWs)
-                    rows_out[occ] = row;
-                    if (!ok && oob) atomicAdd(oob, 1);
-                }
+            in[t] = j < NV;
+            fld[t] = min(j, NV - 1) / LPR;
+            id[t] = load_id<KIND>(idx, (int64_t)b * dm.F + fld[t]);
+            voc[t] = vocab[fld[t]];
+            roff[t] = row_offset[fld[t]];
+        }
+        const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
+        float4 v[2];
+        int64_t row[2];
+        bool ok[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ok[t] = in[t] && (unsigned)id[t] < (unsigned)voc[t];
+            row[t] = ok[t] ? roff[t] + id[t] : (int64_t)-1;
+            v[t] = table[(ok[t] ? row[t] : 0) * LPR + c];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!ok[t]) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c == 0 && in[t]) {
+                const int64_t occ = (int64_t)b * dm.F + fld[t];
+                if (dd.rows_fm) dd.rows_fm[(int64_t)fld[t] * dm.B + b] = row[t];     // for the election blocks (see DedupeWs)
+                rows_out[occ] = row[t];
+                if (!ok[t] && oob) atomicAdd(oob, 1);
             }
         }
         DT_STAMP(stamps, 1);
@@ -180,7 +197,6 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
                 if (j < NV) v[t] = emb_drop4(v[t], seed, drop.thr, drop.inv_keep, (unsigned)b, (unsigned)(4 * j));
             }
         }
-        const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
         float lp = (wlin && lane < dm.Nd) ? dv * wlin[dm.F + lane] : 0.f;
         float4 S = make_float4(0.f, 0.f, 0.f, 0.f), Q = S;
         float* xrow = X + (int64_t)b * dm.CP;
@@ -1044,20 +1060,33 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) wc[l][k] = l <= L ? src[64 * k + lane] : 0.f;
             }
-#pragma unroll 2
+            // no `l <= L` guard: the coefficient columns beyond L are zero and so is wc[l] (round 2's ISA reading: the
+            // guards became 62 branches, each guarded term read its coefficient with a scalar ds_read_b32 + s_waitcnt — 72
+            // exposed LDS latencies per wave).  A row's coefficients arrive as three 16-byte broadcast reads, the next
+            // row's before this row's stores.
+            static_assert(LC + 1 <= 12, "three float4 of coefficients per row");
+            floatx4 cq[2][3];
+            {
+                const int row0 = wave * (kTM / 4);
+                cq[0][0] = ld4(crF + row0 * 16); cq[0][1] = ld4(crF + row0 * 16 + 4); cq[0][2] = ld4(crF + row0 * 16 + 8);
+            }
+#pragma unroll
             for (int r8 = 0; r8 < kTM / 4; ++r8) {
                 const int row = wave * (kTM / 4) + r8;
                 const int64_t m = m0 + row;
+                if (r8 + 1 < kTM / 4) {
+                    cq[(r8 + 1) & 1][0] = ld4(crF + (row + 1) * 16);
+                    cq[(r8 + 1) & 1][1] = ld4(crF + (row + 1) * 16 + 4);
+                    cq[(r8 + 1) & 1][2] = ld4(crF + (row + 1) * 16 + 8);
+                }
                 float acc[NCH];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
 #pragma unroll
                 for (int l = 0; l <= LC; ++l) {
-                    if (l <= L) {
-                        const float cf = crF[row * 16 + l];
+                    const float cf = cq[r8 & 1][l >> 2][l & 3];
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k) acc[k] += cf * wc[l][k];
-                    }
+                    for (int k = 0; k < NCH; ++k) acc[k] += cf * wc[l][k];
                 }
                 if (m < dm.B) {
 #pragma unroll
