@@ -138,8 +138,11 @@ class GraphedStep:
 
     def _body(self, b):
         dm = self.dm
-        loss, logit = dm.forward_backward([b[0], b[1]], b[2])   # fused plan when the graph has one
-        if self.with_optimizer and not self._dp:
+        fused_opt = self.with_optimizer and not self._dp
+        # fused plan when the graph has one; apply_rows: optimizer.step() follows at once (DeepModel.train_step's order),
+        # so the DeepFM step applies the update of the rows looked up once inside its own kernels
+        loss, logit = dm.forward_backward([b[0], b[1]], b[2], apply_rows=fused_opt and self.strategy is None)
+        if fused_opt:
             dm.optimizer.step()          # single GPU: the Adam step is part of the captured graph
         self.loss = loss
 

@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// address of lr_t (the bias-corrected rate the CURRENT step uses) inside the device-resident Adam step state (optim.hip)
+const float* adam_state_lr_t(const void* state);
+
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

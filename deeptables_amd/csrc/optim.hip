@@ -37,6 +37,8 @@ __device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, int t) 
     return lr * sqrtf(1.0f - powf(b2, (float)t)) / (1.0f - powf(b1, (float)t));
 }
 
+const float* adam_state_lr_t(const void* state) { return &reinterpret_cast<const AdamState*>(state)->lr_t; }
+
 __global__ void k_adam_state_init(AdamState* st, float lr, float b1, float b2, int steps_done) {
     st->t = steps_done + 1;
     st->lr_t = adam_lr_t(lr, b1, b2, steps_done + 1);
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
                                                          const int* __restrict__ mark, float lr_host,
                                                          AdamState* __restrict__ st, float b1, float b2, float eps,
                                                          int row_blocks, DenseTail tail, int advance, float lr,
-                                                         int sstride, SegTail seg) {
+                                                         int sstride, SegTail seg, int segments_only) {
     unsigned ticket;
     const float lr_t = adam_read_lr(st, lr_host, advance, ticket);
     if ((int)blockIdx.x >= row_blocks) {      // trailing blocks: the model's dense parameters (one flat buffer)
@@ -413,7 +415,8 @@ __global__ __launch_bounds__(256) void k_adam_rows_owner(float* __restrict__ tab
         // state's arrival ticket: +6 us for 1024 of them); a wave's region count is loaded before its own rows
         int nseg0 = 0;
         if (VW == 4 && seg.nseg) nseg0 = seg.nseg[((int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % seg.regions];
-        adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
+        // segments_only: the rows looked up once were updated inside the train step (dt_deepfm_train_step_adam)
+        if (!segments_only) adam_rows_owner_body<VW>(table, m, v, rows, values, n, D, slots, mark, lr_t, b1, b2, eps, sstride);
         if (VW == 4 && seg.nseg) adam_segments(seg, row_blocks, nseg0, table, m, v, values, D, lr_t, b1, b2, eps, sstride);
     }
     adam_finish(st, ticket, lr, b1, b2);
@@ -631,7 +634,15 @@ extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int
                                      float lr, const int* seg_nseg, const int64_t* seg_row, const int* seg_off,
                                      const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
                                      void* stream) {
-    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -1 && dense_n >= 0, "dt_adam_rows_step: bad sizes");
+    DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -2 && dense_n >= 0, "dt_adam_rows_step: bad sizes");
+    // fields == -2: as -1 (rows distinct) AND the rows with an entry in `rows` were already updated inside the train step
+    // (dt_deepfm_train_step_adam): only the segments and the dense tail are left
+    const int segments_only = fields == -2 ? 1 : 0;
+    if (segments_only) {
+        fields = -1;
+        DT_REQUIRE(D % 4 == 0, "dt_adam_rows_step_seg: fields = -2 needs D %% 4 == 0 (D=%d)", D);
+        if (!seg_nseg) n_rows = 0;            // nothing sparse left: the dense tail runs as a plain dense step
+    }
     DT_REQUIRE(!advance || state, "dt_adam_rows_step: advance needs the device state");
     DT_REQUIRE(dense_n == 0 || (dense_p && dense_g && dense_m && dense_v), "dt_adam_rows_step: null dense tail");
     if (n_rows == 0)      // nothing sparse this step: the tail (and the advance) run as a plain dense step
@@ -686,15 +697,18 @@ extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int
         }
     }
     if (D % 4 == 0) {
-        const int row_blocks = (int)((n_rows * (D / 4) + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
+        int row_blocks = (int)((n_rows * (D / 4) + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
+        // segments only: enough waves to walk the regions (every block takes the state's arrival ticket: few blocks)
+        static const int seg_blocks_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
+        if (segments_only) row_blocks = row_blocks < 512 ? row_blocks : (seg_blocks_env > 0 ? seg_blocks_env : 512);
         hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st,
                            table, m, v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail,
-                           advance, lr, sstride, seg);
+                           advance, lr, sstride, seg, segments_only);
     } else {
         const int row_blocks = (int)((n_rows * D + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
         hipLaunchKernelGGL(k_adam_rows_owner<1>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st, table, m,
                            v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail, advance,
-                           lr, sstride, seg);
+                           lr, sstride, seg, 0);
     }
     return launch_status("dt_adam_rows_step");
 }

@@ -80,6 +80,21 @@ def _dedupe_in_step(plan, B, backward):
     return not plan.emb.uses_dense_grad(plan.D)
 
 
+def _rows_in_step(plan, B, backward, apply_rows):
+    """The pipelined DeepFM step can apply the optimizer's row-sparse update to the rows looked up once INSIDE the step
+    (dt_deepfm_train_step_adam): only when the caller promises `optimizer.step()` follows at once (DeepModel.train_step),
+    the in-step dedupe is on (single process, row-sparse table, B <= 8192), the optimizer is the library's KerasAdam with
+    nothing between the gradient and its update (no pending all-reduce hook), and DT_AMD_ROWS_IN_STEP != 0."""
+    if not (apply_rows and backward and plan.dm.model.training and _dedupe_in_step(plan, B, backward)):
+        return None
+    if os.environ.get('DT_AMD_ROWS_IN_STEP', '1') == '0' or os.environ.get('DT_STEP_PIPE', '1') == '0':
+        return None
+    opt = getattr(plan.dm, 'optimizer', None)
+    if not getattr(opt, 'supports_rows_in_step', False) or getattr(opt, 'pre_dense_hook', None) is not None:
+        return None
+    return opt
+
+
 def _segments(buf, B, F):
     seg = buf.get('segments')
     if seg is None:
@@ -269,9 +284,11 @@ class FusedDeepFM:
         self.dm.model._dt_sharded_step = True
         return self.loss_view, buf['logit']
 
-    def run(self, idx, dense, y, backward=True):
+    def run(self, idx, dense, y, backward=True, apply_rows=False):
         """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
-        (views of one static buffer) and registers the embedding table's sparse gradient."""
+        (views of one static buffer) and registers the embedding table's sparse gradient.  apply_rows=True: the caller
+        runs `optimizer.step()` right after this call, so the step may update the table rows looked up once itself
+        (`_rows_in_step`); the registered sparse gradient then carries `fields = -2` (segments only)."""
         st = self.dm.config.distribute_strategy
         if backward and getattr(st, 'sharded_embeddings', False) and st.active and \
                 not self.emb.uses_dense_grad(self.D):
@@ -288,24 +305,34 @@ class FusedDeepFM:
         table = self.emb.tables[self.key]
         training = self.dm.model.training
         dedupe = _dedupe_in_step(self, B, backward)
-        check(lib().dt_deepfm_train_step(
-            ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
-            ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
-            ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
-            ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
-            float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
-            ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
-            ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            ptr(self.emb.oob_count) if self.emb.check_oob else None,
-            ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'], 1.0, 0,
-            (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
-            'dt_deepfm_train_step')
+        opt = _rows_in_step(self, B, backward, apply_rows)
+        head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
+                ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
+                ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
+                ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
+                float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
+                ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
+                ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(self.emb.oob_count) if self.emb.check_oob else None,
+                ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
+        if opt is not None:
+            # the rows looked up once are updated where their gradient is formed (csrc/deepfm.hip k_wgrad_rows)
+            slots = opt._st(table, rows=True)
+            check(lib().dt_deepfm_train_step_adam(
+                *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
+                opt.b1, opt.b2, opt.eps, stream_ptr()), 'dt_deepfm_train_step_adam')
+        else:
+            check(lib().dt_deepfm_train_step(
+                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
+                ptr(self.drop_seed), stream_ptr()), 'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
-            # with the in-step dedupe: rows looked up once keep their entry, the others travel as segments
+            # with the in-step dedupe: rows looked up once keep their entry, the others travel as segments; fields = -2:
+            # the entries of `rows` were applied inside the step, the optimizer only walks the segments
             self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
-                                                             fields=-1 if dedupe else None,
+                                                             fields=(-2 if opt is not None else -1) if dedupe else None,
                                                              segments=_segments(buf, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
@@ -430,7 +457,7 @@ class FusedDCN(FusedDeepFM):
             self._bufs[B] = b
         return b
 
-    def run(self, idx, dense, y, backward=True):
+    def run(self, idx, dense, y, backward=True, apply_rows=False):
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)

@@ -257,9 +257,11 @@ class DeepModel:
             self._fused_plan = make_fused_plan(self)
         return self._fused_plan
 
-    def forward_backward(self, inputs, y, sample_weight=None):
+    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False):
         """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
-        sample_weight [B] (Keras fit's sample_weight x class_weight): the weighted loss runs on the layer-by-layer path."""
+        sample_weight [B] (Keras fit's sample_weight x class_weight): the weighted loss runs on the layer-by-layer path.
+        apply_rows=True is the caller's promise that `self.optimizer.step()` follows immediately (train_step): a fused
+        plan may then apply the row-sparse update of the table rows looked up once inside its own kernels."""
         plan = self.fused_plan() if (self.model.training and sample_weight is None) else None
         self.optimizer.zero_grad(flat=plan is None) if hasattr(self.optimizer, 'register_flat_group') \
             else self.optimizer.zero_grad()
@@ -267,7 +269,7 @@ class DeepModel:
         if plan is not None:
             cat = inputs[0]
             dense = inputs[1] if len(inputs) > 1 else None
-            loss, logit = plan.run(cat, dense, y)
+            loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit
         # generic path: the dense gradients accumulate in the model-wide flat buffer (None without one)
@@ -281,8 +283,8 @@ class DeepModel:
 
     def train_step(self, inputs, y, sample_weight=None):
         """forward -> loss -> backward -> (data-parallel gradient exchange) -> optimizer step."""
-        loss, logit = self.forward_backward(inputs, y, sample_weight)
         strategy = self.config.distribute_strategy
+        loss, logit = self.forward_backward(inputs, y, sample_weight, apply_rows=strategy is None)
         if strategy is not None:
             strategy.exchange_gradients(self.model, self.optimizer)
         self.optimizer.step()

@@ -83,6 +83,7 @@ class KerasAdam:
     with the right bias correction."""
 
     supports_row_segments = True      # takes SparseRowGrad.segments (dt_adam_rows_step_seg)
+    supports_rows_in_step = True      # a fused step may apply the update of the rows looked up once itself (fields = -2)
     _name = 'Adam'
 
     def __init__(self, params, embedding_layers=(), learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
@@ -285,10 +286,12 @@ class KerasAdam:
             if hints != {None}:                           # an explicit layout promise overrides the layer default
                 fields = hints.pop() if len(hints) == 1 else 0
                 fields = 0 if fields is None else int(fields)
+            if fields == -2 and len(grads) != 1:
+                raise ValueError('a sparse gradient whose rows were applied inside the step cannot be concatenated')
             if fields == -1 and len(grads) != 1:
                 fields = 0                                # distinct within each piece only
             values = values if values.is_contiguous() else values.contiguous()
-            if fields == -1:
+            if fields in (-1, -2):
                 slots = mark = None
                 n_slots = 0
             else:

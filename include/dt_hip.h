@@ -409,6 +409,27 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
                          int* oob_count, void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale,
                          int grad_rows_field_major, int phases, float embedding_dropout, unsigned* dropout_seed,
                          void* stream);
+/* dt_deepfm_train_step_adam — the same step with the optimizer's row-sparse update fused into it (replaces, for the looked-up
+ * table rows, the `apply_gradients` half of keras.Model.train_step that DeepModel.fit drives, deepmodel.py:114-129 with
+ * the Adam of :321-322).  `table` is updated IN PLACE for every row looked up exactly once in the batch (Keras-Adam
+ * read-modify-write of p and its slots adam_m / adam_v right where the row's gradient is formed: the gradient row never
+ * reaches HBM); slot_stride = floats between the slot records of consecutive rows (D: two [V,D] arrays, 2 D: one
+ * [V,2,D] array with v == m + D); adam_state = the device step state of dt_adam_state_init (lr_t is read from it; NULL:
+ * the scalar lr_t).  Needs phases == 2 (| DT_STEP_LOSS_MSE) and dedupe_ws: rows looked up several times leave as
+ * segments (their members' gradient rows in grad_rows, rows_out == -1) and are updated, together with the dense
+ * parameters and the state's advance, by dt_adam_rows_step_seg(..., fields = -2, ...) — which skips the entries of
+ * `rows` (already applied here). */
+int dt_deepfm_train_step_adam(const void* idx, int idx_kind, float* table, const int64_t* row_offset,
+                              const int32_t* vocab, const float* dense, const float* y, int B, int F, int D,
+                              int Nd, const float* w_lin, const float* bn_gamma, const float* bn_beta,
+                              float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum,
+                              const float* W1, const float* b1, const float* W2, const float* b2,
+                              const float* w3, const float* w_out, const float* b_out, float* logit_out,
+                              int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
+                              int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
+                              float embedding_dropout, unsigned* dropout_seed, float* adam_m, float* adam_v,
+                              int slot_stride, const void* adam_state, float lr_t, float beta1, float beta2, float eps,
+                              void* stream);
 /* embedding_dropout > 0 (ModelConfig.embedding_dropout, config.py:84: SpatialDropout1D on every [B,1,D] embedding =
  * element dropout scaled by 1/(1-p)): element (b, f, d) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b, f*D+d) >=
  * p * 2^32.  *dropout_seed is a DEVICE word, advanced by the step itself (so a captured graph draws a fresh mask at every

@@ -276,6 +276,89 @@ def _check_once(dm, batch, adam, lr, accept):
     return res
 
 
+def check_rows_in_step(dm, batch, steps=1):
+    """The in-step row update (dt_deepfm_train_step_adam: DeepModel.train_step applies Keras Adam to the table rows looked
+    up once INSIDE the step's last launch, the optimizer launch only walks the segments) against the SEPARATE path
+    `check_train_step` pins to the oracle (forward_backward, then optimizer.step over every lookup's gradient row), on one
+    model: snapshot -> separate path -> record -> restore -> in-step path -> compare the touched table rows, their m / v
+    slots, every dense parameter and the optimizer's step count.  -> dict of error figures (absolute, on parameters
+    ~5e-2 moved by steps of ~1e-3).  Checker only: nothing here is timed."""
+    idx, dense, y = batch
+    emb = dm.model.layers_by_name['emb_categorical_vars_all']
+    D = emb.groups[0][0]
+    key = f'd{D}'
+    table = emb.tables[key]
+    opt = dm.optimizer
+    plan = dm.fused_plan()
+    assert plan is not None
+    dm.model.train()
+    ins = [idx, dense] if dense is not None else [idx]
+    rows = (idx.long() + getattr(emb, f'row_offset_{key}')[None, :].long()).reshape(-1).unique()
+    slots = opt._st(table, rows=True)
+    dense_ps = [p for _, p in dense_parameters(dm)]
+
+    def snap():
+        st = {'rows': table.detach()[rows].clone(), 'm': slots['m'][rows].clone(), 'v': slots['v'][rows].clone(),
+              'dense': [p.detach().clone() for p in dense_ps],
+              'dm': [opt._st(p)['m'].clone() for p in dense_ps], 'dv': [opt._st(p)['v'].clone() for p in dense_ps],
+              'bn': [b.detach().clone() for b in dm.model.buffers()], 't': opt.t}
+        if hasattr(plan, 'drop_seed'):
+            st['seed'] = plan.drop_seed.clone()
+        return st
+
+    def restore(st):
+        with torch.no_grad():
+            table.data[rows] = st['rows']
+            slots['m'][rows] = st['m']
+            slots['v'][rows] = st['v']
+            for p, v, m_, v_ in zip(dense_ps, st['dense'], st['dm'], st['dv']):
+                p.data.copy_(v)
+                opt._st(p)['m'].copy_(m_)
+                opt._st(p)['v'].copy_(v_)
+            for b, v in zip(dm.model.buffers(), st['bn']):
+                b.copy_(v)
+            if 'seed' in st:
+                plan.drop_seed.copy_(st['seed'])
+        opt.t = st['t']
+
+    s0 = snap()
+    for _ in range(steps):
+        dm.forward_backward(ins, y)
+        opt.step()
+    torch.cuda.synchronize()
+    a = snap()
+    restore(s0)
+    took = []
+    for _ in range(steps):
+        dm.forward_backward(ins, y, apply_rows=True)
+        sg = emb.sparse_grads.get(key) or []
+        took.append(bool(sg) and all(getattr(g, 'fields', None) == -2 for g in sg))
+        opt.step()
+    torch.cuda.synchronize()
+    b = snap()
+
+    def err(x, y_):
+        return (x.double() - y_.double()).abs().max().item() if x.numel() else 0.0
+
+    def rel(x, y_):
+        return err(x, y_) / max(x.double().abs().max().item(), 1e-300) if x.numel() else 0.0
+    res = {'rows_in_step_taken': all(took), 'rows_checked': int(rows.numel()),
+           'rows_moved': (a['rows'] - s0['rows']).abs().max().item(),
+           'table_abs_err': err(a['rows'], b['rows']), 'm_rel_err': rel(a['m'], b['m']), 'v_rel_err': rel(a['v'], b['v']),
+           'dense_abs_err': max(err(x, y_) for x, y_ in zip(a['dense'], b['dense'])),
+           'steps_counted': (a['t'], b['t'])}
+    return res
+
+
+def rows_in_step_ok(res):
+    """both paths form the same gradient with the same kernels; the update rule runs in two different kernels (fused
+    multiply-add contraction may differ by an ulp): parameters within 1e-7 absolute (values ~5e-2, steps ~1e-3), slots
+    within 1e-5 of their largest entry"""
+    return bool(res['rows_in_step_taken'] and res['rows_moved'] > 0 and res['table_abs_err'] <= 1e-7 and
+                res['m_rel_err'] <= 1e-5 and res['v_rel_err'] <= 1e-5 and res['dense_abs_err'] <= 1e-7 and
+                res['steps_counted'][0] == res['steps_counted'][1])
+
+
 def verdict(res, grad_tol=2e-4):
     """The acceptance rule bench.py's `parity` leg and tests/test_headline_gpu.py share.  Gather bit-exact, the same set of
     table rows, logits within north_star's 1e-4 (of max(1, max |logit|)), gradients within `grad_tol` of each tensor's

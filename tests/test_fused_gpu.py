@@ -14,7 +14,8 @@ def build(F, Nd, D, vocab, seed=3, use_bias=True, nets=None, task='binary', **ex
     from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
     functional.set_seed(seed)
     conf = ModelConfig(nets=nets or deepnets.DeepFM, fixed_embedding_dim=True, embeddings_output_dim=D,
-                       embedding_dropout=0, metrics=['AUC'], output_use_bias=use_bias, **extra)
+                       embedding_dropout=extra.pop('embedding_dropout', 0), metrics=['AUC'], output_use_bias=use_bias,
+                       **extra)
     cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
     conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])] if Nd else []
     dm = DeepModel(task, 2 if task == 'binary' else 1, conf, cats, conts)
@@ -521,3 +522,22 @@ def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2):
         assert W1[:, H1:].abs().sum().item() == 0 and W2[H1:].abs().sum().item() == 0 and W2[:, H2:].abs().sum().item() == 0
         assert flat[o['db1'] + H1:o['db1'] + 128].abs().sum().item() == 0
         assert flat[o['db2'] + H2:o['db2'] + 64].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize('vocab,B,F,D,drop', [(30, 256, 26, 16, 0.0), (5000, 1000, 26, 16, 0.0), (5000, 513, 26, 16, 0.3),
+                                              (200000, 4096, 26, 16, 0.0), (3000, 300, 7, 32, 0.0), (900, 77, 5, 8, 0.0)])
+def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab, B, F, D, drop):
+    """DeepModel.train_step on the pipelined DeepFM step applies Keras Adam to the table rows looked up once inside the
+    step (dt_deepfm_train_step_adam, k_wgrad_rows) and leaves only the segments to the optimizer launch: same tables,
+    slots, dense parameters and step count as forward_backward + optimizer.step over every lookup's gradient row — from
+    many duplicates (vocab 30: almost every lookup is a segment member) to almost none, ragged tiles, with dropout."""
+    from deeptables_amd.models import layers as L
+    from oracle import headline
+    monkeypatch.setattr(L, 'DENSE_GRAD_MAX_ELEMS', 0)          # row-sparse ("lazy") update also on these small tables
+    dm, cats = build(F, 13, D, vocab=vocab, embedding_dropout=drop)
+    assert type(dm.fused_plan()).__name__ == 'FusedDeepFM'
+    for seed in (5, 6):                                        # two batches: the second one starts from non-zero slots
+        idx, dense, y = batch(cats, 13, B, seed=seed)
+        res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2)
+        assert headline.rows_in_step_ok(res), res
+        dm.train_step([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))   # move on (in-step path)

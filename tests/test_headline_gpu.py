@@ -120,3 +120,22 @@ def test_headline_config_float32_ids_second_step(dev):
     res2 = headline.check_train_step(dm, batches[1], adam=True)      # t = 2: only fwd/bwd figures are closed-form
     assert res2['max_abs_logit_err'] < 1e-4 and res2['rows_identical'] and res2['rows_grad_rel_err'] < 2e-4, res2
     assert res2['untouched_rows_unchanged'], res2
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'zipf'])
+def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist):
+    """what bench.py times since round 3: the step with the rows looked up once updated inside it
+    (dt_deepfm_train_step_adam) — same table rows, slots and dense parameters as the oracle-checked separate path"""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.DeepFM, dev)
+    bench.N_BATCHES, keep = 2, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind=dist)
+    finally:
+        bench.N_BATCHES = keep
+    for b in batches:
+        res = headline.check_rows_in_step(dm, b)
+        assert headline.rows_in_step_ok(res), res
+        dm.train_step([b[0], b[1]], b[2])
