@@ -1888,15 +1888,19 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     const float* __restrict__ H1, const float* __restrict__ dH1,
                                                     const float* __restrict__ dH2, int row_blocks, int rows_per_block,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
-                                                    RowsEpi ep, RowsAdam ad, EmbDrop drop) {
+                                                    RowsEpi ep, RowsAdam ad, EmbDrop drop,
+                                                    unsigned long long* stamps_rows) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
     __shared__ unsigned arrived;
     if (threadIdx.x == 0) arrived = 0u;
     __syncthreads();          // the only hardware barrier: the two halves never wait for each other afterwards
     if (threadIdx.x < 256)
         wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
-    else
+    else {
+        if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
         rows_epilogue<DCN>((int)threadIdx.x - 256, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
+        if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 }  // namespace dt
@@ -2168,7 +2172,8 @@ static int tower_train_step(
         hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
         hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                            ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
-                           stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop);
+                           stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
+                           stamps ? stamps + (int64_t)tiles * 16 : nullptr);
         // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
         hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
                            accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);

@@ -11,8 +11,11 @@ model = os.environ.get('MODEL', 'DeepFM')
 dm = bench.build_model(getattr(deepnets, model), dev, None, bench.D, bench.MODEL_PARAMS.get(model))
 batches = bench.make_batches(8192, dev, 1)
 dm.model.train()
-for i in range(5):
-    dm.forward_backward([batches[i][0], batches[i][1]], batches[i][2])
+for i in range(5):       # ROWS=1: with the optimizer step (the in-step row update of the pipelined DeepFM step)
+    if os.environ.get('ROWS'):
+        dm.train_step([batches[i][0], batches[i][1]], batches[i][2])
+    else:
+        dm.forward_backward([batches[i][0], batches[i][1]], batches[i][2])
 torch.cuda.synchronize()
 plan = dm.fused_plan()
 ws = plan._bufs[8192]['ws']
@@ -25,8 +28,9 @@ v1 = 'DT_DEEPFM_V1' in os.environ
 labels = [{0: 'entry', 1: 'staged', 2: 'gemm1', 3: 'h1 stored', 4: 'gemm2+h2', 5: 'end'},
           {0: 'entry', 1: 'prologue', 2: 'dH1', 3: 'end(dXn)'}] if v1 else \
     [{0: 'entry', 6: 'prologue loads issued', 7: 'bn params in LDS', 1: 'chunk0 staged', 2: 'gemm1 done',
-      3: 'h1 in LDS', 4: 'gemm2 + partial logits (DCN: the cross forward = P GEMM + scalar steps)', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)', 9: 'DCN: gemm2 done, cross vectors in LDS', 10: 'DCN: dH2 / dH1 done (top of the backward)', 11: 'DCN: coefficients + xhat tile in LDS', 12: 'DCN: dXc rows + G = xhat^T coeff stored'},
-     {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'},
+      3: 'h1 in LDS', 4: 'gemm2 + partial logits (DCN: the cross forward = P GEMM + scalar steps)', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)', 13: 'pipelined: xhat tile + dH1 operand staged', 14: 'pipelined: dXn GEMM + partial sums done', 15: 'pipelined: dXn rows stored', 9: 'DCN: gemm2 done, cross vectors in LDS', 10: 'DCN: dH2 / dH1 done (top of the backward)', 11: 'DCN: coefficients + xhat tile in LDS', 12: 'DCN: dXc rows + G = xhat^T coeff stored'},
+     ({0: 'entry (memory waves of k_wgrad_rows)', 3: 'end (rows updated / stored)'} if (model == 'DeepFM' and os.environ.get('DT_STEP_PIPE', '1') != '0') else
+      {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'}),
      {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)'},
      {0: 'entry', 1: 'ids + hash insert done, row loads issued', 2: 'rows arrived, X stores issued', 3: 'row sums done', 4: 'block barrier', 5: 'end (BN partials)'}]
 for k, kn in enumerate(['k_mlp_fwd', 'k_mlp_bwd'] + ([] if v1 else ['k_wgrad', 'k_sparse_fwd'])):
