@@ -21,6 +21,7 @@
 // reduction pass each.
 #include <stdlib.h>
 #include "common.h"
+#include "adam_dev.h"
 
 namespace dt {
 
@@ -1181,9 +1182,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         };
         auto epi_end = [&](int blk) {
             const int col = 16 * blk + n16;
-            float a = s1, b = s2;
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            // the four lanes n16 + 16 kq of a column meet through v_permlane16/32_swap (no LDS round trips inside the GEMM)
+            const float a = row_pair16(s1, false), b = row_pair16(s2, false);
             if (kq == 0 && col < dm.C) { prec[pl.sdx + col] = a; prec[pl.sdxx + col] = b; }
             s1 = 0.f; s2 = 0.f;
         };
@@ -1237,10 +1237,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         lds_barrier();
         DT_STAMP(stamps, 14);
         // the tile's dXn rows leave as whole rows (the F*D embedding columns: the dense inputs need no gradient)
-        const int fq = (dm.F * dm.D) >> 2;
-        for (int e = tid; e < kTM * fq; e += 256) {
-            const int row = e / fq, q = e - row * fq;
-            if (m0 + row < dm.B) st4(dxn_out + (int64_t)(m0 + row) * CP + 4 * q, ld4(xs + row * XS + 4 * q));
+        const int fq = (dm.F * dm.D) >> 2;                 // 16-byte pieces per row (<= 128): 256 / fq rows per pass
+        const int rgs = 256 / fq, rg = tid / fq, q = tid - rg * fq;
+        if (rg < rgs) {
+            for (int row = rg; row < kTM; row += rgs)
+                if (m0 + row < dm.B) st4(dxn_out + (int64_t)(m0 + row) * CP + 4 * q, ld4(xs + row * XS + 4 * q));
         }
         DT_STAMP(stamps, 15);
     }
@@ -1268,27 +1269,33 @@ struct PipeRed {
 __device__ __forceinline__ void wgrad_reduce_parts(float* red, int rb, const DeepFmDims& dm, const float* __restrict__ part,
                                                    int nparts, float* __restrict__ accum, const DeepFmAccum& al, int Lc,
                                                    const PipeRed& pr) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
     const Part3 pl = part3_layout(dm.CP, Lc, pr.cm1 ? 1 : 0);
     {
-        // record entries in the order slin | db1 | db2 | dw3 | dwo | dbo | loss
+        // record entries in the order slin | db1 | db2 | dw3 | dwo | dbo | loss; the block's nw waves take every nw-th
+        // tile, 16 loads in flight per lane (k_reduce_parts: 16 waves x 16 = the 256 tiles of B = 8192 in ONE round trip;
+        // the 4-wave form of round 2 paid 16 dependent round trips, hidden behind k_wgrad4's heavy blocks there)
         const int e = rb * 64 + lane;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        float acc = 0.f;
         if (e < pl.n) {
             const float* src = part + e;
-            int t = wave;
-            for (; t + 12 < nparts; t += 16) {
-                v0 += src[(int64_t)t * pl.stride];
-                v1 += src[(int64_t)(t + 4) * pl.stride];
-                v2 += src[(int64_t)(t + 8) * pl.stride];
-                v3 += src[(int64_t)(t + 12) * pl.stride];
+            for (int t0 = wave; t0 < nparts; t0 += 16 * nw) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int t = t0 + u * nw;
+                    const float x = src[(int64_t)min(t, nparts - 1) * pl.stride];      // unconditional, clamped
+                    v[u] = t < nparts ? x : 0.f;
+                }
+                acc += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                       (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
             }
-            for (; t < nparts; t += 4) v0 += src[(int64_t)t * pl.stride];
         }
-        red[wave * 64 + lane] = (v0 + v1) + (v2 + v3);
+        red[wave * 64 + lane] = acc;
         __syncthreads();
         if (wave == 0 && e < pl.n) {
-            const float v = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+            float v = 0.f;
+            for (int w = 0; w < nw; ++w) v += red[w * 64 + lane];
             int64_t dst = -1;
             if (e < pl.db1) dst = al.slin + e;
             else if (e < pl.db2) dst = al.db1 + (e - pl.db1);
@@ -1451,6 +1458,13 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
     DT_STAMP(stamps, 5);
 }
 
+// R of the pipelined step: the record reduction alone, 16 waves per 64 entries
+__global__ __launch_bounds__(1024) void k_reduce_parts(DeepFmDims dm, const float* __restrict__ part, int nparts,
+                                                       float* __restrict__ accum, DeepFmAccum al, int Lc, PipeRed pr) {
+    __shared__ float red[16 * 64];
+    wgrad_reduce_parts(red, (int)blockIdx.x, dm, part, nparts, accum, al, Lc, pr);
+}
+
 __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
                                                 const float* __restrict__ H1, const float* __restrict__ dH1,
                                                 const float* __restrict__ dH2, int nred_blocks, int row_blocks,
@@ -1471,12 +1485,19 @@ __global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, Mlp
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
 // waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
 // d linear_logit kernel: field f = its D columns, dense k = one column.
-__global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, DeepFmDims dm, float* accum,
-                                                   DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
-                                                   int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
-                                                   const float* __restrict__ w3c, int pipe) {
-    __shared__ floatx2 sm[4][64];
+// the optimizer's dense half for the pipelined step's last launch (k_finish_step): flat parameter / slot buffers laid out
+// like the accumulator buffer (fused.py: "parameters mirror the gradient layout"), p == NULL: gradients only
+struct DenseAdam {
+    float *p, *m, *v;
+    float lr_t, b1, b2, eps;
+};
+
+__device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, const DeepFmDims& dm, float* accum,
+                                               const DeepFmAccum& al, const float* __restrict__ wpart, int row_blocks,
+                                               int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
+                                               const float* __restrict__ w3c, int pipe, floatx2 (*sm)[64],
+                                               const DenseAdam& da) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && Lc == 0) {
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
@@ -1487,6 +1508,7 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
                 v = accum[al.slin + dm.F * dm.D + (q - dm.F)];
             }
             accum[al.dwlin + q] = v;
+            if (da.p) adam_one(da.p, da.m, da.v, al.dwlin + q, v, da.lr_t, da.b1, da.b2, da.eps);
         }
     }
     // one block per column (of X, then of dH2); its 4 waves add up every 4th batch slice with all loads in flight
@@ -1516,14 +1538,26 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
     if (wave != 0) return;
     m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     if (w2) {       // row `row` of dW2^T: dW2[k][row] for k = 2 lane, 2 lane + 1
-        accum[al.dW2 + (int64_t)(2 * lane) * kH2 + row] = m.x;
-        accum[al.dW2 + (int64_t)(2 * lane + 1) * kH2 + row] = m.y;
+        const int64_t i0 = al.dW2 + (int64_t)(2 * lane) * kH2 + row, i1 = al.dW2 + (int64_t)(2 * lane + 1) * kH2 + row;
+        accum[i0] = m.x;
+        accum[i1] = m.y;
+        if (da.p) {
+            adam_one(da.p, da.m, da.v, i0, m.x, da.lr_t, da.b1, da.b2, da.eps);
+            adam_one(da.p, da.m, da.v, i1, m.y, da.lr_t, da.b1, da.b2, da.eps);
+        }
         return;
     }
     const float dg = wave_sum(w.x * m.x + w.y * m.y);
     const float db = wave_sum(w.x * d.x + w.y * d.y);
-    *reinterpret_cast<floatx2*>(accum + al.dW1 + (int64_t)col * kH1 + 2 * lane) =
-        floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
+    {
+        const int64_t i0 = al.dW1 + (int64_t)col * kH1 + 2 * lane;
+        const floatx2 g = floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
+        *reinterpret_cast<floatx2*>(accum + i0) = g;
+        if (da.p) {
+            adam_one(da.p, da.m, da.v, i0, g.x, da.lr_t, da.b1, da.b2, da.eps);
+            adam_one(da.p, da.m, da.v, i0 + 1, g.y, da.lr_t, da.b1, da.b2, da.eps);
+        }
+    }
     if (lane == 0) {
         float sumc = 0.f, sumcx = 0.f;
         if (Lc) {
@@ -1554,6 +1588,53 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
             accum[al.dbeta + col] = db + sumc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, DeepFmDims dm, float* accum,
+                                                   DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
+                                                   int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
+                                                   const float* __restrict__ w3c, int pipe) {
+    __shared__ floatx2 sm[4][64];
+    const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+    bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, pipe, sm, none);
+}
+
+// F: the LAST launch of the pipelined step when the optimizer is handed in (dt_deepfm_train_step_adam with the dense
+// buffers): kernel E' with the Keras-Adam update of every dense element applied where its gradient is finished, the
+// vectors the record reduction finished (db1 .. dbeta) in `small_blocks` further blocks, the segments of the rows looked
+// up several times (optim.hip's walk) in the trailing blocks, and the step state advanced by the last block to arrive —
+// round 2's E' (6.7 us) and optimizer launch (the dependent chain of the segment walk + the dense tail, 9.6 us) side by
+// side in one launch.
+struct FinishSeg {
+    SegTail seg;
+    float *table, *m, *v;
+    const float* values;
+    int sstride, D;
+};
+__global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, DeepFmDims dm, float* accum,
+                                                     DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
+                                                     DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
+                                                     int small_blocks, int seg_blocks, FinishSeg fs) {
+    __shared__ floatx2 sm[4][64];
+    unsigned ticket;
+    da.lr_t = adam_read_lr(st, da.lr_t, 1, ticket);
+    const int b = (int)blockIdx.x;
+    if (b < col_blocks) {
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, 0, nullptr, nullptr, nullptr, 1, sm, da);
+    } else if (b < col_blocks + small_blocks) {
+        // db1 | db2 | dw3 | dwo | dbo | loss | dgamma | dbeta: final since the record reduction (the d w_lin entries that
+        // follow are block 0's); the `loss` words are pads of the parameter buffer, as in the flat optimizer launch
+        const int64_t i = al.db1 + (int64_t)(b - col_blocks) * blockDim.x + threadIdx.x;
+        if (i < al.dwlin) adam_one(da.p, da.m, da.v, i, accum[i], da.lr_t, da.b1, da.b2, da.eps);
+    } else if (fs.seg.nseg) {
+        const int sb = b - col_blocks - small_blocks;
+        const int nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
+        adam_segments(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
+                      fs.sstride, sb);
+    }
+    adam_finish(st, ticket, lr, da.b1, da.b2);
 }
 
 // D: dXn = dH1 . W1^T on 16x16x4 tiles, one 16-column block (x both 16-row halves, sharing the W1 operand) at a
@@ -2020,6 +2101,15 @@ extern "C" int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7) {
     return DT_OK;
 }
 
+// dt_deepfm_train_step_adam with the optimizer's dense half as well: the flat parameter / slot buffers (laid out like accum),
+// the step state to advance and the base learning rate
+struct StepDense {
+    float *p, *m, *v;
+    int64_t n_flat;
+    void* state;
+    float lr;
+};
+
 // the step both entry points run: DeepFM (cross == NULL) or DCN (cross kernels / biases [Lc][C]; w3 = the [C + 64] kernel
 // applied to Concatenate([cross, dnn]), w_lin unused)
 static int tower_train_step(
@@ -2031,7 +2121,7 @@ static int tower_train_step(
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
     float embedding_dropout, unsigned* dropout_seed, void* stream, const float* cross_w, const float* cross_b, int Lc,
-    const RowsAdam* adam = nullptr) {
+    const RowsAdam* adam = nullptr, const StepDense* sdense = nullptr) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
@@ -2156,8 +2246,8 @@ static int tower_train_step(
     if (pipe) {
         // R: the per-tile records -> dense gradients, the BN-backward batch sums and the epilogue's per-column constants
         const PipeRed pr{ws + wl.cm1, ws + wl.cm2, ws + wl.rstd};
-        hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
-                           ws + wl.dH2, nred3, 1, 8, ws + wl.part, tiles, accum, al, ws + wl.wpart, nullptr, Lc, pr);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(ceil_div(pl3.n, 64)), dim3(1024), 0, st, dm, ws + wl.part, tiles, accum, al, Lc,
+                           pr);
         // E + D: one 512-thread block per CU (see k_wgrad_rows)
         const int nmac = (dm.CP >> 6) + 1;
         int row_blocks = 256 / nmac;
@@ -2174,9 +2264,26 @@ static int tower_train_step(
                            ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                            stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
                            stamps ? stamps + (int64_t)tiles * 16 : nullptr);
-        // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
-        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);
+        if (adam && sdense) {
+            // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
+            DT_REQUIRE(sdense->n_flat == al.dwlin + F + Nd, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
+                       "%lld floats (the accumulator layout up to d w_lin)", (long long)sdense->n_flat,
+                       (long long)(al.dwlin + F + Nd));
+            static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
+            const int seg_blocks = seg_env > 0 ? seg_env : 512;
+            const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
+            const DedupeLayout dl = dedupe_layout(B, F);
+            const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
+                               adam->table, adam->m, adam->v, grad_rows, adam->sstride, D};
+            const DenseAdam da{sdense->p, sdense->m, sdense->v, adam->lr_t_host, adam->b1, adam->b2, adam->eps};
+            hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, bn_gamma,
+                               bn_beta, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
+                               dm.C + kH2, small_blocks, seg_blocks, fs);
+        } else {
+            // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
+            hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
+                               accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);
+        }
         if (drop.thr) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else if (phases >= 2) {
         // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
@@ -2240,8 +2347,11 @@ extern "C" int dt_deepfm_train_step(
 // the step with the row-sparse Keras-Adam update of the rows looked up ONCE applied inside it (k_wgrad_rows): `table` is
 // updated in place, adam_m / adam_v are its slots (slot_stride floats between consecutive rows' records: D for two
 // [V,D] arrays, 2 D for one [V,2,D] array), adam_state the device-resident step state of dt_adam_state_init (NULL:
-// lr_t is the host value).  Rows looked up several times leave as segments exactly as in dt_deepfm_train_step and
-// are updated — with the dense parameters — by dt_adam_rows_step_seg(fields = -2), which also advances the state.
+// lr_t is the host value).  dense_n == 0: rows looked up several times leave as segments exactly as in
+// dt_deepfm_train_step and are updated — with the dense parameters — by dt_adam_rows_step_seg(fields = -2), which also
+// advances the state.  dense_n > 0 (= the accumulator layout up to d w_lin; dense_p / dense_m / dense_v: the model's flat
+// parameter buffer and its slots, laid out like accum): the WHOLE optimizer step runs here — the step's last launch
+// finishes the dense gradients, updates every dense element, walks the segments and advances the state (k_finish_step).
 extern "C" int dt_deepfm_train_step_adam(
     const void* idx, int idx_kind, float* table, const int64_t* row_offset, const int32_t* vocab,
     const float* dense, const float* y, int B, int F, int D, int Nd,
@@ -2250,19 +2360,22 @@ extern "C" int dt_deepfm_train_step_adam(
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed,
-    float* adam_m, float* adam_v, int slot_stride, const void* adam_state, float lr_t, float beta1, float beta2,
-    float eps, void* stream) {
+    float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
+    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
     DT_REQUIRE(w_lin && table && adam_m && adam_v, "dt_deepfm_train_step_adam: null pointer");
+    DT_REQUIRE(dense_n == 0 || (dense_p && dense_m && dense_v && adam_state),
+               "dt_deepfm_train_step_adam: the dense half needs the flat buffers and the device step state");
     DT_REQUIRE((phases & 0xf) == 2 && dedupe_ws, "dt_deepfm_train_step_adam: a backward step (phases 2) with dedupe_ws");
     DT_REQUIRE(slot_stride == D || slot_stride == 2 * D, "dt_deepfm_train_step_adam: slot_stride %d (D or 2 D)", slot_stride);
     DT_REQUIRE(((uintptr_t)table | (uintptr_t)adam_m | (uintptr_t)adam_v) % 16 == 0,
                "dt_deepfm_train_step_adam: table / slots must be 16-byte aligned");
     const RowsAdam ad{table, adam_m, adam_v, slot_stride, adam_state ? adam_state_lr_t(adam_state) : nullptr, lr_t, beta1,
                       beta2, eps};
+    const StepDense sd{dense_p, dense_m, dense_v, dense_n, adam_state, lr};
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, w_lin, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, stream, nullptr, nullptr, 0, &ad);
+                            embedding_dropout, dropout_seed, stream, nullptr, nullptr, 0, &ad, dense_n > 0 ? &sd : nullptr);
 }
 
 // ---- DCN (nets ['dcn_nets'], deepnets.py:194-207): the same step with the Cross network (layers.py:428-436) in place of

@@ -315,13 +315,23 @@ class FusedDeepFM:
                 ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
                 ptr(self.emb.oob_count) if self.emb.check_oob else None,
                 ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
+        whole = False
         if opt is not None:
-            # the rows looked up once are updated where their gradient is formed (csrc/deepfm.hip k_wgrad_rows)
+            # the rows looked up once are updated where their gradient is formed (csrc/deepfm.hip k_wgrad_rows); when the
+            # optimizer's flat dense group is this plan's, the step's last launch runs the rest of the optimizer step too
+            # (dense elements, segments, the state's advance: k_finish_step) and `optimizer.step()` has nothing left to do
             slots = opt._st(table, rows=True)
+            flat = getattr(opt, '_flat', None)
+            whole = (flat is not None and flat[0] is self.flat_params and flat[1] is self.accum and
+                     os.environ.get('DT_AMD_STEP_IN_STEP', '1') != '0' and
+                     all(id(p) in flat[5] for p in opt.params if p is not table))
+            dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_deepfm_train_step_adam(
                 *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
-                opt.b1, opt.b2, opt.eps, stream_ptr()), 'dt_deepfm_train_step_adam')
+                opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
+            if whole:
+                opt.applied_in_step()
         else:
             check(lib().dt_deepfm_train_step(
                 *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,

@@ -95,6 +95,7 @@ class KerasAdam:
         # optional callable run right before the dense updates of a step (after the table updates were launched):
         # the data-parallel strategy uses it to wait for an all-reduce it started asynchronously
         self.pre_dense_hook = None
+        self._applied_in_step = False  # a fused step ran this step's whole update itself (applied_in_step)
         self._flat = None             # (flat_param, flat_grad, m, v, n, {id(param): offset})
         self._flat_views = None       # [(param, grad view)] when gradients may be accumulated straight into flat_grad
 
@@ -199,6 +200,7 @@ class KerasAdam:
         """flat=True: members of the registered flat group get their (zeroed) views of the flat gradient buffer as
         `.grad` — backward kernels and autograd accumulate straight into it; flat=False: the caller (a fused step)
         fills the flat buffer itself."""
+        self._applied_in_step = False
         for p in self.params:
             p.grad = None
         if flat and self._flat is not None and self._flat_views is not None:
@@ -208,8 +210,19 @@ class KerasAdam:
         for layer in self.embedding_layers:
             layer.sparse_grads.clear()
 
+    def applied_in_step(self):
+        """A fused train step (fused.FusedDeepFM with dt_deepfm_train_step_adam) has applied THIS step's whole update —
+        table rows, segments, every dense element — and advanced the device step state inside its own launches: the
+        `step()` call that follows only drops the gradients."""
+        self._applied_in_step = True
+
     def step(self):
         if not self.params:
+            return
+        if self._applied_in_step:
+            self._applied_in_step = False
+            for layer in self.embedding_layers:
+                layer.sparse_grads.clear()
             return
         dev_state = self._state_tensor(self.params[0].device)
         st = stream_ptr()

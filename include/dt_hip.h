@@ -416,9 +416,14 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
  * reaches HBM); slot_stride = floats between the slot records of consecutive rows (D: two [V,D] arrays, 2 D: one
  * [V,2,D] array with v == m + D); adam_state = the device step state of dt_adam_state_init (lr_t is read from it; NULL:
  * the scalar lr_t).  Needs phases == 2 (| DT_STEP_LOSS_MSE) and dedupe_ws: rows looked up several times leave as
- * segments (their members' gradient rows in grad_rows, rows_out == -1) and are updated, together with the dense
- * parameters and the state's advance, by dt_adam_rows_step_seg(..., fields = -2, ...) — which skips the entries of
- * `rows` (already applied here). */
+ * segments (their members' gradient rows in grad_rows, rows_out == -1).
+ * dense_n == 0: the segments are updated, together with the dense parameters and the state's advance, by
+ * dt_adam_rows_step_seg(..., fields = -2, ...) — which skips the entries of `rows` (already applied here).
+ * dense_n > 0: dense_p / dense_m / dense_v are the model's flat dense parameter buffer and its Adam slots, laid out like
+ * accum (dense_n = the offset of d w_lin + F + Nd floats); the step's last launch then also applies Keras Adam to every
+ * dense element where its gradient is finished, walks the segments and advances adam_state (lr = the base learning
+ * rate): the call IS keras.Model.train_step — forward, loss, backward and apply_gradients — and no optimizer launch
+ * follows. */
 int dt_deepfm_train_step_adam(const void* idx, int idx_kind, float* table, const int64_t* row_offset,
                               const int32_t* vocab, const float* dense, const float* y, int B, int F, int D,
                               int Nd, const float* w_lin, const float* bn_gamma, const float* bn_beta,
@@ -428,8 +433,8 @@ int dt_deepfm_train_step_adam(const void* idx, int idx_kind, float* table, const
                               int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
                               int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
                               float embedding_dropout, unsigned* dropout_seed, float* adam_m, float* adam_v,
-                              int slot_stride, const void* adam_state, float lr_t, float beta1, float beta2, float eps,
-                              void* stream);
+                              int slot_stride, void* adam_state, float lr_t, float beta1, float beta2, float eps,
+                              float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
 /* embedding_dropout > 0 (ModelConfig.embedding_dropout, config.py:84: SpatialDropout1D on every [B,1,D] embedding =
  * element dropout scaled by 1/(1-p)): element (b, f, d) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b, f*D+d) >=
  * p * 2^32.  *dropout_seed is a DEVICE word, advanced by the step itself (so a captured graph draws a fresh mask at every

@@ -83,6 +83,63 @@ __global__ __launch_bounds__(256) void k_gather3(const float4* __restrict__ pmv,
     out[g * 4 + c] = pmv[(int64_t)rows[g] * 12 + c];
 }
 
+// round 3: does reading a step's p / [m|v] rows EARLIER (while the matrix pipes work) make the later Adam-shaped
+// read-modify-write cheaper?  k_touch reads the rows (all loads in flight, nothing stored unless the impossible happens)
+template <bool WITH_P>
+__global__ __launch_bounds__(256) void k_touch(const float4* __restrict__ table, const float4* __restrict__ mv,
+                                               const int* __restrict__ rows, int64_t n, float4* __restrict__ out) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int c = threadIdx.x & 3;
+    if (g >= n) return;
+    const int64_t row = rows[g];
+    float4 m = mv[row * 8 + c], v = mv[row * 8 + 4 + c];
+    float s = m.x + v.x;
+    if (WITH_P) s += table[row * 4 + c].x;
+    if (s == 12345.678f) out[0] = m;
+}
+// the write half alone: p (64 B) and [m|v] (128 B) stored at random rows, nothing read from the table
+__global__ __launch_bounds__(256) void k_store_rows(float4* __restrict__ table, float4* __restrict__ mv,
+                                                    const int* __restrict__ rows, const float4* __restrict__ grad, int64_t n) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int c = threadIdx.x & 3;
+    if (g >= n) return;
+    const int64_t row = rows[g];
+    const float4 gr = grad[g * 4 + c];
+    table[row * 4 + c] = gr; mv[row * 8 + c] = gr; mv[row * 8 + 4 + c] = gr;
+}
+
+// [m|v] read as ONE 128-byte request per row (8 lanes x 16 B in one instruction) instead of two 64-byte halves
+__global__ __launch_bounds__(256) void k_touch128(const float4* __restrict__ mv, const int* __restrict__ rows, int64_t n,
+                                                  float4* __restrict__ out) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int c = threadIdx.x & 7;
+    if (g >= n) return;
+    const float4 m = mv[(int64_t)rows[g] * 8 + c];
+    if (m.x == 12345.678f) out[0] = m;
+}
+// Adam-shaped update with the slot record handled by 8 lanes (one 128-byte load + one 128-byte store per row) and p by 4
+__global__ __launch_bounds__(256) void k_adamlike128(float4* __restrict__ table, float4* __restrict__ mv,
+                                                     const int* __restrict__ rows, const float4* __restrict__ grad,
+                                                     int64_t n) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int c = threadIdx.x & 7, c4 = c & 3;
+    if (g >= n) return;
+    const int64_t row = rows[g];
+    const float4 gr = grad[g * 4 + c4];
+    float4 s = mv[row * 8 + c];
+    float4 p = table[row * 4 + c4];
+    if (c < 4) { s.x = 0.9f * s.x + 0.1f * gr.x; s.y = 0.9f * s.y + 0.1f * gr.y; s.z = 0.9f * s.z + 0.1f * gr.z; s.w = 0.9f * s.w + 0.1f * gr.w; }
+    else { s.x = 0.99f * s.x + 0.01f * gr.x * gr.x; s.y = 0.99f * s.y + 0.01f * gr.y * gr.y; s.z = 0.99f * s.z + 0.01f * gr.z * gr.z; s.w = 0.99f * s.w + 0.01f * gr.w * gr.w; }
+    // lanes 0..3 hold m, lanes 4..7 v of the same 4 columns: exchange through the wave
+    const float ox = __shfl_xor(s.x, 4, 64), oy = __shfl_xor(s.y, 4, 64), oz = __shfl_xor(s.z, 4, 64), ow = __shfl_xor(s.w, 4, 64);
+    mv[row * 8 + c] = s;
+    if (c < 4) {
+        p.x -= 1e-3f * s.x / (sqrtf(ox) + 1e-7f); p.y -= 1e-3f * s.y / (sqrtf(oy) + 1e-7f);
+        p.z -= 1e-3f * s.z / (sqrtf(oz) + 1e-7f); p.w -= 1e-3f * s.w / (sqrtf(ow) + 1e-7f);
+        table[row * 4 + c4] = p;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
@@ -130,6 +187,35 @@ int main() {
         printf("n=%8lld  interleaved p|m|v records (192 B): adam-like %7.1f us, gather of the p part %7.1f us\n", (long long)n, ta3, tg3);
         printf("n=%8lld  gather R=1 %7.1f us (%5.2f TB/s gathered+written)  R=2 %7.1f us  R=4 %7.1f us | rmw %7.1f us (%5.2f TB/s r+w) | adam-like %7.1f us (%5.2f TB/s)\n",
                (long long)n, t1, n * 128 / t1 / 1e6, t2, t4, tr, n * 128 / tr / 1e6, ta, n * 448 / ta / 1e6);
+    }
+    {
+        const int64_t n = 212992;
+        const unsigned blocks1 = (unsigned)((n * 4 + 255) / 256);
+        float tt = time_us([&](int i) { hipLaunchKernelGGL(k_touch<false>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + i * n, n, out); });
+        float ttp = time_us([&](int i) { hipLaunchKernelGGL(k_touch<true>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (16 + i) * n, n, out); });
+        float tw = time_us([&](int i) { hipLaunchKernelGGL(k_store_rows, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (32 + i) * n, grad, n); });
+        // pairs on fresh rows: touch, then a streaming copy of 56 MB standing in for the step's traffic between the two, then the update
+        float tpair = time_us([&](int i) {
+            hipLaunchKernelGGL(k_touch<true>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (48 + i) * n, n, out);
+            hipLaunchKernelGGL(k_adamlike, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (48 + i) * n, grad, n); });
+        float tpair2 = time_us([&](int i) {
+            hipLaunchKernelGGL(k_touch<true>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (20 + i) * n, n, out);
+            hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, out, out + (56LL << 20) / 16, (56LL << 20) / 16);
+            hipLaunchKernelGGL(k_adamlike, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (20 + i) * n, grad, n); });
+        float tcp = time_us([&](int i) { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, out, out + (56LL << 20) / 16, (56LL << 20) / 16); });
+        float tpair3 = time_us([&](int i) {
+            hipLaunchKernelGGL(k_touch<false>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (60 + i) * n, n, out);
+            hipLaunchKernelGGL(k_adamlike, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + (60 + i) * n, grad, n); });
+        float thot = time_us([&](int i) { hipLaunchKernelGGL(k_adamlike, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + 70 * n, grad, n); });
+        float ttouchhot = time_us([&](int i) { hipLaunchKernelGGL(k_touch<true>, dim3(blocks1), dim3(256), 0, 0, table, mv, rows + 70 * n, n, out); });
+        float t128 = time_us([&](int i) { hipLaunchKernelGGL(k_touch128, dim3(2 * blocks1), dim3(256), 0, 0, mv, rows + i * n, n, out); });
+        float ta128 = time_us([&](int i) { hipLaunchKernelGGL(k_adamlike128, dim3(2 * blocks1), dim3(256), 0, 0, table, mv, rows + (16 + i) * n, grad, n); });
+        printf("n=%8lld  the SAME rows every launch (cache numbers): adam-like %6.1f us, touch p + [m|v] %6.1f us | fresh rows, [m|v] as one 128-byte "
+               "request per row: touch %6.1f us, adam-like %6.1f us\n", (long long)n, thot, ttouchhot, t128, ta128);
+        printf("n=%8lld  touch [m|v] %6.1f us, touch p + [m|v] %6.1f us, store-only p + [m|v] %6.1f us\n", (long long)n, tt, ttp, tw);
+        printf("n=%8lld  touch(p,m,v) + adam-like on the same fresh rows %6.1f us (adam-like after the touch: %6.1f us); with 112 MB of "
+               "streaming traffic between them %6.1f us (copy alone %6.1f us -> adam-like %6.1f us); touch(m,v) + adam-like %6.1f us\n",
+               (long long)n, tpair, tpair - ttp, tpair2, tcp, tpair2 - ttp - tcp, tpair3);
     }
     for (int64_t bytes : {28LL << 20, 256LL << 20}) {
         float tc = time_us([&](int i) { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, table + (int64_t)i * (bytes / 16), (float4*)mv + (int64_t)i * (bytes / 16), bytes / 16); }, 4);
