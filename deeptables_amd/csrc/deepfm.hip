@@ -1880,25 +1880,42 @@ struct RowsEpi {
 };
 constexpr int kRowsUB = 4;
 
+// One WAVE's share of the epilogue.  A wave covers the 16-byte pieces of one batch row (F D/4 <= 64: several rows per pass)
+// or one half of them (F D/4 in (64, 128]: `parts` = 2, wave w takes half w % 2), so its per-column constants are
+// loaded once; work = chunks of kRowsUB passes pulled from an LDS counter per part (`work`), shared by every wave of the
+// block that runs this function — the block's memory waves from the start, its matrix waves once their GEMM is stored
+// (k_wgrad_rows): with B = 8192 the matrix waves are done after ~28 K of the memory waves' ~69 K cycles.
 template <bool DCN>
-__device__ __forceinline__ void rows_epilogue(int tid2, int first_tile, int tile_stride, const DeepFmDims& dm,
-                                              const RowsEpi& a, const RowsAdam& ad, const EmbDrop& drop) {
+__device__ __forceinline__ void rows_epilogue_wave(unsigned* work, int first_tile, int tile_stride, const DeepFmDims& dm,
+                                                   const RowsEpi& a, const RowsAdam& ad, const EmbDrop& drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int LPR = dm.D >> 2, TPR = dm.F * LPR;           // 16-byte pieces per embedding vector / per batch row (<= 128)
-    const int RG = 256 / TPR;                              // batch rows in flight per pass (>= 2)
-    const int rg = tid2 / TPR, piece = tid2 - rg * TPR;
-    const bool active = rg < RG;
+    const int parts = TPR > 64 ? 2 : 1;
+    const int lpp = (TPR + parts - 1) / parts;             // lanes a row (or its half) takes
+    const int rpw = parts == 1 ? 64 / TPR : 1;             // batch rows per pass of the wave
+    const int part = wv & (parts - 1);
+    const int rsub = lane / lpp, pl = lane - rsub * lpp;
+    const int piece = min(part * lpp + pl, TPR - 1);
+    const bool active = rsub < rpw && part * lpp + pl < TPR;
     const int f = piece / LPR, c = piece - f * LPR;
     const int col = 4 * piece;                             // = f * D + 4 c
     const int tiles = (dm.B + kTM - 1) / kTM;
+    const int chunk_rows = rpw * kRowsUB, chunks = (kTM + chunk_rows - 1) / chunk_rows;
     int dshift = 0;
     while ((1 << dshift) < dm.D) ++dshift;
     const floatx4 ca = ld4(a.sc + col), cmu = ld4(a.mean + col), c1 = ld4(a.cm1 + col), c2 = ld4(a.cm2 + col);
     const float wl = DCN ? 0.f : a.wlin[f];
     const float lr_t = ad.lr_t_dev ? *ad.lr_t_dev : ad.lr_t_host;
     const unsigned dseed = drop.thr ? *drop.seed : 0u;
-    for (int tile = first_tile; tile < tiles; tile += tile_stride) {
+    for (;;) {
+        unsigned it = 0;
+        if (lane == 0) it = atomicAdd(&work[part], 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        const int ti = (int)(it / (unsigned)chunks), ch = (int)(it - (unsigned)ti * (unsigned)chunks);
+        const int tile = first_tile + ti * tile_stride;
+        if (tile >= tiles) break;
         const int b0 = tile * kTM;
-        for (int u0 = 0; u0 < kTM; u0 += RG * kRowsUB) {
+        {
             int64_t row[kRowsUB];
             floatx4 gx[kRowsUB], xr[kRowsUB], sv[kRowsUB];
             float dzv[kRowsUB];
@@ -1907,7 +1924,7 @@ __device__ __forceinline__ void rows_epilogue(int tid2, int first_tile, int tile
             // every load is unconditional from a clamped (valid) address; the results of lanes that are not `ok` are unused
 #pragma unroll
             for (int k = 0; k < kRowsUB; ++k) {
-                const int r = u0 + rg + RG * k;
+                const int r = ch * chunk_rows + k * rpw + rsub;
                 ok[k] = active && r < kTM && b0 + r < dm.B;
                 bb[k] = min(b0 + min(r, kTM - 1), dm.B - 1);
                 row[k] = a.rows_out[(int64_t)bb[k] * dm.F + f];
@@ -1970,16 +1987,19 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     const float* __restrict__ dH2, int row_blocks, int rows_per_block,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
                                                     RowsEpi ep, RowsAdam ad, EmbDrop drop,
-                                                    unsigned long long* stamps_rows) {
+                                                    unsigned long long* stamps_rows, int matrix_waves_join) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
-    __shared__ unsigned arrived;
-    if (threadIdx.x == 0) arrived = 0u;
+    __shared__ unsigned arrived, work[2];
+    if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; }
     __syncthreads();          // the only hardware barrier: the two halves never wait for each other afterwards
-    if (threadIdx.x < 256)
+    if (threadIdx.x < 256) {
         wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
-    else {
+        // the GEMM's partial tile is stored: the matrix waves take their share of what is left of the epilogue
+        if (matrix_waves_join) rows_epilogue_wave<DCN>(work, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
+        if (stamps_all && threadIdx.x == 0) stamps_all[(int64_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime();
+    } else {
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
-        rows_epilogue<DCN>((int)threadIdx.x - 256, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
+        rows_epilogue_wave<DCN>(work, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memtime();
     }
 }
@@ -2259,11 +2279,12 @@ static int tower_train_step(
         const RowsEpi ep{ws + wl.dXn, ws + wl.X, ws + wl.dz, ws + wl.S, w_lin, ws + wl.sc, ws + wl.mean, ws + wl.cm1,
                          ws + wl.cm2, rows_out, grad_rows, grad_rows_scale, grad_rows_field_major};
         const RowsAdam ad = adam ? *adam : RowsAdam{nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f, 0.f};
+        static const int join_env = !(getenv("DT_ROWS_JOIN") && atoi(getenv("DT_ROWS_JOIN")) == 0);    // experiment knob
         hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
         hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                            ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                            stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                           stamps ? stamps + (int64_t)tiles * 16 : nullptr);
+                           stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
             DT_REQUIRE(sdense->n_flat == al.dwlin + F + Nd, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
