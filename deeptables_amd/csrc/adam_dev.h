@@ -117,49 +117,65 @@ __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks,
     const int wpr = nw >= sg.regions ? nw / sg.regions : 1, lw = nw >= sg.regions ? gw / sg.regions : 0;
     if (lw >= wpr) return;
     const int e0 = gw % sg.regions;
-    for (int e = e0; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw))
-    for (int sl = lw, nseg = (e == e0 ? nseg0 : sg.nseg[e]); sl < nseg; sl += wpr) {
-        const int s = e * sg.cap + sl;
-        const int64_t row = sg.row[s];
-        const int off = sg.off[s], cnt = sg.cnt[s];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int i = grp;
-        for (; i + 3 * groups < cnt; i += 4 * groups) {      // four members per group in flight
-            const int o0 = sg.list[off + i], o1 = sg.list[off + i + groups], o2 = sg.list[off + i + 2 * groups],
-                      o3 = sg.list[off + i + 3 * groups];
-            const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
-            const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
-            const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
-            const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
-            acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
-            acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
-        }
-        for (; i < cnt; i += groups) {
-            const int o0 = sg.list[off + i];
-            const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
-            acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
-        }
-        for (int o = lpr; o < 64; o <<= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-        }
-        if (grp == 0) {
+    // Dependent round trips per segment: (segment record) -> (member list | p, m, v of the row) -> (members' gradient rows)
+    // -> stores.  The record of the wave's NEXT segment is fetched while the current one is summed (and the first one
+    // before its region's count is even known: index e cap + lw is always inside the arrays), and the row's p / m / v
+    // do not wait for the member sums (round 2 walked list -> values -> p, m, v: five trips).
+    for (int e = e0; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw)) {
+        int sl = lw;
+        int s = e * sg.cap + min(sl, sg.cap - 1);
+        int64_t row = sg.row[s];
+        int off = sg.off[s], cnt = sg.cnt[s];
+        const int nseg = (e == e0 ? nseg0 : sg.nseg[e]);
+        while (sl < nseg) {
+            const int sn = e * sg.cap + min(sl + wpr, sg.cap - 1);
+            const int64_t row_n = sg.row[sn];
+            const int off_n = sg.off[sn], cnt_n = sg.cnt[sn];
             const int64_t i0 = row * D + 4 * part, s0 = row * sstride + 4 * part;
-            float4 p = *reinterpret_cast<const float4*>(table + i0);
-            float4 mi = *reinterpret_cast<const float4*>(m + s0), vi = *reinterpret_cast<const float4*>(v + s0);
-            const float g[4] = {acc.x, acc.y, acc.z, acc.w};
-            float* pp = reinterpret_cast<float*>(&p);
-            float* pm = reinterpret_cast<float*>(&mi);
-            float* pv = reinterpret_cast<float*>(&vi);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pm[k] = b1 * pm[k] + (1.f - b1) * g[k];
-                pv[k] = b2 * pv[k] + (1.f - b2) * g[k] * g[k];
-                pp[k] -= lr_t * pm[k] / (sqrtf(pv[k]) + eps);
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f), mi = p, vi = p;
+            if (grp == 0) {
+                p = *reinterpret_cast<const float4*>(table + i0);
+                mi = *reinterpret_cast<const float4*>(m + s0);
+                vi = *reinterpret_cast<const float4*>(v + s0);
             }
-            *reinterpret_cast<float4*>(m + s0) = mi;
-            *reinterpret_cast<float4*>(v + s0) = vi;
-            *reinterpret_cast<float4*>(table + i0) = p;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int i = grp;
+            for (; i + 3 * groups < cnt; i += 4 * groups) {      // four members per group in flight
+                const int o0 = sg.list[off + i], o1 = sg.list[off + i + groups], o2 = sg.list[off + i + 2 * groups],
+                          o3 = sg.list[off + i + 3 * groups];
+                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
+                const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
+                const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
+                acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
+                acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
+            }
+            for (; i < cnt; i += groups) {
+                const int o0 = sg.list[off + i];
+                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
+            }
+            for (int o = lpr; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            if (grp == 0) {
+                const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+                float* pp = reinterpret_cast<float*>(&p);
+                float* pm = reinterpret_cast<float*>(&mi);
+                float* pv = reinterpret_cast<float*>(&vi);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pm[k] = b1 * pm[k] + (1.f - b1) * g[k];
+                    pv[k] = b2 * pv[k] + (1.f - b2) * g[k] * g[k];
+                    pp[k] -= lr_t * pm[k] / (sqrtf(pv[k]) + eps);
+                }
+                *reinterpret_cast<float4*>(m + s0) = mi;
+                *reinterpret_cast<float4*>(v + s0) = vi;
+                *reinterpret_cast<float4*>(table + i0) = p;
+            }
+            sl += wpr;
+            row = row_n; off = off_n; cnt = cnt_n;
         }
     }
 }

@@ -1152,85 +1152,85 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
             st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
         }
-        const int nblk = (dm.C + 15) >> 4;
-        auto w1row = [&](int blk) {          // row `col` of W1 [C][128], this lane's 4 k of every 16 (clamped: never stored)
-            const int col = min(16 * blk + n16, dm.C - 1);
-            return p.W1 + (int64_t)col * kH1 + 4 * kq;
+        // 32x32x2 tiles (half as many matrix instructions per flop as 16x16x4: with ONE wave per SIMD every instruction
+        // issued between two MFMAs is a bubble of the pipe — the 16x16x4 form of this loop ran at 58 % of the pipe's rate,
+        // 24.7 K cycles for 14.3 K of MFMA work).  K permutation as in GEMM1: lane (c, s), step 4g + j <-> k = 8g + 4s + j,
+        // so A = 16 float4 of row c of the dH1 tile and B = 16 float4 of row `col` of the row-major W1.
+        const int nblk = (dm.C + 31) >> 5;
+        auto w1row = [&](int blk) {          // row `col` of W1 [C][128], this lane's 4 k of every 8 (clamped: never stored)
+            const int col = min(32 * blk + c, dm.C - 1);
+            return p.W1 + (int64_t)col * kH1 + 4 * s;
         };
-        floatx4 bW[2][8];
+        floatx4 bW[2][16];
         if (wave < nblk) {
             const float* wrow = w1row(wave);
 #pragma unroll
-            for (int G = 0; G < 8; ++G) bW[0][G] = ld4(wrow + 16 * G);
+            for (int g = 0; g < 16; ++g) bW[0][g] = ld4(wrow + 8 * g);
         }
-        floatx4 aA[2][8];
+        floatx4 aA[16];
 #pragma unroll
-        for (int G = 0; G < 8; ++G) {
-            aA[0][G] = ld4(h1s + n16 * HS + 16 * G + 4 * kq);
-            aA[1][G] = ld4(h1s + (16 + n16) * HS + 16 * G + 4 * kq);
-        }
+        for (int g = 0; g < 16; ++g) aA[g] = ld4(h1s + c * HS + 8 * g + 4 * s);
         lds_barrier();
         DT_STAMP(stamps, 13);
-        // one epilogue slice (row q of 8) of block `blk`: the lane holds column 16 blk + n16 of rows 16 (q / 4) + 4 kq + q % 4
+        // one epilogue slice (accumulator register r of 16) of block `blk`: the lane holds column 32 blk + c of row
+        // (r % 4) + 8 (r / 4) + 4 s
         float s1 = 0.f, s2 = 0.f;
-        auto epi_addr = [&](int blk, int q) { return xs + (16 * (q >> 2) + 4 * kq + (q & 3)) * XS + 16 * blk + n16; };
-        auto epi_q = [&](int blk, const floatx4& c0, const floatx4& c1, int q, float xh) {
-            const float gx = (q >> 2) ? c1[q & 3] : c0[q & 3];
+        auto epi_addr = [&](int blk, int r) { return xs + ((r & 3) + 8 * (r >> 2) + 4 * s) * XS + 32 * blk + c; };
+        auto epi_q = [&](int blk, float gx, int r, float xh) {
             s1 += gx;
             s2 += gx * xh;
-            *epi_addr(blk, q) = gx;
+            *epi_addr(blk, r) = gx;
         };
         auto epi_end = [&](int blk) {
-            const int col = 16 * blk + n16;
-            // the four lanes n16 + 16 kq of a column meet through v_permlane16/32_swap (no LDS round trips inside the GEMM)
-            const float a = row_pair16(s1, false), b = row_pair16(s2, false);
-            if (kq == 0 && col < dm.C) { prec[pl.sdx + col] = a; prec[pl.sdxx + col] = b; }
+            const int col = 32 * blk + c;
+            const float a = s1 + __shfl_xor(s1, 32, 64), b = s2 + __shfl_xor(s2, 32, 64);      // the two row halves (s = 0, 1)
+            if (s == 0 && col < dm.C) { prec[pl.sdx + col] = a; prec[pl.sdxx + col] = b; }
             s1 = 0.f; s2 = 0.f;
         };
-        // block `blk` from W1 buffer `buf` into (c0, c1); the previous block's epilogue slices ride between the groups
-        auto mm3 = [&](int buf, int blk, floatx4& c0, floatx4& c1, int pblk, const floatx4& p0, const floatx4& p1) {
-            c0 = floatx4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+        // block `blk` from W1 buffer `buf` into `out`; the previous block's 16 epilogue slices ride between the 16 groups
+        auto mm3 = [&](int buf, int blk, floatx16& out, int pblk, const floatx16& prev) {
+            floatx16 a1, a2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
             const bool more = blk + 4 < nblk;
             const float* wnext = w1row(blk + 4);
 #pragma unroll
-            for (int G = 0; G < 8; ++G) {
-                // the previous block's slice G: its xhat read is issued BEFORE this group's MFMAs and consumed after them
-                const float xh = pblk >= 0 ? *epi_addr(pblk, G) : 0.f;
+            for (int g = 0; g < 16; ++g) {
+                // the previous block's slice g: its xhat read is issued BEFORE this group's MFMAs and consumed after them
+                const float xh = pblk >= 0 ? *epi_addr(pblk, g) : 0.f;
                 __builtin_amdgcn_sched_barrier(0);
-                const floatx4 b = bW[buf][G];
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].x, b.x, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].x, b.x, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].y, b.y, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].y, b.y, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].z, b.z, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].z, b.z, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].w, b.w, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].w, b.w, c1, 0, 0, 0);
-                if (more) bW[buf ^ 1][G] = ld4(wnext + 16 * G);       // the next block's W1 operand, one load per 8 MFMAs
-                if (pblk >= 0) epi_q(pblk, p0, p1, G, xh);
+                const floatx4 a = aA[g], b = bW[buf][g];
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, a2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, a2, 0, 0, 0);
+                if (more) bW[buf ^ 1][g] = ld4(wnext + 8 * g);        // the next block's W1 operand, one load per 4 MFMAs
+                if (pblk >= 0) epi_q(pblk, prev[g], g, xh);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[r] = a1[r] + a2[r];
             if (pblk >= 0) epi_end(pblk);
         };
         {
-            // buffer ids and accumulator pairs are literals: everything stays in registers (nblk <= 34: C <= 544 -> at
-            // most 9 blocks per wave)
-            floatx4 ca0, ca1, cb0, cb1;
-            const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+            // buffer ids and result registers are literals: everything stays in registers (nblk <= 17: C <= 544 -> at most
+            // 5 blocks per wave)
+            floatx16 ra, rb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ra[r] = 0.f; rb[r] = 0.f; }
             int last = -1;
-            if (wave < nblk) { mm3(0, wave, ca0, ca1, -1, z4, z4); last = wave; }
-#pragma unroll
-            for (int t = 1; t < 9; t += 2) {
-                if (wave + 4 * t < nblk) { mm3(1, wave + 4 * t, cb0, cb1, wave + 4 * (t - 1), ca0, ca1); last = wave + 4 * t; }
-                if (wave + 4 * (t + 1) < nblk) { mm3(0, wave + 4 * (t + 1), ca0, ca1, wave + 4 * t, cb0, cb1); last = wave + 4 * (t + 1); }
-            }
-            if (last >= 0) {                 // the last block's epilogue (its accumulators: ca for an even count of blocks before it)
+            if (wave < nblk) { mm3(0, wave, ra, -1, rb); last = wave; }
+            if (wave + 4 < nblk) { mm3(1, wave + 4, rb, wave, ra); last = wave + 4; }
+            if (wave + 8 < nblk) { mm3(0, wave + 8, ra, wave + 4, rb); last = wave + 8; }
+            if (wave + 12 < nblk) { mm3(1, wave + 12, rb, wave + 8, ra); last = wave + 12; }
+            if (wave + 16 < nblk) { mm3(0, wave + 16, ra, wave + 12, rb); last = wave + 16; }
+            if (last >= 0) {                 // the last block's epilogue (its results: ra for an even count of blocks before it)
                 const bool in_a = (((last - wave) >> 2) & 1) == 0;
-                float xh[8];
+                float xh[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) xh[q] = *epi_addr(last, q);
+                for (int r = 0; r < 16; ++r) xh[r] = *epi_addr(last, r);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) epi_q(last, in_a ? ca0 : cb0, in_a ? ca1 : cb1, q, xh[q]);
+                for (int r = 0; r < 16; ++r) epi_q(last, in_a ? ra[r] : rb[r], r, xh[r]);
                 epi_end(last);
             }
         }
@@ -1618,9 +1618,14 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
                                                      int small_blocks, int seg_blocks, FinishSeg fs) {
     __shared__ floatx2 sm[4][64];
-    unsigned ticket;
-    da.lr_t = adam_read_lr(st, da.lr_t, 1, ticket);
+    // every thread reads lr_t itself (a uniform scalar load, consumed at the end of its dependency chain) instead of one
+    // thread + an LDS broadcast behind a barrier at the block's start — one dependent round trip less per block; the
+    // barrier before the arrival ticket guarantees every wave of the block HAS read it when the state may advance
     const int b = (int)blockIdx.x;
+    const int sb = b - col_blocks - small_blocks;
+    int nseg0 = 0;
+    if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
+    if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
         bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, 0, nullptr, nullptr, nullptr, 1, sm, da);
     } else if (b < col_blocks + small_blocks) {
@@ -1629,12 +1634,11 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
         const int64_t i = al.db1 + (int64_t)(b - col_blocks) * blockDim.x + threadIdx.x;
         if (i < al.dwlin) adam_one(da.p, da.m, da.v, i, accum[i], da.lr_t, da.b1, da.b2, da.eps);
     } else if (fs.seg.nseg) {
-        const int sb = b - col_blocks - small_blocks;
-        const int nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
         adam_segments(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
                       fs.sstride, sb);
     }
-    adam_finish(st, ticket, lr, da.b1, da.b2);
+    __syncthreads();
+    adam_finish(st, threadIdx.x == 0 ? 0u : kNoTicket, lr, da.b1, da.b2);
 }
 
 // D: dXn = dH1 . W1^T on 16x16x4 tiles, one 16-column block (x both 16-row halves, sharing the W1 operand) at a
@@ -2291,7 +2295,7 @@ static int tower_train_step(
                        "%lld floats (the accumulator layout up to d w_lin)", (long long)sdense->n_flat,
                        (long long)(al.dwlin + F + Nd));
             static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
-            const int seg_blocks = seg_env > 0 ? seg_env : 512;
+            const int seg_blocks = seg_env > 0 ? seg_env : 1024;
             const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
             const DedupeLayout dl = dedupe_layout(B, F);
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
