@@ -125,8 +125,11 @@ class GraphedStep:
     """fwd + loss + bwd captured into hipGraphs — one graph per pre-generated batch, all sharing one memory
     pool, so every replay consumes its batch in place (inputs already resident in HBM, no staging copy)."""
 
-    def __init__(self, dm, batch, device, with_optimizer=False, use_graph=True):
+    def __init__(self, dm, batch, device, with_optimizer=False, use_graph=True, steps_per_graph=1):
         self.dm = dm
+        # consecutive steps captured into ONE hipGraph (each on its own batch): a replay then runs `spg` whole train steps
+        # and the fixed cost of a graph launch (~10 us of idle GPU between two replays) is paid once per `spg` steps
+        self.spg = max(1, int(steps_per_graph))
         self.with_optimizer = with_optimizer
         self.graphs = {}
         self.use_graph = use_graph
@@ -146,8 +149,12 @@ class GraphedStep:
             dm.optimizer.step()          # single GPU: the Adam step is part of the captured graph
         self.loss = loss
 
-    def capture(self, batches):
+    def capture(self, batches, first=0):
+        """`first`: stream position of the first TIMED step — the spg-step windows are laid so that one starts there"""
         from deeptables_amd.models.layers import MultiColumnEmbedding
+        if len(batches) % self.spg:
+            self.spg = 1
+        self.s0 = first % self.spg
         self.dm.model.train()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -161,9 +168,12 @@ class GraphedStep:
         emb_layers = [l for l in self.dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
         pool = None
         for i, b in enumerate(batches):
+            if (i - self.s0) % self.spg:
+                continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                self._body(b)
+                for k in range(self.spg):
+                    self._body(batches[(i + k) % len(batches)])
             if pool is None:
                 pool = g.pool()
             self.graphs[i] = g
@@ -171,6 +181,9 @@ class GraphedStep:
             # static (rows, values) tensors and re-attach them after every replay
             self.sparse_refs[i] = [(l, {k: list(v) for k, v in l.sparse_grads.items()}) for l in emb_layers]
         torch.cuda.synchronize()
+
+    def run_eager(self, b):
+        self._body(b)
 
     def run(self, i, b):
         g = self.graphs.get(i)
@@ -201,21 +214,45 @@ class GraphedStep:
 
 
 def time_steps(step, batches, steps, warmup, barrier):
+    """EXACTLY `steps` train steps are timed (after `warmup` untimed ones).  With `spg` steps per captured graph a replay
+    runs spg consecutive steps: warmup / steps that are not multiples of spg are completed with eager steps."""
     nb = len(batches)
-    for i in range(warmup):
-        step.run(i % nb, batches[i % nb])
+    spg = getattr(step, 'spg', 1) if getattr(step, 'graphs', None) else 1
+    s0 = getattr(step, 's0', 0)
+
+    def advance(pos, n, evs=None):
+        """run n steps starting at stream position `pos`; one event per launch unit -> [(event index, steps)]"""
+        done = 0
+        while done < n:
+            i = (pos + done) % nb
+            if spg > 1 and (i - s0) % spg == 0 and n - done >= spg:
+                step.run(i, batches[i])
+                k = spg
+            else:
+                step.run(i, batches[i]) if spg == 1 else step.run_eager(batches[i])
+                k = 1
+            done += k
+            if evs is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()                 # HIP event on the launch stream after every launch unit (median / p10 / p90 below)
+                evs.append((e, k))
+    advance(0, warmup)
     barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs = []
+    e0 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(steps):
-        step.run((warmup + i) % nb, batches[(warmup + i) % nb])
-        evs[i + 1].record()            # HIP event on the launch stream after every step (median / p10 / p90 below)
+    e0.record()
+    advance(warmup, steps, evs)
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps))      # us
+    per, prev = [], e0
+    for e, k in evs:
+        per += [prev.elapsed_time(e) * 1e3 / k] * k          # us per step (a replay of k steps: its mean)
+        prev = e
+    per.sort()
+    evs = [e0] + [e for e, _ in evs]
 
     def pct(q):
         return per[min(len(per) - 1, int(q * len(per)))]
@@ -376,6 +413,8 @@ def main():
     ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN', 'AFM', 'FiBiNet', 'FGCNN', 'PNN'])
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--steps-per-graph', type=int, default=5,
+                    help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the benchmarked configuration')
@@ -439,8 +478,15 @@ def main():
     sharded = getattr(strategy, 'sharded_embeddings', False) and strategy.active and dm.fused_plan() is not None
     if sharded:
         args.no_graph = True        # collectives inside the step: launched eagerly, not captured
-    step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph)
-    step.capture(batches)
+    spg = 1
+    if world == 1 and strategy is None and not args.no_graph:
+        # the largest window <= --steps-per-graph that divides both the timed steps and the batch ring (so that exactly
+        # `steps` steps are timed, all of them through graph replays)
+        spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0 and N_BATCHES % d == 0)
+    step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
+                       steps_per_graph=spg)
+    step.capture(batches, first=args.warmup)
+    spg = step.spg
     wall, ev_s, step_stats = time_steps(step, batches, args.steps, args.warmup, barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
@@ -465,7 +511,8 @@ def main():
                                    f', Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
-                       'hipgraph': not args.no_graph, 'optimizer_in_timed_region': not args.no_optimizer,
+                       'hipgraph': not args.no_graph, 'steps_per_graph_replay': spg,
+                       'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),

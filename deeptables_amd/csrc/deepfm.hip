@@ -1145,13 +1145,6 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         //      it have been read), A = the dH1 tile in h1s (both 16-row halves share a W1 operand), wave w owns the
         //      16-column blocks w, w + 4, ..; block k's epilogue (partial sums; dXn replaces xhat in place) is issued
         //      between the MFMA groups of block k + 1.
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
-            st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
-            st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
-        }
         // 32x32x2 tiles (half as many matrix instructions per flop as 16x16x4: with ONE wave per SIMD every instruction
         // issued between two MFMAs is a bubble of the pipe — the 16x16x4 form of this loop ran at 58 % of the pipe's rate,
         // 24.7 K cycles for 14.3 K of MFMA work).  K permutation as in GEMM1: lane (c, s), step 4g + j <-> k = 8g + 4s + j,
@@ -1162,10 +1155,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             return p.W1 + (int64_t)col * kH1 + 4 * s;
         };
         floatx4 bW[2][16];
-        if (wave < nblk) {
+        if (wave < nblk) {       // the first block's W1 operand is on its way while the tile is re-staged
             const float* wrow = w1row(wave);
 #pragma unroll
             for (int g = 0; g < 16; ++g) bW[0][g] = ld4(wrow + 8 * g);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
+            st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
+            st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
         }
         floatx4 aA[16];
 #pragma unroll
@@ -1524,6 +1524,25 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         d = *reinterpret_cast<const floatx2*>(accum + al.db1 + 2 * lane);
         ga = gamma[col]; be = beta[col];
     }
+    // the optimizer's p / m / v of the two elements wave 0 finishes: fetched with the slices (k_finish_step), not after them
+    const int64_t e0 = w2 ? al.dW2 + (int64_t)(2 * lane) * kH2 + row : al.dW1 + (int64_t)col * kH1 + 2 * lane;
+    const int64_t e1 = w2 ? e0 + kH2 : e0 + 1;
+    float pp[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+    if (da.p && wave == 0) {
+        pp[0] = da.p[e0]; pp[1] = da.p[e1]; pm[0] = da.m[e0]; pm[1] = da.m[e1]; pv[0] = da.v[e0]; pv[1] = da.v[e1];
+    }
+    auto adam2 = [&](float g0, float g1) {       // Keras Adam on elements e0, e1 from the prefetched slots
+        const float g[2] = {g0, g1};
+        const int64_t ei[2] = {e0, e1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float mi = da.b1 * pm[k] + (1.f - da.b1) * g[k];
+            const float vi = da.b2 * pv[k] + (1.f - da.b2) * g[k] * g[k];
+            da.m[ei[k]] = mi;
+            da.v[ei[k]] = vi;
+            da.p[ei[k]] = pp[k] - da.lr_t * mi / (sqrtf(vi) + da.eps);
+        }
+    };
     floatx2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1538,25 +1557,17 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     if (wave != 0) return;
     m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     if (w2) {       // row `row` of dW2^T: dW2[k][row] for k = 2 lane, 2 lane + 1
-        const int64_t i0 = al.dW2 + (int64_t)(2 * lane) * kH2 + row, i1 = al.dW2 + (int64_t)(2 * lane + 1) * kH2 + row;
-        accum[i0] = m.x;
-        accum[i1] = m.y;
-        if (da.p) {
-            adam_one(da.p, da.m, da.v, i0, m.x, da.lr_t, da.b1, da.b2, da.eps);
-            adam_one(da.p, da.m, da.v, i1, m.y, da.lr_t, da.b1, da.b2, da.eps);
-        }
+        accum[e0] = m.x;
+        accum[e1] = m.y;
+        if (da.p) adam2(m.x, m.y);
         return;
     }
     const float dg = wave_sum(w.x * m.x + w.y * m.y);
     const float db = wave_sum(w.x * d.x + w.y * d.y);
     {
-        const int64_t i0 = al.dW1 + (int64_t)col * kH1 + 2 * lane;
         const floatx2 g = floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
-        *reinterpret_cast<floatx2*>(accum + i0) = g;
-        if (da.p) {
-            adam_one(da.p, da.m, da.v, i0, g.x, da.lr_t, da.b1, da.b2, da.eps);
-            adam_one(da.p, da.m, da.v, i0 + 1, g.y, da.lr_t, da.b1, da.b2, da.eps);
-        }
+        *reinterpret_cast<floatx2*>(accum + e0) = g;
+        if (da.p) adam2(g.x, g.y);
     }
     if (lane == 0) {
         float sumc = 0.f, sumcx = 0.f;
@@ -2295,7 +2306,7 @@ static int tower_train_step(
                        "%lld floats (the accumulator layout up to d w_lin)", (long long)sdense->n_flat,
                        (long long)(al.dwlin + F + Nd));
             static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
-            const int seg_blocks = seg_env > 0 ? seg_env : 1024;
+            const int seg_blocks = seg_env > 0 ? seg_env : 512;
             const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
             const DedupeLayout dl = dedupe_layout(B, F);
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
