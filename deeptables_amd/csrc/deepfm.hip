@@ -1960,7 +1960,9 @@ __device__ __forceinline__ void rows_epilogue_wave(unsigned* work, int first_til
                 upd[k] = ok[k] && ad.table && row[k] >= 0;
                 if (ad.table) {
                     const int64_t rr = upd[k] ? row[k] : 0;
-                    pv[k] = ld4(ad.table + (rr << dshift) + 4 * c);
+                    // without embedding dropout the X tile holds the looked-up table rows bit for bit (kernel A copied them,
+                    // nothing has written the table since): p needs no second random read — 5 random accesses per row, not 6
+                    pv[k] = drop.thr ? ld4(ad.table + (rr << dshift) + 4 * c) : xr[k];
                     mv[k] = ld4(ad.m + rr * ad.sstride + 4 * c);
                     vv[k] = ld4(ad.v + rr * ad.sstride + 4 * c);
                 }
@@ -2306,7 +2308,8 @@ static int tower_train_step(
                        "%lld floats (the accumulator layout up to d w_lin)", (long long)sdense->n_flat,
                        (long long)(al.dwlin + F + Nd));
             static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
-            const int seg_blocks = seg_env > 0 ? seg_env : 512;
+            // 512 blocks: 1.5 us faster with uniform ids (878 segments), 1024: 4.6 us faster with Zipf ids (15 K segments)
+            const int seg_blocks = seg_env > 0 ? seg_env : 1024;
             const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
             const DedupeLayout dl = dedupe_layout(B, F);
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
