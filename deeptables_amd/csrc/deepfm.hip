@@ -502,6 +502,8 @@ struct MlpParams {
     const float *bn2, *beta;
     float eps, momentum;
     float *moving_mean, *moving_var, *mean_w, *rstd_w, *sc_w, *betap_w;
+    float* gammap_w;      // this step's gamma, published like betap: the finishing launch (k_finish_step) reads gamma / beta while
+                          // it UPDATES the parameters themselves in other blocks
 };
 
 
@@ -649,6 +651,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         }
         if (blockIdx.x == 0 && col < CP) {         // published for kernels E / D (launched after this one) + moving statistics
             p.mean_w[col] = bnv[0][i]; p.rstd_w[col] = rstd; p.sc_w[col] = bnv[1][i]; p.betap_w[col] = bnv[2][i];
+            p.gammap_w[col] = col < dm.C ? p.gamma[col] : 0.f;
             if (col < dm.C) {
                 if (p.moving_mean) p.moving_mean[col] = p.moving_mean[col] * p.momentum + bnv[0][i] * (1.f - p.momentum);
                 if (p.moving_var) p.moving_var[col] = p.moving_var[col] * p.momentum + var * (1.f - p.momentum);
@@ -2046,7 +2049,7 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 // workspace layout (floats)
 struct DeepFmWs {
     int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, dXc, dXn, cm1,
-        cm2, total;
+        cm2, gammap, total;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
@@ -2073,6 +2076,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.dXn = take(L > 0 ? 0 : rows * dm.CP);         // pipelined step: dXn = dH1 . W1^T (kernel C -> the row-gradient epilogue)
     w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
+    w.gammap = take(dm.CP);
     w.total = o;
     return w;
 }
@@ -2178,7 +2182,7 @@ static int tower_train_step(
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
-                 ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap};
+                 ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.gammap};
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)(dcn ? W2 : w3) | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
     const int tiles = ceil_div(B, kTM);
@@ -2315,8 +2319,9 @@ static int tower_train_step(
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
                                adam->table, adam->m, adam->v, grad_rows, adam->sstride, D};
             const DenseAdam da{sdense->p, sdense->m, sdense->v, adam->lr_t_host, adam->b1, adam->b2, adam->eps};
-            hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, bn_gamma,
-                               bn_beta, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
+            // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
+            hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
+                               ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
                                dm.C + kH2, small_blocks, seg_blocks, fs);
         } else {
             // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)

@@ -538,6 +538,9 @@ def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab
     assert type(dm.fused_plan()).__name__ == 'FusedDeepFM'
     for seed in (5, 6):                                        # two batches: the second one starts from non-zero slots
         idx, dense, y = batch(cats, 13, B, seed=seed)
-        res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2)
-        assert headline.rows_in_step_ok(res), res
+        # repeated: the first version of the finishing launch read gamma / beta while other blocks of the SAME launch updated
+        # them — a race that showed up in one run out of a few (tools/r3/dbg_ab2.py tells which tensors moved)
+        for rep in range(4):
+            res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2 + rep % 2)
+            assert headline.rows_in_step_ok(res), (rep, res)
         dm.train_step([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))   # move on (in-step path)
