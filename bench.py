@@ -138,6 +138,7 @@ class GraphedStep:
         self.sparse_refs = {}
         self._opt_graph = None      # data parallel: the optimizer step is a second captured graph, after the exchange
         self._dp_steps = 0
+        self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] HIP events around fwd+bwd | exchange | optimizer
 
     def _body(self, b):
         dm = self.dm
@@ -185,7 +186,23 @@ class GraphedStep:
     def run_eager(self, b):
         self._body(b)
 
+    def phase_times(self):
+        """mean microseconds of the three phases of a data-parallel step (HIP events on the launch stream; read after
+        the timed region): what a scaling run needs to diagnose itself"""
+        if not self.phase_events:
+            return None
+        torch.cuda.synchronize()
+        n = len(self.phase_events)
+        fb = sum(a.elapsed_time(b) for a, b, _, _ in self.phase_events) / n * 1e3
+        ex = sum(b.elapsed_time(c) for _, b, c, _ in self.phase_events) / n * 1e3
+        op = sum(c.elapsed_time(d) for _, _, c, d in self.phase_events) / n * 1e3
+        return {'fwd_bwd_us': fb, 'exchange_us': ex, 'opt_us': op, 'steps': n}
+
     def run(self, i, b):
+        ev = None
+        if self._dp and self.phase_events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         g = self.graphs.get(i)
         if g is not None:
             g.replay()
@@ -196,7 +213,11 @@ class GraphedStep:
         if self._dp:
             # data parallel = two captured halves around the (eager) RCCL collectives: [fwd+bwd graph] -> dense
             # all-reduce + sparse all-gather into persistent buffers -> [optimizer graph]
+            if ev:
+                ev[1].record()
             self.strategy.exchange_gradients(self.dm.model, self.dm.optimizer if self.with_optimizer else None)
+            if ev:
+                ev[2].record()
             if self.with_optimizer:
                 sharded = getattr(self.dm.model, '_dt_sharded_step', False)
                 if self._opt_graph is not None:
@@ -211,6 +232,9 @@ class GraphedStep:
                 else:
                     self.dm.optimizer.step()     # first steps (slot buffers get allocated) and the sharded-table step
             self._dp_steps += 1
+            if ev:
+                ev[3].record()
+                self.phase_events.append(tuple(ev))
 
 
 def time_steps(step, batches, steps, warmup, barrier):
@@ -239,6 +263,8 @@ def time_steps(step, batches, steps, warmup, barrier):
     advance(0, warmup)
     barrier()
     torch.cuda.synchronize()
+    if getattr(step, '_dp', False):
+        step.phase_events = []
     evs = []
     e0 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -422,6 +448,8 @@ def main():
     ap.add_argument('--tables', default='replicated', choices=['replicated', 'sharded'],
                     help='N>1: replicated tables + dense all-reduce + deduped sparse all-gather (the reference\'s '
                          'MirroredStrategy shape, default) or embedding rows owned per field by one rank (all-to-all)')
+    ap.add_argument('--bucket-ratio', type=float, default=1.0,
+                    help='N>1, replicated tables: wire size of a rank\'s sparse bucket / its lookups (1.0 never overflows)')
     ap.add_argument('--force-dp', action='store_true',
                     help='N=1: run the data-parallel step structure anyway (world size 1: collectives are no-ops)')
     ap.add_argument('--force-sharded', action='store_true', help='N=1: run the sharded-table step anyway (eager)')
@@ -438,6 +466,7 @@ def main():
         cls = ShardedEmbeddingStrategy if (args.tables == 'sharded' or args.force_sharded) else DataParallelStrategy
         strategy = cls.from_env('nccl')
         strategy.assume_uniform_batches = True      # fixed batch per rank: no count exchange / host sync
+        strategy.sparse_bucket_ratio = args.bucket_ratio
         if args.force_sharded:
             strategy.force = True
         if args.force_dp:
@@ -488,6 +517,8 @@ def main():
     step.capture(batches, first=args.warmup)
     spg = step.spg
     wall, ev_s, step_stats = time_steps(step, batches, args.steps, args.warmup, barrier)
+    if strategy is not None and hasattr(strategy, 'check_sparse_overflow'):
+        strategy.check_sparse_overflow()            # a bucket that dropped entries invalidates the run: fail loudly
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -534,6 +565,13 @@ def main():
             if bf16:
                 result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
 
+        ph = step.phase_times()
+        if ph is not None:          # N > 1 (or --force-dp): where a data-parallel step spends its time, on rank 0
+            result['phases'] = ph
+            st_ = strategy
+            result['config']['sparse_exchange'] = ('unique (row, summed grad) buckets, ratio %.2f' % st_.sparse_bucket_ratio) \
+                if (getattr(st_, 'compacts_segments', False) and not sharded and os.environ.get('DT_AMD_DP_DEDUPE', '1') != '0') \
+                else 'per-lookup (rows, values)'
         if parity is not None:
             result['parity'] = parity
         if not args.no_extras and world == 1:

@@ -376,9 +376,108 @@ __global__ __launch_bounds__(256) void k_sgd_rows(float* __restrict__ table, con
     }
 }
 
+// ---- bucketed sparse gradient for the data-parallel exchange (north_star: "bucketed sparse embedding grads") -------------
+// A fused step hands out the rows looked up once as per-lookup entries (rows >= 0) and the rows looked up several times as
+// segments (DedupeWs, csrc/deepfm.hip).  k_rows_compact turns that into UNIQUE (row, summed gradient x scale) entries
+// packed at the front of (out_rows, out_vals): what a rank puts on the wire instead of one entry per lookup — with
+// Zipf ids half as many entries, and every receiver applies W x (unique rows) updates instead of W x B x F.
+//   leading blocks : one lane group (D/4 lanes) per lookup; the wave's valid lookups take consecutive slots behind ONE
+//                    atomicAdd on the counter (ballot + popcount)
+//   trailing blocks: one wave per segment (the walk of adam_segments): members summed, one slot per segment
+// Entries beyond `cap` are dropped and counted in counter[1] (the caller checks it on the host outside the step);
+// out_rows must be pre-filled with -1.
+__global__ __launch_bounds__(256) void k_rows_compact(const int64_t* __restrict__ rows, const float* __restrict__ values,
+                                                      int64_t n, int D, SegTail sg, int row_blocks, int seg_blocks,
+                                                      float scale, int64_t cap, int64_t* __restrict__ out_rows,
+                                                      float* __restrict__ out_vals, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = D >> 2, groups = 64 / lpr, grp = lane / lpr, part = lane - grp * lpr;
+    if ((int)blockIdx.x < row_blocks) {
+        const int64_t occ = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+        const bool in = occ < n;
+        const int64_t row = in ? rows[occ] : -1;
+        const bool lead = part == 0 && row >= 0;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row >= 0) g = *reinterpret_cast<const float4*>(values + occ * D + 4 * part);
+        const unsigned long long mask = __ballot(lead);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&counter[0], __popcll(mask));
+        base = __builtin_amdgcn_readfirstlane(base);
+        // slot of this lane's lookup: its lead lane's rank among the wave's lead lanes
+        const int lead_lane = grp * lpr;
+        const int pos = base + __popcll(mask & ((1ULL << lead_lane) - 1ULL));
+        if (row >= 0) {
+            if (pos < cap) {
+                if (part == 0) out_rows[pos] = row;
+                *reinterpret_cast<float4*>(out_vals + (int64_t)pos * D + 4 * part) =
+                    make_float4(g.x * scale, g.y * scale, g.z * scale, g.w * scale);
+            } else if (part == 0) {
+                atomicAdd(&counter[1], 1);
+            }
+        }
+        return;
+    }
+    if (!sg.nseg) return;
+    const int gw = ((int)blockIdx.x - row_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int nw = seg_blocks * (int)(blockDim.x >> 6);
+    const int wpr = nw >= sg.regions ? nw / sg.regions : 1, lw = nw >= sg.regions ? gw / sg.regions : 0;
+    if (lw >= wpr) return;
+    for (int e = gw % sg.regions; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw)) {
+        const int nseg = sg.nseg[e];
+        for (int sl = lw; sl < nseg; sl += wpr) {
+            const int s = e * sg.cap + sl;
+            const int64_t row = sg.row[s];
+            const int off = sg.off[s], cnt = sg.cnt[s];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = grp; i < cnt; i += groups) {
+                const int o0 = sg.list[off + i];
+                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
+            }
+            for (int o = lpr; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&counter[0], 1);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (grp == 0) {
+                if (pos < cap) {
+                    if (part == 0) out_rows[pos] = row;
+                    *reinterpret_cast<float4*>(out_vals + (int64_t)pos * D + 4 * part) =
+                        make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+                } else if (part == 0) {
+                    atomicAdd(&counter[1], 1);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dt
 
 using namespace dt;
+
+extern "C" int dt_rows_compact(const int64_t* rows, const float* values, int64_t n_rows, int D, const int* seg_nseg,
+                               const int64_t* seg_row, const int* seg_off, const int* seg_cnt, const int* seg_list,
+                               int seg_regions, int seg_cap, float scale, int64_t cap, int64_t* out_rows, float* out_vals,
+                               int* counter2, void* stream) {
+    DT_REQUIRE(n_rows >= 0 && cap > 0 && rows && values && out_rows && out_vals && counter2, "dt_rows_compact: bad arguments");
+    const int lpr = D / 4;
+    DT_UNSUPPORTED(D % 4 || lpr < 1 || lpr > 64 || (lpr & (lpr - 1)), "dt_rows_compact: D = 4 * 2^k <= 256 (D=%d)", D);
+    DT_REQUIRE(!seg_nseg || (seg_row && seg_off && seg_cnt && seg_list && seg_regions > 0 && seg_cap > 0),
+               "dt_rows_compact: bad segment arrays");
+    hipStream_t st = as_stream(stream);
+    hipMemsetAsync(counter2, 0, 2 * sizeof(int), st);
+    hipMemsetAsync(out_rows, 0xff, (size_t)cap * sizeof(int64_t), st);          // -1: unused slots are skipped by every consumer
+    const SegTail sg{seg_nseg, seg_row, seg_off, seg_cnt, seg_list, seg_regions, seg_cap};
+    const int row_blocks = (int)((n_rows * lpr + 255) / 256);
+    const int seg_blocks = seg_nseg ? 1024 : 0;
+    if (row_blocks + seg_blocks == 0) return DT_OK;
+    hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)(row_blocks + seg_blocks)), dim3(256), 0, st, rows, values, n_rows, D, sg,
+                       row_blocks, seg_blocks, scale, cap, out_rows, out_vals, counter2);
+    return launch_status("dt_rows_compact");
+}
 
 extern "C" int dt_bce_logits(const float* z, const float* y, int64_t n, float* loss, float* dz, void* stream) {
     DT_REQUIRE(n > 0 && z && y && loss && dz, "dt_bce_logits: bad arguments");

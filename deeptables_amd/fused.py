@@ -75,8 +75,12 @@ def _dedupe_in_step(plan, B, backward):
     if not getattr(opt, 'supports_row_segments', False):
         return False
     st = plan.dm.config.distribute_strategy
-    if st is not None and int(getattr(st, 'world_size', 1)) > 1:
-        return False
+    if st is not None and (int(getattr(st, 'world_size', 1)) > 1 or getattr(st, 'force_dp', False)):
+        # data parallel: only with an exchange that packs the segments into unique (row, summed gradient) entries before
+        # the all-gather (parallel.DataParallelStrategy.allgather_sparse); DT_AMD_DP_DEDUPE=0: per-lookup entries on the wire
+        if not getattr(st, 'compacts_segments', False) or getattr(st, 'sharded_embeddings', False) or \
+                os.environ.get('DT_AMD_DP_DEDUPE', '1') == '0':
+            return False
     return not plan.emb.uses_dense_grad(plan.D)
 
 

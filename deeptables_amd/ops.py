@@ -76,6 +76,29 @@ class SparseRowGrad:
         return rows, self.values
 
 
+def compact_rows(grad, cap, scale=1.0, out_rows=None, out_vals=None, counter=None):
+    """SparseRowGrad of a fused step (entries for the rows looked up once + segments) -> SparseRowGrad of UNIQUE
+    (row, summed gradient * scale) entries packed at the front of [cap] buffers (row -1 = unused slot): the bucket a
+    data-parallel rank puts on the wire (dt_rows_compact).  Returns (grad, counter): counter[0] = entries produced,
+    counter[1] = entries that did not fit `cap` (a device tensor: read it outside the step)."""
+    rows = grad.rows.reshape(-1)
+    D = grad.values.shape[-1]
+    values = grad.values.reshape(-1, D)
+    values = values if values.is_contiguous() else values.contiguous()
+    dev = rows.device
+    if out_rows is None:
+        out_rows = torch.empty((cap,), dtype=torch.int64, device=dev)
+    if out_vals is None:
+        out_vals = torch.empty((cap, D), dtype=torch.float32, device=dev)
+    if counter is None:
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    seg = grad.segments
+    sg = [ptr(t) for t in seg[:5]] + [int(seg[5]), int(seg[6])] if seg is not None else [None] * 5 + [0, 0]
+    check(lib().dt_rows_compact(ptr(rows), ptr(values), rows.numel(), D, *sg, float(scale), int(cap), ptr(out_rows),
+                                ptr(out_vals), ptr(counter), stream_ptr()), 'dt_rows_compact')
+    return SparseRowGrad(out_rows, out_vals, fields=0), counter
+
+
 class _EmbeddingLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, table, row_offset, vocab, holder, dense_grad, oob):

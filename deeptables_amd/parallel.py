@@ -26,7 +26,16 @@ from .ops import SparseRowGrad
 class DataParallelStrategy:
     """Pass as `ModelConfig(distribute_strategy=...)`."""
 
-    def __init__(self, device=None, process_group=None, assume_uniform_batches=False):
+    # the fused steps may keep their in-step row dedupe under data parallel: the exchange packs a rank's sparse gradient
+    # into unique (row, summed gradient) entries first (`allgather_sparse`, ops.compact_rows)
+    compacts_segments = True
+
+    def __init__(self, device=None, process_group=None, assume_uniform_batches=False, sparse_bucket_ratio=1.0):
+        # wire size of a rank's sparse bucket as a fraction of its lookups (B x F entries): 1.0 can never overflow; with
+        # skewed ids (Criteo-like: ~0.5 of the lookups are distinct rows) a smaller bucket halves the all-gather.  Entries
+        # that do not fit are DROPPED and counted: `check_sparse_overflow()` raises on the host (call it outside the step).
+        self.sparse_bucket_ratio = float(sparse_bucket_ratio)
+        self._overflow_counters = []
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; use DataParallelStrategy.from_env()')
         self.group = process_group
@@ -138,8 +147,28 @@ class DataParallelStrategy:
         """SparseRowGrad -> SparseRowGrad of all ranks' rows (values pre-divided by world size).  With
         assume_uniform_batches the results live in persistent buffers (one set per `tag`)."""
         W = self.world_size
-        if W == 1:
+        if W == 1 and not getattr(self, 'force_dp', False):
             return grad
+        if getattr(grad, 'segments', None) is not None or getattr(grad, 'fields', None) == -1:
+            # a fused step's deduplicated gradient: pack unique (row, summed gradient / W) entries into a fixed-size
+            # bucket (persistent, so the step stays capturable) and gather THAT — "bucketed sparse grads"
+            from . import ops
+            n, D = grad.rows.numel(), grad.values.shape[-1]
+            dev = grad.rows.device
+            cap = max(1, int(np.ceil(self.sparse_bucket_ratio * n)))
+            b_rows = self._persistent(('b_rows', tag), (cap,), torch.int64, dev)
+            b_vals = self._persistent(('b_vals', tag), (cap, D), torch.float32, dev)
+            ctr = self._persistent(('b_ctr', tag), (2,), torch.int32, dev)
+            if not any(c is ctr for c in self._overflow_counters):
+                self._overflow_counters.append(ctr)
+            ops.compact_rows(grad, cap, 1.0 / W, b_rows, b_vals, ctr)
+            if W == 1:
+                return SparseRowGrad(b_rows, b_vals, fields=0)
+            all_rows = self._persistent(('rows', tag), (W * cap,), torch.int64, dev)
+            all_vals = self._persistent(('vals', tag), (W * cap, D), torch.float32, dev)
+            self._all_gather_into(all_rows, b_rows)
+            self._all_gather_into(all_vals, b_vals)
+            return SparseRowGrad(all_rows, all_vals, fields=0)     # rows of different ranks may coincide: global dedupe
         if self.assume_uniform_batches:
             n, D = grad.rows.numel(), grad.values.shape[1]
             dev = grad.rows.device
@@ -167,12 +196,22 @@ class DataParallelStrategy:
         self._all_gather_into(all_vals, vals)
         return SparseRowGrad(all_rows, all_vals)     # padded entries carry row -1 and are skipped
 
+    def check_sparse_overflow(self):
+        """host check of the sparse buckets (sparse_bucket_ratio < 1): raises if any step dropped entries"""
+        for c in self._overflow_counters:
+            dropped = int(c[1].item())
+            if dropped:
+                raise RuntimeError(f'sparse gradient bucket overflow: {dropped} unique rows did not fit '
+                                   f'sparse_bucket_ratio={self.sparse_bucket_ratio}; raise it (1.0 never overflows)')
+
     def exchange_gradients(self, model, optimizer=None):
         from .models.layers import MultiColumnEmbedding
-        if self.world_size == 1:
+        if self.world_size == 1 and not getattr(self, 'force_dp', False):
             return
         flat = getattr(model, '_dt_flat_grad', None)
         work = None
+        if self.world_size == 1:
+            flat = None                 # force_dp at world size 1: only the sparse bucketing below does anything
         if flat is not None:
             # the fused train step already keeps every dense gradient in ONE contiguous buffer: all-reduce it in
             # place (async, overlapped with the sparse all-gathers below), no bucket copy in or out
@@ -182,7 +221,7 @@ class DataParallelStrategy:
                     p.grad.untyped_storage().data_ptr() != base]     # e.g. a small table's dense gradient
             if rest:
                 self.allreduce_dense(rest)
-        else:
+        elif self.world_size > 1:
             self.allreduce_dense([p for p in model.parameters() if p.requires_grad])
         tag = 0
         for layer in model.modules():

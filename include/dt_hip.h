@@ -237,6 +237,16 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
  * (seg_row[s], seg_off[s], seg_cnt[s]) with seg_list[seg_off .. +seg_cnt) naming the `values` rows to sum.  Their
  * entries of `rows` must be -1.  The waves of the same launch sum a segment's members and apply the update to its table
  * row: no lookup adds into a shared gradient row.                                                                   */
+/* dt_rows_compact — the "bucketed sparse embedding gradient" of the data-parallel exchange (replaces what
+ * tf.distribute.MirroredStrategy all-gathers for an IndexedSlices gradient, deepmodel.py:88-103): a fused step's sparse
+ * gradient (rows looked up once as entries of (rows, values), rows looked up several times as segments — dt_deepfm_train_step)
+ * becomes UNIQUE (row, summed gradient * scale) entries packed at the front of out_rows [cap] / out_vals [cap, D];
+ * unused slots hold row -1.  counter2 (two device ints): [0] = entries produced, [1] = entries dropped because they did
+ * not fit `cap` (check on the host outside the step).  seg_* as in dt_adam_rows_step_seg (seg_nseg NULL: no segments). */
+int dt_rows_compact(const int64_t* rows, const float* values, int64_t n_rows, int D, const int* seg_nseg,
+                    const int64_t* seg_row, const int* seg_off, const int* seg_cnt, const int* seg_list,
+                    int seg_regions, int seg_cap, float scale, int64_t cap, int64_t* out_rows, float* out_vals,
+                    int* counter2, void* stream);
 int dt_adam_rows_step_seg(float* table, float* m, float* v, const int64_t* rows, float* values, int64_t n_rows, int D,
                           int fields, void* slots, int64_t n_slots, int* mark, float lr_t, float beta1, float beta2,
                           float eps, void* state, float* dense_p, const float* dense_g, float* dense_m, float* dense_v,

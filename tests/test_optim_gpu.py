@@ -241,3 +241,42 @@ def test_pre_dense_hook_orders_table_updates_first(dev):
         assert opt.t == 2 and (len(called) == 2) == use_hook and opt.pre_dense_hook is None
         out.append((table.detach().cpu().clone(), w.detach().cpu().clone()))
     assert torch.equal(out[0][0], out[1][0]) and torch.allclose(out[0][1], out[1][1], atol=1e-7)
+
+
+@pytest.mark.parametrize('vocab,B', [(30, 256), (2000, 777), (100000, 4096)])
+def test_rows_compact_packs_unique_rows_with_summed_gradients(dev, monkeypatch, vocab, B):
+    """dt_rows_compact (the data-parallel exchange's sparse bucket): a fused step's gradient — entries for the rows looked
+    up once + segments — becomes one entry per distinct row holding scale x the sum over its lookups, packed at the
+    front; a bucket that is too small drops entries and says how many."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import test_fused_gpu as T
+    from deeptables_amd import ops
+    from deeptables_amd.models import layers as L
+    from oracle import headline
+    monkeypatch.setattr(L, 'DENSE_GRAD_MAX_ELEMS', 0)
+    dm, cats = T.build(26, 13, 16, vocab=vocab)
+    idx, dense, y = T.batch(cats, 13, B, seed=3)
+    dm.model.train()
+    dm.forward_backward([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))
+    g = dm.model.layers_by_name['emb_categorical_vars_all'].sparse_grads['d16'][0]
+    assert g.segments is not None
+    rows_e, vals_e = g.expanded()
+    u_ref, v_ref = headline.merge_rows(rows_e.reshape(-1).cpu(), vals_e.reshape(-1, 16).double().cpu())
+    n = rows_e.numel()
+    out, ctr = ops.compact_rows(g, n, scale=0.5)
+    torch.cuda.synchronize()
+    produced, dropped = int(ctr[0]), int(ctr[1])
+    assert dropped == 0 and produced == u_ref.numel()
+    r = out.rows.cpu()
+    assert bool((r[:produced] >= 0).all()) and bool((r[produced:] == -1).all())
+    order = torch.argsort(r[:produced])
+    assert torch.equal(r[:produced][order], u_ref)
+    got = out.values.double().cpu()[:produced][order]
+    assert (got - 0.5 * v_ref).abs().max().item() <= 1e-6 * max(v_ref.abs().max().item(), 1e-30) + 1e-12
+    # a bucket of half the distinct rows: that many entries kept, the rest counted as dropped
+    cap = max(1, produced // 2)
+    out2, ctr2 = ops.compact_rows(g, cap)
+    torch.cuda.synchronize()
+    assert int(ctr2[0]) == produced and int(ctr2[1]) == produced - cap
+    assert bool((out2.rows >= 0).all())
