@@ -569,9 +569,13 @@ def main():
         if ph is not None:          # N > 1 (or --force-dp): where a data-parallel step spends its time, on rank 0
             result['phases'] = ph
             st_ = strategy
-            result['config']['sparse_exchange'] = ('unique (row, summed grad) buckets, ratio %.2f' % st_.sparse_bucket_ratio) \
-                if (getattr(st_, 'compacts_segments', False) and not sharded and os.environ.get('DT_AMD_DP_DEDUPE', '1') != '0') \
-                else 'per-lookup (rows, values)'
+            bucketed = getattr(st_, 'compacts_segments', False) and not sharded and os.environ.get('DT_AMD_DP_DEDUPE', '1') != '0'
+            result['config']['sparse_exchange'] = (
+                'per-lookup (rows, values)' if not bucketed else
+                'one entry per distinct row of the rank (segments summed in place), holes skipped by the receivers'
+                if st_.sparse_bucket_ratio >= 1.0 else
+                'unique (row, summed grad) entries packed into a bucket of %.2f x the lookups' % st_.sparse_bucket_ratio)
+
         if parity is not None:
             result['parity'] = parity
         if not args.no_extras and world == 1:

@@ -82,6 +82,7 @@ SIGNATURES = {
     'dt_adam_rows_step_seg': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
                                    _c_f32, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
+    'dt_rows_merge_segments': (_c_int, [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     'dt_rows_compact': (_c_int, [_ptr, _ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_f32, _c_i64,
                                  _ptr, _ptr, _ptr, _ptr]),
     'dt_bce_logits': (_c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),

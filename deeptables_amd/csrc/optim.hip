@@ -454,9 +454,72 @@ __global__ __launch_bounds__(256) void k_rows_compact(const int64_t* __restrict_
     }
 }
 
+// The cheap form of the bucket (no slot counter: 18 K returning atomics on one word cost 200 us): every segment's members are
+// summed INTO the gradient row of its first member, whose entry of `rows` gets the table row back; the other members
+// keep row -1.  The (rows, values) pair then holds one entry per distinct row of the rank (and holes the consumers skip)
+// in its original [.., fields] layout: same wire size, but a receiver applies W x (distinct rows) updates.
+__global__ __launch_bounds__(256) void k_rows_merge_segments(int64_t* __restrict__ rows, float* __restrict__ values, int D,
+                                                             SegTail sg, int seg_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = D >> 2, groups = 64 / lpr, grp = lane / lpr, part = lane - grp * lpr;
+    const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int nw = seg_blocks * (int)(blockDim.x >> 6);
+    const int wpr = nw >= sg.regions ? nw / sg.regions : 1, lw = nw >= sg.regions ? gw / sg.regions : 0;
+    if (lw >= wpr) return;
+    for (int e = gw % sg.regions; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw)) {
+        const int nseg = sg.nseg[e];
+        for (int sl = lw; sl < nseg; sl += wpr) {
+            const int s = e * sg.cap + sl;
+            const int64_t row = sg.row[s];
+            const int off = sg.off[s], cnt = sg.cnt[s];
+            const int first = sg.list[off];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int i = grp;
+            for (; i + 3 * groups < cnt; i += 4 * groups) {      // four members per group in flight
+                const int o0 = sg.list[off + i], o1 = sg.list[off + i + groups], o2 = sg.list[off + i + 2 * groups],
+                          o3 = sg.list[off + i + 3 * groups];
+                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
+                const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
+                const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
+                acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
+                acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
+            }
+            for (; i < cnt; i += groups) {
+                const int o0 = sg.list[off + i];
+                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
+            }
+            for (int o = lpr; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            // every read of the members' rows (this wave's, above) is complete before the first member's row is overwritten
+            if (grp == 0) {
+                *reinterpret_cast<float4*>(values + (int64_t)first * D + 4 * part) = acc;
+                if (part == 0) rows[first] = row;
+            }
+        }
+    }
+}
+
 }  // namespace dt
 
 using namespace dt;
+
+extern "C" int dt_rows_merge_segments(int64_t* rows, float* values, int D, const int* seg_nseg, const int64_t* seg_row,
+                                      const int* seg_off, const int* seg_cnt, const int* seg_list, int seg_regions,
+                                      int seg_cap, void* stream) {
+    DT_REQUIRE(rows && values && seg_nseg && seg_row && seg_off && seg_cnt && seg_list && seg_regions > 0 && seg_cap > 0,
+               "dt_rows_merge_segments: bad arguments");
+    const int lpr = D / 4;
+    DT_UNSUPPORTED(D % 4 || lpr < 1 || lpr > 64 || (lpr & (lpr - 1)), "dt_rows_merge_segments: D = 4 * 2^k <= 256 (D=%d)", D);
+    const SegTail sg{seg_nseg, seg_row, seg_off, seg_cnt, seg_list, seg_regions, seg_cap};
+    const int seg_blocks = 1024;
+    hipLaunchKernelGGL(k_rows_merge_segments, dim3(seg_blocks), dim3(256), 0, as_stream(stream), rows, values, D, sg,
+                       seg_blocks);
+    return launch_status("dt_rows_merge_segments");
+}
 
 extern "C" int dt_rows_compact(const int64_t* rows, const float* values, int64_t n_rows, int D, const int* seg_nseg,
                                const int64_t* seg_row, const int* seg_off, const int* seg_cnt, const int* seg_list,

@@ -76,6 +76,20 @@ class SparseRowGrad:
         return rows, self.values
 
 
+def merge_segments_(grad):
+    """In place: the segments of a fused step's SparseRowGrad are summed into their first member's entry
+    (dt_rows_merge_segments) -> SparseRowGrad over the same (rows, values) with one entry per distinct row of the step, the
+    other members keeping row -1, in the original [.., fields] layout (fields = -1: rows are distinct)."""
+    seg = grad.segments
+    if seg is None:
+        return grad
+    D = grad.values.shape[-1]
+    assert grad.values.is_contiguous() and grad.rows.is_contiguous()
+    check(lib().dt_rows_merge_segments(ptr(grad.rows), ptr(grad.values), D, *[ptr(t) for t in seg[:5]], int(seg[5]),
+                                       int(seg[6]), stream_ptr()), 'dt_rows_merge_segments')
+    return SparseRowGrad(grad.rows, grad.values, fields=-1)
+
+
 def compact_rows(grad, cap, scale=1.0, out_rows=None, out_vals=None, counter=None):
     """SparseRowGrad of a fused step (entries for the rows looked up once + segments) -> SparseRowGrad of UNIQUE
     (row, summed gradient * scale) entries packed at the front of [cap] buffers (row -1 = unused slot): the bucket a

@@ -243,6 +243,12 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
  * becomes UNIQUE (row, summed gradient * scale) entries packed at the front of out_rows [cap] / out_vals [cap, D];
  * unused slots hold row -1.  counter2 (two device ints): [0] = entries produced, [1] = entries dropped because they did
  * not fit `cap` (check on the host outside the step).  seg_* as in dt_adam_rows_step_seg (seg_nseg NULL: no segments). */
+/* dt_rows_merge_segments — the same bucket without packing (no slot counter): in place, every segment's members are summed
+ * into the gradient row of its FIRST member, whose entry of `rows` gets the table row back (the other members keep -1):
+ * (rows, values) then holds one entry per distinct row of the rank in its original [.., fields] layout. */
+int dt_rows_merge_segments(int64_t* rows, float* values, int D, const int* seg_nseg, const int64_t* seg_row,
+                           const int* seg_off, const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
+                           void* stream);
 int dt_rows_compact(const int64_t* rows, const float* values, int64_t n_rows, int D, const int* seg_nseg,
                     const int64_t* seg_row, const int* seg_off, const int* seg_cnt, const int* seg_list,
                     int seg_regions, int seg_cap, float scale, int64_t cap, int64_t* out_rows, float* out_vals,

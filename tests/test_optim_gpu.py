@@ -280,3 +280,13 @@ def test_rows_compact_packs_unique_rows_with_summed_gradients(dev, monkeypatch, 
     torch.cuda.synchronize()
     assert int(ctr2[0]) == produced and int(ctr2[1]) == produced - cap
     assert bool((out2.rows >= 0).all())
+    # the in-place form (the exchange's default): segments summed into their first member's entry, holes elsewhere
+    merged = ops.merge_segments_(g)
+    torch.cuda.synchronize()
+    rm = merged.rows.reshape(-1).cpu()
+    keep = rm >= 0
+    assert int(keep.sum()) == u_ref.numel() and merged.fields == -1
+    order = torch.argsort(rm[keep])
+    assert torch.equal(rm[keep][order], u_ref)
+    gm = merged.values.reshape(-1, 16).double().cpu()[keep][order]
+    assert (gm - v_ref).abs().max().item() <= 1e-6 * max(v_ref.abs().max().item(), 1e-30) + 1e-12
