@@ -129,6 +129,12 @@ SIGNATURES = {
                                    _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr, _ptr]),
+    'dt_dcn_train_step_adam': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
+                                        _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32,
+                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr,
+                                        _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
+                                        _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
 }
 
 DT_IDX_F32, DT_IDX_I32 = 0, 1

@@ -596,7 +596,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                                                   float* __restrict__ dlogit, float* __restrict__ dz_out,
                                                   float* __restrict__ part, unsigned long long* stamps, DcnArgs dc,
                                                   float* __restrict__ dxn_out) {
-    static_assert(!(G3 && LC), "the pipelined step is DeepFM's");
+    // G3 with LC > 0 (DCN): the cross network's share of dXn, sum_l coeff[r][l] Wc_l, enters the same GEMM as 16 more K steps
+    // (A = the coefficient tile crF, B = the layer vectors in LDS) — round 2 formed it on the VALU (12 K cycles) and sent it
+    // through HBM (dXc, 14.7 MB written and re-read)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
     constexpr int CP = 64 * NCH, XS = CP + kPad, HS = kH1 + kPad;
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         }
         lds_barrier();
         DT_STAMP(stamps, 11);
-        {   // dXn_cross: wave w owns rows 8 w .. 8 w + 7, lanes run along the columns (256-byte row segments to HBM)
+        if constexpr (!G3) {   // dXn_cross: wave w owns rows 8 w .. 8 w + 7, lanes run along the columns (256-byte row segments to HBM)
             float wc[LC + 1][NCH];
 #pragma unroll
             for (int l = 0; l <= LC; ++l) {
@@ -1164,11 +1166,19 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             for (int g = 0; g < 16; ++g) bW[0][g] = ld4(wrow + 8 * g);
         }
         lds_barrier();
+        if constexpr (LC == 0) {     // (DCN: the cross backward above has already put xhat there)
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
-            st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
-            st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
+            for (int j = 0; j < NCH; ++j) {
+                const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
+                st4(xs + srow * XS + 64 * j + qcol, (xv[j][0] - mu) * rs);
+                st4(xs + (srow + 16) * XS + 64 * j + qcol, (xv[j][1] - mu) * rs);
+            }
+        }
+        // DCN: A operand of the 16 extra K steps = row c of the coefficient tile crF [32][16] (k = 8 g + 4 s + j as above)
+        floatx4 aC[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (LC > 0) {
+            aC[0] = ld4(crF + c * 16 + 4 * s);
+            aC[1] = ld4(crF + c * 16 + 8 + 4 * s);
         }
         floatx4 aA[16];
 #pragma unroll
@@ -1210,6 +1220,26 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                 if (more) bW[buf ^ 1][g] = ld4(wnext + 8 * g);        // the next block's W1 operand, one load per 4 MFMAs
                 if (pblk >= 0) epi_q(pblk, prev[g], g, xh);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (LC > 0) {
+                // + sum_l coeff[r][l] Wc_l[col]: B = the layer vectors of this column from LDS (cwL: kernels | biases | w3c,
+                // zero beyond C), Wc_L = w3c, nothing beyond L (the coefficient columns there are zero as well)
+                const int L = dc.L, col = 32 * blk + c;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    float bw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int l = 8 * g2 + 4 * s + j;
+                        const float* src = l < L ? cwL + l * CP : cwL + 2 * L * CP;
+                        const float v = src[col];
+                        bw[j] = l <= L ? v : 0.f;
+                    }
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[g2].x, bw[0], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[g2].y, bw[1], a2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[g2].z, bw[2], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[g2].w, bw[3], a2, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[r] = a1[r] + a2[r];
@@ -1596,6 +1626,14 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
                 accum[al.dcb + (int64_t)j * dm.C + col] = suffix;
                 suffix += sc[16 + j] * cw[(int64_t)j * dm.C + col];
             }
+            if (da.p) {      // k_finish_step: this column's cross kernels / biases / w3c entry, once every read of them is done
+                for (int l = 0; l < Lc; ++l) {
+                    const int64_t iw = al.dcw + (int64_t)l * dm.C + col, ib = al.dcb + (int64_t)l * dm.C + col;
+                    adam_one(da.p, da.m, da.v, iw, accum[iw], da.lr_t, da.b1, da.b2, da.eps);
+                    adam_one(da.p, da.m, da.v, ib, accum[ib], da.lr_t, da.b1, da.b2, da.eps);
+                }
+                adam_one(da.p, da.m, da.v, al.dw3 + col, accum[al.dw3 + col], da.lr_t, da.b1, da.b2, da.eps);
+            }
         }
         if (!pipe) {         // the pipelined step's record reduction has written both already (sum_b dXn xhat, sum_b dXn)
             accum[al.dgamma + col] = dg + sumcx;
@@ -1630,7 +1668,9 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
                                                      const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                      DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
-                                                     int small_blocks, int seg_blocks, FinishSeg fs) {
+                                                     int small_blocks, int seg_blocks, FinishSeg fs, int Lc,
+                                                     const float* __restrict__ cw, const float* __restrict__ cb,
+                                                     const float* __restrict__ w3c) {
     __shared__ floatx2 sm[4][64];
     // every thread reads lr_t itself (a uniform scalar load, consumed at the end of its dependency chain) instead of one
     // thread + an LDS broadcast behind a barrier at the block's start — one dependent round trip less per block; the
@@ -1641,12 +1681,14 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
     if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, 0, nullptr, nullptr, nullptr, 1, sm, da);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, 1, sm, da);
     } else if (b < col_blocks + small_blocks) {
-        // db1 | db2 | dw3 | dwo | dbo | loss | dgamma | dbeta: final since the record reduction (the d w_lin entries that
-        // follow are block 0's); the `loss` words are pads of the parameter buffer, as in the flat optimizer launch
+        // db1 | db2 | [DCN: the cross part of dw3, finished per column by the blocks above] | dw3 | dwo | dbo | loss | dgamma
+        // | dbeta: final since the record reduction (the d w_lin entries — DCN: the cross kernels / biases — that follow
+        // belong to the blocks above); the `loss` words are pads of the parameter buffer, as in the flat optimizer launch
         const int64_t i = al.db1 + (int64_t)(b - col_blocks) * blockDim.x + threadIdx.x;
-        if (i < al.dwlin) adam_one(da.p, da.m, da.v, i, accum[i], da.lr_t, da.b1, da.b2, da.eps);
+        if (i < al.dwlin && (i < al.dw3 || i >= al.dw3d))
+            adam_one(da.p, da.m, da.v, i, accum[i], da.lr_t, da.b1, da.b2, da.eps);
     } else if (fs.seg.nseg) {
         adam_segments(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
                       fs.sstride, sb);
@@ -2071,10 +2113,10 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.wpart = take((int64_t)256 * 8192);            // k_wgrad4's per-slice partial macro tiles (<= 256 heavy blocks)
     w.bnp = take((int64_t)blocksA * 3 * dm.C);
     w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
-    w.part = take((int64_t)tiles * part3_layout(dm.CP, L, L > 0 ? 0 : 1).stride);
+    w.part = take((int64_t)tiles * part3_layout(dm.CP, L, 1).stride);
     w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
-    w.dXn = take(L > 0 ? 0 : rows * dm.CP);         // pipelined step: dXn = dH1 . W1^T (kernel C -> the row-gradient epilogue)
+    w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
     w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
     w.gammap = take(dm.CP);
     w.total = o;
@@ -2223,7 +2265,7 @@ static int tower_train_step(
     unsigned long long* stamps = stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
     // the pipelined launch sequence (DeepFM backward steps; DT_STEP_PIPE=0 keeps round 2's A B C E E' D): A B C+dXn R [E|D+Adam] E'
     static const bool pipe_env = !(getenv("DT_STEP_PIPE") && atoi(getenv("DT_STEP_PIPE")) == 0);
-    const bool pipe = !dcn && phases >= 2 && (pipe_env || adam);
+    const bool pipe = phases >= 2 && (pipe_env || adam);
     DT_REQUIRE(!adam || (pipe && dd.rows_fm && !grad_rows_field_major),
                "dt_deepfm_train_step_adam: the in-step row update needs a backward step with the in-step dedupe (dedupe_ws) "
                "and row-major row gradients");
@@ -2261,7 +2303,12 @@ static int tower_train_step(
         DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
 #define DT_C(N)                                                                                                     \
     case N:                                                                                                         \
-        if (dcn) {                                                                                                  \
+        if (dcn && pipe) {                                                                                          \
+            hipFuncSetAttribute((const void*)k_mlp_fwd3<N, kCrossMax, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
+            hipLaunchKernelGGL((k_mlp_fwd3<N, kCrossMax, true>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, \
+                               ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
+                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);      \
+        } else if (dcn) {                                                                                           \
             hipFuncSetAttribute((const void*)k_mlp_fwd3<N, kCrossMax>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
             hipLaunchKernelGGL((k_mlp_fwd3<N, kCrossMax>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm,     \
                                ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
@@ -2301,16 +2348,25 @@ static int tower_train_step(
                          ws + wl.cm2, rows_out, grad_rows, grad_rows_scale, grad_rows_field_major};
         const RowsAdam ad = adam ? *adam : RowsAdam{nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f, 0.f};
         static const int join_env = !(getenv("DT_ROWS_JOIN") && atoi(getenv("DT_ROWS_JOIN")) == 0);    // experiment knob
-        hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
-        hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
-                           ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
-                           stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                           stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
+        if (dcn) {
+            hipFuncSetAttribute((const void*)k_wgrad_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
+            hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
+                               ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
+                               stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
+        } else {
+            hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
+            hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
+                               ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
+                               stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
+        }
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
-            DT_REQUIRE(sdense->n_flat == al.dwlin + F + Nd, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
-                       "%lld floats (the accumulator layout up to d w_lin)", (long long)sdense->n_flat,
-                       (long long)(al.dwlin + F + Nd));
+            const int64_t want_flat = dcn ? al.dcb + (int64_t)Lc * dm.C : al.dwlin + F + Nd;
+            DT_REQUIRE(sdense->n_flat == want_flat, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
+                       "%lld floats (the accumulator layout up to its last gradient)", (long long)sdense->n_flat,
+                       (long long)want_flat);
             static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
             // 512 blocks: 1.5 us faster with uniform ids (878 segments), 1024: 4.6 us faster with Zipf ids (15 K segments)
             const int seg_blocks = seg_env > 0 ? seg_env : 1024;
@@ -2322,7 +2378,7 @@ static int tower_train_step(
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
-                               dm.C + kH2, small_blocks, seg_blocks, fs);
+                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3);
         } else {
             // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
@@ -2461,6 +2517,35 @@ extern "C" int dt_dcn_accum_offsets(int F, int D, int Nd, int L, int64_t* out12)
     const int64_t v[12] = {a.dW1, a.dW2, a.db1, a.db2, a.dw3, a.dwo, a.dbo, a.loss, a.dgamma, a.dbeta, a.dcw, a.dcb};
     for (int i = 0; i < 12; ++i) out12[i] = v[i];
     return DT_OK;
+}
+
+// dt_dcn_train_step with the optimizer step inside (see dt_deepfm_train_step_adam): dense_n = dt_dcn_accum_offsets' d cross_b
+// offset + L * C floats
+extern "C" int dt_dcn_train_step_adam(
+    const void* idx, int idx_kind, float* table, const int64_t* row_offset, const int32_t* vocab,
+    const float* dense, const float* y, int B, int F, int D, int Nd,
+    const float* cross_w, const float* cross_b, int L, const float* bn_gamma, const float* bn_beta,
+    float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1,
+    const float* W2, const float* b2, const float* w3, const float* w_out, const float* b_out,
+    float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
+    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed,
+    float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
+    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
+    DT_REQUIRE(cross_w && cross_b && table && adam_m && adam_v, "dt_dcn_train_step_adam: null pointer");
+    DT_UNSUPPORTED(L < 1 || L > kCrossMax, "dt_dcn_train_step_adam: %d cross layers (1..%d)", L, kCrossMax);
+    DT_REQUIRE((phases & 0xf) == 2 && dedupe_ws, "dt_dcn_train_step_adam: a backward step (phases 2) with dedupe_ws");
+    DT_REQUIRE(slot_stride == D || slot_stride == 2 * D, "dt_dcn_train_step_adam: slot_stride %d (D or 2 D)", slot_stride);
+    DT_REQUIRE(((uintptr_t)table | (uintptr_t)adam_m | (uintptr_t)adam_v) % 16 == 0,
+               "dt_dcn_train_step_adam: table / slots must be 16-byte aligned");
+    DT_REQUIRE(dense_n == 0 || (dense_p && dense_m && dense_v && adam_state),
+               "dt_dcn_train_step_adam: the dense half needs the flat buffers and the device step state");
+    const RowsAdam ad{table, adam_m, adam_v, slot_stride, adam_state ? adam_state_lr_t(adam_state) : nullptr, lr_t, beta1,
+                      beta2, eps};
+    const StepDense sd{dense_p, dense_m, dense_v, dense_n, adam_state, lr};
+    return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, nullptr, bn_gamma, bn_beta,
+                            bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
+                            rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
+                            embedding_dropout, dropout_seed, stream, cross_w, cross_b, L, &ad, dense_n > 0 ? &sd : nullptr);
 }
 
 extern "C" int dt_dcn_train_step(

@@ -484,23 +484,38 @@ class FusedDCN(FusedDeepFM):
         table = self.emb.tables[self.key]
         training = self.dm.model.training
         dedupe = _dedupe_in_step(self, B, backward)
-        check(lib().dt_dcn_train_step(
-            ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
-            ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
-            ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),
-            ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
-            float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
-            ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.out.kernel), ptr(self.one), ptr(self.out.bias),
-            ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            ptr(self.emb.oob_count) if self.emb.check_oob else None,
-            ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'],
-            (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed), stream_ptr()),
-            'dt_dcn_train_step')
+        opt = _rows_in_step(self, B, backward, apply_rows)
+        head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
+                ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
+                ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),
+                ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
+                float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
+                ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.out.kernel), ptr(self.one), ptr(self.out.bias),
+                ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(self.emb.oob_count) if self.emb.check_oob else None,
+                ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
+        if opt is not None:      # the whole optimizer step inside the train step (see FusedDeepFM.run)
+            slots = opt._st(table, rows=True)
+            flat = getattr(opt, '_flat', None)
+            whole = (flat is not None and flat[0] is self.flat_params and flat[1] is self.accum and
+                     os.environ.get('DT_AMD_STEP_IN_STEP', '1') != '0' and
+                     all(id(p) in flat[5] for p in opt.params if p is not table))
+            dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
+            check(lib().dt_dcn_train_step_adam(
+                *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
+                opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
+            if whole:
+                opt.applied_in_step()
+        else:
+            check(lib().dt_dcn_train_step(
+                *head, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
+                ptr(self.drop_seed), stream_ptr()), 'dt_dcn_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
             self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
-                                                             fields=-1 if dedupe else None,
+                                                             fields=(-2 if opt is not None else -1) if dedupe else None,
                                                              segments=_segments(buf, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients

@@ -410,6 +410,18 @@ int dt_dcn_train_step(const void* idx, int idx_kind, const float* table, const i
                       const float* b_out, float* logit_out, int64_t* rows_out, float* grad_rows, float* accum,
                       void* workspace, int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
                       float embedding_dropout, unsigned* dropout_seed, void* stream);
+/* dt_dcn_train_step with the optimizer step inside — arguments and semantics as dt_deepfm_train_step_adam (dense_n = the
+ * offset of d cross_b + L * C floats of the dt_dcn_accum_offsets layout). */
+int dt_dcn_train_step_adam(const void* idx, int idx_kind, float* table, const int64_t* row_offset,
+                           const int32_t* vocab, const float* dense, const float* y, int B, int F, int D, int Nd,
+                           const float* cross_w, const float* cross_b, int L, const float* bn_gamma, const float* bn_beta,
+                           float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1,
+                           const float* b1, const float* W2, const float* b2, const float* w3, const float* w_out,
+                           const float* b_out, float* logit_out, int64_t* rows_out, float* grad_rows, float* accum,
+                           void* workspace, int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
+                           float embedding_dropout, unsigned* dropout_seed, float* adam_m, float* adam_v, int slot_stride,
+                           void* adam_state, float lr_t, float beta1, float beta2, float eps, float* dense_p,
+                           float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
 int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
 /* debugging aid: offset (floats) of the per-block phase timestamps written when DT_DEEPFM_STAMPS is set */

@@ -524,9 +524,10 @@ def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2):
         assert flat[o['db2'] + H2:o['db2'] + 64].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
 @pytest.mark.parametrize('vocab,B,F,D,drop', [(30, 256, 26, 16, 0.0), (5000, 1000, 26, 16, 0.0), (5000, 513, 26, 16, 0.3),
                                               (200000, 4096, 26, 16, 0.0), (3000, 300, 7, 32, 0.0), (900, 77, 5, 8, 0.0)])
-def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab, B, F, D, drop):
+def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab, B, F, D, drop, net):
     """DeepModel.train_step on the pipelined DeepFM step applies Keras Adam to the table rows looked up once inside the
     step (dt_deepfm_train_step_adam, k_wgrad_rows) and leaves only the segments to the optimizer launch: same tables,
     slots, dense parameters and step count as forward_backward + optimizer.step over every lookup's gradient row — from
@@ -534,8 +535,10 @@ def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab
     from deeptables_amd.models import layers as L
     from oracle import headline
     monkeypatch.setattr(L, 'DENSE_GRAD_MAX_ELEMS', 0)          # row-sparse ("lazy") update also on these small tables
-    dm, cats = build(F, 13, D, vocab=vocab, embedding_dropout=drop)
-    assert type(dm.fused_plan()).__name__ == 'FusedDeepFM'
+    from deeptables_amd.models import deepnets
+    extra = dict(nets=deepnets.DCN, cross_params={'num_cross_layer': 3 if D == 8 else 6}) if net == 'DCN' else {}
+    dm, cats = build(F, 13, D, vocab=vocab, embedding_dropout=drop, **extra)
+    assert type(dm.fused_plan()).__name__ == 'Fused' + net
     for seed in (5, 6):                                        # two batches: the second one starts from non-zero slots
         idx, dense, y = batch(cats, 13, B, seed=seed)
         # repeated: the first version of the finishing launch read gamma / beta while other blocks of the SAME launch updated

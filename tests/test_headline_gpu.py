@@ -129,7 +129,7 @@ def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist):
     import bench
     from oracle import headline
     from deeptables_amd.models import deepnets
-    dm = bench.build_model(deepnets.DeepFM, dev)
+    dm = bench.build_model(getattr(deepnets, net), dev, None, bench.D, bench.MODEL_PARAMS.get(net))
     bench.N_BATCHES, keep = 2, bench.N_BATCHES
     try:
         batches = bench.make_batches(8192, dev, seed=1234, dist_kind=dist)
