@@ -122,8 +122,9 @@ def test_headline_config_float32_ids_second_step(dev):
     assert res2['untouched_rows_unchanged'], res2
 
 
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
 @pytest.mark.parametrize('dist', ['uniform', 'zipf'])
-def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist):
+def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist, net):
     """what bench.py times since round 3: the step with the rows looked up once updated inside it
     (dt_deepfm_train_step_adam) — same table rows, slots and dense parameters as the oracle-checked separate path"""
     import bench
