@@ -1597,12 +1597,38 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     }
     const float dg = wave_sum(w.x * m.x + w.y * m.y);
     const float db = wave_sum(w.x * d.x + w.y * d.y);
+    const float ga_b = ga, be_b = be;
     {
         const floatx2 g = floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
         *reinterpret_cast<floatx2*>(accum + e0) = g;
         if (da.p) adam2(g.x, g.y);
     }
-    if (lane == 0) {
+    if (Lc && pipe) {
+        // pipelined DCN step: lane l <= Lc finishes layer l of this column (lane Lc: the w3c entry) — the gradients, and in
+        // k_finish_step their Adam update, of the 2 Lc + 1 elements run side by side (one lane walking them took 13
+        // dependent round trips: 19 us for the launch).  The BN-backward sums are the record reduction's (sdx / sdxx).
+        const float* sc = accum + al.sumc;
+        if (lane <= Lc) {
+            const int l = lane;
+            const float sdz = sc[31];
+            float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
+            for (int j = 0; j < Lc; ++j) {
+                const float bj = cb[(int64_t)j * dm.C + col], wj = cw[(int64_t)j * dm.C + col];
+                if (j < l) cl += bj;
+                if (j > l) suf += sc[16 + j] * wj;
+            }
+            const int64_t ig = l < Lc ? al.dcw + (int64_t)l * dm.C + col : al.dw3 + col;
+            const float G = accum[ig];
+            const float gw = ga_b * G + be_b * sc[l] + (l < Lc ? sc[16 + l] : sdz) * cl;
+            const float gb = sdz * w3c[col] + suf;                // d b_l (l < Lc)
+            accum[ig] = gw;
+            if (l < Lc) accum[al.dcb + (int64_t)l * dm.C + col] = gb;
+            if (da.p) {
+                adam_one(da.p, da.m, da.v, ig, gw, da.lr_t, da.b1, da.b2, da.eps);
+                if (l < Lc) adam_one(da.p, da.m, da.v, al.dcb + (int64_t)l * dm.C + col, gb, da.lr_t, da.b1, da.b2, da.eps);
+            }
+        }
+    } else if (lane == 0) {
         float sumc = 0.f, sumcx = 0.f;
         if (Lc) {
             // DCN: the cross gradients of this column from the reduced tile records (see the cross backward of kernel C):
