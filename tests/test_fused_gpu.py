@@ -545,5 +545,5 @@ def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab
         # them — a race that showed up in one run out of a few (tools/r3/dbg_ab2.py tells which tensors moved)
         for rep in range(4):
             res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2 + rep % 2)
-            assert headline.rows_in_step_ok(res), (rep, res)
+            assert headline.rows_in_step_ok(res), str((rep, sorted(res.items())))
         dm.train_step([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))   # move on (in-step path)

@@ -138,5 +138,5 @@ def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist, net):
         bench.N_BATCHES = keep
     for b in batches:
         res = headline.check_rows_in_step(dm, b)
-        assert headline.rows_in_step_ok(res), res
+        assert headline.rows_in_step_ok(res), str(sorted(res.items()))
         dm.train_step([b[0], b[1]], b[2])
