@@ -10,7 +10,8 @@ import json
 import os
 import sys
 
-WIDE = {'k_mlp_fwd3': 'X tile streamed as float4', 'k_dx_sparse_bwd': 'X and dH1 tiles streamed as float4'}
+WIDE = {'k_mlp_fwd3': 'X tile streamed as float4', 'k_dx_sparse_bwd': 'X and dH1 tiles streamed as float4',
+        'k_wgrad_rows': 'X / dH1 / H1 / dXn streamed as 8- and 16-byte lanes (its random [m|v] rows are a quarter of its reads)'}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,17 +59,26 @@ def main():
         'algorithmic_fwd_bwd': int(fwd_bwd), 'algorithmic_adam': int(opt),
     }
     out['traffic_over_algorithmic'] = round(out['bytes_per_step_corrected'] / out['algorithmic_bytes_per_step'], 2)
+    # counter calibration on known-bytes kernels (tools/make_calibration.py), when given: recorded next to the figures it
+    # qualifies — random 64-byte row reads / read-modify-writes and 16-byte-lane streams each have their own factor
+    cal = next((a for a in sys.argv[3:] if a.endswith('.json')), None)
+    if cal and os.path.exists(cal):
+        try:
+            out['calibration'] = json.load(open(cal))
+        except Exception as e:
+            out['calibration'] = {'error': repr(e)}
     # the hash of the kernel sources the passes ran on: taken from the run's own record when given (argv[3] = the
     # bench log holding the "[build] ok ... source hash X" line), else from the tree — bench.py only reports
     # roofline.traffic while this matches the sources it is running
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     out['source_hash'] = ge.source_hash()
-    if len(sys.argv) > 3:
-        import re
-        m = re.search(r'source hash ([0-9a-f]{16})', open(sys.argv[3]).read())
-        if m:
-            out['source_hash'] = m.group(1)
+    for a in sys.argv[3:]:
+        if a.endswith('.log') and os.path.exists(a):
+            import re
+            m = re.search(r'source hash ([0-9a-f]{16})', open(a).read())
+            if m:
+                out['source_hash'] = m.group(1)
     path = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
     json.dump(out, open(path, 'w'), indent=2)
     print(json.dumps(out, indent=2))
