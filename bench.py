@@ -328,6 +328,15 @@ def parity_leg(args, device):
             ok = ok and good
             rules.add(rule)
             out[kind] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in r.items()}
+            if dm.fused_plan() is not None:
+                # what the timed region runs: the optimizer step INSIDE the fused step (rows looked up once updated where
+                # their gradient is formed, dense elements / segments / state in the last launch) against the separate
+                # path checked just above — same table rows, slots, dense parameters, step count (oracle/headline.py)
+                b2 = make_batches(args.batch, device, seed=4321, dist_kind=kind)[0]
+                ri = headline.check_rows_in_step(dm, b2)
+                ri['ok'] = headline.rows_in_step_ok(ri)
+                ok = ok and ri['ok']
+                out[kind]['in_step_optimizer'] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in ri.items()}
     finally:
         N_BATCHES = keep
     out['tolerance'] = ('gather bit-exact; logits 1e-4 (north_star) of max(1, max |logit|): a 6-layer Cross network puts '

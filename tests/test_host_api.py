@@ -283,3 +283,35 @@ def test_committed_traffic_json_names_the_sources_it_was_measured_on():
     if j['source_hash'] != ge.source_hash():
         warnings.warn(f"profiles/deepfm_traffic.json was measured on sources {j['source_hash']}, the tree is at "
                       f"{ge.source_hash()}: bench.py will print roofline.traffic = null until tools_pmc.sh is re-run")
+
+
+def test_roofline_fraction_follows_from_the_committed_evidence():
+    """every roofline number reproducible — the committed bench line's `roofline.frac` is recomputed from its
+    own fields and the formula of SURVEY §8(d), its per-step time is consistent with the committed rocprofv3 kernel stats,
+    and `roofline.traffic` is the committed traffic json's figure."""
+    import csv
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, 'profiles', 'r03_bench_line.json')).read())
+    rf = line['roofline']
+    F, ND, D, B = 26, 13, 16, 8192
+    n_dense = (F * D + ND) * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1 + 2 * (F * D + ND) + (F + ND)
+    bpr = 4 * F + 4 * ND + 8 + 12 * F * D + 12.0 * n_dense / B + 6 * 4 * F * D       # fwd+bwd 5,250 + row Adam 9,984
+    assert abs(bpr - rf['algorithmic_bytes_per_row']) < 1.0
+    achieved = B * bpr / (rf['launch_us'] * 1e-6) / 1e9
+    assert abs(achieved - rf['achieved']) / rf['achieved'] < 1e-6
+    assert abs(rf['frac'] - achieved / 8000.0) < 1e-9 and rf['peak'] == 8000.0 and rf['bound'] == 'hbm'
+    # the step time against the kernel-trace summary of the same command: the kernels of one step sum to no more than the
+    # step, and to no less than 85 % of it (the rest: kernel boundaries + the replay's fixed cost)
+    stats = {r['Name'].split('(')[0].replace('void ', ''): float(r['AverageNs']) / 1e3
+             for r in csv.DictReader(open(os.path.join(root, 'profiles', 'r03_deepfm_kernel_stats.csv')))}
+    step_kernels = [v for k, v in stats.items() if k.startswith('dt::k_') and 'state_init' not in k]
+    assert len(step_kernels) == 6, sorted(stats)
+    assert 0.85 * rf['launch_us'] <= sum(step_kernels) <= 1.02 * rf['launch_us'], (sum(step_kernels), rf['launch_us'])
+    tj = json.load(open(os.path.join(root, 'profiles', 'deepfm_traffic.json')))
+    if rf['traffic'] is not None:
+        assert rf['traffic'] == tj['bytes_per_step_corrected']
+    assert tj['algorithmic_bytes_per_step'] == int(B * (4 * F + 4 * ND + 8 + 12 * F * D) + 12 * n_dense) + B * 6 * 4 * F * D
+    cal = tj['calibration']['kernels']
+    assert 0.9 < cal['k_gather<2>']['fetch_factor'] < 1.1 and 0.45 < cal['k_copy 28 MB (16 B/lane stream)']['fetch_factor'] < 0.55
