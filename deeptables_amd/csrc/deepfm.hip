@@ -305,13 +305,17 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
                                                float* __restrict__ moving_var, const float* __restrict__ W1,
                                                PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
                                                int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
-    if ((int)blockIdx.x >= bn_blocks + layout_blocks) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
+    // block order: election | BN level 1 | weight layouts — the election (loads, LDS hash, scan, three barriers) is the longest
+    // chain of the launch and starts first; its block ids keep id % 8 = the XCD (elect_blocks is a multiple of 8)
+    const int elect_blocks = (int)gridDim.x - bn_blocks - layout_blocks;
+    const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
+    if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots[];    // [kElectSlots] + bitmap of the slots with >= 2 lookups + scan scratch
         unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
         int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]
         // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
         // so the field's row list is fetched into ONE L2 instead of eight
-        const int e = (int)blockIdx.x - bn_blocks - layout_blocks;
+        const int e = (int)blockIdx.x;
         const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
         const int f = 8 * (j >> dd.parts_log2) + ((int)blockIdx.x & 7);
         if (f >= dm.F) {
@@ -407,8 +411,8 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
         }
         return;
     }
-    if ((int)blockIdx.x >= bn_blocks) {  // weight layouts
-        const int wb = (int)blockIdx.x - bn_blocks, nwb = layout_blocks;
+    if (bid >= bn_blocks) {  // weight layouts
+        const int wb = bid - bn_blocks, nwb = layout_blocks;
         // W1L: float4 j of lane (c = l%32, s = l/32) of wave w in k-group g = W1[8g + 4s + j][32w + c]  (k_mlp_fwd3 GEMM1)
         floatx4_t* w1l = reinterpret_cast<floatx4_t*>(o.W1L);
         const int n4 = dm.CP * kH1 / 4;
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
     __shared__ float wtri[16][3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cgroups = (dm.C + 63) >> 6;
-    const int cg = blockIdx.x % cgroups, slice = blockIdx.x / cgroups;
+    const int cg = bid % cgroups, slice = bid / cgroups;
     const int col = cg * 64 + lane;
     const bool cok = col < dm.C;
     const int per = (chunks + kBnSlices - 1) / kBnSlices;
@@ -1541,9 +1545,9 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
                                                const DeepFmAccum& al, const float* __restrict__ wpart, int row_blocks,
                                                int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
                                                const float* __restrict__ w3c, int pipe, floatx2 (*sm)[64],
-                                               const DenseAdam& da) {
+                                               const DenseAdam& da, int blk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && Lc == 0) {
+    if (blk == 0 && Lc == 0) {
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
             float v = 0.f;
             if (q < dm.F) {
@@ -1556,7 +1560,7 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         }
     }
     // one block per column (of X, then of dH2); its 4 waves add up every 4th batch slice with all loads in flight
-    const int col = blockIdx.x;
+    const int col = blk;
     const bool w2 = col >= dm.C;
     const int mac = w2 ? (dm.CP >> 6) : (col >> 6), row = w2 ? col - dm.C : (col & 63);
     const float* src = wpart + (int64_t)mac * row_blocks * 8192 + row * 128 + 2 * lane;
@@ -1686,7 +1690,7 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
                                                    const float* __restrict__ w3c, int pipe) {
     __shared__ floatx2 sm[4][64];
     const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
-    bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, pipe, sm, none);
+    bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, pipe, sm, none, (int)blockIdx.x);
 }
 
 // F: the LAST launch of the pipelined step when the optimizer is handed in (dt_deepfm_train_step_adam with the dense
@@ -1712,13 +1716,16 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
     // every thread reads lr_t itself (a uniform scalar load, consumed at the end of its dependency chain) instead of one
     // thread + an LDS broadcast behind a barrier at the block's start — one dependent round trip less per block; the
     // barrier before the arrival ticket guarantees every wave of the block HAS read it when the state may advance
-    const int b = (int)blockIdx.x;
-    const int sb = b - col_blocks - small_blocks;
+    // block order: segments | small vectors | columns — the segment walk is the launch's longest dependent chain (record ->
+    // list + p, m, v -> members' rows -> stores) and starts first
+    const int sb = (int)blockIdx.x < seg_blocks ? (int)blockIdx.x : -1;
+    const int b = sb >= 0 ? col_blocks + small_blocks : (int)blockIdx.x - seg_blocks < small_blocks
+                      ? col_blocks + ((int)blockIdx.x - seg_blocks) : (int)blockIdx.x - seg_blocks - small_blocks;
     int nseg0 = 0;
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
     if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, 1, sm, da);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, 1, sm, da, b);
     } else if (b < col_blocks + small_blocks) {
         // db1 | db2 | [DCN: the cross part of dw3, finished per column by the blocks above] | dw3 | dwo | dbo | loss | dgamma
         // | dbeta: final since the record reduction (the d w_lin entries — DCN: the cross kernels / biases — that follow

@@ -352,9 +352,11 @@ def check_rows_in_step(dm, batch, steps=1):
 
 def rows_in_step_ok(res):
     """both paths form the same gradient with the same kernels; the update rule runs in two different kernels (fused
-    multiply-add contraction may differ by an ulp or two): table rows within 1e-7 absolute (values ~5e-2, steps ~1e-3),
-    dense parameters (values up to ~1 in the tests) within 1e-6, slots within 1e-5 of their largest entry"""
-    return bool(res['rows_in_step_taken'] and res['rows_moved'] > 0 and res['table_abs_err'] <= 1e-7 and
+    multiply-add contraction may differ by an ulp or two, and the members of a segment are summed in the order the
+    election's cursor handed out — not the same from run to run): table rows within 5e-7 absolute (values ~5e-2, steps
+    ~1e-3: 0.05 % of a step; seen: 1.2e-7 after three steps with dropout), dense parameters (values up to ~1 in the
+    tests) within 1e-6, slots within 1e-5 of their largest entry"""
+    return bool(res['rows_in_step_taken'] and res['rows_moved'] > 0 and res['table_abs_err'] <= 5e-7 and
                 res['m_rel_err'] <= 1e-5 and res['v_rel_err'] <= 1e-5 and res['dense_abs_err'] <= 1e-6 and
                 res['steps_counted'][0] == res['steps_counted'][1])
 
