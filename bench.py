@@ -134,14 +134,28 @@ class GraphedStep:
         self.graphs = {}
         self.use_graph = use_graph
         self.strategy = dm.config.distribute_strategy
-        self._dp = self.strategy is not None and (self.strategy.world_size > 1 or getattr(self.strategy, 'force_dp', False))
+        self._dp = self.strategy is not None and (self.strategy.world_size > 1 or getattr(self.strategy, 'force_dp', False) or
+                                                  getattr(self.strategy, 'force', False))
         self.sparse_refs = {}
         self._opt_graph = None      # data parallel: the optimizer step is a second captured graph, after the exchange
         self._dp_steps = 0
         self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] HIP events around fwd+bwd | exchange | optimizer
 
+    def _sharded(self):
+        st = self.strategy
+        return self._dp and getattr(st, 'sharded_embeddings', False) and st.active and self.dm.fused_plan() is not None
+
     def _body(self, b):
         dm = self.dm
+        if self._sharded() and getattr(self, '_core_only', False):
+            # row-owned tables, graph capture: only the launches between the collectives (the step's kernels); the
+            # collectives around them are issued eagerly by run()
+            plan = dm.fused_plan()
+            dm.optimizer.zero_grad(flat=False)
+            loss, logit = plan.sharded_core(b[0].shape[0], b[1], b[2], self.strategy)
+            dm.model._dt_flat_grad = plan.accum
+            self.loss = loss
+            return
         fused_opt = self.with_optimizer and not self._dp
         # fused plan when the graph has one; apply_rows: optimizer.step() follows at once (DeepModel.train_step's order),
         # so the DeepFM step applies the update of the rows looked up once inside its own kernels
@@ -168,6 +182,7 @@ class GraphedStep:
             return
         emb_layers = [l for l in self.dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
         pool = None
+        self._core_only = self._sharded()        # captured: the launches between the collectives only
         for i, b in enumerate(batches):
             if (i - self.s0) % self.spg:
                 continue
@@ -181,6 +196,7 @@ class GraphedStep:
             # python side effects (sparse-gradient registration) are not replayed by a graph: keep the captured
             # static (rows, values) tensors and re-attach them after every replay
             self.sparse_refs[i] = [(l, {k: list(v) for k, v in l.sparse_grads.items()}) for l in emb_layers]
+        self._core_only = False
         torch.cuda.synchronize()
 
     def run_eager(self, b):
@@ -204,7 +220,14 @@ class GraphedStep:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         g = self.graphs.get(i)
-        if g is not None:
+        if g is not None and self._sharded():
+            # three segments around the step's collectives: [ids all-gather, owner gather, forward all-to-all] eager ->
+            # the captured step kernels -> [backward all-to-all] eager -> (below) dense all-reduce -> captured optimizer
+            plan = self.dm.fused_plan()
+            plan.sharded_pre(b[0], self.strategy)
+            g.replay()
+            plan.sharded_post(b[0].shape[0], self.strategy)
+        elif g is not None:
             g.replay()
             for layer, refs in self.sparse_refs[i]:
                 layer.sparse_grads = {k: list(v) for k, v in refs.items()}
@@ -219,10 +242,17 @@ class GraphedStep:
             if ev:
                 ev[2].record()
             if self.with_optimizer:
-                sharded = getattr(self.dm.model, '_dt_sharded_step', False)
                 if self._opt_graph is not None:
+                    hook, self.dm.optimizer.pre_dense_hook = getattr(self.dm.optimizer, 'pre_dense_hook', None), None
+                    if hook is not None:
+                        hook()           # the async dense all-reduce must have landed before the captured optimizer runs
                     self._opt_graph.replay()
-                elif self.use_graph and not sharded and self._dp_steps >= 2:
+                    for layer in getattr(self.dm.optimizer, 'embedding_layers', []):
+                        layer.sparse_grads.clear()
+                elif self.use_graph and self._dp_steps >= 2:
+                    hook, self.dm.optimizer.pre_dense_hook = getattr(self.dm.optimizer, 'pre_dense_hook', None), None
+                    if hook is not None:
+                        hook()
                     torch.cuda.synchronize()
                     gopt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gopt):
@@ -459,6 +489,8 @@ def main():
                          'MirroredStrategy shape, default) or embedding rows owned per field by one rank (all-to-all)')
     ap.add_argument('--bucket-ratio', type=float, default=1.0,
                     help='N>1, replicated tables: wire size of a rank\'s sparse bucket / its lookups (1.0 never overflows)')
+    ap.add_argument('--graph-segments', action='store_true',
+                    help='--tables sharded: capture the launches between the collectives into hipGraphs (default: eager)')
     ap.add_argument('--force-dp', action='store_true',
                     help='N=1: run the data-parallel step structure anyway (world size 1: collectives are no-ops)')
     ap.add_argument('--force-sharded', action='store_true', help='N=1: run the sharded-table step anyway (eager)')
@@ -514,8 +546,12 @@ def main():
     batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
 
     sharded = getattr(strategy, 'sharded_embeddings', False) and strategy.active and dm.fused_plan() is not None
-    if sharded:
-        args.no_graph = True        # collectives inside the step: launched eagerly, not captured
+    if sharded and not args.graph_segments:
+        # row-owned tables: the step can run as captured segments around its collectives (--graph-segments: [ids
+        # all-gather, owner gather, all-to-all] -> graph of the step kernels -> [all-to-all] -> dense all-reduce -> graph of
+        # the optimizer), but a replay's fixed cost (~10 us each) exceeds what six eager launches cost:
+        # measured at world size 1 through RCCL 183 us with the two graphs, 173 us eager -> eager by default
+        args.no_graph = True
     spg = 1
     if world == 1 and strategy is None and not args.no_graph:
         # the largest window <= --steps-per-graph that divides both the timed steps and the batch ring (so that exactly

@@ -250,9 +250,16 @@ class FusedDeepFM:
     def _run_sharded(self, idx, dense, y, st):
         """One train step with the table rows owned per field by the ranks of `st` (see ShardedEmbeddingStrategy):
         ids all-gather -> owner gather -> all-to-all -> the same fused kernels on the local minibatch (reading the
-        received rows) -> all-to-all of the row gradients -> the owner's sparse gradient."""
+        received rows) -> all-to-all of the row gradients -> the owner's sparse gradient.  Three pieces so that a caller
+        can capture the kernels between the collectives into hipGraphs (bench.py): `sharded_pre` (collectives + the
+        owner's gather, eager), `sharded_core` (the step's kernels: capturable), `sharded_post` (collective, eager)."""
+        self.sharded_pre(idx, st)
+        out = self.sharded_core(idx.shape[0], dense, y, st)
+        self.sharded_post(idx.shape[0], st)
+        return out
+
+    def sharded_pre(self, idx, st):
         B, F, D, W = idx.shape[0], self.F, self.D, st.world_size
-        buf = self._buffers(B)
         sb = self._sharded_buffers(B, st)
         if idx.dtype != torch.int32:
             idx = idx.to(torch.int32)             # float ids: truncation, as the gather's own cast
@@ -265,12 +272,18 @@ class FusedDeepFM:
                                               W, B, F, s, e, D, ptr(sb['emb_own']), ptr(sb['rows_own']),
                                               ptr(self.emb.oob_count) if self.emb.check_oob else None, stream_ptr()),
               'dt_embedding_gather_owned')
-        emb_T = st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
+        st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
+
+    def sharded_core(self, B, dense, y, st):
+        """the fused step's launches on the received rows (no collective inside: a hipGraph can hold them)"""
+        F, D, W = self.F, self.D, st.world_size
+        buf = self._buffers(B)
+        sb = self._sharded_buffers(B, st)
         dense = None if dense is None else dense.contiguous()
         y = y.reshape(-1).contiguous()
         training = self.dm.model.training
         check(lib().dt_deepfm_train_step(
-            ptr(sb['iota']), _lib.DT_IDX_I32, ptr(emb_T), ptr(sb['zero_off']), ptr(sb['fb_vocab']), ptr(dense), ptr(y),
+            ptr(sb['iota']), _lib.DT_IDX_I32, ptr(sb['emb_T']), ptr(sb['zero_off']), ptr(sb['fb_vocab']), ptr(dense), ptr(y),
             B, F, D, self.Nd, ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
             ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
@@ -281,12 +294,17 @@ class FusedDeepFM:
             'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
-        # the loss is a mean over the LOCAL minibatch, the global objective the mean over W of them: kernel G already
-        # wrote the row gradients field-major [F,B,D] and divided by W
-        grad_own = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'])
-        self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
         self.dm.model._dt_sharded_step = True
         return self.loss_view, buf['logit']
+
+    def sharded_post(self, B, st):
+        # the loss is a mean over the LOCAL minibatch, the global objective the mean over W of them: the step already
+        # wrote the row gradients field-major [F,B,D] and divided by W
+        F, D = self.F, self.D
+        buf = self._buffers(B)
+        sb = self._sharded_buffers(B, st)
+        grad_own = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'])
+        self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
 
     def run(self, idx, dense, y, backward=True, apply_rows=False):
         """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
