@@ -59,35 +59,56 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// Round 3: every MFMA operand is a 16-byte LDS read.  An MFMA contraction index may be permuted freely as long as A and
+// B agree, so lane (c, s) takes FOUR consecutive k (one float4) and spends them on four consecutive 32x32x2 steps:
+// step 4g + jj <-> k' = 8g + 4s + jj.  For the A operand Z[m][(i,j)] = x0[m][i] xk[m][j] that means four consecutive j of
+// ONE i: the contraction runs over k' = i HkP + j with HkP = Hk rounded up to 4 (x_k padded with zeros, W rows of a padded j
+// read as zero: +7.7 % steps at Hk = 26, none at 64), the x_k tile sits in LDS as [m][j] (j contiguous) and the W chunk
+// TRANSPOSED as [n][k'] (k' contiguous).  Round 2's loop read one float per operand and MFMA step (24 ds_read_b32 + the
+// (i, j) walk per 16 MFMAs: 42 % of the fp32-MFMA rate); this one 5 ds_read_b128.
 // kAnyAct = false: only linear / relu reach the epilogue (no libm code next to the 64 accumulators; with the full
 // activation switch inlined there the kernel spills the accumulators and runs 7x slower)
+typedef float cin_f4 __attribute__((ext_vector_type(4)));
+constexpr int kCinKC4 = 16;                       // k' per W chunk
+constexpr int kCinWS = kCinKC4 + 4;               // LDS row stride of a W chunk [n][k']: 20 = 4 x odd -> conflict-free 16-byte reads
+__host__ __device__ inline int cin_hkp(int Hk) { return (Hk + 3) & ~3; }
+__host__ __device__ inline int cin_xks(int Hk) {  // row stride of the x_k tile [m][j]: 4 x odd
+    const int h = cin_hkp(Hk);
+    return ((h >> 2) & 1) ? h : h + 4;
+}
+
 template <bool kAnyAct>
 __global__ __launch_bounds__(256, 2) void k_cin_fwd(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ W, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
     int D, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int K = F0 * Hk;
+    const int HkP = cin_hkp(Hk), XS = cin_xks(Hk), F0S = F0 | 1;
+    const int KP = F0 * HkP;                                // padded contraction length
     const int64_t M = (int64_t)B * D;
-    const int S0 = cin_slab(F0, D), Sk = cin_slab(Hk, D), NB = cin_nb(D);
-    float* x0t = lds;
-    float* xkt = x0t + NB * S0;
-    float* wt = xkt + NB * Sk;  // [2][kCinKC][kCinTileN]
+    float* xkt = lds;                                       // [128][XS]   x_k[m][j], zero for j >= Hk
+    float* wt = xkt + kCinTileM * XS;                       // [2][128][kCinWS]  W chunk, transposed
+    float* x0t = wt + 2 * kCinTileN * kCinWS;               // [128][F0S]  x_0[m][i]
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * kCinTileM;
     const int n0 = blockIdx.y * kCinTileN;
-    const int b_first = (int)(m0 / D);
-    stage_rows(x0, x0_bs, B, F0, D, b_first, NB, S0, x0t);
-    stage_rows(xk, xk_bs, B, Hk, D, b_first, NB, Sk, xkt);
-
-    // this lane's A-operand row
-    const int64_t m = m0 + wave * 32 + c;
-    const bool mvalid = m < M;
-    const int bl = (int)(m / D) - b_first, d = (int)(m % D);
-    const float* x0row = x0t + bl * S0 + d;
-    const float* xkrow = xkt + bl * Sk + d;
+    // stage the tiles: element (m, j) from x[b][j][d], m = b D + d (lanes along m: 64-byte pieces of a row at D = 16)
+    {
+        const int ml = threadIdx.x & (kCinTileM - 1), h = threadIdx.x >> 7;          // 2 threads per row m
+        const int64_t m = m0 + ml;
+        const bool ok = m < M;
+        const int64_t b = ok ? m / D : 0;
+        const int d = ok ? (int)(m - b * D) : 0;
+        const float* pk = xk + b * xk_bs + d;
+        const float* p0 = x0 + b * x0_bs + d;
+        for (int j = h; j < XS; j += 2) xkt[ml * XS + j] = (ok && j < Hk) ? pk[(int64_t)j * D] : 0.f;
+        for (int i = h; i < F0; i += 2) x0t[ml * F0S + i] = ok ? p0[(int64_t)i * D] : 0.f;
+    }
+    const int ml = wave * 32 + c;                           // this lane's A-operand row
+    const float* xkrow = xkt + ml * XS;
+    const float* x0row = x0t + ml * F0S;
 
     floatx16 acc[4];
 #pragma unroll
@@ -95,43 +116,53 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-    const int nchunks = (K + kCinKC - 1) / kCinKC;
-    // W chunk loader: 256 threads x 8 floats = 16 x 128
+    const int nchunks = (KP + kCinKC4 - 1) / kCinKC4;
+    // W chunk loader: 256 threads x 8 floats = 16 k' x 128 n, read along n (coalesced), stored transposed
     float wreg[8];
     auto load_w = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int idx = threadIdx.x + 256 * r;
             const int kk = idx >> 7, n = idx & 127;
-            const int k = chunk * kCinKC + kk;
-            wreg[r] = (k < K && n0 + n < L) ? W[(int64_t)k * L + n0 + n] : 0.f;
+            const int kp = chunk * kCinKC4 + kk;
+            const int i = kp / HkP, j = kp - i * HkP;
+            wreg[r] = (kp < KP && j < Hk && n0 + n < L) ? W[((int64_t)i * Hk + j) * L + n0 + n] : 0.f;
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) wt[buf * kCinKC * kCinTileN + threadIdx.x + 256 * r] = wreg[r];
+        for (int r = 0; r < 8; ++r) {
+            const int idx = threadIdx.x + 256 * r;
+            wt[buf * kCinTileN * kCinWS + (idx & 127) * kCinWS + (idx >> 7)] = wreg[r];
+        }
     };
     load_w(0);
     store_w(0);
     __syncthreads();
     const int nblocks_n = min(4, (L - n0 + 31) / 32);
-    int ki = s / Hk, kj = s % Hk;  // (i,j) of k = 2*step + s, advanced incrementally
+    int ki = 0, kj = 4 * s;                                 // (i, j0) of this lane's k' = 8g + 4s (+ chunk base), advanced by 8: the two
+                                                            // halves of a wave (s = 0, 1) cross into the next i at different steps
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks) load_w(chunk + 1);
-        const float* wb = wt + buf * kCinKC * kCinTileN;
+        const float* wb = wt + buf * kCinTileN * kCinWS + c * kCinWS + 4 * s;
 #pragma unroll
-        for (int kk2 = 0; kk2 < kCinKC / 2; ++kk2) {
-            const int k = chunk * kCinKC + 2 * kk2 + s;
-            float a = 0.f;
-            if (mvalid && k < K) a = x0row[ki * D] * xkrow[kj * D];
-            kj += 2;
-            while (kj >= Hk) { kj -= Hk; ++ki; }
-            const float* wrow = wb + (2 * kk2 + s) * kCinTileN + c;
+        for (int g = 0; g < kCinKC4 / 8; ++g) {
+            cin_f4 a = {0.f, 0.f, 0.f, 0.f};
+            if (ki < F0) a = *reinterpret_cast<const cin_f4*>(xkrow + kj) * x0row[ki];
+            kj += 8;
+            if (kj >= HkP) { kj -= HkP; ++ki; }
+            cin_f4 bq[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bq[nb] = *reinterpret_cast<const cin_f4*>(wb + nb * 32 * kCinWS + 8 * g);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                if (nb < nblocks_n)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[nb * 32], acc[nb], 0, 0, 0);
+                if (nb < nblocks_n) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nb].x, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[nb].y, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nb].z, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nb].w, acc[nb], 0, 0, 0);
+                }
         }
         if (chunk + 1 < nchunks) store_w(buf ^ 1);
         __syncthreads();
@@ -180,10 +211,12 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int64_t M = (int64_t)B * D;
     const int S0 = cin_slab(F0, D), Sk = cin_slab(Hk, D), NB = cin_nb(D);
-    const int LP = 2 * LH + 1;  // padded W row (lanes walk rows)
+    constexpr int LP = 2 * LH + 4;  // padded W row (lanes walk rows): 4 x odd floats -> conflict-free 16-byte reads
+    constexpr int NG = LH / 4;      // groups of 8 l: lane (c, s) holds l = 8g + 4s + jj, jj = 0..3, as ONE float4 (round 3:
+                                    // the K permutation of k_cin_fwd — 16 ds_read_b128 per 64 MFMAs instead of 64 ds_read_b32)
     float* x0t = lds;
     float* xkt = x0t + NB * S0;
-    float* wt = xkt + NB * Sk;  // [2][32][LP]
+    float* wt = lds + ((NB * S0 + NB * Sk + 3) & ~3);  // [2][32][LP], 16-byte aligned
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
@@ -198,18 +231,21 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     const int d = mvalid ? (int)(m % D) : 0;
     const int bl = (int)b - b_first;
 
-    // G[m][l] for l = 2*t + s, kept in registers for the whole tile
-    float G[LH];
+    // G[m][l] for l = 8g + 4s + jj, kept in registers for the whole tile
+    cin_f4 G[NG];
 #pragma unroll
-    for (int t = 0; t < LH; ++t) {
-        const int l = 2 * t + s;
-        float g = 0.f;
-        if (mvalid && l < L) {
-            const int64_t o = (b * L + l) * D + d;
-            g = gy[o];
-            g *= act_grad_from_y(y[o], act);
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int l = 8 * g + 4 * s + jj;
+            float gv = 0.f;
+            if (mvalid && l < L) {
+                const int64_t o = (b * L + l) * D + d;
+                gv = gy[o];
+                gv *= act_grad_from_y(y[o], act);
+            }
+            G[g][jj] = gv;
         }
-        G[t] = g;
     }
     __syncthreads();
     // xk values this lane needs: j = jb*32 + (r&3) + 8*(r>>2) + 4*s
@@ -226,13 +262,25 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     const int njb = (Hk + 31) / 32;
     const int nchunks = F0 * njb;
     // W chunk (i, jb): rows k = i*Hk + jb*32 + r (r<32, j<Hk), cols l < L  -> wt[r][l]
+    const bool wvec = (L % 4 == 0);
     auto stage_w = [&](int chunk, int buf) {
         const int i = chunk / njb, jb = chunk - i * njb;
         float* dst = wt + buf * 32 * LP;
-        for (int e = threadIdx.x; e < 32 * 2 * LH; e += 256) {
-            const int r = e / (2 * LH), l = e - r * (2 * LH);
+        for (int e = threadIdx.x; e < 32 * (2 * LH / 4); e += 256) {        // 16-byte pieces: rows of W are contiguous in l
+            const int r = e / (2 * LH / 4), l = 4 * (e - r * (2 * LH / 4));
             const int j = jb * 32 + r;
-            dst[r * LP + l] = (j < Hk && l < L) ? W[((int64_t)i * Hk + j) * L + l] : 0.f;
+            const float* src = W + ((int64_t)i * Hk + j) * L + l;
+            cin_f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < Hk) {
+                if (wvec && l + 3 < L) v = *reinterpret_cast<const cin_f4*>(src);
+                else {
+                    if (l < L) v.x = src[0];
+                    if (l + 1 < L) v.y = src[1];
+                    if (l + 2 < L) v.z = src[2];
+                    if (l + 3 < L) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<cin_f4*>(dst + r * LP + l) = v;
         }
     };
     stage_w(0, 0);
@@ -241,13 +289,20 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
         if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
-        const float* wrow = wt + buf * 32 * LP + c * LP + s;
-        floatx16 acc;
+        const float* wrow = wt + buf * 32 * LP + c * LP + 4 * s;
+        floatx16 acc, acc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < LH; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[2 * t], G[t], acc, 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+            const cin_f4 a = *reinterpret_cast<const cin_f4*>(wrow + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, G[g].x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, G[g].y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, G[g].z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, G[g].w, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         // contract T^T[j, m] (16 j's in this lane) against xk and x0
         const float x0v = mvalid ? x0t[bl * S0 + i * D + d] : 0.f;
         float p = 0.f;
@@ -282,6 +337,11 @@ constexpr int kCinMC = 64;  // (b,d) rows per LDS chunk
 
 constexpr int kCinKT = 2;   // 32-row K sub-tiles per wave: every staged G value feeds 2 MFMAs
 
+// Round 3: the three tiles sit in LDS TRANSPOSED — x0T[i][m], xkT[j][m], gT[l][m], m contiguous — so that lane (c, s) reads
+// the four consecutive m = 8g + 4s + jj of its K-permuted MFMA steps as ONE float4 per operand: A = x0T[ki] * xkT[kj]
+// (elementwise, Z regenerated), B = gT[l].  8 ds_read_b128 per 32 MFMAs (round 2: 32 ds_read_b32 + 8 multiplies).
+constexpr int kCinMS = kCinMC + 4;     // row stride: 68 = 4 x odd
+
 __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
@@ -289,25 +349,28 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = F0 * Hk;
     const int64_t M = (int64_t)B * D;
-    const int F0P = F0 | 1, HkP = Hk | 1, LPAD = kCinTileN + 1;
-    float* x0T = lds;                 // [MC][F0P]
-    float* xkT = x0T + kCinMC * F0P;  // [MC][HkP]
-    float* gT = xkT + kCinMC * HkP;   // [MC][LPAD]
+    float* x0T = lds;                      // [F0][MS]
+    float* xkT = x0T + F0 * kCinMS;        // [Hk][MS]
+    float* gT = xkT + Hk * kCinMS;         // [128][MS]
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int kbase = blockIdx.x * (128 * kCinKT) + wave * (32 * kCinKT);
-    int ki[kCinKT], kj[kCinKT];
-    bool kvalid[kCinKT];
+    const float* arow0[kCinKT];
+    const float* arowk[kCinKT];
+    float amask[kCinKT];
 #pragma unroll
     for (int u = 0; u < kCinKT; ++u) {
         const int k = kbase + 32 * u + c;   // this lane's A row (i,j) in sub-tile u
-        kvalid[u] = k < K;
-        ki[u] = kvalid[u] ? k / Hk : 0;
-        kj[u] = kvalid[u] ? k % Hk : 0;
+        const bool kv = k < K;
+        const int ki = kv ? k / Hk : 0, kj = kv ? k % Hk : 0;
+        arow0[u] = x0T + ki * kCinMS + 4 * s;
+        arowk[u] = xkT + kj * kCinMS + 4 * s;
+        amask[u] = kv ? 1.f : 0.f;
     }
     const int n0 = blockIdx.z * kCinTileN;
     const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    const float* brow = gT + c * kCinMS + 4 * s;
     const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
     const int64_t m_end = min(M, m_begin + rows_per_split);
 
@@ -321,18 +384,18 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 
     for (int64_t mc = m_begin; mc < m_end; mc += kCinMC) {
         __syncthreads();
-        // stage transposed tiles: rows mm = mc + r.  A thread always stages the same r = tid % 64 (256 threads, 64 rows per
-        // chunk), so its (batch row, d) offset is computed once per chunk, not once per element
+        // stage the transposed tiles: rows mm = mc + r.  A thread always stages the same r = tid % 64 (256 threads, 64 rows per
+        // chunk): its (batch row, d) offset is computed once per chunk; lanes run along m, so every LDS store is contiguous
         const int64_t b0 = mc / D;
         const int d0 = (int)(mc - b0 * D);
         const int rows = (int)min((int64_t)kCinMC, m_end - mc);
-        const int r_ = threadIdx.x & (kCinMC - 1), i_first = threadIdx.x / kCinMC;        // element e = i * 64 + r, i = i_first + 4 k
+        const int r_ = threadIdx.x & (kCinMC - 1), i_first = threadIdx.x / kCinMC;        // element (i, r), i = i_first + 4 k
         const int q_ = d0 + r_, bq_ = q_ / D, dq_ = q_ - bq_ * D;
         const bool rok = r_ < rows;
         const float* x0p = x0 + (b0 + bq_) * x0_bs + dq_;
         const float* xkp = xk + (b0 + bq_) * xk_bs + dq_;
-        for (int i = i_first; i < F0; i += 256 / kCinMC) x0T[r_ * F0P + i] = rok ? x0p[i * D] : 0.f;
-        for (int j = i_first; j < Hk; j += 256 / kCinMC) xkT[r_ * HkP + j] = rok ? xkp[j * D] : 0.f;
+        for (int i = i_first; i < F0; i += 256 / kCinMC) x0T[i * kCinMS + r_] = rok ? x0p[(int64_t)i * D] : 0.f;
+        for (int j = i_first; j < Hk; j += 256 / kCinMC) xkT[j * kCinMS + r_] = rok ? xkp[(int64_t)j * D] : 0.f;
         {
             const int64_t ob = ((b0 + bq_) * L + n0) * D + dq_;
             for (int l = i_first; l < kCinTileN; l += 256 / kCinMC) {
@@ -342,25 +405,29 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
                     g = gy[o];
                     g *= act_grad_from_y(y[o], act);
                 }
-                gT[r_ * LPAD + l] = g;
+                gT[l * kCinMS + r_] = g;
             }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int t = 0; t < kCinMC / 2; ++t) {
-            const int r = 2 * t + s;
-            float a[kCinKT];
+#pragma unroll 2
+        for (int g = 0; g < kCinMC / 8; ++g) {
+            cin_f4 a[kCinKT];
 #pragma unroll
             for (int u = 0; u < kCinKT; ++u)
-                a[u] = kvalid[u] ? x0T[r * F0P + ki[u]] * xkT[r * HkP + kj[u]] : 0.f;
-            const float* grow = gT + r * LPAD + c;
+                a[u] = *reinterpret_cast<const cin_f4*>(arow0[u] + 8 * g) * *reinterpret_cast<const cin_f4*>(arowk[u] + 8 * g) * amask[u];
+            cin_f4 bq[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bq[nb] = *reinterpret_cast<const cin_f4*>(brow + nb * 32 * kCinMS + 8 * g);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 if (nb < nblocks_n) {
-                    const float g = grow[nb * 32];
 #pragma unroll
-                    for (int u = 0; u < kCinKT; ++u)
-                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], g, acc[u][nb], 0, 0, 0);
+                    for (int u = 0; u < kCinKT; ++u) {
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, bq[nb].x, acc[u][nb], 0, 0, 0);
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bq[nb].y, acc[u][nb], 0, 0, 0);
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, bq[nb].z, acc[u][nb], 0, 0, 0);
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, bq[nb].w, acc[u][nb], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -419,8 +486,7 @@ extern "C" int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W
     if (B == 0) return DT_OK;
     DT_REQUIRE(x0 && xk && W && y, "dt_cin_layer_fwd: null pointer");
     DT_REQUIRE(act >= 0 && act < DT_ACT_COUNT, "dt_cin_layer_fwd: act %d", act);
-    const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
-                        2 * kCinKC * kCinTileN) * sizeof(float);
+    const size_t lds = ((size_t)kCinTileM * cin_xks(Hk) + 2 * kCinTileN * kCinWS + (size_t)kCinTileM * (F0 | 1)) * sizeof(float);
     DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd: tiles need %zu B of LDS (> 160 KiB)", lds);
     const int64_t M = (int64_t)B * D;
     dim3 grid((unsigned)((M + kCinTileM - 1) / kCinTileM), (unsigned)ceil_div(L, kCinTileN));
@@ -441,7 +507,7 @@ static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t
                         const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D,
                         float* gx0, float* gxk, hipStream_t st) {
     const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
-                        2 * 32 * (2 * LH + 1)) * sizeof(float);
+                        2 * 32 * (2 * LH + 4) + 4) * sizeof(float);
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
@@ -492,7 +558,7 @@ extern "C" int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + kCinMC - 1) / kCinMC * kCinMC;
     splits = (int)((M + rps - 1) / rps);
-    const size_t lds = (size_t)kCinMC * ((F0 | 1) + (Hk | 1) + kCinTileN + 1) * sizeof(float);
+    const size_t lds = (size_t)kCinMS * (F0 + Hk + kCinTileN) * sizeof(float);
     hipFuncSetAttribute((const void*)k_cin_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_cin_wgrad, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride,
                        xk, xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
