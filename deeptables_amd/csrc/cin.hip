@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd(
     const int nblocks_n = min(4, (L - n0 + 31) / 32);
     int ki = 0, kj = 4 * s;                                 // (i, j0) of this lane's k' = 8g + 4s (+ chunk base), advanced by 8: the two
                                                             // halves of a wave (s = 0, 1) cross into the next i at different steps
+    while (kj >= HkP) { kj -= HkP; ++ki; }                  // HkP = 4: the upper half starts in row i = 1
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks) load_w(chunk + 1);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd(
             cin_f4 a = {0.f, 0.f, 0.f, 0.f};
             if (ki < F0) a = *reinterpret_cast<const cin_f4*>(xkrow + kj) * x0row[ki];
             kj += 8;
-            if (kj >= HkP) { kj -= HkP; ++ki; }
+            while (kj >= HkP) { kj -= HkP; ++ki; }       // (HkP may be 4: two rows of i per group)
             cin_f4 bq[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) bq[nb] = *reinterpret_cast<const cin_f4*>(wb + nb * 32 * kCinWS + 8 * g);
