@@ -55,6 +55,9 @@ SIGNATURES = {
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr]),
     'dt_cin_layer_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'dt_cin_bwd_workspace_bytes': (_c_i64, [_c_int] * 5),
+    'dt_cin_layer_bwd_ws': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_cin_bf16_workspace_bytes': (_c_i64, [_c_int, _c_int, _c_int]),
     'dt_cin_layer_fwd_bf16': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr]),

@@ -346,7 +346,7 @@ constexpr int kCinMS = kCinMC + 4;     // row stride: 68 = 4 x odd
 __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
-    int D, int64_t rows_per_split, float* __restrict__ gW) {
+    int D, int64_t rows_per_split, float* __restrict__ gW, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = F0 * Hk;
     const int64_t M = (int64_t)B * D;
@@ -443,9 +443,32 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kk = kbase + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * s;
-                if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[u][nb][r]);
+                if (kk >= K) continue;
+                // part: this batch split's own [K][L] slab (plain 128-byte row stores), summed by k_cin_wgrad_reduce — the
+                // 512 blocks of a layer otherwise issue 512 x 256 x 128 = 16.7 M float atomics (round 3: 848 -> see DESIGN)
+                if (part) part[((int64_t)blockIdx.y * K + kk) * L + l] = acc[u][nb][r];
+                else atomicAdd(&gW[(int64_t)kk * L + l], acc[u][nb][r]);
             }
         }
+}
+
+// grad_W[k][l] += sum over the batch splits of part[split][k][l]   (16-byte lanes, the splits' loads in flight together)
+__global__ __launch_bounds__(256) void k_cin_wgrad_reduce(const float* __restrict__ part, int splits, int64_t n4,
+                                                          float* __restrict__ gW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    cin_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const cin_f4* p = reinterpret_cast<const cin_f4*>(part) + i;
+    int sp = 0;
+    for (; sp + 8 <= splits; sp += 8) {
+        cin_f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * n4];
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; sp < splits; ++sp) acc += p[(int64_t)sp * n4];
+    cin_f4* g = reinterpret_cast<cin_f4*>(gW) + i;
+    *g = *g + acc;
 }
 
 // grad_bias[l] += sum_{b,d} G[b,l,d]
@@ -522,10 +545,54 @@ static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t
     return launch_status("dt_cin_layer_bwd(dgrad)");
 }
 
+static int cin_wgrad_splits(int B, int F0, int Hk, int L, int D, int64_t* rps_out) {
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    const int kblocks = ceil_div(K, 128 * kCinKT), nblocks = ceil_div(L, kCinTileN);
+    // exactly one residency round: 256 CUs x 2 blocks (<= 256 registers per lane, 59 KB of LDS per block)
+    int splits = 512 / (kblocks * nblocks);
+    if (splits < 1) splits = 1;
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + kCinMC - 1) / kCinMC * kCinMC;
+    splits = (int)((M + rps - 1) / rps);
+    if (rps_out) *rps_out = rps;
+    return splits;
+}
+
+// bytes of the optional workspace of dt_cin_layer_bwd_ws: one [K][L] slab per batch split of the weight-gradient kernel
+extern "C" int64_t dt_cin_bwd_workspace_bytes(int B, int F0, int Hk, int L, int D) {
+    if (B <= 0 || F0 <= 0 || Hk <= 0 || L <= 0 || D <= 0) return 0;
+    return (int64_t)cin_wgrad_splits(B, F0, Hk, L, D, nullptr) * F0 * Hk * L * (int64_t)sizeof(float);
+}
+
+static int cin_layer_bwd(const float* x0, const float* xk, const float* W, const float* y,
+                         const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                         int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                         float* grad_W, float* grad_bias, float* ws, void* stream);
+
 extern "C" int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const float* y,
                                 const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
                                 int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
                                 float* grad_W, float* grad_bias, void* stream) {
+    return cin_layer_bwd(x0, xk, W, y, grad_y, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, grad_x0, grad_xk, grad_W,
+                         grad_bias, nullptr, stream);
+}
+
+// the same with a workspace of dt_cin_bwd_workspace_bytes (16-byte aligned): the weight-gradient kernel's batch splits store
+// their partial [K][L] tiles there and one reduction adds them to grad_W — no float atomics, deterministic
+extern "C" int dt_cin_layer_bwd_ws(const float* x0, const float* xk, const float* W, const float* y,
+                                   const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                                   int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                                   float* grad_W, float* grad_bias, void* ws, void* stream) {
+    DT_REQUIRE(ws && ((uintptr_t)ws | (uintptr_t)grad_W) % 16 == 0, "dt_cin_layer_bwd_ws: ws / grad_W null or not 16-byte aligned");
+    return cin_layer_bwd(x0, xk, W, y, grad_y, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, grad_x0, grad_xk, grad_W,
+                         grad_bias, reinterpret_cast<float*>(ws), stream);
+}
+
+static int cin_layer_bwd(const float* x0, const float* xk, const float* W, const float* y,
+                         const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                         int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                         float* grad_W, float* grad_bias, float* ws, void* stream) {
     int rc = cin_check("dt_cin_layer_bwd", B, F0, Hk, L, D);
     if (rc) return rc;
     if (B == 0) return DT_OK;
@@ -551,18 +618,18 @@ extern "C" int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W
     if (rc) return rc;
 
     const int K = F0 * Hk;
-    const int64_t M = (int64_t)B * D;
     const int kblocks = ceil_div(K, 128 * kCinKT), nblocks = ceil_div(L, kCinTileN);
-    // exactly one residency round: 256 CUs x 2 blocks (<= 256 registers per lane, 57 KB of LDS per block)
-    int splits = 512 / (kblocks * nblocks);
-    if (splits < 1) splits = 1;
-    int64_t rps = (M + splits - 1) / splits;
-    rps = (rps + kCinMC - 1) / kCinMC * kCinMC;
-    splits = (int)((M + rps - 1) / rps);
+    int64_t rps;
+    const int splits = cin_wgrad_splits(B, F0, Hk, L, D, &rps);
+    const bool slabs = ws && ((int64_t)K * L) % 4 == 0;
     const size_t lds = (size_t)kCinMS * (F0 + Hk + kCinTileN) * sizeof(float);
     hipFuncSetAttribute((const void*)k_cin_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_cin_wgrad, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride,
-                       xk, xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
+                       xk, xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, grad_W, slabs ? ws : nullptr);
+    if (slabs) {
+        const int64_t n4 = (int64_t)K * L / 4;
+        hipLaunchKernelGGL(k_cin_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, splits, n4, grad_W);
+    }
     if (grad_bias)
         hipLaunchKernelGGL(k_cin_bias_grad, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D,
                            grad_bias);

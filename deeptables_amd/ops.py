@@ -5,6 +5,8 @@ Each Function is the forward+backward of one reference `Layer.call` in
 deeptables/models/layers.py; torch is only the carrier of device memory, streams and the
 autograd tape.  All functions require CUDA(HIP) tensors — no CPU fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -439,9 +441,17 @@ class _CinLayer(torch.autograd.Function):
                                               F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb), ptr(ws),
                                               stream_ptr()), 'dt_cin_layer_bwd_bf16')
         else:
-            check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
-                                         F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
-                                         stream_ptr()), 'dt_cin_layer_bwd')
+            # the weight-gradient kernel's batch splits store partial [K][L] slabs in a workspace (no float atomics)
+            nws = lib().dt_cin_bwd_workspace_bytes(B, F0, Hk, L, D)
+            if os.environ.get('DT_AMD_CIN_WGRAD_ATOMIC') == '1' or nws <= 0:
+                check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                             F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
+                                             stream_ptr()), 'dt_cin_layer_bwd')
+            else:
+                ws = torch.empty((nws + 3) // 4, dtype=torch.float32, device=x0.device)
+                check(lib().dt_cin_layer_bwd_ws(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                                F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb), ptr(ws),
+                                                stream_ptr()), 'dt_cin_layer_bwd_ws')
         return gx0, gxk, gW, gb, None, None
 
 

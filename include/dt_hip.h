@@ -181,6 +181,14 @@ int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const flo
                      const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
                      int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
                      float* grad_W, float* grad_bias, void* stream);
+/* the same with a workspace (dt_cin_bwd_workspace_bytes, 16-byte aligned): the weight-gradient kernel's batch splits store
+ * their partial [K][L] tiles there and one reduction adds them to grad_W — no float atomics (16.7 M per layer at the
+ * Criteo shape), deterministic */
+int64_t dt_cin_bwd_workspace_bytes(int B, int F0, int Hk, int L, int D);
+int dt_cin_layer_bwd_ws(const float* x0, const float* xk, const float* W, const float* y,
+                        const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
+                        int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
+                        float* grad_W, float* grad_bias, void* ws, void* stream);
 
 /* ---- a12 MultiheadAttention core (models/layers.py:129-145) ------------------------------- *
  * q,k,v [B,F,D] (already relu(Dense(x)), layers.py:123-125); H heads split on the last axis
