@@ -286,9 +286,13 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     };
     stage_w(0, 0);
     __syncthreads();
+    // grad_x0[b,i,d] += sum_j ...: summed over the i's j-blocks in a register, ONE read-modify-write per i whose read is issued
+    // at the i's first chunk (round 2: a dependent global load + store in every chunk)
+    float p_acc = 0.f, gx0_old = 0.f;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
+        if (jb == 0 && mvalid && s == 0) gx0_old = gx0[(b * F0 + i) * D + d];
         if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
         const float* wrow = wt + buf * 32 * LP + c * LP + 4 * s;
         floatx16 acc, acc2;
@@ -317,7 +321,11 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
                 }
             }
         p += __shfl_xor(p, 32, 64);
-        if (mvalid && s == 0) gx0[(b * F0 + i) * D + d] += p;  // unique owner of (b,i,d)
+        p_acc += p;
+        if (jb == njb - 1) {
+            if (mvalid && s == 0) gx0[(b * F0 + i) * D + d] = gx0_old + p_acc;  // unique owner of (b,i,d)
+            p_acc = 0.f;
+        }
         __syncthreads();
     }
     if (mvalid) {
@@ -374,6 +382,9 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
     const float* brow = gT + c * kCinMS + 4 * s;
     const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
     const int64_t m_end = min(M, m_begin + rows_per_split);
+    // 16-byte staging needs 4 consecutive m inside one batch row and aligned addresses
+    const bool vec4 = (D % 4 == 0) && (x0_bs % 4 == 0) && (xk_bs % 4 == 0) &&
+                      ((((uintptr_t)x0 | (uintptr_t)xk | (uintptr_t)y | (uintptr_t)gy) & 15) == 0);
 
     floatx16 acc[kCinKT][4];
 #pragma unroll
@@ -387,6 +398,49 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
         __syncthreads();
         // stage the transposed tiles: rows mm = mc + r.  A thread always stages the same r = tid % 64 (256 threads, 64 rows per
         // chunk): its (batch row, d) offset is computed once per chunk; lanes run along m, so every LDS store is contiguous
+        if (vec4) {
+            // 16-byte staging: 4 consecutive m of one tile row are 4 consecutive d of one (b, row) — a float4 load and a
+            // float4 LDS store; the thread's loads of a batch are issued before its first store (round 3: the scalar form below
+            // waited for ~55 dependent 4-byte loads per thread and chunk, three times the chunk's MFMA time)
+            constexpr int QR = kCinMC / 4;                                   // 16-byte pieces per tile row
+            constexpr int kStB = 4;                                          // pieces per thread and batch (7: the 128 accumulators spill)
+            const int ntask = (F0 + Hk + kCinTileN) * QR;
+            const int rows = (int)min((int64_t)kCinMC, m_end - mc);
+            for (int t0 = threadIdx.x; t0 < ntask; t0 += 256 * kStB) {
+                cin_f4 v[kStB], yv[kStB];
+                int dst[kStB];
+#pragma unroll
+                for (int u = 0; u < kStB; ++u) {
+                    const int t = t0 + 256 * u;
+                    dst[u] = -1;
+                    v[u] = cin_f4{0.f, 0.f, 0.f, 0.f};
+                    yv[u] = cin_f4{1.f, 1.f, 1.f, 1.f};
+                    if (t >= ntask) continue;
+                    const int row = t / QR, q = t - row * QR;
+                    dst[u] = row * kCinMS + 4 * q;
+                    if (4 * q >= rows) continue;
+                    const int64_t m = mc + 4 * q, b = m / D;
+                    const int d = (int)(m - b * D);
+                    if (row < F0) v[u] = *reinterpret_cast<const cin_f4*>(x0 + b * x0_bs + (int64_t)row * D + d);
+                    else if (row < F0 + Hk) v[u] = *reinterpret_cast<const cin_f4*>(xk + b * xk_bs + (int64_t)(row - F0) * D + d);
+                    else if (n0 + row - F0 - Hk < L) {
+                        const int64_t o = (b * L + n0 + row - F0 - Hk) * D + d;
+                        v[u] = *reinterpret_cast<const cin_f4*>(gy + o);
+                        if (act != DT_ACT_LINEAR) yv[u] = *reinterpret_cast<const cin_f4*>(y + o);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kStB; ++u) {
+                    if (dst[u] < 0) continue;
+                    cin_f4 o = v[u];
+                    if (act != DT_ACT_LINEAR && dst[u] >= (F0 + Hk) * kCinMS) {
+                        o.x *= act_grad_from_y(yv[u].x, act); o.y *= act_grad_from_y(yv[u].y, act);
+                        o.z *= act_grad_from_y(yv[u].z, act); o.w *= act_grad_from_y(yv[u].w, act);
+                    }
+                    *reinterpret_cast<cin_f4*>(lds + dst[u]) = o;
+                }
+            }
+        } else {
         const int64_t b0 = mc / D;
         const int d0 = (int)(mc - b0 * D);
         const int rows = (int)min((int64_t)kCinMC, m_end - mc);
@@ -408,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
                 }
                 gT[l * kCinMS + r_] = g;
             }
+        }
         }
         __syncthreads();
 #pragma unroll 2
