@@ -120,13 +120,15 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd(
     // W chunk loader: 256 threads x 8 floats = 16 k' x 128 n, read along n (coalesced), stored transposed
     float wreg[8];
     auto load_w = [&](int chunk) {
+        const int kp0 = chunk * kCinKC4;                    // wave-uniform: ONE division per chunk, the rows walk on from it
+        const int i0 = kp0 / HkP, j0 = kp0 - i0 * HkP;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int idx = threadIdx.x + 256 * r;
             const int kk = idx >> 7, n = idx & 127;
-            const int kp = chunk * kCinKC4 + kk;
-            const int i = kp / HkP, j = kp - i * HkP;
-            wreg[r] = (kp < KP && j < Hk && n0 + n < L) ? W[((int64_t)i * Hk + j) * L + n0 + n] : 0.f;
+            int i = i0, j = j0 + kk;
+            while (j >= HkP) { j -= HkP; ++i; }
+            wreg[r] = (i < F0 && j < Hk && n0 + n < L) ? W[((int64_t)i * Hk + j) * L + n0 + n] : 0.f;
         }
     };
     auto store_w = [&](int buf) {
@@ -215,15 +217,15 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     constexpr int LP = 2 * LH + 4;  // padded W row (lanes walk rows): 4 x odd floats -> conflict-free 16-byte reads
     constexpr int NG = LH / 4;      // groups of 8 l: lane (c, s) holds l = 8g + 4s + jj, jj = 0..3, as ONE float4 (round 3:
                                     // the K permutation of k_cin_fwd — 16 ds_read_b128 per 64 MFMAs instead of 64 ds_read_b32)
-    float* x0t = lds;
-    float* xkt = x0t + NB * S0;
-    float* wt = lds + ((NB * S0 + NB * Sk + 3) & ~3);  // [2][32][LP], 16-byte aligned
+    // x_0 is NOT staged (round 3): a lane needs ONE x_0 value per chunk, fetched from L2 before the chunk's 64 MFMAs; without its
+    // 14 KB the kernel's LDS (67 KB at the Criteo shape) fits twice per CU
+    float* xkt = lds;
+    float* wt = lds + ((NB * Sk + 3) & ~3);  // [2][32][LP], 16-byte aligned
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * kCinTileM;
     const int b_first = (int)(m0 / D);
-    stage_rows(x0, x0_bs, B, F0, D, b_first, NB, S0, x0t);
     stage_rows(xk, xk_bs, B, Hk, D, b_first, NB, Sk, xkt);
 
     const int64_t m = m0 + wave * 32 + c;  // the column of T^T this lane owns
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
         if (jb == 0 && mvalid && s == 0) gx0_old = gx0[(b * F0 + i) * D + d];
+        const float x0v = mvalid ? x0[b * x0_bs + (int64_t)i * D + d] : 0.f;
         if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
         const float* wrow = wt + buf * 32 * LP + c * LP + 4 * s;
         floatx16 acc, acc2;
@@ -309,7 +312,6 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         // contract T^T[j, m] (16 j's in this lane) against xk and x0
-        const float x0v = mvalid ? x0t[bl * S0 + i * D + d] : 0.f;
         float p = 0.f;
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj)
@@ -585,8 +587,7 @@ template <int LH, int JB>
 static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const float* W,
                         const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D,
                         float* gx0, float* gxk, hipStream_t st) {
-    const size_t lds = ((size_t)cin_nb(D) * (cin_slab(F0, D) + cin_slab(Hk, D)) +
-                        2 * 32 * (2 * LH + 4) + 4) * sizeof(float);
+    const size_t lds = ((size_t)cin_nb(D) * cin_slab(Hk, D) + 2 * 32 * (2 * LH + 4) + 4) * sizeof(float);
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
