@@ -300,16 +300,16 @@ class CIN(Layer):
         for idx, layer_size in enumerate(self.cross_layer_size):
             bias = self.bias[idx] if self.use_bias else None
             curr_out = ops.cin_layer(x, hidden, self._filter(idx, layer_size), bias, self.activation, self.mfma_dtype)  # [B,L,D]
+            # only sum_D of the direct-connect channels is ever used (layers.py:720-721 `reduce_sum(result, -1)`): pool each
+            # layer's share where it is produced instead of concatenating [B, sum L, D] first
             if self.direct:
-                direct_connect, hidden = curr_out, curr_out
+                hidden, pooled = curr_out, torch.sum(curr_out, -1)
             elif idx != n - 1:
-                half = layer_size // 2
-                hidden, direct_connect = curr_out[:, :half], curr_out[:, half:]
+                hidden, pooled = ops.cin_split_pool(curr_out, layer_size // 2)      # next layer's input (view) | pooled rest
             else:
-                direct_connect, hidden = curr_out, None
-            final_result.append(direct_connect)
+                hidden, pooled = None, torch.sum(curr_out, -1)
+            final_result.append(pooled)
         result = torch.cat(final_result, dim=1) if len(final_result) > 1 else final_result[0]
-        result = torch.sum(result, -1)
         if self.use_residual:
             ex0 = self.exFM_out0(result)
             return self.exFM_out(torch.cat([ex0, result], dim=1))

@@ -455,6 +455,41 @@ class _CinLayer(torch.autograd.Function):
         return gx0, gxk, gW, gb, None, None
 
 
+class _CinSplitPool(torch.autograd.Function):
+    """CIN `direct=False` bookkeeping of one layer output y [B,L,D] (layers.py:713-718, :720-721): the first `half` channels
+    feed the next layer (a view of y), the others go to the result — of which only the sum over D is ever used
+    (`tf.reduce_sum(result, -1)`), so they are pooled here.  Backward: the layer's incoming gradient [B,L,D] is assembled
+    in place from the two pieces (hidden half copied, pooled half broadcast over D) — torch's slice / cat / sum backward
+    built two zero-filled full-size tensors, added them and expanded the pooled gradient (6 launches per layer)."""
+
+    @staticmethod
+    def forward(ctx, y, half):
+        ctx.shape, ctx.half = tuple(y.shape), int(half)
+        hidden = y[:, :half]
+        pooled = y[:, half:].sum(-1)
+        return hidden, pooled
+
+    @staticmethod
+    def backward(ctx, g_hidden, g_pooled):
+        B, L, D = ctx.shape
+        half = ctx.half
+        gy = torch.empty(ctx.shape, dtype=torch.float32, device=(g_pooled if g_pooled is not None else g_hidden).device)
+        if g_hidden is None:
+            gy[:, :half].zero_()
+        else:
+            gy[:, :half].copy_(g_hidden)
+        if g_pooled is None:
+            gy[:, half:].zero_()
+        else:
+            gy[:, half:].copy_(g_pooled.unsqueeze(-1).expand(B, L - half, D))
+        return gy, None
+
+
+def cin_split_pool(y, half):
+    """y [B,L,D] -> (y[:, :half] (view), sum_D y[:, half:] [B, L-half])"""
+    return _CinSplitPool.apply(y, int(half))
+
+
 def cin_layer(x0, xk, W, bias=None, activation='relu', mfma_dtype='float32'):
     """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias).
     mfma_dtype: 'float32' (exact fp32 MFMA, the default) or 'bf16' (bf16 operands, fp32 accumulation: ~1e-2)."""
