@@ -210,7 +210,7 @@ template <int LH /* ceil(L/2) upper bound: 64 or 128 */, int JB /* ceil(Hk/32) u
 __global__ __launch_bounds__(256) void k_cin_dgrad(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ W, const float* __restrict__ y, const float* __restrict__ gy, int act,
-    int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
+    int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk, int overwrite) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int64_t M = (int64_t)B * D;
     const int S0 = cin_slab(F0, D), Sk = cin_slab(Hk, D), NB = cin_nb(D);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad(
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
-        if (jb == 0 && mvalid && s == 0) gx0_old = gx0[(b * F0 + i) * D + d];
+        if (jb == 0 && mvalid && s == 0 && !overwrite) gx0_old = gx0[(b * F0 + i) * D + d];
         const float x0v = mvalid ? x0[b * x0_bs + (int64_t)i * D + d] : 0.f;
         if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
         const float* wrow = wt + buf * 32 * LP + c * LP + 4 * s;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad(
 
 // grad_W[k][l] += sum over the batch splits of part[split][k][l]   (16-byte lanes, the splits' loads in flight together)
 __global__ __launch_bounds__(256) void k_cin_wgrad_reduce(const float* __restrict__ part, int splits, int64_t n4,
-                                                          float* __restrict__ gW) {
+                                                          float* __restrict__ gW, int overwrite) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     cin_f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_cin_wgrad_reduce(const float* __restric
     }
     for (; sp < splits; ++sp) acc += p[(int64_t)sp * n4];
     cin_f4* g = reinterpret_cast<cin_f4*>(gW) + i;
-    *g = *g + acc;
+    *g = overwrite ? acc : *g + acc;
 }
 
 // grad_bias[l] += sum_{b,d} G[b,l,d]
@@ -586,7 +586,7 @@ extern "C" int dt_cin_layer_fwd(const float* x0, const float* xk, const float* W
 template <int LH, int JB>
 static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const float* W,
                         const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D,
-                        float* gx0, float* gxk, hipStream_t st) {
+                        float* gx0, float* gxk, hipStream_t st, int overwrite) {
     const size_t lds = ((size_t)cin_nb(D) * cin_slab(Hk, D) + 2 * 32 * (2 * LH + 4) + 4) * sizeof(float);
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd: tiles need %zu B of LDS (> 160 KiB)", lds);
@@ -597,7 +597,7 @@ static int launch_dgrad(const float* x0, int64_t x0_bs, const float* xk, int64_t
     hipFuncSetAttribute((const void*)k_cin_dgrad<LH, JB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     hipLaunchKernelGGL((k_cin_dgrad<LH, JB>), grid, dim3(256), lds, st, x0, x0_bs, xk, xk_bs, W, y, gy,
-                       act, B, F0, Hk, L, D, gx0, gxk);
+                       act, B, F0, Hk, L, D, gx0, gxk, overwrite);
     return launch_status("dt_cin_layer_bwd(dgrad)");
 }
 
@@ -660,7 +660,7 @@ static int cin_layer_bwd(const float* x0, const float* xk, const float* W, const
     const int jb = ceil_div(Hk, 32);
 #define DT_DGRAD(LHV, JBV)                                                                          \
     rc = launch_dgrad<LHV, JBV>(x0, x0_bstride, xk, xk_bstride, W, y, grad_y, act, B, F0, Hk, L, D, \
-                                grad_x0, grad_xk, st)
+                                grad_x0, grad_xk, st, ws ? 1 : 0)
     if (L <= 128) {
         if (jb <= 1) DT_DGRAD(64, 1);
         else if (jb <= 2) DT_DGRAD(64, 2);
@@ -678,13 +678,14 @@ static int cin_layer_bwd(const float* x0, const float* xk, const float* W, const
     int64_t rps;
     const int splits = cin_wgrad_splits(B, F0, Hk, L, D, &rps);
     const bool slabs = ws && ((int64_t)K * L) % 4 == 0;
+    if (ws && !slabs) hipMemsetAsync(grad_W, 0, (size_t)K * L * sizeof(float), st);      // the _ws contract: grad_W is overwritten
     const size_t lds = (size_t)kCinMS * (F0 + Hk + kCinTileN) * sizeof(float);
     hipFuncSetAttribute((const void*)k_cin_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_cin_wgrad, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride,
                        xk, xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, grad_W, slabs ? ws : nullptr);
     if (slabs) {
         const int64_t n4 = (int64_t)K * L / 4;
-        hipLaunchKernelGGL(k_cin_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, splits, n4, grad_W);
+        hipLaunchKernelGGL(k_cin_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, splits, n4, grad_W, 1);
     }
     if (grad_bias)
         hipLaunchKernelGGL(k_cin_bias_grad, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D,

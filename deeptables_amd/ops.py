@@ -431,9 +431,12 @@ class _CinLayer(torch.autograd.Function):
         Hk = xk.shape[1]
         L = W.shape[1]
         gy = _f32c(gy)
-        gx0 = torch.zeros_like(x0)
-        gxk = torch.zeros((B, Hk, D), dtype=torch.float32, device=x0.device)
-        gW = torch.zeros_like(W)
+        nws = 0 if ctx.bf16 or os.environ.get('DT_AMD_CIN_WGRAD_ATOMIC') == '1' else \
+            lib().dt_cin_bwd_workspace_bytes(B, F0, Hk, L, D)
+        alloc = torch.empty if nws > 0 else torch.zeros          # dt_cin_layer_bwd_ws overwrites the three gradients
+        gx0 = alloc(x0.shape, dtype=torch.float32, device=x0.device)
+        gxk = alloc((B, Hk, D), dtype=torch.float32, device=x0.device)
+        gW = alloc(W.shape, dtype=torch.float32, device=x0.device)
         gb = torch.zeros((L,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
         if ctx.bf16:
             ws = torch.empty((lib().dt_cin_bf16_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
@@ -442,8 +445,7 @@ class _CinLayer(torch.autograd.Function):
                                               stream_ptr()), 'dt_cin_layer_bwd_bf16')
         else:
             # the weight-gradient kernel's batch splits store partial [K][L] slabs in a workspace (no float atomics)
-            nws = lib().dt_cin_bwd_workspace_bytes(B, F0, Hk, L, D)
-            if os.environ.get('DT_AMD_CIN_WGRAD_ATOMIC') == '1' or nws <= 0:
+            if nws <= 0:
                 check(lib().dt_cin_layer_bwd(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
                                              F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb),
                                              stream_ptr()), 'dt_cin_layer_bwd')

@@ -183,7 +183,8 @@ int dt_cin_layer_bwd(const float* x0, const float* xk, const float* W, const flo
                      float* grad_W, float* grad_bias, void* stream);
 /* the same with a workspace (dt_cin_bwd_workspace_bytes, 16-byte aligned): the weight-gradient kernel's batch splits store
  * their partial [K][L] tiles there and one reduction adds them to grad_W — no float atomics (16.7 M per layer at the
- * Criteo shape), deterministic */
+ * Criteo shape), deterministic.  In this form grad_x0, grad_xk and grad_W are OVERWRITTEN (no zero-fill by the caller);
+ * grad_bias is still accumulated. */
 int64_t dt_cin_bwd_workspace_bytes(int B, int F0, int Hk, int L, int D);
 int dt_cin_layer_bwd_ws(const float* x0, const float* xk, const float* W, const float* y,
                         const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
