@@ -111,11 +111,11 @@ SIGNATURES = {
     'dt_deepfm_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_f32, _c_int, _c_int,
-                                      _c_f32, _ptr, _ptr]),
+                                      _c_f32, _ptr, _c_f32, _ptr, _ptr]),
     'dt_deepfm_train_step_adam': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                            _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int,
-                                           _c_f32, _ptr, _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
+                                           _c_f32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
                                            _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
     'dt_deepfm_dropout_hash': (ctypes.c_uint32, [ctypes.c_uint32] * 3),
     'dt_embedding_gather_owned': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -131,11 +131,11 @@ SIGNATURES = {
     'dt_dcn_train_step': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                    _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32,
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                   _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr, _ptr]),
+                                   _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr, _c_f32, _ptr, _ptr]),
     'dt_dcn_train_step_adam': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                         _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32,
                                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr,
+                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr, _c_f32, _ptr,
                                         _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
                                         _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
 }

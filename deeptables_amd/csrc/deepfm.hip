@@ -93,6 +93,11 @@ struct EmbDrop {
     unsigned thr;            // drop iff hash < thr; 0 = no dropout
     float inv_keep;
     unsigned* seed;          // device word
+    // ModelConfig.dense_dropout (reference config.py:83; Dropout on the continuous inputs, reference deepmodel.py:429-430 'dropout_dense_input'):
+    // the same counter hash on the packed columns F*D + k of the concat row, its own rate; 0 = none.  Forward only: the
+    // continuous inputs take no gradient.
+    unsigned thr_dense;
+    float inv_keep_dense;
 };
 __host__ __device__ inline unsigned emb_drop_hash(unsigned seed, unsigned b, unsigned col) {
     unsigned x = seed ^ (b * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             voc[t] = vocab[fld[t]];
             roff[t] = row_offset[fld[t]];
         }
-        const float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
+        float dv = lane < dm.Nd ? dense[(int64_t)b * dm.Nd + lane] : 0.f;
+        if (drop.thr_dense)          // Dropout on the continuous inputs: they feed the concat row, its BN statistics and `linear`
+            dv = emb_drop_hash(*drop.seed, (unsigned)b, (unsigned)(dm.F * D + lane)) >= drop.thr_dense ? dv * drop.inv_keep_dense : 0.f;
         float4 v[2];
         int64_t row[2];
         bool ok[2];
@@ -588,6 +595,7 @@ struct DcnArgs {
     float* dXc;                  // [B][CP] d loss / d Xn through the cross network (kernel C -> kernel D)
     int mse;                     // loss: 0 = BinaryCrossentropy on the sigmoid output, 1 = MeanSquaredError on the linear output
     int wt;                      // pipelined step: write-through stores of the tile's outputs (st4_wt)
+    const float* sw;             // [B] per-row loss weights (Keras sample_weight x class_weight; loss = sum_b w_b l_b / B), NULL: 1
 };
 constexpr int kCrossMax = 8;     // cross layers the fused DCN step takes
 constexpr int kCrossScal = 48 * 16;                                  // floats of the P / Gram block (k_mlp_fwd3 crP)
@@ -769,13 +777,14 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             cst[u] = src[col];
         }
     }
-    float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f;
+    float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f, swv = 1.f;
     if (wave == 0) {
         wov = p.wo[0];
         bov = p.bo ? p.bo[0] : 0.f;
         if (lane < 32 && m0 + lane < dm.B) {
             if (LC == 0) { linv = lin[m0 + lane]; fmv = fm[m0 + lane]; }
             yv = y[m0 + lane];
+            if (dc.sw) swv = dc.sw[m0 + lane];
         }
     }
     float h1r[16];
@@ -937,6 +946,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                 loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
                 dl = (pr - yv) / (float)dm.B;
             }
+            loss *= swv;         // Keras: per-sample loss times its weight, summed, divided by the batch size
+            dl *= swv;
             if (s == 0) {
                 z_out[m] = zz;
                 logit_out[m] = lg;
@@ -2248,7 +2259,8 @@ static int tower_train_step(
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
-    float embedding_dropout, unsigned* dropout_seed, void* stream, const float* cross_w, const float* cross_b, int Lc,
+    float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+    const float* sample_weight, void* stream, const float* cross_w, const float* cross_b, int Lc,
     const RowsAdam* adam = nullptr, const StepDense* sdense = nullptr) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
@@ -2266,7 +2278,7 @@ static int tower_train_step(
     const int mse = (phases & DT_STEP_LOSS_MSE) ? 1 : 0;
     phases &= 0xf;
     static const int wt_env_c = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;
-    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, (wt_env_c >> 1) & 1};
+    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, (wt_env_c >> 1) & 1, sample_weight};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
@@ -2298,7 +2310,15 @@ static int tower_train_step(
         hipMemsetAsync(ws + wl.X + (int64_t)B * dm.CP, 0, (size_t)pad * dm.CP * sizeof(float), st);
         hipMemsetAsync(ws + wl.dH1 + (int64_t)B * kH1, 0, (size_t)pad * kH1 * sizeof(float), st);
     }
-    EmbDrop drop{0u, 1.f, dropout_seed};
+    EmbDrop drop{0u, 1.f, dropout_seed, 0u, 1.f};
+    if (dense_input_dropout > 0.f && Nd > 0) {
+        DT_REQUIRE(dense_input_dropout < 1.f && dropout_seed, "dt_deepfm_train_step: dense_input_dropout %f needs a rate < 1 "
+                                                               "and the device seed word", dense_input_dropout);
+        const double t = (double)dense_input_dropout * 4294967296.0;
+        drop.thr_dense = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        if (drop.thr_dense == 0) drop.thr_dense = 1;
+        drop.inv_keep_dense = 1.0f / (1.0f - dense_input_dropout);
+    }
     if (embedding_dropout > 0.f) {
         DT_REQUIRE(embedding_dropout < 1.f && dropout_seed, "dt_deepfm_train_step: embedding_dropout %f needs a rate < 1 and "
                                                              "the device seed word", embedding_dropout);
@@ -2434,7 +2454,7 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
                                accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);
         }
-        if (drop.thr) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
+        if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else if (phases >= 2) {
         // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
         const int nmac = (dm.CP >> 6) + 1;
@@ -2469,7 +2489,7 @@ static int tower_train_step(
                                ws + wl.S, mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
                                drop, stamps ? stamps + (int64_t)tiles * 16 : nullptr, nullptr);
         }
-        if (drop.thr) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
+        if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else {
         // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
         hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
@@ -2486,12 +2506,13 @@ extern "C" int dt_deepfm_train_step(
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
-    float embedding_dropout, unsigned* dropout_seed, void* stream) {
+    float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+    const float* sample_weight, void* stream) {
     DT_REQUIRE(w_lin, "dt_deepfm_train_step: null pointer");
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, w_lin, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, grad_rows_scale,
-                            grad_rows_field_major, phases, embedding_dropout, dropout_seed, stream, nullptr, nullptr, 0);
+                            grad_rows_field_major, phases, embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, nullptr, nullptr, 0);
 }
 
 // the step with the row-sparse Keras-Adam update of the rows looked up ONCE applied inside it (k_wgrad_rows): `table` is
@@ -2509,7 +2530,8 @@ extern "C" int dt_deepfm_train_step_adam(
     float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1, const float* W2,
     const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
-    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed,
+    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+    const float* sample_weight,
     float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
     float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
     DT_REQUIRE(w_lin && table && adam_m && adam_v, "dt_deepfm_train_step_adam: null pointer");
@@ -2525,7 +2547,7 @@ extern "C" int dt_deepfm_train_step_adam(
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, w_lin, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, stream, nullptr, nullptr, 0, &ad, dense_n > 0 ? &sd : nullptr);
+                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, nullptr, nullptr, 0, &ad, dense_n > 0 ? &sd : nullptr);
 }
 
 // ---- DCN (nets ['dcn_nets'], deepnets.py:194-207): the same step with the Cross network (layers.py:428-436) in place of
@@ -2578,7 +2600,8 @@ extern "C" int dt_dcn_train_step_adam(
     float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1,
     const float* W2, const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
-    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed,
+    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+    const float* sample_weight,
     float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
     float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
     DT_REQUIRE(cross_w && cross_b && table && adam_m && adam_v, "dt_dcn_train_step_adam: null pointer");
@@ -2595,7 +2618,7 @@ extern "C" int dt_dcn_train_step_adam(
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, nullptr, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, stream, cross_w, cross_b, L, &ad, dense_n > 0 ? &sd : nullptr);
+                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, cross_w, cross_b, L, &ad, dense_n > 0 ? &sd : nullptr);
 }
 
 extern "C" int dt_dcn_train_step(
@@ -2605,11 +2628,12 @@ extern "C" int dt_dcn_train_step(
     float* bn_moving_mean, float* bn_moving_var, float bn_eps, float bn_momentum, const float* W1, const float* b1,
     const float* W2, const float* b2, const float* w3, const float* w_out, const float* b_out,
     float* logit_out, int64_t* rows_out, float* grad_rows, float* accum, void* workspace, int* oob_count,
-    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, void* stream) {
+    void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+    const float* sample_weight, void* stream) {
     DT_REQUIRE(cross_w && cross_b, "dt_dcn_train_step: null pointer");
     DT_UNSUPPORTED(L < 1 || L > kCrossMax, "dt_dcn_train_step: %d cross layers (1..%d)", L, kCrossMax);
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, nullptr, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, stream, cross_w, cross_b, L);
+                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, cross_w, cross_b, L);
 }

@@ -117,10 +117,21 @@ def fused_enabled():
     return os.environ.get('DT_AMD_FUSED', '1') != '0'
 
 
+def _row_weights(sample_weight, y):
+    """Keras fit's sample_weight x class_weight as the [B] fp32 vector the step's loss block reads (None: unweighted)."""
+    if sample_weight is None:
+        return None
+    w = sample_weight.reshape(-1).to(device=y.device, dtype=torch.float32).contiguous()
+    if w.shape[0] != y.shape[0]:
+        raise ValueError(f'sample_weight has {w.shape[0]} entries for {y.shape[0]} rows')
+    return w
+
+
 class FusedDeepFM:
     """Whole-step executor for the DeepFM graph.  Holds the static workspace / gradient buffers."""
 
     NETS = {'linear', 'fm_nets', 'dnn_nets'}
+    takes_sample_weight = True                # the loss block scales each row's loss / dlogit (csrc/deepfm.hip DcnArgs.sw)
 
     @classmethod
     def eligible(cls, dm):
@@ -130,7 +141,7 @@ class FusedDeepFM:
                 return False
             if _step_loss(dm) is None:
                 return False
-            if c.stacking_op != consts.STACKING_OP_ADD or c.dense_dropout:
+            if c.stacking_op != consts.STACKING_OP_ADD or not (0 <= float(c.dense_dropout or 0) < 1):
                 return False
             if not (0 <= float(c.embedding_dropout or 0) < 1):
                 return False
@@ -192,6 +203,8 @@ class FusedDeepFM:
         # embedding_dropout (config.py:84): element dropout inside the step's kernels; the seed word lives on the device
         # and is advanced by the step (a captured graph draws a new mask at every replay)
         self.emb_dropout = float(dm.config.embedding_dropout or 0)
+        # dense_dropout (config.py:83): Dropout on the continuous input columns, masked where kernel A packs them
+        self.dense_dropout = float(dm.config.dense_dropout or 0) if self.Nd else 0.0
         seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
         self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         # duplicate lookups are resolved inside the step (kernels A and G) unless DT_AMD_FUSED_DEDUPE=0
@@ -247,14 +260,14 @@ class FusedDeepFM:
             self._bufs[key] = sb
         return sb
 
-    def _run_sharded(self, idx, dense, y, st):
+    def _run_sharded(self, idx, dense, y, st, sample_weight=None):
         """One train step with the table rows owned per field by the ranks of `st` (see ShardedEmbeddingStrategy):
         ids all-gather -> owner gather -> all-to-all -> the same fused kernels on the local minibatch (reading the
         received rows) -> all-to-all of the row gradients -> the owner's sparse gradient.  Three pieces so that a caller
         can capture the kernels between the collectives into hipGraphs (bench.py): `sharded_pre` (collectives + the
         owner's gather, eager), `sharded_core` (the step's kernels: capturable), `sharded_post` (collective, eager)."""
         self.sharded_pre(idx, st)
-        out = self.sharded_core(idx.shape[0], dense, y, st)
+        out = self.sharded_core(idx.shape[0], dense, y, st, sample_weight)
         self.sharded_post(idx.shape[0], st)
         return out
 
@@ -274,13 +287,14 @@ class FusedDeepFM:
               'dt_embedding_gather_owned')
         st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
 
-    def sharded_core(self, B, dense, y, st):
+    def sharded_core(self, B, dense, y, st, sample_weight=None):
         """the fused step's launches on the received rows (no collective inside: a hipGraph can hold them)"""
         F, D, W = self.F, self.D, st.world_size
         buf = self._buffers(B)
         sb = self._sharded_buffers(B, st)
         dense = None if dense is None else dense.contiguous()
         y = y.reshape(-1).contiguous()
+        sw = _row_weights(sample_weight, y)
         training = self.dm.model.training
         check(lib().dt_deepfm_train_step(
             ptr(sb['iota']), _lib.DT_IDX_I32, ptr(sb['emb_T']), ptr(sb['zero_off']), ptr(sb['fb_vocab']), ptr(dense), ptr(y),
@@ -290,7 +304,7 @@ class FusedDeepFM:
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
             None, None, 0, 1.0 / W, 1, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
-            stream_ptr()),
+            self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()),
             'dt_deepfm_train_step')
         for p, g in self.grad_views:
             p.grad = g
@@ -306,7 +320,7 @@ class FusedDeepFM:
         grad_own = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'])
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False):
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None):
         """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
         (views of one static buffer) and registers the embedding table's sparse gradient.  apply_rows=True: the caller
         runs `optimizer.step()` right after this call, so the step may update the table rows looked up once itself
@@ -314,7 +328,7 @@ class FusedDeepFM:
         st = self.dm.config.distribute_strategy
         if backward and getattr(st, 'sharded_embeddings', False) and st.active and \
                 not self.emb.uses_dense_grad(self.D):
-            return self._run_sharded(idx, dense, y, st)
+            return self._run_sharded(idx, dense, y, st, sample_weight)
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
@@ -324,6 +338,7 @@ class FusedDeepFM:
             idx = idx.to(torch.int32)
         dense = None if dense is None else dense.contiguous()
         y = y.reshape(-1).contiguous()
+        sw = _row_weights(sample_weight, y)
         table = self.emb.tables[self.key]
         training = self.dm.model.training
         dedupe = _dedupe_in_step(self, B, backward)
@@ -350,14 +365,14 @@ class FusedDeepFM:
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_deepfm_train_step_adam(
                 *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
-                ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
+                self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_deepfm_train_step(
                 *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
-                ptr(self.drop_seed), stream_ptr()), 'dt_deepfm_train_step')
+                ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
@@ -393,7 +408,7 @@ class FusedDCN(FusedDeepFM):
                 return False
             if _step_loss(dm) is None:
                 return False
-            if c.dense_dropout or not (0 <= float(c.embedding_dropout or 0) < 1):
+            if not (0 <= float(c.dense_dropout or 0) < 1) or not (0 <= float(c.embedding_dropout or 0) < 1):
                 return False
             st = c.distribute_strategy
             if getattr(st, 'sharded_embeddings', False) and getattr(st, 'active', False):
@@ -459,6 +474,8 @@ class FusedDCN(FusedDeepFM):
             self.grad_views.append((self.out.bias, a[o['dbo']:o['dbo'] + 1]))
         self.loss_view = a[o['loss']:o['loss'] + 1]
         self.emb_dropout = float(dm.config.embedding_dropout or 0)
+        # dense_dropout (config.py:83): Dropout on the continuous input columns, masked where kernel A packs them
+        self.dense_dropout = float(dm.config.dense_dropout or 0) if self.Nd else 0.0
         seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
         self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
@@ -489,7 +506,7 @@ class FusedDCN(FusedDeepFM):
             self._bufs[B] = b
         return b
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False):
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None):
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
@@ -499,6 +516,7 @@ class FusedDCN(FusedDeepFM):
             idx = idx.to(torch.int32)
         dense = None if dense is None else dense.contiguous()
         y = y.reshape(-1).contiguous()
+        sw = _row_weights(sample_weight, y)
         table = self.emb.tables[self.key]
         training = self.dm.model.training
         dedupe = _dedupe_in_step(self, B, backward)
@@ -521,14 +539,14 @@ class FusedDCN(FusedDeepFM):
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_dcn_train_step_adam(
                 *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
-                ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
+                self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_dcn_train_step(
                 *head, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
-                ptr(self.drop_seed), stream_ptr()), 'dt_dcn_train_step')
+                ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_dcn_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g

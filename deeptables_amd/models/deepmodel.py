@@ -259,17 +259,21 @@ class DeepModel:
 
     def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False):
         """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
-        sample_weight [B] (Keras fit's sample_weight x class_weight): the weighted loss runs on the layer-by-layer path.
+        sample_weight [B] (Keras fit's sample_weight x class_weight): the DeepFM / DCN plans scale each row's loss inside
+        their loss block; other plans leave a weighted step to the layer-by-layer path.
         apply_rows=True is the caller's promise that `self.optimizer.step()` follows immediately (train_step): a fused
         plan may then apply the row-sparse update of the table rows looked up once inside its own kernels."""
-        plan = self.fused_plan() if (self.model.training and sample_weight is None) else None
+        plan = self.fused_plan() if self.model.training else None
+        if plan is not None and sample_weight is not None and not getattr(plan, 'takes_sample_weight', False):
+            plan = None
         self.optimizer.zero_grad(flat=plan is None) if hasattr(self.optimizer, 'register_flat_group') \
             else self.optimizer.zero_grad()
         self._step_used_plan = plan is not None
         if plan is not None:
             cat = inputs[0]
             dense = inputs[1] if len(inputs) > 1 else None
-            loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows)
+            kw = {} if sample_weight is None else {'sample_weight': sample_weight}
+            loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows, **kw)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit
         # generic path: the dense gradients accumulate in the model-wide flat buffer (None without one)

@@ -418,7 +418,8 @@ int dt_dcn_train_step(const void* idx, int idx_kind, const float* table, const i
                       const float* b1, const float* W2, const float* b2, const float* w3, const float* w_out,
                       const float* b_out, float* logit_out, int64_t* rows_out, float* grad_rows, float* accum,
                       void* workspace, int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
-                      float embedding_dropout, unsigned* dropout_seed, void* stream);
+                      float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+                      const float* sample_weight, void* stream);
 /* dt_dcn_train_step with the optimizer step inside — arguments and semantics as dt_deepfm_train_step_adam (dense_n = the
  * offset of d cross_b + L * C floats of the dt_dcn_accum_offsets layout). */
 int dt_dcn_train_step_adam(const void* idx, int idx_kind, float* table, const int64_t* row_offset,
@@ -428,7 +429,8 @@ int dt_dcn_train_step_adam(const void* idx, int idx_kind, float* table, const in
                            const float* b1, const float* W2, const float* b2, const float* w3, const float* w_out,
                            const float* b_out, float* logit_out, int64_t* rows_out, float* grad_rows, float* accum,
                            void* workspace, int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
-                           float embedding_dropout, unsigned* dropout_seed, float* adam_m, float* adam_v, int slot_stride,
+                           float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+                           const float* sample_weight, float* adam_m, float* adam_v, int slot_stride,
                            void* adam_state, float lr_t, float beta1, float beta2, float eps, float* dense_p,
                            float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
@@ -445,7 +447,7 @@ int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, cons
                          int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
                          int* oob_count, void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale,
                          int grad_rows_field_major, int phases, float embedding_dropout, unsigned* dropout_seed,
-                         void* stream);
+                         float dense_input_dropout, const float* sample_weight, void* stream);
 /* dt_deepfm_train_step_adam — the same step with the optimizer's row-sparse update fused into it (replaces, for the looked-up
  * table rows, the `apply_gradients` half of keras.Model.train_step that DeepModel.fit drives, deepmodel.py:114-129 with
  * the Adam of :321-322).  `table` is updated IN PLACE for every row looked up exactly once in the batch (Keras-Adam
@@ -469,13 +471,21 @@ int dt_deepfm_train_step_adam(const void* idx, int idx_kind, float* table, const
                               const float* w3, const float* w_out, const float* b_out, float* logit_out,
                               int64_t* rows_out, float* grad_rows, float* accum, void* workspace,
                               int* oob_count, void* dedupe_ws, int64_t dedupe_slots, int phases,
-                              float embedding_dropout, unsigned* dropout_seed, float* adam_m, float* adam_v,
+                              float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
+                              const float* sample_weight, float* adam_m, float* adam_v,
                               int slot_stride, void* adam_state, float lr_t, float beta1, float beta2, float eps,
                               float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
 /* embedding_dropout > 0 (ModelConfig.embedding_dropout, config.py:84: SpatialDropout1D on every [B,1,D] embedding =
  * element dropout scaled by 1/(1-p)): element (b, f, d) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b, f*D+d) >=
  * p * 2^32.  *dropout_seed is a DEVICE word, advanced by the step itself (so a captured graph draws a fresh mask at every
- * replay); pass 0 / NULL at inference. */
+ * replay); pass 0 / NULL at inference.
+ * dense_input_dropout > 0 (ModelConfig.dense_dropout, config.py:83: the Dropout 'dropout_dense_input' on the concatenated
+ * continuous inputs, deepmodel.py:429-430): continuous value (b, k) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b,
+ * F*D + k) >= p * 2^32 and scaled by 1/(1-p), where the step packs it into the concat row — `linear`, the BN statistics
+ * and the tower all see the masked value, as in the reference graph.
+ * sample_weight [B] or NULL (keras.Model.fit's sample_weight x class_weight, deepmodel.py:114-129 passes both through):
+ * loss = sum_b w_b * l_b / B and every gradient follows from d loss / d logit_b = w_b * (...) / B (Keras
+ * SUM_OVER_BATCH_SIZE reduction of the weighted per-sample losses). */
 unsigned dt_deepfm_dropout_hash(unsigned seed, unsigned b, unsigned col);
 
 #ifdef __cplusplus

@@ -474,14 +474,90 @@ def test_fused_step_with_embedding_dropout_matches_oracle_with_the_same_mask(dev
     assert int(plan.drop_seed.item()) & 0xFFFFFFFF == (seed * 1664525 + 1013904223) & 0xFFFFFFFF
 
 
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+@pytest.mark.parametrize('task', ['binary', 'regression'])
+def test_fused_weighted_step_with_dense_dropout_matches_oracle(dev, net, task):
+    """Keras sample / class weights (loss = sum_b w_b l_b / B, reference deepmodel.py:114-129 hands both to
+    keras fit) and ModelConfig.dense_dropout (Dropout on the continuous inputs, reference deepmodel.py:429-430) stay on the
+    fused plan: the oracle, fed the continuous columns with the step's own keep mask, gives the same weighted loss, logits
+    and gradients."""
+    from deeptables_amd.models import deepnets
+    from oracle import bridge, reference_layers as R
+    F, Nd, D, B, rate = 9, 6, 8, 200, 0.25
+    extra = dict(cross_params={'num_cross_layer': 2}) if net == 'DCN' else {}
+    dm, cats = build(F, Nd, D, vocab=30, nets=getattr(deepnets, net), task=task, dense_dropout=rate, **extra)
+    plan = dm.fused_plan()
+    assert plan is not None and plan.takes_sample_weight and plan.dense_dropout == rate
+    idx, dense, y = batch(cats, Nd, B)
+    if task == 'regression':
+        y = torch.randn(B, 1, generator=torch.Generator().manual_seed(2))
+    wts = torch.rand(B, generator=torch.Generator().manual_seed(8)) * 2 + 0.1
+    wts[::7] = 0                                                   # class_weight 0 rows take no part
+    seed = 0x2468ACE
+    plan.drop_seed.fill_(seed)
+    assert Nd <= D                                                 # the hash columns of the continuous inputs: F*D + k
+    keep = torch.from_numpy(_emb_keep(seed, B, F + 1, D, rate)[:, F * D:F * D + Nd])
+    assert 0 < float((keep == 0).double().mean()) < 2 * rate
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = R.model_forward(w, idx.float(), dense.double() * keep, dm.config.nets, bridge.oracle_config(dm),
+                                   training=True)
+    z = ref_logit.reshape(B)
+    t = y.double().reshape(B)
+    per = (torch.clamp(z, min=0) - z * t + torch.log1p(torch.exp(-z.abs()))) if task == 'binary' else (z - t) ** 2
+    ref_loss = (per * wts.double()).sum() / B
+    ref_loss.backward()
+    dm.model.train()
+    loss, logit = dm.forward_backward([idx.int().to(dev), dense.to(dev)], y.to(dev), wts.to(dev))
+    torch.cuda.synchronize()
+    assert dm._step_used_plan
+    assert (logit.double().cpu() - ref_logit.detach()).abs().max().item() < 1e-4
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-5 * max(1.0, abs(float(ref_loss)))
+    L = dm.model.layers_by_name
+    pre = 'dcn' if net == 'DCN' else 'dnn'
+    assert rel(L[pre + '_dense_1'].kernel.grad, w['dcn_dnn' if net == 'DCN' else 'dnn'][0][0].grad) < 2e-4
+    table = L['emb_categorical_vars_all'].tables[f'd{D}']
+    tabs = w['emb_categorical_vars_all']
+    assert rel(table.grad, torch.cat([t_.grad for t_ in tabs], 0)) < 2e-4
+    assert int(plan.drop_seed.item()) & 0xFFFFFFFF == (seed * 1664525 + 1013904223) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+def test_fused_weighted_train_steps_equal_the_layer_by_layer_path(dev, net):
+    """six weighted TRAIN steps (in-step optimizer included) on the fused plan against a twin without a plan"""
+    from deeptables_amd.models import deepnets
+    F, Nd, D, B = 26, 13, 16, 700
+    extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+    dm, cats = build(F, Nd, D, vocab=300, nets=getattr(deepnets, net), **extra)
+    twin, _ = build(F, Nd, D, vocab=300, nets=getattr(deepnets, net), **extra)
+    twin._fused_plan = None
+    with torch.no_grad():
+        for (n1, p1), (n2, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+            p2.copy_(p1)
+    dm.model.train(); twin.model.train()
+    g = torch.Generator().manual_seed(5)
+    for step in range(6):
+        idx_s, dense_s, y_s = batch(cats, Nd, B, seed=70 + step)
+        ins_s = [idx_s.int().to(dev), dense_s.to(dev)]
+        wts = (torch.rand(B, generator=g) * 3).to(dev)
+        l1, _ = dm.train_step(ins_s, y_s.to(dev), wts)
+        l2, _ = twin.train_step(ins_s, y_s.to(dev), wts)
+        assert dm._step_used_plan and not twin._step_used_plan
+        assert abs(float(l1) - float(l2)) < 2e-5, step
+    for (n1, p1), (_, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
+        assert rel(p1, p2) < 5e-4, n1
+
+
 @pytest.mark.parametrize('net,H1,H2', [('DeepFM', 100, 40), ('DCN', 32, 64)])
-def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2):
+def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2, monkeypatch):
     """once a fused plan with a narrow tower exists, the tower parameters and their Adam moments are
     STRIDED views of zero-padded slabs.  A step with sample weights takes the layer-by-layer path and hands the optimizer
     ordinary autograd gradients: the update must land on the right elements (and keep the pads zero), not treat the views
-    as contiguous.  Unweighted (fused) and weighted steps interleaved against a twin that never builds a plan; and a
-    weighted FIRST step does not build the plan as a side effect."""
+    as contiguous.  Unweighted (fused) and weighted steps interleaved against a twin that never builds a plan.  (Since
+    round 3 the DeepFM / DCN plans take the weights themselves — test_fused_weighted_step_* below; here the plan is told not
+    to, which is the path any plan without `takes_sample_weight` goes.)"""
+    from deeptables_amd import fused
     from deeptables_amd.models import deepnets
+    monkeypatch.setattr(fused.FusedDeepFM, 'takes_sample_weight', False)
     F, Nd, D, B = 11, 5, 8, 300
     extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
     hu = {'hidden_units': ((H1, 0, False), (H2, 0, False)), 'activation': 'relu'}
@@ -499,7 +575,7 @@ def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2):
     w0 = (torch.rand(B, generator=g) + 0.5).to(dev)
     l1, _ = dm.train_step(ins_s, y_s.to(dev), w0)
     l2, _ = twin.train_step(ins_s, y_s.to(dev), w0)
-    assert not hasattr(dm, '_fused_plan'), 'a weighted step built the fused plan'
+    assert not dm._step_used_plan, 'a weighted step ran on a plan that does not take weights'
     assert abs(float(l1) - float(l2)) < 1e-5
     for step in range(6):
         idx_s, dense_s, y_s = batch(cats, Nd, B, seed=50 + step)
