@@ -484,9 +484,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the benchmarked configuration')
     ap.add_argument('--no-extras', action='store_true')
-    ap.add_argument('--tables', default='replicated', choices=['replicated', 'sharded'],
+    ap.add_argument('--tables', default='auto', choices=['auto', 'replicated', 'sharded'],
                     help='N>1: replicated tables + dense all-reduce + deduped sparse all-gather (the reference\'s '
-                         'MirroredStrategy shape, default) or embedding rows owned per field by one rank (all-to-all)')
+                         'MirroredStrategy shape) or embedding rows owned per field by one rank (all-to-all). auto = sharded '
+                         'for the headline DeepFM step (the only layout whose per-rank exchange and row updates do not grow '
+                         'with N: DESIGN.md §5), replicated for the other models')
     ap.add_argument('--bucket-ratio', type=float, default=1.0,
                     help='N>1, replicated tables: wire size of a rank\'s sparse bucket / its lookups (1.0 never overflows)')
     ap.add_argument('--graph-segments', action='store_true',
@@ -497,6 +499,8 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.tables == 'auto':
+        args.tables = 'sharded' if (args.model == 'DeepFM' and not args.force_dp) else 'replicated'
     strategy = None
     if world > 1 or args.force_sharded or args.force_dp:
         from deeptables_amd.parallel import DataParallelStrategy, ShardedEmbeddingStrategy

@@ -186,15 +186,27 @@ __device__ __forceinline__ void ai_apply(const ai_f4 (&p)[2][2], const float* ys
     }
 }
 
-template <int D, int DH>
+template <int D, int DH, bool DROP>
 __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, AiW w4, int B, int F, int NP,
                                                      float* __restrict__ out_a, float* __restrict__ lse_out,
-                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
+                                                     unsigned drop_thr, float inv_keep, unsigned seed,
+                                                     const float* __restrict__ bn_shift, float* __restrict__ bn_part) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float* ys = lds + wave * 32 * C::YS;
+    // BatchNormalization statistics of the layer's output (layers.py:151) ride along (bn_part != NULL): every lane owns the
+    // float4 column lane % (D/4) of all the rows it stores and keeps sum / sum of squares of (a - K), K = bn_shift (the
+    // moving mean: near the batch mean after a few steps, and the same for every block, so partials add up without a
+    // merge formula).  bn_part = [D] copy of K | [gridDim.x][2][D] block sums; dt_autoint_fwd_bn's second launch finishes.
+    ai_f4 bnK = {0.f, 0.f, 0.f, 0.f}, bnS = bnK, bnQ = bnK;
+    if (bn_part && bn_shift) {
+        bnK = *reinterpret_cast<const ai_f4*>(bn_shift + 4 * (lane % (D / 4)));
+        if (blockIdx.x == 0 && threadIdx.x < D / 4) *reinterpret_cast<ai_f4*>(bn_part + 4 * threadIdx.x) = bnK;
+    } else if (bn_part && blockIdx.x == 0 && threadIdx.x < D / 4) {
+        *reinterpret_cast<ai_f4*>(bn_part + 4 * threadIdx.x) = bnK;
+    }
     const int M = NP * D;                                   // columns of Wcat
     float wr[D / 4][C::TK], br[D / 4];
 #pragma unroll
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float pv = st[J][I][r] * inv;
-                        if (drop_thr) pv *= ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep);
+                        if (DROP) pv *= ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep);
                         st[J][I][r] = pv;
                     }
             }
@@ -268,25 +280,125 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
         // the row block [F][D] leaves as whole rows
         for (int e = lane; e < F * (D / 4); e += 64) {
             const int i = e / (D / 4), c4 = e - i * (D / 4);
-            *reinterpret_cast<ai_f4*>(out_a + ((int64_t)b * F + i) * D + 4 * c4) =
-                *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+            const ai_f4 v = *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+            *reinterpret_cast<ai_f4*>(out_a + ((int64_t)b * F + i) * D + 4 * c4) = v;
+            const ai_f4 dlt = v - bnK;
+            bnS += dlt;
+            bnQ += dlt * dlt;
         }
         ai_fence();
     }
+    if (bn_part) {
+        // lanes with the same float4 column -> lane % (D/4); waves through their (dead) slabs; one record per block
+#pragma unroll
+        for (int o = D / 4; o < 64; o <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bnS[c] += __shfl_xor(bnS[c], o, 64);
+                bnQ[c] += __shfl_xor(bnQ[c], o, 64);
+            }
+        }
+        if (lane < D / 4) {
+            *reinterpret_cast<ai_f4*>(ys + 4 * lane) = bnS;
+            *reinterpret_cast<ai_f4*>(ys + D + 4 * lane) = bnQ;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * D) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += lds[w * 32 * C::YS + threadIdx.x];
+            bn_part[D + (int64_t)blockIdx.x * 2 * D + threadIdx.x] = v;
+        }
+    }
+}
+
+// second launch of dt_autoint_fwd_bn: every block adds up the forward's block sums (<= 512 records of 2 D floats: L2 reads,
+// 1024 threads, eight independent loads in flight each), forms mean / rstd, and normalises its share of a -> y; block 0 also
+// leaves save_mean / save_rstd for the backward and moves the moving statistics (bn.hip k_bn_finalize's arithmetic).  The
+// shift K is read from the record's copy, NOT from moving_mean (block 0 rewrites that while others are still here).
+__global__ __launch_bounds__(1024) void k_autoint_bn_apply(const float* __restrict__ a, int total4, int D,
+                                                           const float* __restrict__ part, int nparts, float inv_n,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float momentum, float* __restrict__ moving_mean,
+                                                           float* __restrict__ moving_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    __shared__ __attribute__((aligned(16))) float cmean[32], crstd[32], cg[32], cb[32];
+    const int t = threadIdx.x, W2 = 2 * D;                  // W2 = 32 or 64 values per record
+    const int grp = t / W2, ngrp = 1024 / W2, col = t - grp * W2;
+    const float* pp = part + D + col;
+    float tot = 0.f;
+    for (int k = grp; k < nparts; k += 32 * ngrp) {         // 32 records in flight per thread: one round trip for 512 records
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = k + u * ngrp < nparts ? pp[(int64_t)(k + u * ngrp) * W2] : 0.f;
+#pragma unroll
+        for (int u = 16; u > 0; u >>= 1)
+#pragma unroll
+            for (int w = 0; w < u; ++w) v[w] += v[w + u];
+        tot += v[0];
+    }
+    red[t] = tot;
+    __syncthreads();
+    if (t < D) {
+        float S = 0.f, Q = 0.f;
+        for (int g2 = 0; g2 < ngrp; ++g2) {
+            S += red[g2 * W2 + t];
+            Q += red[g2 * W2 + D + t];
+        }
+        const float K = part[t];
+        const float dm = S * inv_n;                         // mean - K
+        const float mean = K + dm;
+        const float var = fmaxf(Q * inv_n - dm * dm, 0.f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        cmean[t] = mean;
+        crstd[t] = rstd;
+        cg[t] = gamma ? gamma[t] : 1.f;
+        cb[t] = beta ? beta[t] : 0.f;
+        if (blockIdx.x == 0) {
+            save_mean[t] = mean;
+            save_rstd[t] = rstd;
+            if (moving_mean) moving_mean[t] = moving_mean[t] * momentum + mean * (1.f - momentum);
+            if (moving_var) moving_var[t] = moving_var[t] * momentum + var * (1.f - momentum);
+        }
+    }
+    __syncthreads();
+    // the float4 column of a thread is the same in every iteration (the stride is a multiple of D/4)
+    const int c4 = t & (D / 4 - 1);
+    const ai_f4 m = *reinterpret_cast<const ai_f4*>(cmean + 4 * c4), r = *reinterpret_cast<const ai_f4*>(crstd + 4 * c4);
+    const ai_f4 g = *reinterpret_cast<const ai_f4*>(cg + 4 * c4), bb = *reinterpret_cast<const ai_f4*>(cb + 4 * c4);
+    const ai_f4* a4 = reinterpret_cast<const ai_f4*>(a);
+    ai_f4* y4 = reinterpret_cast<ai_f4*>(y);
+    const int stride = gridDim.x * 1024;
+    int e = blockIdx.x * 1024 + t;
+    for (; e + 3 * stride < total4; e += 4 * stride) {       // four 16-byte loads in flight per thread
+        const ai_f4 v0 = a4[e], v1 = a4[e + stride], v2 = a4[e + 2 * stride], v3 = a4[e + 3 * stride];
+        y4[e] = (v0 - m) * r * g + bb;                       // the rounding sequence of bn.hip k_bn_apply
+        y4[e + stride] = (v1 - m) * r * g + bb;
+        y4[e + 2 * stride] = (v2 - m) * r * g + bb;
+        y4[e + 3 * stride] = (v3 - m) * r * g + bb;
+    }
+    for (; e < total4; e += stride) y4[e] = (a4[e] - m) * r * g + bb;
 }
 
 // Backward.  g = gradient w.r.t. a = relu(O + R) (after the BatchNormalization backward), a = the saved forward output.
 // dY [B,F,NP*D] = gradient w.r.t. the PRE-activations of q | k | v [| residual] (the weight gradient x^T dY is a
 // batch reduction and stays dt_dense_bwd's); dX [B,F,D] = dY Wcat^T is formed here, from the slab.
 // 8 waves per block (two per SIMD); the weights live ONCE per block in LDS (wl [D][NP*D+4]), not in registers.
-// (Tried and dropped: x^T dY accumulated in-kernel — 64 accumulator registers per wave do not fit beside the head
-// loop at two waves per SIMD, and a block-shared LDS accumulator fed by ds_add_f32 ran at ~1 lane-atomic per 3 cycles:
-// 358 us against 189 + 42 us for this kernel + the Dense weight-gradient kernel.)
-template <int D, int DH>
-__global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
-                                                     const float* __restrict__ g, int B, int F, int NP,
-                                                     float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
-                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
+// (Round 2 tried a block-shared LDS accumulator for x^T dY fed by ds_add_f32: ~1 lane-atomic per 3 cycles, 358 us against
+// 189 + 42 us for this kernel + the Dense weight-gradient kernel.  Round 3's WG variant below keeps the accumulators in
+// registers — 245 VGPRs, no spill, with the per-element dropout code compiled out.)
+// WG (round 3): the kernel / bias gradients x^T dY and colsum(dY) (the batch reduction dt_dense_bwd ran as its own launch,
+// re-reading the 109 MB of dY this kernel had just written) are accumulated HERE, per wave in 64 + 8 accumulator registers,
+// from the dY slab while it is still in LDS: dWc[d][m] += sum_field x[field][d] dY[field][m] as 2 x (M/16) MFMA tiles x 7
+// field steps per batch row.  The block's eight waves sum their accumulators through the (dead) slabs at the end and leave
+// ONE partial [D*M + M] per block in wpart; dt_autoint_bwd_w's second launch adds the <= 256 partials and writes the four
+// Keras variables' gradients.  dY itself never reaches HBM (pass dY = NULL).
+template <int D, int DH, bool WG, bool DROP>
+__device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
+                                            const float* __restrict__ g, int B, int F, int NP,
+                                            float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
+                                            unsigned drop_thr, float inv_keep, unsigned seed, float* __restrict__ wpart) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -316,6 +428,15 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
     }
     const float scale = 1.0f / sqrtf((float)DH);
     const int nwaves = gridDim.x * 8;
+    constexpr int WT = WG ? D / 4 : 1;                      // column tiles of dY (4D / 16)
+    constexpr int WSTEPS = 7;                               // field steps of the weight-gradient product (fields 4s + q < 28)
+    ai_f4 wacc[D / 16][WT];                                 // wacc[T][ct][r] = dWc[16T + 4q + r][16ct + n]
+    float bacc[2] = {0.f, 0.f};                             // column sums of dY: columns lane and 64 + lane
+#pragma unroll
+    for (int ct = 0; ct < WT; ++ct) {
+#pragma unroll
+        for (int T = 0; T < D / 16; ++T) wacc[T][ct] = ai_f4{0.f, 0.f, 0.f, 0.f};
+    }
     float xa[2][C::TK];
     int64_t b = (int64_t)blockIdx.x * 8 + wave;
     if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
@@ -419,7 +540,7 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = pt[J][I][r] * inv;
-                        const float keep = drop_thr ? ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep) : 1.f;
+                        const float keep = DROP ? ai_keep(seed, drop_thr, (unsigned)b, h, i, 16 * J + 4 * q + r, inv_keep) : 1.f;
                         dpt[J][I][r] *= keep;                               // gradient w.r.t. the un-dropped probability
                         pt[J][I][r] = pv;
                         delta += pv * dpt[J][I][r];
@@ -473,7 +594,7 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
                     for (int J = 0; J < 2; ++J) {
                         const int j = 16 * J + n;
                         const float pv = j < F ? __expf(pn[I][J][r] * scale - m) * inv : 0.f;
-                        const float keep = drop_thr ? ai_keep(seed, drop_thr, (unsigned)b, h, i, j, inv_keep) : 1.f;
+                        const float keep = DROP ? ai_keep(seed, drop_thr, (unsigned)b, h, i, j, inv_keep) : 1.f;
                         pdrop[I][J][r] = i < F ? pv * keep : 0.f;
                         pn[I][J][r] = i < F ? pv * (dpn[I][J][r] * keep - delta) * scale : 0.f;            // dS[i][j]
                     }
@@ -526,8 +647,18 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
             *reinterpret_cast<ai_f4*>(dY + ((int64_t)b * F + i) * M + 4 * c4) =
                 *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
         }
+        // x^T as the A operand of the weight-gradient product: xw[T][s] = x[b][4s + q][16T + n] (fields >= F: 0); these hit L2
+        // (the wave read the row a few microseconds ago) and fly under the dX product
+        float xw[D / 16][WG ? WSTEPS : 1];
+        if (WG) {
+#pragma unroll
+            for (int s = 0; s < WSTEPS; ++s)
+#pragma unroll
+                for (int T = 0; T < D / 16; ++T)
+                    xw[T][s] = 4 * s + q < F ? x[((int64_t)b * F + 4 * s + q) * D + 16 * T + n] : 0.f;
+        }
         if (b + nwaves < B) ai_load_x<D>(x, b + nwaves, F, n, q, xa);      // next row's operand flies under the dX product
-        if (dX) {
+        if (dX || WG) {
             // the residual block of the slab becomes d(pre-activation of R) = dZ * (R > 0): the slab row is now dY
             if (NP == 4) {
 #pragma unroll
@@ -543,6 +674,28 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
                 }
             }
             ai_fence();
+        }
+        if (WG) {
+#pragma unroll
+            for (int s = 0; s < WSTEPS; ++s) {
+                const float* yr = ys + (4 * s + q) * C::YS + n;
+#pragma unroll
+                for (int ct = 0; ct < WT; ++ct) {
+                    if (16 * ct >= M) break;
+                    const float dv_ = yr[16 * ct];
+#pragma unroll
+                    for (int T = 0; T < D / 16; ++T)
+                        wacc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[T][s], dv_, wacc[T][ct], 0, 0, 0);
+                }
+            }
+        }
+        if (WG) {
+            for (int i = 0; i < F; ++i) {
+                bacc[0] += ys[i * C::YS + lane];
+                if (64 + lane < M) bacc[1] += ys[i * C::YS + 64 + lane];
+            }
+        }
+        if (dX) {
             // dX[i][k] = sum_m dY[i][m] W[k][m]; the contraction index is permuted so that a lane's m are contiguous
             // (m = (M/4) q + t): A and B operands are 16-byte LDS reads
             ai_f4 dx[2][D / 16];
@@ -584,6 +737,89 @@ __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x
         }
         ai_fence();
     }
+    if (WG) {
+        // the eight waves' accumulators -> their slabs ([D][YS]: row d, column m), summed by the whole block
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < WT; ++ct) {
+            if (16 * ct >= M) break;
+#pragma unroll
+            for (int T = 0; T < D / 16; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ys[(16 * T + 4 * q + r) * C::YS + 16 * ct + n] = wacc[T][ct][r];
+        }
+        __syncthreads();
+        float* out = wpart + (int64_t)blockIdx.x * (D * M + M);
+        constexpr int SLAB = 32 * C::YS + 96;
+        const float* s0 = lds + D * WS;
+        for (int e = threadIdx.x; e < D * M; e += blockDim.x) {
+            const int d = e / M, m = e - d * M;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s0[w * SLAB + d * C::YS + m];
+            out[e] = v;
+        }
+        __syncthreads();
+        // bias partials: every wave leaves its column sums in row 0 of its slab
+        ys[lane] = bacc[0];
+        ys[64 + lane] = bacc[1];
+        __syncthreads();
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s0[w * SLAB + m];
+            out[D * M + m] = v;
+        }
+    }
+}
+
+template <int D, int DH, bool DROP>
+__global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
+                                                     const float* __restrict__ g, int B, int F, int NP,
+                                                     float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
+                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
+    ai_bwd_body<D, DH, false, DROP>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr);
+}
+template <int D, int DH, bool DROP>
+__global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
+                                                       const float* __restrict__ g, int B, int F, int NP,
+                                                       float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
+                                                       unsigned seed, float* __restrict__ wpart) {
+    ai_bwd_body<D, DH, true, DROP>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart);
+}
+
+// sum of the per-block partials -> the gradients of the NP Keras kernels [NP][D][D] (gW[p][k][j] = dWc[k][p D + j]) and
+// biases [NP][D]; nparts <= 256
+__global__ __launch_bounds__(1024) void k_autoint_wgrad_reduce(const float* __restrict__ wpart, int nparts, int D, int M,
+                                                               float* __restrict__ gW, float* __restrict__ gb) {
+    // a block owns 64 consecutive elements (coalesced 256-byte reads of every partial); its 16 waves split the partials
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = D * M + M;
+    const int e = blockIdx.x * 64 + lane;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int p = wave + 16 * u;
+        v[u] = (e < total && p < nparts) ? wpart[(int64_t)p * total + e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+        for (int w = 0; w < u; ++w) v[w] += v[w + u];
+    red[wave][lane] = v[0];
+    __syncthreads();
+    if (wave == 0 && e < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        if (e < D * M) {
+            const int k = e / M, m = e - k * M;
+            gW[((int64_t)(m / D) * D + k) * D + (m % D)] = t;
+        } else {
+            gb[e - D * M] = t;
+        }
+    }
 }
 
 }  // namespace dt
@@ -600,28 +836,29 @@ extern "C" unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned 
     return ai_hash(seed, b, h, i, j);
 }
 
+// the attention-weight dropout is a compile-time variant (DROP): with rate 0 the per-element mask code and its 32 branches
+// per head are not in the kernel at all
+#define DT_AI_LAUNCH(KERNEL, DV, HV, WAVES, ...)                                                                           \
+    do {                                                                                                                   \
+        if (thr) {                                                                                                         \
+            hipFuncSetAttribute((const void*)KERNEL<DV, HV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+            hipLaunchKernelGGL((KERNEL<DV, HV, true>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);             \
+        } else {                                                                                                           \
+            hipFuncSetAttribute((const void*)KERNEL<DV, HV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((KERNEL<DV, HV, false>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);            \
+        }                                                                                                                  \
+    } while (0)
 #define DT_AI_DISPATCH(KERNEL, WAVES, LDS_FLOATS, ...)                                                             \
     do {                                                                                                           \
         const int dh = D / H;                                                                                      \
         int blocks = (int)((B + (WAVES) - 1) / (WAVES));                                                           \
         if (blocks > 2048 / (WAVES)) blocks = 2048 / (WAVES);                                                      \
         const size_t lds = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
-        if (D == 32 && dh == 8) {                                                                                  \
-            hipFuncSetAttribute((const void*)KERNEL<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((KERNEL<32, 8>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
-        } else if (D == 32 && dh == 16) {                                                                          \
-            hipFuncSetAttribute((const void*)KERNEL<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
-            hipLaunchKernelGGL((KERNEL<32, 16>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                   \
-        } else if (D == 16 && dh == 4) {                                                                           \
-            hipFuncSetAttribute((const void*)KERNEL<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((KERNEL<16, 4>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
-        } else if (D == 16 && dh == 8) {                                                                           \
-            hipFuncSetAttribute((const void*)KERNEL<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((KERNEL<16, 8>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                    \
-        } else {                                                                                                   \
-            hipFuncSetAttribute((const void*)KERNEL<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
-            hipLaunchKernelGGL((KERNEL<16, 16>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);                   \
-        }                                                                                                          \
+        if (D == 32 && dh == 8) DT_AI_LAUNCH(KERNEL, 32, 8, WAVES, __VA_ARGS__);                                   \
+        else if (D == 32 && dh == 16) DT_AI_LAUNCH(KERNEL, 32, 16, WAVES, __VA_ARGS__);                            \
+        else if (D == 16 && dh == 4) DT_AI_LAUNCH(KERNEL, 16, 4, WAVES, __VA_ARGS__);                              \
+        else if (D == 16 && dh == 8) DT_AI_LAUNCH(KERNEL, 16, 8, WAVES, __VA_ARGS__);                              \
+        else DT_AI_LAUNCH(KERNEL, 16, 16, WAVES, __VA_ARGS__);                                                     \
     } while (0)
 
 static bool ai_drop(float rate, unsigned* thr, float* inv_keep) {
@@ -658,7 +895,8 @@ extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, 
     unsigned thr; float inv_keep;
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_fwd: dropout_rate %f", dropout_rate);
     hipStream_t st = as_stream(stream);
-    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed);
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
+                   (const float*)nullptr, (float*)nullptr);
     return launch_status("dt_autoint_fwd");
 }
 
@@ -683,4 +921,93 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
     DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, w4, a, g, (int)B, F, NP, dY,
                    dX, bn, thr, inv_keep, seed);
     return launch_status("dt_autoint_bwd");
+}
+
+// dt_autoint_bwd with the four Dense layers' kernel / bias gradients formed inside the same launch (+ one small reduction):
+// replaces dt_autoint_bwd(dY) + dt_dense_bwd(x, dY).  gW [NP][D][D], gb [NP][D] (NP = 3 or 4: q | k | v [| residual]) are
+// OVERWRITTEN; workspace: dt_autoint_bwd_workspace_bytes(B, D) bytes.  dX may be NULL (input without gradient).
+extern "C" int64_t dt_autoint_bwd_workspace_bytes(int64_t B, int D) {
+    int64_t blocks = (B + 7) / 8;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    return blocks * (int64_t)(D * 4 * D + 4 * D) * (int64_t)sizeof(float);
+}
+
+extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
+                                const float* bq, const float* bk, const float* bv, const float* br, const float* a,
+                                const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
+                                const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
+                                float* dX, float* gW, float* gb, void* workspace, void* stream) {
+    DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
+    DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
+    DT_REQUIRE(gW && gb && workspace, "dt_autoint_bwd_w: null gradient / workspace pointer");
+    const int NP = Wr ? 4 : 3;
+    const int M = NP * D;
+    hipStream_t st = as_stream(stream);
+    if (B == 0) {
+        hipMemsetAsync(gW, 0, sizeof(float) * D * M, st);
+        hipMemsetAsync(gb, 0, sizeof(float) * M, st);
+        return launch_status("dt_autoint_bwd_w");
+    }
+    DT_REQUIRE(x && a && g && B > 0 && B < (1LL << 31), "dt_autoint_bwd_w: null pointer / bad batch");
+    const float* Ws[4] = {Wq, Wk, Wv, Wr};
+    const float* bs[4] = {bq, bk, bv, br};
+    AiW w4;
+    DT_REQUIRE(ai_weights(Ws, bs, NP, &w4), "dt_autoint_bwd_w: null weight pointer");
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_bwd_w: dropout_rate %f", dropout_rate);
+    DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd_w: incomplete BatchNormalization arguments");
+    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
+    float* wpart = static_cast<float*>(workspace);
+    DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, w4, a, g, (int)B, F, NP,
+                   dX, bn, thr, inv_keep, seed, wpart);
+    int nparts = (int)((B + 7) / 8);
+    if (nparts > 256) nparts = 256;
+    const int total = D * M + M;
+    hipLaunchKernelGGL(k_autoint_wgrad_reduce, dim3((total + 63) / 64), dim3(1024), 0, st, wpart, nparts, D, M, gW, gb);
+    return launch_status("dt_autoint_bwd_w");
+}
+
+// dt_autoint_fwd followed by the layer's training-mode BatchNormalization (layers.py:151) in TWO launches instead of four:
+// the statistics are block sums written by the attention kernel's epilogue, the second launch finishes them in its
+// prologue and normalises.  out_a = relu(attention + residual) (kept for the backward), out_y = BN(out_a); save_mean /
+// save_rstd [D] for dt_autoint_bwd*; moving_mean / moving_var updated as dt_bn_train_fwd does.
+// workspace: dt_autoint_fwd_bn_workspace_bytes(B, D) bytes.
+extern "C" int64_t dt_autoint_fwd_bn_workspace_bytes(int64_t B, int D) {
+    int64_t blocks = (B + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return (int64_t)sizeof(float) * (D + blocks * 2 * D);
+}
+
+extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
+                                 const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
+                                 int D, int H, float dropout_rate, unsigned seed, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* moving_mean, float* moving_var, float* out_a,
+                                 float* out_y, float* save_mean, float* save_rstd, void* workspace, void* stream) {
+    DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd_bn: unsupported shape F=%d D=%d H=%d", F, D, H);
+    DT_REQUIRE(x && out_a && out_y && save_mean && save_rstd && workspace && B > 0 && B < (1LL << 31),
+               "dt_autoint_fwd_bn: null pointer / bad batch");
+    const int NP = Wr ? 4 : 3;
+    const float* Ws[4] = {Wq, Wk, Wv, Wr};
+    const float* bs[4] = {bq, bk, bv, br};
+    AiW w4;
+    DT_REQUIRE(ai_weights(Ws, bs, NP, &w4), "dt_autoint_fwd_bn: null weight pointer");
+    unsigned thr; float inv_keep;
+    DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_fwd_bn: dropout_rate %f", dropout_rate);
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    float* lse = nullptr;
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
+                   (const float*)moving_mean, part);
+    int nparts = (int)((B + 3) / 4);
+    if (nparts > 512) nparts = 512;
+    const int64_t total4 = B * F * (D / 4);
+    DT_REQUIRE(total4 < (1LL << 31), "dt_autoint_fwd_bn: tensor too large");
+    int blocks = (int)((total4 + 1023) / 1024);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_autoint_bn_apply, dim3(blocks), dim3(1024), 0, st, out_a, (int)total4, D, part, nparts,
+                       1.0f / ((float)B * (float)F), gamma, beta, eps, momentum, moving_mean, moving_var, save_mean,
+                       save_rstd, out_y);
+    return launch_status("dt_autoint_fwd_bn");
 }

@@ -575,6 +575,19 @@ def autoint_dropout_keep(seed, B, H, F, rate, device='cpu'):
     return (x >= thr).to(torch.float32) / (1.0 - float(rate))
 
 
+_AUTOINT_WS = {}
+
+
+def _autoint_ws(B, D, device, nbytes=None, tag='w'):
+    """per-block partials of dt_autoint_bwd_w / dt_autoint_fwd_bn (one buffer per (kind, size, device): launches are
+    stream-ordered, and a partial buffer is consumed by the launch that follows its producer)"""
+    n = int(lib().dt_autoint_bwd_workspace_bytes(int(B), int(D))) if nbytes is None else int(nbytes)
+    key = (tag, n, str(device))
+    if key not in _AUTOINT_WS:
+        _AUTOINT_WS[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
+    return _AUTOINT_WS[key]
+
+
 class _AutoIntLayer(torch.autograd.Function):
     """forward(x, num_heads, dropout_rate, seed, bn, *wb): wb = Wq, Wk, Wv[, Wr], bq, bk, bv[, br] (the Keras variables,
     never concatenated).  bn = None -> returns a = relu(attention + residual); bn = (gamma, beta, moving_mean,
@@ -590,6 +603,22 @@ class _AutoIntLayer(torch.autograd.Function):
         Ws, bs = wb[:NP] + [None] * (4 - NP), wb[NP:] + [None] * (4 - NP)
         B, F, D = x.shape
         a = torch.empty_like(x)
+        if bn is not None and B > 0 and os.environ.get('DT_AMD_AUTOINT_BN', 'fused') != 'separate':
+            # attention + BatchNormalization in two launches: the statistics ride in the attention kernel's epilogue
+            moving_mean, moving_var, eps, momentum = bn
+            y = torch.empty_like(a)
+            mean = torch.empty((D,), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((D,), dtype=torch.float32, device=x.device)
+            n = int(lib().dt_autoint_fwd_bn_workspace_bytes(B, D))
+            ws = _autoint_ws(0, D, x.device, nbytes=n, tag='bn')
+            check(lib().dt_autoint_fwd_bn(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
+                                          float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(gamma), ptr(beta), float(eps),
+                                          float(momentum), ptr(moving_mean), ptr(moving_var), ptr(a), ptr(y), ptr(mean),
+                                          ptr(rstd), ptr(ws), stream_ptr()), 'dt_autoint_fwd_bn')
+            ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, True)
+            ctx.save_for_backward(x, a, *wb, mean, rstd, *([gamma] if gamma is not None else []))
+            ctx.has_affine = (gamma is not None, beta is not None)
+            return y
         check(lib().dt_autoint_fwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
                                    float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, stream_ptr()),
               'dt_autoint_fwd')
@@ -632,6 +661,18 @@ class _AutoIntLayer(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty_like(x) if need_x else None
         M = NP * D
+        if F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense':
+            # the kernel / bias gradients are accumulated inside the layer's backward launch (csrc/autoint.hip WG): the
+            # pre-activation gradients dY [B*F, NP*D] never reach HBM and no Dense weight-gradient launch follows
+            gWs = torch.empty((NP, D, D), dtype=torch.float32, device=x.device)
+            gbs = torch.empty((NP, D), dtype=torch.float32, device=x.device)
+            wsw = _autoint_ws(B, D, x.device)
+            check(lib().dt_autoint_bwd_w(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
+                                         rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(gx), ptr(gWs),
+                                         ptr(gbs), ptr(wsw), stream_ptr()), 'dt_autoint_bwd_w')
+            return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
+                    gbeta if has_bn and ctx.has_affine[1] else None, *[gWs[i] for i in range(NP)],
+                    *[gbs[i] for i in range(NP)])
         dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
         check(lib().dt_autoint_bwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                    rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dY), ptr(gx),

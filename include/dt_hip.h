@@ -326,6 +326,28 @@ int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float
                    const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                    int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
                    const float* bn_rstd, const float* bn_sums, float* dY, float* dX, void* stream);
+/* dt_autoint_fwd_bn — dt_autoint_fwd followed by the layer's training-mode BatchNormalization (layers.py:151) in two
+ * launches instead of four: the attention kernel's epilogue leaves per-block sums of (a - moving_mean) and its square, the
+ * second launch adds them up in its prologue, normalises (out_y = BN(out_a)), writes save_mean / save_rstd [D] for the
+ * backward and moves moving_mean / moving_var (Keras: moving = moving * momentum + batch * (1 - momentum), biased batch
+ * variance).  workspace: dt_autoint_fwd_bn_workspace_bytes(B, D) bytes. */
+int64_t dt_autoint_fwd_bn_workspace_bytes(int64_t B, int D);
+int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
+                      const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
+                      float dropout_rate, unsigned seed, const float* gamma, const float* beta, float eps, float momentum,
+                      float* moving_mean, float* moving_var, float* out_a, float* out_y, float* save_mean,
+                      float* save_rstd, void* workspace, void* stream);
+/* dt_autoint_bwd_w — the same backward with the kernel / bias gradients of dense_Q | dense_K | dense_V [| dense_residual]
+ * (layers.py:104-108; in the reference: four MatMul + BiasAddGrad ops over [B*F, D]) accumulated inside the launch from the
+ * pre-activation gradients while they are in LDS, plus one small reduction launch: dY never reaches HBM and no
+ * dt_dense_bwd follows.  gW [NP][D][D] (the Keras kernels' layout, one after the other), gb [NP][D]: OVERWRITTEN.
+ * F <= 28.  workspace: dt_autoint_bwd_workspace_bytes(B, D) bytes (per-block partials). */
+int64_t dt_autoint_bwd_workspace_bytes(int64_t B, int D);
+int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
+                     const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
+                     int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
+                     const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
+                     void* stream);
 
 /* ---- model-parallel tables: owner-side gather (parallel.ShardedEmbeddingStrategy; the role the sharded
  *      embedding_lookup of a parameter-server strategy plays) ------------------------------------------- *

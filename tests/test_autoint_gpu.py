@@ -29,7 +29,9 @@ def reference(x, Wcat, bcat, H, use_residual, keep=None):
 @pytest.mark.parametrize('B,F,D,H,res,rate', [(5, 26, 32, 4, True, 0.0), (64, 26, 32, 4, True, 0.0),
                                               (33, 7, 16, 2, True, 0.0), (17, 32, 16, 4, False, 0.0),
                                               (9, 1, 16, 1, True, 0.0), (40, 26, 32, 2, True, 0.0),
-                                              (31, 26, 32, 4, True, 0.3), (12, 13, 16, 4, False, 0.5)])
+                                              (31, 26, 32, 4, True, 0.3), (12, 13, 16, 4, False, 0.5),
+                                              (2100, 26, 32, 4, True, 0.0), (300, 28, 16, 2, True, 0.2),
+                                              (2500, 27, 32, 2, False, 0.0)])
 def test_autoint_layer_matches_float64_reference(dev, B, F, D, H, res, rate):
     from deeptables_amd import ops
     g = torch.Generator().manual_seed(B * 131 + F)
@@ -90,12 +92,13 @@ def test_layer_with_dropout_trains_and_is_identity_at_inference(dev):
     assert torch.equal(y1, y2)
 
 
-def test_layer_with_fused_batchnorm_backward_equals_separate_kernels(dev):
-    """training mode: BN(a) with the BN backward folded into the layer's backward kernel == autoint_layer followed by
-    ops.batchnorm_train (bn.hip's three-kernel backward)"""
+@pytest.mark.parametrize('B,F,D,H', [(48, 26, 32, 4), (2500, 26, 32, 4), (700, 13, 16, 2), (3, 1, 16, 1)])
+def test_layer_with_fused_batchnorm_backward_equals_separate_kernels(dev, B, F, D, H):
+    """training mode: BN(a) with its statistics formed in the attention kernel's epilogue (dt_autoint_fwd_bn) and the BN
+    backward folded into the layer's backward kernel == autoint_layer followed by ops.batchnorm_train (bn.hip's
+    three-kernel forward and backward); the moving statistics start away from 0 / 1 (they are the kernel's shift)"""
     from deeptables_amd import ops
     g = torch.Generator().manual_seed(5)
-    B, F, D, H = 48, 26, 32, 4
     x = (torch.randn(B, F, D, generator=g) * 0.6).to(dev)
     Ws = [(torch.randn(D, D, generator=g) * 0.25).to(dev) for _ in range(4)]
     bs = [(torch.randn(D, generator=g) * 0.1).to(dev) for _ in range(4)]
@@ -106,7 +109,7 @@ def test_layer_with_fused_batchnorm_backward_equals_separate_kernels(dev):
     for fused in (True, False):
         leaves = [t.clone().requires_grad_(True) for t in [x] + Ws + bs + [gamma, beta]]
         xx, W4, b4, ga, be = leaves[0], leaves[1:5], leaves[5:9], leaves[9], leaves[10]
-        mm, mv = torch.zeros(D, device=dev), torch.ones(D, device=dev)
+        mm, mv = torch.full((D,), 0.3, device=dev), torch.full((D,), 0.7, device=dev)
         if fused:
             y = ops.autoint_layer(xx, W4, b4, H, 0.0, 0, batch_norm=(ga, be, mm, mv, 1e-3, 0.99))
         else:
