@@ -359,6 +359,30 @@ __global__ __launch_bounds__(256) void k_bce_logits(const float* __restrict__ z,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n);
 }
+// the same as ONE workgroup (n <= 32 K: a minibatch's logits): the loss is stored, not accumulated — no zero-fill node ahead
+// of the launch, no atomics, a fixed summation order
+__global__ __launch_bounds__(1024) void k_bce_logits_one(const float* __restrict__ z, const float* __restrict__ y, int n,
+                                                         float* __restrict__ loss, float* __restrict__ dz) {
+    __shared__ float red[16];
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float zi = z[i], yi = y[i];
+        const float e = expf(-fabsf(zi));
+        acc += fmaxf(zi, 0.f) - zi * yi + log1pf(e);
+        const float sig = zi >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        dz[i] = (sig - yi) * inv_n;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = t * inv_n;
+    }
+}
 
 // ---- SGD (keras.optimizers.SGD, momentum 0): p -= lr * g; duplicates of a row simply add up ----------------
 __global__ __launch_bounds__(256) void k_sgd_dense(float* __restrict__ p, const float* __restrict__ g, int64_t n,
@@ -545,6 +569,10 @@ extern "C" int dt_rows_compact(const int64_t* rows, const float* values, int64_t
 extern "C" int dt_bce_logits(const float* z, const float* y, int64_t n, float* loss, float* dz, void* stream) {
     DT_REQUIRE(n > 0 && z && y && loss && dz, "dt_bce_logits: bad arguments");
     hipStream_t st = as_stream(stream);
+    if (n <= 32768) {
+        hipLaunchKernelGGL(k_bce_logits_one, dim3(1), dim3(1024), 0, st, z, y, (int)n, loss, dz);
+        return launch_status("dt_bce_logits");
+    }
     hipMemsetAsync(loss, 0, sizeof(float), st);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;

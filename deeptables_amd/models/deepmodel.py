@@ -282,7 +282,10 @@ class DeepModel:
         logit = self.model(inputs)
         loss = self._loss(logit, y) if sample_weight is None else \
             training.weighted_loss(self.loss_name, logit, y, sample_weight)
-        loss.backward()
+        if loss.dim() == 0 and loss.dtype == torch.float32:
+            loss.backward(training.unit_grad(loss.device))      # no ones-fill launch (and the BCE skips the multiply)
+        else:
+            loss.backward()
         return loss.detach(), logit.detach()
 
     def train_step(self, inputs, y, sample_weight=None):

@@ -16,6 +16,23 @@ from .utils import consts
 # ---------------------------------------------------------------------------------------------
 # losses (keras.losses.* selected by DeepModel.__compile_model, deepmodel.py:324-338)
 # ---------------------------------------------------------------------------------------------
+_UNIT_GRAD = {}
+
+
+def unit_grad(device):
+    """the constant 1.0 `loss.backward()` would allocate and fill at every step: a cached 0-dim tensor per device.  A loss
+    function that sees it as its incoming gradient (same storage) skips the multiplication by it."""
+    key = str(device)
+    if key not in _UNIT_GRAD:
+        _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT_GRAD[key]
+
+
+def _is_unit_grad(g):
+    u = _UNIT_GRAD.get(str(g.device))
+    return u is not None and g.dim() == 0 and g.data_ptr() == u.data_ptr()
+
+
 class _BceFromLogits(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, y):
@@ -29,7 +46,7 @@ class _BceFromLogits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        return dz * g, None
+        return (dz if _is_unit_grad(g) else dz * g), None
 
 
 def bce_from_logits(logit, y):
