@@ -2276,7 +2276,12 @@ static int tower_train_step(
     const DeepFmAccum al = deepfm_accum_layout(dm.C, dm.CP, F, Nd, Lc);
     float* ws = reinterpret_cast<float*>(workspace);
     const int mse = (phases & DT_STEP_LOSS_MSE) ? 1 : 0;
+    // DT_STEP_SKIP_FINISH / DT_STEP_FINISH_ONLY: the pipelined backward step without / as only its last launch (E': the dense
+    // gradients' last level), so that a caller whose row gradients leave through a collective (row-owned tables) can start
+    // that collective behind the row-gradient launch and let E' run beside it
+    const bool skip_finish = (phases & DT_STEP_SKIP_FINISH) != 0, finish_only = (phases & DT_STEP_FINISH_ONLY) != 0;
     phases &= 0xf;
+    DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
     static const int wt_env_c = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;
     const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, (wt_env_c >> 1) & 1, sample_weight};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
@@ -2332,6 +2337,22 @@ static int tower_train_step(
     // the pipelined launch sequence (DeepFM backward steps; DT_STEP_PIPE=0 keeps round 2's A B C E E' D): A B C+dXn R [E|D+Adam] E'
     static const bool pipe_env = !(getenv("DT_STEP_PIPE") && atoi(getenv("DT_STEP_PIPE")) == 0);
     const bool pipe = phases >= 2 && (pipe_env || adam);
+    DT_REQUIRE(!(skip_finish || finish_only) || (pipe && !adam),
+               "dt_deepfm_train_step: DT_STEP_SKIP_FINISH / DT_STEP_FINISH_ONLY belong to the pipelined backward step without "
+               "the in-step optimizer");
+    auto wgrad_row_blocks = [&]() {      // batch slices of the weight-gradient launch: one 512-thread block per CU
+        const int nmac = (dm.CP >> 6) + 1;
+        int rb = 256 / nmac;
+        if (rb >= 8) rb &= ~7;
+        while (rb > 1 && (B + rb - 1) / rb < 64) rb >>= 1;
+        return rb < 1 ? 1 : rb;
+    };
+    if (finish_only) {
+        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
+                           accum, al, ws + wl.wpart, wgrad_row_blocks(), Lc, cross_w, cross_b, w3, 1);
+        if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
+        return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
+    }
     DT_REQUIRE(!adam || (pipe && dd.rows_fm && !grad_rows_field_major),
                "dt_deepfm_train_step_adam: the in-step row update needs a backward step with the in-step dedupe (dedupe_ws) "
                "and row-major row gradients");
@@ -2404,10 +2425,7 @@ static int tower_train_step(
                            pr);
         // E + D: one 512-thread block per CU (see k_wgrad_rows)
         const int nmac = (dm.CP >> 6) + 1;
-        int row_blocks = 256 / nmac;
-        if (row_blocks >= 8) row_blocks &= ~7;
-        while (row_blocks > 1 && (B + row_blocks - 1) / row_blocks < 64) row_blocks >>= 1;
-        if (row_blocks < 1) row_blocks = 1;
+        const int row_blocks = wgrad_row_blocks();
         const int rows_per_block = ((B + row_blocks - 1) / row_blocks + 7) & ~7;
         const size_t ldsE = (size_t)4 * 8192 * sizeof(float);
         const RowsEpi ep{ws + wl.dXn, ws + wl.X, ws + wl.dz, ws + wl.S, w_lin, ws + wl.sc, ws + wl.mean, ws + wl.cm1,
@@ -2449,12 +2467,13 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
                                dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3);
-        } else {
+        } else if (!skip_finish) {
             // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
                                accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);
         }
-        if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
+        if ((drop.thr || drop.thr_dense) && !skip_finish)
+            hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else if (phases >= 2) {
         // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
         const int nmac = (dm.CP >> 6) + 1;

@@ -267,8 +267,19 @@ class FusedDeepFM:
         can capture the kernels between the collectives into hipGraphs (bench.py): `sharded_pre` (collectives + the
         owner's gather, eager), `sharded_core` (the step's kernels: capturable), `sharded_post` (collective, eager)."""
         self.sharded_pre(idx, st)
-        out = self.sharded_core(idx.shape[0], dense, y, st, sample_weight)
-        self.sharded_post(idx.shape[0], st)
+        if os.environ.get('DT_AMD_SHARDED_OVERLAP', '0') != '1':
+            out = self.sharded_core(idx.shape[0], dense, y, st, sample_weight)
+            self.sharded_post(idx.shape[0], st)
+            return out
+        # opt-in (DT_AMD_SHARDED_OVERLAP=1): the row gradients are final one launch before the step is, so their all-to-all
+        # can start there and the step's last launch (the dense gradients' last level, ~7 us) run beside it.  Measured at
+        # world size 1 through RCCL (gpurun_out/r3c23): 214 us against 171 us for the plain order — the two stream
+        # hand-overs cost more than the launch they hide — so the plain order is the default.
+        out = self.sharded_core(idx.shape[0], dense, y, st, sample_weight, part=_lib.DT_STEP_SKIP_FINISH)
+        work = self.sharded_post(idx.shape[0], st, async_op=True)
+        self.sharded_core(idx.shape[0], dense, y, st, sample_weight, part=_lib.DT_STEP_FINISH_ONLY)
+        if work is not None:
+            work.wait()               # stream-ordered: the launches that follow (the owner's row update) see the received rows
         return out
 
     def sharded_pre(self, idx, st):
@@ -287,7 +298,7 @@ class FusedDeepFM:
               'dt_embedding_gather_owned')
         st.forward_exchange(sb['emb_own'].view(W, Fo, B, D), F, B, out=sb['emb_T'])
 
-    def sharded_core(self, B, dense, y, st, sample_weight=None):
+    def sharded_core(self, B, dense, y, st, sample_weight=None, part=0):
         """the fused step's launches on the received rows (no collective inside: a hipGraph can hold them)"""
         F, D, W = self.F, self.D, st.world_size
         buf = self._buffers(B)
@@ -303,7 +314,7 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 1.0 / W, 1, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+            None, None, 0, 1.0 / W, 1, 2 | part | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
             self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()),
             'dt_deepfm_train_step')
         for p, g in self.grad_views:
@@ -311,14 +322,18 @@ class FusedDeepFM:
         self.dm.model._dt_sharded_step = True
         return self.loss_view, buf['logit']
 
-    def sharded_post(self, B, st):
+    def sharded_post(self, B, st, async_op=False):
         # the loss is a mean over the LOCAL minibatch, the global objective the mean over W of them: the step already
         # wrote the row gradients field-major [F,B,D] and divided by W
         F, D = self.F, self.D
         buf = self._buffers(B)
         sb = self._sharded_buffers(B, st)
-        grad_own = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'])
+        if async_op:
+            grad_own, work = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own'], async_op=True)
+        else:
+            grad_own, work = st.backward_exchange(buf['grad_rows'].view(F, B, D), F, B, out=sb['grad_own']), None
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
+        return work
 
     def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None):
         """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter

@@ -248,6 +248,17 @@ class DataParallelStrategy:
             flat.div_(self.world_size)
 
 
+class _StreamWork:
+    """what an asynchronous exchange hands back when it ran as plain launches on a side stream"""
+
+    def __init__(self, stream, device):
+        self.stream, self.device = stream, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return True
+
+
 class ShardedEmbeddingStrategy(DataParallelStrategy):
     """Dense layers data-parallel, embedding ROWS owned by one rank each (model-parallel tables).
 
@@ -290,17 +301,25 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
         return out
 
     # -- collectives (all_to_all_single where the backend has it; gloo: all_gather + slice) -----------
-    def _all_to_all(self, out, inp, out_splits, in_splits):
+    def _all_to_all(self, out, inp, out_splits, in_splits, async_op=False):
+        """async_op: returns a handle whose .wait() orders the CURRENT stream behind the exchange (RCCL: the collective's own
+        stream; world size 1: the copy on a side stream), or None when the exchange was synchronous"""
         W = self.world_size
         if W == 1:
+            if async_op and out.is_cuda:
+                side = self._side_stream(out.device)
+                side.wait_stream(torch.cuda.current_stream(out.device))
+                with torch.cuda.stream(side):
+                    out.copy_(inp)
+                return _StreamWork(side, out.device)
             out.copy_(inp)
-            return
+            return None
         if self._a2a_ok is None:
             self._a2a_ok = dist.get_backend(self.group) != 'gloo'
         if self._a2a_ok:
-            dist.all_to_all_single(out, inp, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
-                                   group=self.group)
-            return
+            work = dist.all_to_all_single(out, inp, output_split_sizes=list(out_splits),
+                                          input_split_sizes=list(in_splits), group=self.group, async_op=bool(async_op))
+            return work if async_op else None
         # gloo has no all_to_all: everybody gathers everybody's (padded) input and cuts its piece out
         n = torch.tensor([inp.shape[0]], dtype=torch.int64)
         sizes = [torch.zeros_like(n) for _ in range(W)]
@@ -354,17 +373,24 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
                          [Fo * B] * self.world_size)
         return out.view(F, B, D)
 
-    def backward_exchange(self, grad_T, F, B, out=None):
-        """grad_T [F, B, D] (gradient of the local loss w.r.t. the received rows) -> [W, F_own, B, D] at the owner."""
+    def _side_stream(self, device):
+        s = getattr(self, '_side', None)
+        if s is None:
+            s = self._side = torch.cuda.Stream(device=device)
+        return s
+
+    def backward_exchange(self, grad_T, F, B, out=None, async_op=False):
+        """grad_T [F, B, D] (gradient of the local loss w.r.t. the received rows) -> [W, F_own, B, D] at the owner.
+        async_op=True -> (out, handle or None): the caller issues more launches, then handle.wait()."""
         D = grad_T.shape[-1]
         bounds = self.field_bounds(F)
         Fo = bounds[self.rank][1] - bounds[self.rank][0]
         W = self.world_size
         if out is None:
             out = torch.empty((W * Fo * B, D), dtype=grad_T.dtype, device=grad_T.device)
-        self._all_to_all(out.view(W * Fo * B, D), grad_T.reshape(F * B, D), [Fo * B] * W,
-                         [(e - s) * B for s, e in bounds])
-        return out.view(W, Fo, B, D)
+        work = self._all_to_all(out.view(W * Fo * B, D), grad_T.reshape(F * B, D), [Fo * B] * W,
+                                [(e - s) * B for s, e in bounds], async_op=async_op)
+        return (out.view(W, Fo, B, D), work) if async_op else out.view(W, Fo, B, D)
 
     def sync_tables(self, emb_layer):
         """Make every rank's copy of the packed tables whole again: each owner broadcasts its fields' rows."""

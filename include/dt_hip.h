@@ -412,8 +412,14 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * then the number of regions and their capacity) say which grad_rows entries to sum for which row.
  * dt_adam_rows_step_seg consumes exactly that (fields = -1: no dedupe pass).
  * grad_rows_field_major != 0 (model-parallel tables, no dedupe_ws): grad_rows is written as [F,B,D] and multiplied
- * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.                              */
+ * by grad_rows_scale (1/world size), ready for the all-to-all back to the row owners.
+ * phases | DT_STEP_SKIP_FINISH: a backward step without its LAST launch (the last level of the dense gradients): every
+ * row gradient is final when the call's launches are, so the collective that carries them to the row owners can start
+ * there; the same call with phases | DT_STEP_FINISH_ONLY (same arguments) then issues only that last launch, which runs
+ * beside the collective.  accum is complete after the second call.                                                  */
 #define DT_STEP_LOSS_MSE 0x10
+#define DT_STEP_SKIP_FINISH 0x20
+#define DT_STEP_FINISH_ONLY 0x40
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7_host);

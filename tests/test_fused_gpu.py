@@ -354,11 +354,15 @@ def test_fused_steps_take_narrower_towers(dev, tmp_path, net, H1, H2):
     assert (dm.model(ins) - twin.model(ins)).abs().max().item() < 1e-4
 
 
-def test_sharded_embedding_step_single_rank_equals_plain(dev):
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, monkeypatch):
     """ShardedEmbeddingStrategy(force=True) on ONE rank drives the whole model-parallel-table step (ids exchange,
     owner gather, all-to-all, fused kernels on the received rows, gradient all-to-all, owner Adam) through RCCL with
-    world size 1; after several train steps it must agree with the plain fused step."""
+    world size 1; after several train steps it must agree with the plain fused step.  overlap = 1 (opt-in): the gradient
+    all-to-all starts behind the row-gradient launch and the step's last launch runs beside it (DT_STEP_SKIP_FINISH /
+    DT_STEP_FINISH_ONLY); 0 (default): the step as one call, then the exchange."""
     import os
+    monkeypatch.setenv('DT_AMD_SHARDED_OVERLAP', overlap)
     import socket
     import torch.distributed as dist
     from deeptables_amd import functional
