@@ -366,12 +366,25 @@ __global__ __launch_bounds__(1024) void k_bce_logits_one(const float* __restrict
     __shared__ float red[16];
     const float inv_n = 1.0f / (float)n;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float zi = z[i], yi = y[i];
-        const float e = expf(-fabsf(zi));
-        acc += fmaxf(zi, 0.f) - zi * yi + log1pf(e);
-        const float sig = zi >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-        dz[i] = (sig - yi) * inv_n;
+    for (int base = 0; base < n; base += 8 * 1024) {        // eight independent loads of z and y in flight per thread
+        float zv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(base + u * 1024 + (int)threadIdx.x, n - 1);
+            zv[u] = z[i];
+            yv[u] = y[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 1024 + (int)threadIdx.x;
+            if (i < n) {
+                const float zi = zv[u], yi = yv[u];
+                const float e = expf(-fabsf(zi));
+                acc += fmaxf(zi, 0.f) - zi * yi + log1pf(e);
+                const float sig = zi >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                dz[i] = (sig - yi) * inv_n;
+            }
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

@@ -361,14 +361,23 @@ def rows_in_step_ok(res):
                 res['steps_counted'][0] == res['steps_counted'][1])
 
 
-def verdict(res, grad_tol=2e-4):
+def verdict(res, grad_tol=2e-4, bf16=False):
     """The acceptance rule bench.py's `parity` leg and tests/test_headline_gpu.py share.  Gather bit-exact, the same set of
     table rows, logits within north_star's 1e-4 (of max(1, max |logit|)), gradients within `grad_tol` of each tensor's
     largest entry.  Relu kinks: when the float64 oracle saw relu inputs within float32 rounding of zero
     (`relu_units_near_kink` > 0: |input| < 1e-6 of the layer's rms) the two precisions legitimately take different
     derivatives at those units, and each such unit moves one rank-1 term of a weight gradient (1 / sqrt(#rows) of a column
     of it).  Then — and only then — the gradients are judged by their relative L2 error (< 2e-3) with the largest single
-    entry within 5e-2; the figures are all reported."""
+    entry within 5e-2; the figures are all reported.
+    bf16=True (the opt-in bf16 CIN contractions, DT_AMD_CIN_DTYPE=bf16): north_star's bf16 bar — logits within 1e-2 — and
+    the gradients by their relative L2 error (< 2e-2, largest single entry within 1e-1): every CIN product was rounded to 8
+    mantissa bits on the way in."""
+    if bf16:
+        ok = bool(res['gather_bit_exact'] and res['rows_identical'] and
+                  res['max_abs_logit_err'] < 1e-2 * max(1.0, res['max_abs_logit']))
+        loose = (res['dense_grad_l2_rel_err'] < 2e-2 and res['rows_grad_l2_rel_err'] < 2e-2 and
+                 res['dense_grad_rel_err'] < 1e-1 and res['rows_grad_rel_err'] < 1e-1)
+        return ok and loose, 'bf16 (logits 1e-2; gradients L2 2e-2, max 1e-1)'
     ok = bool(res['gather_bit_exact'] and res['rows_identical'] and
               res['max_abs_logit_err'] < 1e-4 * max(1.0, res['max_abs_logit']))
     strict = res['dense_grad_rel_err'] < grad_tol and res['rows_grad_rel_err'] < grad_tol

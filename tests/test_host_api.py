@@ -302,16 +302,30 @@ def test_roofline_fraction_follows_from_the_committed_evidence():
     achieved = B * bpr / (rf['launch_us'] * 1e-6) / 1e9
     assert abs(achieved - rf['achieved']) / rf['achieved'] < 1e-6
     assert abs(rf['frac'] - achieved / 8000.0) < 1e-9 and rf['peak'] == 8000.0 and rf['bound'] == 'hbm'
-    # the step time against the kernel-trace summary of the same command: the kernels of one step sum to no more than the
-    # step, and to no less than 85 % of it (the rest: kernel boundaries + the replay's fixed cost)
+    # the step time against the kernel-trace summary of the same command: the kernels of one step sum to the step within
+    # -15 % (kernel boundaries + the replay's fixed cost are in the step, not in the sum) / +5 % (under the tracer every
+    # dispatch is timed on its own: with ten steps per replay the untraced step has almost no idle time left to absorb that)
     stats = {r['Name'].split('(')[0].replace('void ', ''): float(r['AverageNs']) / 1e3
              for r in csv.DictReader(open(os.path.join(root, 'profiles', 'r03_deepfm_kernel_stats.csv')))}
     step_kernels = [v for k, v in stats.items() if k.startswith('dt::k_') and 'state_init' not in k]
     assert len(step_kernels) == 6, sorted(stats)
-    assert 0.85 * rf['launch_us'] <= sum(step_kernels) <= 1.02 * rf['launch_us'], (sum(step_kernels), rf['launch_us'])
+    assert 0.85 * rf['launch_us'] <= sum(step_kernels) <= 1.05 * rf['launch_us'], (sum(step_kernels), rf['launch_us'])
     tj = json.load(open(os.path.join(root, 'profiles', 'deepfm_traffic.json')))
     if rf['traffic'] is not None:
         assert rf['traffic'] == tj['bytes_per_step_corrected']
     assert tj['algorithmic_bytes_per_step'] == int(B * (4 * F + 4 * ND + 8 + 12 * F * D) + 12 * n_dense) + B * 6 * 4 * F * D
     cal = tj['calibration']['kernels']
     assert 0.9 < cal['k_gather<2>']['fetch_factor'] < 1.1 and 0.45 < cal['k_copy 28 MB (16 B/lane stream)']['fetch_factor'] < 0.55
+
+
+def test_parity_verdict_uses_the_bf16_bar_only_in_bf16_mode():
+    """oracle/headline.verdict: the figures the bf16 CIN mode measured at bench size (gpurun_out/r03_line_xdeepfm_bf16,
+    round 3) pass north_star's bf16 bar (logits 1e-2) and fail the fp32 one; a wrong gather fails both"""
+    from oracle import headline
+    res = {'gather_bit_exact': True, 'rows_identical': True, 'max_abs_logit_err': 4.357e-05, 'max_abs_logit': 6.856,
+           'dense_grad_rel_err': 0.004838, 'dense_grad_l2_rel_err': 0.005716, 'rows_grad_rel_err': 0.0008991,
+           'rows_grad_l2_rel_err': 0.0001644, 'relu_units_near_kink': 45}
+    assert headline.verdict(res, bf16=True)[0] is True
+    assert headline.verdict(res)[0] is False
+    assert headline.verdict(dict(res, gather_bit_exact=False), bf16=True)[0] is False
+    assert headline.verdict(dict(res, max_abs_logit_err=0.2), bf16=True)[0] is False
