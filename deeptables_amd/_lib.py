@@ -56,6 +56,8 @@ SIGNATURES = {
     'dt_cin_layer_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_cin_bwd_workspace_bytes': (_c_i64, [_c_int] * 5),
+    'dt_cin_pool': (_c_int, [_ptr, _c_i64, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    'dt_cin_pool_bwd': (_c_int, [_ptr, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr, _ptr]),
     'dt_cin_layer_bwd_ws': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                      _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_cin_bf16_workspace_bytes': (_c_i64, [_c_int, _c_int, _c_int]),

@@ -548,6 +548,43 @@ __global__ __launch_bounds__(256) void k_cin_bias_grad(const float* __restrict__
     if ((threadIdx.x & 63) == 0) atomicAdd(&gbias[l], sacc);
 }
 
+// CIN `direct=False` bookkeeping of one layer output y [B,L,D] (layers.py:713-721): channels [half, L) leave the stack and only
+// their sum over D is ever used (tf.reduce_sum(result, -1), :726).  One thread per (b, l): D/4 16-byte loads of one row,
+// consecutive threads on consecutive rows (torch's reduce over the strided slice ran at 1 TB/s: 34 us per layer).
+__global__ __launch_bounds__(256) void k_cin_pool(const float* __restrict__ y, int64_t n, int L, int D, int half,
+                                                  float* __restrict__ pooled) {
+    const int LH = L - half, D4 = D >> 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / LH;
+        const int l = (int)(t - b * LH);
+        const cin_f4* p = reinterpret_cast<const cin_f4*>(y + (b * L + half + l) * (int64_t)D);
+        cin_f4 a = p[0];
+#pragma unroll 4
+        for (int i = 1; i < D4; ++i) a += p[i];
+        pooled[t] = (a.x + a.y) + (a.z + a.w);
+    }
+}
+// its backward: the layer's incoming gradient gy [B,L,D] assembled in ONE pass — channels < half from g_hidden [B,half,D] (NULL:
+// zero), the others the pooled gradient g_pooled [B,L-half] broadcast over D (NULL: zero).  One thread per float4 of gy.
+__global__ __launch_bounds__(256) void k_cin_pool_bwd(const float* __restrict__ g_hidden, const float* __restrict__ g_pooled,
+                                                      int64_t n4, int L, int D, int half, float* __restrict__ gy) {
+    const int D4 = D >> 2, LH = L - half;
+    const int64_t row4 = (int64_t)L * D4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / row4;
+        const int r = (int)(t - b * row4);
+        const int l = r / D4;
+        cin_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (l < half) {
+            if (g_hidden) v = reinterpret_cast<const cin_f4*>(g_hidden)[b * (int64_t)half * D4 + r];
+        } else if (g_pooled) {
+            const float g = g_pooled[b * LH + (l - half)];
+            v = cin_f4{g, g, g, g};
+        }
+        reinterpret_cast<cin_f4*>(gy)[t] = v;
+    }
+}
+
 }  // namespace dt
 
 using namespace dt;
@@ -691,4 +728,31 @@ static int cin_layer_bwd(const float* x0, const float* xk, const float* W, const
         hipLaunchKernelGGL(k_cin_bias_grad, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D,
                            grad_bias);
     return launch_status("dt_cin_layer_bwd(wgrad)");
+}
+
+// y [B,L,D] -> pooled [B, L-half] = sum_D y[:, half:, :]   (the CIN result channels of one layer; half = 0: all of them)
+extern "C" int dt_cin_pool(const float* y, int64_t B, int L, int D, int half, float* pooled, void* stream) {
+    DT_REQUIRE(B >= 0 && L > 0 && D > 0 && D % 4 == 0 && half >= 0 && half < L, "dt_cin_pool: bad sizes B=%lld L=%d D=%d half=%d",
+               (long long)B, L, D, half);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(y && pooled && ((uintptr_t)y % 16 == 0), "dt_cin_pool: null / unaligned pointer");
+    const int64_t n = B * (L - half);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_cin_pool, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), y, n, L, D, half, pooled);
+    return launch_status("dt_cin_pool");
+}
+
+// gy [B,L,D] = concat(g_hidden [B,half,D] or 0, broadcast_D(g_pooled [B,L-half]) or 0): the backward of the split + pool
+extern "C" int dt_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int64_t B, int L, int D, int half, float* gy,
+                               void* stream) {
+    DT_REQUIRE(B >= 0 && L > 0 && D > 0 && D % 4 == 0 && half >= 0 && half < L, "dt_cin_pool_bwd: bad sizes");
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(gy && ((uintptr_t)gy % 16 == 0) && ((uintptr_t)g_hidden % 16 == 0), "dt_cin_pool_bwd: null / unaligned pointer");
+    const int64_t n4 = B * L * (D / 4);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_cin_pool_bwd, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g_hidden, g_pooled, n4, L, D,
+                       half, gy);
+    return launch_status("dt_cin_pool_bwd");
 }

@@ -307,7 +307,7 @@ class CIN(Layer):
             elif idx != n - 1:
                 hidden, pooled = ops.cin_split_pool(curr_out, layer_size // 2)      # next layer's input (view) | pooled rest
             else:
-                hidden, pooled = None, torch.sum(curr_out, -1)
+                hidden, pooled = None, ops.cin_split_pool(curr_out, 0)[1]            # the last layer: every channel is pooled
             final_result.append(pooled)
         result = torch.cat(final_result, dim=1) if len(final_result) > 1 else final_result[0]
         if self.use_residual:

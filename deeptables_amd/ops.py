@@ -468,7 +468,13 @@ class _CinSplitPool(torch.autograd.Function):
     def forward(ctx, y, half):
         ctx.shape, ctx.half = tuple(y.shape), int(half)
         hidden = y[:, :half]
-        pooled = y[:, half:].sum(-1)
+        B, L, D = y.shape
+        ctx.hip = bool(y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and D % 4 == 0 and B > 0)
+        if ctx.hip:
+            pooled = torch.empty((B, L - half), dtype=torch.float32, device=y.device)
+            check(lib().dt_cin_pool(ptr(y), B, L, D, int(half), ptr(pooled), stream_ptr()), 'dt_cin_pool')
+        else:
+            pooled = y[:, half:].sum(-1)
         return hidden, pooled
 
     @staticmethod
@@ -476,6 +482,11 @@ class _CinSplitPool(torch.autograd.Function):
         B, L, D = ctx.shape
         half = ctx.half
         gy = torch.empty(ctx.shape, dtype=torch.float32, device=(g_pooled if g_pooled is not None else g_hidden).device)
+        if ctx.hip:
+            gh = None if g_hidden is None else _f32c(g_hidden)
+            gp = None if g_pooled is None else _f32c(g_pooled)
+            check(lib().dt_cin_pool_bwd(ptr(gh), ptr(gp), B, L, D, half, ptr(gy), stream_ptr()), 'dt_cin_pool_bwd')
+            return gy, None
         if g_hidden is None:
             gy[:, :half].zero_()
         else:

@@ -190,6 +190,12 @@ int dt_cin_layer_bwd_ws(const float* x0, const float* xk, const float* W, const 
                         const float* grad_y, int act, int B, int F0, int Hk, int L, int D,
                         int64_t x0_bstride, int64_t xk_bstride, float* grad_x0, float* grad_xk,
                         float* grad_W, float* grad_bias, void* ws, void* stream);
+/* CIN `direct=False` split (layers.py:713-721, :726): of a layer's output y [B,L,D] the channels [half, L) leave the stack and
+ * only their sum over D is used.  dt_cin_pool: pooled [B, L-half] = sum_D y[:, half:, :] (half = 0: every channel — the last
+ * layer).  dt_cin_pool_bwd: the layer's incoming gradient gy [B,L,D] in one pass = concat(g_hidden [B,half,D] or zeros
+ * when NULL, g_pooled [B,L-half] broadcast over D or zeros when NULL).  D % 4 == 0. */
+int dt_cin_pool(const float* y, int64_t B, int L, int D, int half, float* pooled, void* stream);
+int dt_cin_pool_bwd(const float* g_hidden, const float* g_pooled, int64_t B, int L, int D, int half, float* gy, void* stream);
 
 /* ---- a12 MultiheadAttention core (models/layers.py:129-145) ------------------------------- *
  * q,k,v [B,F,D] (already relu(Dense(x)), layers.py:123-125); H heads split on the last axis

@@ -321,3 +321,32 @@ def test_dense(dev, N, K, M, act, bias):
     assert rel_err(xd.grad, xr.grad) < TOL and rel_err(Wd.grad, Wr.grad) < TOL
     if bias:
         assert rel_err(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('B,L,D,half', [(37, 128, 16, 64), (5, 10, 8, 0), (300, 7, 4, 3), (1, 2, 32, 1), (2049, 128, 16, 0)])
+def test_cin_split_pool_matches_torch(dev, B, L, D, half):
+    """ops.cin_split_pool (dt_cin_pool / dt_cin_pool_bwd): the `direct=False` bookkeeping of CIN.call (layers.py:713-721, :726)
+    — hidden half as a view, the rest pooled over D; the backward assembles the layer's gradient in one pass — against the
+    same thing written with torch slicing / sum"""
+    from deeptables_amd import ops
+    g = torch.Generator().manual_seed(B + L)
+    y = torch.randn(B, L, D, generator=g).to(dev)
+    gh = torch.randn(B, half, D, generator=g).to(dev)
+    gp = torch.randn(B, L - half, generator=g).to(dev)
+    y1 = y.clone().requires_grad_(True)
+    h1, p1 = ops.cin_split_pool(y1, half)
+    y2 = y.clone().requires_grad_(True)
+    h2, p2 = y2[:, :half], y2[:, half:].sum(-1)
+    assert torch.equal(h1, h2)
+    assert (p1 - p2).abs().max().item() <= 1e-5 * max(1.0, p2.abs().max().item())
+    if half:
+        (h1 * gh).sum().backward(retain_graph=True)
+        (h2 * gh).sum().backward(retain_graph=True)
+    (p1 * gp).sum().backward()
+    (p2 * gp).sum().backward()
+    assert torch.allclose(y1.grad, y2.grad, rtol=0, atol=1e-6)
+    # only one of the two outputs used: the other half of the gradient is zero
+    y3 = y.clone().requires_grad_(True)
+    ops.cin_split_pool(y3, half)[1].sum().backward()
+    assert torch.equal(y3.grad[:, :half], torch.zeros_like(y3.grad[:, :half]))
+    assert torch.equal(y3.grad[:, half:], torch.ones_like(y3.grad[:, half:]))
