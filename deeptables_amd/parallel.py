@@ -156,7 +156,7 @@ class DataParallelStrategy:
             # receivers skip, so each applies W x (distinct rows) updates instead of W x B x F
             from . import ops
             grad = ops.merge_segments_(grad)
-            if W == 1:
+            if W == 1 and not getattr(self, 'force_collectives', False):
                 return grad
         elif getattr(grad, 'segments', None) is not None or getattr(grad, 'fields', None) == -1:
             # sparse_bucket_ratio < 1: pack unique (row, summed gradient / W) entries into a SMALLER fixed-size bucket
@@ -172,7 +172,7 @@ class DataParallelStrategy:
             if not any(c is ctr for c in self._overflow_counters):
                 self._overflow_counters.append(ctr)
             ops.compact_rows(grad, cap, 1.0 / W, b_rows, b_vals, ctr)
-            if W == 1:
+            if W == 1 and not getattr(self, 'force_collectives', False):
                 return SparseRowGrad(b_rows, b_vals, fields=0)
             all_rows = self._persistent(('rows', tag), (W * cap,), torch.int64, dev)
             all_vals = self._persistent(('vals', tag), (W * cap, D), torch.float32, dev)
@@ -220,8 +220,9 @@ class DataParallelStrategy:
             return
         flat = getattr(model, '_dt_flat_grad', None)
         work = None
-        if self.world_size == 1:
+        if self.world_size == 1 and not getattr(self, 'force_collectives', False):
             flat = None                 # force_dp at world size 1: only the sparse bucketing below does anything
+        # force_collectives (tests, with force_dp): world size 1 still issues the flat all-reduce and the sparse all-gathers
         if flat is not None:
             # the fused train step already keeps every dense gradient in ONE contiguous buffer: all-reduce it in
             # place (async, overlapped with the sparse all-gathers below), no bucket copy in or out
@@ -305,7 +306,7 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
         """async_op: returns a handle whose .wait() orders the CURRENT stream behind the exchange (RCCL: the collective's own
         stream; world size 1: the copy on a side stream), or None when the exchange was synchronous"""
         W = self.world_size
-        if W == 1:
+        if W == 1 and not getattr(self, 'force_collectives', False):
             if async_op and out.is_cuda:
                 side = self._side_stream(out.device)
                 side.wait_stream(torch.cuda.current_stream(out.device))
@@ -343,7 +344,7 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
         """idx [B,F] int32 of the local minibatch -> [W, B, F] ids of every rank's minibatch."""
         W = self.world_size
         B, F = idx.shape
-        if W == 1:
+        if W == 1 and not getattr(self, 'force_collectives', False):
             return idx.reshape(1, B, F)
         all_idx = torch.empty((W * B, F), dtype=idx.dtype, device=idx.device)
         dist.all_gather_into_tensor(all_idx, idx.contiguous(), group=self.group)
@@ -354,7 +355,7 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
         W = self.world_size
         B = idx.shape[0]
         s, e = self.field_bounds(F)[self.rank]
-        if W == 1:
+        if W == 1 and not getattr(self, 'force_collectives', False):
             all_idx = idx.reshape(1, B, F)
         else:
             all_idx = torch.empty((W * B, F), dtype=idx.dtype, device=idx.device)
@@ -409,8 +410,10 @@ class ShardedEmbeddingStrategy(DataParallelStrategy):
     def exchange_gradients(self, model, optimizer=None):
         """Dense gradients only — the embedding gradients already travelled to their owners inside the step.
         With an optimizer that has a `pre_dense_hook`, the flat all-reduce is started asynchronously and waited for
-        only right before the dense update, so it overlaps the owners' table updates."""
-        if self.world_size == 1:
+        only right before the dense update, so it overlaps the owners' table updates.
+        `force_collectives` (tests): world size 1 still issues every collective — the RCCL calls of the N > 1 step
+        (all_gather_into_tensor, all_to_all_single with split sizes, the asynchronous all_reduce) on one rank."""
+        if self.world_size == 1 and not getattr(self, 'force_collectives', False):
             return
         if getattr(model, '_dt_sharded_step', False):
             flat = getattr(model, '_dt_flat_grad', None)

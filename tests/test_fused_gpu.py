@@ -354,8 +354,8 @@ def test_fused_steps_take_narrower_towers(dev, tmp_path, net, H1, H2):
     assert (dm.model(ins) - twin.model(ins)).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize('overlap', ['1', '0'])
-def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, monkeypatch):
+@pytest.mark.parametrize('overlap,collectives', [('1', False), ('0', False), ('0', True), ('1', True)])
+def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, collectives, monkeypatch):
     """ShardedEmbeddingStrategy(force=True) on ONE rank drives the whole model-parallel-table step (ids exchange,
     owner gather, all-to-all, fused kernels on the received rows, gradient all-to-all, owner Adam) through RCCL with
     world size 1; after several train steps it must agree with the plain fused step.  overlap = 1 (opt-in): the gradient
@@ -376,6 +376,9 @@ def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, monkeypat
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     st = ShardedEmbeddingStrategy.from_env('nccl')
     st.force = True
+    # collectives=True: no world-size-1 shortcuts — ids all_gather_into_tensor, both all_to_all_single calls (with their split
+    # lists) and the asynchronous dense all_reduce really go through RCCL, as they do at N > 1
+    st.force_collectives = collectives
     old = dl.DENSE_GRAD_MAX_ELEMS
     dl.DENSE_GRAD_MAX_ELEMS = 0                      # sparse-gradient path (as with 1M-row tables)
     try:
@@ -405,6 +408,63 @@ def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, monkeypat
                 losses[k].append(float(l))
         assert models[1].model._dt_sharded_step is True and models[0].model._dt_sharded_step is False
         assert np.allclose(losses[0], losses[1], atol=1e-6), (losses)
+        for (n0, p0), (n1, p1) in zip(models[0].model.named_parameters(), models[1].model.named_parameters()):
+            assert (p0 - p1).abs().max().item() < 2e-6, n0
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('uniform', [True, False])
+def test_data_parallel_step_single_rank_through_rccl_equals_plain(dev, uniform):
+    """DataParallelStrategy on ONE rank with force_dp + force_collectives: the replicated-table step of N > 1 — in-step dedupe
+    kept, segments merged in place, the flat dense all-reduce and the sparse all-gathers really issued through RCCL (world
+    size 1), the optimizer's global dedupe over the gathered entries — against the plain fused step, several train steps
+    with duplicate and out-of-range ids.  uniform=False: the variable-count exchange (counts all-gather + padding)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel, layers as dl
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    from deeptables_amd.parallel import DataParallelStrategy
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    st = DataParallelStrategy.from_env('nccl')
+    st.force_dp = True
+    st.force_collectives = True
+    st.assume_uniform_batches = uniform
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    try:
+        F, Nd, D, B, vocab = 26, 13, 16, 512, 120            # vocab 120: most lookups are segment members
+        models = []
+        for strategy in (None, st):
+            functional.set_seed(12)
+            conf = ModelConfig(nets=['linear', 'fm_nets', 'dnn_nets'], fixed_embedding_dim=True,
+                               embeddings_output_dim=D, embedding_dropout=0, dense_dropout=0, metrics=['AUC'],
+                               distribute_strategy=strategy)
+            cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
+            conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])]
+            dm = DeepModel('binary', 2, conf, cats, conts)
+            dm.build()
+            dm.model.train()
+            models.append(dm)
+        g = torch.Generator().manual_seed(3)
+        losses = [[], []]
+        for step in range(4):
+            idx = torch.stack([torch.randint(0, vocab + i, (B,), generator=g) for i in range(F)], 1)
+            if step == 2:
+                idx[::17, 3] = vocab + 500
+            dense = torch.randn(B, Nd, generator=g)
+            y = (torch.rand(B, 1, generator=g) < 0.3).float()
+            for k, dm in enumerate(models):
+                l, _ = dm.train_step([idx.int().to(dev), dense.to(dev)], y.to(dev))
+                losses[k].append(float(l))
+        assert np.allclose(losses[0], losses[1], atol=1e-6), losses
         for (n0, p0), (n1, p1) in zip(models[0].model.named_parameters(), models[1].model.named_parameters()):
             assert (p0 - p1).abs().max().item() < 2e-6, n0
     finally:
