@@ -596,7 +596,9 @@ def main():
                        'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
+                         'frac': achieved / HBM_PEAK_GBS,
+                         # the PMC passes were taken on the single-process six-launch step: no figure for the N > 1 step structures
+                         'traffic': pmc_traffic(args) if strategy is None else None,
                          'launch': 'one hipGraph replay = one train step (fwd+bwd' + ('' if args.no_optimizer else '+Adam') + ')',
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
             'step_us': step_stats,
