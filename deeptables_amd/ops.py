@@ -461,11 +461,14 @@ class _CinSplitPool(torch.autograd.Function):
     """CIN `direct=False` bookkeeping of one layer output y [B,L,D] (layers.py:713-718, :720-721): the first `half` channels
     feed the next layer (a view of y), the others go to the result — of which only the sum over D is ever used
     (`tf.reduce_sum(result, -1)`), so they are pooled here.  Backward: the layer's incoming gradient [B,L,D] is assembled
-    in place from the two pieces (hidden half copied, pooled half broadcast over D) — torch's slice / cat / sum backward
-    built two zero-filled full-size tensors, added them and expanded the pooled gradient (6 launches per layer)."""
+    in ONE pass from the two pieces (hidden half copied, pooled half broadcast over D) — torch's slice / cat / sum backward
+    built two zero-filled full-size tensors, added them and expanded the pooled gradient (6 launches per layer).
+    One HIP launch each way (dt_cin_pool / dt_cin_pool_bwd) for contiguous float32 y with D % 4 == 0; other device layouts
+    take the same steps as torch device ops.  CUDA(HIP) tensors only, like every function of this module."""
 
     @staticmethod
     def forward(ctx, y, half):
+        require_cuda(y)
         ctx.shape, ctx.half = tuple(y.shape), int(half)
         hidden = y[:, :half]
         B, L, D = y.shape
@@ -590,10 +593,11 @@ _AUTOINT_WS = {}
 
 
 def _autoint_ws(B, D, device, nbytes=None, tag='w'):
-    """per-block partials of dt_autoint_bwd_w / dt_autoint_fwd_bn (one buffer per (kind, size, device): launches are
-    stream-ordered, and a partial buffer is consumed by the launch that follows its producer)"""
+    """per-block partials of dt_autoint_bwd_w / dt_autoint_fwd_bn: one buffer per (kind, size, device, STREAM) — a partial
+    buffer is written and consumed by two launches of the same call, so calls on one stream may share it; calls on
+    different streams must not"""
     n = int(lib().dt_autoint_bwd_workspace_bytes(int(B), int(D))) if nbytes is None else int(nbytes)
-    key = (tag, n, str(device))
+    key = (tag, n, str(device), int(torch.cuda.current_stream(device).cuda_stream))
     if key not in _AUTOINT_WS:
         _AUTOINT_WS[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
     return _AUTOINT_WS[key]
