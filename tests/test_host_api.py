@@ -329,3 +329,27 @@ def test_parity_verdict_uses_the_bf16_bar_only_in_bf16_mode():
     assert headline.verdict(res)[0] is False
     assert headline.verdict(dict(res, gather_bit_exact=False), bf16=True)[0] is False
     assert headline.verdict(dict(res, max_abs_logit_err=0.2), bf16=True)[0] is False
+
+
+def test_row_weights_of_the_fused_steps_are_validated():
+    """fused._row_weights: Keras' sample_weight x class_weight vector as the step's loss block reads it — float32, flat,
+    contiguous, one entry per row; a wrong length raises instead of reading past the end"""
+    from deeptables_amd.fused import _row_weights
+    y = torch.zeros(6, 1)
+    assert _row_weights(None, y) is None
+    w = _row_weights(torch.arange(12, dtype=torch.float64)[::2].reshape(6, 1), y)
+    assert w.dtype == torch.float32 and w.shape == (6,) and w.is_contiguous()
+    assert torch.equal(w, torch.tensor([0., 2., 4., 6., 8., 10.]))
+    with pytest.raises(ValueError, match='sample_weight has 5 entries for 6 rows'):
+        _row_weights(torch.ones(5), y)
+
+
+def test_unit_gradient_is_recognised_by_storage_not_by_value():
+    """training.unit_grad: the cached 1.0 handed to loss.backward(); a loss function skips the multiplication only for THAT
+    tensor — another tensor holding 1.0 (or a scaled loss's gradient) is multiplied as usual"""
+    from deeptables_amd import training
+    u = training.unit_grad(torch.device('cpu'))
+    assert u.dim() == 0 and float(u) == 1.0 and training.unit_grad(torch.device('cpu')) is u
+    assert training._is_unit_grad(u)
+    assert not training._is_unit_grad(torch.ones(()))
+    assert not training._is_unit_grad(torch.ones(1))

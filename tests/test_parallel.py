@@ -178,6 +178,11 @@ def _sharded_worker(rank, world, port, q):
     grad_own = st.backward_exchange(grad_all[rank].contiguous(), F, B)
     assert grad_own.shape == (world, e - s, B, D)
     assert torch.equal(grad_own, grad_all[:, s:e])
+    # the asynchronous form (fused.FusedDeepFM._run_sharded's opt-in overlap): (out, handle or None), the same rows
+    grad_own2, work = st.backward_exchange(grad_all[rank].contiguous(), F, B, async_op=True)
+    if work is not None:
+        work.wait()
+    assert torch.equal(grad_own2, grad_own)
     dense = torch.zeros(F * V, D)
     dense.index_add_(0, rows_own.reshape(-1), grad_own.reshape(-1, D))
     ref = torch.zeros(F * V, D)
