@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
 }
 
 // ------------------------------------------------------------------------------------------
-// dgrad: grad_x0 (+=), grad_xk (=).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
+// dgrad: grad_x0 (=), grad_xk (=): both OVERWRITTEN (one block owns a 128-row tile of m and all of its (i, j)).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
 // lane that owns column m against xk / x0; grad_x0 is gathered in LDS and flushed once.
 // ------------------------------------------------------------------------------------------
 template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */>
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
     for (int e = threadIdx.x; e < kBM * F0; e += 256) {
         const int i = e / kBM, r = e - i * kBM;
         const int64_t mm = m0 + r;
-        if (mm < M) gx0[((mm / D) * F0 + i) * D + (mm % D)] += g0T[r * F0S + i];
+        if (mm < M) gx0[((mm / D) * F0 + i) * D + (mm % D)] = g0T[r * F0S + i];     // this block is the only writer of (m, i)
     }
 }
 
@@ -333,11 +333,65 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.f;
 
+    // 16-byte staging needs 4 consecutive m inside one batch row (D % 4 == 0; chunk starts are multiples of 64) and aligned
+    // addresses
+    const bool vec4 = (D % 4 == 0) && (x0_bs % 4 == 0) && (xk_bs % 4 == 0) &&
+                      ((((uintptr_t)x0 | (uintptr_t)xk | (uintptr_t)y | (uintptr_t)gy) & 15) == 0);
     for (int64_t mc = m_begin; mc < m_end; mc += kBMC) {
         __syncthreads();
         const int64_t b0 = mc / D;
         const int d0 = (int)(mc - b0 * D);
         const int rows = (int)min((int64_t)kBMC, m_end - mc);
+        if (vec4) {
+            // as cin.hip's k_cin_wgrad (round 3): 4 consecutive m of a tile row are 4 consecutive d of one (b, row) — one
+            // 16-byte load, one 16-byte (x0 / x_k, fp32) or 8-byte (G, bf16) LDS store; a thread's loads of a batch are issued
+            // before its first store.  The scalar form below waited for ~70 dependent 4-byte loads per thread and chunk — many
+            // times the chunk's bf16 MFMA time.
+            constexpr int QR = kBMC / 4;
+            constexpr int kStB = 4;
+            const int ntask = (F0 + Hk + kBN) * QR;
+            for (int t0 = threadIdx.x; t0 < ntask; t0 += 256 * kStB) {
+                cb_f4 v[kStB], yv[kStB];
+                int dst[kStB];       // >= 0: float offset of a 16-byte fp32 store (x0s | xks are contiguous); <= -2: G, bf16 offset -dst - 2
+#pragma unroll
+                for (int u = 0; u < kStB; ++u) {
+                    const int t = t0 + 256 * u;
+                    dst[u] = -1;
+                    v[u] = cb_f4{0.f, 0.f, 0.f, 0.f};
+                    yv[u] = cb_f4{1.f, 1.f, 1.f, 1.f};
+                    if (t >= ntask) continue;
+                    const int row = t / QR, q = t - row * QR;
+                    dst[u] = row < F0 + Hk ? row * XS + 4 * q : -2 - ((row - F0 - Hk) * GS + 4 * q);
+                    if (4 * q >= rows) continue;
+                    const int64_t m = mc + 4 * q, b = m / D;
+                    const int d = (int)(m - b * D);
+                    if (row < F0) v[u] = *reinterpret_cast<const cb_f4*>(x0 + b * x0_bs + (int64_t)row * D + d);
+                    else if (row < F0 + Hk) v[u] = *reinterpret_cast<const cb_f4*>(xk + b * xk_bs + (int64_t)(row - F0) * D + d);
+                    else if (n0 + row - F0 - Hk < L) {
+                        const int64_t o = (b * L + n0 + row - F0 - Hk) * D + d;
+                        v[u] = *reinterpret_cast<const cb_f4*>(gy + o);
+                        if (act != DT_ACT_LINEAR) yv[u] = *reinterpret_cast<const cb_f4*>(y + o);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kStB; ++u) {
+                    if (dst[u] == -1) continue;
+                    cb_f4 o = v[u];
+                    if (dst[u] >= 0) {
+                        *reinterpret_cast<cb_f4*>(lds + dst[u]) = o;
+                    } else {
+                        if (act != DT_ACT_LINEAR) {
+                            o.x *= act_grad_from_y(yv[u].x, act); o.y *= act_grad_from_y(yv[u].y, act);
+                            o.z *= act_grad_from_y(yv[u].z, act); o.w *= act_grad_from_y(yv[u].w, act);
+                        }
+                        typedef __bf16 cb_b4 __attribute__((ext_vector_type(4)));
+                        cb_b4 h;
+                        h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+                        *reinterpret_cast<cb_b4*>(gsb + (-dst[u] - 2)) = h;
+                    }
+                }
+            }
+        } else {
         for (int e = threadIdx.x; e < kBMC * F0; e += 256) {
             const int i = e / kBMC, r = e - i * kBMC;
             const int q = d0 + r, bq = q / D, dq = q - bq * D;
@@ -357,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
                 g = gy[o] * act_grad_from_y(y[o], act);
             }
             gsb[l * GS + r] = (__bf16)g;
+        }
         }
         __syncthreads();
 #pragma unroll

@@ -434,8 +434,9 @@ class _CinLayer(torch.autograd.Function):
         nws = 0 if ctx.bf16 or os.environ.get('DT_AMD_CIN_WGRAD_ATOMIC') == '1' else \
             lib().dt_cin_bwd_workspace_bytes(B, F0, Hk, L, D)
         alloc = torch.empty if nws > 0 else torch.zeros          # dt_cin_layer_bwd_ws overwrites the three gradients
-        gx0 = alloc(x0.shape, dtype=torch.float32, device=x0.device)
-        gxk = alloc((B, Hk, D), dtype=torch.float32, device=x0.device)
+        alloc_x = torch.empty if (nws > 0 or ctx.bf16) else torch.zeros     # ... and the bf16 backward grad_x0 / grad_xk
+        gx0 = alloc_x(x0.shape, dtype=torch.float32, device=x0.device)
+        gxk = alloc_x((B, Hk, D), dtype=torch.float32, device=x0.device)
         gW = alloc(W.shape, dtype=torch.float32, device=x0.device)
         gb = torch.zeros((L,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
         if ctx.bf16:

@@ -302,7 +302,8 @@ int dt_dense_bwd(const float* x, const float* W, const float* y, const float* gr
 /* ---- CIN layer, bf16-MFMA mode (opt-in; north_star "logits within 1e-2 bf16") --------------------------------------- *
  * Same contract as dt_cin_layer_fwd / dt_cin_layer_bwd, computed on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32
  * accumulation): results within 1e-2 of the float64 oracle instead of 1e-4.  ws: dt_cin_bf16_workspace_bytes(F0, Hk, L)
- * bytes (bf16 re-layouts of W, rebuilt by every call).  L <= 256, Hk <= 128, F0 <= 128.                            */
+ * bytes (bf16 re-layouts of W, rebuilt by every call).  L <= 256, Hk <= 128, F0 <= 128.  dt_cin_layer_bwd_bf16 OVERWRITES
+ * grad_x0 / grad_xk (no zero fill needed, as dt_cin_layer_bwd_ws); grad_W / grad_bias accumulate as in dt_cin_layer_bwd. */
 int64_t dt_cin_bf16_workspace_bytes(int F0, int Hk, int L);
 int dt_cin_layer_fwd_bf16(const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
                           int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y, void* ws, void* stream);
