@@ -350,6 +350,129 @@ def check_rows_in_step(dm, batch, steps=1):
     return res
 
 
+def _adam_band(p, g, m, v, t, lr, dg):
+    """Keras-Adam update of (p, m, v) with gradient g, and how far the new p moves when g is off by +-dg (the band a
+    float32 gradient cannot be told apart from the float64 one in): Adam divides by sqrt(v) + 1e-7, so where |g| is of
+    the order of epsilon / sqrt(1 - beta_2) ~ 3e-6 the update is g / eps-like and amplifies gradient rounding."""
+    pn, mn, vn = R.keras_adam_step(p, g, m, v, t, lr=lr)
+    hi, _, _ = R.keras_adam_step(p, g + dg, m, v, t, lr=lr)
+    lo, _, _ = R.keras_adam_step(p, g - dg, m, v, t, lr=lr)
+    return pn, mn, vn, 0.5 * (hi - lo).abs()
+
+
+def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
+    """The train step AS bench.py TIMES IT — `forward_backward(apply_rows=True)` + `optimizer.step()`: the Keras-Adam update
+    of the rows looked up once inside launch E|D, of the segments and of every dense element inside the step's last
+    launch — for len(batches) CONSECUTIVE steps, against the oracle DIRECTLY (deepmodel.py:319-346 keras Adam on the
+    gradients of deepmodel.py:259-317):
+      at every step the float64 oracle gradient at the product's current weights (row gradients merged per table row)
+      goes through R.keras_adam_step with the ORACLE'S OWN running m / v (read from the product's slots the first time a
+      row / parameter is met — zeros on a fresh model — and carried in float64 afterwards: from the second step on the
+      product's WARM-slot arithmetic is what is compared), and table rows, row slots, dense parameters and dense slots
+      are compared after the step.
+    m / v are linear / quadratic in the gradient: compared at `4e-4` of the tensor's largest entry.  The parameter is
+    compared at `upd_tol` of the step's largest move, EXCEPT where the update rule amplifies float32 gradient rounding
+    (`_adam_band`: entries whose new value moves by more than upd_tol / 2 of the step when the gradient is off by
+    g_band x the tensor's largest |g|); those entries are masked and COUNTED (`*_masked`).  Batch 2.. reuse half of the
+    previous batch's id rows so that many rows are met with warm slots.  -> dict of figures; `in_step_vs_oracle_ok`."""
+    emb = dm.model.layers_by_name['emb_categorical_vars_all']
+    D = emb.groups[0][0]
+    key = f'd{D}'
+    table = emb.tables[key]
+    opt = dm.optimizer
+    assert dm.fused_plan() is not None
+    dm.model.train()
+    slots = opt._st(table, rows=True)
+    dense = dense_parameters(dm)
+    tables_cpu = None
+    known = torch.empty(0, dtype=torch.int64)                      # rows the oracle carries m / v for (sorted)
+    km = torch.empty(0, D, dtype=torch.float64)
+    kv = torch.empty(0, D, dtype=torch.float64)
+    dstate = {}                                                    # dense parameter name -> (m, v) float64
+    res = {'steps': len(batches), 'rows_in_step_taken': True, 'warm_rows': 0}
+    worst = {'rows_p': 0.0, 'rows_m': 0.0, 'rows_v': 0.0, 'dense_p': 0.0, 'dense_m': 0.0, 'dense_v': 0.0}
+    masked = {'rows': 0, 'rows_total': 0, 'dense': 0, 'dense_total': 0}
+    prev_idx = None
+    for step, (idx, dn, y) in enumerate(batches):
+        if prev_idx is not None:                                   # half of the previous batch's lookups come back
+            idx = idx.clone()
+            half = idx.shape[0] // 2
+            sel = torch.randperm(prev_idx.shape[0], generator=torch.Generator().manual_seed(5 + step))[:half]
+            idx[:half] = prev_idx[sel.to(prev_idx.device)]
+        prev_idx = idx
+        # table rows change between the steps: fresh float32 CPU copies of the tables (bit-exact values)
+        ref = oracle_train_step(dm, idx, dn, y, tables_cpu=None)
+        u_ref, g_ref = merge_rows(ref['rows'], ref['row_grads'].double())
+        pairs = oracle_dense_grads(dm, ref['weights'])
+        t = opt.t + 1
+        dev_rows = u_ref.to(table.device)
+        p0 = table.detach()[dev_rows].double().cpu()
+        m0 = slots['m'][dev_rows].double().cpu()
+        v0 = slots['v'][dev_rows].double().cpu()
+        if known.numel():
+            pos = torch.searchsorted(known, u_ref).clamp(max=known.numel() - 1)
+            hit = known[pos] == u_ref
+            m0[hit], v0[hit] = km[pos[hit]], kv[pos[hit]]
+            res['warm_rows'] += int(hit.sum())
+        dense0 = {}
+        for p, g in pairs:
+            name = next(n for n, q in dense if q is p)
+            st = opt._st(p)
+            mm, vv = dstate.get(name, (st['m'].detach().double().cpu().reshape(g.shape),
+                                       st['v'].detach().double().cpu().reshape(g.shape)))
+            dense0[name] = (p.detach().double().cpu().reshape(g.shape), g.detach().double(), mm, vv)
+        # ---- the product's step, as timed ----
+        ins = [idx, dn] if dn is not None else [idx]
+        dm.forward_backward(ins, y, apply_rows=True)
+        sg = emb.sparse_grads.get(key) or []
+        res['rows_in_step_taken'] = res['rows_in_step_taken'] and bool(sg) and \
+            all(getattr(s, 'fields', None) == -2 for s in sg)
+        opt.step()
+        torch.cuda.synchronize()
+        # ---- rows ----
+        pn, mn, vn, band = _adam_band(p0, g_ref, m0, v0, t, lr, g_band * g_ref.abs().max())
+        stepsz = (pn - p0).abs().max().item()
+        got_p = table.detach()[dev_rows].double().cpu()
+        keep = band <= 0.5 * upd_tol * stepsz
+        masked['rows'] += int((~keep).sum())
+        masked['rows_total'] += keep.numel()
+        worst['rows_p'] = max(worst['rows_p'], ((got_p - pn).abs() * keep).max().item() / max(stepsz, 1e-30))
+        worst['rows_m'] = max(worst['rows_m'], _rel(slots['m'][dev_rows], mn))
+        worst['rows_v'] = max(worst['rows_v'], _rel(slots['v'][dev_rows], vn))
+        # the oracle's running slots: merge this step's rows into the known set
+        allr = torch.cat([known, u_ref])
+        allm, allv = torch.cat([km, mn]), torch.cat([kv, vn])
+        order = torch.argsort(allr, stable=True)
+        allr, allm, allv = allr[order], allm[order], allv[order]
+        last = torch.ones_like(allr, dtype=torch.bool)
+        last[:-1] = allr[1:] != allr[:-1]                          # stable sort: a row's newest entry is its last
+        known, km, kv = allr[last], allm[last], allv[last]
+        # ---- dense parameters ----
+        for p, _ in pairs:
+            name = next(n for n, q in dense if q is p)
+            pb, g, mm, vv = dense0[name]
+            pn, mn, vn, band = _adam_band(pb, g, mm, vv, t, lr, g_band * g.abs().max())
+            dstate[name] = (mn, vn)
+            stepsz = max((pn - pb).abs().max().item(), 1e-30)
+            keep = band <= 0.5 * upd_tol * stepsz
+            masked['dense'] += int((~keep).sum())
+            masked['dense_total'] += keep.numel()
+            st = opt._st(p)
+            worst['dense_p'] = max(worst['dense_p'],
+                                   ((p.detach().double().cpu().reshape(pn.shape) - pn).abs() * keep).max().item() / stepsz)
+            worst['dense_m'] = max(worst['dense_m'], _rel(st['m'].reshape(mn.shape), mn))
+            worst['dense_v'] = max(worst['dense_v'], _rel(st['v'].reshape(vn.shape), vn))
+        res['steps_counted'] = opt.t
+    res.update({f'{k}_err': v for k, v in worst.items()})
+    res.update({'rows_masked': masked['rows'], 'rows_compared': masked['rows_total'] - masked['rows'],
+                'dense_masked': masked['dense'], 'dense_compared': masked['dense_total'] - masked['dense'],
+                'upd_tol_of_step': upd_tol, 'gradient_band_of_max': g_band})
+    res['ok'] = bool(res['rows_in_step_taken'] and worst['rows_p'] <= upd_tol and worst['dense_p'] <= upd_tol and
+                     max(worst['rows_m'], worst['dense_m']) <= 4e-4 and max(worst['rows_v'], worst['dense_v']) <= 4e-4 and
+                     masked['rows'] <= 0.5 * masked['rows_total'] and masked['dense'] <= 0.5 * masked['dense_total'])
+    return res
+
+
 def rows_in_step_ok(res):
     """both paths form the same gradient with the same kernels; the update rule runs in two different kernels (fused
     multiply-add contraction may differ by an ulp or two, and the members of a segment are summed in the order the

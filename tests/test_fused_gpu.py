@@ -415,12 +415,15 @@ def test_sharded_embedding_step_single_rank_equals_plain(dev, overlap, collectiv
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
 @pytest.mark.parametrize('uniform', [True, False])
-def test_data_parallel_step_single_rank_through_rccl_equals_plain(dev, uniform):
+def test_data_parallel_step_single_rank_through_rccl_equals_plain(dev, uniform, net):
     """DataParallelStrategy on ONE rank with force_dp + force_collectives: the replicated-table step of N > 1 — in-step dedupe
     kept, segments merged in place, the flat dense all-reduce and the sparse all-gathers really issued through RCCL (world
     size 1), the optimizer's global dedupe over the gathered entries — against the plain fused step, several train steps
-    with duplicate and out-of-range ids.  uniform=False: the variable-count exchange (counts all-gather + padding)."""
+    with duplicate and out-of-range ids.  uniform=False: the variable-count exchange (counts all-gather + padding).
+    net = 'DCN': BASELINE.json configs[4] — DCN (6 cross layers) under data parallel (run_dt.py:35-44, deepmodel.py:88-103):
+    the FusedDCN plan's flat gradient buffer (tower + cross kernels / biases) through the one all-reduce."""
     import os
     import socket
     import torch.distributed as dist
@@ -444,15 +447,18 @@ def test_data_parallel_step_single_rank_through_rccl_equals_plain(dev, uniform):
         models = []
         for strategy in (None, st):
             functional.set_seed(12)
-            conf = ModelConfig(nets=['linear', 'fm_nets', 'dnn_nets'], fixed_embedding_dim=True,
+            extra = {'nets': ['dcn_nets'], 'cross_params': {'num_cross_layer': 6}} if net == 'DCN' else \
+                {'nets': ['linear', 'fm_nets', 'dnn_nets']}
+            conf = ModelConfig(fixed_embedding_dim=True,
                                embeddings_output_dim=D, embedding_dropout=0, dense_dropout=0, metrics=['AUC'],
-                               distribute_strategy=strategy)
+                               distribute_strategy=strategy, **extra)
             cats = [CategoricalColumn(f'C{i}', vocab + i, D) for i in range(F)]
             conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(Nd)])]
             dm = DeepModel('binary', 2, conf, cats, conts)
             dm.build()
             dm.model.train()
             models.append(dm)
+        assert type(models[1].fused_plan()).__name__ == ('FusedDCN' if net == 'DCN' else 'FusedDeepFM')
         g = torch.Generator().manual_seed(3)
         losses = [[], []]
         for step in range(4):
@@ -464,7 +470,7 @@ def test_data_parallel_step_single_rank_through_rccl_equals_plain(dev, uniform):
             for k, dm in enumerate(models):
                 l, _ = dm.train_step([idx.int().to(dev), dense.to(dev)], y.to(dev))
                 losses[k].append(float(l))
-        assert np.allclose(losses[0], losses[1], atol=1e-6), losses
+        assert np.allclose(losses[0], losses[1], atol=1e-6 if net == 'DeepFM' else 2e-5), losses
         for (n0, p0), (n1, p1) in zip(models[0].model.named_parameters(), models[1].model.named_parameters()):
             assert (p0 - p1).abs().max().item() < 2e-6, n0
     finally:
@@ -687,3 +693,26 @@ def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab
             res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2 + rep % 2)
             assert headline.rows_in_step_ok(res), str((rep, sorted(res.items())))
         dm.train_step([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))   # move on (in-step path)
+
+
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+def test_in_step_optimizer_matches_oracle_adam_over_three_steps(dev, net):
+    """small sizes (most lookups are segment members, every row warm from step 2 on): the step with the optimizer inside
+    its launches against oracle.headline.check_in_step_vs_oracle — R.keras_adam_step on the oracle's own gradient and its
+    own running slots"""
+    from oracle import headline
+    from deeptables_amd.models import deepnets, layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    try:
+        F, Nd, D, B = 26, 13, 16, 512
+        extra = dict(cross_params={'num_cross_layer': 4}) if net == 'DCN' else {}
+        dm, cats = build(F, Nd, D, vocab=300, nets=getattr(deepnets, net), **extra)
+        batches = []
+        for s in range(3):
+            idx, dense, y = batch(cats, Nd, B, seed=20 + s)
+            batches.append((idx.int().to(dev), dense.to(dev), y.to(dev)))
+        res = headline.check_in_step_vs_oracle(dm, batches)
+        assert res['ok'] and res['steps_counted'] == 3 and res['warm_rows'] > 1000, str(sorted(res.items()))
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old

@@ -140,3 +140,24 @@ def test_headline_rows_in_step_equals_separate_optimizer_step(dev, dist, net):
         res = headline.check_rows_in_step(dm, b)
         assert headline.rows_in_step_ok(res), str(sorted(res.items()))
         dm.train_step([b[0], b[1]], b[2])
+
+
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+@pytest.mark.parametrize('dist', ['uniform', 'zipf'])
+def test_headline_in_step_optimizer_matches_oracle_adam_two_steps(dev, dist, net):
+    """the TIMED path itself against the oracle (no product path in between): two consecutive steps with the optimizer
+    inside the step's launches, table rows / row slots / dense parameters / dense slots against R.keras_adam_step on
+    the float64 oracle gradient — warm slots from the second step on (deepmodel.py:319-346)"""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(getattr(deepnets, net), dev, None, bench.D, bench.MODEL_PARAMS.get(net))
+    bench.N_BATCHES, keep = 2, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=777, dist_kind=dist)
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_in_step_vs_oracle(dm, batches)
+    assert res['ok'], str(sorted(res.items()))
+    assert res['steps_counted'] == 2 and res['warm_rows'] > 30000, res
+    assert res['rows_masked'] < 0.05 * (res['rows_masked'] + res['rows_compared']), res

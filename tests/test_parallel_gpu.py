@@ -24,15 +24,17 @@ def _free_port():
     return p
 
 
-def _model(strategy):
+def _model(strategy, net='DeepFM'):
     from deeptables_amd import functional
     from deeptables_amd.models import ModelConfig, DeepModel, deepnets
     from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
     from deeptables_amd.models import layers as dl
     dl.DENSE_GRAD_MAX_ELEMS = 0                  # row-sparse table gradients, as at benchmark size
     functional.set_seed(11)
-    conf = ModelConfig(nets=deepnets.DeepFM, fixed_embedding_dim=True, embeddings_output_dim=D, embedding_dropout=0,
-                       metrics=['AUC'], distribute_strategy=strategy)
+    # net = 'DCN': BASELINE.json configs[4] — DCN with 6 cross layers under data parallel (run_dt.py:35-44)
+    extra = dict(nets=deepnets.DCN, cross_params={'num_cross_layer': 6}) if net == 'DCN' else dict(nets=deepnets.DeepFM)
+    conf = ModelConfig(fixed_embedding_dim=True, embeddings_output_dim=D, embedding_dropout=0,
+                       metrics=['AUC'], distribute_strategy=strategy, **extra)
     cats = [CategoricalColumn(f'C{i}', V + i, D) for i in range(F)]
     conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(ND)])]
     dm = DeepModel('binary', 2, conf, cats, conts)
@@ -60,7 +62,7 @@ def _weights(dm):
     return {n: p.detach().cpu().clone() for n, p in dm.model.named_parameters()}
 
 
-def _worker(rank, port, kind, q):
+def _worker(rank, port, kind, q, net='DeepFM'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W), LOCAL_RANK='0')
     torch.cuda.set_device(0)
     from deeptables_amd.parallel import DataParallelStrategy, ShardedEmbeddingStrategy
@@ -68,7 +70,7 @@ def _worker(rank, port, kind, q):
     st = cls.from_env('gloo')
     st.device = torch.device('cuda', 0)
     st.assume_uniform_batches = True
-    dm = _model(st)
+    dm = _model(st, net)
     st.broadcast_parameters(dm.model)
     dm.model.train()
     dev = st.device
@@ -84,11 +86,11 @@ def _worker(rank, port, kind, q):
     dist.destroy_process_group()
 
 
-def _emulate():
+def _emulate(net='DeepFM'):
     """the same three steps in ONE process: each replica's forward/backward in turn on the shared weights, gradients
     combined as the exchange does, one optimizer step"""
     from deeptables_amd.ops import SparseRowGrad
-    dm = _model(None)
+    dm = _model(None, net)
     dm.model.train()
     dev = torch.device('cuda', 0)
     emb = dm.model.layers_by_name['emb_categorical_vars_all']
@@ -120,18 +122,19 @@ def _emulate():
     return _weights(dm)
 
 
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
 @pytest.mark.parametrize('kind', ['replicated', 'sharded'])
-def test_two_process_train_steps_match_single_process_emulation(dev, kind):
+def test_two_process_train_steps_match_single_process_emulation(dev, kind, net):
     from deeptables_amd.models import layers as dl
     keep = dl.DENSE_GRAD_MAX_ELEMS
     try:
-        want = _emulate()                 # (_model switches this process to row-sparse table gradients)
+        want = _emulate(net)              # (_model switches this process to row-sparse table gradients)
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = keep
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, kind, q)) for r in range(W)]
+    procs = [ctx.Process(target=_worker, args=(r, port, kind, q, net)) for r in range(W)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(W))
@@ -142,4 +145,4 @@ def test_two_process_train_steps_match_single_process_emulation(dev, kind):
         for name, w in want.items():
             g = torch.from_numpy(got[r][name])
             err = (g - w).abs().max().item()
-            assert err <= 2e-6 + 1e-5 * w.abs().max().item(), (kind, r, name, err)
+            assert err <= 2e-6 + 1e-5 * w.abs().max().item(), (kind, net, r, name, err)
