@@ -10,8 +10,9 @@ One "step" = one pass of the hot path over one batch already resident in HBM: fo
 backward down to the embedding row-gradients (the IndexedSlices values), the Keras-Adam update of
 every dense parameter and of the looked-up table rows and — for N > 1 — the RCCL gradient exchange.
 The optimizer IS in the timed region (`config.optimizer_in_timed_region`; `--no-optimizer` times
-fwd+bwd alone, and the default run also reports that as `fwd_bwd_only_rows_per_s`).  One hipGraph
-per pre-generated batch is captured once and replayed.
+fwd+bwd alone, and the default run also reports that as `fwd_bwd_only_rows_per_s`).  The timed object is the product's
+compiled loop (deeptables_amd/compiled.py, `DeepModel.fit(steps_per_execution=k)`): k consecutive steps per captured hipGraph
+over static input slots gathered from the device-resident table; `fit_rows_per_s` is DeepModel.fit itself.
 
 Before anything is timed, rank 0 runs ONE step of the benchmarked configuration through
 oracle/headline.py (CPU oracle, float64) and reports `parity` (logit / gradient / Adam errors).
@@ -121,185 +122,57 @@ def make_batches(batch, device, seed, dist_kind='uniform'):
     return out
 
 
-class GraphedStep:
-    """fwd + loss + bwd captured into hipGraphs — one graph per pre-generated batch, all sharing one memory
-    pool, so every replay consumes its batch in place (inputs already resident in HBM, no staging copy)."""
-
-    def __init__(self, dm, batch, device, with_optimizer=False, use_graph=True, steps_per_graph=1):
-        self.dm = dm
-        # consecutive steps captured into ONE hipGraph (each on its own batch): a replay then runs `spg` whole train steps
-        # and the fixed cost of a graph launch (~10 us of idle GPU between two replays) is paid once per `spg` steps
-        self.spg = max(1, int(steps_per_graph))
-        self.with_optimizer = with_optimizer
-        self.graphs = {}
-        self.use_graph = use_graph
-        self.strategy = dm.config.distribute_strategy
-        self._dp = self.strategy is not None and (self.strategy.world_size > 1 or getattr(self.strategy, 'force_dp', False) or
-                                                  getattr(self.strategy, 'force', False))
-        self.sparse_refs = {}
-        self._opt_graph = None      # data parallel: the optimizer step is a second captured graph, after the exchange
-        self._dp_steps = 0
-        self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] HIP events around fwd+bwd | exchange | optimizer
-
-    def _sharded(self):
-        st = self.strategy
-        return self._dp and getattr(st, 'sharded_embeddings', False) and st.active and self.dm.fused_plan() is not None
-
-    def _body(self, b):
-        dm = self.dm
-        if self._sharded() and getattr(self, '_core_only', False):
-            # row-owned tables, graph capture: only the launches between the collectives (the step's kernels); the
-            # collectives around them are issued eagerly by run()
-            plan = dm.fused_plan()
-            dm.optimizer.zero_grad(flat=False)
-            loss, logit = plan.sharded_core(b[0].shape[0], b[1], b[2], self.strategy)
-            dm.model._dt_flat_grad = plan.accum
-            self.loss = loss
-            return
-        fused_opt = self.with_optimizer and not self._dp
-        # fused plan when the graph has one; apply_rows: optimizer.step() follows at once (DeepModel.train_step's order),
-        # so the DeepFM step applies the update of the rows looked up once inside its own kernels
-        loss, logit = dm.forward_backward([b[0], b[1]], b[2], apply_rows=fused_opt and self.strategy is None)
-        if fused_opt:
-            dm.optimizer.step()          # single GPU: the Adam step is part of the captured graph
-        self.loss = loss
-
-    def capture(self, batches, first=0):
-        """`first`: stream position of the first TIMED step — the spg-step windows are laid so that one starts there"""
-        from deeptables_amd.models.layers import MultiColumnEmbedding
-        if len(batches) % self.spg:
-            self.spg = 1
-        self.s0 = first % self.spg
-        self.dm.model.train()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for i in range(3):
-                self._body(batches[i % len(batches)])
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        if not self.use_graph:
-            return
-        emb_layers = [l for l in self.dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
-        pool = None
-        self._core_only = self._sharded()        # captured: the launches between the collectives only
-        for i, b in enumerate(batches):
-            if (i - self.s0) % self.spg:
-                continue
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                for k in range(self.spg):
-                    self._body(batches[(i + k) % len(batches)])
-            if pool is None:
-                pool = g.pool()
-            self.graphs[i] = g
-            # python side effects (sparse-gradient registration) are not replayed by a graph: keep the captured
-            # static (rows, values) tensors and re-attach them after every replay
-            self.sparse_refs[i] = [(l, {k: list(v) for k, v in l.sparse_grads.items()}) for l in emb_layers]
-        self._core_only = False
-        torch.cuda.synchronize()
-
-    def run_eager(self, b):
-        self._body(b)
-
-    def phase_times(self):
-        """mean microseconds of the three phases of a data-parallel step (HIP events on the launch stream; read after
-        the timed region): what a scaling run needs to diagnose itself"""
-        if not self.phase_events:
-            return None
-        torch.cuda.synchronize()
-        n = len(self.phase_events)
-        fb = sum(a.elapsed_time(b) for a, b, _, _ in self.phase_events) / n * 1e3
-        ex = sum(b.elapsed_time(c) for _, b, c, _ in self.phase_events) / n * 1e3
-        op = sum(c.elapsed_time(d) for _, _, c, d in self.phase_events) / n * 1e3
-        return {'fwd_bwd_us': fb, 'exchange_us': ex, 'opt_us': op, 'steps': n}
-
-    def run(self, i, b):
-        ev = None
-        if self._dp and self.phase_events is not None:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            ev[0].record()
-        g = self.graphs.get(i)
-        if g is not None and self._sharded():
-            # three segments around the step's collectives: [ids all-gather, owner gather, forward all-to-all] eager ->
-            # the captured step kernels -> [backward all-to-all] eager -> (below) dense all-reduce -> captured optimizer
-            plan = self.dm.fused_plan()
-            plan.sharded_pre(b[0], self.strategy)
-            g.replay()
-            plan.sharded_post(b[0].shape[0], self.strategy)
-        elif g is not None:
-            g.replay()
-            for layer, refs in self.sparse_refs[i]:
-                layer.sparse_grads = {k: list(v) for k, v in refs.items()}
-        else:
-            self._body(b)
-        if self._dp:
-            # data parallel = two captured halves around the (eager) RCCL collectives: [fwd+bwd graph] -> dense
-            # all-reduce + sparse all-gather into persistent buffers -> [optimizer graph]
-            if ev:
-                ev[1].record()
-            self.strategy.exchange_gradients(self.dm.model, self.dm.optimizer if self.with_optimizer else None)
-            if ev:
-                ev[2].record()
-            if self.with_optimizer:
-                if self._opt_graph is not None:
-                    hook, self.dm.optimizer.pre_dense_hook = getattr(self.dm.optimizer, 'pre_dense_hook', None), None
-                    if hook is not None:
-                        hook()           # the async dense all-reduce must have landed before the captured optimizer runs
-                    self._opt_graph.replay()
-                    for layer in getattr(self.dm.optimizer, 'embedding_layers', []):
-                        layer.sparse_grads.clear()
-                elif self.use_graph and self._dp_steps >= 2:
-                    hook, self.dm.optimizer.pre_dense_hook = getattr(self.dm.optimizer, 'pre_dense_hook', None), None
-                    if hook is not None:
-                        hook()
-                    torch.cuda.synchronize()
-                    gopt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gopt):
-                        self.dm.optimizer.step()
-                    self._opt_graph = gopt
-                    gopt.replay()
-                else:
-                    self.dm.optimizer.step()     # first steps (slot buffers get allocated) and the sharded-table step
-            self._dp_steps += 1
-            if ev:
-                ev[3].record()
-                self.phase_events.append(tuple(ev))
+def make_feed(batches):
+    """the pre-generated batches as ONE device-resident table (training.TableBatches, resident mode): what `DeepModel.fit`
+    trains on; batch i = rows [i*B, (i+1)*B)"""
+    from deeptables_amd.training import TableBatches
+    idx = torch.cat([b[0] for b in batches])
+    dense = torch.cat([b[1] for b in batches])
+    y = torch.cat([b[2] for b in batches])
+    return TableBatches.from_device([idx, dense], ['cat', 'cont'], y, y_ndim=2)
 
 
-def time_steps(step, batches, steps, warmup, barrier):
-    """EXACTLY `steps` train steps are timed (after `warmup` untimed ones).  With `spg` steps per captured graph a replay
-    runs spg consecutive steps: warmup / steps that are not multiples of spg are completed with eager steps."""
-    nb = len(batches)
-    spg = getattr(step, 'spg', 1) if getattr(step, 'graphs', None) else 1
-    s0 = getattr(step, 's0', 0)
+def ring_order(feed, batch, n_steps, device):
+    """row order of n_steps consecutive steps over the ring of pre-generated batches (batch 0, 1, ..., N-1, 0, ...)"""
+    return torch.arange(n_steps * batch, device=device, dtype=torch.int64) % feed.n
 
-    def advance(pos, n, evs=None):
-        """run n steps starting at stream position `pos`; one event per launch unit -> [(event index, steps)]"""
-        done = 0
-        while done < n:
-            i = (pos + done) % nb
-            if spg > 1 and (i - s0) % spg == 0 and n - done >= spg:
-                step.run(i, batches[i])
-                k = spg
-            else:
-                step.run(i, batches[i]) if spg == 1 else step.run_eager(batches[i])
-                k = 1
-            done += k
-            if evs is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()                 # HIP event on the launch stream after every launch unit (median / p10 / p90 below)
-                evs.append((e, k))
-    advance(0, warmup)
+
+def spin_gpu(device, ms=60.0):
+    """~`ms` of light streaming work that touches nothing of the model: the timed region starts with the clocks up (a
+    20-step timed region is 2.5 ms long; an idle GPU spends it ramping)"""
+    buf = torch.empty(16 << 20, dtype=torch.float32, device=device)       # 64 MB
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        buf.add_(1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    per = max(e0.elapsed_time(e1) / 20, 1e-3)
+    for _ in range(int(ms / per) + 1):
+        buf.add_(1.0)
+
+
+def time_steps(loop, steps, warmup, barrier, device, spin=True):
+    """EXACTLY `steps` train steps are timed after `warmup` untimed ones, all through the product's compiled loop
+    (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides both counts, so the warm-up runs through replays
+    of the same graph — the timed replays are never a graph's first launch)."""
+    loop.run(warmup)
+    if spin:
+        spin_gpu(device)
     barrier()
     torch.cuda.synchronize()
-    if getattr(step, '_dp', False):
-        step.phase_events = []
+    if loop.dp:
+        loop.phase_events = []
     evs = []
+
+    def mark(k):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                 # HIP event on the launch stream after every launch unit (median / p10 / p90 below)
+        evs.append((e, k))
     e0 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    advance(warmup, steps, evs)
+    loop.run(steps, on_execution=mark)
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -308,12 +181,12 @@ def time_steps(step, batches, steps, warmup, barrier):
         per += [prev.elapsed_time(e) * 1e3 / k] * k          # us per step (a replay of k steps: its mean)
         prev = e
     per.sort()
-    evs = [e0] + [e for e, _ in evs]
 
     def pct(q):
         return per[min(len(per) - 1, int(q * len(per)))]
-    stats = {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'mean': sum(per) / len(per), 'n': len(per)}
-    return wall, evs[0].elapsed_time(evs[-1]) / 1e3, stats
+    stats = {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'mean': sum(per) / len(per), 'n': len(per),
+             'launch_units': len(evs)}
+    return wall, e0.elapsed_time(evs[-1][0]) / 1e3, stats
 
 
 TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
@@ -551,22 +424,24 @@ def main():
     batches = make_batches(args.batch, device, seed=1234 + rank, dist_kind=args.dist)
 
     sharded = getattr(strategy, 'sharded_embeddings', False) and strategy.active and dm.fused_plan() is not None
-    if sharded and not args.graph_segments:
-        # row-owned tables: the step can run as captured segments around its collectives (--graph-segments: [ids
-        # all-gather, owner gather, all-to-all] -> graph of the step kernels -> [all-to-all] -> dense all-reduce -> graph of
-        # the optimizer), but a replay's fixed cost (~10 us each) exceeds what six eager launches cost:
-        # measured at world size 1 through RCCL 183 us with the two graphs, 173 us eager -> eager by default
-        args.no_graph = True
+    # The timed object is the PRODUCT's compiled loop (deeptables_amd/compiled.py — what DeepModel.fit(steps_per_execution=k)
+    # runs): k consecutive train steps per captured hipGraph over static input slots filled from the device-resident table.
+    # k = the largest value <= --steps-per-graph dividing BOTH the timed steps and the warm-up, so that exactly `steps` steps
+    # are timed, all through replays, and the warm-up has already replayed the same graph (row-owned tables: the step stays
+    # eager unless --graph-segments — a replay's fixed cost exceeds six eager launches there).
+    from deeptables_amd.compiled import CompiledTrainLoop
+    feed = make_feed(batches)
     spg = 1
     if world == 1 and strategy is None and not args.no_graph:
-        # the largest window <= --steps-per-graph that divides both the timed steps and the batch ring (so that exactly
-        # `steps` steps are timed, all of them through graph replays)
-        spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0 and N_BATCHES % d == 0)
-    step = GraphedStep(dm, args.batch, device, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
-                       steps_per_graph=spg)
-    step.capture(batches, first=args.warmup)
-    spg = step.spg
-    wall, ev_s, step_stats = time_steps(step, batches, args.steps, args.warmup, barrier)
+        spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1)
+                  if args.steps % d == 0 and (args.warmup % d == 0 or args.warmup == 0))
+    loop = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
+                             graph_segments=args.graph_segments)
+    warm_capture = 2
+    loop.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
+    loop.capture(warm_steps=warm_capture)
+    spg = loop.k if loop.graph is not None else 1
+    wall, ev_s, step_stats = time_steps(loop, args.steps, args.warmup, barrier, device)
     if strategy is not None and hasattr(strategy, 'check_sparse_overflow'):
         strategy.check_sparse_overflow()            # a bucket that dropped entries invalidates the run: fail loudly
     t = torch.tensor([wall], dtype=torch.float64, device=device)
@@ -592,14 +467,18 @@ def main():
                                    f', Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
-                       'hipgraph': not args.no_graph, 'steps_per_graph_replay': spg,
+                       'hipgraph': loop.graph is not None, 'steps_per_graph_replay': spg,
+                       'timed_object': 'deeptables_amd.compiled.CompiledTrainLoop (DeepModel.fit steps_per_execution)',
+                       'graph_uploaded_before_first_replay': bool(loop.uploaded),
                        'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          # the PMC passes were taken on the single-process six-launch step: no figure for the N > 1 step structures
                          'traffic': pmc_traffic(args) if strategy is None else None,
-                         'launch': 'one hipGraph replay = one train step (fwd+bwd' + ('' if args.no_optimizer else '+Adam') + ')',
+                         'launch': f'one train step (fwd+bwd' + ('' if args.no_optimizer else '+Adam') +
+                                   f') = one hipGraph replay / {spg} steps per replay: launch_us = HIP-event time of the timed '
+                                   f'replays / the steps they hold',
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
             'step_us': step_stats,
         }
@@ -612,12 +491,13 @@ def main():
             result['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
                                   'traffic': None, 'mfma_dtype': 'bf16 (fp32 accumulate)' if bf16 else 'f32',
                                   'flops_per_row': fpr, 'launch_us': step_s * 1e6,
-                                  'launch': 'one hipGraph replay = one train step; flops = the CIN / attention contractions, '
-                                            'fwd + dgrad + wgrad'}
+                                  'launch': f'one train step = one hipGraph replay / {spg}; flops = the CIN / attention '
+                                            'contractions, fwd + dgrad + wgrad'}
             if bf16:
                 result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
 
-        ph = step.phase_times()
+        result['first_replay_us'] = loop.first_replay_us()
+        ph = loop.phase_times()
         if ph is not None:          # N > 1 (or --force-dp): where a data-parallel step spends its time, on rank 0
             result['phases'] = ph
             st_ = strategy
@@ -633,10 +513,29 @@ def main():
         if not args.no_extras and world == 1:
             try:
                 result['kernels'] = kernel_breakdown(dm, args.batch, device, batches[1]) if args.model == 'DeepFM' else {}
+                if not args.no_optimizer and strategy is None:
+                    # DeepModel.fit itself on the resident feed, metrics off (what a DeepTable.fit user gets): the first call
+                    # captures, the timed call reuses the captured loop; shuffled epochs, loss read back once per epoch
+                    keep_metrics, dm.config.metrics = dm.config.metrics, []
+                    try:
+                        dm.fit(feed, batch_size=args.batch, epochs=1, verbose=0, shuffle=True, steps_per_execution=spg)
+                        torch.cuda.synchronize()
+                        ep = max(2, min(20, args.steps // 10))
+                        t0 = time.perf_counter()
+                        dm.fit(feed, batch_size=args.batch, epochs=ep, verbose=0, shuffle=True, steps_per_execution=spg)
+                        torch.cuda.synchronize()
+                        dt_fit = time.perf_counter() - t0
+                        result['fit_rows_per_s'] = ep * (feed.n // args.batch) * args.batch / dt_fit
+                        result['fit_note'] = (f'DeepModel.fit(feed, epochs={ep}, steps_per_execution={spg}, shuffle=True), '
+                                              f'{feed.n // args.batch} steps per epoch, metrics off, wall clock incl. the '
+                                              f'per-epoch permutation and loss read-back')
+                    finally:
+                        dm.config.metrics = keep_metrics
                 if not args.no_optimizer:      # the same step without the Adam launches, for comparison
-                    fb = GraphedStep(dm, args.batch, device, with_optimizer=False, use_graph=not args.no_graph)
-                    fb.capture(batches)
-                    w2, _, _ = time_steps(fb, batches, args.steps, 5, barrier)
+                    fb = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=False, use_graph=not args.no_graph)
+                    fb.set_order(ring_order(feed, args.batch, 2 + spg + args.steps, device))
+                    fb.capture(warm_steps=2)
+                    w2, _, _ = time_steps(fb, args.steps, spg, barrier, device, spin=False)
                     result['fwd_bwd_only_rows_per_s'] = args.batch * args.steps / w2
             except Exception as e:   # diagnostics must not kill the contract line
                 result['extras_error'] = repr(e)

@@ -1,0 +1,352 @@
+# -*- coding:utf-8 -*-
+"""The compiled train loop: Keras' `model.compile(steps_per_execution=k)` (the knob of the reference's
+`DeepModel.__compile_model`, deeptables/models/deepmodel.py:319-346, driven by `keras.Model.fit`,
+deepmodel.py:114-129) on MI355X — `k` consecutive train steps captured ONCE into one hipGraph over static
+input slots and replayed by `DeepModel.fit`.
+
+Why: a fused DeepFM / DCN step is six launches of ~15-35 us; launched eagerly from Python the host cannot keep
+up (~3.5 us per launch + the interpreter), and even a one-step graph pays its fixed replay cost (~10 us of idle
+GPU between two replays) every step.  One graph of k steps keeps the launches of consecutive steps back to back.
+
+Data path (inputs never leave HBM): the epoch's row order is a device vector (`set_order`); before a replay the
+k*B indices of its steps are copied into the static `sel` vector (one stream-ordered copy), the graph's first
+nodes gather those rows of the resident feed (`training.TableBatches`, resident mode) into the slots, step i of
+the graph trains on slot rows [i*B, (i+1)*B).  Step counter, Adam's lr_t and the dropout seed live on the device
+and advance inside the graph, so every replay is a new step.
+
+Under a data-parallel strategy (`parallel.DataParallelStrategy`, world size > 1 or forced) RCCL collectives are
+not captured: the step is [graph: gather + forward + backward] -> exchange_gradients (eager) -> [graph: the
+optimizer launches]; with row-owned tables (`ShardedEmbeddingStrategy`) the step stays eager unless
+`graph_segments=True`.  k is 1 in both cases.
+"""
+import ctypes
+
+import torch
+
+from . import training
+
+
+def _hip_graph_upload(graph):
+    """hipGraphUpload of a captured torch graph onto the current stream: the first `replay()` then costs what every
+    later one costs (an un-uploaded 60-node graph pays ~60-200 us on its first launch).  Best effort: returns False when
+    the handle or the symbol is unavailable."""
+    try:
+        handle = graph.raw_cuda_graph_exec()
+        hip = ctypes.CDLL('libamdhip64.so')
+        fn = hip.hipGraphUpload
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        fn.restype = ctypes.c_int
+        return fn(ctypes.c_void_p(int(handle)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    except Exception:
+        return False
+
+
+class CompiledTrainLoop:
+    """`loop = CompiledTrainLoop(dm, feed, batch_size, steps_per_execution=10); loop.capture();
+    loop.set_order(perm or None); loop.run(n_steps)`.
+
+    feed: a resident `training.TableBatches`.  `run` executes exactly n_steps train steps from the current position of
+    the order vector: whole executions (k steps per replay) and, when n_steps is not a multiple of k, the remaining
+    steps eagerly through the same slots.  `on_execution(k_steps)` is called after every launch unit is enqueued (bench.py
+    records a HIP event there); `collect=True` keeps per-step (loss, logits, y) on the device for the epoch's metrics."""
+
+    def __init__(self, dm, feed, batch_size, steps_per_execution=10, with_optimizer=True, use_graph=True,
+                 graph_segments=False):
+        if not feed.resident:
+            raise ValueError('CompiledTrainLoop needs a device-resident feed (training.TableBatches(resident=True))')
+        self.dm, self.feed = dm, feed
+        self.B = int(batch_size)
+        self.with_optimizer = with_optimizer
+        self.use_graph = use_graph
+        self.graph_segments = graph_segments
+        self.strategy = dm.config.distribute_strategy
+        st = self.strategy
+        self.dp = st is not None and (st.world_size > 1 or getattr(st, 'force_dp', False) or getattr(st, 'force', False))
+        self.k = 1 if self.dp else max(1, int(steps_per_execution))
+        self.device = feed.device
+        n = self.k * self.B
+        self.sel = torch.zeros(n, dtype=torch.int64, device=self.device)
+        self.slots = [torch.empty((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=self.device) for b in feed.blocks]
+        self.slot_y = None if feed.y is None else \
+            torch.empty((n,) + tuple(feed.y.shape[1:]), dtype=feed.y.dtype, device=self.device)
+        self.order = None           # device int64 vector: the epoch's row order (None: 0, 1, 2, ...)
+        self.pos = 0                # next row of the order to train on
+        self.graph = None
+        self.opt_graph = None       # data parallel: the optimizer launches, captured after the gather buffers exist
+        self._dp_steps = 0
+        self._sparse_refs = None
+        self.logits = None          # [k, B, outputs] static: step i's logits
+        self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
+        self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] around fwd+bwd | exchange | optimizer (bench.py)
+        self._first_events = None
+        self.uploaded = False
+
+    # -- the feed ---------------------------------------------------------------------------------------------
+    def set_order(self, perm=None):
+        """the row order the following `run` calls walk (a device int64 permutation of the feed's rows, or None)"""
+        self.order = perm
+        self.pos = 0
+
+    def _select(self, steps):
+        """the next steps*B row indices -> the front of `sel` (stream-ordered copy, no host sync)"""
+        n = steps * self.B
+        if self.pos + n > self.rows_available():
+            raise IndexError('CompiledTrainLoop.run past the end of the order: call set_order() for the next epoch')
+        if self.order is None:
+            torch.arange(self.pos, self.pos + n, out=self.sel[:n])
+        else:
+            self.sel[:n].copy_(self.order[self.pos:self.pos + n])
+        self.pos += n
+
+    def rows_available(self):
+        return (self.feed.n if self.order is None else int(self.order.numel()))
+
+    def steps_left(self):
+        return (self.rows_available() - self.pos) // self.B
+
+    def _gather(self, steps=None):
+        n = (self.k if steps is None else steps) * self.B
+        for blk, slot in zip(self.feed.blocks, self.slots):
+            torch.index_select(blk, 0, self.sel[:n], out=slot[:n])
+        if self.slot_y is not None:
+            torch.index_select(self.feed.y, 0, self.sel[:n], out=self.slot_y[:n])
+
+    def _step_inputs(self, i):
+        s, e = i * self.B, (i + 1) * self.B
+        ins = [sl[s:e] for sl in self.slots]
+        yb = None if self.slot_y is None else self.slot_y[s:e]
+        wb = None
+        if self.feed.weighted:
+            wb, yb = yb[:, -1].contiguous(), yb[:, :-1].contiguous()
+            if self.feed.y_ndim == 1:
+                yb = yb.reshape(-1)
+        return ins, yb, wb
+
+    # -- one train step on slot i (what the graph holds) -------------------------------------------------------------
+    def _sharded(self):
+        st = self.strategy
+        return self.dp and getattr(st, 'sharded_embeddings', False) and st.active and self.dm.fused_plan() is not None
+
+    def _body(self, i, core_only=False):
+        dm = self.dm
+        ins, yb, wb = self._step_inputs(i)
+        if core_only:
+            # row-owned tables, graph capture: only the launches between the collectives (the step's kernels)
+            plan = dm.fused_plan()
+            dm.optimizer.zero_grad(flat=False)
+            loss, logit = plan.sharded_core(self.B, ins[1] if len(ins) > 1 else None, yb, self.strategy, wb)
+            dm.model._dt_flat_grad = plan.accum
+            return
+        fused_opt = self.with_optimizer and not self.dp
+        loss, logit = dm.forward_backward(ins, yb, wb, apply_rows=fused_opt and self.strategy is None,
+                                          logit_out=None if self.logits is None else self.logits[i])
+        if fused_opt:
+            dm.optimizer.step()             # single process: the optimizer step is part of the captured graph
+        used_plan = getattr(dm, '_step_used_plan', False)
+        if self.logits is None:             # first (eager) step: the static outputs of the k steps
+            self.logits = torch.empty((self.k,) + tuple(logit.shape), dtype=logit.dtype, device=logit.device)
+            self.losses = torch.zeros(self.k, dtype=torch.float32, device=logit.device)
+        if logit.data_ptr() != self.logits[i].data_ptr():
+            self.logits[i].copy_(logit)     # layer-by-layer path / row-owned tables: the step wrote its own buffer
+        if not used_plan:
+            self.losses[i].copy_(loss.reshape(()))
+        self._losses_from_logits = bool(used_plan)
+
+    def capture(self, warm_steps=2, collect=None):
+        """`warm_steps` eager steps on a side stream (lazy buffers, the optimizer's slot records) — they ARE train steps on
+        the next rows of the current order: the caller counts them (-> their number) — then the capture."""
+        dm = self.dm
+        dm.model.train()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warm_steps):
+                self._eager_steps(1, collect)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if not self.use_graph or (self._sharded() and not self.graph_segments):
+            return warm_steps
+        from .models.layers import MultiColumnEmbedding
+        emb_layers = [l for l in dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
+        core_only = self._sharded()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            if not core_only:
+                self._gather()
+            for i in range(self.k):
+                self._body(i, core_only=core_only)
+        self.graph = g
+        # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
+        # (rows, values) tensors and re-attach them after every replay (data parallel: the exchange reads them)
+        self._sparse_refs = [(l, {key: list(v) for key, v in l.sparse_grads.items()}) for l in emb_layers]
+        for layer in emb_layers:
+            if not self.dp and self.with_optimizer:
+                layer.sparse_grads.clear()
+        torch.cuda.synchronize()
+        self.uploaded = _hip_graph_upload(g)
+        torch.cuda.synchronize()
+        return warm_steps
+
+    # -- running ---------------------------------------------------------------------------------------------------
+    def _eager_steps(self, n, collect=None):
+        """n steps through the slots without the graph (one at a time: slot 0)"""
+        for _ in range(n):
+            self._select(1)
+            self._gather(1)
+            self._run_unit(eager=True)
+            if collect is not None:
+                self._collect(collect, 1)
+
+    def _run_unit(self, eager=False):
+        """one launch unit: a replay of k steps (or one eager step on slot 0) + under data parallel the exchange and the
+        optimizer"""
+        ev = None
+        if self.dp and self.phase_events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        g = None if eager else self.graph
+        if g is not None and self._sharded():
+            plan = self.dm.fused_plan()
+            self._gather()
+            plan.sharded_pre(self.slots[0][:self.B], self.strategy)
+            g.replay()
+            plan.sharded_post(self.B, self.strategy)
+        elif g is not None:
+            g.replay()
+            if self.dp or not self.with_optimizer:
+                for layer, refs in self._sparse_refs:
+                    layer.sparse_grads = {key: list(v) for key, v in refs.items()}
+        else:
+            self._body(0)
+        if self.dp:
+            if ev:
+                ev[1].record()
+            opt = self.dm.optimizer
+            self.strategy.exchange_gradients(self.dm.model, opt if self.with_optimizer else None)
+            if ev:
+                ev[2].record()
+            if self.with_optimizer:
+                if self.opt_graph is not None:
+                    hook, opt.pre_dense_hook = getattr(opt, 'pre_dense_hook', None), None
+                    if hook is not None:
+                        hook()          # the asynchronous dense all-reduce must have landed before the captured optimizer runs
+                    self.opt_graph.replay()
+                    for layer in getattr(opt, 'embedding_layers', []):
+                        layer.sparse_grads.clear()
+                elif self.use_graph and self._dp_steps >= 2 and (not self._sharded() or self.graph_segments):
+                    hook, opt.pre_dense_hook = getattr(opt, 'pre_dense_hook', None), None
+                    if hook is not None:
+                        hook()
+                    torch.cuda.synchronize()
+                    gopt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gopt):
+                        opt.step()
+                    self.opt_graph = gopt
+                    gopt.replay()
+                else:
+                    opt.step()          # first steps (slot buffers get allocated) and the eager row-owned step
+            self._dp_steps += 1
+            if ev:
+                ev[3].record()
+                self.phase_events.append(tuple(ev))
+
+    def run(self, n_steps, on_execution=None, collect=None):
+        """exactly n_steps train steps.  collect: a dict with lists 'loss', 'logit', 'y' that receive per-execution device
+        tensors ([k] losses, [k*B, ...] logits / labels) — the epoch's metrics read them once at its end."""
+        done = 0
+        while done < n_steps:
+            if self.graph is not None and n_steps - done >= self.k:
+                self._select(self.k)
+                first = self._first_events is None
+                if first:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                self._run_unit()
+                if first:
+                    e1.record()
+                    self._first_events = (e0, e1)
+                k = self.k
+            else:
+                self._select(1)
+                self._gather(1)
+                self._run_unit(eager=True)
+                k = 1
+            done += k
+            if collect is not None:
+                self._collect(collect, k)
+            if on_execution is not None:
+                on_execution(k)
+        return done
+
+    def first_replay_us(self):
+        """HIP-event time of the first replay of the captured graph (None: none yet)"""
+        if self._first_events is None:
+            return None
+        torch.cuda.synchronize()
+        return self._first_events[0].elapsed_time(self._first_events[1]) * 1e3
+
+    def _collect(self, out, k):
+        n = k * self.B
+        logits = self.logits[:k]
+        yk = wk = None
+        if self.slot_y is not None:
+            yk = self.slot_y[:n]
+            if self.feed.weighted:
+                wk, yk = yk[:, -1], yk[:, :-1]
+                if self.feed.y_ndim == 1:
+                    yk = yk.reshape(-1)
+        if getattr(self, '_losses_from_logits', False):
+            # a fused plan evaluates the loss inside its kernels (one word of its gradient buffer, overwritten by the
+            # next step): the epoch's loss curve is re-evaluated here from the k steps' logits, once per execution
+            z = logits.reshape(k, self.B, -1)
+            t = yk.reshape(k, self.B, -1).to(z.dtype)
+            if self.dm.loss_name == 'binary_crossentropy':
+                per = (torch.clamp(z, min=0) - z * t + torch.log1p(torch.exp(-z.abs()))).mean(-1)
+            else:
+                per = ((z - t) ** 2).mean(-1)
+            if wk is not None:
+                per = per * wk.reshape(k, self.B).to(z.dtype)
+            out['loss'].append(per.mean(-1))
+        else:
+            out['loss'].append(self.losses[:k].clone())
+        if out.get('want_outputs', True):
+            out['logit'].append(logits.reshape((n,) + tuple(logits.shape[2:])).clone())
+            out['y'].append(yk.clone())
+
+    def phase_times(self):
+        """mean microseconds of the three phases of a data-parallel step (HIP events on the launch stream; read after the
+        timed region): what a scaling run needs to diagnose itself"""
+        if not self.phase_events:
+            return None
+        torch.cuda.synchronize()
+        n = len(self.phase_events)
+        fb = sum(a.elapsed_time(b) for a, b, _, _ in self.phase_events) / n * 1e3
+        ex = sum(b.elapsed_time(c) for _, b, c, _ in self.phase_events) / n * 1e3
+        op = sum(c.elapsed_time(d) for _, _, c, d in self.phase_events) / n * 1e3
+        return {'fwd_bwd_us': fb, 'exchange_us': ex, 'opt_us': op, 'steps': n}
+
+
+def resolve_steps_per_execution(dm, requested, feed, batch_size, steps_per_epoch):
+    """`fit(steps_per_execution=...)`: an int k > 1 asks for the compiled loop; 'auto' (the default, also
+    `training.DEFAULT_STEPS_PER_EXECUTION`) compiles when the graph has a fused whole-step plan (known to be
+    capturable: no host synchronisation inside the step), the feed is device resident and an epoch holds at least two
+    executions; 1 / None / 0: eager steps."""
+    if requested is None:
+        requested = training.DEFAULT_STEPS_PER_EXECUTION
+    if requested in (0, 1, False):
+        return 1
+    if not getattr(feed, 'resident', False) or feed.device.type != 'cuda':
+        return 1
+    st = dm.config.distribute_strategy
+    if st is not None and st.world_size > 1:
+        import torch.distributed as dist
+        if dist.get_backend(st.group) != 'nccl':
+            return 1                      # host-staged collectives (gloo tests): nothing to gain from captured halves
+    if requested == 'auto':
+        if dm.fused_plan() is None or (feed.weighted and not getattr(dm.fused_plan(), 'takes_sample_weight', False)):
+            return 1
+        k = 10
+        while k > 1 and steps_per_epoch < 2 * k:
+            k //= 2
+        return max(k, 1)
+    return max(1, min(int(requested), int(steps_per_epoch)))

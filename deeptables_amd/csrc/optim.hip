@@ -568,7 +568,9 @@ extern "C" int dt_rows_compact(const int64_t* rows, const float* values, int64_t
     DT_REQUIRE(!seg_nseg || (seg_row && seg_off && seg_cnt && seg_list && seg_regions > 0 && seg_cap > 0),
                "dt_rows_compact: bad segment arrays");
     hipStream_t st = as_stream(stream);
-    hipMemsetAsync(counter2, 0, 2 * sizeof(int), st);
+    // only the slot counter restarts: counter2[1] (entries that did not fit) is a RUNNING total over the calls, so a host check
+    // after many steps still sees an overflow of any of them (the caller zeroes the pair once, when it allocates it)
+    hipMemsetAsync(counter2, 0, sizeof(int), st);
     hipMemsetAsync(out_rows, 0xff, (size_t)cap * sizeof(int64_t), st);          // -1: unused slots are skipped by every consumer
     const SegTail sg{seg_nseg, seg_row, seg_off, seg_cnt, seg_list, seg_regions, seg_cap};
     const int row_blocks = (int)((n_rows * lpr + 255) / 256);

@@ -335,8 +335,9 @@ class FusedDeepFM:
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
         return work
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None):
-        """-> (loss [1] view, logit [B,1]).  With backward=True fills `.grad` of every dense parameter
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None):
+        """-> (loss [1] view, logit [B,1]).  logit_out: a caller-owned [B,1] fp32 buffer the step writes its logits to (the
+        compiled loop keeps one per captured step) instead of the plan's own.  With backward=True fills `.grad` of every dense parameter
         (views of one static buffer) and registers the embedding table's sparse gradient.  apply_rows=True: the caller
         runs `optimizer.step()` right after this call, so the step may update the table rows looked up once itself
         (`_rows_in_step`); the registered sparse gradient then carries `fields = -2` (segments only)."""
@@ -356,6 +357,11 @@ class FusedDeepFM:
         sw = _row_weights(sample_weight, y)
         table = self.emb.tables[self.key]
         training = self.dm.model.training
+        logit = buf['logit']
+        if logit_out is not None:
+            if logit_out.shape != logit.shape or logit_out.dtype != logit.dtype or not logit_out.is_contiguous():
+                raise ValueError(f'logit_out must be a contiguous float32 {tuple(logit.shape)} tensor')
+            logit = logit_out
         dedupe = _dedupe_in_step(self, B, backward)
         opt = _rows_in_step(self, B, backward, apply_rows)
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
@@ -364,7 +370,7 @@ class FusedDeepFM:
                 ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
                 float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
                 ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
-                ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(logit), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
                 ptr(self.emb.oob_count) if self.emb.check_oob else None,
                 ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
         whole = False
@@ -403,7 +409,7 @@ class FusedDeepFM:
                                                    ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
                 table.grad = g
                 self.emb.sparse_grads.pop(self.key, None)
-        return self.loss_view, buf['logit']
+        return self.loss_view, logit
 
 
 _DCN_ACC_NAMES = ['dW1', 'dW2', 'db1', 'db2', 'dw3', 'dwo', 'dbo', 'loss', 'dgamma', 'dbeta', 'dcw', 'dcb']
@@ -521,7 +527,7 @@ class FusedDCN(FusedDeepFM):
             self._bufs[B] = b
         return b
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None):
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None):
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
@@ -534,6 +540,11 @@ class FusedDCN(FusedDeepFM):
         sw = _row_weights(sample_weight, y)
         table = self.emb.tables[self.key]
         training = self.dm.model.training
+        logit = buf['logit']
+        if logit_out is not None:
+            if logit_out.shape != logit.shape or logit_out.dtype != logit.dtype or not logit_out.is_contiguous():
+                raise ValueError(f'logit_out must be a contiguous float32 {tuple(logit.shape)} tensor')
+            logit = logit_out
         dedupe = _dedupe_in_step(self, B, backward)
         opt = _rows_in_step(self, B, backward, apply_rows)
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
@@ -542,7 +553,7 @@ class FusedDCN(FusedDeepFM):
                 ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
                 float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
                 ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.out.kernel), ptr(self.one), ptr(self.out.bias),
-                ptr(buf['logit']), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(logit), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
                 ptr(self.emb.oob_count) if self.emb.check_oob else None,
                 ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
         if opt is not None:      # the whole optimizer step inside the train step (see FusedDeepFM.run)
@@ -575,7 +586,7 @@ class FusedDCN(FusedDeepFM):
                                                    ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
                 table.grad = g
                 self.emb.sparse_grads.pop(self.key, None)
-        return self.loss_view, buf['logit']
+        return self.loss_view, logit
 
 
 def make_fused_plan(dm):

@@ -257,12 +257,13 @@ class DeepModel:
             self._fused_plan = make_fused_plan(self)
         return self._fused_plan
 
-    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False):
+    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None):
         """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
         sample_weight [B] (Keras fit's sample_weight x class_weight): the DeepFM / DCN plans scale each row's loss inside
         their loss block; other plans leave a weighted step to the layer-by-layer path.
         apply_rows=True is the caller's promise that `self.optimizer.step()` follows immediately (train_step): a fused
-        plan may then apply the row-sparse update of the table rows looked up once inside its own kernels."""
+        plan may then apply the row-sparse update of the table rows looked up once inside its own kernels.
+        logit_out: caller-owned buffer for a fused plan's logits (compiled.CompiledTrainLoop: one per captured step)."""
         plan = self.fused_plan() if self.model.training else None
         if plan is not None and sample_weight is not None and not getattr(plan, 'takes_sample_weight', False):
             plan = None
@@ -273,6 +274,8 @@ class DeepModel:
             cat = inputs[0]
             dense = inputs[1] if len(inputs) > 1 else None
             kw = {} if sample_weight is None else {'sample_weight': sample_weight}
+            if logit_out is not None:
+                kw['logit_out'] = logit_out
             loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows, **kw)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit
@@ -302,10 +305,20 @@ class DeepModel:
     def fit(self, X=None, y=None, batch_size=128, epochs=1, verbose=1, callbacks=None, validation_split=0.2,
             validation_data=None, shuffle=True, class_weight=None, sample_weight=None, initial_epoch=0,
             steps_per_epoch=None, validation_steps=None, validation_freq=1, max_queue_size=10, workers=1,
-            use_multiprocessing=False):
-        n_fit_rows, tr_i = len(X), None
+            use_multiprocessing=False, steps_per_execution=None):
+        """deepmodel.py:114-129 (`model.fit`).  steps_per_execution (Keras' `model.compile` argument, deepmodel.py:319-346):
+        k > 1 trains through compiled.CompiledTrainLoop — k consecutive train steps captured into ONE hipGraph over static
+        input slots the device-resident feed fills, replayed steps_per_epoch // k times per epoch; None: the module default
+        (`training.DEFAULT_STEPS_PER_EXECUTION`, 'auto' = compiled when the graph has a fused whole-step plan); 1: eager."""
+        feed = X if isinstance(X, training.TableBatches) else None    # a ready (device-resident) feed: trained on as it is
+        if feed is not None:
+            if validation_data is None:
+                validation_split = 0
+            if class_weight is not None or sample_weight is not None:
+                raise ValueError('fit(feed): per-row weights belong into the feed (TableBatches(sample_weight=...))')
+        n_fit_rows, tr_i = (feed.n if feed is not None else len(X)), None
         if validation_data is None:
-            n = len(X)
+            n = n_fit_rows
             n_val = int(math.ceil(n * validation_split)) if validation_split else 0
             if n_val > 0:
                 # under a distribute strategy every rank must hold out the SAME rows (one partition, then sharded)
@@ -328,7 +341,7 @@ class DeepModel:
         # labels; reference deeptable.py:354-365 passes both through to keras)
         weights = None
         if class_weight is not None or sample_weight is not None:
-            weights = np.ones(len(X), dtype=np.float32) if sample_weight is None else \
+            weights = np.ones(n_fit_rows if tr_i is None else len(tr_i), dtype=np.float32) if sample_weight is None else \
                 np.asarray(sample_weight, dtype=np.float32).reshape(-1).copy()
             if sample_weight is not None:
                 # the caller's weights belong to the rows as passed in: checked against THAT length, then sliced with the
@@ -350,21 +363,24 @@ class DeepModel:
             self.build(strategy.device if strategy is not None else None)
         if strategy is not None:
             strategy.broadcast_parameters(self.model)
-            if weights is not None:
+            if feed is not None:
+                pass                                # a ready feed holds this rank's rows already
+            elif weights is not None:
                 (X, y), weights = strategy.shard(X, y), strategy.shard(weights, weights)[0]
             else:
                 X, y = strategy.shard(X, y)
-        train = training.TableBatches(X, y, self.categorical_columns, self.continuous_columns, self.device,
-                                      self.task, self.num_classes,
-                                      var_len_categorical_columns=self.var_len_categorical_columns,
-                                      resident=getattr(self, 'feed_resident', None), sample_weight=weights)
+        train = feed if feed is not None else \
+            training.TableBatches(X, y, self.categorical_columns, self.continuous_columns, self.device,
+                                  self.task, self.num_classes,
+                                  var_len_categorical_columns=self.var_len_categorical_columns,
+                                  resident=getattr(self, 'feed_resident', None), sample_weight=weights)
         val = None
         if X_val is not None and len(X_val) > 0:
             val = training.TableBatches(X_val, y_val, self.categorical_columns, self.continuous_columns,
                                         self.device, self.task, self.num_classes,
                                         var_len_categorical_columns=self.var_len_categorical_columns)
         if steps_per_epoch is None:
-            steps_per_epoch = max(len(X) // batch_size, 1)
+            steps_per_epoch = max(train.n // batch_size, 1)
         history = training.History()
         metrics = list(self.config.metrics or [])
         stop = False
@@ -373,11 +389,37 @@ class DeepModel:
                 cb.set_model(self)
             if hasattr(cb, 'on_train_begin'):
                 cb.on_train_begin()
+        from .. import compiled
+        bs = min(batch_size, train.n)
+        spe = compiled.resolve_steps_per_execution(self, steps_per_execution if steps_per_execution is not None
+                                                   else getattr(self, 'steps_per_execution', None),
+                                                   train, bs, steps_per_epoch)
+        loop = None
+        if spe > 1 and train.n >= bs:
+            loop = getattr(self, 'compiled_loop', None)       # the same feed object again: the captured graph is reused
+            if loop is None or loop.feed is not train or loop.B != bs or loop.k != (1 if loop.dp else spe):
+                loop = compiled.CompiledTrainLoop(self, train, bs, spe)
+        self.compiled_loop = loop           # (for callers that look: None = eager steps)
+        want_out = bool(metrics)
         for epoch in range(initial_epoch, epochs):
             self.model.train()
             losses, probs, ys = [], [], []
             step = 0
-            while step < steps_per_epoch:
+            if loop is not None:
+                # the compiled loop: the epoch's order is ONE device permutation (drawn exactly where the eager feed draws
+                # its own: same batches for the same seed), walked k steps per replay; a pass over the table ends the order
+                col = {'loss': losses, 'logit': probs, 'y': ys, 'want_outputs': want_out}
+                while step < steps_per_epoch:
+                    loop.set_order(train._permutation(None) if shuffle else None)
+                    if loop.graph is None and loop.logits is None:
+                        step += loop.capture(warm_steps=min(2, steps_per_epoch - step, loop.steps_left()), collect=col)
+                    n = min(steps_per_epoch - step, loop.steps_left())
+                    if n <= 0:
+                        break
+                    step += loop.run(n, collect=col)
+                losses = [torch.cat([l.reshape(-1) for l in losses])] if losses else []
+                probs = [self._activate(p) for p in probs]
+            while loop is None and step < steps_per_epoch:
                 progressed = False
                 for ins, yb in train.iterate(min(batch_size, train.n), shuffle, drop_remainder=True):
                     wb = None
@@ -395,7 +437,10 @@ class DeepModel:
                         break
                 if not progressed:
                     break
-            logs = {'loss': float(torch.stack(losses).mean().item()) if losses else float('nan')}
+            if strategy is not None and getattr(strategy, 'sparse_bucket_ratio', 1.0) < 1.0 and \
+                    hasattr(strategy, 'check_sparse_overflow'):
+                strategy.check_sparse_overflow()       # a bucket that dropped entries in ANY step of the epoch: fail loudly
+            logs = {'loss': float(torch.cat([l.reshape(-1) for l in losses]).mean().item()) if losses else float('nan')}
             if probs:
                 yp, yt = torch.cat(probs).cpu().numpy(), torch.cat(ys).cpu().numpy()
                 for m in metrics:
@@ -518,6 +563,7 @@ class DeepModel:
     def release(self):
         self.model = None
         self.optimizer = None
+        self.compiled_loop = None
 
 
 class ModelDesc:

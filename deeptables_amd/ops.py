@@ -591,17 +591,26 @@ def autoint_dropout_keep(seed, B, H, F, rate, device='cpu'):
 
 
 _AUTOINT_WS = {}
+_AUTOINT_WS_RETIRED = []
 
 
 def _autoint_ws(B, D, device, nbytes=None, tag='w'):
-    """per-block partials of dt_autoint_bwd_w / dt_autoint_fwd_bn: one buffer per (kind, size, device, STREAM) — a partial
-    buffer is written and consumed by two launches of the same call, so calls on one stream may share it; calls on
-    different streams must not"""
+    """per-block partials of dt_autoint_bwd_w / dt_autoint_fwd_bn: ONE grow-only buffer per (kind, device, STREAM) — a
+    partial buffer is written and consumed by two launches of the same call, so calls on one stream may share it; calls
+    on different streams must not.  Keyed without the size: a ragged last batch or a validation batch size reuses the
+    buffer (reallocated only when a LARGER one is needed), instead of pinning a new one per distinct B."""
     n = int(lib().dt_autoint_bwd_workspace_bytes(int(B), int(D))) if nbytes is None else int(nbytes)
-    key = (tag, n, str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    if key not in _AUTOINT_WS:
-        _AUTOINT_WS[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
-    return _AUTOINT_WS[key]
+    key = (tag, str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _AUTOINT_WS.get(key)
+    if buf is None or buf.numel() * 4 < n:
+        if buf is not None:
+            # a captured hipGraph may hold the old buffer's address: it stays alive (growth is geometric, so only a few
+            # are ever retired)
+            _AUTOINT_WS_RETIRED.append(buf)
+            n = max(n, int(buf.numel() * 4 * 1.5))
+        buf = torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+        _AUTOINT_WS[key] = buf
+    return buf
 
 
 class _AutoIntLayer(torch.autograd.Function):

@@ -147,8 +147,18 @@ class DataParallelStrategy:
         """SparseRowGrad -> SparseRowGrad of all ranks' rows (values pre-divided by world size).  With
         assume_uniform_batches the results live in persistent buffers (one set per `tag`)."""
         W = self.world_size
+        if getattr(grad, 'fields', None) == -2:
+            raise RuntimeError('a sparse gradient whose rows were already applied inside the train step '
+                               '(forward_backward(apply_rows=True)) cannot be exchanged: apply_rows belongs to the '
+                               'single-process train_step only')
         if W == 1 and not getattr(self, 'force_dp', False):
             return grad
+        if self.sparse_bucket_ratio < 1.0 and getattr(grad, 'segments', None) is None and \
+                getattr(grad, 'fields', None) != -1 and not getattr(self, '_warned_ratio', False):
+            import warnings
+            warnings.warn('sparse_bucket_ratio < 1 is ignored for a sparse gradient without the in-step dedupe '
+                          '(B > 8192, DT_AMD_FUSED_DEDUPE=0 or a layer-by-layer graph): per-lookup entries are gathered')
+            self._warned_ratio = True
         if getattr(grad, 'segments', None) is not None and self.sparse_bucket_ratio >= 1.0:
             # a fused step's deduplicated gradient, bucket as large as the lookups: sum every segment into its first
             # member's entry IN PLACE (no packing, no slot counter — 18 K returning atomics on one word cost 200 us) and
@@ -165,10 +175,20 @@ class DataParallelStrategy:
             from . import ops
             n, D = grad.rows.numel(), grad.values.shape[-1]
             dev = grad.rows.device
+            if W > 1 and not self.assume_uniform_batches:
+                # the bucket's size must be the same on every rank (all_gather_into_tensor): derive it from the largest
+                # local lookup count (one small all-reduce + a host read per step — the price of ragged batches)
+                cdev = 'cpu' if dist.get_backend(self.group) == 'gloo' else dev
+                nmax = torch.tensor([n], dtype=torch.int64, device=cdev)
+                dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
+                n = int(nmax.item())
             cap = max(1, int(np.ceil(self.sparse_bucket_ratio * n)))
             b_rows = self._persistent(('b_rows', tag), (cap,), torch.int64, dev)
             b_vals = self._persistent(('b_vals', tag), (cap, D), torch.float32, dev)
+            fresh = ('b_ctr', tag) not in {k[0] for k in getattr(self, '_bufs', {})}
             ctr = self._persistent(('b_ctr', tag), (2,), torch.int32, dev)
+            if fresh:
+                ctr.zero_()           # [1] is a running total of dropped entries (dt_rows_compact resets only [0])
             if not any(c is ctr for c in self._overflow_counters):
                 self._overflow_counters.append(ctr)
             ops.compact_rows(grad, cap, 1.0 / W, b_rows, b_vals, ctr)

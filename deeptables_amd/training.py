@@ -8,9 +8,18 @@ import math
 import numpy as np
 import torch
 
+import os
+
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .utils import consts
+
+# `DeepModel.fit(steps_per_execution=None)` falls back to this (Keras' `model.compile(steps_per_execution=...)`,
+# deepmodel.py:319-346): 'auto' = k consecutive train steps per captured hipGraph (compiled.CompiledTrainLoop) when the
+# graph has a fused whole-step plan and the feed is device resident, eager steps otherwise; an int forces k; 1 = eager
+DEFAULT_STEPS_PER_EXECUTION = os.environ.get('DT_AMD_STEPS_PER_EXECUTION', 'auto')
+if DEFAULT_STEPS_PER_EXECUTION != 'auto':
+    DEFAULT_STEPS_PER_EXECUTION = int(DEFAULT_STEPS_PER_EXECUTION)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -217,6 +226,15 @@ class KerasAdam:
         """flat=True: members of the registered flat group get their (zeroed) views of the flat gradient buffer as
         `.grad` — backward kernels and autograd accumulate straight into it; flat=False: the caller (a fused step)
         fills the flat buffer itself."""
+        # forward_backward(apply_rows=True) is a promise that step() follows at once: the rows looked up once were already
+        # updated inside the step.  A gradient of that kind still pending here means the promise was broken (the segments and
+        # the dense parameters never got their half of the update): fail loudly instead of training on half-applied steps
+        if not self._applied_in_step:
+            for layer in self.embedding_layers:
+                for grads in layer.sparse_grads.values():
+                    if any(getattr(g, 'fields', None) == -2 for g in grads):
+                        raise RuntimeError('forward_backward(apply_rows=True) was not followed by optimizer.step(): the '
+                                           'table rows looked up once are updated, the segments and dense parameters are not')
         self._applied_in_step = False
         for p in self.params:
             p.grad = None
@@ -528,6 +546,22 @@ class TableBatches:
             self._ring = max(2, int(ring))
             self._staging = None
             self._copy_stream = torch.cuda.Stream(self.device) if pin else None
+
+    @classmethod
+    def from_device(cls, blocks, kinds, y=None, y_ndim=None, weighted=False):
+        """A resident feed over tensors that already live on the device (a synthetic table generated there, bench.py):
+        blocks in model input order (cat ids int32 [N,F], var-len id blocks, continuous blocks float32), kinds the matching
+        'cat' / 'var' / 'cont' tags, y float32 [N] or [N, outputs] (its last column the per-row weight when `weighted`)."""
+        self = cls.__new__(cls)
+        self.n = int(blocks[0].shape[0])
+        self.weighted = bool(weighted)
+        self.device = blocks[0].device
+        self.kinds = list(kinds)
+        self.blocks = [b.contiguous() for b in blocks]
+        self.y = None if y is None else y.contiguous()
+        self.y_ndim = y_ndim if y_ndim is not None else (None if y is None else y.dim())
+        self.resident = True
+        return self
 
     # kept for callers that look at the pieces
     @property

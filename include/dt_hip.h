@@ -256,8 +256,9 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
  * tf.distribute.MirroredStrategy all-gathers for an IndexedSlices gradient, deepmodel.py:88-103): a fused step's sparse
  * gradient (rows looked up once as entries of (rows, values), rows looked up several times as segments — dt_deepfm_train_step)
  * becomes UNIQUE (row, summed gradient * scale) entries packed at the front of out_rows [cap] / out_vals [cap, D];
- * unused slots hold row -1.  counter2 (two device ints): [0] = entries produced, [1] = entries dropped because they did
- * not fit `cap` (check on the host outside the step).  seg_* as in dt_adam_rows_step_seg (seg_nseg NULL: no segments). */
+ * unused slots hold row -1.  counter2 (two device ints, zeroed by the caller once): [0] = entries produced by THIS call
+ * (reset by every call), [1] = entries dropped because they did not fit `cap`, a RUNNING total over all calls (check it on
+ * the host outside the step, at any later time).  seg_* as in dt_adam_rows_step_seg (seg_nseg NULL: no segments). */
 /* dt_rows_merge_segments — the same bucket without packing (no slot counter): in place, every segment's members are summed
  * into the gradient row of its FIRST member, whose entry of `rows` gets the table row back (the other members keep -1):
  * (rows, values) then holds one entry per distinct row of the rank in its original [.., fields] layout. */

@@ -1,0 +1,150 @@
+# -*- coding:utf-8 -*-
+"""GPU: `DeepModel.fit(steps_per_execution=k)` — k consecutive train steps per captured hipGraph over static input slots
+(deeptables_amd/compiled.py; Keras' `model.compile(steps_per_execution=...)`, reference deepmodel.py:319-346 driven by
+`model.fit`, deepmodel.py:114-129) — must train exactly like the eager step-by-step `fit`: same batches for the same
+seed, same weights after several shuffled epochs, same loss curve and metrics."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F, ND, D, V = 8, 3, 16, 40
+
+
+def _frame(n, seed=0, task='binary'):
+    rng = np.random.RandomState(seed)
+    df = pd.DataFrame({f'C{i}': rng.randint(0, V + i, n) for i in range(F)})
+    for j in range(ND):
+        df[f'I{j}'] = rng.randn(n).astype(np.float32)
+    y = (rng.rand(n) < 0.3).astype(np.float32) if task == 'binary' else rng.randn(n).astype(np.float32)
+    return df, y
+
+
+def _model(net, task='binary', seed=4, **extra):
+    from deeptables_amd import functional
+    from deeptables_amd.models import ModelConfig, DeepModel, deepnets
+    from deeptables_amd.models.metainfo import CategoricalColumn, ContinuousColumn
+    functional.set_seed(seed)
+    conf = ModelConfig(nets=getattr(deepnets, net), fixed_embedding_dim=True, embeddings_output_dim=D, embedding_dropout=0,
+                       metrics=['AUC'] if task == 'binary' else ['mse'], **extra)
+    cats = [CategoricalColumn(f'C{i}', V + i, D) for i in range(F)]
+    conts = [ContinuousColumn('input_continuous_all', [f'I{j}' for j in range(ND)])]
+    dm = DeepModel(task, 2 if task == 'binary' else 1, conf, cats, conts)
+    dm.build()
+    return dm
+
+
+def _fit(dm, df, y, spe, **kw):
+    torch.manual_seed(123)                      # the epoch permutations come from the device generator
+    torch.cuda.manual_seed_all(123)
+    return dm.fit(df, y, batch_size=64, epochs=3, verbose=0, validation_split=0, shuffle=True,
+                  steps_per_execution=spe, **kw)
+
+
+def _same(a, b, tol=2e-6):
+    for (n0, p0), (n1, p1) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert n0 == n1
+        err = (p0 - p1).abs().max().item()
+        assert err <= tol, (n0, err)
+
+
+@pytest.mark.parametrize('sparse', [True, False])
+@pytest.mark.parametrize('net,task', [('DeepFM', 'binary'), ('DCN', 'binary'), ('DeepFM', 'regression')])
+def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
+    from deeptables_amd.models import layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    if sparse:
+        dl.DENSE_GRAD_MAX_ELEMS = 0             # row-sparse tables: the optimizer runs inside the fused step's launches
+    try:
+        df, y = _frame(64 * 23 + 17, task=task)     # 23 steps per epoch: two replays of 10 + three eager steps
+        extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+        eager, graphed = _model(net, task, **extra), _model(net, task, **extra)
+        h0 = _fit(eager, df, y, 1)
+        h1 = _fit(graphed, df, y, 10)
+        assert eager.compiled_loop is None
+        loop = graphed.compiled_loop
+        assert loop is not None and loop.graph is not None and loop.k == 10
+        assert type(graphed.fused_plan()).__name__ == ('FusedDCN' if net == 'DCN' else 'FusedDeepFM')
+        _same(eager, graphed)
+        assert eager.optimizer.t == graphed.optimizer.t == 3 * 23
+        assert np.allclose(h0.history['loss'], h1.history['loss'], atol=2e-6), (h0.history, h1.history)
+        key = 'auc' if task == 'binary' else 'mse'
+        assert np.allclose(h0.history[key], h1.history[key], atol=1e-5), (h0.history, h1.history)
+        # predictions of the graphed model agree with the eager one's
+        assert np.abs(eager.predict(df.iloc[:200]) - graphed.predict(df.iloc[:200])).max() < 1e-5
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+def test_auto_steps_per_execution_compiles_fused_plans_only(dev):
+    """the default ('auto'): a graph with a whole-step plan trains through the compiled loop, others step eagerly"""
+    df, y = _frame(64 * 40)
+    dm = _model('DeepFM')
+    dm.fit(df, y, batch_size=64, epochs=1, verbose=0, validation_split=0)
+    assert dm.compiled_loop is not None and dm.compiled_loop.graph is not None and dm.compiled_loop.k == 10
+    other = _model('AFM')
+    other.fit(df, y, batch_size=64, epochs=1, verbose=0, validation_split=0)
+    assert other.compiled_loop is None
+    short = _model('DeepFM')
+    short.fit(df.iloc[:64 * 3], y[:64 * 3], batch_size=64, epochs=1, verbose=0, validation_split=0)
+    assert short.compiled_loop is None              # three steps per epoch: nothing to replay
+
+
+def test_graphed_fit_with_sample_weights_and_validation(dev):
+    """Keras sample_weight x class_weight ride as the feed's last label column into the captured steps; validation runs
+    between the replayed epochs"""
+    from deeptables_amd.models import layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    try:
+        df, y = _frame(64 * 30)
+        w = np.random.RandomState(5).rand(len(df)).astype(np.float32) + 0.5
+        eager, graphed = _model('DeepFM'), _model('DeepFM')
+        dv, yv = _frame(300, seed=9)
+        h0 = _fit(eager, df, y, 1, sample_weight=w, class_weight={0: 1.0, 1: 2.0}, validation_data=(dv, yv))
+        h1 = _fit(graphed, df, y, 5, sample_weight=w, class_weight={0: 1.0, 1: 2.0}, validation_data=(dv, yv))
+        assert graphed.compiled_loop is not None and graphed.compiled_loop.k == 5
+        _same(eager, graphed)
+        assert np.allclose(h0.history['loss'], h1.history['loss'], atol=2e-6)
+        assert np.allclose(h0.history['val_loss'], h1.history['val_loss'], atol=2e-6)
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+def test_layer_by_layer_graph_is_capturable_on_request(dev):
+    """an explicit steps_per_execution also captures graphs without a whole-step plan (the autograd path through the
+    layer kernels): xDeepFM, four steps per replay"""
+    df, y = _frame(64 * 12)
+    cin = dict(cin_params={'cross_layer_size': (16, 16), 'activation': 'relu', 'use_residual': False, 'use_bias': False,
+                           'direct': False, 'reduce_D': False})
+    eager, graphed = _model('xDeepFM', **cin), _model('xDeepFM', **cin)
+    h0 = _fit(eager, df, y, 1)
+    h1 = _fit(graphed, df, y, 4)
+    assert graphed.compiled_loop is not None and graphed.compiled_loop.graph is not None
+    _same(eager, graphed, tol=5e-6)
+    assert np.allclose(h0.history['loss'], h1.history['loss'], atol=5e-6)
+
+
+def test_compiled_loop_on_a_device_feed_reuses_its_graph(dev):
+    """bench.py's use: `fit(feed)` on a ready device-resident TableBatches; the second call replays the first call's graph"""
+    from deeptables_amd.training import TableBatches
+    from deeptables_amd.models import layers as dl
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    try:
+        g = torch.Generator().manual_seed(1)
+        n = 64 * 20
+        idx = torch.stack([torch.randint(0, V + i, (n,), generator=g) for i in range(F)], 1).int().to(dev)
+        dense = torch.randn(n, ND, generator=g).to(dev)
+        y = (torch.rand(n, 1, generator=g) < 0.3).float().to(dev)
+        feed = TableBatches.from_device([idx, dense], ['cat', 'cont'], y, y_ndim=2)
+        dm = _model('DeepFM')
+        dm.fit(feed, batch_size=64, epochs=1, verbose=0, steps_per_execution=5)
+        loop = dm.compiled_loop
+        t1 = dm.optimizer.t
+        dm.fit(feed, batch_size=64, epochs=2, verbose=0, steps_per_execution=5)
+        assert dm.compiled_loop is loop and dm.optimizer.t == t1 + 40
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old

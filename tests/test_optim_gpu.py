@@ -280,6 +280,12 @@ def test_rows_compact_packs_unique_rows_with_summed_gradients(dev, monkeypatch, 
     torch.cuda.synchronize()
     assert int(ctr2[0]) == produced and int(ctr2[1]) == produced - cap
     assert bool((out2.rows >= 0).all())
+    # the dropped count is a RUNNING total over the calls on one counter (a host check after many steps must still see the
+    # overflow of any of them); the slot counter restarts with every call
+    ops.compact_rows(g, cap, counter=ctr2)
+    ops.compact_rows(g, n, counter=ctr2)
+    torch.cuda.synchronize()
+    assert int(ctr2[0]) == produced and int(ctr2[1]) == 2 * (produced - cap)
     # the in-place form (the exchange's default): segments summed into their first member's entry, holes elsewhere
     merged = ops.merge_segments_(g)
     torch.cuda.synchronize()
