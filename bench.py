@@ -241,6 +241,16 @@ def parity_leg(args, device):
                 ri['ok'] = headline.rows_in_step_ok(ri)
                 ok = ok and ri['ok']
                 out[kind]['in_step_optimizer'] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in ri.items()}
+                # ... and the timed path against the ORACLE itself: two consecutive steps with the optimizer inside the step's
+                # launches, rows / slots / dense parameters against keras_adam_step on the float64 oracle gradient and the
+                # oracle's own running m / v (warm slots in the second step) — oracle/headline.check_in_step_vs_oracle
+                N_BATCHES = 2
+                b3 = make_batches(args.batch, device, seed=777, dist_kind=kind)
+                N_BATCHES = 1
+                rv = headline.check_in_step_vs_oracle(dm, b3)
+                ok = ok and rv['ok']
+                out[kind]['in_step_optimizer']['vs_oracle'] = {k: (float(f'{v:.3e}') if isinstance(v, float) else v)
+                                                               for k, v in rv.items()}
     finally:
         N_BATCHES = keep
     out['tolerance'] = ('gather bit-exact; logits 1e-4 (north_star; 1e-2 in bf16 mode) of max(1, max |logit|): a 6-layer Cross '

@@ -54,11 +54,13 @@ def oracle_train_step(dm, idx, dense, y, dtype=torch.float64, tables_cpu=None):
     dn = None if dense is None else dense.detach().cpu().to(dtype)
     R.RELU_PROBE = probe = []
     R.RELU_NEAR = near = []
+    R.RELU_TOTAL = total = []
     try:
         logit, _ = R.model_forward(w, idx_c.to(torch.float32), dn, dm.config.nets, bridge.oracle_config(dm), training=True)
     finally:
         R.RELU_PROBE = None
         R.RELU_NEAR = None
+        R.RELU_TOTAL = None
     loss = R.binary_crossentropy_from_logits(logit, y.detach().cpu().to(dtype))
     loss.backward()
     B, F = idx_c.shape
@@ -72,6 +74,7 @@ def oracle_train_step(dm, idx, dense, y, dtype=torch.float64, tables_cpu=None):
         rows[:, f] = torch.where(ok.reshape(-1), ids.reshape(-1).long() + offs[f], torch.full((B,), -1, dtype=torch.int64))
         grads.append(r.grad.reshape(B, 1, -1))
     return {'min_abs_relu_input': min(probe) if probe else float('inf'), 'relu_units_near_kink': int(sum(near)),
+            'relu_units': int(sum(total)),
             'logit': logit.detach(), 'loss': float(loss.detach()), 'weights': w, 'rows': rows,
             'row_grads': torch.cat(grads, 1), 'tables_cpu': tables_cpu, 'row_offsets': offs}
 
@@ -211,6 +214,7 @@ def _check_once(dm, batch, adam, lr, accept):
     res['dense_grad_l2_rel_err'] = worst_l2
     res['dense_grads_checked'] = len(pairs)
     res['relu_units_near_kink'] = ref['relu_units_near_kink']
+    res['relu_units'] = ref['relu_units']
     # (3) the sparse gradient, merged per table row on both sides
     sg = emb.sparse_grads[key]
     # rows looked up several times travel as segments (ops.SparseRowGrad.segments): one entry per lookup again
@@ -490,8 +494,9 @@ def verdict(res, grad_tol=2e-4, bf16=False):
     largest entry.  Relu kinks: when the float64 oracle saw relu inputs within float32 rounding of zero
     (`relu_units_near_kink` > 0: |input| < 1e-6 of the layer's rms) the two precisions legitimately take different
     derivatives at those units, and each such unit moves one rank-1 term of a weight gradient (1 / sqrt(#rows) of a column
-    of it).  Then — and only then — the gradients are judged by their relative L2 error (< 2e-3) with the largest single
-    entry within 5e-2; the figures are all reported.
+    of it).  Then — and only then — the gradients are judged by their relative L2 error against a bound that follows from
+    the COUNT of such units (4 sqrt(2 n / relu units), at most 2e-3) with the largest single entry within 5e-2; the figures
+    are all reported.
     bf16=True (the opt-in bf16 CIN contractions, DT_AMD_CIN_DTYPE=bf16): north_star's bf16 bar — logits within 1e-2 — and
     the gradients by their relative L2 error (< 2e-2, largest single entry within 1e-1): every CIN product was rounded to 8
     mantissa bits on the way in."""
@@ -504,8 +509,16 @@ def verdict(res, grad_tol=2e-4, bf16=False):
     ok = bool(res['gather_bit_exact'] and res['rows_identical'] and
               res['max_abs_logit_err'] < 1e-4 * max(1.0, res['max_abs_logit']))
     strict = res['dense_grad_rel_err'] < grad_tol and res['rows_grad_rel_err'] < grad_tol
-    if res.get('relu_units_near_kink', 0) > 0 and not strict:
-        loose = (res['dense_grad_l2_rel_err'] < 2e-3 and res['rows_grad_l2_rel_err'] < 2e-3 and
+    near = res.get('relu_units_near_kink', 0)
+    if near > 0 and not strict:
+        # what the COUNTED kink units can contribute, not a blanket allowance: one flipped relu' changes one sample's term of
+        # one column of a weight gradient — relative L2 ~ sqrt(2 / units of that layer) of the tensor — so n independent
+        # kinks among `relu_units` evaluated units allow sqrt(2 n / units), taken with a safety factor of 4 (units differ in
+        # size) and never above the old blanket 2e-3; the largest single entry stays within 5e-2 (one sample's term against
+        # a column summed over the batch).  A gradient defect of a few percent fails this whatever the kink count is.
+        import math
+        l2_tol = min(2e-3, max(grad_tol, 4.0 * math.sqrt(2.0 * near / max(res.get('relu_units', 0), 1))))
+        loose = (res['dense_grad_l2_rel_err'] < l2_tol and res['rows_grad_l2_rel_err'] < l2_tol and
                  res['dense_grad_rel_err'] < 5e-2 and res['rows_grad_rel_err'] < 5e-2)
-        return ok and loose, 'kink-aware (L2 2e-3, max 5e-2)'
+        return ok and loose, f'kink-aware ({near} of {res.get("relu_units", 0)} relu units near the kink: L2 {l2_tol:.1e}, max 5e-2)'
     return ok and strict, f'strict ({grad_tol:g} of the tensor max)'

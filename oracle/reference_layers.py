@@ -137,6 +137,7 @@ def outer_product(xs, kernel, kernel_type='mat'):
 # set to a list by oracle/headline.py: every relu evaluation appends min |input|
 RELU_PROBE = None
 RELU_NEAR = None        # set to a list next to RELU_PROBE: per relu evaluation, how many inputs lie within 1e-6 rms of zero
+RELU_TOTAL = None       # set to a list next to RELU_PROBE: per relu evaluation, how many inputs it had
 
 
 def _activation(name):
@@ -150,6 +151,8 @@ def _activation(name):
                     RELU_PROBE.append(float(a.min()))
                     if RELU_NEAR is not None:   # units within float32 rounding of the kink: |input| < 1e-6 of the tensor's rms
                         RELU_NEAR.append(int(((a > 0) & (a < 1e-6 * float(a.pow(2).mean().sqrt()))).sum()))
+                    if RELU_TOTAL is not None:
+                        RELU_TOTAL.append(int(a.numel()))
                 return torch.relu(t)
             return probed_relu
         return torch.relu
