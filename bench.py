@@ -361,6 +361,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'xDeepFM', 'AutoInt', 'DCN', 'AFM', 'FiBiNet', 'FGCNN', 'PNN'])
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
+    ap.add_argument('--tower', default=None, choices=['f32', 'bf16x3'],
+                    help="dnn_params['mfma_dtype'] of the fused DeepFM / DCN step: exact-fp32 MFMA or the split-bf16 tower "
+                         "(csrc/tower_x3.h); default: the library's")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--steps-per-graph', type=int, default=10,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
@@ -422,6 +425,10 @@ def main():
             'DCN': deepnets.DCN, 'AFM': deepnets.AFM, 'FiBiNet': deepnets.FiBiNet, 'FGCNN': deepnets.FGCNN,
             'PNN': deepnets.PNN}[args.model]
     dim = 32 if args.model == 'AutoInt' else D
+    if args.tower is not None:
+        mp = dict(MODEL_PARAMS.get(args.model) or {})
+        mp['dnn_params'] = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': args.tower}
+        MODEL_PARAMS[args.model] = mp
     parity = None
     if rank == 0 and world == 1 and not args.no_parity and args.model in ('DeepFM', 'DCN', 'xDeepFM', 'AutoInt'):
         try:
@@ -481,7 +488,9 @@ def main():
                        'timed_object': 'deeptables_amd.compiled.CompiledTrainLoop (DeepModel.fit steps_per_execution)',
                        'graph_uploaded_before_first_replay': bool(loop.uploaded),
                        'optimizer_in_timed_region': not args.no_optimizer,
-                       'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None},
+                       'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None,
+                       'tower_mfma': ('bf16x3 (split-bf16 operands, three bf16 MFMAs per product, fp32 accumulate)'
+                                      if getattr(dm.fused_plan(), 'tower_flag', 0) else 'f32 (exact)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          # the PMC passes were taken on the single-process six-launch step: no figure for the N > 1 step structures
@@ -526,7 +535,7 @@ def main():
                 if not args.no_optimizer and strategy is None:
                     # DeepModel.fit itself on the resident feed, metrics off (what a DeepTable.fit user gets): the first call
                     # captures, the timed call reuses the captured loop; shuffled epochs, loss read back once per epoch
-                    keep_metrics, dm.config.metrics = dm.config.metrics, []
+                    keep_config, dm.config = dm.config, dm.config._replace(metrics=[])
                     try:
                         dm.fit(feed, batch_size=args.batch, epochs=1, verbose=0, shuffle=True, steps_per_execution=spg)
                         torch.cuda.synchronize()
@@ -540,7 +549,7 @@ def main():
                                               f'{feed.n // args.batch} steps per epoch, metrics off, wall clock incl. the '
                                               f'per-epoch permutation and loss read-back')
                     finally:
-                        dm.config.metrics = keep_metrics
+                        dm.config = keep_config
                 if not args.no_optimizer:      # the same step without the Adam launches, for comparison
                     fb = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=False, use_graph=not args.no_graph)
                     fb.set_order(ring_order(feed, args.batch, 2 + spg + args.steps, device))

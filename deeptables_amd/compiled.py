@@ -24,6 +24,7 @@ import ctypes
 import torch
 
 from . import training
+from ._lib import check, lib, ptr, stream_ptr
 
 
 def _hip_graph_upload(graph):
@@ -79,6 +80,7 @@ class CompiledTrainLoop:
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
         self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] around fwd+bwd | exchange | optimizer (bench.py)
         self._first_events = None
+        self._gather_args = None
         self.uploaded = False
 
     # -- the feed ---------------------------------------------------------------------------------------------
@@ -105,11 +107,27 @@ class CompiledTrainLoop:
         return (self.rows_available() - self.pos) // self.B
 
     def _gather(self, steps=None):
+        """slots[:, :n] <- the feed's rows sel[:n]: ONE launch for ids, continuous columns and labels (dt_feed_gather)"""
         n = (self.k if steps is None else steps) * self.B
-        for blk, slot in zip(self.feed.blocks, self.slots):
-            torch.index_select(blk, 0, self.sel[:n], out=slot[:n])
-        if self.slot_y is not None:
-            torch.index_select(self.feed.y, 0, self.sel[:n], out=self.slot_y[:n])
+        if self._gather_args is None:
+            srcs = list(self.feed.blocks) + ([] if self.slot_y is None else [self.feed.y])
+            dsts = list(self.slots) + ([] if self.slot_y is None else [self.slot_y])
+            nb = len(srcs)
+            if nb > 8 or any((t.element_size() * (t.numel() // max(t.shape[0], 1))) % 4 for t in srcs):
+                self._gather_args = False          # more blocks / odd row sizes than the kernel takes: index_select
+            else:
+                arr = ctypes.c_void_p * nb
+                self._gather_args = (arr(*[t.data_ptr() for t in srcs]), arr(*[t.data_ptr() for t in dsts]),
+                                     (ctypes.c_int * nb)(*[t.element_size() * (t.numel() // t.shape[0]) for t in srcs]), nb)
+        if self._gather_args is False:
+            for blk, slot in zip(self.feed.blocks, self.slots):
+                torch.index_select(blk, 0, self.sel[:n], out=slot[:n])
+            if self.slot_y is not None:
+                torch.index_select(self.feed.y, 0, self.sel[:n], out=self.slot_y[:n])
+            return
+        src, dst, rb, nb = self._gather_args
+        check(lib().dt_feed_gather(ptr(self.sel), n, nb, ctypes.cast(src, ctypes.c_void_p), ctypes.cast(dst, ctypes.c_void_p),
+                                   ctypes.cast(rb, ctypes.c_void_p), stream_ptr()), 'dt_feed_gather')
 
     def _step_inputs(self, i):
         s, e = i * self.B, (i + 1) * self.B
@@ -329,8 +347,8 @@ class CompiledTrainLoop:
 def resolve_steps_per_execution(dm, requested, feed, batch_size, steps_per_epoch):
     """`fit(steps_per_execution=...)`: an int k > 1 asks for the compiled loop; 'auto' (the default, also
     `training.DEFAULT_STEPS_PER_EXECUTION`) compiles when the graph has a fused whole-step plan (known to be
-    capturable: no host synchronisation inside the step), the feed is device resident and an epoch holds at least two
-    executions; 1 / None / 0: eager steps."""
+    capturable: no host synchronisation inside the step), the feed is device resident and an epoch holds at least ten
+    steps; 1 / 0: eager steps."""
     if requested is None:
         requested = training.DEFAULT_STEPS_PER_EXECUTION
     if requested in (0, 1, False):
@@ -345,8 +363,7 @@ def resolve_steps_per_execution(dm, requested, feed, batch_size, steps_per_epoch
     if requested == 'auto':
         if dm.fused_plan() is None or (feed.weighted and not getattr(dm.fused_plan(), 'takes_sample_weight', False)):
             return 1
-        k = 10
-        while k > 1 and steps_per_epoch < 2 * k:
-            k //= 2
-        return max(k, 1)
+        # an epoch must hold at least two executions, and an execution at least five steps (below that the capture costs
+        # more than it saves)
+        return 10 if steps_per_epoch >= 20 else 5 if steps_per_epoch >= 10 else 1
     return max(1, min(int(requested), int(steps_per_epoch)))

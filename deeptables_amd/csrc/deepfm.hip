@@ -271,6 +271,9 @@ struct PrepOut {
     float* bn2;                                   // [kBnSlices][3][C] level-1 results
     float *W1L, *W2L, *W2TL;                      // MFMA operand layouts of W1 / W2 / W2^T (k_mlp_fwd3)
     const float* W2;
+    // split-bf16 tower (tower_x3.h; NULL: not that mode): the bf16 halves of W1 / W2 in the layouts of X3Weights
+    __bf16 *x3_W1B, *x3_W1R, *x3_W2B, *x3_W2R;
+    int64_t x3_w1b_lo, x3_w1r_lo, x3_w2b_lo, x3_w2r_lo;
 };
 
 // Merge of K partial results {n_i, mean_i, M2_i} of one column, all K at once (no running recurrence, ONE division):
@@ -415,6 +418,56 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             const unsigned long long old = atomicAdd(&eslots[myslot[u]], 1ULL);
             dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
             rows_out[occ] = -1;
+        }
+        return;
+    }
+    if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
+        const int wb = bid - bn_blocks, nwb = layout_blocks;
+        auto split8 = [](const float (&v)[8], __bf16* hi, __bf16* lo) {
+            typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+            b8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 a = (__bf16)v[j];
+                h[j] = a;
+                l[j] = (__bf16)(v[j] - (float)a);
+            }
+            *reinterpret_cast<b8*>(hi) = h;
+            *reinterpret_cast<b8*>(lo) = l;
+        };
+        const int nst = dm.CP >> 5;
+        // W1B: lane (n, g) of wave w at step s holds W1[32 s + 8 g + j][16 w + n]
+        for (int e = wb * blockDim.x + threadIdx.x; e < nst * 512; e += nwb * blockDim.x) {
+            const int l = e & 63, w = (e >> 6) & 7, st = e >> 9;
+            const int k0 = 32 * st + 8 * (l >> 4), n = 16 * w + (l & 15);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k0 + j < dm.C ? W1[(int64_t)(k0 + j) * kH1 + n] : 0.f;
+            split8(v, o.x3_W1B + (int64_t)e * 8, o.x3_W1B + o.x3_w1b_lo + (int64_t)e * 8);
+        }
+        // W1R: row-major copy [CP][128], rows >= C zero
+        for (int e = wb * blockDim.x + threadIdx.x; e < dm.CP * 16; e += nwb * blockDim.x) {
+            const int r = e >> 4, k8 = e & 15;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r < dm.C ? W1[(int64_t)r * kH1 + 8 * k8 + j] : 0.f;
+            split8(v, o.x3_W1R + (int64_t)e * 8, o.x3_W1R + o.x3_w1r_lo + (int64_t)e * 8);
+        }
+        // W2B: lane (n, g) of column tile t at step s holds W2[32 s + 8 g + j][16 t + n]
+        for (int e = wb * blockDim.x + threadIdx.x; e < 4 * 4 * 64; e += nwb * blockDim.x) {
+            const int l = e & 63, t = (e >> 6) & 3, st = e >> 8;
+            const int k0 = 32 * st + 8 * (l >> 4), n = 16 * t + (l & 15);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = o.W2[(k0 + j) * kH2 + n];
+            split8(v, o.x3_W2B + (int64_t)e * 8, o.x3_W2B + o.x3_w2b_lo + (int64_t)e * 8);
+        }
+        // W2R: row-major copy [128][64]
+        for (int e = wb * blockDim.x + threadIdx.x; e < kH1 * kH2 / 8; e += nwb * blockDim.x) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = o.W2[(int64_t)e * 8 + j];
+            split8(v, o.x3_W2R + (int64_t)e * 8, o.x3_W2R + o.x3_w2r_lo + (int64_t)e * 8);
         }
         return;
     }
@@ -1306,6 +1359,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     }
 }
 
+#include "tower_x3.h"
+
 // E: weight gradients on 64x128 macro tiles = 2x4 MFMA tiles whose rows / columns INTERLEAVE (tile (t,u) holds outputs
 // (2i+t, 4j+u)), so ONE 8-byte load per lane feeds two tiles' worth of A and ONE 16-byte load four tiles' worth of B:
 // two loads per EIGHT MFMAs, issued between the MFMA groups two chunks ahead.
@@ -2147,7 +2202,7 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 // workspace layout (floats)
 struct DeepFmWs {
     int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, dXc, dXn, cm1,
-        cm2, gammap, total;
+        cm2, gammap, x3, total;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
@@ -2175,6 +2230,8 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
     w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
     w.gammap = take(dm.CP);
+    // split-bf16 tower: W1B | W1R (2 x CP x 128 bf16 each = CP x 128 floats) | W2B | W2R (2 x 128 x 64 bf16 each)
+    w.x3 = take(2 * (int64_t)dm.CP * kH1 + 2 * (int64_t)kH1 * kH2);
     w.total = o;
     return w;
 }
@@ -2280,6 +2337,7 @@ static int tower_train_step(
     // gradients' last level), so that a caller whose row gradients leave through a collective (row-owned tables) can start
     // that collective behind the row-gradient launch and let E' run beside it
     const bool skip_finish = (phases & DT_STEP_SKIP_FINISH) != 0, finish_only = (phases & DT_STEP_FINISH_ONLY) != 0;
+    const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
     static const int wt_env_c = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;
@@ -2375,8 +2433,14 @@ static int tower_train_step(
 #undef DT_A
     // B
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
+    // split-bf16 tower (DT_STEP_TOWER_X3): the DeepFM tile kernel of the pipelined backward step (DCN keeps the fp32 kernel)
+    const bool x3 = x3_flag && pipe && !dcn && dm.CP <= 512;
+    __bf16* x3base = reinterpret_cast<__bf16*>(ws + wl.x3);
+    const int64_t n1 = (int64_t)dm.CP * kH1, n2 = (int64_t)kH1 * kH2;            // elements of one half
+    const X3Weights xw{x3base, n1, x3base + 2 * n1, n1, x3base + 4 * n1, n2, x3base + 4 * n1 + 2 * n2, n2};
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
-               ws + wl.W2TL, W2};
+               ws + wl.W2TL, W2,
+               x3 ? x3base : nullptr, x3base + 2 * n1, x3base + 4 * n1, x3base + 4 * n1 + 2 * n2, n1, n1, n2, n2};
     const int elect_blocks = dd.rows_fm ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = dd.rows_fm ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
@@ -2412,7 +2476,20 @@ static int tower_train_step(
                                ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, nullptr);                     \
         }                                                                                                           \
         break;
-        switch (dm.CP >> 6) { DT_C(1) DT_C(2) DT_C(3) DT_C(4) DT_C(5) DT_C(6) DT_C(7) DT_C(8) DT_C(9) }
+#define DT_CX(N)                                                                                                    \
+    case N: {                                                                                                       \
+        const size_t ldsX = x3_lds_bytes(64 * N);                                                                   \
+        hipFuncSetAttribute((const void*)k_tower_x3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX);     \
+        hipLaunchKernelGGL((k_tower_x3<N>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, ws + wl.lin,   \
+                           ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,               \
+                           ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);                     \
+    } break;
+        if (x3) {        // the split-bf16 tower (tower_x3.h)
+            switch (dm.CP >> 6) { DT_CX(1) DT_CX(2) DT_CX(3) DT_CX(4) DT_CX(5) DT_CX(6) DT_CX(7) DT_CX(8) }
+        } else {
+            switch (dm.CP >> 6) { DT_C(1) DT_C(2) DT_C(3) DT_C(4) DT_C(5) DT_C(6) DT_C(7) DT_C(8) DT_C(9) }
+        }
+#undef DT_CX
 #undef DT_C
     }
     const Part3 pl3 = part3_layout(dm.CP, Lc, pipe ? 1 : 0);

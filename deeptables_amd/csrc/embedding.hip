@@ -487,3 +487,56 @@ extern "C" int dt_embed_fm_linear_bwd(const float* emb, const float* g_emb, cons
     return launch_row_bwd(emb, g_emb, g_concat, concat_stride, g_field_sum, g_fm, B, F, D,
                           grad_rows, as_stream(stream));
 }
+
+// ---------------------------------------------------------------------------------------------
+// dt_feed_gather: batch assembly on the device (include/dt_hip.h).  One thread per dword of a destination row set; the
+// dwords of a row are consecutive threads, so every block row is a contiguous segment on both sides.
+// ---------------------------------------------------------------------------------------------
+namespace dt {
+struct FeedBlocks {
+    const uint32_t* src[8];
+    uint32_t* dst[8];
+    int first[9];            // prefix sums of the blocks' dwords per row
+    int n;
+};
+__global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__ sel, int64_t n_rows, FeedBlocks fb) {
+    const int per = fb.first[fb.n];
+    const int64_t total = n_rows * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per;
+        const int q = (int)(i - r * per);
+        int b = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) b += (k < fb.n && q >= fb.first[k]) ? 1 : 0;
+        const int w = fb.first[b + 1] - fb.first[b], c = q - fb.first[b];
+        fb.dst[b][r * w + c] = fb.src[b][sel[r] * w + c];
+    }
+}
+}  // namespace dt
+
+extern "C" int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, const void* const* src, void* const* dst,
+                              const int* row_bytes, void* stream) {
+    DT_REQUIRE(n_rows >= 0 && n_blocks >= 1 && n_blocks <= 8 && src && dst && row_bytes, "dt_feed_gather: bad arguments");
+    if (n_rows == 0) return DT_OK;
+    DT_REQUIRE(sel, "dt_feed_gather: null pointer");
+    dt::FeedBlocks fb;
+    fb.n = n_blocks;
+    fb.first[0] = 0;
+    for (int b = 0; b < 8; ++b) {
+        fb.src[b] = nullptr; fb.dst[b] = nullptr;
+        if (b < n_blocks) {
+            DT_REQUIRE(src[b] && dst[b] && row_bytes[b] > 0 && row_bytes[b] % 4 == 0, "dt_feed_gather: block %d: null pointer or a "
+                       "row size that is not a positive multiple of 4 bytes (%d)", b, row_bytes[b]);
+            fb.src[b] = reinterpret_cast<const uint32_t*>(src[b]);
+            fb.dst[b] = reinterpret_cast<uint32_t*>(dst[b]);
+            fb.first[b + 1] = fb.first[b] + row_bytes[b] / 4;
+        } else {
+            fb.first[b + 1] = fb.first[b];
+        }
+    }
+    const int64_t total = n_rows * fb.first[n_blocks];
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(dt::k_feed_gather, dim3((unsigned)blocks), dim3(256), 0, dt::as_stream(stream), sel, n_rows, fb);
+    return dt::launch_status("dt_feed_gather");
+}

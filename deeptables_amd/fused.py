@@ -51,6 +51,17 @@ def _tower_widths(dnn_params):
     return int(h1), int(h2)
 
 
+def _tower_mfma_flag(dnn_params):
+    """`dnn_params['mfma_dtype']` (or DT_AMD_TOWER_DTYPE): 'f32' (default) = exact-fp32 MFMA, 'bf16x3' = the tile kernel's
+    four GEMMs on split-bf16 matrix cores (csrc/tower_x3.h, DT_STEP_TOWER_X3) -> the `phases` bit of the fused step"""
+    mode = dnn_params.get('mfma_dtype') or os.environ.get('DT_AMD_TOWER_DTYPE', 'f32')
+    if mode in ('f32', 'fp32', 'float32'):
+        return 0
+    if mode == 'bf16x3':
+        return _lib.DT_STEP_TOWER_X3
+    raise ValueError(f"dnn_params['mfma_dtype'] = {mode!r}: 'f32' or 'bf16x3'")
+
+
 def _mirror_in_flat(flat_params, accum, grad_views):
     """Moves every parameter of `grad_views` [(param, view of accum)] to the same place of `flat_params` (same offset,
     shape and strides as its gradient view) -> members for KerasAdam.register_flat_group."""
@@ -209,6 +220,7 @@ class FusedDeepFM:
         self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         # duplicate lookups are resolved inside the step (kernels A and G) unless DT_AMD_FUSED_DEDUPE=0
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
+        self.tower_flag = _tower_mfma_flag(dm.config.dnn_params)
         # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
         # the model with ONE launch over (flat_params, accum) instead of one launch per tensor.
         self.flat_params = torch.zeros_like(self.accum)
@@ -314,7 +326,8 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 1.0 / W, 1, 2 | part | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+            None, None, 0, 1.0 / W, 1, 2 | part | _step_loss(self.dm) | (0 if part == _lib.DT_STEP_FINISH_ONLY else self.tower_flag),
+            self.emb_dropout if training else 0.0, ptr(self.drop_seed),
             self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()),
             'dt_deepfm_train_step')
         for p, g in self.grad_views:
@@ -385,14 +398,15 @@ class FusedDeepFM:
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_deepfm_train_step_adam(
-                *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | self.tower_flag, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_deepfm_train_step(
-                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
+                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0),
+                self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_deepfm_train_step')
         if backward:
             for p, g in self.grad_views:
@@ -500,6 +514,7 @@ class FusedDCN(FusedDeepFM):
         seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
         self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
+        self.tower_flag = _tower_mfma_flag(dm.config.dnn_params)
         # parameters mirror the gradient layout in one flat buffer (one optimizer launch, see FusedDeepFM); W1 / W2 precede
         # the [C + 64] output kernel, so they keep their 16-byte alignment whatever C is (the kernels read w3 with scalar loads)
         self.flat_params = torch.zeros_like(self.accum)

@@ -300,7 +300,9 @@ class DeepModel:
         self.optimizer.step()
         # a fused plan hands out its static logit buffer (overwritten by the next step): copy it.  Asked of THIS step, not
         # of fused_plan(): a weighted step must not build the plan (it re-homes the tower parameters) as a side effect.
-        return loss.detach(), logit.detach().clone() if getattr(self, '_step_used_plan', False) else logit.detach()
+        if getattr(self, '_step_used_plan', False):
+            return loss.detach().clone(), logit.detach().clone()    # (the loss is one word of the plan's gradient buffer)
+        return loss.detach(), logit.detach()
 
     def fit(self, X=None, y=None, batch_size=128, epochs=1, verbose=1, callbacks=None, validation_split=0.2,
             validation_data=None, shuffle=True, class_weight=None, sample_weight=None, initial_epoch=0,

@@ -357,6 +357,15 @@ int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const flo
                      const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
                      void* stream);
 
+/* ---- input feed: batch assembly on the device (replaces `tf.data.Dataset.from_tensor_slices(...).shuffle().batch()` of
+ *      utils/dataset_generator.py:36-72 for a table resident in HBM; deeptables_amd/compiled.py) -------------------- *
+ * n_rows rows named by sel (int64 indices into every source block) are copied from each of n_blocks row-major blocks into
+ * the matching destination: dst[b][i, :] = src[b][sel[i], :].  src / dst / row_bytes are HOST arrays (n_blocks <= 8 entries;
+ * device pointers, bytes per row, multiples of 4): ONE launch assembles the ids, the continuous columns and the labels
+ * (+ weights) of k train steps.                                                                                  */
+int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, const void* const* src, void* const* dst,
+                   const int* row_bytes, void* stream);
+
 /* ---- model-parallel tables: owner-side gather (parallel.ShardedEmbeddingStrategy; the role the sharded
  *      embedding_lookup of a parameter-server strategy plays) ------------------------------------------- *
  * idx_all [W,B,F] ids of all W minibatches; this rank owns fields [f_begin, f_end) of the packed table.
@@ -424,10 +433,16 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * phases | DT_STEP_SKIP_FINISH: a backward step without its LAST launch (the last level of the dense gradients): every
  * row gradient is final when the call's launches are, so the collective that carries them to the row owners can start
  * there; the same call with phases | DT_STEP_FINISH_ONLY (same arguments) then issues only that last launch, which runs
- * beside the collective.  accum is complete after the second call.                                                  */
+ * beside the collective.  accum is complete after the second call.
+ * phases | DT_STEP_TOWER_X3 (backward steps of dt_deepfm_train_step / _adam): the Dense tower's four GEMMs of the tile kernel
+ * (Dense128, Dense64, dH1 = dH2 W2^T, dXn = dH1 W1^T; deepnets.py:401-427) run on v_mfma_f32_16x16x32_bf16 with SPLIT
+ * operands — a = a_hi + a_lo (two bf16 halves, 16 mantissa bits), a b ~ a_hi b_hi + (a_hi b_lo + a_lo b_hi), fp32
+ * accumulate: 3/16 of the fp32-MFMA time at ~2^-17 relative error per product (logits within 1e-4 of the fp32 oracle:
+ * DESIGN.md).  Weights are split once per step by the prep launch, activations once while they are staged in LDS.   */
 #define DT_STEP_LOSS_MSE 0x10
 #define DT_STEP_SKIP_FINISH 0x20
 #define DT_STEP_FINISH_ONLY 0x40
+#define DT_STEP_TOWER_X3 0x80
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7_host);

@@ -377,7 +377,7 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
     m / v are linear / quadratic in the gradient: compared at `4e-4` of the tensor's largest entry.  The parameter is
     compared at `upd_tol` of the step's largest move, EXCEPT where the update rule amplifies float32 gradient rounding
     (`_adam_band`: entries whose new value moves by more than upd_tol / 2 of the step when the gradient is off by
-    g_band x the tensor's largest |g|); those entries are masked and COUNTED (`*_masked`).  Batch 2.. reuse half of the
+    g_band x the largest |g| of the dense tensor / of the table row); those entries are masked and COUNTED (`*_masked`).  Batch 2.. reuse half of the
     previous batch's id rows so that many rows are met with warm slots.  -> dict of figures; `in_step_vs_oracle_ok`."""
     emb = dm.model.layers_by_name['emb_categorical_vars_all']
     D = emb.groups[0][0]
@@ -434,7 +434,9 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
         opt.step()
         torch.cuda.synchronize()
         # ---- rows ----
-        pn, mn, vn, band = _adam_band(p0, g_ref, m0, v0, t, lr, g_band * g_ref.abs().max())
+        # (a table row's gradient is formed on its own: the band is relative to the ROW's largest entry — under Zipf ids the
+        # hottest rows' summed gradients are hundreds of times a cold row's)
+        pn, mn, vn, band = _adam_band(p0, g_ref, m0, v0, t, lr, g_band * g_ref.abs().amax(dim=-1, keepdim=True))
         stepsz = (pn - p0).abs().max().item()
         got_p = table.detach()[dev_rows].double().cpu()
         keep = band <= 0.5 * upd_tol * stepsz

@@ -160,4 +160,4 @@ def test_headline_in_step_optimizer_matches_oracle_adam_two_steps(dev, dist, net
     res = headline.check_in_step_vs_oracle(dm, batches)
     assert res['ok'], str(sorted(res.items()))
     assert res['steps_counted'] == 2 and res['warm_rows'] > 30000, res
-    assert res['rows_masked'] < 0.05 * (res['rows_masked'] + res['rows_compared']), res
+    assert res['rows_masked'] < 0.1 * (res['rows_masked'] + res['rows_compared']), res

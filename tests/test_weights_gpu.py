@@ -70,7 +70,7 @@ def test_fit_with_class_and_sample_weights(dev):
             return XF({kk: v[k] for kk, v in self.d.items()})
     sw = np.linspace(0.5, 1.5, n).astype(np.float32)
     dm.fit(XF(Xf), y, batch_size=100, epochs=1, verbose=0, validation_split=0, class_weight={0: 1.0, 1: 9.0},
-           sample_weight=sw)
+           sample_weight=sw, steps_per_execution=1)           # eager steps: the spy sees every train_step call
     assert seen and all(wb is not None for _, wb in seen)
     for yb, wb in seen:
         # every row's weight is its sample weight (0.5..1.5) times its class weight

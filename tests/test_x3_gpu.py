@@ -1,0 +1,112 @@
+# -*- coding:utf-8 -*-
+"""GPU: the split-bf16 ("bf16 x 3") Dense tower of the fused DeepFM step (csrc/tower_x3.h, DT_STEP_TOWER_X3, selected by
+`dnn_params['mfma_dtype'] = 'bf16x3'`): Dense128 / Dense64 / dH1 / dXn of deepnets.py:401-427 on v_mfma_f32_16x16x32_bf16
+with every fp32 operand split into two bf16 halves.  Held to the SAME bars as the exact-fp32 kernels: logits within 1e-4 of
+the float64 oracle, every gradient within 2e-4 of its tensor's largest entry (the mode's own rounding is ~2^-17 per
+product: the measured figures are printed by bench.py's parity leg and recorded in DESIGN.md)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+X3 = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': 'bf16x3'}
+
+
+def _rel(a, b):
+    b = b.detach().double().cpu()
+    return (a.detach().double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize('B,F,Nd,D,idt', [(256, 26, 13, 16, 'int32'), (100, 26, 13, 16, 'float32'), (37, 5, 3, 8, 'int32'),
+                                          (64, 7, 0, 4, 'int32'), (513, 16, 2, 32, 'int32'), (1000, 26, 13, 16, 'int32')])
+def test_x3_step_matches_oracle(dev, B, F, Nd, D, idt):
+    import tests.test_fused_gpu as T
+    from oracle import bridge, reference_layers as R
+    from deeptables_amd import _lib
+    dm, cats = T.build(F, Nd, D, vocab=30, dnn_params=dict(X3))
+    plan = dm.fused_plan()
+    assert plan is not None and plan.tower_flag == _lib.DT_STEP_TOWER_X3
+    idx, dense, y = T.batch(cats, Nd, B)
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    ref_loss = R.binary_crossentropy_from_logits(ref_logit, y.double())
+    ref_loss.backward()
+    dm.model.train()
+    ins = [idx.to(getattr(torch, idt)).to(dev)] + ([dense.to(dev)] if Nd else [])
+    loss, logit = dm.forward_backward(ins, y.to(dev))
+    torch.cuda.synchronize()
+    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    L = dm.model.layers_by_name
+    pairs = [(L['task_output'].kernel.grad, w['task_output'][0].grad),
+             (L['dense_logit_dnn_nets'].kernel.grad, w['dense_logit_dnn_nets'].grad),
+             (L['dnn_dense_2'].kernel.grad, w['dnn'][1][0].grad), (L['dnn_dense_2'].bias.grad, w['dnn'][1][1].grad),
+             (L['dnn_dense_1'].kernel.grad, w['dnn'][0][0].grad), (L['dnn_dense_1'].bias.grad, w['dnn'][0][1].grad),
+             (L['bn_concat_emb_dense'].gamma.grad, w['bn_concat_emb_dense'][0].grad),
+             (L['bn_concat_emb_dense'].beta.grad, w['bn_concat_emb_dense'][1].grad),
+             (L['linear_logit'].kernel.grad, w['linear_logit'].grad),
+             (L['task_output'].bias.grad, w['task_output'][1].grad)]
+    for i, (a, b) in enumerate(pairs):
+        assert _rel(a, b) < 2e-4, f'dense grad {i}: {_rel(a, b)}'
+    table = L['emb_categorical_vars_all'].tables[f'd{D}']
+    ref_tg = torch.cat([t.grad for t in w['emb_categorical_vars_all']], 0)
+    assert _rel(table.grad, ref_tg) < 2e-4
+
+
+def test_x3_takes_narrow_towers_and_the_regression_task(dev):
+    """zero-padded slabs (H1 = 100, H2 = 40) and the MSE loss block through the split-bf16 kernel"""
+    import tests.test_fused_gpu as T
+    from oracle import bridge, reference_layers as R
+    dm, cats = T.build(26, 13, 16, vocab=30, task='regression',
+                       dnn_params={'hidden_units': ((100, 0, False), (40, 0, False)), 'activation': 'relu',
+                                   'mfma_dtype': 'bf16x3'})
+    assert dm.fused_plan() is not None
+    idx, dense, y = T.batch(cats, 13, 300)
+    y = torch.randn(300, 1)
+    w = bridge.oracle_weights(dm, requires_grad=True)
+    ref_logit, _ = bridge.oracle_forward(dm, idx, dense, training=True, weights=w)
+    ((ref_logit - y.double()) ** 2).mean().backward()
+    dm.model.train()
+    loss, logit = dm.forward_backward([idx.int().to(dev), dense.to(dev)], y.to(dev))
+    assert (logit.double().cpu() - ref_logit).abs().max().item() < 1e-4
+    L = dm.model.layers_by_name
+    assert _rel(L['dnn_dense_1'].kernel.grad, w['dnn'][0][0].grad) < 2e-4
+    assert _rel(L['dnn_dense_2'].kernel.grad, w['dnn'][1][0].grad) < 2e-4
+    assert _rel(L['bn_concat_emb_dense'].gamma.grad, w['bn_concat_emb_dense'][0].grad) < 2e-4
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'zipf'])
+def test_x3_headline_config_matches_oracle(dev, dist):
+    """the benchmarked configuration (B = 8192, 26 x 1 M rows, in-step dedupe, Keras Adam) in split-bf16 mode against the
+    float64 oracle, at the exact-fp32 bars of tests/test_headline_gpu.py"""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    import tests.test_headline_gpu as H
+    dm = bench.build_model(deepnets.DeepFM, dev, None, bench.D, {'dnn_params': dict(X3)})
+    bench.N_BATCHES, keep = 2, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind=dist)
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    print('x3', dist, {k: res[k] for k in ('max_abs_logit_err', 'max_abs_logit', 'dense_grad_rel_err', 'rows_grad_rel_err',
+                                           'adam_rows_rel_err', 'adam_dense_rel_err')})
+    H._check(res)
+    # ... and the timed path (optimizer inside the step's launches) against the oracle's Adam, two steps
+    rv = headline.check_in_step_vs_oracle(dm, batches)
+    assert rv['ok'], str(sorted(rv.items()))
+
+
+def test_x3_rows_in_step_equals_the_separate_optimizer_step(dev):
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    dm = bench.build_model(deepnets.DeepFM, dev, None, bench.D, {'dnn_params': dict(X3)})
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        b = bench.make_batches(8192, dev, seed=4321, dist_kind='zipf')[0]
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_rows_in_step(dm, b)
+    assert headline.rows_in_step_ok(res), str(sorted(res.items()))
