@@ -452,9 +452,10 @@ def main():
     if world == 1 and strategy is None and not args.no_graph:
         spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1)
                   if args.steps % d == 0 and (args.warmup % d == 0 or args.warmup == 0))
-    loop = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
-                             graph_segments=args.graph_segments)
     warm_capture = 2
+    loop = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
+                             graph_segments=args.graph_segments,
+                             order_capacity=max(feed.n, (warm_capture + args.warmup + args.steps) * args.batch))
     loop.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
     loop.capture(warm_steps=warm_capture)
     spg = loop.k if loop.graph is not None else 1
@@ -551,7 +552,8 @@ def main():
                     finally:
                         dm.config = keep_config
                 if not args.no_optimizer:      # the same step without the Adam launches, for comparison
-                    fb = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=False, use_graph=not args.no_graph)
+                    fb = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=False, use_graph=not args.no_graph,
+                                           order_capacity=max(feed.n, (2 + spg + args.steps) * args.batch))
                     fb.set_order(ring_order(feed, args.batch, 2 + spg + args.steps, device))
                     fb.capture(warm_steps=2)
                     w2, _, _ = time_steps(fb, args.steps, spg, barrier, device, spin=False)

@@ -125,7 +125,7 @@ SIGNATURES = {
                                            _c_f32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
                                            _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
     'dt_deepfm_dropout_hash': (ctypes.c_uint32, [ctypes.c_uint32] * 3),
-    'dt_feed_gather': (_c_int, [_ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr]),
+    'dt_feed_gather': (_c_int, [_ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_embedding_gather_owned': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                            _c_int, _ptr, _ptr, _ptr, _ptr]),
     'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),

@@ -52,7 +52,7 @@ class CompiledTrainLoop:
     records a HIP event there); `collect=True` keeps per-step (loss, logits, y) on the device for the epoch's metrics."""
 
     def __init__(self, dm, feed, batch_size, steps_per_execution=10, with_optimizer=True, use_graph=True,
-                 graph_segments=False):
+                 graph_segments=False, order_capacity=None):
         if not feed.resident:
             raise ValueError('CompiledTrainLoop needs a device-resident feed (training.TableBatches(resident=True))')
         self.dm, self.feed = dm, feed
@@ -66,11 +66,16 @@ class CompiledTrainLoop:
         self.k = 1 if self.dp else max(1, int(steps_per_execution))
         self.device = feed.device
         n = self.k * self.B
-        self.sel = torch.zeros(n, dtype=torch.int64, device=self.device)
+        # the epoch's row order lives in a persistent device vector and a device cursor walks it (dt_feed_gather advances it
+        # behind every gather): a replay needs NO host-side feed work.  order_capacity: longest order set_order() will see
+        self.order_cap = int(order_capacity or feed.n)
+        self.order_buf = torch.arange(self.order_cap, dtype=torch.int64, device=self.device)
+        self.order_len = min(self.order_cap, feed.n)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.sel = torch.zeros(n, dtype=torch.int64, device=self.device)     # (index_select fallback of odd feeds only)
         self.slots = [torch.empty((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=self.device) for b in feed.blocks]
         self.slot_y = None if feed.y is None else \
             torch.empty((n,) + tuple(feed.y.shape[1:]), dtype=feed.y.dtype, device=self.device)
-        self.order = None           # device int64 vector: the epoch's row order (None: 0, 1, 2, ...)
         self.pos = 0                # next row of the order to train on
         self.graph = None
         self.opt_graph = None       # data parallel: the optimizer launches, captured after the gather buffers exist
@@ -80,28 +85,43 @@ class CompiledTrainLoop:
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
         self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] around fwd+bwd | exchange | optimizer (bench.py)
         self._first_events = None
-        self._gather_args = None
         self.uploaded = False
+        srcs = list(feed.blocks) + ([] if self.slot_y is None else [feed.y])
+        dsts = list(self.slots) + ([] if self.slot_y is None else [self.slot_y])
+        nb = len(srcs)
+        if nb > 8 or any((t.element_size() * (t.numel() // max(t.shape[0], 1))) % 4 for t in srcs):
+            self._gather_args = False              # more blocks / odd row sizes than dt_feed_gather takes: index_select
+        else:
+            arr = ctypes.c_void_p * nb
+            self._gather_args = (arr(*[t.data_ptr() for t in srcs]), arr(*[t.data_ptr() for t in dsts]),
+                                 (ctypes.c_int * nb)(*[t.element_size() * (t.numel() // t.shape[0]) for t in srcs]), nb)
 
     # -- the feed ---------------------------------------------------------------------------------------------
     def set_order(self, perm=None):
-        """the row order the following `run` calls walk (a device int64 permutation of the feed's rows, or None)"""
-        self.order = perm
+        """the row order the following `run` calls walk (a device int64 permutation of the feed's rows, or None = 0, 1, ..):
+        copied into the persistent order vector, the device cursor back at its start (two stream-ordered launches)"""
+        n = self.feed.n if perm is None else int(perm.numel())
+        if n > self.order_cap:
+            raise ValueError(f'set_order: {n} rows, the loop was built for at most {self.order_cap} (order_capacity)')
+        if perm is None:
+            torch.arange(n, out=self.order_buf[:n])
+        else:
+            self.order_buf[:n].copy_(perm)
+        self.order_len = n
+        self.cursor.zero_()
         self.pos = 0
 
     def _select(self, steps):
-        """the next steps*B row indices -> the front of `sel` (stream-ordered copy, no host sync)"""
+        """host-side bookkeeping of the device cursor (the gather itself reads and advances it)"""
         n = steps * self.B
         if self.pos + n > self.rows_available():
             raise IndexError('CompiledTrainLoop.run past the end of the order: call set_order() for the next epoch')
-        if self.order is None:
-            torch.arange(self.pos, self.pos + n, out=self.sel[:n])
-        else:
-            self.sel[:n].copy_(self.order[self.pos:self.pos + n])
+        if self._gather_args is False:          # index_select fallback: the indices are copied out by the host-known position
+            self.sel[:n].copy_(self.order_buf[self.pos:self.pos + n])
         self.pos += n
 
     def rows_available(self):
-        return (self.feed.n if self.order is None else int(self.order.numel()))
+        return self.order_len
 
     def steps_left(self):
         return (self.rows_available() - self.pos) // self.B
@@ -109,16 +129,6 @@ class CompiledTrainLoop:
     def _gather(self, steps=None):
         """slots[:, :n] <- the feed's rows sel[:n]: ONE launch for ids, continuous columns and labels (dt_feed_gather)"""
         n = (self.k if steps is None else steps) * self.B
-        if self._gather_args is None:
-            srcs = list(self.feed.blocks) + ([] if self.slot_y is None else [self.feed.y])
-            dsts = list(self.slots) + ([] if self.slot_y is None else [self.slot_y])
-            nb = len(srcs)
-            if nb > 8 or any((t.element_size() * (t.numel() // max(t.shape[0], 1))) % 4 for t in srcs):
-                self._gather_args = False          # more blocks / odd row sizes than the kernel takes: index_select
-            else:
-                arr = ctypes.c_void_p * nb
-                self._gather_args = (arr(*[t.data_ptr() for t in srcs]), arr(*[t.data_ptr() for t in dsts]),
-                                     (ctypes.c_int * nb)(*[t.element_size() * (t.numel() // t.shape[0]) for t in srcs]), nb)
         if self._gather_args is False:
             for blk, slot in zip(self.feed.blocks, self.slots):
                 torch.index_select(blk, 0, self.sel[:n], out=slot[:n])
@@ -126,8 +136,9 @@ class CompiledTrainLoop:
                 torch.index_select(self.feed.y, 0, self.sel[:n], out=self.slot_y[:n])
             return
         src, dst, rb, nb = self._gather_args
-        check(lib().dt_feed_gather(ptr(self.sel), n, nb, ctypes.cast(src, ctypes.c_void_p), ctypes.cast(dst, ctypes.c_void_p),
-                                   ctypes.cast(rb, ctypes.c_void_p), stream_ptr()), 'dt_feed_gather')
+        check(lib().dt_feed_gather(ptr(self.order_buf), n, nb, ctypes.cast(src, ctypes.c_void_p),
+                                   ctypes.cast(dst, ctypes.c_void_p), ctypes.cast(rb, ctypes.c_void_p), ptr(self.cursor),
+                                   stream_ptr()), 'dt_feed_gather')
 
     def _step_inputs(self, i):
         s, e = i * self.B, (i + 1) * self.B

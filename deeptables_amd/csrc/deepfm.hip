@@ -423,51 +423,55 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
         const int wb = bid - bn_blocks, nwb = layout_blocks;
-        auto split8 = [](const float (&v)[8], __bf16* hi, __bf16* lo) {
-            typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-            b8 h, l;
+        typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+        // v = p0 + p1 (+ p2): bf16 parts, each the rounding of what the parts before it left (three parts: exact)
+        auto split8 = [](const float (&v)[8], __bf16* dst, int64_t stride, int parts) {
+            b8 q[3];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const __bf16 a = (__bf16)v[j];
-                h[j] = a;
-                l[j] = (__bf16)(v[j] - (float)a);
+                float r = v[j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const __bf16 a = (__bf16)r;
+                    q[k][j] = a;
+                    r -= (float)a;
+                }
             }
-            *reinterpret_cast<b8*>(hi) = h;
-            *reinterpret_cast<b8*>(lo) = l;
+            for (int k = 0; k < parts; ++k) *reinterpret_cast<b8*>(dst + k * stride) = q[k];
         };
         const int nst = dm.CP >> 5;
-        // W1B: lane (n, g) of wave w at step s holds W1[32 s + 8 g + j][16 w + n]
+        // W1B (3 parts): lane (n, g) of wave w at step s holds W1[32 s + 8 g + j][16 w + n]
         for (int e = wb * blockDim.x + threadIdx.x; e < nst * 512; e += nwb * blockDim.x) {
             const int l = e & 63, w = (e >> 6) & 7, st = e >> 9;
             const int k0 = 32 * st + 8 * (l >> 4), n = 16 * w + (l & 15);
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = k0 + j < dm.C ? W1[(int64_t)(k0 + j) * kH1 + n] : 0.f;
-            split8(v, o.x3_W1B + (int64_t)e * 8, o.x3_W1B + o.x3_w1b_lo + (int64_t)e * 8);
+            split8(v, o.x3_W1B + (int64_t)e * 8, o.x3_w1b_lo, 3);
         }
-        // W1R: row-major copy [CP][128], rows >= C zero
+        // W1R (2 parts): row-major copy [CP][128], rows >= C zero
         for (int e = wb * blockDim.x + threadIdx.x; e < dm.CP * 16; e += nwb * blockDim.x) {
             const int r = e >> 4, k8 = e & 15;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = r < dm.C ? W1[(int64_t)r * kH1 + 8 * k8 + j] : 0.f;
-            split8(v, o.x3_W1R + (int64_t)e * 8, o.x3_W1R + o.x3_w1r_lo + (int64_t)e * 8);
+            split8(v, o.x3_W1R + (int64_t)e * 8, o.x3_w1r_lo, 2);
         }
-        // W2B: lane (n, g) of column tile t at step s holds W2[32 s + 8 g + j][16 t + n]
+        // W2B (3 parts): lane (n, g) of column tile t at step s holds W2[32 s + 8 g + j][16 t + n]
         for (int e = wb * blockDim.x + threadIdx.x; e < 4 * 4 * 64; e += nwb * blockDim.x) {
             const int l = e & 63, t = (e >> 6) & 3, st = e >> 8;
             const int k0 = 32 * st + 8 * (l >> 4), n = 16 * t + (l & 15);
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = o.W2[(k0 + j) * kH2 + n];
-            split8(v, o.x3_W2B + (int64_t)e * 8, o.x3_W2B + o.x3_w2b_lo + (int64_t)e * 8);
+            split8(v, o.x3_W2B + (int64_t)e * 8, o.x3_w2b_lo, 3);
         }
-        // W2R: row-major copy [128][64]
+        // W2R (2 parts): row-major copy [128][64]
         for (int e = wb * blockDim.x + threadIdx.x; e < kH1 * kH2 / 8; e += nwb * blockDim.x) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = o.W2[(int64_t)e * 8 + j];
-            split8(v, o.x3_W2R + (int64_t)e * 8, o.x3_W2R + o.x3_w2r_lo + (int64_t)e * 8);
+            split8(v, o.x3_W2R + (int64_t)e * 8, o.x3_w2r_lo, 2);
         }
         return;
     }
@@ -2230,8 +2234,8 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
     w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
     w.gammap = take(dm.CP);
-    // split-bf16 tower: W1B | W1R (2 x CP x 128 bf16 each = CP x 128 floats) | W2B | W2R (2 x 128 x 64 bf16 each)
-    w.x3 = take(2 * (int64_t)dm.CP * kH1 + 2 * (int64_t)kH1 * kH2);
+    // split-bf16 tower: W1B (3 bf16 parts of CP x 128) | W1R (2 parts) | W2B (3 parts of 128 x 64) | W2R (2 parts)
+    w.x3 = take((5 * (int64_t)dm.CP * kH1 + 5 * (int64_t)kH1 * kH2 + 1) / 2);
     w.total = o;
     return w;
 }
@@ -2434,13 +2438,13 @@ static int tower_train_step(
     // B
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     // split-bf16 tower (DT_STEP_TOWER_X3): the DeepFM tile kernel of the pipelined backward step (DCN keeps the fp32 kernel)
-    const bool x3 = x3_flag && pipe && !dcn && dm.CP <= 512;
+    const bool x3 = x3_flag && pipe && !dcn && dm.CP <= 512 && x3_fits(dm.CP);      // (wider rows: the fp32 tile kernel)
     __bf16* x3base = reinterpret_cast<__bf16*>(ws + wl.x3);
-    const int64_t n1 = (int64_t)dm.CP * kH1, n2 = (int64_t)kH1 * kH2;            // elements of one half
-    const X3Weights xw{x3base, n1, x3base + 2 * n1, n1, x3base + 4 * n1, n2, x3base + 4 * n1 + 2 * n2, n2};
+    const int64_t n1 = (int64_t)dm.CP * kH1, n2 = (int64_t)kH1 * kH2;            // elements of one part
+    __bf16 *x3_w1b = x3base, *x3_w1r = x3base + 3 * n1, *x3_w2b = x3base + 5 * n1, *x3_w2r = x3base + 5 * n1 + 3 * n2;
+    const X3Weights xw{x3_w1b, n1, x3_w1r, n1, x3_w2b, n2, x3_w2r, n2};
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
-               ws + wl.W2TL, W2,
-               x3 ? x3base : nullptr, x3base + 2 * n1, x3base + 4 * n1, x3base + 4 * n1 + 2 * n2, n1, n1, n2, n2};
+               ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2};
     const int elect_blocks = dd.rows_fm ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = dd.rows_fm ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);

@@ -499,7 +499,10 @@ struct FeedBlocks {
     int first[9];            // prefix sums of the blocks' dwords per row
     int n;
 };
-__global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__ sel, int64_t n_rows, FeedBlocks fb) {
+__global__ void k_feed_advance(int64_t* cursor, int64_t n) { *cursor += n; }
+__global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__ sel, int64_t n_rows, FeedBlocks fb,
+                                                     const int64_t* __restrict__ cursor) {
+    if (cursor) sel += *cursor;
     const int per = fb.first[fb.n];
     const int64_t total = n_rows * per;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__
 }  // namespace dt
 
 extern "C" int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, const void* const* src, void* const* dst,
-                              const int* row_bytes, void* stream) {
+                              const int* row_bytes, int64_t* cursor, void* stream) {
     DT_REQUIRE(n_rows >= 0 && n_blocks >= 1 && n_blocks <= 8 && src && dst && row_bytes, "dt_feed_gather: bad arguments");
     if (n_rows == 0) return DT_OK;
     DT_REQUIRE(sel, "dt_feed_gather: null pointer");
@@ -537,6 +540,8 @@ extern "C" int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, 
     const int64_t total = n_rows * fb.first[n_blocks];
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(dt::k_feed_gather, dim3((unsigned)blocks), dim3(256), 0, dt::as_stream(stream), sel, n_rows, fb);
+    hipLaunchKernelGGL(dt::k_feed_gather, dim3((unsigned)blocks), dim3(256), 0, dt::as_stream(stream), sel, n_rows, fb,
+                       (const int64_t*)cursor);
+    if (cursor) hipLaunchKernelGGL(dt::k_feed_advance, dim3(1), dim3(1), 0, dt::as_stream(stream), cursor, n_rows);
     return dt::launch_status("dt_feed_gather");
 }

@@ -404,8 +404,29 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
             sel = torch.randperm(prev_idx.shape[0], generator=torch.Generator().manual_seed(5 + step))[:half]
             idx[:half] = prev_idx[sel.to(prev_idx.device)]
         prev_idx = idx
-        # table rows change between the steps: fresh float32 CPU copies of the tables (bit-exact values)
-        ref = oracle_train_step(dm, idx, dn, y, tables_cpu=None)
+        # table rows change between the steps: fresh float32 CPU copies of the tables (bit-exact values).
+        # relu'(0) (check_train_step's note): with 1.5 M relu units per batch every few batches one unit's float64 input lies
+        # within float32 rounding of zero and the two precisions take different derivatives — one sample's whole term of
+        # dW1 / db1 / its row gradients.  Whether THIS batch has such a unit is found out without touching the model: the
+        # product's plain forward + backward (gradients only, nothing applied; the timed path's forward is the same kernels
+        # on the same inputs, bit for bit) is compared with the oracle's dense gradients first; on a mismatch the Dense
+        # biases are shifted by 2e-5 — the weights both sides then use — and the pair is evaluated again (`kink_shifts`).
+        ins = [idx, dn] if dn is not None else [idx]
+        for attempt in range(4):
+            ref = oracle_train_step(dm, idx, dn, y, tables_cpu=None)
+            pairs = oracle_dense_grads(dm, ref['weights'])
+            dm.forward_backward(ins, y)
+            torch.cuda.synchronize()
+            flip = max(_rel_stats(p.grad.reshape(g.shape), g)[0] for p, g in pairs)
+            opt.zero_grad()
+            if flip < 2e-4 or attempt == 3:
+                break
+            res['kink_shifts'] = res.get('kink_shifts', 0) + 1
+            with torch.no_grad():
+                for name, layer in dm.model.layers_by_name.items():
+                    if (name.startswith('dnn_dense_') or name.startswith('dcn_dense_')) and getattr(layer, 'bias', None) is not None:
+                        layer.bias.add_(2e-5)
+        res['plain_path_dense_grad_rel_err'] = max(res.get('plain_path_dense_grad_rel_err', 0.0), flip)
         u_ref, g_ref = merge_rows(ref['rows'], ref['row_grads'].double())
         pairs = oracle_dense_grads(dm, ref['weights'])
         t = opt.t + 1
@@ -426,7 +447,6 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
                                        st['v'].detach().double().cpu().reshape(g.shape)))
             dense0[name] = (p.detach().double().cpu().reshape(g.shape), g.detach().double(), mm, vv)
         # ---- the product's step, as timed ----
-        ins = [idx, dn] if dn is not None else [idx]
         dm.forward_backward(ins, y, apply_rows=True)
         sg = emb.sparse_grads.get(key) or []
         res['rows_in_step_taken'] = res['rows_in_step_taken'] and bool(sg) and \
