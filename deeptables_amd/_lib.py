@@ -128,6 +128,7 @@ SIGNATURES = {
     'dt_feed_gather': (_c_int, [_ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_embedding_gather_owned': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                            _c_int, _ptr, _ptr, _ptr, _ptr]),
+    'dt_deepfm_preelect': (_c_int, [_ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _c_i64, _ptr]),
     'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_segments': (_c_int, [_c_int, _c_int, _ptr]),
@@ -152,6 +153,7 @@ DT_IDX_F32, DT_IDX_I32 = 0, 1
 DT_STEP_LOSS_MSE = 0x10
 DT_STEP_SKIP_FINISH, DT_STEP_FINISH_ONLY = 0x20, 0x40
 DT_STEP_TOWER_X3 = 0x80
+DT_STEP_PREELECTED = 0x100
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
 # keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)
 ACT_CODES = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3, 'elu': 4, 'selu': 5, 'softplus': 6, 'softsign': 7,

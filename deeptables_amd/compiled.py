@@ -85,6 +85,8 @@ class CompiledTrainLoop:
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
         self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] around fwd+bwd | exchange | optimizer (bench.py)
         self._first_events = None
+        self._slots_per_step = False
+        self.preelected = False
         self.uploaded = False
         srcs = list(feed.blocks) + ([] if self.slot_y is None else [feed.y])
         dsts = list(self.slots) + ([] if self.slot_y is None else [self.slot_y])
@@ -156,7 +158,7 @@ class CompiledTrainLoop:
         st = self.strategy
         return self.dp and getattr(st, 'sharded_embeddings', False) and st.active and self.dm.fused_plan() is not None
 
-    def _body(self, i, core_only=False):
+    def _body(self, i, core_only=False, preelected=False):
         dm = self.dm
         ins, yb, wb = self._step_inputs(i)
         if core_only:
@@ -168,7 +170,8 @@ class CompiledTrainLoop:
             return
         fused_opt = self.with_optimizer and not self.dp
         loss, logit = dm.forward_backward(ins, yb, wb, apply_rows=fused_opt and self.strategy is None,
-                                          logit_out=None if self.logits is None else self.logits[i])
+                                          logit_out=None if self.logits is None else self.logits[i],
+                                          slot=i if self._slots_per_step else 0, preelected=preelected)
         if fused_opt:
             dm.optimizer.step()             # single process: the optimizer step is part of the captured graph
         used_plan = getattr(dm, '_step_used_plan', False)
@@ -198,12 +201,34 @@ class CompiledTrainLoop:
         from .models.layers import MultiColumnEmbedding
         emb_layers = [l for l in dm.model.modules() if isinstance(l, MultiColumnEmbedding)]
         core_only = self._sharded()
+        # the ids-only half of steps 2..k (packed rows of the lookups, the election of the rows looked up several times:
+        # fused.preelect) depends on the gathered ids alone: it runs on a forked branch of the graph beside step 1, and the
+        # steps behind it skip that work (every captured step has its own rows / segment buffers for this)
+        plan = dm.fused_plan()
+        pre = (self.k > 1 and not self.dp and not core_only and plan is not None and hasattr(plan, 'can_preelect') and
+               plan.can_preelect(self.B) and self.feed.kinds[0] == 'cat' and
+               self.slots[0].dtype in (torch.int32, torch.float32))
+        self._slots_per_step = bool(pre)
+        self.preelected = bool(pre)
+        if pre:                              # the steps' own rows / segment buffers exist before the capture starts
+            for i in range(1, self.k):
+                plan._slot_buffers(self.B, i)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             if not core_only:
                 self._gather()
+            if pre:
+                main = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for i in range(1, self.k):
+                        plan.preelect(self.slots[0][i * self.B:(i + 1) * self.B], slot=i)
             for i in range(self.k):
-                self._body(i, core_only=core_only)
+                if pre and i == 1:
+                    torch.cuda.current_stream().wait_stream(side)
+                self._body(i, core_only=core_only, preelected=pre and i >= 1)
+        self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
         # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
         # (rows, values) tensors and re-attach them after every replay (data parallel: the exchange reads them)

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             if (c == 0 && in[t]) {
                 const int64_t occ = (int64_t)b * dm.F + fld[t];
                 if (dd.rows_fm) dd.rows_fm[(int64_t)fld[t] * dm.B + b] = row[t];     // for the election blocks (see DedupeWs)
-                rows_out[occ] = row[t];
+                if (rows_out) rows_out[occ] = row[t];         // (NULL: a pre-elected step, dt_deepfm_preelect wrote them)
                 if (!ok[t] && oob) atomicAdd(oob, 1);
             }
         }
@@ -309,19 +309,12 @@ __device__ __forceinline__ void bn_merge_slices(const float* __restrict__ bn2, i
     var = n > 0.f ? m2 / n : 0.f;
 }
 
-__global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
-                                               float eps, float momentum, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float* __restrict__ moving_mean,
-                                               float* __restrict__ moving_var, const float* __restrict__ W1,
-                                               PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
-                                               int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
-    // block order: election | BN level 1 | weight layouts — the election (loads, LDS hash, scan, three barriers) is the longest
-    // chain of the launch and starts first; its block ids keep id % 8 = the XCD (elect_blocks is a multiple of 8)
-    const int elect_blocks = (int)gridDim.x - bn_blocks - layout_blocks;
-    const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
-    if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
-        extern __shared__ unsigned long long eslots[];    // [kElectSlots] + bitmap of the slots with >= 2 lookups + scan scratch
-        unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
+// One election block of the in-step dedupe (see DedupeWs): block e = (field, hash partition) of a grid whose ids keep
+// e % 8 = the XCD.  Reads the field's row list rows_fm [F][B], turns the rows looked up several times into segments and
+// marks their members -1 in rows_out.  `eslots`: kElectSlots 64-bit LDS slots + bitmap + scan scratch.
+__device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, const DeepFmDims& dm,
+                                            int64_t* __restrict__ rows_out) {
+                unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
         int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]
         // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
         // so the field's row list is fetched into ONE L2 instead of eight
@@ -420,6 +413,51 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             rows_out[occ] = -1;
         }
         return;
+}
+
+// the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
+__global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {
+    extern __shared__ unsigned long long eslots_dyn[];
+    elect_block(eslots_dyn, dd, dm, rows_out);
+}
+
+// ids -> packed table rows (-1 = id out of range), row-major rows_out [B][F] (what the row-gradient epilogue reads) and
+// field-major rows_fm [F][B] (what the election reads): a block takes 64 batch rows, both sides in contiguous segments
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rows_of_ids(const void* __restrict__ idx, const int64_t* __restrict__ row_offset,
+                                                     const int32_t* __restrict__ vocab, DeepFmDims dm,
+                                                     int64_t* __restrict__ rows_out, int64_t* __restrict__ rows_fm) {
+    __shared__ int64_t tile[64][129];             // F <= 128
+    const int b0 = blockIdx.x * 64;
+    const int nb = min(64, dm.B - b0);
+    for (int e = threadIdx.x; e < nb * dm.F; e += blockDim.x) {
+        const int r = e / dm.F, f = e - r * dm.F;
+        const int id = load_id<KIND>(idx, (int64_t)(b0 + r) * dm.F + f);
+        const int64_t row = (unsigned)id < (unsigned)vocab[f] ? row_offset[f] + id : (int64_t)-1;
+        rows_out[(int64_t)(b0 + r) * dm.F + f] = row;
+        tile[r][f] = row;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < dm.F * 64; e += blockDim.x) {
+        const int f = e >> 6, r = e & 63;
+        if (r < nb) rows_fm[(int64_t)f * dm.B + b0 + r] = tile[r][f];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
+                                               float eps, float momentum, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                               float* __restrict__ moving_var, const float* __restrict__ W1,
+                                               PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
+                                               int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
+    // block order: election | BN level 1 | weight layouts — the election (loads, LDS hash, scan, three barriers) is the longest
+    // chain of the launch and starts first; its block ids keep id % 8 = the XCD (elect_blocks is a multiple of 8)
+    const int elect_blocks = (int)gridDim.x - bn_blocks - layout_blocks;
+    const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
+    if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
+        extern __shared__ unsigned long long eslots_dyn[];
+        elect_block(eslots_dyn, dd, dm, rows_out);
+        return;
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
         const int wb = bid - bn_blocks, nwb = layout_blocks;
@@ -440,38 +478,38 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             for (int k = 0; k < parts; ++k) *reinterpret_cast<b8*>(dst + k * stride) = q[k];
         };
         const int nst = dm.CP >> 5;
-        // W1B (3 parts): lane (n, g) of wave w at step s holds W1[32 s + 8 g + j][16 w + n]
-        for (int e = wb * blockDim.x + threadIdx.x; e < nst * 512; e += nwb * blockDim.x) {
-            const int l = e & 63, w = (e >> 6) & 7, st = e >> 9;
-            const int k0 = 32 * st + 8 * (l >> 4), n = 16 * w + (l & 15);
-            float v[8];
+        // One item of each of the four layouts per thread and pass, every load of the pass requested before the first store:
+        // ONE memory round trip per pass (four loops after each other cost four, and made this the launch's longest chain)
+        const int n1b = nst * 512, n1r = dm.CP * 16, n2b = 4 * 4 * 64, n2r = kH1 * kH2 / 8;
+        const int nmax = n1b > n1r ? n1b : n1r;
+        for (int e = wb * blockDim.x + threadIdx.x; e < nmax; e += nwb * blockDim.x) {
+            float v1[8], v2[8], v3[8], v4[8];
+            const bool a1 = e < n1b, a2 = e < n1r, a3 = e < n2b, a4 = e < n2r;
+            if (a1) {        // W1B (3 parts): lane (n, g) of wave w at step s holds W1[32 s + 8 g + j][16 w + n]
+                const int l = e & 63, w = (e >> 6) & 7, st = e >> 9;
+                const int k0 = 32 * st + 8 * (l >> 4), n = 16 * w + (l & 15);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = k0 + j < dm.C ? W1[(int64_t)(k0 + j) * kH1 + n] : 0.f;
-            split8(v, o.x3_W1B + (int64_t)e * 8, o.x3_w1b_lo, 3);
-        }
-        // W1R (2 parts): row-major copy [CP][128], rows >= C zero
-        for (int e = wb * blockDim.x + threadIdx.x; e < dm.CP * 16; e += nwb * blockDim.x) {
-            const int r = e >> 4, k8 = e & 15;
-            float v[8];
+                for (int j = 0; j < 8; ++j) v1[j] = k0 + j < dm.C ? W1[(int64_t)(k0 + j) * kH1 + n] : 0.f;
+            }
+            if (a2) {        // W1R (2 parts): row-major copy [CP][128], rows >= C zero
+                const int r = e >> 4, k8 = e & 15;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r < dm.C ? W1[(int64_t)r * kH1 + 8 * k8 + j] : 0.f;
-            split8(v, o.x3_W1R + (int64_t)e * 8, o.x3_w1r_lo, 2);
-        }
-        // W2B (3 parts): lane (n, g) of column tile t at step s holds W2[32 s + 8 g + j][16 t + n]
-        for (int e = wb * blockDim.x + threadIdx.x; e < 4 * 4 * 64; e += nwb * blockDim.x) {
-            const int l = e & 63, t = (e >> 6) & 3, st = e >> 8;
-            const int k0 = 32 * st + 8 * (l >> 4), n = 16 * t + (l & 15);
-            float v[8];
+                for (int j = 0; j < 8; ++j) v2[j] = r < dm.C ? W1[(int64_t)r * kH1 + 8 * k8 + j] : 0.f;
+            }
+            if (a3) {        // W2B (3 parts): lane (n, g) of column tile t at step s holds W2[32 s + 8 g + j][16 t + n]
+                const int l = e & 63, t = (e >> 6) & 3, st = e >> 8;
+                const int k0 = 32 * st + 8 * (l >> 4), n = 16 * t + (l & 15);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = o.W2[(k0 + j) * kH2 + n];
-            split8(v, o.x3_W2B + (int64_t)e * 8, o.x3_w2b_lo, 3);
-        }
-        // W2R (2 parts): row-major copy [128][64]
-        for (int e = wb * blockDim.x + threadIdx.x; e < kH1 * kH2 / 8; e += nwb * blockDim.x) {
-            float v[8];
+                for (int j = 0; j < 8; ++j) v3[j] = o.W2[(k0 + j) * kH2 + n];
+            }
+            if (a4) {        // W2R (2 parts): row-major copy [128][64]
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = o.W2[(int64_t)e * 8 + j];
-            split8(v, o.x3_W2R + (int64_t)e * 8, o.x3_w2r_lo, 2);
+                for (int j = 0; j < 8; ++j) v4[j] = o.W2[(int64_t)e * 8 + j];
+            }
+            if (a1) split8(v1, o.x3_W1B + (int64_t)e * 8, o.x3_w1b_lo, 3);
+            if (a2) split8(v2, o.x3_W1R + (int64_t)e * 8, o.x3_w1r_lo, 2);
+            if (a3) split8(v3, o.x3_W2B + (int64_t)e * 8, o.x3_w2b_lo, 3);
+            if (a4) split8(v4, o.x3_W2R + (int64_t)e * 8, o.x3_w2r_lo, 2);
         }
         return;
     }
@@ -2301,6 +2339,38 @@ extern "C" int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7) {
     return DT_OK;
 }
 
+// The ids-only half of a step's in-step dedupe, run AHEAD of the step (another stream, an earlier point of a captured graph):
+// rows_out [B][F] <- the packed table row of every lookup (-1: id out of range, or a member of a segment), dedupe_ws <- the
+// segments.  The step itself then runs with phases | DT_STEP_PREELECTED on the same idx / rows_out / dedupe_ws.
+extern "C" int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset, const int32_t* vocab, int B,
+                                  int F, int64_t* rows_out, void* dedupe_ws, int64_t dedupe_slots, void* stream) {
+    DT_REQUIRE(idx && row_offset && vocab && rows_out && dedupe_ws && B > 0 && F > 0 && F <= 128,
+               "dt_deepfm_preelect: bad arguments");
+    DT_REQUIRE(idx_kind == DT_IDX_F32 || idx_kind == DT_IDX_I32, "dt_deepfm_preelect: idx_kind %d", idx_kind);
+    DT_REQUIRE(dedupe_slots == (int64_t)B * F, "dt_deepfm_preelect: dedupe_slots=%lld must be dt_deepfm_dedupe_slots(B, F)",
+               (long long)dedupe_slots);
+    DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
+                   "dt_deepfm_preelect: the in-step dedupe takes batches up to %d rows (B=%d)", kElectSlots, B);
+    DT_REQUIRE((uintptr_t)dedupe_ws % 16 == 0, "dt_deepfm_preelect: dedupe_ws must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const DedupeLayout dl = dedupe_layout(B, F);
+    char* base = reinterpret_cast<char*>(dedupe_ws);
+    DedupeWs dd{reinterpret_cast<int64_t*>(base + dl.rows_fm), dl.parts_log2, reinterpret_cast<int*>(base + dl.nseg),
+                reinterpret_cast<int64_t*>(base + dl.seg_row), reinterpret_cast<int*>(base + dl.seg_off),
+                reinterpret_cast<int*>(base + dl.seg_cnt), reinterpret_cast<int*>(base + dl.seg_list)};
+    DeepFmDims dm{B, F, 0, 0, 0, 0};
+    if (idx_kind == DT_IDX_F32)
+        hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_F32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
+                           dd.rows_fm);
+    else
+        hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_I32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
+                           dd.rows_fm);
+    const size_t ldsB = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
+    hipFuncSetAttribute((const void*)k_elect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+    hipLaunchKernelGGL(k_elect, dim3(dl.eblocks), dim3(1024), ldsB, st, dd, dm, rows_out);
+    return launch_status("dt_deepfm_preelect");
+}
+
 // dt_deepfm_train_step_adam with the optimizer's dense half as well: the flat parameter / slot buffers (laid out like accum),
 // the step state to advance and the base learning rate
 struct StepDense {
@@ -2342,6 +2412,7 @@ static int tower_train_step(
     // that collective behind the row-gradient launch and let E' run beside it
     const bool skip_finish = (phases & DT_STEP_SKIP_FINISH) != 0, finish_only = (phases & DT_STEP_FINISH_ONLY) != 0;
     const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0;
+    const bool preelected = (phases & DT_STEP_PREELECTED) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
     static const int wt_env_c = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;
@@ -2372,6 +2443,8 @@ static int tower_train_step(
         dd.seg_list = reinterpret_cast<int*>(base + dl.seg_list);
         dd.parts_log2 = dl.parts_log2;
     }
+    DT_REQUIRE(!preelected || (dd.rows_fm && !grad_rows_field_major),
+               "dt_deepfm_train_step: DT_STEP_PREELECTED needs a backward step with dedupe_ws (filled by dt_deepfm_preelect)");
     if (B % kTM) {       // ragged last tile: its workspace rows beyond B are read (unmasked) by the tile kernels -> keep them zero
         const int64_t pad = (int64_t)tiles * kTM - B;
         hipMemsetAsync(ws + wl.X + (int64_t)B * dm.CP, 0, (size_t)pad * dm.CP * sizeof(float), st);
@@ -2419,12 +2492,15 @@ static int tower_train_step(
                "dt_deepfm_train_step_adam: the in-step row update needs a backward step with the in-step dedupe (dedupe_ws) "
                "and row-major row gradients");
 
-    // A
+    // A (a pre-elected step: rows_out / rows_fm and the segments exist already — kernel A writes neither, the prep launch
+    //    has no election blocks)
+    DedupeWs ddA = dd;
+    if (preelected) ddA.rows_fm = nullptr;
     const int blocksA = ceil_div(B, kRowsPerBlockA);
 #define DT_A(KIND, L)                                                                                        \
     hipLaunchKernelGGL((k_sparse_fwd<KIND, L, kRowsPerBlockA>), dim3(blocksA), dim3(64 * kRowsPerBlockA), 0, st, idx, \
                        (const float4*)table, row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, \
-                       rows_out, oob_count, ws + wl.bnp, dd, grad_rows, ws + wl.S, drop,                     \
+                       preelected ? (int64_t*)nullptr : rows_out, oob_count, ws + wl.bnp, ddA, grad_rows, ws + wl.S, drop, \
                        stamps ? stamps + (int64_t)tiles * 48 : nullptr)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
@@ -2445,8 +2521,8 @@ static int tower_train_step(
     const X3Weights xw{x3_w1b, n1, x3_w1r, n1, x3_w2b, n2, x3_w2r, n2};
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2};
-    const int elect_blocks = dd.rows_fm ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
-    const size_t ldsB = dd.rows_fm ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
+    const int elect_blocks = (dd.rows_fm && !preelected) ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
+    const size_t ldsB = elect_blocks ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,
                        bn_momentum, bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, 56, dd, rows_out,

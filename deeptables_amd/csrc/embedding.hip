@@ -500,19 +500,24 @@ struct FeedBlocks {
     int n;
 };
 __global__ void k_feed_advance(int64_t* cursor, int64_t n) { *cursor += n; }
+// one wave per destination row: lane q copies dword q of the row's blocks (q += 64 for wider rows); the row index is one
+// scalar load per wave, no division per element (the first version — a thread per dword with a 64-bit division and a
+// dependent index load each — took 17 us for the 13 MB of ten 8192-row steps)
 __global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__ sel, int64_t n_rows, FeedBlocks fb,
                                                      const int64_t* __restrict__ cursor) {
     if (cursor) sel += *cursor;
     const int per = fb.first[fb.n];
-    const int64_t total = n_rows * per;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / per;
-        const int q = (int)(i - r * per);
-        int b = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_rows; r += nwaves) {
+        const int64_t srow = sel[r];
+        for (int q = lane; q < per; q += 64) {
+            int b = 0;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) b += (k < fb.n && q >= fb.first[k]) ? 1 : 0;
-        const int w = fb.first[b + 1] - fb.first[b], c = q - fb.first[b];
-        fb.dst[b][r * w + c] = fb.src[b][sel[r] * w + c];
+            for (int k = 1; k < 8; ++k) b += (k < fb.n && q >= fb.first[k]) ? 1 : 0;
+            const int w = fb.first[b + 1] - fb.first[b], c = q - fb.first[b];
+            fb.dst[b][r * w + c] = fb.src[b][srow * w + c];
+        }
     }
 }
 }  // namespace dt
@@ -537,9 +542,8 @@ extern "C" int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, 
             fb.first[b + 1] = fb.first[b];
         }
     }
-    const int64_t total = n_rows * fb.first[n_blocks];
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    int64_t blocks = (n_rows + 3) / 4;                 // four waves (rows) per block
+    if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(dt::k_feed_gather, dim3((unsigned)blocks), dim3(256), 0, dt::as_stream(stream), sel, n_rows, fb,
                        (const int64_t*)cursor);
     if (cursor) hipLaunchKernelGGL(dt::k_feed_advance, dim3(1), dim3(1), 0, dt::as_stream(stream), cursor, n_rows);

@@ -251,6 +251,44 @@ class FusedDeepFM:
             self._bufs[B] = b
         return b
 
+    # -- per-slot id state: the compiled loop (compiled.CompiledTrainLoop) keeps k steps in one hipGraph and runs the ids-only
+    #    work of steps 2..k ahead of them; every captured step then needs its OWN rows / segment buffers --------------------
+    def _slot_buffers(self, B, slot):
+        buf = self._buffers(B)
+        if not slot:
+            return buf
+        slots = buf.setdefault('slots', {})
+        sb = slots.get(slot)
+        if sb is None:
+            dev = self.device
+            sb = {'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
+                  'dedupe': torch.zeros((lib().dt_deepfm_dedupe_bytes(B, self.F) + 7) // 8, dtype=torch.int64, device=dev),
+                  'dedupe_slots': buf['dedupe_slots']}
+            slots[slot] = sb
+        return sb
+
+    def can_preelect(self, B):
+        """the step's ids-only half can run ahead of it (dt_deepfm_preelect): in-step dedupe on, single process"""
+        st = self.dm.config.distribute_strategy
+        # OFF by default (DT_AMD_PREELECT=1 turns it on).  Measured (tools/r4/call7.sh): a forked branch of a captured hipGraph
+        # does not run beside the main branch on this stack — the executor ran the nine elections first, on one queue, then
+        # alternated queues per step with ~9.5 us joins: 131.9 us per step against 109.5 us with every step electing for
+        # itself.  The entry point stays for a caller that owns a second stream outside a graph.
+        return bool(st is None and _dedupe_in_step(self, B, True) and os.environ.get('DT_AMD_PREELECT', '0') == '1')
+
+    def preelect(self, idx, slot):
+        """rows + segments of batch `idx` into slot `slot`'s buffers, on the current stream; the step that follows is run
+        with `run(..., slot=slot, preelected=True)`"""
+        B = idx.shape[0]
+        sb = self._slot_buffers(B, slot)
+        idx = idx.contiguous()
+        kind = _lib.DT_IDX_F32 if idx.dtype == torch.float32 else _lib.DT_IDX_I32
+        if idx.dtype not in (torch.float32, torch.int32):
+            raise ValueError('preelect: ids must be float32 or int32')
+        check(lib().dt_deepfm_preelect(ptr(idx), kind, ptr(getattr(self.emb, f'row_offset_{self.key}')),
+                                       ptr(getattr(self.emb, f'vocab_{self.key}')), B, self.F, ptr(sb['rows']),
+                                       ptr(sb['dedupe']), sb['dedupe_slots'], stream_ptr()), 'dt_deepfm_preelect')
+
     # -- model-parallel tables (parallel.ShardedEmbeddingStrategy) --------------------------------------
     def _sharded_buffers(self, B, st):
         key = ('sharded', B)
@@ -350,8 +388,9 @@ class FusedDeepFM:
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
         return work
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None):
-        """-> (loss [1] view, logit [B,1]).  logit_out: a caller-owned [B,1] fp32 buffer the step writes its logits to (the
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None, slot=0,
+            preelected=False):
+        """-> (loss [1] view, logit [B,1]).  slot / preelected: the compiled loop's per-step id buffers (`preelect`).  logit_out: a caller-owned [B,1] fp32 buffer the step writes its logits to (the
         compiled loop keeps one per captured step) instead of the plan's own.  With backward=True fills `.grad` of every dense parameter
         (views of one static buffer) and registers the embedding table's sparse gradient.  apply_rows=True: the caller
         runs `optimizer.step()` right after this call, so the step may update the table rows looked up once itself
@@ -379,15 +418,19 @@ class FusedDeepFM:
             logit = logit_out
         dedupe = _dedupe_in_step(self, B, backward)
         opt = _rows_in_step(self, B, backward, apply_rows)
+        ids = self._slot_buffers(B, slot) if (slot and dedupe) else buf        # this step's rows / segment buffers
+        pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
+        if preelected and not pre:
+            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process, B <= 8192)')
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
                 ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
                 float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
                 ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
-                ptr(logit), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(logit), ptr(ids['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
                 ptr(self.emb.oob_count) if self.emb.check_oob else None,
-                ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
+                ptr(ids['dedupe']) if dedupe else None, buf['dedupe_slots'])
         whole = False
         if opt is not None:
             # the rows looked up once are updated where their gradient is formed (csrc/deepfm.hip k_wgrad_rows); when the
@@ -400,14 +443,14 @@ class FusedDeepFM:
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_deepfm_train_step_adam(
-                *head, 2 | _step_loss(self.dm) | self.tower_flag, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | self.tower_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_deepfm_train_step(
-                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0),
+                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0) | pre,
                 self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_deepfm_train_step')
         if backward:
@@ -415,13 +458,13 @@ class FusedDeepFM:
                 p.grad = g
             # with the in-step dedupe: rows looked up once keep their entry, the others travel as segments; fields = -2:
             # the entries of `rows` were applied inside the step, the optimizer only walks the segments
-            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
+            self.emb.sparse_grads[self.key] = [SparseRowGrad(ids['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
                                                              fields=(-2 if opt is not None else -1) if dedupe else None,
-                                                             segments=_segments(buf, B, self.F) if dedupe else None)]
+                                                             segments=_segments(ids, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)
-                check(lib().dt_embedding_bwd_dense(ptr(buf['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
+                check(lib().dt_embedding_bwd_dense(ptr(ids['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
                                                    ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
                 table.grad = g
                 self.emb.sparse_grads.pop(self.key, None)
@@ -544,7 +587,8 @@ class FusedDCN(FusedDeepFM):
             self._bufs[B] = b
         return b
 
-    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None):
+    def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None, slot=0,
+            preelected=False):
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
@@ -564,15 +608,19 @@ class FusedDCN(FusedDeepFM):
             logit = logit_out
         dedupe = _dedupe_in_step(self, B, backward)
         opt = _rows_in_step(self, B, backward, apply_rows)
+        ids = self._slot_buffers(B, slot) if (slot and dedupe) else buf        # this step's rows / segment buffers
+        pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
+        if preelected and not pre:
+            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process, B <= 8192)')
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),
                 ptr(self.bn.moving_mean) if training else None, ptr(self.bn.moving_variance) if training else None,
                 float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
                 ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.out.kernel), ptr(self.one), ptr(self.out.bias),
-                ptr(logit), ptr(buf['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
+                ptr(logit), ptr(ids['rows']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
                 ptr(self.emb.oob_count) if self.emb.check_oob else None,
-                ptr(buf['dedupe']) if dedupe else None, buf['dedupe_slots'])
+                ptr(ids['dedupe']) if dedupe else None, buf['dedupe_slots'])
         if opt is not None:      # the whole optimizer step inside the train step (see FusedDeepFM.run)
             slots = opt._st(table, rows=True)
             flat = getattr(opt, '_flat', None)
@@ -581,25 +629,25 @@ class FusedDCN(FusedDeepFM):
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_dcn_train_step_adam(
-                *head, 2 | _step_loss(self.dm), self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_dcn_train_step(
-                *head, (2 if backward else 1) | _step_loss(self.dm), self.emb_dropout if training else 0.0,
+                *head, (2 if backward else 1) | _step_loss(self.dm) | pre, self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_dcn_train_step')
         if backward:
             for p, g in self.grad_views:
                 p.grad = g
-            self.emb.sparse_grads[self.key] = [SparseRowGrad(buf['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
+            self.emb.sparse_grads[self.key] = [SparseRowGrad(ids['rows'].view(-1), buf['grad_rows'].view(-1, self.D),
                                                              fields=(-2 if opt is not None else -1) if dedupe else None,
-                                                             segments=_segments(buf, B, self.F) if dedupe else None)]
+                                                             segments=_segments(ids, B, self.F) if dedupe else None)]
             if self.emb.uses_dense_grad(self.D):
                 # small tables keep exact dense-Adam semantics: densify the row gradients
                 g = torch.zeros_like(table)
-                check(lib().dt_embedding_bwd_dense(ptr(buf['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
+                check(lib().dt_embedding_bwd_dense(ptr(ids['rows']), ptr(buf['grad_rows']), B * self.F, self.D,
                                                    ptr(g), stream_ptr()), 'dt_embedding_bwd_dense')
                 table.grad = g
                 self.emb.sparse_grads.pop(self.key, None)

@@ -257,7 +257,7 @@ class DeepModel:
             self._fused_plan = make_fused_plan(self)
         return self._fused_plan
 
-    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None):
+    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None, slot=0, preelected=False):
         """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
         sample_weight [B] (Keras fit's sample_weight x class_weight): the DeepFM / DCN plans scale each row's loss inside
         their loss block; other plans leave a weighted step to the layer-by-layer path.
@@ -276,6 +276,8 @@ class DeepModel:
             kw = {} if sample_weight is None else {'sample_weight': sample_weight}
             if logit_out is not None:
                 kw['logit_out'] = logit_out
+            if slot:
+                kw['slot'], kw['preelected'] = slot, preelected
             loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows, **kw)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit

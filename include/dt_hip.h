@@ -438,13 +438,21 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * beside the collective.  accum is complete after the second call.
  * phases | DT_STEP_TOWER_X3 (backward steps of dt_deepfm_train_step / _adam): the Dense tower's four GEMMs of the tile kernel
  * (Dense128, Dense64, dH1 = dH2 W2^T, dXn = dH1 W1^T; deepnets.py:401-427) run on v_mfma_f32_16x16x32_bf16 with SPLIT
- * operands — a = a_hi + a_lo (two bf16 halves, 16 mantissa bits), a b ~ a_hi b_hi + (a_hi b_lo + a_lo b_hi), fp32
- * accumulate: 3/16 of the fp32-MFMA time at ~2^-17 relative error per product (logits within 1e-4 of the fp32 oracle:
- * DESIGN.md).  Weights are split once per step by the prep launch, activations once while they are staged in LDS.   */
+ * operands and fp32 accumulation (csrc/tower_x3.h): forward a = a1 + a2 + a3 (three bf16 parts = all 24 mantissa bits,
+ * six products, the dropped terms 2^-24 of the product: fp32-class logits and relu decisions), backward a = a_hi + a_lo
+ * (16 bits, three products, 2^-17 per product).  6/16 resp. 3/16 of the fp32-MFMA time.  Weights are split once per step
+ * by the prep launch, activations while they are staged.
+ * phases | DT_STEP_PREELECTED: rows_out and dedupe_ws were filled for THIS idx by dt_deepfm_preelect — the step's ids-only
+ * work (packed rows of the lookups, the election of the rows looked up several times) ran ahead of it, on another stream or at
+ * an earlier point of a captured graph (deeptables_amd/compiled.py: the elections of steps 2..k of an execution run beside
+ * step 1), and is left out of the step's gather and prep launches.                                                */
 #define DT_STEP_LOSS_MSE 0x10
 #define DT_STEP_SKIP_FINISH 0x20
 #define DT_STEP_FINISH_ONLY 0x40
 #define DT_STEP_TOWER_X3 0x80
+#define DT_STEP_PREELECTED 0x100
+int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset, const int32_t* vocab, int B, int F,
+                       int64_t* rows_out, void* dedupe_ws, int64_t dedupe_slots, void* stream);
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7_host);

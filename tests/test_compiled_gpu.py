@@ -66,6 +66,7 @@ def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
         assert eager.compiled_loop is None
         loop = graphed.compiled_loop
         assert loop is not None and loop.graph is not None and loop.k == 10
+        assert not loop.preelected                   # (opt-in, next test)
         assert type(graphed.fused_plan()).__name__ == ('FusedDCN' if net == 'DCN' else 'FusedDeepFM')
         _same(eager, graphed)
         assert eager.optimizer.t == graphed.optimizer.t == 3 * 23
@@ -146,5 +147,27 @@ def test_compiled_loop_on_a_device_feed_reuses_its_graph(dev):
         t1 = dm.optimizer.t
         dm.fit(feed, batch_size=64, epochs=2, verbose=0, steps_per_execution=5)
         assert dm.compiled_loop is loop and dm.optimizer.t == t1 + 40
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+def test_preelected_steps_train_like_eager_steps(dev, monkeypatch):
+    """DT_AMD_PREELECT=1: the ids-only half of steps 2..k of an execution (packed rows, the election of the rows looked up
+    several times: dt_deepfm_preelect) runs ahead of them on a forked branch of the captured graph, the steps skip it
+    (DT_STEP_PREELECTED).  Same weights as eager steps; vocab 40: most lookups are segment members"""
+    from deeptables_amd.models import layers as dl
+    monkeypatch.setenv('DT_AMD_PREELECT', '1')
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    try:
+        for net in ('DeepFM', 'DCN'):
+            df, y = _frame(64 * 23 + 17)
+            extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
+            eager, graphed = _model(net, **extra), _model(net, **extra)
+            h0 = _fit(eager, df, y, 1)
+            h1 = _fit(graphed, df, y, 10)
+            assert graphed.compiled_loop.preelected and graphed.compiled_loop.k == 10
+            _same(eager, graphed)
+            assert np.allclose(h0.history['loss'], h1.history['loss'], atol=2e-6)
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
