@@ -227,7 +227,7 @@ def parity_leg(args, device):
         for kind in (('uniform', 'zipf') if args.model in ('DeepFM', 'DCN') else (args.dist,)):
             b = make_batches(args.batch, device, seed=1234, dist_kind=kind)[0]
             r = headline.check_train_step(dm, b)
-            bf16 = args.model == 'xDeepFM' and os.environ.get('DT_AMD_CIN_DTYPE', '') == 'bf16'
+            bf16 = args.model == 'xDeepFM' and (os.environ.get('DT_AMD_CIN_DTYPE', '') == 'bf16' or args.cin == 'bf16')
             good, rule = headline.verdict(r, bf16=bf16)
             ok = ok and good
             rules.add(rule)
@@ -364,6 +364,8 @@ def main():
     ap.add_argument('--tower', default=None, choices=['f32', 'bf16x3'],
                     help="dnn_params['mfma_dtype'] of the fused DeepFM / DCN step: exact-fp32 MFMA or the split-bf16 tower "
                          "(csrc/tower_x3.h); default: the library's")
+    ap.add_argument('--cin', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                    help="cin_params['mfma_dtype'] of xDeepFM: exact-fp32 MFMA, split-bf16 (fp32 bars) or plain bf16 (1e-2 bars)")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--steps-per-graph', type=int, default=10,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
@@ -429,6 +431,10 @@ def main():
         mp = dict(MODEL_PARAMS.get(args.model) or {})
         mp['dnn_params'] = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': args.tower}
         MODEL_PARAMS[args.model] = mp
+    if args.cin is not None and args.model == 'xDeepFM':
+        mp = dict(MODEL_PARAMS['xDeepFM'])
+        mp['cin_params'] = dict(mp['cin_params'], mfma_dtype={'f32': 'float32'}.get(args.cin, args.cin))
+        MODEL_PARAMS['xDeepFM'] = mp
     parity = None
     if rank == 0 and world == 1 and not args.no_parity and args.model in ('DeepFM', 'DCN', 'xDeepFM', 'AutoInt'):
         try:
@@ -504,12 +510,21 @@ def main():
         }
         fpr = mfma_flops_per_row(args.model, dim)
         if fpr is not None:      # CIN / attention graphs: the matrix cores bound the step, not HBM
-            bf16 = args.model == 'xDeepFM' and os.environ.get('DT_AMD_CIN_DTYPE') == 'bf16'
-            peak = MFMA_PEAK_BF16_TFLOPS if bf16 else MFMA_PEAK_F32_TFLOPS
+            cin_mode = (MODEL_PARAMS.get('xDeepFM', {}).get('cin_params', {}).get('mfma_dtype') or
+                        os.environ.get('DT_AMD_CIN_DTYPE', 'float32')) if args.model == 'xDeepFM' else 'float32'
+            bf16 = cin_mode == 'bf16'
+            x3 = cin_mode == 'bf16x3'
+            # split-bf16: the useful flops are still the fp32 contraction's; priced against the bf16 pipe they run on
+            peak = MFMA_PEAK_BF16_TFLOPS if (bf16 or x3) else MFMA_PEAK_F32_TFLOPS
             tf = args.batch * fpr / step_s / 1e12
             result['roofline_hbm'] = result['roofline']
             result['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
-                                  'traffic': None, 'mfma_dtype': 'bf16 (fp32 accumulate)' if bf16 else 'f32',
+                                  'traffic': None,
+                                  'mfma_dtype': ('bf16 (fp32 accumulate)' if bf16 else
+                                                 'split-bf16: 6 bf16 MFMAs per product forward, 3 backward (fp32 accumulate, fp32 '
+                                                 'bars); frac = useful flops / bf16 peak, issued MFMA flops are 4x that' if x3
+                                                 else 'f32'),
+                                  'frac_of_f32_mfma_peak': tf / MFMA_PEAK_F32_TFLOPS,
                                   'flops_per_row': fpr, 'launch_us': step_s * 1e6,
                                   'launch': f'one train step = one hipGraph replay / {spg}; flops = the CIN / attention '
                                             'contractions, fwd + dgrad + wgrad'}

@@ -65,6 +65,11 @@ SIGNATURES = {
                                        _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr]),
     'dt_cin_layer_bwd_bf16': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'dt_cin_bf16x3_workspace_bytes': (_c_i64, [_c_int, _c_int, _c_int]),
+    'dt_cin_layer_fwd_bf16x3': (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                         _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr]),
+    'dt_cin_layer_bwd_bf16x3': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                         _c_int, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_mha_core_fwd': (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32, _ptr,
                                  _ptr, _ptr]),
     'dt_mha_core_bwd': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -13,6 +13,14 @@
 //   * wgrad contracts over the rows m = (b,d): x0 / xk / G are staged [i][m], [j][m], [l][m] so that 8 consecutive m
 //     are one read.
 // Tile shapes, the T-never-stored dgrad and the batch-split wgrad follow cin.hip.
+//
+// SPLIT-bf16 mode (round 4; dt_cin_layer_fwd_bf16x3 / _bwd_bf16x3, cin_params['mfma_dtype'] = 'bf16x3'): the same three
+// kernels with every fp32 operand split into NP bf16 parts (a = a_1 + .. + a_NP, each the rounding of what the parts before
+// it left; three parts = all 24 mantissa bits) and the products a_p b_q with p + q <= NP + 1 on the matrix cores, fp32
+// accumulate — as csrc/tower_x3.h does for the Dense tower.  FORWARD: three parts, six products (the dropped terms are 2^-24
+// of the product): fp32-class outputs, so the layer's relu units land on the other side of their kink no more often than
+// with fp32 arithmetic.  BACKWARD (dgrad, wgrad): two parts, three products (2^-17 per product).  gfx950's fp32 MFMA runs
+// at 1/16 of the bf16 rate: 6/16 resp. 3/16 of its time.
 #include "common.h"
 
 namespace dt {
@@ -40,26 +48,62 @@ __device__ __forceinline__ cb_b8 cb_zero() {
     for (int e = 0; e < 8; ++e) r[e] = (__bf16)0.f;
     return r;
 }
+// v = out[0] + .. + out[NP-1]: bf16 parts, each the rounding of what the parts before it left
+template <int NP>
+__device__ __forceinline__ void cb_split(const float (&v)[8], cb_b8 (&out)[NP]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r = v[e];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const __bf16 a = (__bf16)r;
+            out[k][e] = a;
+            r -= (float)a;
+        }
+    }
+}
+// acc += sum_{p + q < NP} a[p] b[q], smallest terms first
+template <int NP>
+__device__ __forceinline__ void cb_mma(cb_f16v& acc, const cb_b8 (&a)[NP], const cb_b8 (&b)[NP]) {
+#pragma unroll
+    for (int t = NP - 1; t >= 0; --t)
+#pragma unroll
+        for (int pa = 0; pa <= t; ++pa) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[t - pa], acc, 0, 0, 0);
+}
 __host__ __device__ inline int cb_hp(int Hk) { return (Hk + 7) & ~7; }
 __host__ __device__ inline int cb_lq(int L) { return (L + 15) & ~15; }
 
 // W [F0*Hk][L] fp32 -> WT [Lp][Kp] bf16 (Lp = L rounded up to 128, Kp = F0*Hp, k' = i*Hp + j) and
 //                      WN [F0*njb*32][Lq] bf16 (row (i*njb + jb)*32 + r <-> j = 32 jb + r), zero padded
+template <int NP>
 __global__ __launch_bounds__(256) void k_cin_pack_w(const float* __restrict__ W, int F0, int Hk, int L,
                                                     __bf16* __restrict__ WT, __bf16* __restrict__ WN) {
     const int Hp = cb_hp(Hk), Kp = F0 * Hp, Lp = (L + kBN - 1) / kBN * kBN, Lq = cb_lq(L), njb = (Hk + 31) / 32;
-    const int64_t nT = (int64_t)Lp * Kp, nN = (int64_t)F0 * njb * 32 * Lq;
+    const int64_t nT = (int64_t)Lp * Kp, nN = (int64_t)F0 * njb * 32 * Lq;        // elements of ONE part of each layout
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nT + nN; e += (int64_t)gridDim.x * blockDim.x) {
+        float r;
+        __bf16* dst;
+        int64_t stride;
         if (e < nT) {
+            if (!WT) continue;
             const int n = (int)(e / Kp), kp = (int)(e - (int64_t)n * Kp);
             const int i = kp / Hp, j = kp - i * Hp;
-            WT[e] = (__bf16)((n < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + n] : 0.f);
+            r = (n < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + n] : 0.f;
+            dst = WT + e; stride = nT;
         } else {
+            if (!WN) continue;
             const int64_t q = e - nT;
             const int row = (int)(q / Lq), l = (int)(q - (int64_t)row * Lq);
-            const int ib = row >> 5, r = row & 31;
-            const int i = ib / njb, j = (ib - i * njb) * 32 + r;
-            WN[q] = (__bf16)((l < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + l] : 0.f);
+            const int ib = row >> 5, rr = row & 31;
+            const int i = ib / njb, j = (ib - i * njb) * 32 + rr;
+            r = (l < L && j < Hk) ? W[((int64_t)i * Hk + j) * L + l] : 0.f;
+            dst = WN + q; stride = nN;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const __bf16 a = (__bf16)r;
+            dst[k * stride] = a;
+            r -= (float)a;
         }
     }
 }
@@ -67,18 +111,20 @@ __global__ __launch_bounds__(256) void k_cin_pack_w(const float* __restrict__ W,
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <bool kAnyAct>  // false: linear / relu only (see k_cin_fwd)
+template <bool kAnyAct, int NP>  // kAnyAct false: linear / relu only (see k_cin_fwd); NP: bf16 parts per operand (1: plain bf16 mode)
 __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
-    const __bf16* __restrict__ WT, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L, int D,
-    float* __restrict__ y) {
+    const __bf16* __restrict__ WT, int64_t wt_part, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
+    int D, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KCH = NP == 1 ? kBK : 16;              // k' per LDS chunk of W^T (split mode: NP x the bytes per k')
+    constexpr int WSb = KCH + 8;                         // bf16 row stride of a chunk row: 80 / 48 B -> distinct bank groups
     const int Hp = cb_hp(Hk), Kp = F0 * Hp;
     const int F0S = F0 | 1, HS = Hp + 4;
     const int64_t M = (int64_t)B * D;
     float* x0T = lds;                    // [kBM][F0S]
     float* xkT = x0T + kBM * F0S;        // [kBM][HS], zero beyond Hk
-    __bf16* wtb = reinterpret_cast<__bf16*>(xkT + kBM * HS);     // [2][kBN][kBWS]
+    __bf16* wtb = reinterpret_cast<__bf16*>(xkT + kBM * HS);     // [2][NP][kBN][WSb]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * kBM;
@@ -94,23 +140,26 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
         const int64_t m = m0 + r;
         xkT[r * HS + j] = (m < M && j < Hk) ? xk[(m / D) * xk_bs + (int64_t)j * D + (m % D)] : 0.f;
     }
-    // W^T chunk loader: 128 filters x 32 k' bf16 = 512 x 16 B, two per thread
-    const int Lp = (L + kBN - 1) / kBN * kBN;
-    (void)Lp;
-    cb_f4 wreg[2];
+    // W^T chunk loader: NP parts x 128 filters x KCH k' bf16 in 16-byte pieces, kWR per thread
+    constexpr int kPieces = NP * kBN * (KCH / 8), kWR = (kPieces + 255) / 256;
+    cb_f4 wreg[kWR];
     auto load_w = [&](int chunk) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = threadIdx.x + 256 * u, n = e >> 2, pc = e & 3;
-            const int kp = chunk * kBK + 8 * pc;
-            wreg[u] = kp < Kp ? *reinterpret_cast<const cb_f4*>(WT + (int64_t)(n0 + n) * Kp + kp) : cb_f4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (KCH / 8), n = (e / (KCH / 8)) % kBN, part = e / ((KCH / 8) * kBN);
+            const int kp = chunk * KCH + 8 * pc;
+            wreg[u] = (e < kPieces && kp < Kp)
+                          ? *reinterpret_cast<const cb_f4*>(WT + part * wt_part + (int64_t)(n0 + n) * Kp + kp)
+                          : cb_f4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = threadIdx.x + 256 * u, n = e >> 2, pc = e & 3;
-            *reinterpret_cast<cb_f4*>(wtb + (buf * kBN + n) * kBWS + 8 * pc) = wreg[u];
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (KCH / 8), n = (e / (KCH / 8)) % kBN, part = e / ((KCH / 8) * kBN);
+            if (e < kPieces) *reinterpret_cast<cb_f4*>(wtb + ((buf * NP + part) * kBN + n) * WSb + 8 * pc) = wreg[u];
         }
     };
     cb_f16v acc[4];
@@ -118,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    const int nchunks = (Kp + kBK - 1) / kBK;
+    const int nchunks = (Kp + KCH - 1) / KCH;
     load_w(0);
     store_w(0);
     __syncthreads();
@@ -130,21 +179,26 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks) load_w(chunk + 1);
 #pragma unroll
-        for (int st = 0; st < kBK / 16; ++st) {
-            const int kp = chunk * kBK + 16 * st + 8 * s;
-            cb_b8 a = cb_zero();
+        for (int st = 0; st < KCH / 16; ++st) {
+            const int kp = chunk * KCH + 16 * st + 8 * s;
+            cb_b8 a[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) a[q] = cb_zero();
             if (kp < Kp) {
                 const int i = kp / Hp, j0 = kp - i * Hp;
                 const float xv = x0r[i];
-                const cb_f4 lo = *reinterpret_cast<const cb_f4*>(xkr + j0), hi = *reinterpret_cast<const cb_f4*>(xkr + j0 + 4);
-                a = cb_pack(lo * xv, hi * xv);
+                const cb_f4 lo = *reinterpret_cast<const cb_f4*>(xkr + j0) * xv, hi = *reinterpret_cast<const cb_f4*>(xkr + j0 + 4) * xv;
+                const float z[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                cb_split<NP>(z, a);
             }
-            const __bf16* wrow = wtb + (buf * kBN + c) * kBWS + 16 * st + 8 * s;
+            const __bf16* wrow = wtb + (buf * NP * kBN + c) * WSb + 16 * st + 8 * s;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 if (nb < nblocks_n) {
-                    const cb_b8 b = *reinterpret_cast<const cb_b8*>(wrow + nb * 32 * kBWS);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+                    cb_b8 b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const cb_b8*>(wrow + (q * kBN + nb * 32) * WSb);
+                    cb_mma<NP>(acc[nb], a, b);
                 }
         }
         if (chunk + 1 < nchunks) store_w(buf ^ 1);
@@ -184,17 +238,17 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
 // dgrad: grad_x0 (=), grad_xk (=): both OVERWRITTEN (one block owns a 128-row tile of m and all of its (i, j)).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
 // lane that owns column m against xk / x0; grad_x0 is gathered in LDS and flushed once.
 // ------------------------------------------------------------------------------------------
-template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */>
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */>
 __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
-    const __bf16* __restrict__ WN, const float* __restrict__ y, const float* __restrict__ gy, int act,
+    const __bf16* __restrict__ WN, int64_t wn_part, const float* __restrict__ y, const float* __restrict__ gy, int act,
     int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int64_t M = (int64_t)B * D;
     const int F0S = F0 | 1, Lq = cb_lq(L), WS = 16 * LSTEPS + 8;
     float* x0T = lds;                    // [kBM][F0S]
     float* g0T = x0T + kBM * F0S;        // [kBM][F0S] grad_x0 of the tile
-    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + kBM * F0S);   // [2][32][WS]
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + kBM * F0S);   // [2][NP][32][WS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * kBM;
@@ -211,7 +265,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
     const int d = mvalid ? (int)(m % D) : 0;
 
     // G[m][l] for l = 16 st + 8 s + e as the B operand, kept in registers for the whole tile
-    cb_b8 G[LSTEPS];
+    cb_b8 G[LSTEPS][NP];
 #pragma unroll
     for (int st = 0; st < LSTEPS; ++st) {
         float gv[8];
@@ -225,7 +279,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
             }
             gv[e] = g;
         }
-        G[st] = cb_pack(cb_f4{gv[0], gv[1], gv[2], gv[3]}, cb_f4{gv[4], gv[5], gv[6], gv[7]});
+        cb_split<NP>(gv, G[st]);
     }
     // xk values this lane needs: j = jb*32 + (r&3) + 8*(r>>2) + 4*s
     float xkv[JB][16], gxk_acc[JB][16];
@@ -243,9 +297,11 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
     auto stage_w = [&](int chunk, int buf) {
         const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
         const int pieces = Lq / 8;                      // 16-byte pieces per row
-        for (int e = threadIdx.x; e < 32 * pieces; e += 256) {
-            const int r = e / pieces, pc = e - r * pieces;
-            *reinterpret_cast<cb_f4*>(wtl + (buf * 32 + r) * WS + 8 * pc) = *reinterpret_cast<const cb_f4*>(src + r * Lq + 8 * pc);
+        for (int e = threadIdx.x; e < NP * 32 * pieces; e += 256) {
+            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
+            const int r = q / pieces, pc = q - r * pieces;
+            *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) =
+                *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
         }
     };
     const int lsteps = Lq / 16;
@@ -255,14 +311,18 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
         if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
-        const __bf16* wrow = wtl + (buf * 32 + c) * WS + 8 * s;
+        const __bf16* wrow = wtl + (buf * NP * 32 + c) * WS + 8 * s;
         cb_f16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int st = 0; st < LSTEPS; ++st)
-            if (st < lsteps)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cb_b8*>(wrow + 16 * st), G[st], acc, 0, 0, 0);
+            if (st < lsteps) {
+                cb_b8 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * 32 * WS + 16 * st);
+                cb_mma<NP>(acc, a, G[st]);
+            }
         // contract T^T[j, m] (16 j's in this lane) against xk and x0
         const float x0v = x0T[row * F0S + i];
         float p = 0.f;
@@ -298,6 +358,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
 // ------------------------------------------------------------------------------------------
 // wgrad: grad_W[k, l] += sum_m Z[m,k] G[m,l]
 // ------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
@@ -308,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
     constexpr int XS = kBMC + 4, GS = kBMC + 8;
     float* x0s = lds;                    // [F0][XS]  (rows m contiguous)
     float* xks = x0s + F0 * XS;          // [Hk][XS]
-    __bf16* gsb = reinterpret_cast<__bf16*>(xks + Hk * XS);     // [kBN][GS]
+    __bf16* gsb = reinterpret_cast<__bf16*>(xks + Hk * XS);     // [NP][kBN][GS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int kbase = blockIdx.x * (128 * kBKT) + wave * (32 * kBKT);
@@ -385,9 +446,18 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
                             o.z *= act_grad_from_y(yv[u].z, act); o.w *= act_grad_from_y(yv[u].w, act);
                         }
                         typedef __bf16 cb_b4 __attribute__((ext_vector_type(4)));
-                        cb_b4 h;
-                        h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
-                        *reinterpret_cast<cb_b4*>(gsb + (-dst[u] - 2)) = h;
+                        float rr[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            cb_b4 h;
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const __bf16 a = (__bf16)rr[e4];
+                                h[e4] = a;
+                                rr[e4] -= (float)a;
+                            }
+                            *reinterpret_cast<cb_b4*>(gsb + q * kBN * GS + (-dst[u] - 2)) = h;
+                        }
                     }
                 }
             }
@@ -410,32 +480,41 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
                 const int64_t o = ((b0 + bq) * L + n0 + l) * D + dq;
                 g = gy[o] * act_grad_from_y(y[o], act);
             }
-            gsb[l * GS + r] = (__bf16)g;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const __bf16 a = (__bf16)g;
+                gsb[q * kBN * GS + l * GS + r] = a;
+                g -= (float)a;
+            }
         }
         }
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < kBMC / 16; ++st) {
             const int r0 = 16 * st + 8 * s;
-            cb_b8 a[kBKT];
+            cb_b8 a[kBKT][NP];
 #pragma unroll
             for (int u = 0; u < kBKT; ++u) {
-                a[u] = cb_zero();
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[u][q] = cb_zero();
                 if (kvalid[u]) {
                     const float* xp = x0s + ki[u] * XS + r0;
                     const float* kp = xks + kj[u] * XS + r0;
-                    a[u] = cb_pack(*reinterpret_cast<const cb_f4*>(xp) * *reinterpret_cast<const cb_f4*>(kp),
-                                   *reinterpret_cast<const cb_f4*>(xp + 4) * *reinterpret_cast<const cb_f4*>(kp + 4));
+                    const cb_f4 lo = *reinterpret_cast<const cb_f4*>(xp) * *reinterpret_cast<const cb_f4*>(kp),
+                                hi = *reinterpret_cast<const cb_f4*>(xp + 4) * *reinterpret_cast<const cb_f4*>(kp + 4);
+                    const float z[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    cb_split<NP>(z, a[u]);
                 }
             }
             const __bf16* grow = gsb + c * GS + r0;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 if (nb < nblocks_n) {
-                    const cb_b8 g = *reinterpret_cast<const cb_b8*>(grow + nb * 32 * GS);
+                    cb_b8 g[NP];
 #pragma unroll
-                    for (int u = 0; u < kBKT; ++u)
-                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], g, acc[u][nb], 0, 0, 0);
+                    for (int q = 0; q < NP; ++q) g[q] = *reinterpret_cast<const cb_b8*>(grow + (q * kBN + nb * 32) * GS);
+#pragma unroll
+                    for (int u = 0; u < kBKT; ++u) cb_mma<NP>(acc[u][nb], a[u], g);
                 }
         }
     }
@@ -481,78 +560,94 @@ static int cinb_check(const char* who, int B, int F0, int Hk, int L, int D) {
     return DT_OK;
 }
 
-// workspace: WT [Lp][Kp] + WN [F0*njb*32][Lq], bf16
-extern "C" int64_t dt_cin_bf16_workspace_bytes(int F0, int Hk, int L) {
+// workspace: NPF parts of WT [Lp][Kp] + NPB parts of WN [F0*njb*32][Lq], bf16
+static int64_t cinb_nT(int F0, int Hk, int L) { return ((int64_t)(L + kBN - 1) / kBN * kBN) * ((int64_t)F0 * cb_hp(Hk)); }
+static int64_t cinb_nN(int F0, int Hk, int L) { return (int64_t)F0 * ((Hk + 31) / 32) * 32 * cb_lq(L); }
+static int64_t cinb_ws_bytes(int F0, int Hk, int L, int npf, int npb) {
     if (F0 <= 0 || Hk <= 0 || L <= 0) return 0;
-    const int64_t Kp = (int64_t)F0 * cb_hp(Hk), Lp = (L + kBN - 1) / kBN * kBN;
-    const int64_t nN = (int64_t)F0 * ((Hk + 31) / 32) * 32 * cb_lq(L);
-    return 2 * (Lp * Kp + nN) + 64;
+    return 2 * (npf * cinb_nT(F0, Hk, L) + npb * cinb_nN(F0, Hk, L)) + 64;
+}
+extern "C" int64_t dt_cin_bf16_workspace_bytes(int F0, int Hk, int L) { return cinb_ws_bytes(F0, Hk, L, 1, 1); }
+extern "C" int64_t dt_cin_bf16x3_workspace_bytes(int F0, int Hk, int L) { return cinb_ws_bytes(F0, Hk, L, 3, 2); }
+
+// the filter's bf16 parts: WT (forward, NPF parts) at the start of ws, WN (dgrad, NPB parts) behind it; a NULL result is not packed
+template <int NP>
+static void cinb_pack(const float* W, int F0, int Hk, int L, __bf16* WT, __bf16* WN, hipStream_t st) {
+    hipLaunchKernelGGL(k_cin_pack_w<NP>, dim3(512), dim3(256), 0, st, W, F0, Hk, L, WT, WN);
 }
 
-static void cinb_pack(const float* W, int F0, int Hk, int L, void* ws, __bf16** WT, __bf16** WN, hipStream_t st) {
-    const int64_t Kp = (int64_t)F0 * cb_hp(Hk), Lp = (L + kBN - 1) / kBN * kBN;
-    *WT = reinterpret_cast<__bf16*>(ws);
-    *WN = *WT + ((Lp * Kp + 7) & ~(int64_t)7);
-    hipLaunchKernelGGL(k_cin_pack_w, dim3(512), dim3(256), 0, st, W, F0, Hk, L, *WT, *WN);
+template <int NP>
+static int cinb_fwd(const char* who, const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
+                    int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y, void* ws, void* stream) {
+    int rc = cinb_check(who, B, F0, Hk, L, D);
+    if (rc) return rc;
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(x0 && xk && W && y && ws, "%s: null pointer", who);
+    DT_REQUIRE(act >= 0 && act < DT_ACT_COUNT, "%s: act %d", who, act);
+    hipStream_t st = as_stream(stream);
+    __bf16* WT = reinterpret_cast<__bf16*>(ws);
+    cinb_pack<NP>(W, F0, Hk, L, WT, nullptr, st);
+    constexpr int KCH = NP == 1 ? kBK : 16;
+    const size_t lds = ((size_t)kBM * ((F0 | 1) + cb_hp(Hk) + 4)) * sizeof(float) + (size_t)2 * NP * kBN * (KCH + 8) * 2;
+    DT_UNSUPPORTED(lds > 160 * 1024, "%s: tiles need %zu B of LDS (> 160 KiB)", who, lds);
+    const int64_t M = (int64_t)B * D;
+    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
+    if (act == DT_ACT_LINEAR || act == DT_ACT_RELU) {
+        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cin_fwd_bf16<false, NP>), grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT,
+                           cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);
+    } else {
+        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cin_fwd_bf16<true, NP>), grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT,
+                           cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);
+    }
+    return launch_status(who);
 }
 
 extern "C" int dt_cin_layer_fwd_bf16(const float* x0, const float* xk, const float* W, const float* bias, int act, int B,
                                      int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y,
                                      void* ws, void* stream) {
-    int rc = cinb_check("dt_cin_layer_fwd_bf16", B, F0, Hk, L, D);
-    if (rc) return rc;
-    if (B == 0) return DT_OK;
-    DT_REQUIRE(x0 && xk && W && y && ws, "dt_cin_layer_fwd_bf16: null pointer");
-    DT_REQUIRE(act >= 0 && act < DT_ACT_COUNT, "dt_cin_layer_fwd_bf16: act %d", act);
-    hipStream_t st = as_stream(stream);
-    __bf16 *WT, *WN;
-    cinb_pack(W, F0, Hk, L, ws, &WT, &WN, st);
-    const size_t lds = ((size_t)kBM * ((F0 | 1) + cb_hp(Hk) + 4)) * sizeof(float) + (size_t)2 * kBN * kBWS * 2;
-    DT_UNSUPPORTED(lds > 160 * 1024, "dt_cin_layer_fwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
-    const int64_t M = (int64_t)B * D;
-    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
-    if (act == DT_ACT_LINEAR || act == DT_ACT_RELU) {
-        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_cin_fwd_bf16<false>, grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT, bias, act,
-                           B, F0, Hk, L, D, y);
-    } else {
-        hipFuncSetAttribute((const void*)k_cin_fwd_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_cin_fwd_bf16<true>, grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT, bias, act,
-                           B, F0, Hk, L, D, y);
-    }
-    return launch_status("dt_cin_layer_fwd_bf16");
+    return cinb_fwd<1>("dt_cin_layer_fwd_bf16", x0, xk, W, bias, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, y, ws, stream);
+}
+extern "C" int dt_cin_layer_fwd_bf16x3(const float* x0, const float* xk, const float* W, const float* bias, int act, int B,
+                                       int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y,
+                                       void* ws, void* stream) {
+    return cinb_fwd<3>("dt_cin_layer_fwd_bf16x3", x0, xk, W, bias, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, y, ws, stream);
 }
 
-template <int LSTEPS, int JB>
-static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, const float* y,
-                          const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
+template <int LSTEPS, int JB, int NP>
+static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, int64_t wn_part,
+                          const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
                           hipStream_t st) {
-    const size_t lds = (size_t)2 * kBM * (F0 | 1) * sizeof(float) + (size_t)2 * 32 * (16 * LSTEPS + 8) * 2;
+    const size_t lds = (size_t)2 * kBM * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * LSTEPS + 8) * 2;
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
     }
     const int64_t M = (int64_t)B * D;
-    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB>), dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, x0, x0_bs,
-                       xk, xk_bs, WN, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
+    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP>), dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, x0, x0_bs,
+                       xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
     return launch_status("dt_cin_layer_bwd_bf16(dgrad)");
 }
 
-extern "C" int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y,
-                                     int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride,
-                                     float* grad_x0, float* grad_xk, float* grad_W, float* grad_bias, void* ws,
-                                     void* stream) {
-    int rc = cinb_check("dt_cin_layer_bwd_bf16", B, F0, Hk, L, D);
+// NPF: parts the workspace holds for the forward layout (the backward's WN parts start behind them)
+template <int NP, int NPF>
+static int cinb_bwd(const char* who, const float* x0, const float* xk, const float* W, const float* y, const float* grad_y,
+                    int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* grad_x0,
+                    float* grad_xk, float* grad_W, float* grad_bias, void* ws, void* stream) {
+    int rc = cinb_check(who, B, F0, Hk, L, D);
     if (rc) return rc;
     if (B == 0) return DT_OK;
-    DT_REQUIRE(x0 && xk && W && y && grad_y && grad_x0 && grad_xk && grad_W && ws, "dt_cin_layer_bwd_bf16: null pointer");
+    DT_REQUIRE(x0 && xk && W && y && grad_y && grad_x0 && grad_xk && grad_W && ws, "%s: null pointer", who);
     hipStream_t st = as_stream(stream);
-    __bf16 *WT, *WN;
-    cinb_pack(W, F0, Hk, L, ws, &WT, &WN, st);
+    __bf16* WN = reinterpret_cast<__bf16*>(ws) + ((NPF * cinb_nT(F0, Hk, L) + 7) & ~(int64_t)7);
+    cinb_pack<NP>(W, F0, Hk, L, nullptr, WN, st);
+    const int64_t wn_part = cinb_nN(F0, Hk, L);
     const int jb = ceil_div(Hk, 32);
 #define DT_DGRAD_B(LS, JBV)                                                                                          \
-    rc = launch_dgrad_b<LS, JBV>(x0, x0_bstride, xk, xk_bstride, WN, y, grad_y, act, B, F0, Hk, L, D, grad_x0, grad_xk, st)
+    rc = launch_dgrad_b<LS, JBV, NP>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, grad_x0, \
+                                     grad_xk, st)
     if (L <= 128) {
         if (jb <= 1) DT_DGRAD_B(8, 1);
         else if (jb <= 2) DT_DGRAD_B(8, 2);
@@ -572,11 +667,26 @@ extern "C" int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const flo
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + kBMC - 1) / kBMC * kBMC;
     splits = (int)((M + rps - 1) / rps);
-    const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)kBN * (kBMC + 8) * 2;
-    hipFuncSetAttribute((const void*)k_cin_wgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cin_wgrad_bf16, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride,
+    const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)NP * kBN * (kBMC + 8) * 2;
+    hipFuncSetAttribute((const void*)k_cin_wgrad_bf16<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cin_wgrad_bf16<NP>, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride,
                        y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
     if (grad_bias)
         hipLaunchKernelGGL(k_cin_bias_grad_b, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D, grad_bias);
-    return launch_status("dt_cin_layer_bwd_bf16(wgrad)");
+    return launch_status(who);
+}
+
+extern "C" int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y,
+                                     int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride,
+                                     float* grad_x0, float* grad_xk, float* grad_W, float* grad_bias, void* ws,
+                                     void* stream) {
+    return cinb_bwd<1, 1>("dt_cin_layer_bwd_bf16", x0, xk, W, y, grad_y, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, grad_x0,
+                          grad_xk, grad_W, grad_bias, ws, stream);
+}
+extern "C" int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y,
+                                       int act, int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride,
+                                       float* grad_x0, float* grad_xk, float* grad_W, float* grad_bias, void* ws,
+                                       void* stream) {
+    return cinb_bwd<2, 3>("dt_cin_layer_bwd_bf16x3", x0, xk, W, y, grad_y, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, grad_x0,
+                          grad_xk, grad_W, grad_bias, ws, stream);
 }

@@ -509,14 +509,22 @@ __global__ __launch_bounds__(256) void k_feed_gather(const int64_t* __restrict__
     const int per = fb.first[fb.n];
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t r = wave; r < n_rows; r += nwaves) {
-        const int64_t srow = sel[r];
+    constexpr int R = 8;                          // rows per wave and pass: R index loads, then R source loads in flight
+    for (int64_t r0 = wave * R; r0 < n_rows; r0 += nwaves * R) {
+        int64_t srow[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) srow[u] = sel[min(r0 + u, n_rows - 1)];
         for (int q = lane; q < per; q += 64) {
             int b = 0;
 #pragma unroll
             for (int k = 1; k < 8; ++k) b += (k < fb.n && q >= fb.first[k]) ? 1 : 0;
             const int w = fb.first[b + 1] - fb.first[b], c = q - fb.first[b];
-            fb.dst[b][r * w + c] = fb.src[b][srow * w + c];
+            uint32_t v[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = fb.src[b][srow[u] * w + c];
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (r0 + u < n_rows) fb.dst[b][(r0 + u) * w + c] = v[u];
         }
     }
 }
@@ -542,7 +550,7 @@ extern "C" int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, 
             fb.first[b + 1] = fb.first[b];
         }
     }
-    int64_t blocks = (n_rows + 3) / 4;                 // four waves (rows) per block
+    int64_t blocks = (n_rows + 31) / 32;               // four waves of eight rows per block
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(dt::k_feed_gather, dim3((unsigned)blocks), dim3(256), 0, dt::as_stream(stream), sel, n_rows, fb,
                        (const int64_t*)cursor);

@@ -399,6 +399,7 @@ def outer_product(x, kernel, kernel_type='mat'):
 class _CinLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, xk, W, bias, act, bf16):
+        # bf16: False = exact fp32 MFMA, True / 'bf16' = plain bf16 operands (1e-2 mode), 'bf16x3' = split-bf16 (fp32 bars)
         require_cuda(x0, xk, W)
         x0, W = _f32c(x0), _f32c(W)
         if xk.dtype != torch.float32:
@@ -412,7 +413,12 @@ class _CinLayer(torch.autograd.Function):
         y = torch.empty((B, L, D), dtype=torch.float32, device=x0.device)
         bias_c = None if bias is None else _f32c(bias)
         ctx.bf16 = bool(bf16)
-        if ctx.bf16:     # opt-in bf16-MFMA mode (csrc/cin_bf16.hip): 1e-2 instead of 1e-4 against the float64 oracle
+        ctx.x3 = bf16 == 'bf16x3'
+        if ctx.x3:       # split-bf16 mode (csrc/cin_bf16.hip, NP parts): the exact kernels' parity bars on the bf16 matrix cores
+            ws = torch.empty((lib().dt_cin_bf16x3_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
+            check(lib().dt_cin_layer_fwd_bf16x3(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
+                                                F0 * D, xk.stride(0), ptr(y), ptr(ws), stream_ptr()), 'dt_cin_layer_fwd_bf16x3')
+        elif ctx.bf16:   # opt-in bf16-MFMA mode (csrc/cin_bf16.hip): 1e-2 instead of 1e-4 against the float64 oracle
             ws = torch.empty((lib().dt_cin_bf16_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
             check(lib().dt_cin_layer_fwd_bf16(ptr(x0), ptr(xk), ptr(W), ptr(bias_c), act, B, F0, Hk, L, D,
                                               F0 * D, xk.stride(0), ptr(y), ptr(ws), stream_ptr()), 'dt_cin_layer_fwd_bf16')
@@ -439,7 +445,12 @@ class _CinLayer(torch.autograd.Function):
         gxk = alloc_x((B, Hk, D), dtype=torch.float32, device=x0.device)
         gW = alloc(W.shape, dtype=torch.float32, device=x0.device)
         gb = torch.zeros((L,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
-        if ctx.bf16:
+        if ctx.x3:
+            ws = torch.empty((lib().dt_cin_bf16x3_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
+            check(lib().dt_cin_layer_bwd_bf16x3(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
+                                                F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb), ptr(ws),
+                                                stream_ptr()), 'dt_cin_layer_bwd_bf16x3')
+        elif ctx.bf16:
             ws = torch.empty((lib().dt_cin_bf16_workspace_bytes(F0, Hk, L) + 3) // 4, dtype=torch.float32, device=x0.device)
             check(lib().dt_cin_layer_bwd_bf16(ptr(x0), ptr(xk), ptr(W), ptr(y), ptr(gy), ctx.act, B, F0, Hk, L, D,
                                               F0 * D, xk.stride(0), ptr(gx0), ptr(gxk), ptr(gW), ptr(gb), ptr(ws),
@@ -509,11 +520,13 @@ def cin_split_pool(y, half):
 
 def cin_layer(x0, xk, W, bias=None, activation='relu', mfma_dtype='float32'):
     """x0 [B,F0,D], xk [B,Hk,D], W [F0*Hk, L] -> y [B,L,D] = act(conv1d(outer(x0,xk), W) + bias).
-    mfma_dtype: 'float32' (exact fp32 MFMA, the default) or 'bf16' (bf16 operands, fp32 accumulation: ~1e-2)."""
+    mfma_dtype: 'float32' (exact fp32 MFMA), 'bf16x3' (split-bf16 operands on the bf16 matrix cores: three parts and six
+    products in the forward, two parts and three products in the backward, fp32 accumulate — the exact kernels' bars) or 'bf16'
+    (plain bf16 operands, fp32 accumulation: ~1e-2)."""
     act = _lib.act_code(activation, 'CIN')
-    if mfma_dtype not in ('float32', 'fp32', 'f32', 'bf16', 'bfloat16'):
-        raise ValueError(f'CIN mfma_dtype {mfma_dtype!r}: expected float32 or bf16')
-    return _CinLayer.apply(x0, xk, W, bias, act, mfma_dtype in ('bf16', 'bfloat16'))
+    if mfma_dtype not in ('float32', 'fp32', 'f32', 'bf16', 'bfloat16', 'bf16x3'):
+        raise ValueError(f'CIN mfma_dtype {mfma_dtype!r}: expected float32, bf16x3 or bf16')
+    return _CinLayer.apply(x0, xk, W, bias, act, 'bf16x3' if mfma_dtype == 'bf16x3' else mfma_dtype in ('bf16', 'bfloat16'))
 
 
 # ------------------------------------------------------------------------------------------------

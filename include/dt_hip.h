@@ -311,6 +311,16 @@ int dt_cin_layer_fwd_bf16(const float* x0, const float* xk, const float* W, cons
 int dt_cin_layer_bwd_bf16(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y, int act,
                           int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* grad_x0,
                           float* grad_xk, float* grad_W, float* grad_bias, void* ws, void* stream);
+/* ---- CIN layer, SPLIT-bf16 mode (cin_params['mfma_dtype'] = 'bf16x3'): the same contract and kernels with every fp32 operand
+ * split into bf16 parts and the partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate — forward: three parts (all 24
+ * mantissa bits), six products, fp32-class outputs and relu decisions; backward: two parts, three products (2^-17 per
+ * product).  Held to the exact kernels' bars (1e-4 / 2e-4 against the float64 oracle).  ws: dt_cin_bf16x3_workspace_bytes. */
+int64_t dt_cin_bf16x3_workspace_bytes(int F0, int Hk, int L);
+int dt_cin_layer_fwd_bf16x3(const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
+                            int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y, void* ws, void* stream);
+int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, const float* y, const float* grad_y, int act,
+                            int B, int F0, int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* grad_x0,
+                            float* grad_xk, float* grad_W, float* grad_bias, void* ws, void* stream);
 
 /* ---- AutoInt interacting layer (MultiheadAttention.call, layers.py:119-153) minus its BatchNormalization -------- *
  * x [B,F,D]; Wq/Wk/Wv/Wr [D,D] and bq/bk/bv/br [D]: kernels / biases of dense_Q, dense_K, dense_V, dense_residual

@@ -110,3 +110,62 @@ def test_x3_rows_in_step_equals_the_separate_optimizer_step(dev):
         bench.N_BATCHES = keep
     res = headline.check_rows_in_step(dm, b)
     assert headline.rows_in_step_ok(res), str(sorted(res.items()))
+
+
+# ---- CIN on split-bf16 matrix cores (csrc/cin_bf16.hip with NP parts; cin_params['mfma_dtype'] = 'bf16x3') -------------------
+@pytest.mark.parametrize('B,F0,Hk,L,D,bias,act', [(5, 4, 4, 6, 3, False, 'relu'), (64, 26, 26, 128, 16, False, 'relu'),
+                                                 (40, 26, 64, 128, 16, True, 'relu'), (9, 5, 7, 33, 8, True, 'linear'),
+                                                 (20, 6, 100, 200, 4, False, 'relu'), (12, 5, 6, 40, 8, True, 'tanh'),
+                                                 (300, 26, 64, 128, 16, False, 'relu')])
+def test_cin_layer_split_bf16_holds_the_fp32_bar(dev, B, F0, Hk, L, D, bias, act):
+    """CIN.call (layers.py:689-710) with three-part operands / six products in the forward, two parts / three products in
+    the backward: outputs and all four gradients within 1e-4 of the float64 restatement — the bar of the exact-fp32 kernels
+    (tests/test_kernels_gpu.py::test_cin_layer)"""
+    import numpy as np
+    from deeptables_amd import ops
+    from oracle import reference_layers as R
+    g = torch.Generator().manual_seed(B + F0 + Hk + L)
+
+    def rnd(shape, scale=1.0):
+        return torch.randn(shape, generator=g, dtype=torch.float64) * scale
+    x0, xk = rnd((B, F0, D), 0.5), rnd((B, Hk, D), 0.5)
+    W = rnd((F0 * Hk, L), 1.0 / np.sqrt(F0 * Hk))
+    bv = rnd((L,), 0.1) if bias else None
+    up = rnd((B, L, D))
+    x0r, xkr, Wr = (t.clone().requires_grad_(True) for t in (x0, xk, W))
+    bvr = bv.clone().requires_grad_(True) if bias else None
+    y = torch.einsum('bid,bjd,ijl->bld', x0r, xkr, Wr.reshape(F0, Hk, L))
+    if bias:
+        y = y + bvr[None, :, None]
+    ref = R._activation(act)(y)
+    (ref * up).sum().backward()
+    x0d, xkd, Wd = (t.float().to(dev).requires_grad_(True) for t in (x0, xk, W))
+    bd = bv.float().to(dev).requires_grad_(True) if bias else None
+    out = ops.cin_layer(x0d, xkd, Wd, bd, act, 'bf16x3')
+    (out * up.float().to(dev)).sum().backward()
+    assert _rel(out, ref) < 1e-4, _rel(out, ref)
+    assert _rel(x0d.grad, x0r.grad) < 1e-4 and _rel(xkd.grad, xkr.grad) < 1e-4
+    assert _rel(Wd.grad, Wr.grad) < 1e-4
+    if bias:
+        assert _rel(bd.grad, bvr.grad) < 1e-4
+
+
+def test_xdeepfm_config_split_bf16_matches_oracle(dev):
+    """bench.py --model xDeepFM --cin bf16x3 at the size it is timed (B = 8192, CIN 3 x 128): the same figures and the same
+    verdict rule as the exact-fp32 path (tests/test_headline_gpu.py::test_xdeepfm_config_matches_oracle)"""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    import tests.test_headline_gpu as H
+    params = dict(bench.MODEL_PARAMS['xDeepFM'])
+    params['cin_params'] = dict(params['cin_params'], mfma_dtype='bf16x3')
+    dm = bench.build_model(deepnets.xDeepFM, dev, None, bench.D, params)
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(8192, dev, seed=1234, dist_kind='uniform')
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    print('cin x3', {k: res[k] for k in ('max_abs_logit_err', 'max_abs_logit', 'dense_grad_rel_err', 'dense_grad_l2_rel_err',
+                                         'rows_grad_rel_err', 'rows_grad_l2_rel_err', 'relu_units_near_kink')})
+    H._check_layer_path(res, n_dense=15)
