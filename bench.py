@@ -388,6 +388,7 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    tables_auto = args.tables == 'auto'
     if args.tables == 'auto':
         args.tables = 'sharded' if (args.model == 'DeepFM' and not args.force_dp) else 'replicated'
     strategy = None
@@ -475,6 +476,38 @@ def main():
     rows = args.batch * args.steps * world
     value = rows / wall
 
+    # N > 1 with --tables auto: the OTHER table layout on the same ranks, so that one scaling run answers both — `value` is
+    # the default layout (row-owned tables for DeepFM), `other_layout` the reference's MirroredStrategy shape (replicated
+    # tables + dense all-reduce + bucketed sparse all-gather, north_star's split) or vice versa.  Every rank runs it.
+    other = None
+    if (world > 1 or (args.force_sharded and os.environ.get('DT_BENCH_BOTH_LAYOUTS'))) and tables_auto and \
+            args.model == 'DeepFM' and not args.no_extras and not args.no_optimizer:
+        try:
+            from deeptables_amd.parallel import DataParallelStrategy, ShardedEmbeddingStrategy
+            cls2 = DataParallelStrategy if sharded else ShardedEmbeddingStrategy
+            st2 = cls2(device=strategy.device)
+            st2.assume_uniform_batches = True
+            st2.sparse_bucket_ratio = args.bucket_ratio
+            if world == 1:
+                st2.force_dp = True
+            dm2 = build_model(nets, device, st2, dim, MODEL_PARAMS.get(args.model))
+            st2.broadcast_parameters(dm2.model)
+            loop2 = CompiledTrainLoop(dm2, feed, args.batch, 1, use_graph=not args.no_graph,
+                                      order_capacity=max(feed.n, (warm_capture + args.warmup + args.steps) * args.batch))
+            loop2.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
+            loop2.capture(warm_steps=warm_capture)
+            w2, _, st2_stats = time_steps(loop2, args.steps, args.warmup, barrier, device, spin=False)
+            t2 = torch.tensor([w2], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            other = {'parallelism': f'dp{world}' + ('' if sharded else '+table-rows-sharded'),
+                     'rows_per_s': args.batch * args.steps * world / float(t2.item()),
+                     'ms_per_step': float(t2.item()) / args.steps * 1e3, 'step_us': st2_stats, 'phases': loop2.phase_times()}
+            del loop2, dm2
+            torch.cuda.empty_cache()
+        except Exception as e:          # the second layout is a diagnostic: it must not kill the contract line
+            other = {'error': repr(e)}
+
     if rank == 0:
         n_dense = sum(p.numel() for n, p in dm.model.named_parameters() if 'tables' not in n)
         bpr = algorithmic_bytes_per_row(n_dense, args.batch, dim, optimizer=not args.no_optimizer)
@@ -511,7 +544,7 @@ def main():
         fpr = mfma_flops_per_row(args.model, dim)
         if fpr is not None:      # CIN / attention graphs: the matrix cores bound the step, not HBM
             cin_mode = (MODEL_PARAMS.get('xDeepFM', {}).get('cin_params', {}).get('mfma_dtype') or
-                        os.environ.get('DT_AMD_CIN_DTYPE', 'float32')) if args.model == 'xDeepFM' else 'float32'
+                        os.environ.get('DT_AMD_CIN_DTYPE', 'bf16x3')) if args.model == 'xDeepFM' else 'float32'
             bf16 = cin_mode == 'bf16'
             x3 = cin_mode == 'bf16x3'
             # split-bf16: the useful flops are still the fp32 contraction's; priced against the bf16 pipe they run on
@@ -532,6 +565,10 @@ def main():
                 result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
 
         result['first_replay_us'] = loop.first_replay_us()
+        if other is not None:
+            result['other_layout'] = other
+            if 'rows_per_s' in other:
+                result['replicated_rows_per_s' if sharded else 'sharded_rows_per_s'] = other['rows_per_s']
         ph = loop.phase_times()
         if ph is not None:          # N > 1 (or --force-dp): where a data-parallel step spends its time, on rank 0
             result['phases'] = ph

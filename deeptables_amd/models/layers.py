@@ -225,8 +225,10 @@ class CIN(Layer):
         self.params = params
         self.cross_layer_size = params.get('cross_layer_size', (128, 128,))
         self.activation = params.get('activation', 'relu')
-        # extension of cin_params (config.py:120-127): 'mfma_dtype': 'bf16' selects the bf16-MFMA kernels (1e-2 mode)
-        self.mfma_dtype = params.get('mfma_dtype', os.environ.get('DT_AMD_CIN_DTYPE', 'float32'))
+        # extension of cin_params (config.py:120-127): 'mfma_dtype' = 'bf16x3' (default: split-bf16 operands on the bf16 matrix
+        # cores — three parts / six products forward, two parts / three products backward, fp32 accumulate — held to the exact
+        # kernels' bars), 'float32' (exact fp32 MFMA), 'bf16' (plain bf16 operands: the 1e-2 mode)
+        self.mfma_dtype = params.get('mfma_dtype', os.environ.get('DT_AMD_CIN_DTYPE', 'bf16x3'))
         self.use_residual = params.get('use_residual', False)
         self.use_bias = params.get('use_bias', False)
         self.direct = params.get('direct', False)

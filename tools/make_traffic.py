@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-WIDE = {'k_mlp_fwd3': 'X tile streamed as float4', 'k_dx_sparse_bwd': 'X and dH1 tiles streamed as float4',
+WIDE = {'k_mlp_fwd3': 'X tile streamed as float4', 'k_tower_x3': 'X tile streamed as float4, weight parts as 16-byte lanes', 'k_dx_sparse_bwd': 'X and dH1 tiles streamed as float4',
         'k_wgrad_rows': 'X / dH1 / H1 / dXn streamed as 8- and 16-byte lanes (its random [m|v] rows are a quarter of its reads)'}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
