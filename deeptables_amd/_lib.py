@@ -27,6 +27,7 @@ SIGNATURES = {
     'dt_last_error': (ctypes.c_char_p, []),
     'dt_build_arch': (ctypes.c_char_p, []),
     'dt_source_hash': (ctypes.c_char_p, []),
+    'dt_graph_upload': (_c_int, [_ptr, _ptr]),
     'dt_embedding_fwd': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr,
                                   _ptr, _ptr]),
     'dt_embedding_bwd_dense': (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),

@@ -28,16 +28,13 @@ from ._lib import check, lib, ptr, stream_ptr
 
 
 def _hip_graph_upload(graph):
-    """hipGraphUpload of a captured torch graph onto the current stream: the first `replay()` then costs what every
-    later one costs (an un-uploaded 60-node graph pays ~60-200 us on its first launch).  Best effort: returns False when
-    the handle or the symbol is unavailable."""
+    """hipGraphUpload of a captured torch graph onto the current stream (dt_graph_upload: through libdt_hip.so's HIP
+    runtime, the one torch loaded — never a second copy dlopened by name): the first `replay()` then costs about what every
+    later one costs (an un-uploaded 60-node graph pays ~60-200 us on its first launch).  Best effort: False when the handle
+    is unavailable."""
     try:
         handle = graph.raw_cuda_graph_exec()
-        hip = ctypes.CDLL('libamdhip64.so')
-        fn = hip.hipGraphUpload
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        fn.restype = ctypes.c_int
-        return fn(ctypes.c_void_p(int(handle)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return lib().dt_graph_upload(ctypes.c_void_p(int(handle)), stream_ptr()) == 0
     except Exception:
         return False
 

@@ -21,6 +21,7 @@
 // of the product): fp32-class outputs, so the layer's relu units land on the other side of their kink no more often than
 // with fp32 arithmetic.  BACKWARD (dgrad, wgrad): two parts, three products (2^-17 per product).  gfx950's fp32 MFMA runs
 // at 1/16 of the bf16 rate: 6/16 resp. 3/16 of its time.
+#include <stdlib.h>
 #include "common.h"
 
 namespace dt {
@@ -203,6 +204,140 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
         }
         if (chunk + 1 < nchunks) store_w(buf ^ 1);
         __syncthreads();
+    }
+    // epilogue (as cin.hip): row = (r&3) + 8*(r>>2) + 4*s, col = c
+    const bool vec_ok = (D % 4 == 0);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nblocks_n) continue;
+        const int n = n0 + nb * 32 + c;
+        if (n >= L) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t mr = m0 + wave * 32 + 8 * g + 4 * s;
+            if (mr >= M) continue;
+            const int64_t b = mr / D;
+            const int dd = (int)(mr % D);
+            float ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = kAnyAct ? act_apply(acc[nb][g * 4 + r] + bv, act)
+                                : (act == DT_ACT_RELU ? fmaxf(acc[nb][g * 4 + r] + bv, 0.f) : acc[nb][g * 4 + r] + bv);
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(y + (b * L + n) * D + dd) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t mm = mr + r;
+                    if (mm < M) y[((mm / D) * L + n) * D + (mm % D)] = ov[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, split-bf16, WITHOUT forming Z (round 4).  Y[m, l] = sum_i x0[m, i] T_i[m, l],  T_i[m, l] = sum_j xk[m, j] W[(i, j), l]:
+// the inner sums are F0 small GEMMs whose operands are x_k and W_i THEMSELVES — the A operand (the x_k row of the lane, three
+// bf16 parts) is split ONCE per tile and stays in registers for all F0 GEMMs, the B operand is the pre-split filter — and the
+// outer sum is one scalar x0[m, i] per accumulator row: 16 FMAs per 32x32 tile and i.  The Z-forming kernel above multiplies
+// and splits eight products per lane and MFMA step (56 VALU operations for 24 MFMAs) and ran 404 us per 128-filter layer at
+// the Criteo shape, three times its matrix time.
+// Block = 128 rows m x 128 filters; W_i (three parts x 128 filters x Hp k) goes through ONE LDS buffer per block — two blocks
+// per CU, the other block's MFMAs cover this block's refill.
+// ------------------------------------------------------------------------------------------
+template <bool kAnyAct, int KS /* ceil(Hk / 16) upper bound: 2, 4 or 8 */>
+__global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const __bf16* __restrict__ WT, int64_t wt_part, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
+    int D, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NP = 3;
+    const int Hp = cb_hp(Hk), Kp = F0 * Hp;
+    constexpr int HPM = 16 * KS;                          // k per i the kernel walks (Hp <= HPM; beyond Hp: zero operands)
+    constexpr int WSb = HPM + 8;                          // bf16 row stride of a filter row: an odd number of 16-byte slots
+    const int64_t M = (int64_t)B * D;
+    float* x0T = lds;                                     // [F0][kBM]  x0[m][i], rows m contiguous
+    __bf16* wtb = reinterpret_cast<__bf16*>(x0T + F0 * kBM);       // [NP][kBN][WSb]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * kBN;
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t m = m0 + r;
+        x0T[i * kBM + r] = m < M ? x0[(m / D) * x0_bs + (int64_t)i * D + (m % D)] : 0.f;
+    }
+    // this lane's x_k row, split once: A operand of every GEMM (k = 16 ks + 8 s + e)
+    cb_b8 a[KS][NP];
+    {
+        const int64_t m = m0 + wave * 32 + c;
+        const bool ok = m < M;
+        const float* src = xk + (ok ? (m / D) * xk_bs + (m % D) : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 16 * ks + 8 * s + e;
+                v[e] = (ok && j < Hk) ? src[(int64_t)j * D] : 0.f;
+            }
+            cb_split<NP>(v, a[ks]);
+        }
+    }
+    // W_i loader: NP parts x 128 filters x (HPM / 8) 16-byte pieces
+    constexpr int kPieces = NP * kBN * (HPM / 8), kWR = (kPieces + 255) / 256;
+    cb_f4 wreg[kWR];
+    auto load_w = [&](int i) {
+#pragma unroll
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
+            wreg[u] = (e < kPieces && 8 * pc < Hp)
+                          ? *reinterpret_cast<const cb_f4*>(WT + part * wt_part + (int64_t)(n0 + n) * Kp + (int64_t)i * Hp + 8 * pc)
+                          : cb_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
+            if (e < kPieces) *reinterpret_cast<cb_f4*>(wtb + (part * kBN + n) * WSb + 8 * pc) = wreg[u];
+        }
+    };
+    cb_f16v acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    load_w(0);
+    for (int i = 0; i < F0; ++i) {
+        __syncthreads();                 // every wave is done with W_{i-1} (and, first time, x0T is complete)
+        store_w();
+        __syncthreads();
+        if (i + 1 < F0) load_w(i + 1);   // in flight under this i's MFMAs
+        // x0[m][i] of the 16 accumulator rows of this lane: rows (r & 3) + 8 (r >> 2) + 4 s
+        cb_f4 xq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xq[g] = *reinterpret_cast<const cb_f4*>(x0T + i * kBM + wave * 32 + 8 * g + 4 * s);
+        const __bf16* wrow = wtb + c * WSb + 8 * s;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb >= nblocks_n) continue;
+            cb_f16v t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                cb_b8 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const cb_b8*>(wrow + (q * kBN + nb * 32) * WSb + 16 * ks);
+                cb_mma<NP>(t, a[ks], b);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] += xq[r >> 2][r & 3] * t[r];
+        }
     }
     // epilogue (as cin.hip): row = (r&3) + 8*(r>>2) + 4*s, col = c
     const bool vec_ok = (D % 4 == 0);
@@ -587,11 +722,30 @@ static int cinb_fwd(const char* who, const float* x0, const float* xk, const flo
     hipStream_t st = as_stream(stream);
     __bf16* WT = reinterpret_cast<__bf16*>(ws);
     cinb_pack<NP>(W, F0, Hk, L, WT, nullptr, st);
+    const int64_t M = (int64_t)B * D;
+    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
+    if (NP == 3 && !(getenv("DT_CIN_FWD_Z") && atoi(getenv("DT_CIN_FWD_Z")))) {
+        // the forward that never forms Z (k_cin_fwd_noz): Hk up to 128
+        const int ks = cb_hp(Hk) <= 32 ? 2 : cb_hp(Hk) <= 64 ? 4 : 8;
+        const size_t ldsn = (size_t)F0 * kBM * sizeof(float) + (size_t)3 * kBN * (16 * ks + 8) * 2;
+        const bool any = !(act == DT_ACT_LINEAR || act == DT_ACT_RELU);
+#define DT_NOZ(ANY, KSV)                                                                                                   \
+    do {                                                                                                                   \
+        hipFuncSetAttribute((const void*)k_cin_fwd_noz<ANY, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn);  \
+        hipLaunchKernelGGL((k_cin_fwd_noz<ANY, KSV>), grid, dim3(256), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT,       \
+                           cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);                                             \
+    } while (0)
+        // linear / relu epilogues and Hk <= 64 only: with the libm activations or eight k steps of A parts in registers the
+        // kernel spills (254 VGPRs at four steps already) — those shapes keep the Z-forming kernel
+        if (ldsn <= 160 * 1024 && !any && ks <= 4) {
+            if (ks == 2) DT_NOZ(false, 2); else DT_NOZ(false, 4);
+            return launch_status(who);
+        }
+#undef DT_NOZ
+    }
     constexpr int KCH = NP == 1 ? kBK : 16;
     const size_t lds = ((size_t)kBM * ((F0 | 1) + cb_hp(Hk) + 4)) * sizeof(float) + (size_t)2 * NP * kBN * (KCH + 8) * 2;
     DT_UNSUPPORTED(lds > 160 * 1024, "%s: tiles need %zu B of LDS (> 160 KiB)", who, lds);
-    const int64_t M = (int64_t)B * D;
-    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
     if (act == DT_ACT_LINEAR || act == DT_ACT_RELU) {
         hipFuncSetAttribute((const void*)k_cin_fwd_bf16<false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_cin_fwd_bf16<false, NP>), grid, dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride, WT,

@@ -62,6 +62,10 @@ int dt_version(void);                 /* ABI version, currently 1 */
 const char* dt_last_error(void);      /* thread-local message of the last failing call */
 const char* dt_build_arch(void);      /* "gfx950" */
 const char* dt_source_hash(void);     /* sha256[:16] of the sources this binary was built from (__graft_entry__.source_hash) */
+/* hipGraphUpload of an instantiated graph (hipGraphExec_t) onto `stream`: the compiled train loop (deeptables_amd/compiled.py,
+ * Keras steps_per_execution, deepmodel.py:319-346) uploads its captured k-step graph once, so that the first replay costs
+ * what every later one costs.  Goes through this library's HIP runtime, i.e. the one the host framework loaded.        */
+int dt_graph_upload(void* graph_exec, void* stream);
 
 /* ---- a2  MultiColumnEmbedding.call  (models/layers.py:889-904) -------------------------- *
  * All F columns live in ONE packed table [sum_f vocab_f, D]; column f starts at row
