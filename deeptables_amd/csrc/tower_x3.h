@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     floatx4 xv[NCH];                                              // raw X, kept to the end (xhat, d w_lin)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) xv[j] = ld4(X + (int64_t)(m0 + srow) * CP + 64 * j + qcol);   // rows beyond B are zero (host memset)
-    constexpr int kPF = 3;                                        // GEMM1 B operands in flight (steps ahead)
+    constexpr int kPF = 5;                                        // GEMM1 B operands in flight (steps ahead: ~1 K cycles of MFMAs, an L2 round trip under load)
     const __bf16* w1b = xw.W1B + ((int64_t)wave * 64 + lane) * 8; // + step * 8 * 64 * 8
     x3_b8 bq[kPF][3];
 #pragma unroll
@@ -311,6 +311,22 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     }
     lds_barrier();
     DT_STAMP(stamps, 4);
+    // dXn's B operand (rows of W1) for this wave's first two column tiles: requested here, three phases ahead of its use
+    // (issued in the dH1 phase it stood in that phase's way: 16 loads per lane in front of a barrier)
+    const int NT = (dm.C + 15) >> 4;                               // 16-column tiles of dXn (all C columns: dgamma / dbeta need them)
+    auto w1r = [&](int nt) {
+        const int col = min(16 * nt + n16, CP - 1);
+        return xw.W1R + (int64_t)col * kH1 + 8 * kg;
+    };
+    x3_b8 bW[2][4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (wave + 8 * i < NT) {
+            const __bf16* wr = w1r(wave + 8 * i);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { bW[i][g][0] = x3_ld8(wr + 32 * g); bW[i][g][1] = x3_ld8(wr + xw.w1r_lo + 32 * g); }
+        }
+    }
 
     // ---- logits, loss, dlogit, dz (wave 0; lanes 32..63 mirror rows 0..31 with zero inputs) ----
     if (wave == 0) {
@@ -376,12 +392,6 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     DT_STAMP(stamps, 9);
 
     // ---- dH1 = relu'(H1) (dH2 W2^T), two-part operands: wave w owns hidden units [16w, 16w+16), both row halves; K = 64 ----
-    const int NT = (dm.C + 15) >> 4;                               // 16-column tiles of dXn (all C columns: dgamma / dbeta need them)
-    auto w1r = [&](int nt) {
-        const int col = min(16 * nt + n16, CP - 1);
-        return xw.W1R + (int64_t)col * kH1 + 8 * kg;
-    };
-    x3_b8 bW[2][4][2];                     // dXn's B operand (rows of W1), two column tiles in flight
     {
         floatx4 dH[2], dM[2];
 #pragma unroll
@@ -400,15 +410,6 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 X3_MFMA(dM[t], ah, w2r[g][1]);
                 X3_MFMA(dM[t], al, w2r[g][0]);
             }
-        // the first two column tiles' W1 rows are on their way while the dH1 tile settles
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (wave + 8 * i < NT) {
-                const __bf16* wr = w1r(wave + 8 * i);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { bW[i][g][0] = x3_ld8(wr + 32 * g); bW[i][g][1] = x3_ld8(wr + xw.w1r_lo + 32 * g); }
-            }
-        }
         if (tid < kH2) {
             prec[pl.db2 + tid] = cs[tid] + cs[2 * kH2 + tid];
             prec[pl.dw3 + tid] = cs[kH2 + tid] + cs[3 * kH2 + tid];

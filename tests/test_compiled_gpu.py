@@ -68,13 +68,17 @@ def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
         assert loop is not None and loop.graph is not None and loop.k == 10
         assert not loop.preelected                   # (opt-in, next test)
         assert type(graphed.fused_plan()).__name__ == ('FusedDCN' if net == 'DCN' else 'FusedDeepFM')
-        _same(eager, graphed)
+        # small tables keep Keras' dense table gradient: its scatter adds the lookups' rows with float atomics, whose order
+        # differs from run to run (ulps of a gradient; Adam's g / (sqrt(v) + eps) turns a few of them into 1e-5 of a weight
+        # now and then) — the row-sparse path (segments, no atomics) is held to 2e-6
+        tol = 2e-6 if sparse else 5e-5
+        _same(eager, graphed, tol=tol)
         assert eager.optimizer.t == graphed.optimizer.t == 3 * 23
-        assert np.allclose(h0.history['loss'], h1.history['loss'], atol=2e-6), (h0.history, h1.history)
+        assert np.allclose(h0.history['loss'], h1.history['loss'], atol=tol), (h0.history, h1.history)
         key = 'auc' if task == 'binary' else 'mse'
         assert np.allclose(h0.history[key], h1.history[key], atol=1e-5), (h0.history, h1.history)
         # predictions of the graphed model agree with the eager one's
-        assert np.abs(eager.predict(df.iloc[:200]) - graphed.predict(df.iloc[:200])).max() < 1e-5
+        assert np.abs(eager.predict(df.iloc[:200]) - graphed.predict(df.iloc[:200])).max() < (1e-5 if sparse else 2e-4)
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
 
