@@ -173,6 +173,7 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     t0 = time.perf_counter()
     e0.record()
     loop.run(steps, on_execution=mark)
+    t_enq = time.perf_counter() - t0
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -185,7 +186,10 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     def pct(q):
         return per[min(len(per) - 1, int(q * len(per)))]
     stats = {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'mean': sum(per) / len(per), 'n': len(per),
-             'launch_units': len(evs)}
+             'launch_units': len(evs),
+             # host clock of the timed region: all launch units enqueued after `host_enqueue_us`, the GPU's own time for them
+             # `gpu_us` (HIP events), the rest of `wall_us` is launch latency before the first kernel + the final synchronize
+             'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': e0.elapsed_time(evs[-1][0]) * 1e3}
     return wall, e0.elapsed_time(evs[-1][0]) / 1e3, stats
 
 
