@@ -156,11 +156,16 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     """EXACTLY `steps` train steps are timed after `warmup` untimed ones, all through the product's compiled loop
     (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides both counts, so the warm-up runs through replays
     of the same graph — the timed replays are never a graph's first launch)."""
+    import gc
     loop.run(warmup)
-    if spin:
+    if spin and os.environ.get('DT_BENCH_SPIN'):      # measured (tools/r4/call13.sh): no gain in gpu_us, slower host enqueue
         spin_gpu(device)
     barrier()
     torch.cuda.synchronize()
+    # host hygiene of a 2.3 ms timed region: the parity leg in front of it leaves millions of Python objects behind — a
+    # generation-2 collection inside the region cost ~300 us of host clock (enqueue 501 us against 180 us without the leg)
+    gc.collect()
+    gc.disable()
     if loop.dp:
         loop.phase_events = []
     evs = []
@@ -177,6 +182,7 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    gc.enable()
     per, prev = [], e0
     for e, k in evs:
         per += [prev.elapsed_time(e) * 1e3 / k] * k          # us per step (a replay of k steps: its mean)

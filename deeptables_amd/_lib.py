@@ -160,6 +160,7 @@ DT_STEP_LOSS_MSE = 0x10
 DT_STEP_SKIP_FINISH, DT_STEP_FINISH_ONLY = 0x20, 0x40
 DT_STEP_TOWER_X3 = 0x80
 DT_STEP_PREELECTED = 0x100
+DT_FEED_CURSOR_WORDS = 528          # 16 (1 + 32 ticket groups), csrc/embedding.hip kFeedGroups
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
 # keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)
 ACT_CODES = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3, 'elu': 4, 'selu': 5, 'softplus': 6, 'softsign': 7,

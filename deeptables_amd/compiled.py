@@ -23,7 +23,7 @@ import ctypes
 
 import torch
 
-from . import training
+from . import _lib, training
 from ._lib import check, lib, ptr, stream_ptr
 
 
@@ -68,7 +68,7 @@ class CompiledTrainLoop:
         self.order_cap = int(order_capacity or feed.n)
         self.order_buf = torch.arange(self.order_cap, dtype=torch.int64, device=self.device)
         self.order_len = min(self.order_cap, feed.n)
-        self.cursor = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.cursor = torch.zeros(_lib.DT_FEED_CURSOR_WORDS, dtype=torch.int64, device=self.device)   # [position | dt_feed_gather's arrival tickets]
         self.sel = torch.zeros(n, dtype=torch.int64, device=self.device)     # (index_select fallback of odd feeds only)
         self.slots = [torch.empty((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=self.device) for b in feed.blocks]
         self.slot_y = None if feed.y is None else \
@@ -107,7 +107,7 @@ class CompiledTrainLoop:
         else:
             self.order_buf[:n].copy_(perm)
         self.order_len = n
-        self.cursor.zero_()
+        self.cursor[:1].zero_()
         self.pos = 0
 
     def _select(self, steps):

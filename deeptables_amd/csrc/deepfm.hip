@@ -274,6 +274,10 @@ struct PrepOut {
     // split-bf16 tower (tower_x3.h; NULL: not that mode): the bf16 halves of W1 / W2 in the layouts of X3Weights
     __bf16 *x3_W1B, *x3_W1R, *x3_W2B, *x3_W2R;
     int64_t x3_w1b_lo, x3_w1r_lo, x3_w2b_lo, x3_w2r_lo;
+    // ... and, for DCN, the layer vectors padded to CP: [2 L + 1][CP] = cross kernels | cross biases | w3c (NULL: DeepFM)
+    float* x3_cwp;
+    const float *cw, *cb, *w3c;
+    int L;
 };
 
 // Merge of K partial results {n_i, mean_i, M2_i} of one column, all K at once (no running recurrence, ONE division):
@@ -510,6 +514,14 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
             if (a2) split8(v2, o.x3_W1R + (int64_t)e * 8, o.x3_w1r_lo, 2);
             if (a3) split8(v3, o.x3_W2B + (int64_t)e * 8, o.x3_w2b_lo, 3);
             if (a4) split8(v4, o.x3_W2R + (int64_t)e * 8, o.x3_w2r_lo, 2);
+        }
+        if (o.x3_cwp) {
+            const int nv = (2 * o.L + 1) * dm.CP;
+            for (int e = wb * blockDim.x + threadIdx.x; e < nv; e += nwb * blockDim.x) {
+                const int v = e / dm.CP, col = e - v * dm.CP;
+                const float* src = v < o.L ? o.cw + (int64_t)v * dm.C : v < 2 * o.L ? o.cb + (int64_t)(v - o.L) * dm.C : o.w3c;
+                o.x3_cwp[e] = col < dm.C ? src[col] : 0.f;
+            }
         }
         return;
     }
@@ -2273,7 +2285,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
     w.gammap = take(dm.CP);
     // split-bf16 tower: W1B (3 bf16 parts of CP x 128) | W1R (2 parts) | W2B (3 parts of 128 x 64) | W2R (2 parts)
-    w.x3 = take((5 * (int64_t)dm.CP * kH1 + 5 * (int64_t)kH1 * kH2 + 1) / 2);
+    w.x3 = take((5 * (int64_t)dm.CP * kH1 + 5 * (int64_t)kH1 * kH2 + 1) / 2 + (2 * kCrossMax + 1) * (int64_t)dm.CP);
     w.total = o;
     return w;
 }
@@ -2514,13 +2526,15 @@ static int tower_train_step(
     // B
     const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     // split-bf16 tower (DT_STEP_TOWER_X3): the DeepFM tile kernel of the pipelined backward step (DCN keeps the fp32 kernel)
-    const bool x3 = x3_flag && pipe && !dcn && dm.CP <= 512 && x3_fits(dm.CP);      // (wider rows: the fp32 tile kernel)
+    const bool x3 = x3_flag && pipe && dm.CP <= 512 && x3_fits(dm.CP);      // (wider rows: the fp32 tile kernel)
     __bf16* x3base = reinterpret_cast<__bf16*>(ws + wl.x3);
     const int64_t n1 = (int64_t)dm.CP * kH1, n2 = (int64_t)kH1 * kH2;            // elements of one part
     __bf16 *x3_w1b = x3base, *x3_w1r = x3base + 3 * n1, *x3_w2b = x3base + 5 * n1, *x3_w2r = x3base + 5 * n1 + 3 * n2;
-    const X3Weights xw{x3_w1b, n1, x3_w1r, n1, x3_w2b, n2, x3_w2r, n2};
+    float* x3_cwp = ws + wl.x3 + (5 * n1 + 5 * n2 + 1) / 2;
+    const X3Weights xw{x3_w1b, n1, x3_w1r, n1, x3_w2b, n2, x3_w2r, n2, x3_cwp};
     PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
-               ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2};
+               ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2,
+               x3 && dcn ? x3_cwp : nullptr, cross_w, cross_b, w3, Lc};
     const int elect_blocks = (dd.rows_fm && !preelected) ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = elect_blocks ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
@@ -2558,11 +2572,18 @@ static int tower_train_step(
         break;
 #define DT_CX(N)                                                                                                    \
     case N: {                                                                                                       \
-        const size_t ldsX = x3_lds_bytes(64 * N);                                                                   \
-        hipFuncSetAttribute((const void*)k_tower_x3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX);     \
-        hipLaunchKernelGGL((k_tower_x3<N>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, ws + wl.lin,   \
-                           ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,               \
-                           ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);                     \
+        const size_t ldsX = x3_lds_bytes(64 * N, dcn);                                                              \
+        if (dcn) {                                                                                                  \
+            hipFuncSetAttribute((const void*)k_tower_x3<N, kCrossMax>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
+            hipLaunchKernelGGL((k_tower_x3<N, kCrossMax>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, \
+                               ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
+                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);      \
+        } else {                                                                                                    \
+            hipFuncSetAttribute((const void*)k_tower_x3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
+            hipLaunchKernelGGL((k_tower_x3<N>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, ws + wl.lin, \
+                               ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,           \
+                               ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);                 \
+        }                                                                                                           \
     } break;
         if (x3) {        // the split-bf16 tower (tower_x3.h)
             switch (dm.CP >> 6) { DT_CX(1) DT_CX(2) DT_CX(3) DT_CX(4) DT_CX(5) DT_CX(6) DT_CX(7) DT_CX(8) }

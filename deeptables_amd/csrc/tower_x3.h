@@ -37,6 +37,7 @@ struct X3Weights {
     const __bf16* W1R; int64_t w1r_lo;      // 2 parts, [CP rows][128] row-major copy of W1 (rows >= C zero): dXn's B operand
     const __bf16* W2B; int64_t w2b_lo;      // 3 parts, lane-major: element j of lane (n, g), step s, column tile t = W2[32 s + 8 g + j][16 t + n]
     const __bf16* W2R; int64_t w2r_lo;      // 2 parts, [128][64] row-major copy of W2: dH1's B operand
+    const float* cwp;                       // DCN: [2 L + 1][CP] fp32, zero beyond C: cross kernels | cross biases | w3c
 };
 
 // a = h + l (16 mantissa bits) / a = h + m + l (all 24: exact)
@@ -72,16 +73,18 @@ __device__ __forceinline__ void x3_ld8f(const float* p, float (&v)[8]) {
 //   bnp   4 * CP * 4                  mean | gamma rstd | beta | rstd
 //   h1f   32 * (128 + 4) * 4          H1 fp32, then dH1
 //   d2f   32 * (64 + 4) * 4           dH2 fp32
-__host__ __device__ constexpr size_t x3_lds_bytes(int CP) {
-    return (size_t)3 * kTM * (CP + 16) * 2 + (size_t)4 * CP * 4 + (size_t)kTM * (kH1 + 4) * 4 + (size_t)kTM * (kH2 + 4) * 4;
+// DCN: + pb [2][48][16] (the two K halves of P) | crP [48][16] | crA [32][16] | crF [32][16] | zcs [32]
+__host__ __device__ constexpr size_t x3_lds_bytes(int CP, bool dcn = false) {
+    return (size_t)3 * kTM * (CP + 16) * 2 + (size_t)4 * CP * 4 + (size_t)kTM * (kH1 + 4) * 4 + (size_t)kTM * (kH2 + 4) * 4 +
+           (dcn ? (size_t)(2 * 48 * 16 + 48 * 16 + 2 * kTM * 16 + kTM) * 4 : 0);
 }
 // the fp32 tile + the small arrays must fit behind each other inside xreg
 __host__ __device__ constexpr bool x3_fits(int CP) {
     return (size_t)kTM * (CP + 4) * 4 + (size_t)8 * CP * 4 + (size_t)(5 * kTM + 4 * kH2) * 4 <= (size_t)3 * kTM * (CP + 16) * 2 &&
-           x3_lds_bytes(CP) <= 160 * 1024;
+           x3_lds_bytes(CP, true) <= 160 * 1024;
 }
 
-template <int NCH>
+template <int NCH, int LC = 0>   // LC = kCrossMax: DCN (the Cross network's closed form of k_mlp_fwd3 on the same tile, see there)
 __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, MlpParams p, X3Weights xw, DeepFmDims dm,
                                                   const float* __restrict__ lin, const float* __restrict__ fm,
                                                   const float* __restrict__ y, float* __restrict__ H1,
@@ -104,10 +107,15 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     float* bnp = reinterpret_cast<float*>(base + (size_t)3 * XP * 2);   // [4][CP]
     float* h1f = bnp + 4 * CP;                                    // [32][HF]
     float* d2f = h1f + kTM * HF;                                  // [32][DF]
+    float* pb = d2f + kTM * DF;                                   // DCN: [2][48][16] K halves of P
+    float* crP = pb + 2 * 48 * 16;                                // DCN: [48][16] P[r][l] = Xn[r] . Wc_l (rows 0..31), b_j . Wc_l (rows 32 + j); Wc_L = w3c
+    float* crA = crP + 48 * 16;                                   // DCN: [32][16] a_l of every row, later A_{l+1} and dz (crS)
+    float* crF = crA + kTM * 16;                                  // DCN: [32][16] coeff[r][l] = d loss / d P[r][l]
+    float* zcs = crF + kTM * 16;                                  // DCN: [32] w3c . cross(Xn) per row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.x * kTM;
-    const Part3 pl = part3_layout(dm.CP, 0, 1);
+    const Part3 pl = part3_layout(dm.CP, LC ? dc.L : 0, 1);
     float* prec = part + (int64_t)blockIdx.x * pl.stride;
 
     // ---- prologue.  Request order = the order of use: this thread's BN level-1 slices (needed first, behind one L2 round
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         wov = p.wo[0];
         bov = p.bo ? p.bo[0] : 0.f;
         if (lane < 32 && m0 + lane < dm.B) {
-            linv = lin[m0 + lane]; fmv = fm[m0 + lane];
+            if (LC == 0) { linv = lin[m0 + lane]; fmv = fm[m0 + lane]; }
             yv = y[m0 + lane];
             if (dc.sw) swv = dc.sw[m0 + lane];
         }
@@ -244,6 +252,43 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             }
         }
         DT_STAMP(stamps, 2);
+        if constexpr (LC > 0) {
+            // ---- Cross forward, part 1 (layers.py:428-436 in the closed form of k_mlp_fwd3): P = [Xn ; b_0 .. b_{L-1}] . [w_0 ..
+            //      w_{L-1} w3c], 48 x 16, K = CP, six products (the logits reach +-160: fp32-class or nothing).  Waves 0..5:
+            //      row tile w % 3 (0, 1: the Xn parts in LDS; 2: the bias vectors) x K half w / 3; the halves meet in LDS.
+            if (wave < 6) {
+                const int L = dc.L, mt = wave % 3, kh = wave / 3;
+                const int s0 = kh * (NST / 2), s1 = kh ? NST : NST / 2;
+                const float* brow = xw.cwp + (int64_t)(n16 < L ? n16 : 2 * L) * CP + 8 * kg;       // column n16: w_l, w3c, then zero
+                const float bmask = n16 <= L ? 1.f : 0.f;
+                const float* arow2 = xw.cwp + (int64_t)(L + min(n16, L - 1)) * CP + 8 * kg;        // third row tile: b_j
+                const float amask2 = n16 < L ? 1.f : 0.f;
+                floatx4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = q1, q3 = q1;
+                for (int st = s0; st < s1; ++st) {
+                    float bv[8];
+                    x3_ld8f(brow + 32 * st, bv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] *= bmask;
+                    x3_b8 b1, b2, b3, a1, a2, a3;
+                    x3_split3(bv, b1, b2, b3);
+                    if (mt < 2) {
+                        const __bf16* ap = xb + (16 * mt + n16) * XSB + 32 * st + 8 * kg;
+                        a1 = x3_ld8(ap); a2 = x3_ld8(ap + XP); a3 = x3_ld8(ap + 2 * XP);
+                    } else {
+                        float av[8];
+                        x3_ld8f(arow2 + 32 * st, av);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) av[e] *= amask2;
+                        x3_split3(av, a1, a2, a3);
+                    }
+                    X3_MFMA(q3, a1, b3); X3_MFMA(q3, a2, b2); X3_MFMA(q3, a3, b1);
+                    X3_MFMA(q2, a1, b2); X3_MFMA(q2, a2, b1);
+                    X3_MFMA(q1, a1, b1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[(kh * 48 + 16 * mt + 4 * kg + r) * 16 + n16] = (q3[r] + q2[r]) + q1[r];
+            }
+        }
         // H1 (C layout: column 16w + n16, rows 16t + 4kg + r) -> fp32 in LDS; kept in registers for relu'
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -309,6 +354,9 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         const floatx4 mu = ld4(bnp + 64 * j + qcol), rs = ld4(bnp + 3 * CP + 64 * j + qcol);
         st4(xs + srow * XS + 64 * j + qcol, (xv[j] - mu) * rs);
     }
+    if constexpr (LC > 0) {
+        for (int e = tid; e < 48 * 16; e += 512) crP[e] = pb[e] + pb[48 * 16 + e];
+    }
     lds_barrier();
     DT_STAMP(stamps, 4);
     // dXn's B operand (rows of W1) for this wave's first two column tiles: requested here, three phases ahead of its use
@@ -332,10 +380,45 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     if (wave == 0) {
         const int c = lane & 31, s = lane >> 5;
         const int m = m0 + c;
+        float zc = 0.f;
+        if constexpr (LC > 0) {
+            // Cross forward, part 2: the L scalar steps of row c, everything in registers (x_l = a_l x0 + c_l):
+            //   s_l = a_l p_l + q_l,  a_{l+1} = a_l + s_l,  q_l = (b_0 + .. + b_{l-1}) . Wc_l,  z_c = a_L (x0 . w3c) + c_L . w3c
+            const int L = dc.L;
+            static_assert(LC + 1 <= 12, "three float4 per row of crP");
+            float pr[12], gq[LC][12];
+            {
+                const floatx4 t0 = ld4(crP + c * 16), t1 = ld4(crP + c * 16 + 4), t2 = ld4(crP + c * 16 + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pr[e] = t0[e]; pr[4 + e] = t1[e]; pr[8 + e] = t2[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {                     // Gram rows b_j . Wc_l (the same address in every lane: broadcast)
+                const floatx4 t0 = ld4(crP + (32 + j) * 16), t1 = ld4(crP + (32 + j) * 16 + 4), t2 = ld4(crP + (32 + j) * 16 + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gq[j][e] = t0[e]; gq[j][4 + e] = t1[e]; gq[j][8 + e] = t2[e]; }
+            }
+            float a = 1.f;
+#pragma unroll
+            for (int l = 0; l <= LC; ++l) {
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < LC; ++j)
+                    if (j < l) q += gq[j][l];
+                if (l < L) {
+                    if (s == 0) crA[c * 16 + l] = a;
+                    a += a * pr[l] + q;
+                } else if (l == L) {
+                    if (s == 0) crA[c * 16 + l] = a;
+                    zc = a * pr[l] + q;
+                }
+            }
+        }
         float loss = 0.f, dl = 0.f, zz = 0.f;
         if (m < dm.B) {
             const float pt = (zp[c] + zp[kTM + c]) + (zp[2 * kTM + c] + zp[3 * kTM + c]);
-            zz = (linv + fmv) + pt;                      // Add([linear, fm, dnn]) order
+            zz = LC ? zc + pt                            // Dense(1)(Concatenate([cross, dnn])) (deepnets.py:194-207)
+                    : (linv + fmv) + pt;                 // Add([linear, fm, dnn]) order
             const float lg = zz * wov + bov;
             if (dc.mse) {                                // regression task: 'mse' on the linear task_output
                 const float df = lg - yv;
@@ -378,14 +461,55 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         }
         sb = row_pair16(sb, false); sw = row_pair16(sw, false);          // over the four row groups (lanes with the same n16)
         if (kg == 0) { cs[(mt2 * 2 + 0) * kH2 + 16 * nt2 + n16] = sb; cs[(mt2 * 2 + 1) * kH2 + 16 * nt2 + n16] = sw; }
-        // d linear_logit kernel: sum_rows dz X (raw): the wave's four rows meet through permlane swaps, the eight waves in LDS
-        const float dzr = dzs[srow];
+        if constexpr (LC == 0) {
+            // d linear_logit kernel: sum_rows dz X (raw): the wave's four rows meet through permlane swaps, the eight waves in LDS
+            const float dzr = dzs[srow];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            floatx4 v = xv[j] * dzr;
+            for (int j = 0; j < NCH; ++j) {
+                floatx4 v = xv[j] * dzr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = row_pair16(v[e], false);
-            if (kg == 0) st4(slp + wave * CP + 64 * j + qcol, v);
+                for (int e = 0; e < 4; ++e) v[e] = row_pair16(v[e], false);
+                if (kg == 0) st4(slp + wave * CP + 64 * j + qcol, v);
+            }
+        } else if (wave == 7 && lane < kTM) {
+            // ---- Cross backward in the closed form of the forward (x_L = a_L x0 + c_L, g = dz w3c), per row, scalars only:
+            //   A_L = g . x0 = dz P[r][L];  l = L-1 .. 0:  coeff_l = A_{l+1} a_l,  A_l = A_{l+1} (1 + p_l);  coeff_L = dz a_L
+            //   (k_mlp_fwd3's block of the same name; crS = A_{l+1} | dz replaces the row's a_l once they are in registers)
+            const int L = dc.L, r = lane;
+            float pr[12], av[12];
+            {
+                const floatx4 t0 = ld4(crP + r * 16), t1 = ld4(crP + r * 16 + 4), t2 = ld4(crP + r * 16 + 8);
+                const floatx4 u0 = ld4(crA + r * 16), u1 = ld4(crA + r * 16 + 4), u2 = ld4(crA + r * 16 + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pr[e] = t0[e]; pr[4 + e] = t1[e]; pr[8 + e] = t2[e];
+                    av[e] = u0[e]; av[4 + e] = u1[e]; av[8 + e] = u2[e];
+                }
+            }
+            const float dzv = dzs[r];
+            float pL = 0.f, aL = 0.f;
+#pragma unroll
+            for (int l = 0; l <= LC; ++l) { pL = l == L ? pr[l] : pL; aL = l == L ? av[l] : aL; }
+            float cf[16], sa[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) { cf[l] = 0.f; sa[l] = 0.f; }
+            float A = dzv * pL;
+#pragma unroll
+            for (int l = LC - 1; l >= 0; --l) {
+                if (l < L) {
+                    cf[l] = A * av[l];
+                    sa[l] = A;
+                    A *= 1.f + pr[l];
+                }
+            }
+#pragma unroll
+            for (int l = 0; l <= LC; ++l) cf[l] = l == L ? dzv * aL : cf[l];
+            sa[15] = dzv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st4(crF + r * 16 + 4 * e, floatx4{cf[4 * e], cf[4 * e + 1], cf[4 * e + 2], cf[4 * e + 3]});
+                st4(crA + r * 16 + 4 * e, floatx4{sa[4 * e], sa[4 * e + 1], sa[4 * e + 2], sa[4 * e + 3]});
+            }
         }
     }
     lds_barrier();
@@ -418,11 +542,41 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             const int m = m0 + (tid >> 4);
             if (m < dm.B) st4_sel(dH2 + (int64_t)m * kH2 + 4 * (tid & 15), drow, dc.wt);
         }
-        for (int col = tid; col < CP; col += 512) {
-            float v = 0.f;
+        if constexpr (LC == 0) {
+            for (int col = tid; col < CP; col += 512) {
+                float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += slp[w * CP + col];
-            prec[pl.slin + col] = v;
+                for (int w = 0; w < 8; ++w) v += slp[w * CP + col];
+                prec[pl.slin + col] = v;
+            }
+        } else {
+            // the tile's cross record (k_finish_step turns it into d w_l, d b_j, d w3c and the cross path's BN-backward sums):
+            //   G_l = sum_r coeff[r][l] xhat[r]  (fp32 MFMA, K = the 32 rows),  Sco_l, SA_l, Sdz = ones^T . [coeff | A, dz]
+            const int L = dc.L;
+            float* rec = prec + pl.cross;
+            const float* crS = crA;
+            if (wave == 7) {
+                floatx4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crF[(4 * st + kg) * 16 + n16], d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crS[(4 * st + kg) * 16 + n16], d2, 0, 0, 0);
+                }
+                if (kg == 0) { rec[(L + 1) * CP + n16] = d1[0]; rec[(L + 1) * CP + 16 + n16] = d2[0]; }
+            }
+            float bop[8];
+#pragma unroll
+            for (int st = 0; st < 8; ++st) bop[st] = crF[(4 * st + kg) * 16 + n16];
+            for (int ct = wave; ct < 4 * NCH; ct += 8) {          // 16-column tiles of xhat (zero beyond C)
+                floatx4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kg) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
+                if (n16 <= L) {                                   // C layout: xhat column 16 ct + 4 kg + i, coefficient n16
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rec[n16 * CP + 16 * ct + 4 * kg + i] = d[i];
+                }
+            }
         }
         float colsum = 0.f;
 #pragma unroll
@@ -472,6 +626,18 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 X3_MFMA(gH[0], ah[0][g], bW[buf][g][0]); X3_MFMA(gH[1], ah[1][g], bW[buf][g][0]);
                 X3_MFMA(gM[0], ah[0][g], bW[buf][g][1]); X3_MFMA(gM[1], ah[1][g], bW[buf][g][1]);
                 X3_MFMA(gM[0], al[0][g], bW[buf][g][0]); X3_MFMA(gM[1], al[1][g], bW[buf][g][0]);
+            }
+            if constexpr (LC > 0) {
+                // + sum_l coeff[r][l] Wc_l[col] (exact fp32 MFMA, K = 16 layer slots): A = the coefficient tile, B = the layer
+                // vectors of this column (padded copy: zero beyond C), Wc_L = w3c, nothing beyond L
+                const int L = dc.L;
+#pragma unroll
+                for (int g2 = 0; g2 < 4; ++g2) {
+                    const int l = 4 * g2 + kg;
+                    const float bw = l <= L ? xw.cwp[(int64_t)(l < L ? l : 2 * L) * CP + col] : 0.f;
+                    gH[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(crF[n16 * 16 + l], bw, gH[0], 0, 0, 0);
+                    gH[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(crF[(16 + n16) * 16 + l], bw, gH[1], 0, 0, 0);
+                }
             }
             if (nt + 16 < NT) {              // the tile after next reuses this buffer: its W1 rows are requested now
                 const __bf16* wn = w1r(nt + 16);

@@ -629,14 +629,15 @@ class FusedDCN(FusedDeepFM):
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_dcn_train_step_adam(
-                *head, 2 | _step_loss(self.dm) | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | self.tower_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_dcn_train_step(
-                *head, (2 if backward else 1) | _step_loss(self.dm) | pre, self.emb_dropout if training else 0.0,
+                *head, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0) | pre,
+                self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_dcn_train_step')
         if backward:
             for p, g in self.grad_views:

@@ -376,9 +376,11 @@ int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const flo
  * n_rows rows named by sel (int64 indices into every source block) are copied from each of n_blocks row-major blocks into
  * the matching destination: dst[b][i, :] = src[b][sel[i], :].  src / dst / row_bytes are HOST arrays (n_blocks <= 8 entries;
  * device pointers, bytes per row, multiples of 4): ONE launch assembles the ids, the continuous columns and the labels
- * (+ weights) of k train steps.  cursor (device int64, may be NULL): the rows are sel[*cursor + i] and *cursor advances by
- * n_rows behind the gather — `sel` is then the epoch's whole row order and a captured hipGraph of the call walks it by itself,
- * replay after replay, with no host work in between.                                                              */
+ * (+ weights) of k train steps.  cursor (DT_FEED_CURSOR_WORDS device int64 words, zero-initialised; may be NULL): the rows
+ * are sel[cursor[0] + i] and cursor[0] advances by n_rows behind the gather (the last block to finish does it; the other
+ * words are the blocks' arrival tickets, zero again when the call's launch ends) — `sel` is then the epoch's whole row
+ * order and a captured hipGraph of the call walks it by itself, replay after replay, with no host work in between.   */
+#define DT_FEED_CURSOR_WORDS 528
 int dt_feed_gather(const int64_t* sel, int64_t n_rows, int n_blocks, const void* const* src, void* const* dst,
                    const int* row_bytes, int64_t* cursor, void* stream);
 
