@@ -245,27 +245,31 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
 // Block = 128 rows m x 128 filters; W_i (three parts x 128 filters x Hp k) goes through ONE LDS buffer per block — two blocks
 // per CU, the other block's MFMAs cover this block's refill.
 // ------------------------------------------------------------------------------------------
-template <bool kAnyAct, int KS /* ceil(Hk / 16) upper bound: 2, 4 or 8 */>
-__global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
+// WV = waves per block (32 rows m each).  WV = 8 (large batches): 256 rows per block — every block streams ALL of the filter's
+// parts from L2 (1.28 MB at the Criteo shape), so the 128-row blocks moved 1.3 GB per layer and ran at the L2's pace, not
+// the matrix cores'; twice the rows per block halve that stream.  One 512-thread block per CU then, so W_i is double
+// buffered in LDS (one barrier per i; the other block of a CU no longer covers the refill).
+template <bool kAnyAct, int KS /* ceil(Hk / 16) upper bound: 2, 4 or 8 */, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void k_cin_fwd_noz(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const __bf16* __restrict__ WT, int64_t wt_part, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
     int D, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NP = 3;
+    constexpr int NP = 3, BM = 32 * WV, NT = 64 * WV, NBUF = WV == 8 ? 2 : 1;
     const int Hp = cb_hp(Hk), Kp = F0 * Hp;
     constexpr int HPM = 16 * KS;                          // k per i the kernel walks (Hp <= HPM; beyond Hp: zero operands)
     constexpr int WSb = HPM + 8;                          // bf16 row stride of a filter row: an odd number of 16-byte slots
     const int64_t M = (int64_t)B * D;
-    float* x0T = lds;                                     // [F0][kBM]  x0[m][i], rows m contiguous
-    __bf16* wtb = reinterpret_cast<__bf16*>(x0T + F0 * kBM);       // [NP][kBN][WSb]
+    float* x0T = lds;                                     // [F0][BM]  x0[m][i], rows m contiguous
+    __bf16* wtb = reinterpret_cast<__bf16*>(x0T + F0 * BM);        // [NBUF][NP][kBN][WSb]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
-    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * kBN;
-    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
-        const int i = e / kBM, r = e - i * kBM;
+    for (int e = threadIdx.x; e < BM * F0; e += NT) {
+        const int i = e / BM, r = e - i * BM;
         const int64_t m = m0 + r;
-        x0T[i * kBM + r] = m < M ? x0[(m / D) * x0_bs + (int64_t)i * D + (m % D)] : 0.f;
+        x0T[i * BM + r] = m < M ? x0[(m / D) * x0_bs + (int64_t)i * D + (m % D)] : 0.f;
     }
     // this lane's x_k row, split once: A operand of every GEMM (k = 16 ks + 8 s + e)
     cb_b8 a[KS][NP];
@@ -285,24 +289,24 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
         }
     }
     // W_i loader: NP parts x 128 filters x (HPM / 8) 16-byte pieces
-    constexpr int kPieces = NP * kBN * (HPM / 8), kWR = (kPieces + 255) / 256;
+    constexpr int kPieces = NP * kBN * (HPM / 8), kWR = (kPieces + NT - 1) / NT;
     cb_f4 wreg[kWR];
     auto load_w = [&](int i) {
 #pragma unroll
         for (int u = 0; u < kWR; ++u) {
-            const int e = threadIdx.x + 256 * u;
+            const int e = threadIdx.x + NT * u;
             const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
             wreg[u] = (e < kPieces && 8 * pc < Hp)
                           ? *reinterpret_cast<const cb_f4*>(WT + part * wt_part + (int64_t)(n0 + n) * Kp + (int64_t)i * Hp + 8 * pc)
                           : cb_f4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto store_w = [&]() {
+    auto store_w = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < kWR; ++u) {
-            const int e = threadIdx.x + 256 * u;
+            const int e = threadIdx.x + NT * u;
             const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
-            if (e < kPieces) *reinterpret_cast<cb_f4*>(wtb + (part * kBN + n) * WSb + 8 * pc) = wreg[u];
+            if (e < kPieces) *reinterpret_cast<cb_f4*>(wtb + ((buf * NP + part) * kBN + n) * WSb + 8 * pc) = wreg[u];
         }
     };
     cb_f16v acc[4];
@@ -311,17 +315,12 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
     const int nblocks_n = min(4, (L - n0 + 31) / 32);
-    load_w(0);
-    for (int i = 0; i < F0; ++i) {
-        __syncthreads();                 // every wave is done with W_{i-1} (and, first time, x0T is complete)
-        store_w();
-        __syncthreads();
-        if (i + 1 < F0) load_w(i + 1);   // in flight under this i's MFMAs
+    auto gemm_i = [&](int i, int buf) {
         // x0[m][i] of the 16 accumulator rows of this lane: rows (r & 3) + 8 (r >> 2) + 4 s
         cb_f4 xq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xq[g] = *reinterpret_cast<const cb_f4*>(x0T + i * kBM + wave * 32 + 8 * g + 4 * s);
-        const __bf16* wrow = wtb + c * WSb + 8 * s;
+        for (int g = 0; g < 4; ++g) xq[g] = *reinterpret_cast<const cb_f4*>(x0T + i * BM + wave * 32 + 8 * g + 4 * s);
+        const __bf16* wrow = wtb + (buf * NP * kBN + c) * WSb + 8 * s;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             if (nb >= nblocks_n) continue;
@@ -337,6 +336,28 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] += xq[r >> 2][r & 3] * t[r];
+        }
+    };
+    load_w(0);
+    if constexpr (NBUF == 1) {
+        for (int i = 0; i < F0; ++i) {
+            __syncthreads();                 // every wave is done with W_{i-1} (and, first time, x0T is complete)
+            store_w(0);
+            __syncthreads();
+            if (i + 1 < F0) load_w(i + 1);   // in flight under this i's MFMAs
+            gemm_i(i, 0);
+        }
+    } else {
+        store_w(0);
+        if (F0 > 1) load_w(1);
+        __syncthreads();
+        for (int i = 0; i < F0; ++i) {
+            gemm_i(i, i & 1);
+            // W_{i+1} (in registers since the last iteration) -> the other buffer: its last readers (i - 1) are behind the
+            // barrier that ended that iteration
+            if (i + 1 < F0) store_w((i + 1) & 1);
+            if (i + 2 < F0) load_w(i + 2);
+            __syncthreads();
         }
     }
     // epilogue (as cin.hip): row = (r&3) + 8*(r>>2) + 4*s, col = c
@@ -373,22 +394,27 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_noz(
 // dgrad: grad_x0 (=), grad_xk (=): both OVERWRITTEN (one block owns a 128-row tile of m and all of its (i, j)).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
 // lane that owns column m against xk / x0; grad_x0 is gathered in LDS and flushed once.
 // ------------------------------------------------------------------------------------------
-template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */>
-__global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
+// WV = waves per block, 32 columns m each.  Every block streams ALL of W_N through LDS (852 KB at the Criteo shape with two
+// parts): 1024 blocks of 128 rows moved 870 MB per layer and the kernel ran at the L2's pace (345 us, 19 % of the matrix
+// rate); WV = 8 (large batches) halves the stream.  The next chunk's pieces wait in registers while this chunk's MFMAs run.
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */, int WV>
+__global__ __launch_bounds__(64 * WV) void k_cin_dgrad_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const __bf16* __restrict__ WN, int64_t wn_part, const float* __restrict__ y, const float* __restrict__ gy, int act,
     int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = 32 * WV, NT = 64 * WV;
     const int64_t M = (int64_t)B * D;
-    const int F0S = F0 | 1, Lq = cb_lq(L), WS = 16 * LSTEPS + 8;
-    float* x0T = lds;                    // [kBM][F0S]
-    float* g0T = x0T + kBM * F0S;        // [kBM][F0S] grad_x0 of the tile
-    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + kBM * F0S);   // [2][NP][32][WS]
+    const int F0S = F0 | 1, Lq = cb_lq(L);
+    constexpr int WS = 16 * LSTEPS + 8;
+    float* x0T = lds;                    // [BM][F0S]
+    float* g0T = x0T + BM * F0S;         // [BM][F0S] grad_x0 of the tile
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + BM * F0S);    // [2][NP][32][WS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
-    const int64_t m0 = (int64_t)blockIdx.x * kBM;
-    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
-        const int i = e / kBM, r = e - i * kBM;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    for (int e = threadIdx.x; e < BM * F0; e += NT) {
+        const int i = e / BM, r = e - i * BM;
         const int64_t mm = m0 + r;
         x0T[r * F0S + i] = mm < M ? x0[(mm / D) * x0_bs + (int64_t)i * D + (mm % D)] : 0.f;
         g0T[r * F0S + i] = 0.f;
@@ -428,24 +454,37 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
         }
     const int njb = (Hk + 31) / 32;
     const int nchunks = F0 * njb;
-    // W chunk (i, jb): 32 rows x Lq bf16, contiguous in WN
-    auto stage_w = [&](int chunk, int buf) {
+    // W chunk (i, jb): NP parts x 32 rows x Lq bf16, contiguous in WN; 16-byte pieces, kWP per thread
+    const int pieces = Lq / 8;                          // per row
+    constexpr int kWP = (NP * 32 * 2 * LSTEPS + NT - 1) / NT;
+    cb_f4 wreg[kWP];
+    auto load_w = [&](int chunk) {
         const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
-        const int pieces = Lq / 8;                      // 16-byte pieces per row
-        for (int e = threadIdx.x; e < NP * 32 * pieces; e += 256) {
+#pragma unroll
+        for (int u = 0; u < kWP; ++u) {
+            const int e = threadIdx.x + NT * u;
             const int part = e / (32 * pieces), q = e - part * 32 * pieces;
             const int r = q / pieces, pc = q - r * pieces;
-            *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) =
-                *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
+            if (e < NP * 32 * pieces) wreg[u] = *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < kWP; ++u) {
+            const int e = threadIdx.x + NT * u;
+            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
+            const int r = q / pieces, pc = q - r * pieces;
+            if (e < NP * 32 * pieces) *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) = wreg[u];
         }
     };
     const int lsteps = Lq / 16;
-    stage_w(0, 0);
+    load_w(0);
+    store_w(0);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int i = chunk / njb, jb = chunk - i * njb;
-        if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
+        if (chunk + 1 < nchunks) load_w(chunk + 1);
         const __bf16* wrow = wtl + (buf * NP * 32 + c) * WS + 8 * s;
         cb_f16v acc;
 #pragma unroll
@@ -472,6 +511,7 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
             }
         p += __shfl_xor(p, 32, 64);
         if (s == 0) g0T[row * F0S + i] += p;  // unique owner of (m, i)
+        if (chunk + 1 < nchunks) store_w(buf ^ 1);   // (its last readers, chunk - 1, are behind the previous barrier)
         __syncthreads();
     }
     if (mvalid) {
@@ -483,8 +523,8 @@ __global__ __launch_bounds__(256) void k_cin_dgrad_bf16(
                 if (j < Hk) gxk[(b * Hk + j) * D + d] = gxk_acc[jb][r];
             }
     }
-    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
-        const int i = e / kBM, r = e - i * kBM;
+    for (int e = threadIdx.x; e < BM * F0; e += NT) {
+        const int i = e / BM, r = e - i * BM;
         const int64_t mm = m0 + r;
         if (mm < M) gx0[((mm / D) * F0 + i) * D + (mm % D)] = g0T[r * F0S + i];     // this block is the only writer of (m, i)
     }
@@ -668,6 +708,178 @@ __global__ __launch_bounds__(256, 2) void k_cin_wgrad_bf16(
         }
 }
 
+// wgrad, large-batch form (round 4).  The kernel above gives a block 256 rows of k and all 128 filters: each of its 7 k blocks
+// reads ALL of G and y again (1.27 GB per layer at the Criteo shape) and the kernel ran at the memory system's pace (372 us,
+// 18 % of the matrix rate).  Here a block is EIGHT waves x up to FOUR 32-row k sub-tiles (wave w owns sub-tiles w, w + 8, ..
+// of the block's group) x 64 filters: 2 x 2 (k groups x filter halves) blocks per batch slice, 457 MB per layer; the next
+// chunk's loads wait in registers while this chunk's MFMAs run (one block per CU: nobody else would cover them).
+// Needs the 16-byte staging (D % 4 == 0, aligned pointers) and F0 + Hk <= 96 (three x pieces per thread).
+constexpr int kW2Waves = 8, kW2KT = 4, kW2NB = 2;
+template <int NP>
+__global__ __launch_bounds__(512) void k_cin_wgrad_wide(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const float* __restrict__ y, const float* __restrict__ gy, int act, int B, int F0, int Hk, int L,
+    int D, int64_t rows_per_split, int sub_per_group, float* __restrict__ gW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KT = kW2KT, NB = kW2NB, FN = 32 * NB, NT = 64 * kW2Waves;
+    const int K = F0 * Hk;
+    const int64_t M = (int64_t)B * D;
+    constexpr int XS = kBMC + 4, GS = kBMC + 8;
+    float* x0s = lds;                    // [F0][XS]  (rows m contiguous)
+    float* xks = x0s + F0 * XS;          // [Hk][XS]
+    __bf16* gsb = reinterpret_cast<__bf16*>(xks + Hk * XS);     // [NP][FN][GS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int nsub = (K + 31) >> 5;
+    const int sub0 = blockIdx.x * sub_per_group, sub1 = min(nsub, sub0 + sub_per_group);
+    int ki[KT], kj[KT], kb[KT];
+    bool has[KT], kvalid[KT];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+        const int su = sub0 + wave + kW2Waves * u;
+        has[u] = su < sub1;                 // wave-uniform
+        kb[u] = 32 * su;
+        const int k = kb[u] + c;            // this lane's A row (i,j) in sub-tile u
+        kvalid[u] = has[u] && k < K;
+        ki[u] = kvalid[u] ? k / Hk : 0;
+        kj[u] = kvalid[u] ? k % Hk : 0;
+    }
+    const int n0 = blockIdx.z * FN;
+    const int nblocks_n = min(NB, (L - n0 + 31) / 32);
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(M, m_begin + rows_per_split);
+    cb_f16v acc[KT][NB];
+#pragma unroll
+    for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.f;
+
+    // staging tasks: 16 four-row pieces per tile row; x rows (F0 + Hk <= 96: at most 3 per thread), G rows (64: exactly 2)
+    constexpr int QR = kBMC / 4, XT = 3, GT = FN * QR / NT;
+    static_assert(GT * NT == FN * QR, "G pieces per thread");
+    cb_f4 vx[XT], vg[GT], vy[GT];
+    const int ntx = (F0 + Hk) * QR;
+    auto load_chunk = [&](int64_t mc) {
+        const int rows = (int)min((int64_t)kBMC, m_end - mc);
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int t = threadIdx.x + NT * u;
+            vx[u] = cb_f4{0.f, 0.f, 0.f, 0.f};
+            if (t < ntx) {
+                const int row = t / QR, q = t - row * QR;
+                if (4 * q < rows) {
+                    const int64_t m = mc + 4 * q, b = m / D;
+                    const int d = (int)(m - b * D);
+                    vx[u] = row < F0 ? *reinterpret_cast<const cb_f4*>(x0 + b * x0_bs + (int64_t)row * D + d)
+                                     : *reinterpret_cast<const cb_f4*>(xk + b * xk_bs + (int64_t)(row - F0) * D + d);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GT; ++u) {
+            const int t = threadIdx.x + NT * u;
+            const int row = t / QR, q = t - row * QR;
+            vg[u] = cb_f4{0.f, 0.f, 0.f, 0.f};
+            vy[u] = cb_f4{1.f, 1.f, 1.f, 1.f};
+            if (4 * q < rows && n0 + row < L) {
+                const int64_t m = mc + 4 * q, b = m / D;
+                const int d = (int)(m - b * D);
+                const int64_t o = (b * L + n0 + row) * D + d;
+                vg[u] = *reinterpret_cast<const cb_f4*>(gy + o);
+                if (act != DT_ACT_LINEAR) vy[u] = *reinterpret_cast<const cb_f4*>(y + o);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int t = threadIdx.x + NT * u;
+            if (t < ntx) {
+                const int row = t / QR, q = t - row * QR;
+                *reinterpret_cast<cb_f4*>(lds + row * XS + 4 * q) = vx[u];        // x0s | xks are contiguous
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GT; ++u) {
+            const int t = threadIdx.x + NT * u;
+            const int row = t / QR, q = t - row * QR;
+            cb_f4 o = vg[u];
+            if (act != DT_ACT_LINEAR) {
+                o.x *= act_grad_from_y(vy[u].x, act); o.y *= act_grad_from_y(vy[u].y, act);
+                o.z *= act_grad_from_y(vy[u].z, act); o.w *= act_grad_from_y(vy[u].w, act);
+            }
+            typedef __bf16 cb_b4 __attribute__((ext_vector_type(4)));
+            float rr[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int qq = 0; qq < NP; ++qq) {
+                cb_b4 h;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const __bf16 a = (__bf16)rr[e4];
+                    h[e4] = a;
+                    rr[e4] -= (float)a;
+                }
+                *reinterpret_cast<cb_b4*>(gsb + (qq * FN + row) * GS + 4 * q) = h;
+            }
+        }
+    };
+    if (m_begin < m_end) {
+        load_chunk(m_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int64_t mc = m_begin; mc < m_end; mc += kBMC) {
+        const bool more = mc + kBMC < m_end;
+        if (more) load_chunk(mc + kBMC);
+#pragma unroll
+        for (int st = 0; st < kBMC / 16; ++st) {
+            const int r0 = 16 * st + 8 * s;
+            cb_b8 g[NB][NP];
+            const __bf16* grow = gsb + c * GS + r0;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) g[nb][q] = *reinterpret_cast<const cb_b8*>(grow + (q * FN + nb * 32) * GS);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                if (!has[u]) continue;
+                cb_b8 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = cb_zero();
+                if (kvalid[u]) {
+                    const float* xp = x0s + ki[u] * XS + r0;
+                    const float* kp = xks + kj[u] * XS + r0;
+                    const cb_f4 lo = *reinterpret_cast<const cb_f4*>(xp) * *reinterpret_cast<const cb_f4*>(kp),
+                                hi = *reinterpret_cast<const cb_f4*>(xp + 4) * *reinterpret_cast<const cb_f4*>(kp + 4);
+                    const float z[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    cb_split<NP>(z, a);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    if (nb < nblocks_n) cb_mma<NP>(acc[u][nb], a, g[nb]);
+            }
+        }
+        __syncthreads();                 // every wave is done with this chunk's tiles
+        if (more) store_chunk();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!has[u] || nb >= nblocks_n) continue;
+            const int l = n0 + nb * 32 + c;
+            if (l >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kb[u] + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (kk < K) atomicAdd(&gW[(int64_t)kk * L + l], acc[u][nb][r]);
+            }
+        }
+}
+
 // grad_bias[l] += sum_{b,d} G[b,l,d]   (fp32, as cin.hip)
 __global__ __launch_bounds__(256) void k_cin_bias_grad_b(const float* __restrict__ y, const float* __restrict__ gy,
                                                          int act, int B, int L, int D, float* __restrict__ gbias) {
@@ -711,6 +923,13 @@ static void cinb_pack(const float* W, int F0, int Hk, int L, __bf16* WT, __bf16*
     hipLaunchKernelGGL(k_cin_pack_w<NP>, dim3(512), dim3(256), 0, st, W, F0, Hk, L, WT, WN);
 }
 
+// large batches take the 256-row (eight-wave) blocks of the forward / dgrad: at least one block per CU that way
+// (DT_CIN_WIDE=0 / 1 forces the choice: the A/B knob of DESIGN.md 3.4)
+static bool cinb_wide(int64_t M) {
+    static const int env = getenv("DT_CIN_WIDE") ? atoi(getenv("DT_CIN_WIDE")) : -1;
+    return env >= 0 ? env != 0 : M >= 256 * 128;
+}
+
 template <int NP>
 static int cinb_fwd(const char* who, const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
                     int Hk, int L, int D, int64_t x0_bstride, int64_t xk_bstride, float* y, void* ws, void* stream) {
@@ -727,18 +946,22 @@ static int cinb_fwd(const char* who, const float* x0, const float* xk, const flo
     if (NP == 3 && !(getenv("DT_CIN_FWD_Z") && atoi(getenv("DT_CIN_FWD_Z")))) {
         // the forward that never forms Z (k_cin_fwd_noz): Hk up to 128
         const int ks = cb_hp(Hk) <= 32 ? 2 : cb_hp(Hk) <= 64 ? 4 : 8;
-        const size_t ldsn = (size_t)F0 * kBM * sizeof(float) + (size_t)3 * kBN * (16 * ks + 8) * 2;
+        const bool wide = cinb_wide(M);                  // 256-row blocks (eight waves), the filter double buffered in LDS
+        const int bm = wide ? 256 : kBM;
+        const size_t ldsn = (size_t)F0 * bm * sizeof(float) + (size_t)(wide ? 2 : 1) * 3 * kBN * (16 * ks + 8) * 2;
         const bool any = !(act == DT_ACT_LINEAR || act == DT_ACT_RELU);
-#define DT_NOZ(ANY, KSV)                                                                                                   \
+        const dim3 gridn((unsigned)((M + bm - 1) / bm), (unsigned)ceil_div(L, kBN));
+#define DT_NOZ(ANY, KSV, WVV)                                                                                              \
     do {                                                                                                                   \
-        hipFuncSetAttribute((const void*)k_cin_fwd_noz<ANY, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn);  \
-        hipLaunchKernelGGL((k_cin_fwd_noz<ANY, KSV>), grid, dim3(256), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT,       \
+        hipFuncSetAttribute((const void*)k_cin_fwd_noz<ANY, KSV, WVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn); \
+        hipLaunchKernelGGL((k_cin_fwd_noz<ANY, KSV, WVV>), gridn, dim3(64 * WVV), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT, \
                            cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);                                             \
     } while (0)
         // linear / relu epilogues and Hk <= 64 only: with the libm activations or eight k steps of A parts in registers the
         // kernel spills (254 VGPRs at four steps already) — those shapes keep the Z-forming kernel
         if (ldsn <= 160 * 1024 && !any && ks <= 4) {
-            if (ks == 2) DT_NOZ(false, 2); else DT_NOZ(false, 4);
+            if (wide) { if (ks == 2) DT_NOZ(false, 2, 8); else DT_NOZ(false, 4, 8); }
+            else { if (ks == 2) DT_NOZ(false, 2, 4); else DT_NOZ(false, 4, 4); }
             return launch_status(who);
         }
 #undef DT_NOZ
@@ -769,19 +992,20 @@ extern "C" int dt_cin_layer_fwd_bf16x3(const float* x0, const float* xk, const f
     return cinb_fwd<3>("dt_cin_layer_fwd_bf16x3", x0, xk, W, bias, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, y, ws, stream);
 }
 
-template <int LSTEPS, int JB, int NP>
+template <int LSTEPS, int JB, int NP, int WV>
 static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, int64_t wn_part,
                           const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
                           hipStream_t st) {
-    const size_t lds = (size_t)2 * kBM * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * LSTEPS + 8) * 2;
+    constexpr int BM = 32 * WV;
+    const size_t lds = (size_t)2 * BM * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * LSTEPS + 8) * 2;
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
     }
     const int64_t M = (int64_t)B * D;
-    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP>), dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, x0, x0_bs,
-                       xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
+    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP, WV>), dim3((unsigned)((M + BM - 1) / BM)), dim3(64 * WV), lds, st, x0,
+                       x0_bs, xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
     return launch_status("dt_cin_layer_bwd_bf16(dgrad)");
 }
 
@@ -799,9 +1023,14 @@ static int cinb_bwd(const char* who, const float* x0, const float* xk, const flo
     cinb_pack<NP>(W, F0, Hk, L, nullptr, WN, st);
     const int64_t wn_part = cinb_nN(F0, Hk, L);
     const int jb = ceil_div(Hk, 32);
+    // 256-row blocks when the batch fills the chip with them and their tiles fit the LDS (F0 <= ~100)
+    const bool wide = cinb_wide((int64_t)B * D) &&
+                      (size_t)2 * 256 * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * (L <= 128 ? 8 : 16) + 8) * 2 <= 160 * 1024;
 #define DT_DGRAD_B(LS, JBV)                                                                                          \
-    rc = launch_dgrad_b<LS, JBV, NP>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, grad_x0, \
-                                     grad_xk, st)
+    rc = wide ? launch_dgrad_b<LS, JBV, NP, 8>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, \
+                                               grad_x0, grad_xk, st)                                                 \
+              : launch_dgrad_b<LS, JBV, NP, 4>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, \
+                                               grad_x0, grad_xk, st)
     if (L <= 128) {
         if (jb <= 1) DT_DGRAD_B(8, 1);
         else if (jb <= 2) DT_DGRAD_B(8, 2);
@@ -815,16 +1044,34 @@ static int cinb_bwd(const char* who, const float* x0, const float* xk, const flo
     if (rc) return rc;
     const int K = F0 * Hk;
     const int64_t M = (int64_t)B * D;
-    const int kblocks = ceil_div(K, 128 * kBKT), nblocks = ceil_div(L, kBN);
-    int splits = 512 / (kblocks * nblocks);
-    if (splits < 1) splits = 1;
-    int64_t rps = (M + splits - 1) / splits;
-    rps = (rps + kBMC - 1) / kBMC * kBMC;
-    splits = (int)((M + rps - 1) / rps);
-    const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)NP * kBN * (kBMC + 8) * 2;
-    hipFuncSetAttribute((const void*)k_cin_wgrad_bf16<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cin_wgrad_bf16<NP>, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride,
-                       y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
+    const bool vec4 = (D % 4 == 0) && (x0_bstride % 4 == 0) && (xk_bstride % 4 == 0) &&
+                      ((((uintptr_t)x0 | (uintptr_t)xk | (uintptr_t)y | (uintptr_t)grad_y) & 15) == 0);
+    static const int wide_env = getenv("DT_CIN_WGRAD_WIDE") ? atoi(getenv("DT_CIN_WGRAD_WIDE")) : 1;
+    if (wide_env && vec4 && F0 + Hk <= 96) {
+        // k_cin_wgrad_wide: groups of up to 32 k sub-tiles x 64 filters per block, the batch split over what is left of ~256 blocks
+        const int nsub = ceil_div(K, 32), kgroups = ceil_div(nsub, kW2Waves * kW2KT), spg = ceil_div(nsub, kgroups);
+        const int lgroups = ceil_div(L, 32 * kW2NB);
+        int splits = 256 / (kgroups * lgroups);
+        if (splits < 1) splits = 1;
+        int64_t rps = (M + splits - 1) / splits;
+        rps = (rps + kBMC - 1) / kBMC * kBMC;
+        splits = (int)((M + rps - 1) / rps);
+        const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)NP * 32 * kW2NB * (kBMC + 8) * 2;
+        hipFuncSetAttribute((const void*)k_cin_wgrad_wide<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_wgrad_wide<NP>, dim3(kgroups, splits, lgroups), dim3(512), lds, st, x0, x0_bstride, xk,
+                           xk_bstride, y, grad_y, act, B, F0, Hk, L, D, rps, spg, grad_W);
+    } else {
+        const int kblocks = ceil_div(K, 128 * kBKT), nblocks = ceil_div(L, kBN);
+        int splits = 512 / (kblocks * nblocks);
+        if (splits < 1) splits = 1;
+        int64_t rps = (M + splits - 1) / splits;
+        rps = (rps + kBMC - 1) / kBMC * kBMC;
+        splits = (int)((M + rps - 1) / rps);
+        const size_t lds = (size_t)(F0 + Hk) * (kBMC + 4) * sizeof(float) + (size_t)NP * kBN * (kBMC + 8) * 2;
+        hipFuncSetAttribute((const void*)k_cin_wgrad_bf16<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cin_wgrad_bf16<NP>, dim3(kblocks, splits, nblocks), dim3(256), lds, st, x0, x0_bstride, xk, xk_bstride,
+                           y, grad_y, act, B, F0, Hk, L, D, rps, grad_W);
+    }
     if (grad_bias)
         hipLaunchKernelGGL(k_cin_bias_grad_b, dim3(L, 16), dim3(256), 0, st, y, grad_y, act, B, L, D, grad_bias);
     return launch_status(who);

@@ -8,6 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=['bf16x3', 'f32'], autouse=True)
+def tower_mode(request, monkeypatch):
+    """every test of this file runs the tile kernel of the step both ways: split-bf16 matrix cores (k_tower_x3, the default)
+    and exact-fp32 MFMA (k_mlp_fwd3) — the same bars for both"""
+    monkeypatch.setenv('DT_AMD_TOWER_DTYPE', request.param)
+    return request.param
+
+
 def build(F, Nd, D, vocab, seed=3, use_bias=True, nets=None, task='binary', **extra):
     from deeptables_amd import functional
     from deeptables_amd.models import ModelConfig, DeepModel, deepnets

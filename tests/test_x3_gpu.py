@@ -116,7 +116,10 @@ def test_x3_rows_in_step_equals_the_separate_optimizer_step(dev):
 @pytest.mark.parametrize('B,F0,Hk,L,D,bias,act', [(5, 4, 4, 6, 3, False, 'relu'), (64, 26, 26, 128, 16, False, 'relu'),
                                                  (40, 26, 64, 128, 16, True, 'relu'), (9, 5, 7, 33, 8, True, 'linear'),
                                                  (20, 6, 100, 200, 4, False, 'relu'), (12, 5, 6, 40, 8, True, 'tanh'),
-                                                 (300, 26, 64, 128, 16, False, 'relu')])
+                                                 (300, 26, 64, 128, 16, False, 'relu'),
+                                                 # B D >= 32768: the 256-row (eight-wave) forward / dgrad blocks and the
+                                                 # wide wgrad blocks of large batches, Hk <= 32 and Hk <= 64 forms
+                                                 (2100, 26, 64, 128, 16, False, 'relu'), (2060, 26, 26, 128, 16, True, 'relu')])
 def test_cin_layer_split_bf16_holds_the_fp32_bar(dev, B, F0, Hk, L, D, bias, act):
     """CIN.call (layers.py:689-710) with three-part operands / six products in the forward, two parts / three products in
     the backward: outputs and all four gradients within 1e-4 of the float64 restatement — the bar of the exact-fp32 kernels
@@ -137,6 +140,10 @@ def test_cin_layer_split_bf16_holds_the_fp32_bar(dev, B, F0, Hk, L, D, bias, act
     y = torch.einsum('bid,bjd,ijl->bld', x0r, xkr, Wr.reshape(F0, Hk, L))
     if bias:
         y = y + bvr[None, :, None]
+    if act == 'relu':
+        # a unit within fp32 rounding of its kink may land on the other side of it (millions of units in the large cases:
+        # it happens); no gradient is sent through those, so the comparison is about arithmetic, not about the kink
+        up = torch.where(y.detach().abs() < 1e-5, torch.zeros_like(up), up)
     ref = R._activation(act)(y)
     (ref * up).sum().backward()
     x0d, xkd, Wd = (t.float().to(dev).requires_grad_(True) for t in (x0, xk, W))
