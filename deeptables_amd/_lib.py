@@ -97,7 +97,7 @@ SIGNATURES = {
                                    _ptr]),
     'dt_adam_rows_step_seg': (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _ptr, _c_f32,
                                    _c_f32, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32,
-                                   _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
+                                   _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr]),
     'dt_rows_merge_segments': (_c_int, [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     'dt_rows_compact': (_c_int, [_ptr, _ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_f32, _c_i64,
                                  _ptr, _ptr, _ptr, _ptr]),
@@ -160,6 +160,7 @@ DT_STEP_LOSS_MSE = 0x10
 DT_STEP_SKIP_FINISH, DT_STEP_FINISH_ONLY = 0x20, 0x40
 DT_STEP_TOWER_X3 = 0x80
 DT_STEP_PREELECTED = 0x100
+DT_STEP_TOWER_BF16 = 0x200
 DT_FEED_CURSOR_WORDS = 528          # 16 (1 + 32 ticket groups), csrc/embedding.hip kFeedGroups
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
 # keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)

@@ -211,20 +211,32 @@ class CompiledTrainLoop:
             for i in range(1, self.k):
                 plan._slot_buffers(self.B, i)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            if not core_only:
-                self._gather()
-            if pre:
-                main = torch.cuda.current_stream()
-                side = torch.cuda.Stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    for i in range(1, self.k):
-                        plan.preelect(self.slots[0][i * self.B:(i + 1) * self.B], slot=i)
-            for i in range(self.k):
-                if pre and i == 1:
-                    torch.cuda.current_stream().wait_stream(side)
-                self._body(i, core_only=core_only, preelected=pre and i >= 1)
+        # No cyclic garbage collection while the stream captures: a collection that starts in the middle of the capture runs
+        # the destructors of whatever it finds — an older CompiledTrainLoop's hipGraph, side streams, events of a model the
+        # caller dropped — and a destroy call of that kind inside a global-mode capture aborts the process (seen as an
+        # intermittent SIGABRT "Garbage-collecting" under pytest, where earlier tests' loops are such garbage).
+        # torch.cuda.graph collects once on entry; nothing may be collected after that until the capture has ended.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g):
+                if not core_only:
+                    self._gather()
+                if pre:
+                    main = torch.cuda.current_stream()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        for i in range(1, self.k):
+                            plan.preelect(self.slots[0][i * self.B:(i + 1) * self.B], slot=i)
+                for i in range(self.k):
+                    if pre and i == 1:
+                        torch.cuda.current_stream().wait_stream(side)
+                    self._body(i, core_only=core_only, preelected=pre and i >= 1)
+        finally:
+            if gc_was_on:
+                gc.enable()
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
         # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
@@ -290,8 +302,15 @@ class CompiledTrainLoop:
                         hook()
                     torch.cuda.synchronize()
                     gopt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gopt):
-                        opt.step()
+                    import gc
+                    gc_was_on = gc.isenabled()
+                    gc.disable()                       # (see capture(): no collection inside a stream capture)
+                    try:
+                        with torch.cuda.graph(gopt):
+                            opt.step()
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     self.opt_graph = gopt
                     gopt.replay()
                 else:

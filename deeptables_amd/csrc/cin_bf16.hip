@@ -396,20 +396,23 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void k_cin_fwd_noz(
 // ------------------------------------------------------------------------------------------
 // WV = waves per block, 32 columns m each.  Every block streams ALL of W_N through LDS (852 KB at the Criteo shape with two
 // parts): 1024 blocks of 128 rows moved 870 MB per layer and the kernel ran at the L2's pace (345 us, 19 % of the matrix
-// rate); WV = 8 (large batches) halves the stream.  The next chunk's pieces wait in registers while this chunk's MFMAs run.
-template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */, int WV>
+// rate); WV = 8 (large batches) halves the stream.  CJ = 32-row j blocks per LDS chunk (one barrier per chunk); a chunk's
+// pieces are requested TWO chunks ahead and wait in registers — a chunk's MFMAs (0.3 .. 0.6 us) are shorter than an L2 round
+// trip under load, with one chunk of lookahead every iteration waited for its loads.
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */, int WV,
+          int CJ, bool LA2 /* two chunks of lookahead (a second set of staging registers) */>
 __global__ __launch_bounds__(64 * WV) void k_cin_dgrad_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const __bf16* __restrict__ WN, int64_t wn_part, const float* __restrict__ y, const float* __restrict__ gy, int act,
     int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BM = 32 * WV, NT = 64 * WV;
+    constexpr int BM = 32 * WV, NT = 64 * WV, CR = 32 * CJ;
     const int64_t M = (int64_t)B * D;
     const int F0S = F0 | 1, Lq = cb_lq(L);
     constexpr int WS = 16 * LSTEPS + 8;
     float* x0T = lds;                    // [BM][F0S]
     float* g0T = x0T + BM * F0S;         // [BM][F0S] grad_x0 of the tile
-    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + BM * F0S);    // [2][NP][32][WS]
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + BM * F0S);    // [2][NP][CR][WS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -452,67 +455,90 @@ __global__ __launch_bounds__(64 * WV) void k_cin_dgrad_bf16(
             xkv[jb][r] = (mvalid && j < Hk) ? xk[b * xk_bs + (int64_t)j * D + d] : 0.f;
             gxk_acc[jb][r] = 0.f;
         }
-    const int njb = (Hk + 31) / 32;
-    const int nchunks = F0 * njb;
-    // W chunk (i, jb): NP parts x 32 rows x Lq bf16, contiguous in WN; 16-byte pieces, kWP per thread
+    const int njb = (Hk + 31) / 32;      // (a multiple of CJ: the host's choice of CJ)
+    const int cpi = njb / CJ;            // chunks per i
+    const int nchunks = F0 * cpi;
+    // W chunk: NP parts x CR rows x Lq bf16, contiguous in WN (rows ordered (i, jb, r)); 16-byte pieces, kWP per thread
     const int pieces = Lq / 8;                          // per row
-    constexpr int kWP = (NP * 32 * 2 * LSTEPS + NT - 1) / NT;
-    cb_f4 wreg[kWP];
-    auto load_w = [&](int chunk) {
-        const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
+    constexpr int kWP = (NP * CR * 2 * LSTEPS + NT - 1) / NT;
+    cb_f4 wregA[kWP], wregB[LA2 ? kWP : 1];
+    auto load_w = [&](int chunk, cb_f4 (&wreg)[kWP]) {
+        const __bf16* src = WN + (int64_t)chunk * CR * Lq;
 #pragma unroll
         for (int u = 0; u < kWP; ++u) {
             const int e = threadIdx.x + NT * u;
-            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
+            const int part = e / (CR * pieces), q = e - part * CR * pieces;
             const int r = q / pieces, pc = q - r * pieces;
-            if (e < NP * 32 * pieces) wreg[u] = *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
+            if (e < NP * CR * pieces) wreg[u] = *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, const cb_f4 (&wreg)[kWP]) {
 #pragma unroll
         for (int u = 0; u < kWP; ++u) {
             const int e = threadIdx.x + NT * u;
-            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
+            const int part = e / (CR * pieces), q = e - part * CR * pieces;
             const int r = q / pieces, pc = q - r * pieces;
-            if (e < NP * 32 * pieces) *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) = wreg[u];
+            if (e < NP * CR * pieces) *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * CR + r) * WS + 8 * pc) = wreg[u];
         }
     };
     const int lsteps = Lq / 16;
-    load_w(0);
-    store_w(0);
-    __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    auto compute = [&](int chunk) {
         const int buf = chunk & 1;
-        const int i = chunk / njb, jb = chunk - i * njb;
-        if (chunk + 1 < nchunks) load_w(chunk + 1);
-        const __bf16* wrow = wtl + (buf * NP * 32 + c) * WS + 8 * s;
-        cb_f16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < LSTEPS; ++st)
-            if (st < lsteps) {
-                cb_b8 a[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * 32 * WS + 16 * st);
-                cb_mma<NP>(acc, a, G[st]);
-            }
-        // contract T^T[j, m] (16 j's in this lane) against xk and x0
+        const int i = chunk / cpi, jb0 = (chunk - i * cpi) * CJ;
         const float x0v = x0T[row * F0S + i];
         float p = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < JB; ++jj)
-            if (jj == jb) {
+        for (int cj = 0; cj < CJ; ++cj) {
+            const __bf16* wrow = wtl + (buf * NP * CR + cj * 32 + c) * WS + 8 * s;
+            cb_f16v acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p += xkv[jj][r] * acc[r];
-                    gxk_acc[jj][r] += x0v * acc[r];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < LSTEPS; ++st)
+                if (st < lsteps) {
+                    cb_b8 a[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * CR * WS + 16 * st);
+                    cb_mma<NP>(acc, a, G[st]);
                 }
-            }
+            // contract T^T[j, m] (16 j's in this lane) against xk and x0
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+                if (CJ == JB ? jj == cj : jj == jb0 + cj) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        p += xkv[jj][r] * acc[r];
+                        gxk_acc[jj][r] += x0v * acc[r];
+                    }
+                }
+        }
         p += __shfl_xor(p, 32, 64);
         if (s == 0) g0T[row * F0S + i] += p;  // unique owner of (m, i)
-        if (chunk + 1 < nchunks) store_w(buf ^ 1);   // (its last readers, chunk - 1, are behind the previous barrier)
+    };
+    load_w(0, wregA);
+    store_w(0, wregA);
+    if constexpr (LA2) {
+        // one chunk: `wcur` holds chunk + 1 (requested an iteration ago), `wnext` receives chunk + 2
+        auto body = [&](int chunk, cb_f4 (&wcur)[kWP], cb_f4 (&wnext)[kWP]) {
+            if (chunk + 2 < nchunks) load_w(chunk + 2, wnext);
+            compute(chunk);
+            if (chunk + 1 < nchunks) store_w((chunk & 1) ^ 1, wcur);   // (that buffer's last readers, chunk - 1, are behind the previous barrier)
+            __syncthreads();
+        };
+        if (nchunks > 1) load_w(1, wregA);
         __syncthreads();
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+            body(chunk, wregA, wregB);
+            if (chunk + 1 < nchunks) body(chunk + 1, wregB, wregA);
+        }
+    } else {
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk + 1 < nchunks) load_w(chunk + 1, wregA);
+            compute(chunk);
+            if (chunk + 1 < nchunks) store_w((chunk & 1) ^ 1, wregA);
+            __syncthreads();
+        }
     }
     if (mvalid) {
 #pragma unroll
@@ -992,20 +1018,34 @@ extern "C" int dt_cin_layer_fwd_bf16x3(const float* x0, const float* xk, const f
     return cinb_fwd<3>("dt_cin_layer_fwd_bf16x3", x0, xk, W, bias, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, y, ws, stream);
 }
 
+// CJ (j blocks per LDS chunk): 1 (whole i's, CJ = JB = 2, with two sets of staging registers: 70 VGPRs spilled).
+// The eight-wave form and the second set of staging registers exist for L <= 128, Hk <= 64 (the others spill with them).
+template <int LSTEPS, int JB, int WV>
+constexpr int dgrad_cj() { return 1; }
+template <int LSTEPS, int JB>
+constexpr bool dgrad_roomy() { return LSTEPS == 8 && JB <= 2; }
+template <int LSTEPS, int JB, int NP, int WV>
+static size_t dgrad_lds(int F0) {
+    return (size_t)2 * 32 * WV * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * dgrad_cj<LSTEPS, JB, WV>() * (16 * LSTEPS + 8) * 2;
+}
 template <int LSTEPS, int JB, int NP, int WV>
 static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, int64_t wn_part,
                           const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
                           hipStream_t st) {
-    constexpr int BM = 32 * WV;
-    const size_t lds = (size_t)2 * BM * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * LSTEPS + 8) * 2;
+    constexpr int BM = 32 * WV, CJ = dgrad_cj<LSTEPS, JB, WV>();
+    const size_t lds = dgrad_lds<LSTEPS, JB, NP, WV>(F0);
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
     }
     const int64_t M = (int64_t)B * D;
-    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP, WV>), dim3((unsigned)((M + BM - 1) / BM)), dim3(64 * WV), lds, st, x0,
-                       x0_bs, xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
+    // two chunks of lookahead (a second set of staging registers): measured 245 vs 233 us per 128-filter layer at the Criteo
+    // shape (gpurun_out/r4c19 vs r4c17) — the chunk loop does not wait for its loads; one chunk of lookahead stays
+    constexpr bool LA2 = false;
+    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP, WV, CJ, LA2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP, WV, CJ, LA2>), dim3((unsigned)((M + BM - 1) / BM)), dim3(64 * WV), lds, st,
+                       x0, x0_bs, xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
     return launch_status("dt_cin_layer_bwd_bf16(dgrad)");
 }
 
@@ -1023,14 +1063,21 @@ static int cinb_bwd(const char* who, const float* x0, const float* xk, const flo
     cinb_pack<NP>(W, F0, Hk, L, nullptr, WN, st);
     const int64_t wn_part = cinb_nN(F0, Hk, L);
     const int jb = ceil_div(Hk, 32);
-    // 256-row blocks when the batch fills the chip with them and their tiles fit the LDS (F0 <= ~100)
-    const bool wide = cinb_wide((int64_t)B * D) &&
-                      (size_t)2 * 256 * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * (L <= 128 ? 8 : 16) + 8) * 2 <= 160 * 1024;
+    // 256-row blocks when the batch fills the chip with them and their tiles fit the LDS (whole i's per chunk need an even
+    // number of j blocks there)
+    const bool big = cinb_wide((int64_t)B * D);
 #define DT_DGRAD_B(LS, JBV)                                                                                          \
-    rc = wide ? launch_dgrad_b<LS, JBV, NP, 8>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, \
-                                               grad_x0, grad_xk, st)                                                 \
-              : launch_dgrad_b<LS, JBV, NP, 4>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, \
-                                               grad_x0, grad_xk, st)
+    do {                                                                                                             \
+        if constexpr (dgrad_roomy<LS, JBV>()) {                                                                      \
+            if (big && dgrad_lds<LS, JBV, NP, 8>(F0) <= 160 * 1024 && ceil_div(Hk, 32) % dgrad_cj<LS, JBV, 8>() == 0) { \
+                rc = launch_dgrad_b<LS, JBV, NP, 8>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, \
+                                                    D, grad_x0, grad_xk, st);                                        \
+                break;                                                                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        rc = launch_dgrad_b<LS, JBV, NP, 4>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, D, \
+                                            grad_x0, grad_xk, st);                                                   \
+    } while (0)
     if (L <= 128) {
         if (jb <= 1) DT_DGRAD_B(8, 1);
         else if (jb <= 2) DT_DGRAD_B(8, 2);

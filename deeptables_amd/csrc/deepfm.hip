@@ -2423,7 +2423,8 @@ static int tower_train_step(
     // gradients' last level), so that a caller whose row gradients leave through a collective (row-owned tables) can start
     // that collective behind the row-gradient launch and let E' run beside it
     const bool skip_finish = (phases & DT_STEP_SKIP_FINISH) != 0, finish_only = (phases & DT_STEP_FINISH_ONLY) != 0;
-    const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0;
+    const bool bf16_flag = (phases & DT_STEP_TOWER_BF16) != 0;       // plain bf16: the split kernel with the leading products only
+    const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0 || bf16_flag;
     const bool preelected = (phases & DT_STEP_PREELECTED) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
@@ -2570,20 +2571,18 @@ static int tower_train_step(
                                ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, nullptr);                     \
         }                                                                                                           \
         break;
+#define DT_CXL(N, LCV, ONEV)                                                                                        \
+    do {                                                                                                            \
+        hipFuncSetAttribute((const void*)k_tower_x3<N, LCV, ONEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
+        hipLaunchKernelGGL((k_tower_x3<N, LCV, ONEV>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm,     \
+                           ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,             \
+                           logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);          \
+    } while (0)
 #define DT_CX(N)                                                                                                    \
     case N: {                                                                                                       \
         const size_t ldsX = x3_lds_bytes(64 * N, dcn);                                                              \
-        if (dcn) {                                                                                                  \
-            hipFuncSetAttribute((const void*)k_tower_x3<N, kCrossMax>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
-            hipLaunchKernelGGL((k_tower_x3<N, kCrossMax>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, \
-                               ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
-                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);      \
-        } else {                                                                                                    \
-            hipFuncSetAttribute((const void*)k_tower_x3<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
-            hipLaunchKernelGGL((k_tower_x3<N>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm, ws + wl.lin, \
-                               ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,           \
-                               ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);                 \
-        }                                                                                                           \
+        if (dcn) { if (bf16_flag) DT_CXL(N, kCrossMax, true); else DT_CXL(N, kCrossMax, false); }                   \
+        else { if (bf16_flag) DT_CXL(N, 0, true); else DT_CXL(N, 0, false); }                                       \
     } break;
         if (x3) {        // the split-bf16 tower (tower_x3.h)
             switch (dm.CP >> 6) { DT_CX(1) DT_CX(2) DT_CX(3) DT_CX(4) DT_CX(5) DT_CX(6) DT_CX(7) DT_CX(8) }
@@ -2591,6 +2590,7 @@ static int tower_train_step(
             switch (dm.CP >> 6) { DT_C(1) DT_C(2) DT_C(3) DT_C(4) DT_C(5) DT_C(6) DT_C(7) DT_C(8) DT_C(9) }
         }
 #undef DT_CX
+#undef DT_CXL
 #undef DT_C
     }
     const Part3 pl3 = part3_layout(dm.CP, Lc, pipe ? 1 : 0);

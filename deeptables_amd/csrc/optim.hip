@@ -693,8 +693,9 @@ extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int
                                      const float* dense_g, float* dense_m, float* dense_v, int64_t dense_n, int advance,
                                      float lr, const int* seg_nseg, const int64_t* seg_row, const int* seg_off,
                                      const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
-                                     void* stream) {
+                                     int slot_stride, void* stream) {
     DT_REQUIRE(n_rows >= 0 && D > 0 && fields >= -2 && dense_n >= 0, "dt_adam_rows_step: bad sizes");
+    DT_REQUIRE(slot_stride == D || slot_stride == 2 * D, "dt_adam_rows_step_seg: slot_stride %d (D = %d or 2 D)", slot_stride, D);
     // fields == -2: as -1 (rows distinct) AND the rows with an entry in `rows` were already updated inside the train step
     // (dt_deepfm_train_step_adam): only the segments and the dense tail are left
     const int segments_only = fields == -2 ? 1 : 0;
@@ -725,9 +726,11 @@ extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int
         const int lpr = D / 4;
         DT_UNSUPPORTED(D % 4 || lpr > 64 || (lpr & (lpr - 1)), "dt_adam_rows_step_seg: segments need D = 4 * 2^k <= 256 (D=%d)", D);
     }
-    // slot layout: two separate [V, D] arrays, or ONE [V, 2, D] array with m and v of a row side by side (v == m + D):
-    // a row's m and v then share a 128-byte line and the update touches two random locations per row instead of three
-    const int sstride = (v == m + D) ? 2 * D : D;
+    // slot layout, stated by the caller: slot_stride = D: two separate [V, D] arrays; 2 D: ONE [V, 2, D] array with m and v of a
+    // row side by side (v = m + D) — a row's m and v then share a 128-byte line and the update touches two random locations
+    // per row instead of three
+    const int sstride = slot_stride;
+    DT_REQUIRE(sstride == D || v == m + D, "dt_adam_rows_step_seg: slot_stride 2 D needs v == m + D (interleaved slots)");
     unsigned long long* gslots = nullptr;
     int* mk = mark;
     if (fields == -1) {
@@ -780,5 +783,8 @@ extern "C" int dt_adam_rows_step(float* table, float* m, float* v, const int64_t
                                  float lr, void* stream) {
     return dt_adam_rows_step_seg(table, m, v, rows, values, n_rows, D, fields, slots, n_slots, mark, lr_t, beta1, beta2,
                                  eps, state, dense_p, dense_g, dense_m, dense_v, dense_n, advance, lr, nullptr, nullptr,
-                                 nullptr, nullptr, nullptr, 0, 0, stream);
+                                 nullptr, nullptr, nullptr, 0, 0,
+                                 (m && v == m + D) ? 2 * D : D /* this older entry point has no stride argument: v = m + D means
+                                                                  interleaved [V, 2, D] slots */,
+                                 stream);
 }

@@ -66,6 +66,11 @@ __device__ __forceinline__ void x3_ld8f(const float* p, float (&v)[8]) {
     for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
 }
 #define X3_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+// the lower-order products of a split operand pair: left out in plain-bf16 mode (template ONE, DT_STEP_TOWER_BF16)
+#define X3_LO(acc, a, b)        \
+    do {                        \
+        if constexpr (!ONE) X3_MFMA(acc, a, b); \
+    } while (0)
 
 // LDS plan (bytes), CP = 64 NCH:
 //   xreg  3 * 32 * (CP + 16) * 2      Xn tile as three bf16 parts (GEMM1); afterwards: xhat / dXn fp32 [32][CP + 4], then
@@ -84,7 +89,10 @@ __host__ __device__ constexpr bool x3_fits(int CP) {
            x3_lds_bytes(CP, true) <= 160 * 1024;
 }
 
-template <int NCH, int LC = 0>   // LC = kCrossMax: DCN (the Cross network's closed form of k_mlp_fwd3 on the same tile, see there)
+// ONE: the plain-bf16 mode of north_star ("1e-2 bf16", DT_STEP_TOWER_BF16): only the leading product of every operand pair
+// (the same layouts, the lower parts unused) — results within 1e-2 of the oracle instead of 1e-4; the Cross network's scalars
+// (logits up to +-160) keep their six products.
+template <int NCH, int LC = 0, bool ONE = false>   // LC = kCrossMax: DCN (the Cross network's closed form of k_mlp_fwd3 on the same tile, see there)
 __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, MlpParams p, X3Weights xw, DeepFmDims dm,
                                                   const float* __restrict__ lin, const float* __restrict__ fm,
                                                   const float* __restrict__ y, float* __restrict__ H1,
@@ -237,11 +245,11 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             }
             // the two row halves alternate: no MFMA waits for the one before it
             X3_MFMA(c1[0], a[0][0], b[0]); X3_MFMA(c1[1], a[1][0], b[0]);
-            X3_MFMA(c2[0], a[0][0], b[1]); X3_MFMA(c2[1], a[1][0], b[1]);
-            X3_MFMA(c3[0], a[0][0], b[2]); X3_MFMA(c3[1], a[1][0], b[2]);
-            X3_MFMA(c2[0], a[0][1], b[0]); X3_MFMA(c2[1], a[1][1], b[0]);
-            X3_MFMA(c3[0], a[0][1], b[1]); X3_MFMA(c3[1], a[1][1], b[1]);
-            X3_MFMA(c3[0], a[0][2], b[0]); X3_MFMA(c3[1], a[1][2], b[0]);
+            X3_LO(c2[0], a[0][0], b[1]); X3_LO(c2[1], a[1][0], b[1]);
+            X3_LO(c3[0], a[0][0], b[2]); X3_LO(c3[1], a[1][0], b[2]);
+            X3_LO(c2[0], a[0][1], b[0]); X3_LO(c2[1], a[1][1], b[0]);
+            X3_LO(c3[0], a[0][1], b[1]); X3_LO(c3[1], a[1][1], b[1]);
+            X3_LO(c3[0], a[0][2], b[0]); X3_LO(c3[1], a[1][2], b[0]);
         }
         if constexpr (NST < 4) {           // a GEMM1 too short to hide them in
 #pragma unroll
@@ -325,11 +333,11 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             x3_b8 a1, a2, a3;
             x3_split3(v, a1, a2, a3);
             X3_MFMA(c1, a1, w2q[g][0]);
-            X3_MFMA(c2, a1, w2q[g][1]);
-            X3_MFMA(c3, a1, w2q[g][2]);
-            X3_MFMA(c2, a2, w2q[g][0]);
-            X3_MFMA(c3, a2, w2q[g][1]);
-            X3_MFMA(c3, a3, w2q[g][0]);
+            X3_LO(c2, a1, w2q[g][1]);
+            X3_LO(c3, a1, w2q[g][2]);
+            X3_LO(c2, a2, w2q[g][0]);
+            X3_LO(c3, a2, w2q[g][1]);
+            X3_LO(c3, a3, w2q[g][0]);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -531,8 +539,8 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 x3_b8 ah, al;
                 x3_split2(v, ah, al);
                 X3_MFMA(dH[t], ah, w2r[g][0]);
-                X3_MFMA(dM[t], ah, w2r[g][1]);
-                X3_MFMA(dM[t], al, w2r[g][0]);
+                X3_LO(dM[t], ah, w2r[g][1]);
+                X3_LO(dM[t], al, w2r[g][0]);
             }
         if (tid < kH2) {
             prec[pl.db2 + tid] = cs[tid] + cs[2 * kH2 + tid];
@@ -624,8 +632,8 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 X3_MFMA(gH[0], ah[0][g], bW[buf][g][0]); X3_MFMA(gH[1], ah[1][g], bW[buf][g][0]);
-                X3_MFMA(gM[0], ah[0][g], bW[buf][g][1]); X3_MFMA(gM[1], ah[1][g], bW[buf][g][1]);
-                X3_MFMA(gM[0], al[0][g], bW[buf][g][0]); X3_MFMA(gM[1], al[1][g], bW[buf][g][0]);
+                X3_LO(gM[0], ah[0][g], bW[buf][g][1]); X3_LO(gM[1], ah[1][g], bW[buf][g][1]);
+                X3_LO(gM[0], al[0][g], bW[buf][g][0]); X3_LO(gM[1], al[1][g], bW[buf][g][0]);
             }
             if constexpr (LC > 0) {
                 // + sum_l coeff[r][l] Wc_l[col] (exact fp32 MFMA, K = 16 layer slots): A = the coefficient tile, B = the layer

@@ -54,14 +54,16 @@ def _tower_widths(dnn_params):
 def _tower_mfma_flag(dnn_params):
     """`dnn_params['mfma_dtype']` (or DT_AMD_TOWER_DTYPE): 'bf16x3' (default) = the tile kernel's four GEMMs on split-bf16
     matrix cores (csrc/tower_x3.h, DT_STEP_TOWER_X3: three bf16 parts = all 24 mantissa bits in the forward, two parts in the
-    backward, fp32 accumulate — measured at the exact kernels' parity bars), 'f32' = exact-fp32 MFMA
-    -> the `phases` bit of the fused step"""
+    backward, fp32 accumulate — measured at the exact kernels' parity bars), 'f32' = exact-fp32 MFMA,
+    'bf16' = plain bf16 operands (1e-2 of the oracle: an opt-in precision mode) -> the `phases` bit of the fused step"""
     mode = dnn_params.get('mfma_dtype') or os.environ.get('DT_AMD_TOWER_DTYPE', 'bf16x3')
     if mode in ('f32', 'fp32', 'float32'):
         return 0
     if mode == 'bf16x3':
         return _lib.DT_STEP_TOWER_X3
-    raise ValueError(f"dnn_params['mfma_dtype'] = {mode!r}: 'f32' or 'bf16x3'")
+    if mode in ('bf16', 'bfloat16'):         # north_star's "1e-2 bf16": one bf16 product per operand pair (opt-in)
+        return _lib.DT_STEP_TOWER_BF16
+    raise ValueError(f"dnn_params['mfma_dtype'] = {mode!r}: 'f32', 'bf16x3' or 'bf16'")
 
 
 def _mirror_in_flat(flat_params, accum, grad_views):

@@ -358,7 +358,8 @@ class KerasAdam:
             check(lib().dt_adam_rows_step_seg(ptr(table.data), ptr(s['m']), ptr(s['v']), ptr(rows), ptr(values), n,
                                               D, fields, ptr(slots), n_slots, ptr(mark), 0.0,
                                               self.b1, self.b2, self.eps, sp, ptr(tl[0]), ptr(tl[1]), ptr(tl[2]),
-                                              ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, *sg, st),
+                                              ptr(tl[3]), tl[4], 1 if is_last else 0, self.lr, *sg,
+                                              int(s['m'].stride(0)), st),
                   'dt_adam_rows_step_seg')
         if dense_after:
             hook()

@@ -255,7 +255,9 @@ int dt_adam_rows_step(float* table, float* m, float* v, const int64_t* rows, flo
  * regions of seg_cap slots: region e holds seg_nseg[e] segments (read on the device) at index s = e * seg_cap + i:
  * (seg_row[s], seg_off[s], seg_cnt[s]) with seg_list[seg_off .. +seg_cnt) naming the `values` rows to sum.  Their
  * entries of `rows` must be -1.  The waves of the same launch sum a segment's members and apply the update to its table
- * row: no lookup adds into a shared gradient row.                                                                   */
+ * row: no lookup adds into a shared gradient row.  slot_stride: floats between a row's m (and v) of consecutive table rows —
+ * D: m and v are two [V, D] arrays; 2 D: ONE [V, 2, D] array, v = m + D (a row's m and v in one 128-byte line).  Stated by
+ * the caller, as in dt_deepfm_train_step_adam (dt_adam_rows_step, without the argument, infers 2 D from v == m + D).   */
 /* dt_rows_compact — the "bucketed sparse embedding gradient" of the data-parallel exchange (replaces what
  * tf.distribute.MirroredStrategy all-gathers for an IndexedSlices gradient, deepmodel.py:88-103): a fused step's sparse
  * gradient (rows looked up once as entries of (rows, values), rows looked up several times as segments — dt_deepfm_train_step)
@@ -278,7 +280,7 @@ int dt_adam_rows_step_seg(float* table, float* m, float* v, const int64_t* rows,
                           float eps, void* state, float* dense_p, const float* dense_g, float* dense_m, float* dense_v,
                           int64_t dense_n, int advance, float lr, const int* seg_nseg, const int64_t* seg_row,
                           const int* seg_off, const int* seg_cnt, const int* seg_list, int seg_regions, int seg_cap,
-                          void* stream);
+                          int slot_stride, void* stream);
 
 /* BinaryCrossentropy on a sigmoid output, evaluated from the logits as Keras does in graph mode (deepmodel.py:326-328;
  * the `task_output` activation, deepmodel.py:436-457): loss [1] = mean(max(z,0) - z*y + log1p(exp(-|z|))) and
@@ -452,12 +454,15 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * row gradient is final when the call's launches are, so the collective that carries them to the row owners can start
  * there; the same call with phases | DT_STEP_FINISH_ONLY (same arguments) then issues only that last launch, which runs
  * beside the collective.  accum is complete after the second call.
- * phases | DT_STEP_TOWER_X3 (backward steps of dt_deepfm_train_step / _adam): the Dense tower's four GEMMs of the tile kernel
+ * phases | DT_STEP_TOWER_X3 (backward steps of dt_deepfm_train_step / dt_dcn_train_step / _adam): the Dense tower's four GEMMs of the tile kernel
  * (Dense128, Dense64, dH1 = dH2 W2^T, dXn = dH1 W1^T; deepnets.py:401-427) run on v_mfma_f32_16x16x32_bf16 with SPLIT
  * operands and fp32 accumulation (csrc/tower_x3.h): forward a = a1 + a2 + a3 (three bf16 parts = all 24 mantissa bits,
  * six products, the dropped terms 2^-24 of the product: fp32-class logits and relu decisions), backward a = a_hi + a_lo
  * (16 bits, three products, 2^-17 per product).  6/16 resp. 3/16 of the fp32-MFMA time.  Weights are split once per step
  * by the prep launch, activations while they are staged.
+ * phases | DT_STEP_TOWER_BF16 (north_star's "1e-2 bf16" mode for the tower; backward steps, DeepFM and DCN): the same kernel
+ * with ONE bf16 product per operand pair — plain bf16 operands, fp32 accumulation; logits and gradients within 1e-2 of the
+ * float64 oracle (of each tensor's largest entry) instead of 1e-4.  The Cross network's scalar recurrences keep six products.
  * phases | DT_STEP_PREELECTED: rows_out and dedupe_ws were filled for THIS idx by dt_deepfm_preelect — the step's ids-only
  * work (packed rows of the lookups, the election of the rows looked up several times) ran ahead of it, on another stream or at
  * an earlier point of a captured graph (deeptables_amd/compiled.py: the elections of steps 2..k of an execution run beside
@@ -467,6 +472,7 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
 #define DT_STEP_FINISH_ONLY 0x40
 #define DT_STEP_TOWER_X3 0x80
 #define DT_STEP_PREELECTED 0x100
+#define DT_STEP_TOWER_BF16 0x200
 int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset, const int32_t* vocab, int B, int F,
                        int64_t* rows_out, void* dedupe_ws, int64_t dedupe_slots, void* stream);
 int64_t dt_deepfm_dedupe_slots(int B, int F);

@@ -600,7 +600,7 @@ def test_fused_weighted_step_with_dense_dropout_matches_oracle(dev, net, task):
 
 
 @pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
-def test_fused_weighted_train_steps_equal_the_layer_by_layer_path(dev, net):
+def test_fused_weighted_train_steps_equal_the_layer_by_layer_path(dev, net, tower_mode):
     """six weighted TRAIN steps (in-step optimizer included) on the fused plan against a twin without a plan"""
     from deeptables_amd.models import deepnets
     F, Nd, D, B = 26, 13, 16, 700
@@ -621,8 +621,13 @@ def test_fused_weighted_train_steps_equal_the_layer_by_layer_path(dev, net):
         l2, _ = twin.train_step(ins_s, y_s.to(dev), wts)
         assert dm._step_used_plan and not twin._step_used_plan
         assert abs(float(l1) - float(l2)) < 2e-5, step
+    # Adam divides by sqrt(v): an entry whose gradient is ~0 moves by a good part of lr whichever way its last bits fall, and
+    # the members of a row segment are summed in the election's order (not the same from run to run).  Six steps of lr =
+    # 1e-3 on values of ~5e-2: 5e-4 of the largest entry is 0.4 % of the distance travelled; the split-bf16 backward (two
+    # parts, 2^-17 per product) is held to 3e-3 (seen: 1.7e-3 on one table entry, DCN)
+    tol = 5e-4 if tower_mode == 'f32' else 3e-3
     for (n1, p1), (_, p2) in zip(dm.model.named_parameters(), twin.model.named_parameters()):
-        assert rel(p1, p2) < 5e-4, n1
+        assert rel(p1, p2) < tol, n1
 
 
 @pytest.mark.parametrize('net,H1,H2', [('DeepFM', 100, 40), ('DCN', 32, 64)])

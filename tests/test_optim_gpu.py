@@ -192,8 +192,13 @@ def test_captured_step_replays_with_advancing_bias_correction(dev):
         body()                                      # warm-up (allocates state): step 1
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        body()                                      # capture only (not executed)
+    import gc
+    gc.disable()                                    # (no collection inside a stream capture: deeptables_amd/compiled.py)
+    try:
+        with torch.cuda.graph(graph):
+            body()                                  # capture only (not executed)
+    finally:
+        gc.enable()
     for _ in range(3):
         graph.replay()                              # steps 2, 3, 4
     torch.cuda.synchronize()

@@ -112,6 +112,37 @@ def test_x3_rows_in_step_equals_the_separate_optimizer_step(dev):
     assert headline.rows_in_step_ok(res), str(sorted(res.items()))
 
 
+# ---- the tower's plain-bf16 mode (north_star "1e-2 bf16"; dnn_params['mfma_dtype'] = 'bf16', DT_STEP_TOWER_BF16) -----------
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+def test_bf16_tower_headline_config_holds_the_bf16_bar(dev, net):
+    """B = 8192, 26 x 1 M rows: one bf16 product per operand pair in the tile kernel; logits within north_star's 1e-2 (of
+    max(1, max |logit|)), gradients by relative L2 error < 1e-1 (the relu decisions are taken on 8-bit inputs too:
+    oracle/headline.verdict, bf16='tower').  The gather stays bit-exact and the in-step optimizer agrees with the separate
+    optimizer step of the same mode."""
+    import bench
+    from oracle import headline
+    from deeptables_amd import _lib
+    from deeptables_amd.models import deepnets
+    params = dict(bench.MODEL_PARAMS.get(net) or {})
+    params['dnn_params'] = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': 'bf16'}
+    dm = bench.build_model(getattr(deepnets, net), dev, None, bench.D, params)
+    assert dm.fused_plan().tower_flag == _lib.DT_STEP_TOWER_BF16
+    bench.N_BATCHES, keep = 1, bench.N_BATCHES
+    try:
+        b = bench.make_batches(8192, dev, seed=1234, dist_kind='uniform')[0]
+        b2 = bench.make_batches(8192, dev, seed=4321, dist_kind='zipf')[0]
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, b)
+    print('bf16 tower', net, {k: res[k] for k in ('max_abs_logit_err', 'max_abs_logit', 'dense_grad_rel_err',
+                                                  'dense_grad_l2_rel_err', 'rows_grad_rel_err', 'rows_grad_l2_rel_err')})
+    good, rule = headline.verdict(res, bf16='tower')
+    assert good, (rule, sorted(res.items()))
+    assert res['max_abs_logit_err'] > 1e-6        # (the mode is really on: fp32-class arithmetic lands below this)
+    ri = headline.check_rows_in_step(dm, b2)
+    assert headline.rows_in_step_ok(ri), str(sorted(ri.items()))
+
+
 # ---- CIN on split-bf16 matrix cores (csrc/cin_bf16.hip with NP parts; cin_params['mfma_dtype'] = 'bf16x3') -------------------
 @pytest.mark.parametrize('B,F0,Hk,L,D,bias,act', [(5, 4, 4, 6, 3, False, 'relu'), (64, 26, 26, 128, 16, False, 'relu'),
                                                  (40, 26, 64, 128, 16, True, 'relu'), (9, 5, 7, 33, 8, True, 'linear'),
