@@ -20,6 +20,7 @@ optimizer launches]; with row-owned tables (`ShardedEmbeddingStrategy`) the step
 `graph_segments=True`.  k is 1 in both cases.
 """
 import ctypes
+import os
 
 import torch
 
@@ -211,14 +212,16 @@ class CompiledTrainLoop:
             for i in range(1, self.k):
                 plan._slot_buffers(self.B, i)
         g = torch.cuda.CUDAGraph()
-        # No cyclic garbage collection while the stream captures: a collection that starts in the middle of the capture runs
-        # the destructors of whatever it finds — an older CompiledTrainLoop's hipGraph, side streams, events of a model the
-        # caller dropped — and a destroy call of that kind inside a global-mode capture aborts the process (seen as an
-        # intermittent SIGABRT "Garbage-collecting" under pytest, where earlier tests' loops are such garbage).
-        # torch.cuda.graph collects once on entry; nothing may be collected after that until the capture has ended.
+        # Objects that exist when the capture starts are kept away from the cyclic collector until it ends (gc.freeze): a
+        # collection inside the capture otherwise runs the destructors of whatever old garbage it finds — an earlier
+        # CompiledTrainLoop's hipGraph, side streams, events of a model the caller dropped — and a destroy call of that kind
+        # inside a global-mode capture aborts the process (seen as an intermittent SIGABRT "Garbage-collecting" under pytest,
+        # where earlier tests' loops are such garbage).  The capture's own garbage (autograd nodes of the layer-by-layer path)
+        # is still collected as it appears: with the collector switched off altogether hipStreamEndCapture faulted on those
+        # graphs (gpurun_out/r4c22).
         import gc
-        gc_was_on = gc.isenabled()
-        gc.disable()
+        gc.collect()
+        gc.freeze()
         try:
             with torch.cuda.graph(g):
                 if not core_only:
@@ -235,8 +238,7 @@ class CompiledTrainLoop:
                         torch.cuda.current_stream().wait_stream(side)
                     self._body(i, core_only=core_only, preelected=pre and i >= 1)
         finally:
-            if gc_was_on:
-                gc.enable()
+            gc.unfreeze()
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
         # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
@@ -303,14 +305,13 @@ class CompiledTrainLoop:
                     torch.cuda.synchronize()
                     gopt = torch.cuda.CUDAGraph()
                     import gc
-                    gc_was_on = gc.isenabled()
-                    gc.disable()                       # (see capture(): no collection inside a stream capture)
+                    gc.collect()
+                    gc.freeze()                        # (see capture(): old garbage is not collected inside a stream capture)
                     try:
                         with torch.cuda.graph(gopt):
                             opt.step()
                     finally:
-                        if gc_was_on:
-                            gc.enable()
+                        gc.unfreeze()
                     self.opt_graph = gopt
                     gopt.replay()
                 else:

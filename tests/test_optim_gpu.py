@@ -193,12 +193,13 @@ def test_captured_step_replays_with_advancing_bias_correction(dev):
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
     import gc
-    gc.disable()                                    # (no collection inside a stream capture: deeptables_amd/compiled.py)
+    gc.collect()
+    gc.freeze()                                     # (old garbage stays uncollected inside a stream capture: compiled.py)
     try:
         with torch.cuda.graph(graph):
             body()                                  # capture only (not executed)
     finally:
-        gc.enable()
+        gc.unfreeze()
     for _ in range(3):
         graph.replay()                              # steps 2, 3, 4
     torch.cuda.synchronize()
