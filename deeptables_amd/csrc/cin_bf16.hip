@@ -245,6 +245,132 @@ __global__ __launch_bounds__(256, 2) void k_cin_fwd_bf16(
 // Block = 128 rows m x 128 filters; W_i (three parts x 128 filters x Hp k) goes through ONE LDS buffer per block — two blocks
 // per CU, the other block's MFMAs cover this block's refill.
 // ------------------------------------------------------------------------------------------
+// Four-wave form (128 rows per block, two blocks per CU), round 4's first version: small batches.
+template <bool kAnyAct, int KS /* ceil(Hk / 16) upper bound: 2, 4 or 8 */>
+__global__ __launch_bounds__(256, 2) void k_cin_fwd_noz4(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const __bf16* __restrict__ WT, int64_t wt_part, const float* __restrict__ bias, int act, int B, int F0, int Hk, int L,
+    int D, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NP = 3;
+    const int Hp = cb_hp(Hk), Kp = F0 * Hp;
+    constexpr int HPM = 16 * KS;                          // k per i the kernel walks (Hp <= HPM; beyond Hp: zero operands)
+    constexpr int WSb = HPM + 8;                          // bf16 row stride of a filter row: an odd number of 16-byte slots
+    const int64_t M = (int64_t)B * D;
+    float* x0T = lds;                                     // [F0][kBM]  x0[m][i], rows m contiguous
+    __bf16* wtb = reinterpret_cast<__bf16*>(x0T + F0 * kBM);       // [NP][kBN][WSb]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * kBN;
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t m = m0 + r;
+        x0T[i * kBM + r] = m < M ? x0[(m / D) * x0_bs + (int64_t)i * D + (m % D)] : 0.f;
+    }
+    // this lane's x_k row, split once: A operand of every GEMM (k = 16 ks + 8 s + e)
+    cb_b8 a[KS][NP];
+    {
+        const int64_t m = m0 + wave * 32 + c;
+        const bool ok = m < M;
+        const float* src = xk + (ok ? (m / D) * xk_bs + (m % D) : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 16 * ks + 8 * s + e;
+                v[e] = (ok && j < Hk) ? src[(int64_t)j * D] : 0.f;
+            }
+            cb_split<NP>(v, a[ks]);
+        }
+    }
+    // W_i loader: NP parts x 128 filters x (HPM / 8) 16-byte pieces
+    constexpr int kPieces = NP * kBN * (HPM / 8), kWR = (kPieces + 255) / 256;
+    cb_f4 wreg[kWR];
+    auto load_w = [&](int i) {
+#pragma unroll
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
+            wreg[u] = (e < kPieces && 8 * pc < Hp)
+                          ? *reinterpret_cast<const cb_f4*>(WT + part * wt_part + (int64_t)(n0 + n) * Kp + (int64_t)i * Hp + 8 * pc)
+                          : cb_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < kWR; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int pc = e % (HPM / 8), n = (e / (HPM / 8)) % kBN, part = e / ((HPM / 8) * kBN);
+            if (e < kPieces) *reinterpret_cast<cb_f4*>(wtb + (part * kBN + n) * WSb + 8 * pc) = wreg[u];
+        }
+    };
+    cb_f16v acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int nblocks_n = min(4, (L - n0 + 31) / 32);
+    load_w(0);
+    for (int i = 0; i < F0; ++i) {
+        __syncthreads();                 // every wave is done with W_{i-1} (and, first time, x0T is complete)
+        store_w();
+        __syncthreads();
+        if (i + 1 < F0) load_w(i + 1);   // in flight under this i's MFMAs
+        // x0[m][i] of the 16 accumulator rows of this lane: rows (r & 3) + 8 (r >> 2) + 4 s
+        cb_f4 xq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xq[g] = *reinterpret_cast<const cb_f4*>(x0T + i * kBM + wave * 32 + 8 * g + 4 * s);
+        const __bf16* wrow = wtb + c * WSb + 8 * s;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb >= nblocks_n) continue;
+            cb_f16v t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                cb_b8 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const cb_b8*>(wrow + (q * kBN + nb * 32) * WSb + 16 * ks);
+                cb_mma<NP>(t, a[ks], b);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] += xq[r >> 2][r & 3] * t[r];
+        }
+    }
+    // epilogue (as cin.hip): row = (r&3) + 8*(r>>2) + 4*s, col = c
+    const bool vec_ok = (D % 4 == 0);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nblocks_n) continue;
+        const int n = n0 + nb * 32 + c;
+        if (n >= L) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t mr = m0 + wave * 32 + 8 * g + 4 * s;
+            if (mr >= M) continue;
+            const int64_t b = mr / D;
+            const int dd = (int)(mr % D);
+            float ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = kAnyAct ? act_apply(acc[nb][g * 4 + r] + bv, act)
+                                : (act == DT_ACT_RELU ? fmaxf(acc[nb][g * 4 + r] + bv, 0.f) : acc[nb][g * 4 + r] + bv);
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(y + (b * L + n) * D + dd) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t mm = mr + r;
+                    if (mm < M) y[((mm / D) * L + n) * D + (mm % D)] = ov[r];
+                }
+            }
+        }
+    }
+}
+
+
 // WV = waves per block (32 rows m each).  WV = 8 (large batches): 256 rows per block — every block streams ALL of the filter's
 // parts from L2 (1.28 MB at the Criteo shape), so the 128-row blocks moved 1.3 GB per layer and ran at the L2's pace, not
 // the matrix cores'; twice the rows per block halve that stream.  One 512-thread block per CU then, so W_i is double
@@ -394,25 +520,143 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void k_cin_fwd_noz(
 // dgrad: grad_x0 (=), grad_xk (=): both OVERWRITTEN (one block owns a 128-row tile of m and all of its (i, j)).  T^T[(i, 32 j's), m] = sum_l W[(i,j), l] G[m, l] per chunk, contracted in the
 // lane that owns column m against xk / x0; grad_x0 is gathered in LDS and flushed once.
 // ------------------------------------------------------------------------------------------
+// Four-wave form (128 rows per block, two blocks per CU: small batches), as in round 3; the eight-wave form for large
+// batches follows.  (A version that kept BOTH in one template and staged W through registers two chunks ahead left the
+// four-wave form with one block per CU — 601 us instead of 345 — and the eight-wave form 16 % slower: gpurun_out/r04_*.)
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */>
+__global__ __launch_bounds__(256) void k_cin_dgrad_bf16_4(
+    const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
+    const __bf16* __restrict__ WN, int64_t wn_part, const float* __restrict__ y, const float* __restrict__ gy, int act,
+    int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int64_t M = (int64_t)B * D;
+    const int F0S = F0 | 1, Lq = cb_lq(L), WS = 16 * LSTEPS + 8;
+    float* x0T = lds;                    // [kBM][F0S]
+    float* g0T = x0T + kBM * F0S;        // [kBM][F0S] grad_x0 of the tile
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + kBM * F0S);   // [2][NP][32][WS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = lane >> 5, c = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * kBM;
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t mm = m0 + r;
+        x0T[r * F0S + i] = mm < M ? x0[(mm / D) * x0_bs + (int64_t)i * D + (mm % D)] : 0.f;
+        g0T[r * F0S + i] = 0.f;
+    }
+    const int row = wave * 32 + c;
+    const int64_t m = m0 + row;          // the column of T^T this lane owns
+    const bool mvalid = m < M;
+    const int64_t b = mvalid ? m / D : 0;
+    const int d = mvalid ? (int)(m % D) : 0;
+
+    // G[m][l] for l = 16 st + 8 s + e as the B operand, kept in registers for the whole tile
+    cb_b8 G[LSTEPS][NP];
+#pragma unroll
+    for (int st = 0; st < LSTEPS; ++st) {
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 16 * st + 8 * s + e;
+            float g = 0.f;
+            if (mvalid && l < L) {
+                const int64_t o = (b * L + l) * D + d;
+                g = gy[o] * act_grad_from_y(y[o], act);
+            }
+            gv[e] = g;
+        }
+        cb_split<NP>(gv, G[st]);
+    }
+    // xk values this lane needs: j = jb*32 + (r&3) + 8*(r>>2) + 4*s
+    float xkv[JB][16], gxk_acc[JB][16];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+            xkv[jb][r] = (mvalid && j < Hk) ? xk[b * xk_bs + (int64_t)j * D + d] : 0.f;
+            gxk_acc[jb][r] = 0.f;
+        }
+    const int njb = (Hk + 31) / 32;
+    const int nchunks = F0 * njb;
+    // W chunk (i, jb): 32 rows x Lq bf16, contiguous in WN
+    auto stage_w = [&](int chunk, int buf) {
+        const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
+        const int pieces = Lq / 8;                      // 16-byte pieces per row
+        for (int e = threadIdx.x; e < NP * 32 * pieces; e += 256) {
+            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
+            const int r = q / pieces, pc = q - r * pieces;
+            *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) =
+                *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
+        }
+    };
+    const int lsteps = Lq / 16;
+    stage_w(0, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const int i = chunk / njb, jb = chunk - i * njb;
+        if (chunk + 1 < nchunks) stage_w(chunk + 1, buf ^ 1);
+        const __bf16* wrow = wtl + (buf * NP * 32 + c) * WS + 8 * s;
+        cb_f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < LSTEPS; ++st)
+            if (st < lsteps) {
+                cb_b8 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * 32 * WS + 16 * st);
+                cb_mma<NP>(acc, a, G[st]);
+            }
+        // contract T^T[j, m] (16 j's in this lane) against xk and x0
+        const float x0v = x0T[row * F0S + i];
+        float p = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+            if (jj == jb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p += xkv[jj][r] * acc[r];
+                    gxk_acc[jj][r] += x0v * acc[r];
+                }
+            }
+        p += __shfl_xor(p, 32, 64);
+        if (s == 0) g0T[row * F0S + i] += p;  // unique owner of (m, i)
+        __syncthreads();
+    }
+    if (mvalid) {
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * s;
+                if (j < Hk) gxk[(b * Hk + j) * D + d] = gxk_acc[jb][r];
+            }
+    }
+    for (int e = threadIdx.x; e < kBM * F0; e += 256) {
+        const int i = e / kBM, r = e - i * kBM;
+        const int64_t mm = m0 + r;
+        if (mm < M) gx0[((mm / D) * F0 + i) * D + (mm % D)] = g0T[r * F0S + i];     // this block is the only writer of (m, i)
+    }
+}
+
+
 // WV = waves per block, 32 columns m each.  Every block streams ALL of W_N through LDS (852 KB at the Criteo shape with two
 // parts): 1024 blocks of 128 rows moved 870 MB per layer and the kernel ran at the L2's pace (345 us, 19 % of the matrix
-// rate); WV = 8 (large batches) halves the stream.  CJ = 32-row j blocks per LDS chunk (one barrier per chunk); a chunk's
-// pieces are requested TWO chunks ahead and wait in registers — a chunk's MFMAs (0.3 .. 0.6 us) are shorter than an L2 round
-// trip under load, with one chunk of lookahead every iteration waited for its loads.
-template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */, int WV,
-          int CJ, bool LA2 /* two chunks of lookahead (a second set of staging registers) */>
+// rate); WV = 8 (large batches) halves the stream.  The next chunk's pieces wait in registers while this chunk's MFMAs run.
+template <int LSTEPS /* ceil(L/16) upper bound: 8 or 16 */, int JB /* ceil(Hk/32) upper bound */, int NP /* bf16 parts */, int WV>
 __global__ __launch_bounds__(64 * WV) void k_cin_dgrad_bf16(
     const float* __restrict__ x0, int64_t x0_bs, const float* __restrict__ xk, int64_t xk_bs,
     const __bf16* __restrict__ WN, int64_t wn_part, const float* __restrict__ y, const float* __restrict__ gy, int act,
     int B, int F0, int Hk, int L, int D, float* __restrict__ gx0, float* __restrict__ gxk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BM = 32 * WV, NT = 64 * WV, CR = 32 * CJ;
+    constexpr int BM = 32 * WV, NT = 64 * WV;
     const int64_t M = (int64_t)B * D;
     const int F0S = F0 | 1, Lq = cb_lq(L);
     constexpr int WS = 16 * LSTEPS + 8;
     float* x0T = lds;                    // [BM][F0S]
     float* g0T = x0T + BM * F0S;         // [BM][F0S] grad_x0 of the tile
-    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + BM * F0S);    // [2][NP][CR][WS]
+    __bf16* wtl = reinterpret_cast<__bf16*>(g0T + BM * F0S);    // [2][NP][32][WS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = lane >> 5, c = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -455,90 +699,67 @@ __global__ __launch_bounds__(64 * WV) void k_cin_dgrad_bf16(
             xkv[jb][r] = (mvalid && j < Hk) ? xk[b * xk_bs + (int64_t)j * D + d] : 0.f;
             gxk_acc[jb][r] = 0.f;
         }
-    const int njb = (Hk + 31) / 32;      // (a multiple of CJ: the host's choice of CJ)
-    const int cpi = njb / CJ;            // chunks per i
-    const int nchunks = F0 * cpi;
-    // W chunk: NP parts x CR rows x Lq bf16, contiguous in WN (rows ordered (i, jb, r)); 16-byte pieces, kWP per thread
+    const int njb = (Hk + 31) / 32;
+    const int nchunks = F0 * njb;
+    // W chunk (i, jb): NP parts x 32 rows x Lq bf16, contiguous in WN; 16-byte pieces, kWP per thread
     const int pieces = Lq / 8;                          // per row
-    constexpr int kWP = (NP * CR * 2 * LSTEPS + NT - 1) / NT;
-    cb_f4 wregA[kWP], wregB[LA2 ? kWP : 1];
-    auto load_w = [&](int chunk, cb_f4 (&wreg)[kWP]) {
-        const __bf16* src = WN + (int64_t)chunk * CR * Lq;
+    constexpr int kWP = (NP * 32 * 2 * LSTEPS + NT - 1) / NT;
+    cb_f4 wreg[kWP];
+    auto load_w = [&](int chunk) {
+        const __bf16* src = WN + (int64_t)chunk * 32 * Lq;
 #pragma unroll
         for (int u = 0; u < kWP; ++u) {
             const int e = threadIdx.x + NT * u;
-            const int part = e / (CR * pieces), q = e - part * CR * pieces;
+            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
             const int r = q / pieces, pc = q - r * pieces;
-            if (e < NP * CR * pieces) wreg[u] = *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
+            if (e < NP * 32 * pieces) wreg[u] = *reinterpret_cast<const cb_f4*>(src + part * wn_part + r * Lq + 8 * pc);
         }
     };
-    auto store_w = [&](int buf, const cb_f4 (&wreg)[kWP]) {
+    auto store_w = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < kWP; ++u) {
             const int e = threadIdx.x + NT * u;
-            const int part = e / (CR * pieces), q = e - part * CR * pieces;
+            const int part = e / (32 * pieces), q = e - part * 32 * pieces;
             const int r = q / pieces, pc = q - r * pieces;
-            if (e < NP * CR * pieces) *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * CR + r) * WS + 8 * pc) = wreg[u];
+            if (e < NP * 32 * pieces) *reinterpret_cast<cb_f4*>(wtl + ((buf * NP + part) * 32 + r) * WS + 8 * pc) = wreg[u];
         }
     };
     const int lsteps = Lq / 16;
-    auto compute = [&](int chunk) {
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        const int i = chunk / cpi, jb0 = (chunk - i * cpi) * CJ;
+        const int i = chunk / njb, jb = chunk - i * njb;
+        if (chunk + 1 < nchunks) load_w(chunk + 1);
+        const __bf16* wrow = wtl + (buf * NP * 32 + c) * WS + 8 * s;
+        cb_f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < LSTEPS; ++st)
+            if (st < lsteps) {
+                cb_b8 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * 32 * WS + 16 * st);
+                cb_mma<NP>(acc, a, G[st]);
+            }
+        // contract T^T[j, m] (16 j's in this lane) against xk and x0
         const float x0v = x0T[row * F0S + i];
         float p = 0.f;
 #pragma unroll
-        for (int cj = 0; cj < CJ; ++cj) {
-            const __bf16* wrow = wtl + (buf * NP * CR + cj * 32 + c) * WS + 8 * s;
-            cb_f16v acc;
+        for (int jj = 0; jj < JB; ++jj)
+            if (jj == jb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < LSTEPS; ++st)
-                if (st < lsteps) {
-                    cb_b8 a[NP];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const cb_b8*>(wrow + q * CR * WS + 16 * st);
-                    cb_mma<NP>(acc, a, G[st]);
+                for (int r = 0; r < 16; ++r) {
+                    p += xkv[jj][r] * acc[r];
+                    gxk_acc[jj][r] += x0v * acc[r];
                 }
-            // contract T^T[j, m] (16 j's in this lane) against xk and x0
-#pragma unroll
-            for (int jj = 0; jj < JB; ++jj)
-                if (CJ == JB ? jj == cj : jj == jb0 + cj) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        p += xkv[jj][r] * acc[r];
-                        gxk_acc[jj][r] += x0v * acc[r];
-                    }
-                }
-        }
+            }
         p += __shfl_xor(p, 32, 64);
         if (s == 0) g0T[row * F0S + i] += p;  // unique owner of (m, i)
-    };
-    load_w(0, wregA);
-    store_w(0, wregA);
-    if constexpr (LA2) {
-        // one chunk: `wcur` holds chunk + 1 (requested an iteration ago), `wnext` receives chunk + 2
-        auto body = [&](int chunk, cb_f4 (&wcur)[kWP], cb_f4 (&wnext)[kWP]) {
-            if (chunk + 2 < nchunks) load_w(chunk + 2, wnext);
-            compute(chunk);
-            if (chunk + 1 < nchunks) store_w((chunk & 1) ^ 1, wcur);   // (that buffer's last readers, chunk - 1, are behind the previous barrier)
-            __syncthreads();
-        };
-        if (nchunks > 1) load_w(1, wregA);
+        if (chunk + 1 < nchunks) store_w(buf ^ 1);   // (its last readers, chunk - 1, are behind the previous barrier)
         __syncthreads();
-        for (int chunk = 0; chunk < nchunks; chunk += 2) {
-            body(chunk, wregA, wregB);
-            if (chunk + 1 < nchunks) body(chunk + 1, wregB, wregA);
-        }
-    } else {
-        __syncthreads();
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (chunk + 1 < nchunks) load_w(chunk + 1, wregA);
-            compute(chunk);
-            if (chunk + 1 < nchunks) store_w((chunk & 1) ^ 1, wregA);
-            __syncthreads();
-        }
     }
     if (mvalid) {
 #pragma unroll
@@ -977,17 +1198,22 @@ static int cinb_fwd(const char* who, const float* x0, const float* xk, const flo
         const size_t ldsn = (size_t)F0 * bm * sizeof(float) + (size_t)(wide ? 2 : 1) * 3 * kBN * (16 * ks + 8) * 2;
         const bool any = !(act == DT_ACT_LINEAR || act == DT_ACT_RELU);
         const dim3 gridn((unsigned)((M + bm - 1) / bm), (unsigned)ceil_div(L, kBN));
-#define DT_NOZ(ANY, KSV, WVV)                                                                                              \
+#define DT_NOZ(ANY, KSV)                                                                                                   \
     do {                                                                                                                   \
-        hipFuncSetAttribute((const void*)k_cin_fwd_noz<ANY, KSV, WVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn); \
-        hipLaunchKernelGGL((k_cin_fwd_noz<ANY, KSV, WVV>), gridn, dim3(64 * WVV), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT, \
-                           cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);                                             \
+        if (wide) {                                                                                                        \
+            hipFuncSetAttribute((const void*)k_cin_fwd_noz<ANY, KSV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn); \
+            hipLaunchKernelGGL((k_cin_fwd_noz<ANY, KSV, 8>), gridn, dim3(512), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT, \
+                               cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);                                         \
+        } else {                                                                                                           \
+            hipFuncSetAttribute((const void*)k_cin_fwd_noz4<ANY, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn); \
+            hipLaunchKernelGGL((k_cin_fwd_noz4<ANY, KSV>), gridn, dim3(256), ldsn, st, x0, x0_bstride, xk, xk_bstride, WT, \
+                               cinb_nT(F0, Hk, L), bias, act, B, F0, Hk, L, D, y);                                         \
+        }                                                                                                                  \
     } while (0)
         // linear / relu epilogues and Hk <= 64 only: with the libm activations or eight k steps of A parts in registers the
         // kernel spills (254 VGPRs at four steps already) — those shapes keep the Z-forming kernel
         if (ldsn <= 160 * 1024 && !any && ks <= 4) {
-            if (wide) { if (ks == 2) DT_NOZ(false, 2, 8); else DT_NOZ(false, 4, 8); }
-            else { if (ks == 2) DT_NOZ(false, 2, 4); else DT_NOZ(false, 4, 4); }
+            if (ks == 2) DT_NOZ(false, 2); else DT_NOZ(false, 4);
             return launch_status(who);
         }
 #undef DT_NOZ
@@ -1018,34 +1244,35 @@ extern "C" int dt_cin_layer_fwd_bf16x3(const float* x0, const float* xk, const f
     return cinb_fwd<3>("dt_cin_layer_fwd_bf16x3", x0, xk, W, bias, act, B, F0, Hk, L, D, x0_bstride, xk_bstride, y, ws, stream);
 }
 
-// CJ (j blocks per LDS chunk): 1 (whole i's, CJ = JB = 2, with two sets of staging registers: 70 VGPRs spilled).
-// The eight-wave form and the second set of staging registers exist for L <= 128, Hk <= 64 (the others spill with them).
-template <int LSTEPS, int JB, int WV>
-constexpr int dgrad_cj() { return 1; }
+// the eight-wave dgrad exists for L <= 128, Hk <= 64 (G of 256 filters or four j blocks of x_k values per lane spill at
+// two waves per SIMD)
 template <int LSTEPS, int JB>
 constexpr bool dgrad_roomy() { return LSTEPS == 8 && JB <= 2; }
-template <int LSTEPS, int JB, int NP, int WV>
+template <int LSTEPS, int NP, int WV>
 static size_t dgrad_lds(int F0) {
-    return (size_t)2 * 32 * WV * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * dgrad_cj<LSTEPS, JB, WV>() * (16 * LSTEPS + 8) * 2;
+    return (size_t)2 * 32 * WV * (F0 | 1) * sizeof(float) + (size_t)2 * NP * 32 * (16 * LSTEPS + 8) * 2;
 }
 template <int LSTEPS, int JB, int NP, int WV>
 static int launch_dgrad_b(const float* x0, int64_t x0_bs, const float* xk, int64_t xk_bs, const __bf16* WN, int64_t wn_part,
                           const float* y, const float* gy, int act, int B, int F0, int Hk, int L, int D, float* gx0, float* gxk,
                           hipStream_t st) {
-    constexpr int BM = 32 * WV, CJ = dgrad_cj<LSTEPS, JB, WV>();
-    const size_t lds = dgrad_lds<LSTEPS, JB, NP, WV>(F0);
+    constexpr int BM = 32 * WV;
+    const size_t lds = dgrad_lds<LSTEPS, NP, WV>(F0);
     if (lds > 160 * 1024) {
         set_error("dt_cin_layer_bwd_bf16: tiles need %zu B of LDS (> 160 KiB)", lds);
         return DT_ERR_UNSUPPORTED;
     }
     const int64_t M = (int64_t)B * D;
-    // two chunks of lookahead (a second set of staging registers): measured 245 vs 233 us per 128-filter layer at the Criteo
-    // shape (gpurun_out/r4c19 vs r4c17) — the chunk loop does not wait for its loads; one chunk of lookahead stays
-    constexpr bool LA2 = false;
-    hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP, WV, CJ, LA2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP, WV, CJ, LA2>), dim3((unsigned)((M + BM - 1) / BM)), dim3(64 * WV), lds, st,
-                       x0, x0_bs, xk, xk_bs, WN, wn_part, y, gy, act, B, F0, Hk, L, D, gx0, gxk);
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    if constexpr (WV == 8) {
+        hipFuncSetAttribute((const void*)k_cin_dgrad_bf16<LSTEPS, JB, NP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cin_dgrad_bf16<LSTEPS, JB, NP, 8>), grid, dim3(512), lds, st, x0, x0_bs, xk, xk_bs, WN, wn_part, y,
+                           gy, act, B, F0, Hk, L, D, gx0, gxk);
+    } else {
+        hipFuncSetAttribute((const void*)k_cin_dgrad_bf16_4<LSTEPS, JB, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cin_dgrad_bf16_4<LSTEPS, JB, NP>), grid, dim3(256), lds, st, x0, x0_bs, xk, xk_bs, WN, wn_part, y, gy,
+                           act, B, F0, Hk, L, D, gx0, gxk);
+    }
     return launch_status("dt_cin_layer_bwd_bf16(dgrad)");
 }
 
@@ -1063,13 +1290,12 @@ static int cinb_bwd(const char* who, const float* x0, const float* xk, const flo
     cinb_pack<NP>(W, F0, Hk, L, nullptr, WN, st);
     const int64_t wn_part = cinb_nN(F0, Hk, L);
     const int jb = ceil_div(Hk, 32);
-    // 256-row blocks when the batch fills the chip with them and their tiles fit the LDS (whole i's per chunk need an even
-    // number of j blocks there)
+    // 256-row blocks when the batch fills the chip with them and their tiles fit the LDS
     const bool big = cinb_wide((int64_t)B * D);
 #define DT_DGRAD_B(LS, JBV)                                                                                          \
     do {                                                                                                             \
         if constexpr (dgrad_roomy<LS, JBV>()) {                                                                      \
-            if (big && dgrad_lds<LS, JBV, NP, 8>(F0) <= 160 * 1024 && ceil_div(Hk, 32) % dgrad_cj<LS, JBV, 8>() == 0) { \
+            if (big && dgrad_lds<LS, NP, 8>(F0) <= 160 * 1024) {                                                     \
                 rc = launch_dgrad_b<LS, JBV, NP, 8>(x0, x0_bstride, xk, xk_bstride, WN, wn_part, y, grad_y, act, B, F0, Hk, L, \
                                                     D, grad_x0, grad_xk, st);                                        \
                 break;                                                                                               \

@@ -15,6 +15,9 @@ python bench.py > ${O}_line_deepfm.json 2> ${O}_line_deepfm.err
 python bench.py --dist zipf --no-cpu-baseline > ${O}_line_zipf.json 2> ${O}_line_zipf.err
 python bench.py --tower f32 --no-cpu-baseline --no-parity > ${O}_line_deepfm_f32tower.json 2> ${O}_line_deepfm_f32tower.err
 python bench.py --model DCN --no-cpu-baseline > ${O}_line_dcn.json 2> ${O}_line_dcn.err
+python bench.py --model DCN --tower f32 --no-cpu-baseline --no-parity > ${O}_line_dcn_f32tower.json 2> ${O}_line_dcn_f32tower.err
+python bench.py --tower bf16 --no-cpu-baseline > ${O}_line_deepfm_bf16tower.json 2> ${O}_line_deepfm_bf16tower.err
+python bench.py --model DCN --tower bf16 --no-cpu-baseline > ${O}_line_dcn_bf16tower.json 2> ${O}_line_dcn_bf16tower.err
 python bench.py --model DCN --force-dp --no-cpu-baseline --no-parity > ${O}_line_dcn_dp_w1.json 2> ${O}_line_dcn_dp_w1.err
 python bench.py --model DCN --force-dp --dist zipf --no-cpu-baseline --no-parity > ${O}_line_dcn_dp_w1_zipf.json 2> ${O}_line_dcn_dp_w1_zipf.err
 python bench.py --force-dp --no-cpu-baseline --no-parity > ${O}_line_dp_w1.json 2> ${O}_line_dp_w1.err
@@ -27,11 +30,12 @@ bash tools_prof.sh r04_deepfm --steps 100 --warmup 10 --no-parity > ${O}_stats_d
 bash tools_prof.sh r04_deepfm_zipf --steps 100 --warmup 10 --no-parity --dist zipf > ${O}_stats_deepfm_zipf.txt 2>&1
 bash tools_prof.sh r04_dcn --model DCN --steps 100 --warmup 10 --no-parity > ${O}_stats_dcn.txt 2>&1
 bash tools_prof.sh r04_xdeepfm_x3 --model xDeepFM --steps 20 --warmup 5 --no-parity > ${O}_stats_xdeepfm_x3.txt 2>&1
+DT_CIN_WIDE=0 DT_CIN_WGRAD_WIDE=0 bash tools_prof.sh r04_xdeepfm_x3_narrow --model xDeepFM --steps 20 --warmup 5 --no-parity > ${O}_stats_xdeepfm_x3_narrow.txt 2>&1
 bash tools_prof.sh r04_autoint --model AutoInt --steps 50 --warmup 10 --no-parity > ${O}_stats_autoint.txt 2>&1
 ROWS=1 DT_DEEPFM_STAMPS=1 timeout 200 python tools/phase_times.py > ${O}_deepfm_phase_stamps.txt 2>&1
 bash tools_pmc.sh r04_pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 20 --warmup 5 --no-parity > ${O}_pmc_mfma.txt 2>&1
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6 > ${O}_tests.txt
-for f in driver deepfm zipf deepfm_f32tower dcn dcn_dp_w1 dcn_dp_w1_zipf dp_w1 sharded_w1 xdeepfm xdeepfm_f32 xdeepfm_bf16 autoint; do grep "^{" ${O}_line_$f.json | python -c "
+for f in driver deepfm zipf deepfm_f32tower dcn dcn_f32tower deepfm_bf16tower dcn_bf16tower dcn_dp_w1 dcn_dp_w1_zipf dp_w1 sharded_w1 xdeepfm xdeepfm_f32 xdeepfm_bf16 autoint; do grep "^{" ${O}_line_$f.json | python -c "
 import sys,json
 j=json.loads(sys.stdin.read()); print('$f', round(j['value']/1e6,3), 'M rows/s', round(j['ms_per_step']*1e3,1), 'us', 'median', round(j['step_us']['median'],1), 'frac', round(j['roofline']['frac'],4), 'parity', (j.get('parity') or {}).get('ok'), j.get('phases'), j.get('fit_rows_per_s'), (j.get('other_layout') or {}).get('rows_per_s'))" || tail -3 ${O}_line_$f.err; done
 head -8 ${O}_stats_deepfm.txt; tail -3 ${O}_tests.txt; grep -A3 "k_tower_x3\|k_wgrad_rows" ${O}_pmc_mfma.txt | head -12
