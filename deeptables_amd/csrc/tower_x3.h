@@ -151,6 +151,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     const float bias1 = p.b1[16 * wave + n16];
     const float b2v = p.b2[16 * nt2 + n16], w3v = p.w3[16 * nt2 + n16];
     float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f, swv = 1.f;
+    const float invB = 1.0f / (float)dm.B;                         // (formed here: off the logits phase's dependent chain)
     if (wave == 0) {
         wov = p.wo[0];
         bov = p.bo ? p.bo[0] : 0.f;
@@ -431,11 +432,18 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             if (dc.mse) {                                // regression task: 'mse' on the linear task_output
                 const float df = lg - yv;
                 loss = df * df;
-                dl = 2.0f * df / (float)dm.B;
+                dl = 2.0f * df * invB;
             } else {
-                const float pr = 1.0f / (1.0f + expf(-lg));
-                loss = fmaxf(lg, 0.f) - lg * yv + log1pf(expf(-fabsf(lg)));
-                dl = (pr - yv) / (float)dm.B;
+                // The seven other waves of the block wait at the barrier below for this chain (6.6 K of the tile's 50 K cycles
+                // with libm's expf / log1pf / IEEE divisions: profiles/r04_deepfm_phase_stamps.txt), so it runs on the
+                // hardware transcendentals: e = exp(-|lg|) <= 1 (v_exp_f32), sigmoid = 1 / (1 + e) or e / (1 + e) (v_rcp_f32),
+                // log1p(e) = log(1 + e) (v_log_f32; absolute error <= 6e-8: 1 + e is at least 1).  ~1 ulp each: 3e-7 of
+                // the largest dlogit, against the 2e-4 gradient bar.
+                const float e = __expf(-fabsf(lg));
+                const float r = __frcp_rn(1.0f + e);
+                const float pr = lg >= 0.f ? r : e * r;
+                loss = fmaxf(lg, 0.f) - lg * yv + __logf(1.0f + e);
+                dl = (pr - yv) * invB;
             }
             loss *= swv;
             dl *= swv;
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         if (s == 1) { loss = 0.f; dl = 0.f; }
         float aw = dl * zz, ab = dl;                     // d task_output kernel / bias
         loss = wave_sum(loss); aw = wave_sum(aw); ab = wave_sum(ab);
-        if (lane == 0) { prec[pl.loss] = loss / (float)dm.B; prec[pl.dwo] = aw; prec[pl.dbo] = ab; }
+        if (lane == 0) { prec[pl.loss] = loss * invB; prec[pl.dwo] = aw; prec[pl.dbo] = ab; }
     }
     lds_barrier();
     DT_STAMP(stamps, 5);
