@@ -354,3 +354,66 @@ def test_unit_gradient_is_recognised_by_storage_not_by_value():
     assert training._is_unit_grad(u)
     assert not training._is_unit_grad(torch.ones(()))
     assert not training._is_unit_grad(torch.ones(1))
+
+
+def test_header_constants_equal_the_binding_s():
+    """every `#define DT_*` flag / size of include/dt_hip.h that deeptables_amd/_lib.py mirrors has the same value there"""
+    import re
+    from deeptables_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'dt_hip.h')).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r'^#define (DT_[A-Z0-9_]+) (0x[0-9a-fA-F]+|\d+)\s*$', text, re.M)}
+    assert {'DT_STEP_TOWER_X3', 'DT_STEP_TOWER_BF16', 'DT_STEP_PREELECTED', 'DT_FEED_CURSOR_WORDS'} <= set(defs)
+    mirrored = [n for n in defs if hasattr(_lib, n)]
+    assert len(mirrored) >= 6, mirrored
+    for n in mirrored:
+        assert getattr(_lib, n) == defs[n], n
+    # the step's phase bits do not overlap
+    bits = [defs[n] for n in defs if n.startswith('DT_STEP_')]
+    assert len(bits) == len(set(bits)) and all(b & (b - 1) == 0 for b in bits)
+
+
+def test_tower_precision_modes_map_to_the_step_s_phase_bits(monkeypatch):
+    """dnn_params['mfma_dtype'] / DT_AMD_TOWER_DTYPE -> fused._tower_mfma_flag: split-bf16 is the default, exact fp32 and
+    plain bf16 are options, anything else is an error (no silent fallback to another precision)"""
+    from deeptables_amd import _lib, fused
+    monkeypatch.delenv('DT_AMD_TOWER_DTYPE', raising=False)
+    assert fused._tower_mfma_flag({}) == _lib.DT_STEP_TOWER_X3
+    assert fused._tower_mfma_flag({'mfma_dtype': 'f32'}) == 0
+    assert fused._tower_mfma_flag({'mfma_dtype': 'bf16'}) == _lib.DT_STEP_TOWER_BF16
+    monkeypatch.setenv('DT_AMD_TOWER_DTYPE', 'f32')
+    assert fused._tower_mfma_flag({}) == 0
+    assert fused._tower_mfma_flag({'mfma_dtype': 'bf16x3'}) == _lib.DT_STEP_TOWER_X3        # the config wins over the env
+    with pytest.raises(ValueError):
+        fused._tower_mfma_flag({'mfma_dtype': 'fp8'})
+
+
+def test_parity_verdict_of_the_bf16_tower_mode():
+    """oracle/headline.verdict(bf16='tower'): the figures `bench.py --tower bf16` measured (profiles/r04_bench_lines.jsonl)
+    pass the tower mode's bars (logits 1e-2, gradient L2 1e-1), fail the bf16 CIN mode's (L2 2e-2) and the fp32 ones"""
+    from oracle import headline
+    res = {'gather_bit_exact': True, 'rows_identical': True, 'max_abs_logit_err': 0.00882, 'max_abs_logit': 3.945,
+           'dense_grad_rel_err': 0.01706, 'dense_grad_l2_rel_err': 0.03836, 'rows_grad_rel_err': 0.2346,
+           'rows_grad_l2_rel_err': 0.06196, 'relu_units_near_kink': 2, 'relu_units': 1572864}
+    assert headline.verdict(res, bf16='tower')[0] is True
+    assert headline.verdict(res, bf16=True)[0] is False
+    assert headline.verdict(res)[0] is False
+    assert headline.verdict(dict(res, max_abs_logit_err=0.05), bf16='tower')[0] is False
+    assert headline.verdict(dict(res, rows_grad_l2_rel_err=0.2), bf16='tower')[0] is False
+
+
+def test_steps_per_execution_policy():
+    """compiled.resolve_steps_per_execution: 'auto' compiles only graphs with a whole-step plan on a resident device feed
+    with enough steps per epoch; explicit values are clamped to the epoch; 0 / 1 mean eager"""
+    import types
+    from deeptables_amd import compiled
+    feed = types.SimpleNamespace(resident=True, device=types.SimpleNamespace(type='cuda'), weighted=False)
+    host_feed = types.SimpleNamespace(resident=False, device=types.SimpleNamespace(type='cpu'), weighted=False)
+    plan = types.SimpleNamespace(takes_sample_weight=True)
+    dm = types.SimpleNamespace(config=types.SimpleNamespace(distribute_strategy=None), fused_plan=lambda: plan)
+    no_plan = types.SimpleNamespace(config=types.SimpleNamespace(distribute_strategy=None), fused_plan=lambda: None)
+    r = compiled.resolve_steps_per_execution
+    assert r(dm, 'auto', feed, 8192, 50) == 10 and r(dm, 'auto', feed, 8192, 12) == 5 and r(dm, 'auto', feed, 8192, 3) == 1
+    assert r(no_plan, 'auto', feed, 8192, 50) == 1          # layer-by-layer graphs: on request only
+    assert r(no_plan, 4, feed, 8192, 50) == 4 and r(dm, 100, feed, 8192, 23) == 23
+    assert r(dm, 1, feed, 8192, 50) == 1 and r(dm, 0, feed, 8192, 50) == 1
+    assert r(dm, 'auto', host_feed, 8192, 50) == 1 and r(dm, 10, host_feed, 8192, 50) == 1
