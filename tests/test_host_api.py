@@ -417,3 +417,39 @@ def test_steps_per_execution_policy():
     assert r(no_plan, 4, feed, 8192, 50) == 4 and r(dm, 100, feed, 8192, 23) == 23
     assert r(dm, 1, feed, 8192, 50) == 1 and r(dm, 0, feed, 8192, 50) == 1
     assert r(dm, 'auto', host_feed, 8192, 50) == 1 and r(dm, 10, host_feed, 8192, 50) == 1
+
+
+def test_no_undefined_names_in_the_host_code():
+    """Most of the host code only runs on a GPU box; a name that is never bound anywhere in its module (a missing import —
+    round 4 shipped one to the GPU in compiled.py) is caught here, on the CPU, by walking the syntax trees"""
+    import ast
+    import builtins
+    import glob
+    files = glob.glob(os.path.join(ROOT, 'deeptables_amd', '**', '*.py'), recursive=True) + \
+        [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')] + glob.glob(os.path.join(ROOT, 'oracle', '*.py'))
+    known = set(dir(builtins)) | {'__file__', '__name__', '__doc__'}
+    bad = []
+    for f in files:
+        tree = ast.parse(open(f).read())
+        bound = set()
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                bound.update((a.asname or a.name).split('.')[0] for a in node.names)
+            elif isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                if not isinstance(node, ast.Lambda):
+                    bound.add(node.name)
+                a = node.args
+                bound.update(x.arg for x in a.args + a.kwonlyargs + a.posonlyargs)
+                bound.update(x.arg for x in (a.vararg, a.kwarg) if x is not None)
+            elif isinstance(node, ast.ClassDef):
+                bound.add(node.name)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                bound.add(node.id)
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                bound.add(node.name)
+            elif isinstance(node, (ast.Global, ast.Nonlocal)):
+                bound.update(node.names)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in bound and node.id not in known:
+                bad.append((os.path.relpath(f, ROOT), node.lineno, node.id))
+    assert not bad, bad
