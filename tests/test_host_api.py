@@ -453,3 +453,29 @@ def test_no_undefined_names_in_the_host_code():
             if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in bound and node.id not in known:
                 bad.append((os.path.relpath(f, ROOT), node.lineno, node.id))
     assert not bad, bad
+
+
+def test_ctypes_signatures_follow_the_header_prototypes():
+    """every prototype of include/dt_hip.h against deeptables_amd/_lib.SIGNATURES: the same number of parameters and the same
+    kind (pointer / int / int64 / float) in every position — an ABI drift (a parameter added on one side only) shows up
+    here, on the CPU, instead of as a fault on the GPU box"""
+    import re
+    from deeptables_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'dt_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', '', text)
+    protos = re.findall(r'\b(dt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text)
+    assert len(protos) == len(_lib.SIGNATURES)
+
+    def kind(decl):
+        if '*' in decl:
+            return 'ptr'
+        words = decl.replace('const', ' ').split()
+        base = ' '.join(words[:-1]) if len(words) > 1 else words[0]
+        return {'int': 'int', 'unsigned': 'int', 'int32_t': 'int', 'int64_t': 'i64', 'float': 'f32'}[base]
+
+    of_ctype = {ctypes.c_void_p: 'ptr', ctypes.c_char_p: 'ptr', ctypes.c_int: 'int', ctypes.c_uint: 'int',
+                ctypes.c_int64: 'i64', ctypes.c_float: 'f32'}
+    for name, params in protos:
+        decls = [p.strip() for p in params.split(',') if p.strip() and p.strip() != 'void']
+        assert [kind(d) for d in decls] == [of_ctype[a] for a in _lib.SIGNATURES[name][1]], name
