@@ -527,7 +527,7 @@ def verdict(res, grad_tol=2e-4, bf16=False):
                   res['max_abs_logit_err'] < 1e-2 * max(1.0, res['max_abs_logit']))
         if bf16 == 'tower':
             # the Dense tower on plain bf16 operands (dnn_params['mfma_dtype'] = 'bf16'): the relu decisions of its 192 units per
-            # row are taken on 8-bit inputs as well, so about one unit in a hundred lands on the other side of its kink and
+            # row are taken on 8-bit inputs as well, so ~0.07 % of the units (tests/test_split_bf16_arithmetic.py) land on the other side of their kink and
             # a row's gradient moves by whole terms: relative L2 error < 1e-1, every entry within 5e-1 of its tensor's
             # largest (measured at the Criteo shape: DeepFM 3.8e-2 / 6.2e-2 dense / rows L2, largest entry 0.23)
             loose = (res['dense_grad_l2_rel_err'] < 1e-1 and res['rows_grad_l2_rel_err'] < 1e-1 and
