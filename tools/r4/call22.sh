@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 4, call 22: where bench.py's layer-by-layer models fault (python -X faulthandler) and which change it follows
+# (DT_AMD_CAPTURE_GC=1 left the cyclic collector ON during captures in the tree of that moment — a bisect switch that is gone:
+#  the captures now freeze the old objects instead, deeptables_amd/compiled.py)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4c22
 O=gpurun_out/r4c22
