@@ -268,6 +268,10 @@ def parity_leg(args, device):
     out['tolerance'] = ('gather bit-exact; logits 1e-4 (north_star; 1e-2 in bf16 mode) of max(1, max |logit|): a 6-layer Cross '
                         'network puts logits far above 1; gradients: ' + ' / '.join(sorted(rules)) + ' (oracle/headline.verdict); '
                         'Adam 1e-3 of the step')
+    # what the optimizer figures above are measured against: the oracle's Adam is the row-sparse ("lazy") restatement the
+    # product implements for tables beyond 4 M floats; the reference's Keras Adam densifies the IndexedSlices gradient, so
+    # there every row's m / v decay at every step (DESIGN.md "Known deviations")
+    out['adam_semantics'] = 'row-sparse'
     out['ok'] = bool(ok)
     del dm
     torch.cuda.empty_cache()
@@ -365,6 +369,53 @@ def cpu_baseline(dm, batches, batch, sample_steps=150, max_threads=32):
                       f'{dt:.1f}s)'}
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv=None):
+    """`--gpus N` is a promise about the run, not a label (the reference's multi-GPU script sets the global batch to
+    n_gpus x the per-GPU batch and lets MirroredStrategy place one replica per device: deeptables/tests/models/run_dt.py:35-44):
+      * N > 1 without a launcher around this process (no WORLD_SIZE): re-exec under `python -m torch.distributed.run
+        --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU, and exit with its status;
+      * under a launcher: WORLD_SIZE must equal N, and N devices must be visible — anything else exits non-zero instead of
+        printing an N = 1 number labelled N.
+    DT_BENCH_SPAWN_PROBE=1 (tests/test_host_logic.py, no GPU): every rank joins a gloo group, rank 0 prints
+    {"spawned_ranks": <all-reduced count>} and the process exits before anything touches a device.
+    -> the world size this process runs in"""
+    probe = os.environ.get('DT_BENCH_SPAWN_PROBE') == '1'
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus <= 1:
+            return 1
+        if not probe and torch.cuda.device_count() < args.gpus:
+            sys.exit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} device(s) visible')
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + \
+              list(sys.argv[1:] if argv is None else argv)
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this host driver (RCCL needs it)
+        sys.exit(subprocess.call(cmd, env=env))
+    world = int(os.environ['WORLD_SIZE'])
+    if world != args.gpus:
+        sys.exit(f'bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: the two must agree')
+    if probe:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({'spawned_ranks': int(t.item()), 'world_size': dist.get_world_size()}))
+        dist.destroy_process_group()
+        sys.exit(0)
+    if torch.cuda.device_count() < (world if world > 1 else 1):
+        sys.exit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} device(s) visible')
+    return world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -400,7 +451,7 @@ def main():
     ap.add_argument('--force-sharded', action='store_true', help='N=1: run the sharded-table step anyway (eager)')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    world = launch_ranks(args)
     tables_auto = args.tables == 'auto'
     if args.tables == 'auto':
         args.tables = 'sharded' if (args.model == 'DeepFM' and not args.force_dp) else 'replicated'
@@ -426,6 +477,9 @@ def main():
         torch.cuda.set_device(device)
         rank = 0
     import torch.distributed as dist
+    rccl_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if rccl_ranks != world:
+        sys.exit(f'bench.py --gpus {args.gpus}: the process group holds {rccl_ranks} rank(s)')
 
     def barrier():
         if world > 1:
@@ -537,6 +591,7 @@ def main():
                                    f', Criteo-shaped synthetic: {F} cat x {VOCAB} vocab, '
                                    f'{ND} dense, embed_dim {dim}, batch {args.batch}/GPU, ids {args.dist}',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
+                       'rccl_ranks': rccl_ranks,
                        'hipgraph': loop.graph is not None, 'steps_per_graph_replay': spg,
                        'timed_object': 'deeptables_amd.compiled.CompiledTrainLoop (DeepModel.fit steps_per_execution)',
                        'graph_uploaded_before_first_replay': bool(loop.uploaded),
@@ -555,6 +610,12 @@ def main():
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
             'step_us': step_stats,
         }
+        # the arithmetic the timed path computes in: "f32" alone would hide the split-bf16 operand formats
+        tflag = getattr(dm.fused_plan(), 'tower_flag', 0)
+        if tflag == 0x80:
+            result['dtype'] = 'f32 (split-bf16: 24-bit fwd / 16-bit bwd)'
+        elif tflag == 0x200:
+            result['dtype'] = 'bf16 (tower GEMM operands, fp32 accumulate); f32 elsewhere'
         fpr = mfma_flops_per_row(args.model, dim)
         if fpr is not None:      # CIN / attention graphs: the matrix cores bound the step, not HBM
             cin_mode = (MODEL_PARAMS.get('xDeepFM', {}).get('cin_params', {}).get('mfma_dtype') or
@@ -577,6 +638,8 @@ def main():
                                             'contractions, fwd + dgrad + wgrad'}
             if bf16:
                 result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
+            elif x3:
+                result['dtype'] = 'f32 (split-bf16 CIN: 24-bit fwd / 16-bit bwd)'
 
         result['first_replay_us'] = loop.first_replay_us()
         if other is not None:

@@ -35,8 +35,30 @@ def _hip_graph_upload(graph):
     is unavailable."""
     try:
         handle = graph.raw_cuda_graph_exec()
-        return lib().dt_graph_upload(ctypes.c_void_p(int(handle)), stream_ptr()) == 0
-    except Exception:
+    except (AttributeError, RuntimeError):      # a torch build without the accessor / a graph that is not instantiated
+        return False
+    return lib().dt_graph_upload(ctypes.c_void_p(int(handle)), stream_ptr()) == 0
+
+
+class _old_garbage_frozen:
+    """Objects that exist when a stream capture starts are kept away from the cyclic collector until it ends (gc.freeze): a
+    collection inside the capture otherwise runs the destructors of whatever old garbage it finds — an earlier loop's
+    hipGraph, side streams, events of a model the caller dropped — and a destroy call of that kind inside a global-mode
+    capture aborts the process.  The capture's own garbage is still collected as it appears.  An application that froze
+    objects itself (gc.freeze() at start-up) gets its permanent generation back: unfreeze() empties it, so it is re-frozen."""
+
+    def __enter__(self):
+        import gc
+        self.app_frozen = gc.get_freeze_count() > 0
+        gc.collect()
+        gc.freeze()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        gc.unfreeze()
+        if self.app_frozen:
+            gc.freeze()
         return False
 
 
@@ -54,6 +76,7 @@ class CompiledTrainLoop:
         if not feed.resident:
             raise ValueError('CompiledTrainLoop needs a device-resident feed (training.TableBatches(resident=True))')
         self.dm, self.feed = dm, feed
+        self._owner = None                # set by capture(): (model, optimizer, fused plan) the graph holds pointers into
         self.B = int(batch_size)
         self.with_optimizer = with_optimizer
         self.use_graph = use_graph
@@ -78,6 +101,9 @@ class CompiledTrainLoop:
         self.graph = None
         self.opt_graph = None       # data parallel: the optimizer launches, captured after the gather buffers exist
         self._dp_steps = 0
+        self._opt_graph_sig = None       # addresses / shapes of the exchanged gradients the optimizer graph was captured on
+        self._last_exchange_sig = None
+        self._opt_graph_refused = False
         self._sparse_refs = None
         self.logits = None          # [k, B, outputs] static: step i's logits
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
@@ -95,6 +121,12 @@ class CompiledTrainLoop:
             arr = ctypes.c_void_p * nb
             self._gather_args = (arr(*[t.data_ptr() for t in srcs]), arr(*[t.data_ptr() for t in dsts]),
                                  (ctypes.c_int * nb)(*[t.element_size() * (t.numel() // t.shape[0]) for t in srcs]), nb)
+
+    def owned_by(self, dm):
+        """True while `dm` still holds the model, optimizer and fused plan this loop (and its captured graph) was built on —
+        `DeepModel.fit` rebuilds the loop otherwise (a rebuilt optimizer / plan has new buffers; the graph has the old ones')"""
+        return self._owner is None or \
+            self._owner == (id(dm.model), id(dm.optimizer), id(getattr(dm, '_fused_plan', None)))
 
     # -- the feed ---------------------------------------------------------------------------------------------
     def set_order(self, perm=None):
@@ -167,9 +199,9 @@ class CompiledTrainLoop:
             dm.model._dt_flat_grad = plan.accum
             return
         fused_opt = self.with_optimizer and not self.dp
-        loss, logit = dm.forward_backward(ins, yb, wb, apply_rows=fused_opt and self.strategy is None,
-                                          logit_out=None if self.logits is None else self.logits[i],
-                                          slot=i if self._slots_per_step else 0, preelected=preelected)
+        loss, logit = dm._forward_backward(ins, yb, wb, apply_rows=fused_opt and self.strategy is None,
+                                           logit_out=None if self.logits is None else self.logits[i],
+                                           slot=i if self._slots_per_step else 0, preelected=preelected)
         if fused_opt:
             dm.optimizer.step()             # single process: the optimizer step is part of the captured graph
         used_plan = getattr(dm, '_step_used_plan', False)
@@ -219,10 +251,7 @@ class CompiledTrainLoop:
         # where earlier tests' loops are such garbage).  The capture's own garbage (autograd nodes of the layer-by-layer path)
         # is still collected as it appears: with the collector switched off altogether hipStreamEndCapture faulted on those
         # graphs (gpurun_out/r4c22).
-        import gc
-        gc.collect()
-        gc.freeze()
-        try:
+        with _old_garbage_frozen():
             with torch.cuda.graph(g):
                 if not core_only:
                     self._gather()
@@ -237,10 +266,9 @@ class CompiledTrainLoop:
                     if pre and i == 1:
                         torch.cuda.current_stream().wait_stream(side)
                     self._body(i, core_only=core_only, preelected=pre and i >= 1)
-        finally:
-            gc.unfreeze()
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
+        self._owner = (id(dm.model), id(dm.optimizer), id(getattr(dm, '_fused_plan', None)))
         # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
         # (rows, values) tensors and re-attach them after every replay (data parallel: the exchange reads them)
         self._sparse_refs = [(l, {key: list(v) for key, v in l.sparse_grads.items()}) for l in emb_layers]
@@ -287,9 +315,22 @@ class CompiledTrainLoop:
             if ev:
                 ev[1].record()
             opt = self.dm.optimizer
-            self.strategy.exchange_gradients(self.dm.model, opt if self.with_optimizer else None)
+            # every step of this loop trains on exactly B rows per rank: the exchange may keep its results in persistent
+            # buffers (no count exchange, no fresh allocations) — the precondition of a captured optimizer step
+            st = self.strategy
+            keep_uniform, st.assume_uniform_batches = getattr(st, 'assume_uniform_batches', False), True
+            try:
+                st.exchange_gradients(self.dm.model, opt if self.with_optimizer else None)
+            finally:
+                st.assume_uniform_batches = keep_uniform
             if ev:
                 ev[2].record()
+            sig = self._exchange_signature() if self.with_optimizer else None
+            if self.opt_graph is not None and sig != self._opt_graph_sig:
+                # the exchanged gradients moved (a strategy that does not keep them in place): the captured optimizer step
+                # would read the capture step's addresses — drop it and stay eager
+                self.opt_graph = None
+                self._opt_graph_refused = True
             if self.with_optimizer:
                 if self.opt_graph is not None:
                     hook, opt.pre_dense_hook = getattr(opt, 'pre_dense_hook', None), None
@@ -298,28 +339,42 @@ class CompiledTrainLoop:
                     self.opt_graph.replay()
                     for layer in getattr(opt, 'embedding_layers', []):
                         layer.sparse_grads.clear()
-                elif self.use_graph and self._dp_steps >= 2 and (not self._sharded() or self.graph_segments):
+                elif self.use_graph and self._dp_steps >= 2 and (not self._sharded() or self.graph_segments) and \
+                        not self._opt_graph_refused and sig == self._last_exchange_sig:
                     hook, opt.pre_dense_hook = getattr(opt, 'pre_dense_hook', None), None
                     if hook is not None:
                         hook()
                     torch.cuda.synchronize()
                     gopt = torch.cuda.CUDAGraph()
-                    import gc
-                    gc.collect()
-                    gc.freeze()                        # (see capture(): old garbage is not collected inside a stream capture)
-                    try:
+                    with _old_garbage_frozen():        # (old garbage is not collected inside a stream capture)
                         with torch.cuda.graph(gopt):
                             opt.step()
-                    finally:
-                        gc.unfreeze()
                     self.opt_graph = gopt
+                    self._opt_graph_sig = sig
                     gopt.replay()
                 else:
                     opt.step()          # first steps (slot buffers get allocated) and the eager row-owned step
+            self._last_exchange_sig = sig
             self._dp_steps += 1
             if ev:
                 ev[3].record()
                 self.phase_events.append(tuple(ev))
+
+    def _exchange_signature(self):
+        """(address, shape) of every tensor the optimizer step reads after the exchange: the sparse (rows, values) pairs of
+        the embedding layers and the dense gradients.  A captured optimizer step is only valid while these stay put."""
+        from .models.layers import MultiColumnEmbedding
+        sig = []
+        for layer in self.dm.model.modules():
+            if isinstance(layer, MultiColumnEmbedding):
+                for key in sorted(layer.sparse_grads):
+                    for g in layer.sparse_grads[key]:
+                        sig.append((key, g.rows.data_ptr(), tuple(g.rows.shape), g.values.data_ptr(), tuple(g.values.shape),
+                                    getattr(g, 'fields', None)))
+        for p in self.dm.model.parameters():
+            if p.grad is not None:
+                sig.append((p.grad.data_ptr(), tuple(p.grad.shape)))
+        return tuple(sig)
 
     def run(self, n_steps, on_execution=None, collect=None):
         """exactly n_steps train steps.  collect: a dict with lists 'loss', 'logit', 'y' that receive per-execution device

@@ -53,6 +53,9 @@ class DeepModel:
     # ------------------------------------------------------------------------------------------
     def build(self, device=None):
         self.device = device or default_device()
+        self.compiled_loop = None            # a captured loop holds pointers into the model / optimizer it was built on
+        if hasattr(self, '_fused_plan'):
+            del self._fused_plan
         self.model = self._build_model(self.task, self.num_classes, self.config.nets, self.categorical_columns,
                                        self.continuous_columns, self.config,
                                        self.var_len_categorical_columns).to(self.device)
@@ -257,13 +260,21 @@ class DeepModel:
             self._fused_plan = make_fused_plan(self)
         return self._fused_plan
 
-    def forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None, slot=0, preelected=False):
-        """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads.
+    def forward_backward(self, inputs, y, sample_weight=None, logit_out=None):
+        """forward -> loss -> backward; gradients land in `.grad` / MultiColumnEmbedding.sparse_grads and stay there until
+        the caller's `optimizer.step()`.
         sample_weight [B] (Keras fit's sample_weight x class_weight): the DeepFM / DCN plans scale each row's loss inside
         their loss block; other plans leave a weighted step to the layer-by-layer path.
-        apply_rows=True is the caller's promise that `self.optimizer.step()` follows immediately (train_step): a fused
-        plan may then apply the row-sparse update of the table rows looked up once inside its own kernels.
-        logit_out: caller-owned buffer for a fused plan's logits (compiled.CompiledTrainLoop: one per captured step)."""
+        logit_out: caller-owned buffer for a fused plan's logits."""
+        return self._forward_backward(inputs, y, sample_weight, logit_out=logit_out)
+
+    def _forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None, slot=0, preelected=False,
+                          next_ids=None):
+        """`forward_backward` with the library-internal switches of `train_step` / compiled.CompiledTrainLoop:
+        apply_rows=True is the promise that `self.optimizer.step()` follows immediately: a fused plan may then apply the
+        row-sparse update of the table rows looked up once (and the dense update) inside its own kernels — the gradients are
+        consumed by the call, so this is not a public mode.  slot / preelected / next_ids: the compiled loop's per-step id
+        buffers (fused.FusedDeepFM.run)."""
         plan = self.fused_plan() if self.model.training else None
         if plan is not None and sample_weight is not None and not getattr(plan, 'takes_sample_weight', False):
             plan = None
@@ -276,8 +287,10 @@ class DeepModel:
             kw = {} if sample_weight is None else {'sample_weight': sample_weight}
             if logit_out is not None:
                 kw['logit_out'] = logit_out
-            if slot:
+            if slot or preelected:
                 kw['slot'], kw['preelected'] = slot, preelected
+            if next_ids is not None:
+                kw['next_ids'] = next_ids
             loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows, **kw)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit
@@ -296,7 +309,7 @@ class DeepModel:
     def train_step(self, inputs, y, sample_weight=None):
         """forward -> loss -> backward -> (data-parallel gradient exchange) -> optimizer step."""
         strategy = self.config.distribute_strategy
-        loss, logit = self.forward_backward(inputs, y, sample_weight, apply_rows=strategy is None)
+        loss, logit = self._forward_backward(inputs, y, sample_weight, apply_rows=strategy is None)
         if strategy is not None:
             strategy.exchange_gradients(self.model, self.optimizer)
         self.optimizer.step()
@@ -400,8 +413,11 @@ class DeepModel:
                                                    train, bs, steps_per_epoch)
         loop = None
         if spe > 1 and train.n >= bs:
-            loop = getattr(self, 'compiled_loop', None)       # the same feed object again: the captured graph is reused
-            if loop is None or loop.feed is not train or loop.B != bs or loop.k != (1 if loop.dp else spe):
+            # the same feed object again: the captured graph is reused — as long as everything it holds pointers into is
+            # the object it was captured on (the optimizer's slots, the plan's workspace, the model's parameters)
+            loop = getattr(self, 'compiled_loop', None)
+            if loop is None or loop.feed is not train or loop.B != bs or loop.k != (1 if loop.dp else spe) or \
+                    not loop.owned_by(self):
                 loop = compiled.CompiledTrainLoop(self, train, bs, spe)
         self.compiled_loop = loop           # (for callers that look: None = eager steps)
         want_out = bool(metrics)

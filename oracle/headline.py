@@ -334,7 +334,7 @@ def check_rows_in_step(dm, batch, steps=1):
     restore(s0)
     took = []
     for _ in range(steps):
-        dm.forward_backward(ins, y, apply_rows=True)
+        dm._forward_backward(ins, y, apply_rows=True)
         sg = emb.sparse_grads.get(key) or []
         took.append(bool(sg) and all(getattr(g, 'fields', None) == -2 for g in sg))
         opt.step()
@@ -447,7 +447,7 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
                                        st['v'].detach().double().cpu().reshape(g.shape)))
             dense0[name] = (p.detach().double().cpu().reshape(g.shape), g.detach().double(), mm, vv)
         # ---- the product's step, as timed ----
-        dm.forward_backward(ins, y, apply_rows=True)
+        dm._forward_backward(ins, y, apply_rows=True)
         sg = emb.sparse_grads.get(key) or []
         res['rows_in_step_taken'] = res['rows_in_step_taken'] and bool(sg) and \
             all(getattr(s, 'fields', None) == -2 for s in sg)

@@ -2,6 +2,8 @@
 """CPU: host-side logic added in round 2 that needs no kernel — the per-lookup view of a segmented sparse gradient
 (ops.SparseRowGrad.expanded), Keras' sample / class weighting of the loss (training.weighted_loss), the feed carrying
 per-row weights through a shuffle (training.TableBatches), balanced class weights (DeepTable.get_class_weight)."""
+import os
+
 import numpy as np
 import torch
 
@@ -195,3 +197,34 @@ def test_segmented_sparse_grad_expands_for_random_segment_layouts():
         assert np.array_equal(got.numpy(), rows)
         assert np.array_equal(sg.rows.numpy(), reported)                       # the stored gradient is not modified
     check()
+
+
+def _run_bench(extra_args, env_extra, timeout=300):
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([_sys.executable, os.path.join(root, 'bench.py')] + extra_args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher must run TWO ranks (re-exec under torch.distributed.run),
+    not one rank labelled 2 (reference shape: deeptables/tests/models/run_dt.py:35-44).  The probe mode joins a gloo group
+    and leaves before any device is touched, so this runs on CPU."""
+    import json
+    r = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '0'], {'DT_BENCH_SPAWN_PROBE': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert lines, r.stdout + r.stderr
+    assert json.loads(lines[-1]) == {'spawned_ranks': 2, 'world_size': 2}
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """inside a launcher (WORLD_SIZE set) a different --gpus is an error, not a mislabelled line"""
+    r = _run_bench(['--gpus', '4'], {'DT_BENCH_SPAWN_PROBE': '1', 'WORLD_SIZE': '2', 'RANK': '0'}, timeout=120)
+    assert r.returncode != 0
+    assert 'WORLD_SIZE=2' in (r.stderr + r.stdout)
