@@ -161,6 +161,7 @@ DT_STEP_SKIP_FINISH, DT_STEP_FINISH_ONLY = 0x20, 0x40
 DT_STEP_TOWER_X3 = 0x80
 DT_STEP_PREELECTED = 0x100
 DT_STEP_TOWER_BF16 = 0x200
+DT_STEP_STAMPS = 0x400
 DT_FEED_CURSOR_WORDS = 528          # 16 (1 + 32 ticket groups), csrc/embedding.hip kFeedGroups
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
 # keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)

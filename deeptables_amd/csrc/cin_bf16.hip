@@ -1171,11 +1171,8 @@ static void cinb_pack(const float* W, int F0, int Hk, int L, __bf16* WT, __bf16*
 }
 
 // large batches take the 256-row (eight-wave) blocks of the forward / dgrad: at least one block per CU that way
-// (DT_CIN_WIDE=0 / 1 forces the choice: the A/B knob of DESIGN.md 3.4)
-static bool cinb_wide(int64_t M) {
-    static const int env = getenv("DT_CIN_WIDE") ? atoi(getenv("DT_CIN_WIDE")) : -1;
-    return env >= 0 ? env != 0 : M >= 256 * 128;
-}
+// (round 4's A/B, profiles/r04_xdeepfm_x3_narrow_kernel_stats.csv: 2.49 ms per step against 3.27 ms with the four-wave kernels)
+static bool cinb_wide(int64_t M) { return M >= 256 * 128; }
 
 template <int NP>
 static int cinb_fwd(const char* who, const float* x0, const float* xk, const float* W, const float* bias, int act, int B, int F0,
@@ -1190,7 +1187,7 @@ static int cinb_fwd(const char* who, const float* x0, const float* xk, const flo
     cinb_pack<NP>(W, F0, Hk, L, WT, nullptr, st);
     const int64_t M = (int64_t)B * D;
     dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)ceil_div(L, kBN));
-    if (NP == 3 && !(getenv("DT_CIN_FWD_Z") && atoi(getenv("DT_CIN_FWD_Z")))) {
+    if (NP == 3) {
         // the forward that never forms Z (k_cin_fwd_noz): Hk up to 128
         const int ks = cb_hp(Hk) <= 32 ? 2 : cb_hp(Hk) <= 64 ? 4 : 8;
         const bool wide = cinb_wide(M);                  // 256-row blocks (eight waves), the filter double buffered in LDS
@@ -1319,8 +1316,7 @@ static int cinb_bwd(const char* who, const float* x0, const float* xk, const flo
     const int64_t M = (int64_t)B * D;
     const bool vec4 = (D % 4 == 0) && (x0_bstride % 4 == 0) && (xk_bstride % 4 == 0) &&
                       ((((uintptr_t)x0 | (uintptr_t)xk | (uintptr_t)y | (uintptr_t)grad_y) & 15) == 0);
-    static const int wide_env = getenv("DT_CIN_WGRAD_WIDE") ? atoi(getenv("DT_CIN_WGRAD_WIDE")) : 1;
-    if (wide_env && vec4 && F0 + Hk <= 96) {
+    if (vec4 && F0 + Hk <= 96) {
         // k_cin_wgrad_wide: groups of up to 32 k sub-tiles x 64 filters per block, the batch split over what is left of ~256 blocks
         const int nsub = ceil_div(K, 32), kgroups = ceil_div(nsub, kW2Waves * kW2KT), spg = ceil_div(nsub, kgroups);
         const int lgroups = ceil_div(L, 32 * kW2NB);

@@ -1633,21 +1633,6 @@ __global__ __launch_bounds__(1024) void k_reduce_parts(DeepFmDims dm, const floa
     wgrad_reduce_parts(red, (int)blockIdx.x, dm, part, nparts, accum, al, Lc, pr);
 }
 
-__global__ __launch_bounds__(256) void k_wgrad4(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
-                                                const float* __restrict__ H1, const float* __restrict__ dH1,
-                                                const float* __restrict__ dH2, int nred_blocks, int row_blocks,
-                                                int rows_per_block, const float* __restrict__ part, int nparts,
-                                                float* __restrict__ accum, DeepFmAccum al, float* __restrict__ wpart,
-                                                unsigned long long* stamps_all, int Lc, PipeRed pr) {
-    extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128] (heavy) / [4][64] (reducers)
-    if ((int)blockIdx.x < nred_blocks) {
-        wgrad_reduce_parts(red, (int)blockIdx.x, dm, part, nparts, accum, al, Lc, pr);
-        return;
-    }
-    // nred_blocks is a multiple of 8: hid % 8 is still the XCD
-    wgrad_heavy(red, (int)blockIdx.x - nred_blocks, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all);
-}
-
 // E': adds up the batch slices of E and finishes the BN / W1 gradients.  With M = Xhat^T dH1 and db1 = colsum(dH1):
 //   dgamma = sum_b dXn xhat = rowdot(W1, M)      dbeta = sum_b dXn = W1 . db1      dW1 = gamma M + beta (x) db1
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
@@ -1859,214 +1844,6 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
     }
     __syncthreads();
     adam_finish(st, threadIdx.x == 0 ? 0u : kNoTicket, lr, da.b1, da.b2);
-}
-
-// D: dXn = dH1 . W1^T on 16x16x4 tiles, one 16-column block (x both 16-row halves, sharing the W1 operand) at a
-// time per wave, with everything kernel G of round 1 did as the epilogue:
-//   dX[c]  = gamma rstd (dXn - mean_b(dXn) - xhat mean_b(dXn xhat))
-//   grad_rows[b,f,d] = dX[b,f*D+d] + dz[b] w_lin[f] + dz[b] (S[b,d] - E[b,f,d])
-// Only the F*D embedding columns are computed (the dense inputs need no gradient).
-template <bool DCN>      // DCN: + dXn through the cross network (dXc, written by kernel C), no FM / linear terms
-__global__ __launch_bounds__(512) void k_dx_sparse_bwd(const float* __restrict__ X, const float* __restrict__ dH1,
-                                                       const float* __restrict__ dz, const float* __restrict__ S,
-                                                       MlpParams p, const float* __restrict__ wlin, DeepFmDims dm,
-                                                       const float* __restrict__ accum, DeepFmAccum al,
-                                                       float* __restrict__ grad_rows, DedupeWs dd, float grad_scale,
-                                                       int field_major, EmbDrop drop, unsigned long long* stamps,
-                                                       const float* __restrict__ dXc) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    DT_STAMP(stamps, 0);
-    constexpr int HS = kH1 + kPad, NT = 512;
-    const int XS = dm.CP + kPad, FD = dm.F * dm.D;
-    const int FD16 = ((FD + 15) >> 4) << 4;
-    float* dh1s = lds;                    // [32][HS]
-    float* xs = dh1s + kTM * HS;          // [32][XS] raw X tile; every (row, col) is replaced by its gradient in place
-    float* Ss = xs + kTM * XS;            // [32][D]  S[b][d] = sum_f E[b,f,d]
-    float* cv = Ss + kTM * dm.D;          // [4][FD16]: gamma*rstd | mean | mean_b(dXn) | rstd mean_b(dXn xhat)
-    float* dzs = cv + 4 * FD16;
-    float* wls = dzs + kTM;                              // [F] linear_logit kernel rows of the fields
-    float* xcs = wls + ((dm.F + 3) & ~3);                           // DCN: [32][XS] dXn through the cross network
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves: two per SIMD
-    const int n16 = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * kTM;
-    const int nblk = FD16 >> 4;
-    const float invN = 1.0f / (float)dm.B;
-    int dshift = 0;
-    while ((1 << dshift) < dm.D) ++dshift;               // D is a power of two (4 * LPR)
-
-    // ---- staging.  No loaded value is touched before it is needed (a select on it would drain the queue there):
-    //      addresses are clamped instead, the workspace rows of a ragged last tile are zero (host memset) ----
-    floatx4 hv[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) hv[u] = ld4(dH1 + (int64_t)(m0 + (tid >> 5) + 16 * u) * kH1 + 4 * (tid & 31));
-    floatx4 bW[2][8];
-    auto w1ptr = [&](int blk) {          // row `col` of W1, this lane's 4 k of every 16; columns beyond C are never stored
-        const int col = min(16 * blk + n16, dm.C - 1);
-        return p.W1 + (int64_t)col * kH1 + 4 * kq;
-    };
-    if (wave < nblk) {
-        const float* wrow = w1ptr(wave);
-#pragma unroll
-        for (int G = 0; G < 8; ++G) bW[0][G] = ld4(wrow + 16 * G);
-    }
-    const int q4 = dm.CP >> 2, total = kTM * q4;                  // float4 of the X tile, <= 9 per thread
-    floatx4 xv[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        const int e = min(tid + NT * u, total - 1);
-        const int r = e / q4, q = e - r * q4;
-        if (NT * u < total) xv[u] = ld4(X + (int64_t)(m0 + r) * dm.CP + 4 * q);
-    }
-    floatx4 xcv[DCN ? 9 : 1];
-    if (DCN) {
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int e = min(tid + NT * u, total - 1);
-            const int r = e / q4, q = e - r * q4;
-            const int64_t m = min((int64_t)m0 + r, (int64_t)dm.B - 1);    // dXc has exactly B rows
-            if (NT * u < total) xcv[DCN ? u : 0] = ld4(dXc + m * dm.CP + 4 * q);
-        }
-    }
-    float cvv[4][2];                                              // FD16 <= 544: two columns per thread
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int col = tid + NT * i;
-        if (col < FD) {                  // waves that own no column skip the loads altogether
-            cvv[0][i] = p.sc[col];
-            cvv[1][i] = p.mean[col];
-            cvv[2][i] = accum[al.dbeta + col];
-            cvv[3][i] = p.rstd[col] * accum[al.dgamma + col];
-        }
-    }
-    float dzv = 0.f, wlv = 0.f;
-    floatx4 sv = {0.f, 0.f, 0.f, 0.f};
-    const int s4n = kTM * dm.D / 4;                               // float4 of the S tile (<= 512: D <= 64)
-    if (!DCN) {
-        if (tid < kTM) dzv = dz[min(m0 + tid, dm.B - 1)];
-        if (tid >= 64 && tid < 64 + dm.F) wlv = wlin[tid - 64];
-        if (tid < s4n) sv = ld4(S + (int64_t)m0 * dm.D + 4 * tid);
-    }
-    DT_STAMP(stamps, 6);
-    // dH1 (the A operand) first: the MFMAs of every wave's first block start as soon as it is in LDS; X and the
-    // per-column / per-row constants (needed by the epilogues only) land behind those MFMAs
-#pragma unroll
-    for (int u = 0; u < 2; ++u) st4(dh1s + ((tid >> 5) + 16 * u) * HS + 4 * (tid & 31), hv[u]);
-    lds_barrier();
-    DT_STAMP(stamps, 7);
-    floatx4 aA[2][8];
-#pragma unroll
-    for (int G = 0; G < 8; ++G) {
-        aA[0][G] = ld4(dh1s + n16 * HS + 16 * G + 4 * kq);
-        aA[1][G] = ld4(dh1s + (16 + n16) * HS + 16 * G + 4 * kq);
-    }
-    DT_STAMP(stamps, 1);
-    float dzr[8];
-    auto stage_rest = [&]() {
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int e = tid + NT * u;
-            const int r = e / q4, q = e - r * q4;
-            if (e < total) {
-                st4(xs + r * XS + 4 * q, xv[u]);
-                if (DCN) st4(xcs + r * XS + 4 * q, xcv[DCN ? u : 0]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int col = tid + NT * i;
-            if (col < FD16) {
-                const bool ok = col < FD;
-                cv[col] = ok ? cvv[0][i] : 0.f;
-                cv[FD16 + col] = ok ? cvv[1][i] : 0.f;
-                cv[2 * FD16 + col] = ok ? cvv[2][i] * invN : 0.f;
-                cv[3 * FD16 + col] = ok ? cvv[3][i] * invN : 0.f;
-            }
-        }
-        if (tid < kTM) dzs[tid] = m0 + tid < dm.B ? dzv : 0.f;
-        if (tid >= 64 && tid < 64 + dm.F) wls[tid - 64] = wlv;
-        if (tid < s4n) st4(Ss + 4 * tid, sv);
-    };
-
-    auto mm = [&](int buf, int blk, bool more, floatx4& c0, floatx4& c1) {
-        c0 = floatx4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
-        const float* wnext = w1ptr(blk + 8);
-#pragma unroll
-        for (int G = 0; G < 8; ++G) {
-            const floatx4 b = bW[buf][G];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].x, b.x, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].x, b.x, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].y, b.y, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].y, b.y, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].z, b.z, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].z, b.z, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[0][G].w, b.w, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[1][G].w, b.w, c1, 0, 0, 0);
-            if (more) bW[buf ^ 1][G] = ld4(wnext + 16 * G);       // the next block's W1 operand, one load per 8 MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (blk < 8) DT_STAMP(stamps, 4);
-    };
-    // epilogue: BN backward + FM / linear terms; the row gradient replaces X[row][col] in LDS
-    auto epi = [&](int blk, const floatx4& c0, const floatx4& c1) {
-        const int col = 16 * blk + n16;
-        if (col < FD) {
-            const int f = col >> dshift, d = col & (dm.D - 1);
-            const float ca = cv[col], cmu = cv[FD16 + col], cm1 = cv[2 * FD16 + col], cm2 = cv[3 * FD16 + col];
-            const float wl = wls[f];
-            float xr[8], sr[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
-                xr[q] = xs[row * XS + col];
-                sr[q] = Ss[(row << dshift) + d];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = 16 * (q >> 2) + 4 * kq + (q & 3);
-                const float gx = (q >> 2) ? c1[q & 3] : c0[q & 3];
-                if (DCN) xs[row * XS + col] = ca * ((gx + xcs[row * XS + col]) - cm1 - (xr[q] - cmu) * cm2);
-                else xs[row * XS + col] = ca * (gx - cm1 - (xr[q] - cmu) * cm2) + dzr[q] * wl + dzr[q] * (sr[q] - xr[q]);
-            }
-        }
-        if (blk < 8) DT_STAMP(stamps, 5);
-    };
-    // buffer ids are literals: the operand arrays stay in registers
-    floatx4 c0, c1;
-    if (wave < nblk) mm(0, wave, wave + 8 < nblk, c0, c1);
-    stage_rest();
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dzr[q] = dzs[16 * (q >> 2) + 4 * kq + (q & 3)];
-    if (wave < nblk) epi(wave, c0, c1);
-    if (wave + 8 < nblk) { mm(1, wave + 8, wave + 16 < nblk, c0, c1); epi(wave + 8, c0, c1); }
-    if (wave + 16 < nblk) { mm(0, wave + 16, wave + 24 < nblk, c0, c1); epi(wave + 16, c0, c1); }
-    if (wave + 24 < nblk) { mm(1, wave + 24, wave + 32 < nblk, c0, c1); epi(wave + 24, c0, c1); }
-    if (wave + 32 < nblk) { mm(0, wave + 32, false, c0, c1); epi(wave + 32, c0, c1); }        // nblk <= 34 (C <= 544)
-    __syncthreads();
-    DT_STAMP(stamps, 8);
-
-    // ---- the tile's row gradients leave as whole rows (16-byte lanes) ----
-    const unsigned dseed = drop.thr ? *drop.seed : 0u;
-    const int fq = FD >> 2;                                       // float4 per row
-    float* tile_rows = grad_rows + (int64_t)m0 * FD;
-    for (int e = tid; e < kTM * fq; e += NT) {
-        const int row = e / fq, q = e - row * fq;
-        const int b = m0 + row;
-        if (b >= dm.B) continue;
-        const int col = 4 * q, f = col >> dshift, d = col & (dm.D - 1);
-        floatx4 o = ld4(xs + row * XS + col);
-        if (drop.thr) {          // gradient through the dropped embedding: the same keep-mask as the forward
-            float4 t4 = make_float4(o.x, o.y, o.z, o.w);
-            t4 = emb_drop4(t4, dseed, drop.thr, drop.inv_keep, (unsigned)b, (unsigned)col);
-            o = floatx4{t4.x, t4.y, t4.z, t4.w};
-        }
-        if (field_major) {       // model-parallel tables: [F,B,D], already divided by the world size
-            st4(grad_rows + (((int64_t)f * dm.B + b) << dshift) + d, o * grad_scale);
-            continue;
-        }
-        st4(tile_rows + row * FD + col, o);      // every lookup's own row: duplicates are summed by the optimizer (segments)
-    }
-    DT_STAMP(stamps, 3);
 }
 
 // advances the dropout seed once per step (after kernel D: every reader of this step's value has finished)
@@ -2426,10 +2203,10 @@ static int tower_train_step(
     const bool bf16_flag = (phases & DT_STEP_TOWER_BF16) != 0;       // plain bf16: the split kernel with the leading products only
     const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0 || bf16_flag;
     const bool preelected = (phases & DT_STEP_PREELECTED) != 0;
+    const bool stamps_flag = (phases & DT_STEP_STAMPS) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
-    static const int wt_env_c = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;
-    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, (wt_env_c >> 1) & 1, sample_weight};
+    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, 0, sample_weight};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
@@ -2480,11 +2257,10 @@ static int tower_train_step(
         if (drop.thr == 0) drop.thr = 1;
         drop.inv_keep = 1.0f / (1.0f - embedding_dropout);
     }
-    static const bool stamps_on = getenv("DT_DEEPFM_STAMPS") != nullptr;   // phase timestamps (tools/phase_times.py)
-    unsigned long long* stamps = stamps_on ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
-    // the pipelined launch sequence (DeepFM backward steps; DT_STEP_PIPE=0 keeps round 2's A B C E E' D): A B C+dXn R [E|D+Adam] E'
-    static const bool pipe_env = !(getenv("DT_STEP_PIPE") && atoi(getenv("DT_STEP_PIPE")) == 0);
-    const bool pipe = phases >= 2 && (pipe_env || adam);
+    // phase timestamps (phases | DT_STEP_STAMPS; tools/phase_times.py reads the workspace region back)
+    unsigned long long* stamps = stamps_flag ? reinterpret_cast<unsigned long long*>(ws + wl.stamps) : nullptr;
+    // the pipelined launch sequence of every backward step: A B C+dXn R [E|D+Adam] E'
+    const bool pipe = phases >= 2;
     DT_REQUIRE(!(skip_finish || finish_only) || (pipe && !adam),
                "dt_deepfm_train_step: DT_STEP_SKIP_FINISH / DT_STEP_FINISH_ONLY belong to the pipelined backward step without "
                "the in-step optimizer");
@@ -2594,7 +2370,6 @@ static int tower_train_step(
 #undef DT_C
     }
     const Part3 pl3 = part3_layout(dm.CP, Lc, pipe ? 1 : 0);
-    const int nred3 = (ceil_div(pl3.n, 64) + 7) & ~7;        // k_wgrad4 reducer blocks (a multiple of 8, see the kernel)
     const PipeRed no_pr{nullptr, nullptr, nullptr};
     if (pipe) {
         // R: the per-tile records -> dense gradients, the BN-backward batch sums and the epilogue's per-column constants
@@ -2608,12 +2383,10 @@ static int tower_train_step(
         const size_t ldsE = (size_t)4 * 8192 * sizeof(float);
         const RowsEpi ep{ws + wl.dXn, ws + wl.X, ws + wl.dz, ws + wl.S, w_lin, ws + wl.sc, ws + wl.mean, ws + wl.cm1,
                          ws + wl.cm2, rows_out, grad_rows, grad_rows_scale, grad_rows_field_major};
-        // measured (DT_WT=1 / 2): write-through row-update stores 118.1 vs 114.5 us per step (the launch itself 39.8 vs 35.2 us),
-        // write-through tile outputs no change — the kernel boundaries do not wait for this data; default: plain stores
-        static const int wt_env = getenv("DT_WT") ? atoi(getenv("DT_WT")) : 0;      // bit 0: row update, bit 1: kernel C's outputs
+        // (measured in round 3: write-through row-update stores 118.1 vs 114.5 us per step, write-through tile outputs no
+        // change — the kernel boundaries do not wait for this data: plain stores)
         RowsAdam ad = adam ? *adam : RowsAdam{nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f, 0.f, 0};
-        ad.wt = wt_env & 1;
-        static const int join_env = !(getenv("DT_ROWS_JOIN") && atoi(getenv("DT_ROWS_JOIN")) == 0);    // experiment knob
+        const int join_env = 1;            // the matrix waves join the row epilogue once their tile is stored
         if (dcn) {
             hipFuncSetAttribute((const void*)k_wgrad_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
             hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
@@ -2633,9 +2406,8 @@ static int tower_train_step(
             DT_REQUIRE(sdense->n_flat == want_flat, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
                        "%lld floats (the accumulator layout up to its last gradient)", (long long)sdense->n_flat,
                        (long long)want_flat);
-            static const int seg_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
             // 512 blocks: 1.5 us faster with uniform ids (878 segments), 1024: 4.6 us faster with Zipf ids (15 K segments)
-            const int seg_blocks = seg_env > 0 ? seg_env : 1024;
+            const int seg_blocks = 1024;
             const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
             const DedupeLayout dl = dedupe_layout(B, F);
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
@@ -2652,45 +2424,10 @@ static int tower_train_step(
         }
         if ((drop.thr || drop.thr_dense) && !skip_finish)
             hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
-    } else if (phases >= 2) {
-        // E: one block per CU: (CP/64 + 1) macro tiles x row_blocks batch slices ~ 256
-        const int nmac = (dm.CP >> 6) + 1;
-        int row_blocks = 256 / nmac;
-        if (row_blocks >= 8) row_blocks &= ~7;
-        while (row_blocks > 1 && (B + row_blocks - 1) / row_blocks < 64) row_blocks >>= 1;
-        if (row_blocks < 1) row_blocks = 1;
-        static const int rb_env = getenv("DT_WGRAD_ROWBLOCKS") ? atoi(getenv("DT_WGRAD_ROWBLOCKS")) : 0;   // experiment knob
-        if (rb_env > 0 && rb_env * nmac <= 256) row_blocks = rb_env;
-        const int rows_per_block = ((B + row_blocks - 1) / row_blocks + 7) & ~7;
-        const size_t ldsE = (size_t)4 * 8192 * sizeof(float);
-        hipFuncSetAttribute((const void*)k_wgrad4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
-        hipLaunchKernelGGL(k_wgrad4, dim3(nred3 + nmac * row_blocks), dim3(256), ldsE, st, ws + wl.X, mp, dm,
-                           ws + wl.H1, ws + wl.dH1, ws + wl.dH2, nred3, row_blocks, rows_per_block, ws + wl.part,
-                           tiles, accum, al, ws + wl.wpart, stamps ? stamps + (int64_t)tiles * 32 : nullptr, Lc, no_pr);
-        // E'
-        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 0);
-        // D
-        const int FD16 = ((F * D + 15) >> 4) << 4;
-        const size_t ldsD = ((size_t)kTM * (kH1 + kPad) + kTM * (dm.CP + kPad) + kTM * D + 4 * FD16 + kTM +
-                             ((F + 3) & ~3) + (dcn ? kTM * (dm.CP + kPad) : 0)) * sizeof(float);
-        DT_UNSUPPORTED(ldsD > 160 * 1024, "dt_dcn_train_step: the row-gradient kernel needs %zu B of LDS", ldsD);
-        if (dcn) {
-            hipFuncSetAttribute((const void*)k_dx_sparse_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
-            hipLaunchKernelGGL(k_dx_sparse_bwd<true>, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz,
-                               ws + wl.S, mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
-                               drop, stamps ? stamps + (int64_t)tiles * 16 : nullptr, ws + wl.dXc);
-        } else {
-            hipFuncSetAttribute((const void*)k_dx_sparse_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsD);
-            hipLaunchKernelGGL(k_dx_sparse_bwd<false>, dim3(tiles), dim3(512), ldsD, st, ws + wl.X, ws + wl.dH1, ws + wl.dz,
-                               ws + wl.S, mp, w_lin, dm, accum, al, grad_rows, dd, grad_rows_scale, grad_rows_field_major,
-                               drop, stamps ? stamps + (int64_t)tiles * 16 : nullptr, nullptr);
-        }
-        if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else {
         // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
-        hipLaunchKernelGGL(k_wgrad4, dim3(nred3), dim3(256), 1024, st, ws + wl.X, mp, dm, ws + wl.H1, ws + wl.dH1,
-                           ws + wl.dH2, nred3, 1, 8, ws + wl.part, tiles, accum, al, ws + wl.wpart, nullptr, Lc, no_pr);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(ceil_div(pl3.n, 64)), dim3(1024), 0, st, dm, ws + wl.part, tiles, accum, al, Lc,
+                           no_pr);
     }
     return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
 }

@@ -762,8 +762,7 @@ extern "C" int dt_adam_rows_step_seg(float* table, float* m, float* v, const int
     if (D % 4 == 0) {
         int row_blocks = (int)((n_rows * (D / 4) + 256 * kAdamPieces - 1) / (256 * kAdamPieces));
         // segments only: enough waves to walk the regions (every block takes the state's arrival ticket: few blocks)
-        static const int seg_blocks_env = getenv("DT_ADAM_SEG_BLOCKS") ? atoi(getenv("DT_ADAM_SEG_BLOCKS")) : 0;
-        if (segments_only) row_blocks = row_blocks < 512 ? row_blocks : (seg_blocks_env > 0 ? seg_blocks_env : 512);
+        if (segments_only) row_blocks = row_blocks < 512 ? row_blocks : 512;
         hipLaunchKernelGGL(k_adam_rows_owner<4>, dim3((unsigned)(row_blocks + tail_blocks)), dim3(256), 0, st,
                            table, m, v, rows, values, n_rows, D, gslots, mk, lr_t, as, beta1, beta2, eps, row_blocks, tail,
                            advance, lr, sstride, seg, segments_only);

@@ -106,7 +106,7 @@ def _rows_in_step(plan, B, backward, apply_rows):
     nothing between the gradient and its update (no pending all-reduce hook), and DT_AMD_ROWS_IN_STEP != 0."""
     if not (apply_rows and backward and plan.dm.model.training and _dedupe_in_step(plan, B, backward)):
         return None
-    if os.environ.get('DT_AMD_ROWS_IN_STEP', '1') == '0' or os.environ.get('DT_STEP_PIPE', '1') == '0':
+    if os.environ.get('DT_AMD_ROWS_IN_STEP', '1') == '0':
         return None
     opt = getattr(plan.dm, 'optimizer', None)
     if not getattr(opt, 'supports_rows_in_step', False) or getattr(opt, 'pre_dense_hook', None) is not None:
@@ -225,6 +225,8 @@ class FusedDeepFM:
         # duplicate lookups are resolved inside the step (kernels A and G) unless DT_AMD_FUSED_DEDUPE=0
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
         self.tower_flag = _tower_mfma_flag(dm.config.dnn_params)
+        # diagnostic: s_memtime phase stamps into the workspace (tools/phase_times.py sets DT_AMD_STEP_STAMPS=1)
+        self.diag_flag = _lib.DT_STEP_STAMPS if os.environ.get('DT_AMD_STEP_STAMPS') == '1' else 0
         # Parameters mirror the gradient layout in one flat buffer, so the optimizer updates every dense layer of
         # the model with ONE launch over (flat_params, accum) instead of one launch per tensor.
         self.flat_params = torch.zeros_like(self.accum)
@@ -368,7 +370,7 @@ class FusedDeepFM:
             float(self.bn.epsilon), float(self.bn.momentum), ptr(self.d1.kernel), ptr(self.d1.bias),
             ptr(self.d2.kernel), ptr(self.d2.bias), ptr(self.dl.kernel), ptr(self.out.kernel), ptr(self.out.bias),
             ptr(buf['logit']), ptr(sb['rows_dummy']), ptr(buf['grad_rows']), ptr(self.accum), ptr(buf['ws']),
-            None, None, 0, 1.0 / W, 1, 2 | part | _step_loss(self.dm) | (0 if part == _lib.DT_STEP_FINISH_ONLY else self.tower_flag),
+            None, None, 0, 1.0 / W, 1, 2 | part | _step_loss(self.dm) | (0 if part == _lib.DT_STEP_FINISH_ONLY else self.tower_flag | self.diag_flag),
             self.emb_dropout if training else 0.0, ptr(self.drop_seed),
             self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()),
             'dt_deepfm_train_step')
@@ -445,14 +447,14 @@ class FusedDeepFM:
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_deepfm_train_step_adam(
-                *head, 2 | _step_loss(self.dm) | self.tower_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | self.tower_flag | self.diag_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_deepfm_train_step(
-                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0) | pre,
+                *head, 1.0, 0, (2 if backward else 1) | _step_loss(self.dm) | ((self.tower_flag | self.diag_flag) if backward else 0) | pre,
                 self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_deepfm_train_step')
         if backward:
@@ -562,6 +564,8 @@ class FusedDCN(FusedDeepFM):
         self.drop_seed = torch.tensor([seed], dtype=torch.int32, device=self.device)
         self.dedupe = os.environ.get('DT_AMD_FUSED_DEDUPE', '1') != '0'
         self.tower_flag = _tower_mfma_flag(dm.config.dnn_params)
+        # diagnostic: s_memtime phase stamps into the workspace (tools/phase_times.py sets DT_AMD_STEP_STAMPS=1)
+        self.diag_flag = _lib.DT_STEP_STAMPS if os.environ.get('DT_AMD_STEP_STAMPS') == '1' else 0
         # parameters mirror the gradient layout in one flat buffer (one optimizer launch, see FusedDeepFM); W1 / W2 precede
         # the [C + 64] output kernel, so they keep their 16-byte alignment whatever C is (the kernels read w3 with scalar loads)
         self.flat_params = torch.zeros_like(self.accum)
@@ -631,14 +635,14 @@ class FusedDCN(FusedDeepFM):
                      all(id(p) in flat[5] for p in opt.params if p is not table))
             dn = (ptr(flat[0]), ptr(flat[2]), ptr(flat[3]), int(flat[4]), float(opt.lr)) if whole else (None, None, None, 0, 0.0)
             check(lib().dt_dcn_train_step_adam(
-                *head, 2 | _step_loss(self.dm) | self.tower_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
+                *head, 2 | _step_loss(self.dm) | self.tower_flag | self.diag_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
                 opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
             check(lib().dt_dcn_train_step(
-                *head, (2 if backward else 1) | _step_loss(self.dm) | (self.tower_flag if backward else 0) | pre,
+                *head, (2 if backward else 1) | _step_loss(self.dm) | ((self.tower_flag | self.diag_flag) if backward else 0) | pre,
                 self.emb_dropout if training else 0.0,
                 ptr(self.drop_seed), self.dense_dropout if training else 0.0, ptr(sw), stream_ptr()), 'dt_dcn_train_step')
         if backward:

@@ -473,6 +473,10 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
 #define DT_STEP_TOWER_X3 0x80
 #define DT_STEP_PREELECTED 0x100
 #define DT_STEP_TOWER_BF16 0x200
+/* phases | DT_STEP_STAMPS (diagnostic): wave 0 of every block of the step's kernels writes s_memtime phase stamps into the
+ * workspace region at dt_deepfm_stamps_offset_floats() (tools/phase_times.py reads them back).  The library reads no
+ * environment variables: every switch of a call is in its arguments. */
+#define DT_STEP_STAMPS 0x400
 int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset, const int32_t* vocab, int B, int F,
                        int64_t* rows_out, void* dedupe_ws, int64_t dedupe_slots, void* stream);
 int64_t dt_deepfm_dedupe_slots(int B, int F);

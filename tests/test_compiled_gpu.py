@@ -175,3 +175,51 @@ def test_preelected_steps_train_like_eager_steps(dev, monkeypatch):
             assert np.allclose(h0.history['loss'], h1.history['loss'], atol=2e-6)
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+@pytest.mark.parametrize('uniform', [False, True])
+def test_compiled_data_parallel_fit_trains_like_the_eager_one(dev, uniform):
+    """under data parallel the loop captures `optimizer.step()` into its own graph on the third step.  That is
+    only valid while the exchanged sparse gradients keep their addresses — with a DEFAULT strategy (assume_uniform_batches
+    False) `allgather_sparse` used to hand back freshly allocated tensors every step, so the replays updated the tables from
+    whatever the capture step's (since recycled) buffers held.  World size 1 through RCCL (force_dp + force_collectives: the
+    flat all-reduce and the sparse all-gathers are really issued), row-sparse tables; the compiled fit must leave the weights
+    of the step-by-step fit under the same strategy."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from deeptables_amd.models import layers as dl
+    from deeptables_amd.parallel import DataParallelStrategy
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    old = dl.DENSE_GRAD_MAX_ELEMS
+    dl.DENSE_GRAD_MAX_ELEMS = 0
+    st_made = []
+    try:
+        df, y = _frame(64 * 12)
+
+        def strategy():
+            st = DataParallelStrategy.from_env('nccl') if not st_made else DataParallelStrategy(device=st_made[0].device)
+            st.force_dp = True
+            st.force_collectives = True
+            st.assume_uniform_batches = uniform
+            st_made.append(st)
+            return st
+        eager = _model('DeepFM', distribute_strategy=strategy())
+        graphed = _model('DeepFM', distribute_strategy=strategy())
+        _fit(eager, df, y, 1)
+        _fit(graphed, df, y, 10)
+        assert eager.compiled_loop is None
+        loop = graphed.compiled_loop
+        assert loop is not None and loop.dp and loop.k == 1 and loop.graph is not None
+        assert loop.opt_graph is not None and not loop._opt_graph_refused      # the persistent exchange path was taken
+        assert graphed.config.distribute_strategy.assume_uniform_batches is uniform   # (restored after every exchange)
+        _same(eager, graphed, tol=2e-6)
+        assert eager.optimizer.t == graphed.optimizer.t == 3 * 12
+    finally:
+        dl.DENSE_GRAD_MAX_ELEMS = old
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -14,6 +14,6 @@ python bench.py --dist zipf --no-cpu-baseline > gpurun_out/final_line_zipf.json 
 python bench.py --model DCN --no-cpu-baseline > gpurun_out/final_line_dcn.json 2> gpurun_out/final_line_dcn.err
 bash tools_prof.sh r02_deepfm --steps 100 --warmup 10 --no-parity > gpurun_out/final_stats_deepfm.txt 2>&1
 bash tools_prof.sh r02_dcn --model DCN --steps 50 --warmup 8 --no-parity > gpurun_out/final_stats_dcn.txt 2>&1
-MODEL=DCN DT_DEEPFM_STAMPS=1 timeout 100 python tools/phase_times.py > gpurun_out/final_dcn_stamps.txt 2>&1
+MODEL=DCN DT_AMD_STEP_STAMPS=1 timeout 100 python tools/phase_times.py > gpurun_out/final_dcn_stamps.txt 2>&1
 timeout 240 python -m pytest tests -q -m gpu 2>&1 | tail -5 > gpurun_out/final_tests.txt
 tail -3 gpurun_out/final_tests.txt; cut -c1-200 gpurun_out/final_line_deepfm.json; grep -o '"traffic_over_algorithmic": [0-9.]*' gpurun_out/deepfm_traffic.json

@@ -1,6 +1,6 @@
-# Phase timing of the fused DeepFM kernels from s_memtime stamps (run with DT_DEEPFM_STAMPS=1 on the GPU box).
+# Phase timing of the fused DeepFM kernels from s_memtime stamps (run with DT_AMD_STEP_STAMPS=1 on the GPU box).
 import os, sys
-os.environ['DT_DEEPFM_STAMPS'] = '1'
+os.environ['DT_AMD_STEP_STAMPS'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
@@ -29,7 +29,7 @@ labels = [{0: 'entry', 1: 'staged', 2: 'gemm1', 3: 'h1 stored', 4: 'gemm2+h2', 5
           {0: 'entry', 1: 'prologue', 2: 'dH1', 3: 'end(dXn)'}] if v1 else \
     [{0: 'entry', 6: 'prologue loads issued', 7: 'bn params in LDS', 1: 'chunk0 staged', 2: 'gemm1 done',
       3: 'h1 in LDS', 4: 'gemm2 + partial logits (DCN: the cross forward = P GEMM + scalar steps)', 5: 'logits/loss/dz', 8: 'end (dH2, dH1, slin)', 13: 'pipelined: xhat tile + dH1 operand staged', 14: 'pipelined: dXn GEMM + partial sums done', 15: 'pipelined: dXn rows stored', 9: 'DCN: gemm2 done, cross vectors in LDS', 10: 'DCN: dH2 / dH1 done (top of the backward)', 11: 'DCN: coefficients + xhat tile in LDS', 12: 'DCN: dXc rows + G = xhat^T coeff stored'},
-     ({0: 'entry (memory waves of k_wgrad_rows)', 3: 'end (rows updated / stored)'} if (model == 'DeepFM' and os.environ.get('DT_STEP_PIPE', '1') != '0') else
+     ({0: 'entry (memory waves of k_wgrad_rows)', 3: 'end (rows updated / stored)'} if model == 'DeepFM' else
       {0: 'entry', 6: 'loads issued', 7: 'dH1 in LDS', 1: 'A regs', 4: 'blk0 MFMAs issued', 5: 'blk0 epilogue done (X etc. staged before it)', 8: 'all blocks done', 3: 'end (rows written)'}),
      {0: 'entry', 1: 'chunks 0,1 issued', 2: 'chunk 0 done', 3: 'K loop done', 4: 'LDS reduce done', 5: 'end (partial stored)', 6: 'pipelined: the matrix waves\' share of the row epilogue done'},
      {0: 'entry', 1: 'ids + hash insert done, row loads issued', 2: 'rows arrived, X stores issued', 3: 'row sums done', 4: 'block barrier', 5: 'end (BN partials)'}]
