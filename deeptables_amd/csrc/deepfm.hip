@@ -136,6 +136,33 @@ constexpr int kSegCap = kElectSlots / 2;     // a block's rows with >= 2 lookups
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// Batch-wide sums without a reduction launch (round 5).  Two sets of accumulators live in the workspace as DOUBLES, split
+// into shards so that at most 64 blocks meet on one cache line (a wave's atomic covers whole lines: ~55 line requests per
+// block, against the 1.3 K stores + the 5 us reduction launch + its boundary they replace):
+//   bnacc [kBnShards][2][CP]   sum_b x and sum_b x^2 of every column of the concat row X (kernel A adds, kernel C's prologue
+//                              forms mean / variance in double: E[x^2] - mean^2 loses 2 log2(|mean| / sigma) of 53 bits)
+//   racc  [kRecShards][stride] the tile kernel's per-tile record entries (Part3: db1, db2, dw3, d w_out, d b_out, loss, the
+//                              d w_lin column sums, the two BN-backward sums sdx / sdxx, DCN's cross record)
+// Every addend is an fp32 value; a shard entry is the double sum of at most 64 of them, which is EXACT unless their
+// magnitudes span more than 2^23 — so the totals do not depend on the order the blocks arrive in, and the rounded fp32
+// results are the same from run to run (what the per-tile records + reduction launch guaranteed before).
+// Life cycle: kernel A zeroes racc (kernel C of the same step adds into it); the launch after kernel C zeroes bnacc for the
+// NEXT step's kernel A — the workspace must be zero-filled once before its first use (dt_deepfm_workspace_bytes).
+constexpr int kBnShards = 8;
+constexpr int kRecShards = 4;
+__device__ __forceinline__ void radd(double* p, float v) { unsafeAtomicAdd(p, (double)v); }
+struct RecSrc {
+    const double* racc;          // [kRecShards][stride]
+    int stride;
+};
+__device__ __forceinline__ float rec_sum(const RecSrc& r, int e) {
+    double v = 0.0;
+#pragma unroll
+    for (int sh = 0; sh < kRecShards; ++sh) v += r.racc[(int64_t)sh * r.stride + e];
+    return (float)v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // A: sparse forward.  One wave = one batch row, 16 waves (16 rows) per block: 8192 waves at B = 8192, all
 //    resident at once (2 blocks of 1024 threads per CU) so the two dependent HBM round trips of a gather
 //    (ids -> table rows) overlap across 32 waves per CU.  The block's 16 rows meet in LDS for the BN statistics.
@@ -148,8 +175,9 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     const void* __restrict__ idx, const float4* __restrict__ table, const int64_t* __restrict__ row_offset,
     const int32_t* __restrict__ vocab, const float* __restrict__ dense, const float* __restrict__ wlin,
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
-    int64_t* __restrict__ rows_out, int* __restrict__ oob, float* __restrict__ bn_partial, DedupeWs dd,
-    float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop, unsigned long long* stamps) {
+    int64_t* __restrict__ rows_out, int* __restrict__ oob, double* __restrict__ bnacc, DedupeWs dd,
+    float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop, unsigned long long* stamps,
+    double* __restrict__ racc_zero, int racc_n) {
     __shared__ __attribute__((aligned(16))) float rowbuf[RPB][kMaxC];
     DT_STAMP(stamps, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -240,35 +268,30 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     }
     __syncthreads();
     DT_STAMP(stamps, 4);
-    // ---- BN statistics of this block's rows: exact two-pass {n, mean, M2} per column ----
+    // ---- BN statistics: this block's rows enter the batch sums (see bnacc above); no return value: nobody waits ----
     const int nrows = min(RPB, dm.B - (int)blockIdx.x * RPB);
+    double* acc = bnacc + (int64_t)((int)blockIdx.x & (kBnShards - 1)) * 2 * dm.CP;
     for (int col = threadIdx.x; col < dm.C; col += blockDim.x) {
-        float sum = 0.f;
-        for (int w = 0; w < nrows; ++w) sum += rowbuf[w][col];
-        const float mean = nrows > 0 ? sum / (float)nrows : 0.f;
-        float m2 = 0.f;
+        double sum = 0.0, sq = 0.0;
         for (int w = 0; w < nrows; ++w) {
-            const float d = rowbuf[w][col] - mean;
-            m2 += d * d;
+            const double x = (double)rowbuf[w][col];
+            sum += x;
+            sq += x * x;
         }
-        float* p = bn_partial + (int64_t)blockIdx.x * 3 * dm.C;
-        p[col] = (float)max(nrows, 0);
-        p[dm.C + col] = mean;
-        p[2 * dm.C + col] = m2;
+        unsafeAtomicAdd(acc + col, sum);
+        unsafeAtomicAdd(acc + dm.CP + col, sq);
     }
+    // the record accumulators of this step's tile kernel start from zero
+    for (int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x; i < racc_n; i += (int)(gridDim.x * blockDim.x))
+        racc_zero[i] = 0.0;
     DT_STAMP(stamps, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
-// B: BN finalize + the MFMA operand layouts of W1 / W2 / W2^T (see the round-2 tower notes below)
-//    BN blocks: 64 columns x 16 waves; lanes run along the columns (256-byte coalesced partial rows), every
-//    wave Chan-merges a slice of the chunk list, the 16 slices meet in LDS.
+// B: the in-step dedupe's election + the MFMA operand layouts of W1 / W2 / W2^T (see the round-2 tower notes below).
+//    (Rounds 1-4 also ran level 1 of the BatchNormalization reduction here; the batch sums are kernel A's atomics now.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kBnSlices = 4;    // level-1 BN reduction blocks per 64-column group (each: 16 waves)
-
 struct PrepOut {
-    float *mean, *rstd, *sc, *beta;               // all padded to CP
-    float* bn2;                                   // [kBnSlices][3][C] level-1 results
     float *W1L, *W2L, *W2TL;                      // MFMA operand layouts of W1 / W2 / W2^T (k_mlp_fwd3)
     const float* W2;
     // split-bf16 tower (tower_x3.h; NULL: not that mode): the bf16 halves of W1 / W2 in the layouts of X3Weights
@@ -279,39 +302,6 @@ struct PrepOut {
     const float *cw, *cb, *w3c;
     int L;
 };
-
-// Merge of K partial results {n_i, mean_i, M2_i} of one column, all K at once (no running recurrence, ONE division):
-//   N = sum n_i,  mean = sum n_i mean_i / N,  M2 = sum [M2_i + n_i (mean_i - mean)^2]
-// (the pairwise Chan update costs two divisions per partial on a serial chain: 10K cycles for 16 slices x 2 columns).
-template <int K>
-__device__ __forceinline__ void bn_merge(const float (&nb)[K], const float (&mb)[K], const float (&qb)[K], float& n,
-                                         float& mean, float& m2) {
-    float ns = 0.f, ms = 0.f;
-#pragma unroll
-    for (int w = 0; w < K; ++w) { ns += nb[w]; ms += nb[w] * mb[w]; }
-    n = ns;
-    mean = ns > 0.f ? ms / ns : 0.f;
-    float q = 0.f;
-#pragma unroll
-    for (int w = 0; w < K; ++w) {
-        const float d = mb[w] - mean;
-        q += qb[w] + nb[w] * d * d;
-    }
-    m2 = q;
-}
-
-// level-2 merge of one column's kBnSlices partial results -> (mean, biased variance)
-__device__ __forceinline__ void bn_merge_slices(const float* __restrict__ bn2, int C, int col, float& mean, float& var) {
-    float nb[kBnSlices], mb[kBnSlices], qb[kBnSlices];
-#pragma unroll
-    for (int w = 0; w < kBnSlices; ++w) {
-        const float* q = bn2 + (int64_t)w * 3 * C + col;
-        nb[w] = q[0]; mb[w] = q[C]; qb[w] = q[2 * C];
-    }
-    float n, m2;
-    bn_merge<kBnSlices>(nb, mb, qb, n, mean, m2);
-    var = n > 0.f ? m2 / n : 0.f;
-}
 
 // One election block of the in-step dedupe (see DedupeWs): block e = (field, hash partition) of a grid whose ids keep
 // e % 8 = the XCD.  Reads the field's row list rows_fm [F][B], turns the rows looked up several times into segments and
@@ -448,15 +438,12 @@ __global__ __launch_bounds__(256) void k_rows_of_ids(const void* __restrict__ id
     }
 }
 
-__global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial, int chunks, DeepFmDims dm,
-                                               float eps, float momentum, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float* __restrict__ moving_mean,
-                                               float* __restrict__ moving_var, const float* __restrict__ W1,
-                                               PrepOut o, int bn_blocks, int layout_blocks, DedupeWs dd,
-                                               int64_t* __restrict__ rows_out, float* __restrict__ grad_rows) {
-    // block order: election | BN level 1 | weight layouts — the election (loads, LDS hash, scan, three barriers) is the longest
-    // chain of the launch and starts first; its block ids keep id % 8 = the XCD (elect_blocks is a multiple of 8)
-    const int elect_blocks = (int)gridDim.x - bn_blocks - layout_blocks;
+__global__ __launch_bounds__(1024) void k_prep(DeepFmDims dm, const float* __restrict__ W1, PrepOut o, int layout_blocks,
+                                               DedupeWs dd, int64_t* __restrict__ rows_out) {
+    // block order: election | weight layouts — the election (loads, LDS hash, scan, three barriers) is the longest chain of
+    // the launch and starts first; its block ids keep id % 8 = the XCD (elect_blocks is a multiple of 8)
+    constexpr int bn_blocks = 0;
+    const int elect_blocks = (int)gridDim.x - layout_blocks;
     const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
     if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots_dyn[];
@@ -558,66 +545,16 @@ __global__ __launch_bounds__(1024) void k_prep(const float* __restrict__ partial
         }
         return;
     }
-    // level 1 of the BN reduction: block = (64-column group, slice of the chunk list); lanes along the columns (256-byte
-    // coalesced partial rows), the block's 16 waves split the slice's chunks so that every partial is loaded in ONE
-    // round trip (<= kBnPerWave per wave; one wave walking the slice in batches paid a round trip per batch: 7 us).
-    // The waves' merged triples meet in LDS, wave 0 merges them.  kBnSlices slices per column group keep ~30 CUs
-    // pulling the 2.6 MB of partials; kernel C merges the kBnSlices results per column in its prologue (level 2).
-    __shared__ float wtri[16][3][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cgroups = (dm.C + 63) >> 6;
-    const int cg = bid % cgroups, slice = bid / cgroups;
-    const int col = cg * 64 + lane;
-    const bool cok = col < dm.C;
-    const int per = (chunks + kBnSlices - 1) / kBnSlices;
-    const int k0 = slice * per, k1 = min(chunks, k0 + per);
-    const int nw = (int)(blockDim.x >> 6);
-    constexpr int kBnPerWave = 8;                 // 16 waves x 8 = 128 chunks per slice in one round; more: further rounds
-    float an = 0.f, am = 0.f, aq = 0.f;
-    for (int kb = k0 + wave * kBnPerWave; kb < k1; kb += nw * kBnPerWave) {
-        float nb[kBnPerWave], mb[kBnPerWave], qb[kBnPerWave];
-#pragma unroll
-        for (int u = 0; u < kBnPerWave; ++u) {
-            const int k = kb + u;
-            const bool ok = cok && k < k1;
-            const float* p = partial + (int64_t)(ok ? k : 0) * 3 * dm.C + (cok ? col : 0);
-            // unconditional loads from a clamped (always valid) address, selected afterwards
-            const float v0 = p[0], v1 = p[dm.C], v2 = p[2 * dm.C];
-            nb[u] = ok ? v0 : 0.f;
-            mb[u] = ok ? v1 : 0.f;
-            qb[u] = ok ? v2 : 0.f;
-        }
-        float bn, bm, bq;
-        bn_merge<kBnPerWave>(nb, mb, qb, bn, bm, bq);
-        const float pn[2] = {an, bn}, pm[2] = {am, bm}, pq[2] = {aq, bq};
-        bn_merge<2>(pn, pm, pq, bn, bm, bq);
-        an = bn; am = bm; aq = bq;
-    }
-    wtri[wave][0][lane] = an; wtri[wave][1][lane] = am; wtri[wave][2][lane] = aq;
-    __syncthreads();
-    if (wave != 0) return;
-    float nb[16], mb[16], qb[16];
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const bool ok = w < nw;
-        nb[w] = ok ? wtri[w][0][lane] : 0.f; mb[w] = ok ? wtri[w][1][lane] : 0.f; qb[w] = ok ? wtri[w][2][lane] : 0.f;
-    }
-    float n, mean, m2;
-    bn_merge<16>(nb, mb, qb, n, mean, m2);
-    if (cok) {
-        float* q = o.bn2 + (int64_t)slice * 3 * dm.C;
-        q[col] = n;
-        q[dm.C + col] = mean;
-        q[2 * dm.C + col] = m2;
-    }
 }
 
 struct MlpParams {
     const float *b1, *W2, *b2, *w3, *wo, *bo, *gamma, *mean, *rstd, *sc, *betap;
     const float *W1, *W1L, *W2L, *W2TL;   // original W1 [C][128]; lane-major operand layouts written by k_prep (see k_mlp_fwd3)
-    // BN level-2 merge inside kernel C (k_bn_final folded in): level-1 results, the layer's beta, eps / momentum, the
-    // moving statistics (updated by block 0, may be NULL) and the padded vectors C publishes for kernels E and D
-    const float *bn2, *beta;
+    // BatchNormalization's statistics inside kernel C: the batch sums kernel A accumulated (bnacc [kBnShards][2][CP] doubles),
+    // the layer's beta, eps / momentum, the moving statistics (updated by block 0, may be NULL) and the padded vectors C
+    // publishes for kernels E and D
+    const double* bnacc;
+    const float* beta;
     float eps, momentum;
     float *moving_mean, *moving_var, *mean_w, *rstd_w, *sc_w, *betap_w;
     float* gammap_w;      // this step's gamma, published like betap: the finishing launch (k_finish_step) reads gamma / beta while
@@ -694,6 +631,20 @@ __host__ __device__ inline Part3 part3_layout(int CP, int L = 0, int g3 = 0) {
     return l;
 }
 
+// mean / biased variance of column `col` of the batch from kernel A's sums (double; see bnacc)
+__device__ __forceinline__ void bn_stats_col(const double* __restrict__ bnacc, int CP, int B, int col, float& mean, float& var) {
+    double sx = 0.0, sq = 0.0;
+#pragma unroll
+    for (int sh = 0; sh < kBnShards; ++sh) {
+        sx += bnacc[(int64_t)sh * 2 * CP + col];
+        sq += bnacc[(int64_t)sh * 2 * CP + CP + col];
+    }
+    const double m = sx / (double)B;
+    const double v = sq / (double)B - m * m;
+    mean = (float)m;
+    var = v > 0.0 ? (float)v : 0.f;
+}
+
 // DCN arguments of the tile kernels (cw == NULL: DeepFM)
 struct DcnArgs {
     const float *cw, *cb;        // Cross kernels / biases [L][C] (layers.py:423-426, stacked)
@@ -724,7 +675,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                                                   float* __restrict__ dH1, float* __restrict__ dH2,
                                                   float* __restrict__ z_out, float* __restrict__ logit_out,
                                                   float* __restrict__ dlogit, float* __restrict__ dz_out,
-                                                  float* __restrict__ part, unsigned long long* stamps, DcnArgs dc,
+                                                  double* __restrict__ part, unsigned long long* stamps, DcnArgs dc,
                                                   float* __restrict__ dxn_out) {
     // G3 with LC > 0 (DCN): the cross network's share of dXn, sum_l coeff[r][l] Wc_l, enters the same GEMM as 16 more K steps
     // (A = the coefficient tile crF, B = the layer vectors in LDS) — round 2 formed it on the VALU (12 K cycles) and sent it
@@ -747,7 +698,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     const int s = lane >> 5, c = lane & 31, n16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kTM;
     const Part3 pl = part3_layout(dm.CP, LC ? dc.L : 0, G3 ? 1 : 0);
-    float* prec = part + (int64_t)blockIdx.x * pl.stride;
+    double* prec = part + (int64_t)((int)blockIdx.x & (kRecShards - 1)) * pl.stride;     // this tile's record entries are ADDED (racc)
 
     // ---- prologue: chunks 0 and 1 of X and W1L (everything else is issued inside the GEMM) ----
     const int qcol = 4 * (tid & 15), srow = tid >> 4;      // staging: this thread owns 4 columns of rows srow, srow + 16
@@ -766,8 +717,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         for (int g8 = 0; g8 < 8; ++g8) bq[1][g8] = w1l[(8 + g8) * 256];
     }
     DT_STAMP(stamps, 6);
-    // BN level 2 behind the loads just issued: mean / rstd of this thread's columns from the 16 level-1 slices (every
-    // block for itself: 48 L2-resident loads and ~100 flops per column)
+    // BN statistics behind the loads just issued: mean / rstd of this thread's columns from kernel A's batch sums (every
+    // block for itself: 16 L2-resident 8-byte loads per column)
     float bnv[4][(CP + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (CP + 255) / 256; ++i) {
@@ -775,7 +726,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         bnv[0][i] = 0.f; bnv[1][i] = 0.f; bnv[2][i] = 0.f; bnv[3][i] = 0.f;
         float rstd = 0.f, var = 0.f;
         if (col < dm.C) {
-            bn_merge_slices(p.bn2, dm.C, col, bnv[0][i], var);
+            bn_stats_col(p.bnacc, dm.CP, dm.B, col, bnv[0][i], var);
             rstd = 1.0f / sqrtf(var + p.eps);
             bnv[1][i] = rstd * p.gamma[col];
             bnv[2][i] = p.beta[col];
@@ -1066,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         if (s == 1) { loss = 0.f; dl = 0.f; }        // lanes 32..63 mirror rows 0..31 (linv/fmv/yv are zero there)
         float aw = dl * zz, ab = dl;                 // d task_output kernel / bias
         loss = wave_sum(loss); aw = wave_sum(aw); ab = wave_sum(ab);
-        if (lane == 0) { prec[pl.loss] = loss / (float)dm.B; prec[pl.dwo] = aw; prec[pl.dbo] = ab; }
+        if (lane == 0) { radd(prec + pl.loss, loss / (float)dm.B); radd(prec + pl.dwo, aw); radd(prec + pl.dbo, ab); }
     }
     lds_barrier();
     DT_STAMP(stamps, 5);
@@ -1085,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         }
         sb += __shfl_xor(sb, 16, 64); sw += __shfl_xor(sw, 16, 64);
         sb += __shfl_xor(sb, 32, 64); sw += __shfl_xor(sw, 32, 64);
-        if (kq == 0) { prec[pl.db2 + 16 * wave + n16] = sb; prec[pl.dw3 + 16 * wave + n16] = sw; }
+        if (kq == 0) { radd(prec + pl.db2 + 16 * wave + n16, sb); radd(prec + pl.dw3 + 16 * wave + n16, sw); }
     }
     lds_barrier();
     {
@@ -1119,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
             colsum += g;
         }
         colsum += __shfl_xor(colsum, 32, 64);
-        if (s == 0) prec[pl.db1 + 32 * wave + c] = colsum;
+        if (s == 0) radd(prec + pl.db1 + 32 * wave + c, colsum);
     }
     // d linear_logit kernel: sum_rows dz * X (raw) for this thread's 4 columns of every chunk, rows srow and srow+16;
     // the 4 row groups of a wave meet by shuffles, the 4 waves in LDS (the Xn tile is dead)
@@ -1146,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
     }
     if constexpr (LC == 0) {
         for (int col = tid; col < CP; col += 256)
-            prec[pl.slin + col] = (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]);
+            radd(prec + pl.slin + col, (xs[col] + xs[CP + col]) + (xs[2 * CP + col] + xs[3 * CP + col]));
     } else {
         // ---- Cross backward in the closed form of the forward (x_L = a_L x0 + c_L, g = dz w3c):
         //   per row, scalars only:  A_L = d/d a_L = g . x0 = dz P[r][L];  for l = L-1 .. 0:  coeff_l = d/d p_l = A_{l+1} a_l,
@@ -1157,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         //   Kernel E' finishes per column:  d w_l = gamma G_l + beta Sco_l + SA_l c_l,  d w3c likewise with Sdz c_L,
         //   d b_j = Sdz w3c + sum_{l > j} SA_l w_l,  and the cross path's two BN-backward sums  sum_l Sco_l Wc_l,  sum_l Wc_l G_l.
         const int L = dc.L;
-        float* rec = prec + pl.cross;
+        double* rec = prec + pl.cross;
         DT_STAMP(stamps, 10);
         float* crS = crA;                  // [32][16] A_{l+1} of every row (columns 0..L-1) and dz (column 15); a row's a_l are
                                            // in registers before its lane overwrites them
@@ -1256,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crF[(4 * st + kq) * 16 + n16], d1, 0, 0, 0);
                 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crS[(4 * st + kq) * 16 + n16], d2, 0, 0, 0);
             }
-            if (kq == 0) { rec[(L + 1) * CP + n16] = d1[0]; rec[(L + 1) * CP + 16 + n16] = d2[0]; }
+            if (kq == 0) { radd(rec + (L + 1) * CP + n16, d1[0]); radd(rec + (L + 1) * CP + 16 + n16, d2[0]); }
         }
         {   // G = Xhat^T . coeff: wave w owns the 16-column tiles w, w + 4, ..; K = the tile's 32 rows (8 steps)
             float bop[8];
@@ -1271,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kq) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
                 if (n16 <= L) {                                   // C layout: Xhat column 16 ct + 4 kq + i, coefficient n16
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rec[n16 * CP + 16 * ct + 4 * kq + i] = d[i];
+                    for (int i = 0; i < 4; ++i) radd(rec + n16 * CP + 16 * ct + 4 * kq + i, d[i]);
                 }
             }
         }
@@ -1330,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
         auto epi_end = [&](int blk) {
             const int col = 32 * blk + c;
             const float a = s1 + __shfl_xor(s1, 32, 64), b = s2 + __shfl_xor(s2, 32, 64);      // the two row halves (s = 0, 1)
-            if (s == 0 && col < dm.C) { prec[pl.sdx + col] = a; prec[pl.sdxx + col] = b; }
+            if (s == 0 && col < dm.C) { radd(prec + pl.sdx + col, a); radd(prec + pl.sdxx + col, b); }
             s1 = 0.f; s2 = 0.f;
         };
         // block `blk` from W1 buffer `buf` into `out`; the previous block's 16 epilogue slices ride between the 16 groups
@@ -1426,68 +1377,43 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
 // partial sums C left in `part` (a block owns 64 consecutive record entries).
 constexpr int kWgCh = 4;     // K steps (= 2 batch rows each) per operand chunk
 
-// the pipelined step's extra outputs of the record reduction: the two BN-backward batch sums, as the gradients dbeta /
-// dgamma (accum) and as the per-column constants of the row-gradient epilogue, cm1 = mean_b(dXn), cm2 = rstd mean_b(dXn xhat)
-struct PipeRed {
-    float *cm1, *cm2;            // [CP] workspace vectors (NULL: not the pipelined step)
-    const float* rstd;
+// the optimizer's dense half for the step's last launch (k_finish_step): flat parameter / slot buffers laid out like the
+// accumulator buffer (fused.py: "parameters mirror the gradient layout"), p == NULL: gradients only
+struct DenseAdam {
+    float *p, *m, *v;
+    float lr_t, b1, b2, eps;
 };
 
-// reducer block `rb`: 64 consecutive entries of the per-tile records, summed over the tiles (4 waves x every 4th tile)
-__device__ __forceinline__ void wgrad_reduce_parts(float* red, int rb, const DeepFmDims& dm, const float* __restrict__ part,
-                                                   int nparts, float* __restrict__ accum, const DeepFmAccum& al, int Lc,
-                                                   const PipeRed& pr) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
-    const Part3 pl = part3_layout(dm.CP, Lc, pr.cm1 ? 1 : 0);
-    {
-        // record entries in the order slin | db1 | db2 | dw3 | dwo | dbo | loss; the block's nw waves take every nw-th
-        // tile, 16 loads in flight per lane (k_reduce_parts: 16 waves x 16 = the 256 tiles of B = 8192 in ONE round trip;
-        // the 4-wave form of round 2 paid 16 dependent round trips, hidden behind k_wgrad4's heavy blocks there)
-        const int e = rb * 64 + lane;
-        float acc = 0.f;
-        if (e < pl.n) {
-            const float* src = part + e;
-            for (int t0 = wave; t0 < nparts; t0 += 16 * nw) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int t = t0 + u * nw;
-                    const float x = src[(int64_t)min(t, nparts - 1) * pl.stride];      // unconditional, clamped
-                    v[u] = t < nparts ? x : 0.f;
-                }
-                acc += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                       (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-            }
-        }
-        red[wave * 64 + lane] = acc;
-        __syncthreads();
-        if (wave == 0 && e < pl.n) {
-            float v = 0.f;
-            for (int w = 0; w < nw; ++w) v += red[w * 64 + lane];
-            int64_t dst = -1;
-            if (e < pl.db1) dst = al.slin + e;
-            else if (e < pl.db2) dst = al.db1 + (e - pl.db1);
-            else if (e < pl.dw3) dst = al.db2 + (e - pl.db2);
-            else if (e < pl.dwo) dst = al.dw3d + (e - pl.dw3);
-            else if (e == pl.dwo) dst = al.dwo;
-            else if (e == pl.dbo) dst = al.dbo;
-            else if (e == pl.loss) dst = al.loss;
-            else if (pl.sdx >= 0 && e >= pl.sdx) {       // pipelined step: the BN-backward batch sums (see PipeRed)
-                const bool xx = e >= pl.sdxx;
-                const int col = e - (xx ? pl.sdxx : pl.sdx);
-                const float invN = 1.0f / (float)dm.B;
-                if (col < dm.C) dst = (xx ? al.dgamma : al.dbeta) + col;
-                if (xx) pr.cm2[col] = col < dm.C ? pr.rstd[col] * v * invN : 0.f;
-                else pr.cm1[col] = col < dm.C ? v * invN : 0.f;
-            }
-            else if (e >= pl.cross) {                    // DCN: G_0 .. G_L | scalars (finished per column by kernel E')
-                const int vec = (e - pl.cross) / dm.CP, col = (e - pl.cross) - vec * dm.CP;
-                if (vec == Lc + 1) { if (col < 32) dst = al.sumc + col; }
-                else if (col < dm.C) dst = vec < Lc ? al.dcw + (int64_t)vec * dm.C + col : al.dw3 + col;
-            }
-            if (dst >= 0) accum[dst] = v;
-        }
+// Where record entry e (Part3 order) lands in the gradient buffer: -1 = nowhere (pads; the d w_lin column sums and DCN's
+// cross record, which the finishing launch's column blocks read from the shards themselves and finish per column)
+__device__ __forceinline__ int64_t record_dst(int e, const Part3& pl, const DeepFmAccum& al, const DeepFmDims& dm, int Lc) {
+    if (e < pl.db1) return -1;                                   // slin (DeepFM; DCN: empty)
+    if (e < pl.db2) return al.db1 + (e - pl.db1);
+    if (e < pl.dw3) return al.db2 + (e - pl.db2);
+    if (e < pl.dwo) return al.dw3d + (e - pl.dw3);
+    if (e == pl.dwo) return al.dwo;
+    if (e == pl.dbo) return al.dbo;
+    if (e == pl.loss) return al.loss;
+    if (pl.sdx >= 0 && e >= pl.sdx) {                            // the BN-backward batch sums = dbeta | dgamma
+        const bool xx = e >= pl.sdxx;
+        const int col = e - (xx ? pl.sdxx : pl.sdx);
+        return col < dm.C ? (xx ? al.dgamma : al.dbeta) + col : -1;
     }
+    return -1;
+}
+
+// One thread finishes record entry e: the shards' sum -> the gradient buffer, and (da.p != NULL: k_finish_step) the
+// Keras-Adam update of that dense element — db1, db2, the dnn part of dw3, d w_out, d b_out, dgamma, dbeta; the `loss` word
+// is a pad of the parameter buffer and takes none.
+__device__ __forceinline__ void finish_record_entry(int e, const RecSrc& rs, const Part3& pl, const DeepFmAccum& al,
+                                                    const DeepFmDims& dm, int Lc, float* __restrict__ accum,
+                                                    const DenseAdam& da) {
+    if (e >= pl.n) return;
+    const int64_t dst = record_dst(e, pl, al, dm, Lc);
+    if (dst < 0) return;
+    const float v = rec_sum(rs, e);
+    accum[dst] = v;
+    if (da.p && dst != al.loss && dst != al.loss + 1) adam_one(da.p, da.m, da.v, dst, v, da.lr_t, da.b1, da.b2, da.eps);
 }
 
 // heavy block `hid` of the weight-gradient GEMMs, run by the block's first 256 threads (4 waves); they meet once, at the
@@ -1626,39 +1552,27 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
     DT_STAMP(stamps, 5);
 }
 
-// R of the pipelined step: the record reduction alone, 16 waves per 64 entries
-__global__ __launch_bounds__(1024) void k_reduce_parts(DeepFmDims dm, const float* __restrict__ part, int nparts,
-                                                       float* __restrict__ accum, DeepFmAccum al, int Lc, PipeRed pr) {
-    __shared__ float red[16 * 64];
-    wgrad_reduce_parts(red, (int)blockIdx.x, dm, part, nparts, accum, al, Lc, pr);
-}
-
 // E': adds up the batch slices of E and finishes the BN / W1 gradients.  With M = Xhat^T dH1 and db1 = colsum(dH1):
 //   dgamma = sum_b dXn xhat = rowdot(W1, M)      dbeta = sum_b dXn = W1 . db1      dW1 = gamma M + beta (x) db1
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
 // waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
 // d linear_logit kernel: field f = its D columns, dense k = one column.
-// the optimizer's dense half for the pipelined step's last launch (k_finish_step): flat parameter / slot buffers laid out
-// like the accumulator buffer (fused.py: "parameters mirror the gradient layout"), p == NULL: gradients only
-struct DenseAdam {
-    float *p, *m, *v;
-    float lr_t, b1, b2, eps;
-};
-
 __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, const DeepFmDims& dm, float* accum,
                                                const DeepFmAccum& al, const float* __restrict__ wpart, int row_blocks,
                                                int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
-                                               const float* __restrict__ w3c, int pipe, floatx2 (*sm)[64],
-                                               const DenseAdam& da, int blk) {
+                                               const float* __restrict__ w3c, const RecSrc& rs, const Part3& pl,
+                                               floatx2 (*sm)[64], const DenseAdam& da, int blk) {
+    // (what the tile kernel summed over the batch — db1, the d w_lin column sums, DCN's cross record — is read from the
+    // record shards here: no launch stands between kernel C and this one for them)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blk == 0 && Lc == 0) {
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
             float v = 0.f;
             if (q < dm.F) {
-                for (int d = 0; d < dm.D; ++d) v += accum[al.slin + q * dm.D + d];
+                for (int d = 0; d < dm.D; ++d) v += rec_sum(rs, pl.slin + q * dm.D + d);
             } else {
-                v = accum[al.slin + dm.F * dm.D + (q - dm.F)];
+                v = rec_sum(rs, pl.slin + dm.F * dm.D + (q - dm.F));
             }
             accum[al.dwlin + q] = v;
             if (da.p) adam_one(da.p, da.m, da.v, al.dwlin + q, v, da.lr_t, da.b1, da.b2, da.eps);
@@ -1674,7 +1588,7 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     float ga = 0.f, be = 0.f;
     if (wave == 0 && !w2) {
         w = *reinterpret_cast<const floatx2*>(W1 + (int64_t)col * kH1 + 2 * lane);
-        d = *reinterpret_cast<const floatx2*>(accum + al.db1 + 2 * lane);
+        d = floatx2{rec_sum(rs, pl.db1 + 2 * lane), rec_sum(rs, pl.db1 + 2 * lane + 1)};
         ga = gamma[col]; be = beta[col];
     }
     // the optimizer's p / m / v of the two elements wave 0 finishes: fetched with the slices (k_finish_step), not after them
@@ -1723,23 +1637,24 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         *reinterpret_cast<floatx2*>(accum + e0) = g;
         if (da.p) adam2(g.x, g.y);
     }
-    if (Lc && pipe) {
-        // pipelined DCN step: lane l <= Lc finishes layer l of this column (lane Lc: the w3c entry) — the gradients, and in
+    if (Lc) {
+        // DCN: lane l <= Lc finishes layer l of this column (lane Lc: the w3c entry) — the gradients, and in
         // k_finish_step their Adam update, of the 2 Lc + 1 elements run side by side (one lane walking them took 13
-        // dependent round trips: 19 us for the launch).  The BN-backward sums are the record reduction's (sdx / sdxx).
-        const float* sc = accum + al.sumc;
+        // dependent round trips: 19 us for the launch).  The BN-backward sums are the tile kernel's (sdx / sdxx).
+        // Cross record (see the cross backward of kernel C): vectors G_0 .. G_L [CP] | scalars [32]: Sco_l at l, SA_l at 16 + l, Sdz at 31
+        const int scal = pl.cross + (Lc + 1) * dm.CP;
         if (lane <= Lc) {
             const int l = lane;
-            const float sdz = sc[31];
+            const float sdz = rec_sum(rs, scal + 31);
             float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
             for (int j = 0; j < Lc; ++j) {
                 const float bj = cb[(int64_t)j * dm.C + col], wj = cw[(int64_t)j * dm.C + col];
                 if (j < l) cl += bj;
-                if (j > l) suf += sc[16 + j] * wj;
+                if (j > l) suf += rec_sum(rs, scal + 16 + j) * wj;
             }
             const int64_t ig = l < Lc ? al.dcw + (int64_t)l * dm.C + col : al.dw3 + col;
-            const float G = accum[ig];
-            const float gw = ga_b * G + be_b * sc[l] + (l < Lc ? sc[16 + l] : sdz) * cl;
+            const float G = rec_sum(rs, pl.cross + l * dm.CP + col);
+            const float gw = ga_b * G + be_b * rec_sum(rs, scal + l) + (l < Lc ? rec_sum(rs, scal + 16 + l) : sdz) * cl;
             const float gb = sdz * w3c[col] + suf;                // d b_l (l < Lc)
             accum[ig] = gw;
             if (l < Lc) accum[al.dcb + (int64_t)l * dm.C + col] = gb;
@@ -1748,43 +1663,6 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
                 if (l < Lc) adam_one(da.p, da.m, da.v, al.dcb + (int64_t)l * dm.C + col, gb, da.lr_t, da.b1, da.b2, da.eps);
             }
         }
-    } else if (lane == 0) {
-        float sumc = 0.f, sumcx = 0.f;
-        if (Lc) {
-            // DCN: the cross gradients of this column from the reduced tile records (see the cross backward of kernel C):
-            // accum[dcw + l C + col] holds G_l, accum[dw3 + col] G_L, accum[sumc + ..] the scalar sums
-            const float* sc = accum + al.sumc;
-            const float sdz = sc[31];
-            float c = 0.f;                                        // c_l = b_0 + .. + b_{l-1}
-            for (int l = 0; l < Lc; ++l) {
-                const float G = accum[al.dcw + (int64_t)l * dm.C + col], w = cw[(int64_t)l * dm.C + col];
-                sumc += sc[l] * w;
-                sumcx += w * G;
-                accum[al.dcw + (int64_t)l * dm.C + col] = ga * G + be * sc[l] + sc[16 + l] * c;
-                c += cb[(int64_t)l * dm.C + col];
-            }
-            const float G = accum[al.dw3 + col], w = w3c[col];
-            sumc += sc[Lc] * w;
-            sumcx += w * G;
-            accum[al.dw3 + col] = ga * G + be * sc[Lc] + sdz * c;
-            float suffix = sdz * w;                               // d b_j = Sdz w3c + sum_{l > j} SA_l w_l
-            for (int j = Lc - 1; j >= 0; --j) {
-                accum[al.dcb + (int64_t)j * dm.C + col] = suffix;
-                suffix += sc[16 + j] * cw[(int64_t)j * dm.C + col];
-            }
-            if (da.p) {      // k_finish_step: this column's cross kernels / biases / w3c entry, once every read of them is done
-                for (int l = 0; l < Lc; ++l) {
-                    const int64_t iw = al.dcw + (int64_t)l * dm.C + col, ib = al.dcb + (int64_t)l * dm.C + col;
-                    adam_one(da.p, da.m, da.v, iw, accum[iw], da.lr_t, da.b1, da.b2, da.eps);
-                    adam_one(da.p, da.m, da.v, ib, accum[ib], da.lr_t, da.b1, da.b2, da.eps);
-                }
-                adam_one(da.p, da.m, da.v, al.dw3 + col, accum[al.dw3 + col], da.lr_t, da.b1, da.b2, da.eps);
-            }
-        }
-        if (!pipe) {         // the pipelined step's record reduction has written both already (sum_b dXn xhat, sum_b dXn)
-            accum[al.dgamma + col] = dg + sumcx;
-            accum[al.dbeta + col] = db + sumc;
-        }
     }
 }
 
@@ -1792,10 +1670,26 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
                                                    const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                    DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
                                                    int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
-                                                   const float* __restrict__ w3c, int pipe) {
+                                                   const float* __restrict__ w3c, RecSrc rs, int col_blocks) {
+    // blocks [0, col_blocks): one per column (E'); the blocks behind them: the record entries -> the gradient buffer
     __shared__ floatx2 sm[4][64];
     const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
-    bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, pipe, sm, none, (int)blockIdx.x);
+    const Part3 pl = part3_layout(dm.CP, Lc, 1);
+    if ((int)blockIdx.x < col_blocks)
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, none, (int)blockIdx.x);
+    else
+        finish_record_entry(((int)blockIdx.x - col_blocks) * (int)blockDim.x + (int)threadIdx.x, rs, pl, al, dm, Lc, accum, none);
+}
+
+// forward-only calls: the record entries (the loss) -> the gradient buffer, and the BN accumulators back to zero for the next
+// step's kernel A (a backward step does that in its weight-gradient launch)
+__global__ __launch_bounds__(256) void k_finish_records(DeepFmDims dm, float* accum, DeepFmAccum al, int Lc, RecSrc rs,
+                                                        double* __restrict__ bnacc_zero, int bnacc_n) {
+    const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+    const Part3 pl = part3_layout(dm.CP, Lc, 0);
+    const int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+    finish_record_entry(i, rs, pl, al, dm, Lc, accum, none);
+    for (int j = i; j < bnacc_n; j += (int)(gridDim.x * blockDim.x)) bnacc_zero[j] = 0.0;
 }
 
 // F: the LAST launch of the pipelined step when the optimizer is handed in (dt_deepfm_train_step_adam with the dense
@@ -1816,8 +1710,9 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
                                                      int small_blocks, int seg_blocks, FinishSeg fs, int Lc,
                                                      const float* __restrict__ cw, const float* __restrict__ cb,
-                                                     const float* __restrict__ w3c) {
+                                                     const float* __restrict__ w3c, RecSrc rs) {
     __shared__ floatx2 sm[4][64];
+    const Part3 pl = part3_layout(dm.CP, Lc, 1);
     // every thread reads lr_t itself (a uniform scalar load, consumed at the end of its dependency chain) instead of one
     // thread + an LDS broadcast behind a barrier at the block's start — one dependent round trip less per block; the
     // barrier before the arrival ticket guarantees every wave of the block HAS read it when the state may advance
@@ -1830,14 +1725,11 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
     if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, 1, sm, da, b);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, da, b);
     } else if (b < col_blocks + small_blocks) {
-        // db1 | db2 | [DCN: the cross part of dw3, finished per column by the blocks above] | dw3 | dwo | dbo | loss | dgamma
-        // | dbeta: final since the record reduction (the d w_lin entries — DCN: the cross kernels / biases — that follow
-        // belong to the blocks above); the `loss` words are pads of the parameter buffer, as in the flat optimizer launch
-        const int64_t i = al.db1 + (int64_t)(b - col_blocks) * blockDim.x + threadIdx.x;
-        if (i < al.dwlin && (i < al.dw3 || i >= al.dw3d))
-            adam_one(da.p, da.m, da.v, i, accum[i], da.lr_t, da.b1, da.b2, da.eps);
+        // one thread per record entry: db1 | db2 | dw3 (dnn part) | dwo | dbo | loss | dbeta | dgamma — summed over the shards,
+        // stored, updated (the d w_lin entries — DCN: the cross kernels / biases — belong to the column blocks above)
+        finish_record_entry((b - col_blocks) * (int)blockDim.x + (int)threadIdx.x, rs, pl, al, dm, Lc, accum, da);
     } else if (fs.seg.nseg) {
         adam_segments(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
                       fs.sstride, sb);
@@ -1874,7 +1766,9 @@ struct RowsAdam {
     int wt;                      // write-through stores (st4_wt)
 };
 struct RowsEpi {
-    const float *dXn, *X, *dz, *S, *wlin, *sc, *mean, *cm1, *cm2;
+    const float *dXn, *X, *dz, *S, *wlin, *sc, *mean, *rstd;
+    RecSrc rs;                   // the tile kernel's record shards: sdx / sdxx = the two BN-backward batch sums
+    int sdx, sdxx;
     const int64_t* rows_out;
     float* grad_rows;
     float grad_scale;
@@ -1905,7 +1799,26 @@ __device__ __forceinline__ void rows_epilogue_wave(unsigned* work, int first_til
     const int chunk_rows = rpw * kRowsUB, chunks = (kTM + chunk_rows - 1) / chunk_rows;
     int dshift = 0;
     while ((1 << dshift) < dm.D) ++dshift;
-    const floatx4 ca = ld4(a.sc + col), cmu = ld4(a.mean + col), c1 = ld4(a.cm1 + col), c2 = ld4(a.cm2 + col);
+    const floatx4 ca = ld4(a.sc + col), cmu = ld4(a.mean + col);
+    // the per-column constants of BatchNormalization's backward, cm1 = mean_b(dXn), cm2 = rstd mean_b(dXn xhat), straight from
+    // the shards of the tile kernel's record sums (rounds 3-4: a reduction launch between kernel C and this one wrote them)
+    floatx4 c1, c2;
+    {
+        typedef double doublex2 __attribute__((ext_vector_type(2)));
+        doublex2 s1[2] = {{0.0, 0.0}, {0.0, 0.0}}, s2[2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+        for (int sh = 0; sh < kRecShards; ++sh) {
+            const double* q = a.rs.racc + (int64_t)sh * a.rs.stride;
+            s1[0] += *reinterpret_cast<const doublex2*>(q + a.sdx + col);
+            s1[1] += *reinterpret_cast<const doublex2*>(q + a.sdx + col + 2);
+            s2[0] += *reinterpret_cast<const doublex2*>(q + a.sdxx + col);
+            s2[1] += *reinterpret_cast<const doublex2*>(q + a.sdxx + col + 2);
+        }
+        const floatx4 rsd = ld4(a.rstd + col);
+        const float invN = 1.0f / (float)dm.B;
+        c1 = floatx4{(float)s1[0][0], (float)s1[0][1], (float)s1[1][0], (float)s1[1][1]} * invN;
+        c2 = rsd * floatx4{(float)s2[0][0], (float)s2[0][1], (float)s2[1][0], (float)s2[1][1]} * invN;
+    }
     const float wl = DCN ? 0.f : a.wlin[f];
     const float lr_t = ad.lr_t_dev ? *ad.lr_t_dev : ad.lr_t_host;
     const unsigned dseed = drop.thr ? *drop.seed : 0u;
@@ -1991,7 +1904,8 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     const float* __restrict__ dH2, int row_blocks, int rows_per_block,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
                                                     RowsEpi ep, RowsAdam ad, EmbDrop drop,
-                                                    unsigned long long* stamps_rows, int matrix_waves_join) {
+                                                    unsigned long long* stamps_rows, int matrix_waves_join,
+                                                    double* __restrict__ bnacc_zero, int bnacc_n) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
     __shared__ unsigned arrived, work[2];
     if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; }
@@ -2003,6 +1917,8 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
         if (stamps_all && threadIdx.x == 0) stamps_all[(int64_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime();
     } else {
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+        // kernel C (the only reader of this step's BN batch sums) is done: the accumulators go back to zero for the next kernel A
+        for (int j = (int)blockIdx.x * 256 + ((int)threadIdx.x - 256); j < bnacc_n; j += (int)gridDim.x * 256) bnacc_zero[j] = 0.0;
         rows_epilogue_wave<DCN>(work, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memtime();
     }
@@ -2032,14 +1948,14 @@ extern "C" int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2) 
 
 // workspace layout (floats)
 struct DeepFmWs {
-    int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnp, bn2, part, stamps, dXc, dXn, cm1,
-        cm2, gammap, x3, total;
+    int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnacc, racc, stamps, dXc, dXn,
+        gammap, x3, total;
+    int64_t bnacc_n, racc_n;          // doubles
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
-    const int blocksA = ceil_div(dm.B, kRowsPerBlockA);
     const int tiles = ceil_div(dm.B, kTM);
     const int64_t rows = (int64_t)tiles * kTM;
     w.X = take(rows * dm.CP);
@@ -2053,13 +1969,14 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.W2TL = take((int64_t)kH1 * kH2);
     w.S = take(rows * dm.D);                        // S[b][d] = sum_f E[b,f,d] (kernel A -> kernel D)
     w.wpart = take((int64_t)256 * 8192);            // k_wgrad4's per-slice partial macro tiles (<= 256 heavy blocks)
-    w.bnp = take((int64_t)blocksA * 3 * dm.C);
-    w.bn2 = take((int64_t)kBnSlices * 3 * dm.C);
-    w.part = take((int64_t)tiles * part3_layout(dm.CP, L, 1).stride);
+    // the batch-sum accumulators (doubles; see bnacc / racc in front of kernel A): zero before the first step, kept by the steps
+    w.bnacc_n = (int64_t)kBnShards * 2 * dm.CP;
+    w.bnacc = take(2 * w.bnacc_n);
+    w.racc_n = (int64_t)kRecShards * part3_layout(dm.CP, L, 1).stride;
+    w.racc = take(2 * w.racc_n);
     w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
-    w.cm1 = take(dm.CP); w.cm2 = take(dm.CP);       // pipelined step: mean_b(dXn), rstd mean_b(dXn xhat)
     w.gammap = take(dm.CP);
     // split-bf16 tower: W1B (3 bf16 parts of CP x 128) | W1R (2 parts) | W2B (3 parts of 128 x 64) | W2R (2 parts)
     w.x3 = take((5 * (int64_t)dm.CP * kH1 + 5 * (int64_t)kH1 * kH2 + 1) / 2 + (2 * kCrossMax + 1) * (int64_t)dm.CP);
@@ -2209,7 +2126,7 @@ static int tower_train_step(
     const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, 0, sample_weight};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
-                 ws + wl.bn2, bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
+                 reinterpret_cast<const double*>(ws + wl.bnacc), bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
                  ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.gammap};
     DT_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)(dcn ? W2 : w3) | (uintptr_t)accum) % 16 == 0,
                "dt_deepfm_train_step: W1 / W2 / w3 / accum must be 16-byte aligned");
@@ -2272,8 +2189,10 @@ static int tower_train_step(
         return rb < 1 ? 1 : rb;
     };
     if (finish_only) {
-        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, wgrad_row_blocks(), Lc, cross_w, cross_b, w3, 1);
+        const int rec_blocks_f = ceil_div(part3_layout(dm.CP, Lc, 1).n, 256);
+        const RecSrc rsrc_f{reinterpret_cast<const double*>(ws + wl.racc), part3_layout(dm.CP, Lc, 1).stride};
+        hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks_f), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
+                           accum, al, ws + wl.wpart, wgrad_row_blocks(), Lc, cross_w, cross_b, w3, rsrc_f, dm.C + kH2);
         if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
         return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
     }
@@ -2286,11 +2205,13 @@ static int tower_train_step(
     DedupeWs ddA = dd;
     if (preelected) ddA.rows_fm = nullptr;
     const int blocksA = ceil_div(B, kRowsPerBlockA);
+    double* bnacc = reinterpret_cast<double*>(ws + wl.bnacc);
+    double* racc = reinterpret_cast<double*>(ws + wl.racc);
 #define DT_A(KIND, L)                                                                                        \
     hipLaunchKernelGGL((k_sparse_fwd<KIND, L, kRowsPerBlockA>), dim3(blocksA), dim3(64 * kRowsPerBlockA), 0, st, idx, \
                        (const float4*)table, row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, \
-                       preelected ? (int64_t*)nullptr : rows_out, oob_count, ws + wl.bnp, ddA, grad_rows, ws + wl.S, drop, \
-                       stamps ? stamps + (int64_t)tiles * 48 : nullptr)
+                       preelected ? (int64_t*)nullptr : rows_out, oob_count, bnacc, ddA, grad_rows, ws + wl.S, drop, \
+                       stamps ? stamps + (int64_t)tiles * 48 : nullptr, racc, (int)wl.racc_n)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
@@ -2301,7 +2222,6 @@ static int tower_train_step(
 #undef DT_A_L
 #undef DT_A
     // B
-    const int bn_blocks = ceil_div(dm.C, 64) * kBnSlices;
     // split-bf16 tower (DT_STEP_TOWER_X3): the DeepFM tile kernel of the pipelined backward step (DCN keeps the fp32 kernel)
     const bool x3 = x3_flag && pipe && dm.CP <= 512 && x3_fits(dm.CP);      // (wider rows: the fp32 tile kernel)
     __bf16* x3base = reinterpret_cast<__bf16*>(ws + wl.x3);
@@ -2309,15 +2229,13 @@ static int tower_train_step(
     __bf16 *x3_w1b = x3base, *x3_w1r = x3base + 3 * n1, *x3_w2b = x3base + 5 * n1, *x3_w2r = x3base + 5 * n1 + 3 * n2;
     float* x3_cwp = ws + wl.x3 + (5 * n1 + 5 * n2 + 1) / 2;
     const X3Weights xw{x3_w1b, n1, x3_w1r, n1, x3_w2b, n2, x3_w2r, n2, x3_cwp};
-    PrepOut po{ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap, ws + wl.bn2, ws + wl.W1L, ws + wl.W2L,
+    PrepOut po{ws + wl.W1L, ws + wl.W2L,
                ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2,
                x3 && dcn ? x3_cwp : nullptr, cross_w, cross_b, w3, Lc};
     const int elect_blocks = (dd.rows_fm && !preelected) ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = elect_blocks ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-    hipLaunchKernelGGL(k_prep, dim3(bn_blocks + 56 + elect_blocks), dim3(1024), ldsB, st, ws + wl.bnp, blocksA, dm, bn_eps,
-                       bn_momentum, bn_gamma, bn_beta, bn_moving_mean, bn_moving_var, W1, po, bn_blocks, 56, dd, rows_out,
-                       grad_rows);
+    hipLaunchKernelGGL(k_prep, dim3(56 + elect_blocks), dim3(1024), ldsB, st, dm, W1, po, 56, dd, rows_out);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
         size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
@@ -2329,22 +2247,22 @@ static int tower_train_step(
             hipFuncSetAttribute((const void*)k_mlp_fwd3<N, kCrossMax, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
             hipLaunchKernelGGL((k_mlp_fwd3<N, kCrossMax, true>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, \
                                ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
-                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);      \
+                               logit_out, ws + wl.dlogit, ws + wl.dz, racc, stamps, dca, ws + wl.dXn);      \
         } else if (dcn) {                                                                                           \
             hipFuncSetAttribute((const void*)k_mlp_fwd3<N, kCrossMax>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
             hipLaunchKernelGGL((k_mlp_fwd3<N, kCrossMax>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm,     \
                                ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,         \
-                               logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, nullptr);          \
+                               logit_out, ws + wl.dlogit, ws + wl.dz, racc, stamps, dca, nullptr);          \
         } else if (pipe) {                                                                                          \
             hipFuncSetAttribute((const void*)k_mlp_fwd3<N, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
             hipLaunchKernelGGL((k_mlp_fwd3<N, 0, true>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin, \
                                ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,           \
-                               ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);                 \
+                               ws + wl.dlogit, ws + wl.dz, racc, stamps, dca, ws + wl.dXn);                 \
         } else {                                                                                                    \
             hipFuncSetAttribute((const void*)k_mlp_fwd3<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC); \
             hipLaunchKernelGGL((k_mlp_fwd3<N, 0>), dim3(tiles), dim3(256), ldsC, st, ws + wl.X, mp, dm, ws + wl.lin, \
                                ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z, logit_out,           \
-                               ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, nullptr);                     \
+                               ws + wl.dlogit, ws + wl.dz, racc, stamps, dca, nullptr);                     \
         }                                                                                                           \
         break;
 #define DT_CXL(N, LCV, ONEV)                                                                                        \
@@ -2352,7 +2270,7 @@ static int tower_train_step(
         hipFuncSetAttribute((const void*)k_tower_x3<N, LCV, ONEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsX); \
         hipLaunchKernelGGL((k_tower_x3<N, LCV, ONEV>), dim3(tiles), dim3(512), ldsX, st, ws + wl.X, mp, xw, dm,     \
                            ws + wl.lin, ws + wl.fm, y, ws + wl.H1, ws + wl.dH1, ws + wl.dH2, ws + wl.z,             \
-                           logit_out, ws + wl.dlogit, ws + wl.dz, ws + wl.part, stamps, dca, ws + wl.dXn);          \
+                           logit_out, ws + wl.dlogit, ws + wl.dz, racc, stamps, dca, ws + wl.dXn);          \
     } while (0)
 #define DT_CX(N)                                                                                                    \
     case N: {                                                                                                       \
@@ -2370,19 +2288,18 @@ static int tower_train_step(
 #undef DT_C
     }
     const Part3 pl3 = part3_layout(dm.CP, Lc, pipe ? 1 : 0);
-    const PipeRed no_pr{nullptr, nullptr, nullptr};
+    const RecSrc rsrc{racc, pl3.stride};                  // (the shard stride is the producing tile kernel's: its own layout's)
+    const int rec_blocks = ceil_div(pl3.n, 256);          // one thread per record entry (finish_record_entry)
     if (pipe) {
-        // R: the per-tile records -> dense gradients, the BN-backward batch sums and the epilogue's per-column constants
-        const PipeRed pr{ws + wl.cm1, ws + wl.cm2, ws + wl.rstd};
-        hipLaunchKernelGGL(k_reduce_parts, dim3(ceil_div(pl3.n, 64)), dim3(1024), 0, st, dm, ws + wl.part, tiles, accum, al, Lc,
-                           pr);
+        // (rounds 3-4 ran a reduction launch R here: the tile kernel's record entries are atomics into racc now, and their
+        // consumers — the row epilogue's two per-column constants, the finishing launch — sum the shards themselves)
         // E + D: one 512-thread block per CU (see k_wgrad_rows)
         const int nmac = (dm.CP >> 6) + 1;
         const int row_blocks = wgrad_row_blocks();
         const int rows_per_block = ((B + row_blocks - 1) / row_blocks + 7) & ~7;
         const size_t ldsE = (size_t)4 * 8192 * sizeof(float);
-        const RowsEpi ep{ws + wl.dXn, ws + wl.X, ws + wl.dz, ws + wl.S, w_lin, ws + wl.sc, ws + wl.mean, ws + wl.cm1,
-                         ws + wl.cm2, rows_out, grad_rows, grad_rows_scale, grad_rows_field_major};
+        const RowsEpi ep{ws + wl.dXn, ws + wl.X, ws + wl.dz, ws + wl.S, w_lin, ws + wl.sc, ws + wl.mean, ws + wl.rstd,
+                         rsrc, pl3.sdx, pl3.sdxx, rows_out, grad_rows, grad_rows_scale, grad_rows_field_major};
         // (measured in round 3: write-through row-update stores 118.1 vs 114.5 us per step, write-through tile outputs no
         // change — the kernel boundaries do not wait for this data: plain stores)
         RowsAdam ad = adam ? *adam : RowsAdam{nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f, 0.f, 0};
@@ -2392,13 +2309,13 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n);
         } else {
             hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
             hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n);
         }
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
@@ -2408,7 +2325,7 @@ static int tower_train_step(
                        (long long)want_flat);
             // 512 blocks: 1.5 us faster with uniform ids (878 segments), 1024: 4.6 us faster with Zipf ids (15 K segments)
             const int seg_blocks = 1024;
-            const int small_blocks = ceil_div(al.dwlin - al.db1, 256);
+            const int small_blocks = rec_blocks;
             const DedupeLayout dl = dedupe_layout(B, F);
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
                                adam->table, adam->m, adam->v, grad_rows, adam->sstride, D};
@@ -2416,18 +2333,18 @@ static int tower_train_step(
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
-                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3);
+                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc);
         } else if (!skip_finish) {
-            // E': slices added up, dW1 / dW2 / d w_lin finished (dgamma / dbeta are R's)
-            hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                               accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, 1);
+            // E': slices added up, dW1 / dW2 / d w_lin finished; the record entries (db1 .. dgamma / dbeta) -> accum
+            hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
+                               accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, rsrc, dm.C + kH2);
         }
         if ((drop.thr || drop.thr_dense) && !skip_finish)
             hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
     } else {
         // forward only: reduce just the loss (the other reduced entries are ignored by the caller)
-        hipLaunchKernelGGL(k_reduce_parts, dim3(ceil_div(pl3.n, 64)), dim3(1024), 0, st, dm, ws + wl.part, tiles, accum, al, Lc,
-                           no_pr);
+        hipLaunchKernelGGL(k_finish_records, dim3(max(rec_blocks, 8)), dim3(256), 0, st, dm, accum, al, Lc, rsrc, bnacc,
+                           (int)wl.bnacc_n);
     }
     return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                                                   float* __restrict__ dH1, float* __restrict__ dH2,
                                                   float* __restrict__ z_out, float* __restrict__ logit_out,
                                                   float* __restrict__ dlogit, float* __restrict__ dz_out,
-                                                  float* __restrict__ part, unsigned long long* stamps, DcnArgs dc,
+                                                  double* __restrict__ part, unsigned long long* stamps, DcnArgs dc,
                                                   float* __restrict__ dxn_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DT_STAMP(stamps, 0);
@@ -124,17 +124,17 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     const int n16 = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.x * kTM;
     const Part3 pl = part3_layout(dm.CP, LC ? dc.L : 0, 1);
-    float* prec = part + (int64_t)blockIdx.x * pl.stride;
+    double* prec = part + (int64_t)((int)blockIdx.x & (kRecShards - 1)) * pl.stride;     // this tile's record entries are ADDED (racc)
 
-    // ---- prologue.  Request order = the order of use: this thread's BN level-1 slices (needed first, behind one L2 round
-    //      trip), the X tile (one row, NCH x 4 columns per thread), the first GEMM1 weights, then the small vectors ----
+    // ---- prologue.  Request order = the order of use: this thread's column of kernel A's batch sums (needed first, behind
+    //      one L2 round trip), the X tile (one row, NCH x 4 columns per thread), the first GEMM1 weights, then the small vectors ----
     const int srow = tid >> 4, qcol = 4 * (tid & 15);
     const int bcol = min(tid, dm.C - 1);
-    float bnn[kBnSlices], bnm[kBnSlices], bnq[kBnSlices];
+    double bsx[kBnShards], bsq[kBnShards];
 #pragma unroll
-    for (int w = 0; w < kBnSlices; ++w) {
-        const float* q = p.bn2 + (int64_t)w * 3 * dm.C + bcol;
-        bnn[w] = q[0]; bnm[w] = q[dm.C]; bnq[w] = q[2 * dm.C];
+    for (int w = 0; w < kBnShards; ++w) {
+        bsx[w] = p.bnacc[(int64_t)w * 2 * dm.CP + bcol];
+        bsq[w] = p.bnacc[(int64_t)w * 2 * dm.CP + dm.CP + bcol];
     }
     const float gam = p.gamma[bcol], bet = p.beta[bcol];
     floatx4 xv[NCH];                                              // raw X, kept to the end (xhat, d w_lin)
@@ -162,14 +162,17 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         }
     }
     DT_STAMP(stamps, 6);
-    // BN level 2: mean / rstd of this thread's column from the level-1 slices (every block for itself)
+    // BN statistics: mean / rstd of this thread's column from the batch sums (every block for itself; double: see bnacc)
     {
         const int col = tid;
         float mean = 0.f, sc = 0.f, be = 0.f, rstd = 0.f, var = 0.f;
         if (col < dm.C) {
-            float n, m2;
-            bn_merge<kBnSlices>(bnn, bnm, bnq, n, mean, m2);
-            var = n > 0.f ? m2 / n : 0.f;
+            double sx = 0.0, sq = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBnShards; ++w) { sx += bsx[w]; sq += bsq[w]; }
+            const double md = sx / (double)dm.B, vd = sq / (double)dm.B - md * md;
+            mean = (float)md;
+            var = vd > 0.0 ? (float)vd : 0.f;
             rstd = 1.0f / sqrtf(var + p.eps);
             sc = rstd * gam;
             be = bet;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
         if (s == 1) { loss = 0.f; dl = 0.f; }
         float aw = dl * zz, ab = dl;                     // d task_output kernel / bias
         loss = wave_sum(loss); aw = wave_sum(aw); ab = wave_sum(ab);
-        if (lane == 0) { prec[pl.loss] = loss * invB; prec[pl.dwo] = aw; prec[pl.dbo] = ab; }
+        if (lane == 0) { radd(prec + pl.loss, loss * invB); radd(prec + pl.dwo, aw); radd(prec + pl.dbo, ab); }
     }
     lds_barrier();
     DT_STAMP(stamps, 5);
@@ -551,8 +554,8 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 X3_LO(dM[t], al, w2r[g][0]);
             }
         if (tid < kH2) {
-            prec[pl.db2 + tid] = cs[tid] + cs[2 * kH2 + tid];
-            prec[pl.dw3 + tid] = cs[kH2 + tid] + cs[3 * kH2 + tid];
+            radd(prec + pl.db2 + tid, cs[tid] + cs[2 * kH2 + tid]);
+            radd(prec + pl.dw3 + tid, cs[kH2 + tid] + cs[3 * kH2 + tid]);
         }
         {
             const int m = m0 + (tid >> 4);
@@ -563,13 +566,13 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += slp[w * CP + col];
-                prec[pl.slin + col] = v;
+                radd(prec + pl.slin + col, v);
             }
         } else {
             // the tile's cross record (k_finish_step turns it into d w_l, d b_j, d w3c and the cross path's BN-backward sums):
             //   G_l = sum_r coeff[r][l] xhat[r]  (fp32 MFMA, K = the 32 rows),  Sco_l, SA_l, Sdz = ones^T . [coeff | A, dz]
             const int L = dc.L;
-            float* rec = prec + pl.cross;
+            double* rec = prec + pl.cross;
             const float* crS = crA;
             if (wave == 7) {
                 floatx4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                     d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crF[(4 * st + kg) * 16 + n16], d1, 0, 0, 0);
                     d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, crS[(4 * st + kg) * 16 + n16], d2, 0, 0, 0);
                 }
-                if (kg == 0) { rec[(L + 1) * CP + n16] = d1[0]; rec[(L + 1) * CP + 16 + n16] = d2[0]; }
+                if (kg == 0) { radd(rec + (L + 1) * CP + n16, d1[0]); radd(rec + (L + 1) * CP + 16 + n16, d2[0]); }
             }
             float bop[8];
 #pragma unroll
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kg) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
                 if (n16 <= L) {                                   // C layout: xhat column 16 ct + 4 kg + i, coefficient n16
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rec[n16 * CP + 16 * ct + 4 * kg + i] = d[i];
+                    for (int i = 0; i < 4; ++i) radd(rec + n16 * CP + 16 * ct + 4 * kg + i, d[i]);
                 }
             }
         }
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 colsum += g;
             }
         colsum = row_pair16(colsum, false);
-        if (kg == 0) prec[pl.db1 + 16 * wave + n16] = colsum;
+        if (kg == 0) radd(prec + pl.db1 + 16 * wave + n16, colsum);
     }
     lds_barrier();
     DT_STAMP(stamps, 8);
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                     xs[(16 * t + 4 * kg + r) * XS + col] = gx;      // dXn replaces xhat in place (this lane's own entries)
                 }
             s1 = row_pair16(s1, false); s2 = row_pair16(s2, false);
-            if (kg == 0 && col < dm.C) { prec[pl.sdx + col] = s1; prec[pl.sdxx + col] = s2; }
+            if (kg == 0 && col < dm.C) { radd(prec + pl.sdx + col, s1); radd(prec + pl.sdxx + col, s2); }
         };
         // buffer ids are literals: the operand arrays stay in registers (C <= 512: at most 32 tiles, 4 per wave)
         if (wave < NT) tile(0, wave);

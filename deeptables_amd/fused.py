@@ -244,7 +244,7 @@ class FusedDeepFM:
             if nbytes < 0:
                 raise _lib.DtHipError('fused DeepFM step: unsupported shape')
             dev = self.device
-            b = {'ws': torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev),
+            b = {'ws': torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev),   # zero-filled once: the batch-sum accumulators
                  'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
                  'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
                  'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),
@@ -583,7 +583,7 @@ class FusedDCN(FusedDeepFM):
             if nbytes < 0:
                 raise _lib.DtHipError('fused DCN step: unsupported shape')
             dev = self.device
-            b = {'ws': torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev),
+            b = {'ws': torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev),   # zero-filled once: the batch-sum accumulators
                  'logit': torch.empty((B, 1), dtype=torch.float32, device=dev),
                  'rows': torch.empty((B, self.F), dtype=torch.int64, device=dev),
                  'grad_rows': torch.empty((B, self.F, self.D), dtype=torch.float32, device=dev),

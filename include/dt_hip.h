@@ -495,7 +495,7 @@ int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
  * dt_deepfm_train_step (workspace: dt_dcn_workspace_bytes).                                                        */
 int dt_dcn_supported(int B, int F, int D, int Nd, int H1, int H2, int L);
 int64_t dt_dcn_workspace_bytes(int B, int F, int D, int Nd, int L);
-int64_t dt_dcn_stamps_offset_floats(int B, int F, int D, int Nd, int L);   /* DT_DEEPFM_STAMPS diagnostics */
+int64_t dt_dcn_stamps_offset_floats(int B, int F, int D, int Nd, int L);   /* DT_STEP_STAMPS diagnostics */
 int64_t dt_dcn_accum_floats(int F, int D, int Nd, int L);
 int dt_dcn_accum_offsets(int F, int D, int Nd, int L, int64_t* out12_host);
 int dt_dcn_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,
@@ -520,9 +520,13 @@ int dt_dcn_train_step_adam(const void* idx, int idx_kind, float* table, const in
                            const float* sample_weight, float* adam_m, float* adam_v, int slot_stride,
                            void* adam_state, float lr_t, float beta1, float beta2, float eps, float* dense_p,
                            float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
+/* workspace: dt_deepfm_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED ONCE before its first use (hipMemset / torch.zeros):
+ * it holds the step's batch-sum accumulators (BatchNormalization's sum x / sum x^2 per column, the tile kernel's record sums),
+ * which the launches add into with double-precision atomics and hand back zeroed — a step leaves the invariant as it found it,
+ * so the same workspace serves every following call (any phases) without further initialisation. */
 int64_t dt_deepfm_workspace_bytes(int B, int F, int D, int Nd);
 int64_t dt_deepfm_accum_floats(int F, int D, int Nd);
-/* debugging aid: offset (floats) of the per-block phase timestamps written when DT_DEEPFM_STAMPS is set */
+/* debugging aid: offset (floats) of the per-block phase timestamps written with phases | DT_STEP_STAMPS */
 int64_t dt_deepfm_stamps_offset_floats(int B, int F, int D, int Nd);
 int dt_deepfm_accum_offsets(int F, int D, int Nd, int64_t* out11_host);
 int dt_deepfm_train_step(const void* idx, int idx_kind, const float* table, const int64_t* row_offset,
