@@ -138,6 +138,7 @@ SIGNATURES = {
     'dt_deepfm_dedupe_slots': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_bytes': (_c_i64, [_c_int, _c_int]),
     'dt_deepfm_dedupe_segments': (_c_int, [_c_int, _c_int, _ptr]),
+    'dt_deepfm_dedupe_overflow_offset': (_c_i64, [_c_int, _c_int]),
     'dt_dcn_supported': (_c_int, [_c_int] * 7),
     'dt_dcn_workspace_bytes': (_c_i64, [_c_int] * 5),
     'dt_dcn_stamps_offset_floats': (_c_i64, [_c_int] * 5),

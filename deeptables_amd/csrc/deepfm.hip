@@ -112,7 +112,7 @@ __device__ __forceinline__ float4 emb_drop4(float4 v, unsigned seed, unsigned th
     return v;
 }
 
-constexpr int kElectSlots = 8192;     // LDS hash of one election block (64 KB); also the largest batch the in-step dedupe takes
+constexpr int kElectSlots = 8192;     // LDS hash of one election block (64 KB); batches up to this size keep per-block segment regions
 struct DedupeWs {
     int64_t* rows_fm;            // [F][B] scratch (NULL: no dedupe)
     int parts_log2;              // hash partitions per field
@@ -124,6 +124,10 @@ struct DedupeWs {
     int* seg_off;                // first entry in seg_list (absolute)
     int* seg_cnt;
     int* seg_list;               // [elect blocks][B] lookups (b*F + f)
+    // B > kElectSlots: regions are per FIELD (seg_* [fields padded to 8][B / 2], seg_list [fields padded to 8][B]); a block
+    // reserves its share through these cursors (seg_cur doubles as the consumers' nseg array); NULL: per-block regions
+    int *seg_cur, *list_cur;
+    int* overflow;               // lookups that found their election table full (see elect_block); NULL: not counted
 };
 constexpr int kSegCap = kElectSlots / 2;     // a block's rows with >= 2 lookups: at most B / 2
 
@@ -284,6 +288,10 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     // the record accumulators of this step's tile kernel start from zero
     for (int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x; i < racc_n; i += (int)(gridDim.x * blockDim.x))
         racc_zero[i] = 0.0;
+    if (blockIdx.x == 0 && dd.seg_cur && (int)threadIdx.x < ((dm.F + 7) & ~7)) {     // the election's region cursors (B > kElectSlots)
+        dd.seg_cur[threadIdx.x] = 0;
+        dd.list_cur[threadIdx.x] = 0;
+    }
     DT_STAMP(stamps, 5);
 }
 
@@ -306,113 +314,182 @@ struct PrepOut {
 // One election block of the in-step dedupe (see DedupeWs): block e = (field, hash partition) of a grid whose ids keep
 // e % 8 = the XCD.  Reads the field's row list rows_fm [F][B], turns the rows looked up several times into segments and
 // marks their members -1 in rows_out.  `eslots`: kElectSlots 64-bit LDS slots + bitmap + scan scratch.
-__device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, const DeepFmDims& dm,
-                                            int64_t* __restrict__ rows_out) {
-                unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
-        int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]
-        // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
-        // so the field's row list is fetched into ONE L2 instead of eight
-        const int e = (int)blockIdx.x;
-        const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
-        const int f = 8 * (j >> dd.parts_log2) + ((int)blockIdx.x & 7);
-        if (f >= dm.F) {
-            if (threadIdx.x == 0) dd.nseg[e] = 0;
-            return;
-        }
-        const int tid = threadIdx.x;
-        const int64_t* rf = dd.rows_fm + (int64_t)f * dm.B;
-        constexpr int kMine = kElectSlots / 1024;             // lookups a thread can meet (B <= kElectSlots, 1024 threads)
-        int myslot[kMine];
-        int64_t rowv[kMine];
-#pragma unroll
-        for (int u = 0; u < kMine; ++u) {                     // all of the thread's row loads in flight, the LDS clear below them
-            const int b = tid + 1024 * u;
-            rowv[u] = rf[min(b, dm.B - 1)];
-        }
-        for (int i = tid; i < kElectSlots; i += blockDim.x) eslots[i] = 0ULL;
-        if (tid < kElectSlots / 32) multi[tid] = 0u;
+//   NT    threads that run it: 1024 = a whole block of the prep launch (hardware barriers), 256 = the four matrix waves of a
+//         weight-gradient block running the NEXT step's election in their idle time (k_wgrad_rows; they meet at an LDS counter:
+//         the block's memory waves must not be held at a hardware barrier)
+//   any B: the field's B lookups are walked in chunks of NT x kElU (round 4 took B <= 8192 = one chunk of a 1024-thread block,
+//         slots kept in registers); pass 3 finds a lookup's slot again by probing.  B <= kElectSlots keeps round 4's private
+//         regions (no global counter: a returning device-scope atomic in the middle of the chain costs ~2 us); beyond that a
+//         block's segments / list entries are placed in its FIELD's region through two returning atomics (dd.seg_cur /
+//         dd.list_cur, zeroed by the launch that wrote rows_fm) — per-block regions would take eblocks x B entries.
+// Termination: a block holds at most kElectSlots distinct rows.  B <= kElectSlots guarantees it; for larger batches the hash
+// partitions (~1024 lookups each) would have to be 8x over-full — a lookup that finds the table full is counted in
+// dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row (-> updated as if looked up once).
+constexpr int kElU = 8;               // lookups per thread and chunk, all loads in flight
+struct ElectSync {
+    unsigned* cnt;                    // LDS word of the soft barrier (NT = 256), zeroed by the caller
+    unsigned target;
+};
+template <int NT, bool SOFT>
+__device__ __forceinline__ void elect_barrier(ElectSync& sy) {
+    if constexpr (SOFT) {
+        // LDS operations of a wave complete in order: the arrival (ds_add) follows everything the wave wrote before it
+        sy.target += NT / 64;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) atomicAdd(sy.cnt, 1u);
+        while (*reinterpret_cast<volatile unsigned*>(sy.cnt) < sy.target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    } else {
         __syncthreads();
-        // pass 1: claim (CAS) / count (atomicAdd); the SECOND lookup of a row flags its slot in the bitmap
+    }
+}
+
+template <int NT, bool SOFT>
+__device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
+                                            int64_t* __restrict__ rows_out, ElectSync sy) {
+    unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
+    int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases
+    // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
+    // so the field's row list is fetched into ONE L2 instead of eight
+    const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
+    const int f = 8 * (j >> dd.parts_log2) + (e & 7);
+    if (f >= F) {
+        if (tid == 0 && !dd.seg_cur) dd.nseg[e] = 0;
+        return;
+    }
+    const int64_t* rf = dd.rows_fm + (int64_t)f * B;
+    constexpr int kChunk = NT * kElU;
+    const int nchunks = (B + kChunk - 1) / kChunk;
+    int64_t rowv[kElU];
+    auto load_chunk = [&](int ch) {                       // all of the thread's row loads of the chunk in flight
 #pragma unroll
-        for (int u = 0; u < kMine; ++u) {
-            myslot[u] = -1;
-            const int64_t row = rowv[u];
-            if (tid + 1024 * u >= dm.B || row < 0) continue;
-            const unsigned h = ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u;
-            if ((int)((h >> 13) >> (19 - dd.parts_log2)) != part) continue;          // top bits of h: the partition
-            const unsigned long long key = (unsigned long long)(row + 1) << 24;
+        for (int u = 0; u < kElU; ++u) rowv[u] = rf[min(ch * kChunk + tid + NT * u, B - 1)];
+    };
+    auto mine = [&](int ch, int u, unsigned& h) {         // is lookup (chunk, u) of this thread one of this block's?
+        const int b = ch * kChunk + tid + NT * u;
+        const int64_t row = rowv[u];
+        if (b >= B || row < 0) return false;
+        h = ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u;
+        return (int)((h >> 13) >> (19 - dd.parts_log2)) == part;               // top bits of h: the partition
+    };
+    load_chunk(0);
+    for (int i = tid; i < kElectSlots; i += NT) eslots[i] = 0ULL;
+    for (int i = tid; i < kElectSlots / 32; i += NT) multi[i] = 0u;
+    elect_barrier<NT, SOFT>(sy);
+    // pass 1: claim (CAS) / count (atomicAdd); the SECOND lookup of a row flags its slot in the bitmap
+    int lost = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch) load_chunk(ch);
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) {
+            unsigned h;
+            if (!mine(ch, u, h)) continue;
+            const unsigned long long key = (unsigned long long)(rowv[u] + 1) << 24;
             unsigned slot = h & (kElectSlots - 1);
-            for (;;) {                                        // at most B <= kElectSlots distinct rows: always terminates
+            int probes = 0;
+            for (;; ++probes) {
+                if (probes == kElectSlots) { ++lost; break; }                  // table full (B > kElectSlots only)
                 const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, key | 1ULL);
                 if (prev == 0ULL) break;
-                if ((prev >> 24) == (unsigned long long)(row + 1)) {
+                if ((prev >> 24) == (unsigned long long)(rowv[u] + 1)) {
                     const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
                     if ((old & 0xffffffULL) == 1ULL) atomicOr(&multi[slot >> 5], 1u << (slot & 31));
                     break;
                 }
                 slot = (slot + 1) & (kElectSlots - 1);
             }
-            myslot[u] = (int)slot;
         }
-        __syncthreads();
-        // pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one
-        // exclusive scan over those 256 threads of (segments << 16 | list entries): shuffles inside a wave, the wave
-        // totals through LDS.  (Walking all 8192 slots instead cost 2.6 us per block; with uniform ids ~2 are flagged.)
-        const int lane = tid & 63, wv = tid >> 6;
-        unsigned word = tid < kElectSlots / 32 ? multi[tid] : 0u;
-        int mine = 0;
-        for (unsigned w = word; w; w &= w - 1) {
-            const int slot = 32 * tid + (__ffs((int)w) - 1);
-            mine += (1 << 16) + (int)(eslots[slot] & 0xffffffULL);
-        }
-        int incl = mine;
+    }
+    if (lost && dd.overflow) atomicAdd(dd.overflow, lost);
+    elect_barrier<NT, SOFT>(sy);
+    // pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one
+    // exclusive scan over those 256 threads of (segments << 16 | list entries)... as 64-bit (segments << 32 | entries): a
+    // large batch's hot rows take more than 64 K entries.  Shuffles inside a wave, the wave totals through LDS.
+    const int lane = tid & 63, wv = tid >> 6;
+    static_assert(kElectSlots / 32 == 256 && NT >= 256, "one bitmap word per thread of the first four waves");
+    unsigned word = tid < kElectSlots / 32 ? multi[tid] : 0u;
+    unsigned long long own = 0ULL;
+    for (unsigned w = word; w; w &= w - 1) {
+        const int slot = 32 * tid + (__ffs((int)w) - 1);
+        own += (1ULL << 32) + (eslots[slot] & 0xffffffULL);
+    }
+    unsigned long long incl = own;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63 && wv < 4) scan[wv] = incl;
-        __syncthreads();
-        int before = 0, total = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    unsigned long long* scan64 = reinterpret_cast<unsigned long long*>(scan);  // [4] wave totals, [4..5] region bases
+    if (lane == 63 && wv < 4) scan64[wv] = incl;
+    elect_barrier<NT, SOFT>(sy);
+    unsigned long long before = 0ULL, total = 0ULL;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int t = scan[w];
-            if (w < wv) before += t;
-            total += t;
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long t = scan64[w];
+        if (w < wv) before += t;
+        total += t;
+    }
+    const int nsegs = (int)(total >> 32), nlist = (int)(total & 0xffffffffULL);
+    int base0, base1;                                      // first segment / first list entry of this block (absolute)
+    if (dd.seg_cur) {                                      // B > kElectSlots: the field's region, placed by two returning atomics
+        if (tid == 0) {
+            const int cap = B >> 1;                        // a field's rows with >= 2 lookups: at most B / 2
+            const int fp = f;                              // region = field
+            int s0 = nsegs ? atomicAdd(&dd.seg_cur[fp], nsegs) : 0;
+            int l0 = nlist ? atomicAdd(&dd.list_cur[fp], nlist) : 0;
+            scan[8] = fp * cap + s0;
+            scan[9] = fp * B + l0;
         }
-        if (tid == 0) dd.nseg[e] = total >> 16;
-        const int base0 = e * kSegCap, base1 = e * dm.B;
-        const int excl = before + incl - mine;
-        int sidx = base0 + (excl >> 16), lrel = excl & 0xffff;
-        for (unsigned w = word; w; w &= w - 1) {
-            const int slot = 32 * tid + (__ffs((int)w) - 1);
-            const unsigned long long v = eslots[slot];
-            const int c = (int)(v & 0xffffffULL);
-            dd.seg_row[sidx] = (int64_t)(v >> 24) - 1;
-            dd.seg_off[sidx] = base1 + lrel;
-            dd.seg_cnt[sidx] = c;
-            eslots[slot] = (v & ~0xffffffULL) | 0x800000ULL | (unsigned long long)lrel;    // flag + cursor
-            ++sidx; lrel += c;
-        }
-        __syncthreads();
-        // pass 3: the members of a segment append themselves and leave rows_out
+        elect_barrier<NT, SOFT>(sy);
+        base0 = scan[8]; base1 = scan[9];
+    } else {
+        if (tid == 0) dd.nseg[e] = nsegs;
+        base0 = e * kSegCap; base1 = e * B;
+    }
+    const unsigned long long excl = before + incl - own;
+    int sidx = base0 + (int)(excl >> 32), lrel = (int)(excl & 0xffffffffULL);
+    for (unsigned w = word; w; w &= w - 1) {
+        const int slot = 32 * tid + (__ffs((int)w) - 1);
+        const unsigned long long v = eslots[slot];
+        const int c = (int)(v & 0xffffffULL);
+        dd.seg_row[sidx] = (int64_t)(v >> 24) - 1;
+        dd.seg_off[sidx] = base1 + lrel;
+        dd.seg_cnt[sidx] = c;
+        eslots[slot] = (v & ~0xffffffULL) | 0x800000ULL | (unsigned long long)lrel;    // flag + cursor
+        ++sidx; lrel += c;
+    }
+    elect_barrier<NT, SOFT>(sy);
+    // pass 3: the members of a segment append themselves and leave rows_out (a lookup finds its slot again by probing: the
+    // first probe hits unless the row was displaced in pass 1)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (nchunks > 1) load_chunk(ch);                   // (one chunk: the rows are still in registers)
 #pragma unroll
-        for (int u = 0; u < kMine; ++u) {
-            if (myslot[u] < 0) continue;
-            if (!(eslots[myslot[u]] & 0x800000ULL)) continue;
-            const int b = tid + 1024 * u;
-            const int64_t occ = (int64_t)b * dm.F + f;
-            const unsigned long long old = atomicAdd(&eslots[myslot[u]], 1ULL);
+        for (int u = 0; u < kElU; ++u) {
+            unsigned h;
+            if (!mine(ch, u, h)) continue;
+            const unsigned long long key = (unsigned long long)(rowv[u] + 1);
+            unsigned slot = h & (kElectSlots - 1);
+            unsigned long long v = eslots[slot];
+            int probes = 0;
+            while ((v >> 24) != key && v != 0ULL && probes < kElectSlots) {
+                slot = (slot + 1) & (kElectSlots - 1);
+                v = eslots[slot];
+                ++probes;
+            }
+            if ((v >> 24) != key || !(v & 0x800000ULL)) continue;              // looked up once (or never placed)
+            const int b = ch * kChunk + tid + NT * u;
+            const int64_t occ = (int64_t)b * F + f;
+            const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
             dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
             rows_out[occ] = -1;
         }
-        return;
+    }
 }
 
 // the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
 __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {
     extern __shared__ unsigned long long eslots_dyn[];
-    elect_block(eslots_dyn, dd, dm, rows_out);
+    elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
 }
 
 // ids -> packed table rows (-1 = id out of range), row-major rows_out [B][F] (what the row-gradient epilogue reads) and
@@ -420,8 +497,10 @@ __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int6
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rows_of_ids(const void* __restrict__ idx, const int64_t* __restrict__ row_offset,
                                                      const int32_t* __restrict__ vocab, DeepFmDims dm,
-                                                     int64_t* __restrict__ rows_out, int64_t* __restrict__ rows_fm) {
+                                                     int64_t* __restrict__ rows_out, int64_t* __restrict__ rows_fm,
+                                                     int* __restrict__ seg_cur, int* __restrict__ list_cur) {
     __shared__ int64_t tile[64][129];             // F <= 128
+    if (blockIdx.x == 0 && seg_cur && (int)threadIdx.x < ((dm.F + 7) & ~7)) { seg_cur[threadIdx.x] = 0; list_cur[threadIdx.x] = 0; }
     const int b0 = blockIdx.x * 64;
     const int nb = min(64, dm.B - b0);
     for (int e = threadIdx.x; e < nb * dm.F; e += blockDim.x) {
@@ -447,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_prep(DeepFmDims dm, const float* __res
     const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
     if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots_dyn[];
-        elect_block(eslots_dyn, dd, dm, rows_out);
+        elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
         return;
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
@@ -639,8 +718,9 @@ __device__ __forceinline__ void bn_stats_col(const double* __restrict__ bnacc, i
         sx += bnacc[(int64_t)sh * 2 * CP + col];
         sq += bnacc[(int64_t)sh * 2 * CP + CP + col];
     }
-    const double m = sx / (double)B;
-    const double v = sq / (double)B - m * m;
+    const double invB = 1.0 / (double)B;          // (uniform: one division per wave on the scalar-ish path, not per column)
+    const double m = sx * invB;
+    const double v = sq * invB - m * m;
     mean = (float)m;
     var = v > 0.0 ? (float)v : 0.f;
 }
@@ -1411,9 +1491,18 @@ __device__ __forceinline__ void finish_record_entry(int e, const RecSrc& rs, con
     if (e >= pl.n) return;
     const int64_t dst = record_dst(e, pl, al, dm, Lc);
     if (dst < 0) return;
+    const bool upd = da.p && dst != al.loss && dst != al.loss + 1;
+    float pp = 0.f, pm = 0.f, pv = 0.f;            // the optimizer's operands travel with the shards: one round trip, not two
+    if (upd) { pp = da.p[dst]; pm = da.m[dst]; pv = da.v[dst]; }
     const float v = rec_sum(rs, e);
     accum[dst] = v;
-    if (da.p && dst != al.loss && dst != al.loss + 1) adam_one(da.p, da.m, da.v, dst, v, da.lr_t, da.b1, da.b2, da.eps);
+    if (upd) {
+        const float mi = da.b1 * pm + (1.f - da.b1) * v;
+        const float vi = da.b2 * pv + (1.f - da.b2) * v * v;
+        da.m[dst] = mi;
+        da.v[dst] = vi;
+        da.p[dst] = pp - da.lr_t * mi / (sqrtf(vi) + da.eps);
+    }
 }
 
 // heavy block `hid` of the weight-gradient GEMMs, run by the block's first 256 threads (4 waves); they meet once, at the
@@ -1586,9 +1675,15 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     // wave 0's operands of the final formulas travel with the slices (one memory round trip per block, not two)
     floatx2 w = {0.f, 0.f}, d = {0.f, 0.f};
     float ga = 0.f, be = 0.f;
+    typedef double doublex2 __attribute__((ext_vector_type(2)));
+    doublex2 dq[kRecShards];         // db1[2 lane, 2 lane + 1] of every shard: requested here, summed behind the slices' loads
+#pragma unroll
+    for (int sh = 0; sh < kRecShards; ++sh) dq[sh] = doublex2{0.0, 0.0};
     if (wave == 0 && !w2) {
         w = *reinterpret_cast<const floatx2*>(W1 + (int64_t)col * kH1 + 2 * lane);
-        d = floatx2{rec_sum(rs, pl.db1 + 2 * lane), rec_sum(rs, pl.db1 + 2 * lane + 1)};
+#pragma unroll
+        for (int sh = 0; sh < kRecShards; ++sh)
+            dq[sh] = *reinterpret_cast<const doublex2*>(rs.racc + (int64_t)sh * rs.stride + pl.db1 + 2 * lane);
         ga = gamma[col]; be = beta[col];
     }
     // the optimizer's p / m / v of the two elements wave 0 finishes: fetched with the slices (k_finish_step), not after them
@@ -1623,6 +1718,12 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     __syncthreads();
     if (wave != 0) return;
     m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    {
+        doublex2 t = dq[0];
+#pragma unroll
+        for (int sh = 1; sh < kRecShards; ++sh) t += dq[sh];
+        d = floatx2{(float)t[0], (float)t[1]};
+    }
     if (w2) {       // row `row` of dW2^T: dW2[k][row] for k = 2 lane, 2 lane + 1
         accum[e0] = m.x;
         accum[e1] = m.y;
@@ -2018,20 +2119,42 @@ extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
 }
 
 // byte offsets inside dedupe_ws: rows_fm | nseg | seg_row | seg_off | seg_cnt | seg_list | total
-struct DedupeLayout { int64_t rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, total; int eblocks, parts_log2; };
+struct DedupeLayout {
+    int64_t rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, list_cur, overflow, total;
+    int eblocks, parts_log2;
+    int regions, cap;            // what a consumer of the segments walks: `regions` regions of up to `cap` segments, nseg[region]
+    bool by_field;               // B > kElectSlots: regions = fields (padded to 8), filled through cursors (nseg = the segment cursors)
+};
 static DedupeLayout dedupe_layout(int B, int F) {
     const int64_t n = (int64_t)B * F;
     DedupeLayout l;
     l.parts_log2 = 0;
     while ((1024 << l.parts_log2) < B) ++l.parts_log2;       // ~1024 lookups per election block
-    l.eblocks = (((F + 7) >> 3) << 3) << l.parts_log2;       // fields padded to 8 (XCD-aware ids)
+    const int fpad = ((F + 7) >> 3) << 3;                    // fields padded to 8 (XCD-aware ids)
+    l.eblocks = fpad << l.parts_log2;
+    l.by_field = B > kElectSlots;
+    l.regions = l.by_field ? fpad : l.eblocks;
+    l.cap = l.by_field ? (B >> 1) : kSegCap;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 15) & ~(int64_t)15; return r; };
-    l.rows_fm = take(n * 8); l.nseg = take((int64_t)l.eblocks * 4);
-    l.seg_row = take((int64_t)l.eblocks * kSegCap * 8); l.seg_off = take((int64_t)l.eblocks * kSegCap * 4);
-    l.seg_cnt = take((int64_t)l.eblocks * kSegCap * 4); l.seg_list = take((int64_t)l.eblocks * B * 4);
+    l.rows_fm = take(n * 8); l.nseg = take((int64_t)l.regions * 4);
+    l.seg_row = take((int64_t)l.regions * l.cap * 8); l.seg_off = take((int64_t)l.regions * l.cap * 4);
+    l.seg_cnt = take((int64_t)l.regions * l.cap * 4); l.seg_list = take((int64_t)l.regions * B * 4);
+    l.list_cur = take((int64_t)fpad * 4);
+    l.overflow = take(16);
     l.total = o;
     return l;
+}
+// the device view of a dedupe workspace
+static DedupeWs dedupe_view(void* dedupe_ws, const DedupeLayout& dl) {
+    char* base = reinterpret_cast<char*>(dedupe_ws);
+    DedupeWs dd{reinterpret_cast<int64_t*>(base + dl.rows_fm), dl.parts_log2, reinterpret_cast<int*>(base + dl.nseg),
+                reinterpret_cast<int64_t*>(base + dl.seg_row), reinterpret_cast<int*>(base + dl.seg_off),
+                reinterpret_cast<int*>(base + dl.seg_cnt), reinterpret_cast<int*>(base + dl.seg_list),
+                dl.by_field ? reinterpret_cast<int*>(base + dl.nseg) : nullptr,
+                dl.by_field ? reinterpret_cast<int*>(base + dl.list_cur) : nullptr,
+                reinterpret_cast<int*>(base + dl.overflow)};
+    return dd;
 }
 
 extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) { return dedupe_layout(B, F).total; }
@@ -2041,9 +2164,14 @@ extern "C" int64_t dt_deepfm_dedupe_bytes(int B, int F) { return dedupe_layout(B
 extern "C" int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7) {
     const DedupeLayout l = dedupe_layout(B, F);
     out7[0] = l.nseg; out7[1] = l.seg_row; out7[2] = l.seg_off; out7[3] = l.seg_cnt; out7[4] = l.seg_list;
-    out7[5] = l.eblocks; out7[6] = kSegCap;
+    out7[5] = l.regions; out7[6] = l.cap;
     return DT_OK;
 }
+
+// byte offset of the overflow counter inside dedupe_ws (int32; zero-filled with the workspace): lookups that found their
+// election table full — possible only for B > 8192 with pathologically colliding ids; non-zero = that step's duplicate
+// handling was incomplete (fused.FusedDeepFM.check_dedupe raises)
+extern "C" int64_t dt_deepfm_dedupe_overflow_offset(int B, int F) { return dedupe_layout(B, F).overflow; }
 
 // The ids-only half of a step's in-step dedupe, run AHEAD of the step (another stream, an earlier point of a captured graph):
 // rows_out [B][F] <- the packed table row of every lookup (-1: id out of range, or a member of a segment), dedupe_ws <- the
@@ -2055,22 +2183,18 @@ extern "C" int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* 
     DT_REQUIRE(idx_kind == DT_IDX_F32 || idx_kind == DT_IDX_I32, "dt_deepfm_preelect: idx_kind %d", idx_kind);
     DT_REQUIRE(dedupe_slots == (int64_t)B * F, "dt_deepfm_preelect: dedupe_slots=%lld must be dt_deepfm_dedupe_slots(B, F)",
                (long long)dedupe_slots);
-    DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
-                   "dt_deepfm_preelect: the in-step dedupe takes batches up to %d rows (B=%d)", kElectSlots, B);
+    DT_UNSUPPORTED((int64_t)B * F >= (1LL << 23), "dt_deepfm_preelect: the in-step dedupe takes up to 2^23 lookups (B=%d, F=%d)", B, F);
     DT_REQUIRE((uintptr_t)dedupe_ws % 16 == 0, "dt_deepfm_preelect: dedupe_ws must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const DedupeLayout dl = dedupe_layout(B, F);
-    char* base = reinterpret_cast<char*>(dedupe_ws);
-    DedupeWs dd{reinterpret_cast<int64_t*>(base + dl.rows_fm), dl.parts_log2, reinterpret_cast<int*>(base + dl.nseg),
-                reinterpret_cast<int64_t*>(base + dl.seg_row), reinterpret_cast<int*>(base + dl.seg_off),
-                reinterpret_cast<int*>(base + dl.seg_cnt), reinterpret_cast<int*>(base + dl.seg_list)};
+    const DedupeWs dd = dedupe_view(dedupe_ws, dl);
     DeepFmDims dm{B, F, 0, 0, 0, 0};
     if (idx_kind == DT_IDX_F32)
         hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_F32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
-                           dd.rows_fm);
+                           dd.rows_fm, dd.seg_cur, dd.list_cur);
     else
         hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_I32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
-                           dd.rows_fm);
+                           dd.rows_fm, dd.seg_cur, dd.list_cur);
     const size_t ldsB = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
     hipFuncSetAttribute((const void*)k_elect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_elect, dim3(dl.eblocks), dim3(1024), ldsB, st, dd, dm, rows_out);
@@ -2137,18 +2261,10 @@ static int tower_train_step(
     if (dedupe_ws && phases >= 2) {          // forward-only calls have no sparse gradient to dedupe
         DT_REQUIRE(dedupe_slots == (int64_t)B * F, "dt_deepfm_train_step: dedupe_slots=%lld must be "
                    "dt_deepfm_dedupe_slots(B, F)", (long long)dedupe_slots);
-        DT_UNSUPPORTED(B > kElectSlots || (int64_t)B * F >= (1LL << 24),
-                       "dt_deepfm_train_step: the in-step dedupe takes batches up to %d rows (B=%d)", kElectSlots, B);
+        DT_UNSUPPORTED((int64_t)B * F >= (1LL << 23), "dt_deepfm_train_step: the in-step dedupe takes up to 2^23 lookups (B=%d, F=%d)",
+                       B, F);
         DT_REQUIRE((uintptr_t)dedupe_ws % 16 == 0, "dt_deepfm_train_step: dedupe_ws must be 16-byte aligned");
-        const DedupeLayout dl = dedupe_layout(B, F);
-        char* base = reinterpret_cast<char*>(dedupe_ws);
-        dd.rows_fm = reinterpret_cast<int64_t*>(base + dl.rows_fm);
-        dd.nseg = reinterpret_cast<int*>(base + dl.nseg);
-        dd.seg_row = reinterpret_cast<int64_t*>(base + dl.seg_row);
-        dd.seg_off = reinterpret_cast<int*>(base + dl.seg_off);
-        dd.seg_cnt = reinterpret_cast<int*>(base + dl.seg_cnt);
-        dd.seg_list = reinterpret_cast<int*>(base + dl.seg_list);
-        dd.parts_log2 = dl.parts_log2;
+        dd = dedupe_view(dedupe_ws, dedupe_layout(B, F));
     }
     DT_REQUIRE(!preelected || (dd.rows_fm && !grad_rows_field_major),
                "dt_deepfm_train_step: DT_STEP_PREELECTED needs a backward step with dedupe_ws (filled by dt_deepfm_preelect)");
@@ -2203,7 +2319,7 @@ static int tower_train_step(
     // A (a pre-elected step: rows_out / rows_fm and the segments exist already — kernel A writes neither, the prep launch
     //    has no election blocks)
     DedupeWs ddA = dd;
-    if (preelected) ddA.rows_fm = nullptr;
+    if (preelected) { ddA.rows_fm = nullptr; ddA.seg_cur = nullptr; ddA.list_cur = nullptr; }
     const int blocksA = ceil_div(B, kRowsPerBlockA);
     double* bnacc = reinterpret_cast<double*>(ws + wl.bnacc);
     double* racc = reinterpret_cast<double*>(ws + wl.racc);
@@ -2327,7 +2443,7 @@ static int tower_train_step(
             const int seg_blocks = 1024;
             const int small_blocks = rec_blocks;
             const DedupeLayout dl = dedupe_layout(B, F);
-            const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.eblocks, kSegCap},
+            const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.regions, dl.cap},
                                adam->table, adam->m, adam->v, grad_rows, adam->sstride, D};
             const DenseAdam da{sdense->p, sdense->m, sdense->v, adam->lr_t_host, adam->b1, adam->b2, adam->eps};
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)

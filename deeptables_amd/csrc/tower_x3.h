@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     const float b2v = p.b2[16 * nt2 + n16], w3v = p.w3[16 * nt2 + n16];
     float linv = 0.f, fmv = 0.f, yv = 0.f, wov = 0.f, bov = 0.f, swv = 1.f;
     const float invB = 1.0f / (float)dm.B;                         // (formed here: off the logits phase's dependent chain)
+    const double invBd = 1.0 / (double)dm.B;
     if (wave == 0) {
         wov = p.wo[0];
         bov = p.bo ? p.bo[0] : 0.f;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
             double sx = 0.0, sq = 0.0;
 #pragma unroll
             for (int w = 0; w < kBnShards; ++w) { sx += bsx[w]; sq += bsq[w]; }
-            const double md = sx / (double)dm.B, vd = sq / (double)dm.B - md * md;
+            const double md = sx * invBd, vd = sq * invBd - md * md;
             mean = (float)md;
             var = vd > 0.0 ? (float)vd : 0.f;
             rstd = 1.0f / sqrtf(var + p.eps);

@@ -84,7 +84,7 @@ def _mirror_in_flat(flat_params, accum, grad_views):
 def _dedupe_in_step(plan, B, backward):
     """The in-step dedupe hands the rows looked up several times to the optimizer as SEGMENTS: only for an optimizer that
     takes them, a single process (the data-parallel exchange gathers plain (rows, values)), and row-sparse tables."""
-    if not (backward and plan.dedupe and B <= 8192):
+    if not (backward and plan.dedupe and B * plan.F < (1 << 23)):
         return False
     opt = getattr(plan.dm, 'optimizer', None)
     if not getattr(opt, 'supports_row_segments', False):
@@ -102,7 +102,7 @@ def _dedupe_in_step(plan, B, backward):
 def _rows_in_step(plan, B, backward, apply_rows):
     """The pipelined DeepFM step can apply the optimizer's row-sparse update to the rows looked up once INSIDE the step
     (dt_deepfm_train_step_adam): only when the caller promises `optimizer.step()` follows at once (DeepModel.train_step),
-    the in-step dedupe is on (single process, row-sparse table, B <= 8192), the optimizer is the library's KerasAdam with
+    the in-step dedupe is on (single process, row-sparse table), the optimizer is the library's KerasAdam with
     nothing between the gradient and its update (no pending all-reduce hook), and DT_AMD_ROWS_IN_STEP != 0."""
     if not (apply_rows and backward and plan.dm.model.training and _dedupe_in_step(plan, B, backward)):
         return None
@@ -271,6 +271,21 @@ class FusedDeepFM:
             slots[slot] = sb
         return sb
 
+    def check_dedupe(self):
+        """Host check of the in-step dedupe (reads one word per batch size back: call it outside the step — `DeepModel.fit`
+        does at the end of every epoch, bench.py after the timed region): raises when an election block of a batch beyond
+        8192 rows found its 8192-slot table full, i.e. some duplicate lookups of that step were treated as distinct rows.
+        Needs > 8192 distinct rows of ONE field hashing to ONE of its B / 1024 partitions: not reachable by chance."""
+        for B, buf in self._bufs.items():
+            if not isinstance(B, int) or 'dedupe' not in buf:
+                continue
+            off = int(lib().dt_deepfm_dedupe_overflow_offset(B, self.F))
+            bufs = [buf] + list(buf.get('slots', {}).values())
+            for b in bufs:
+                n = int(b['dedupe'].view(torch.int32)[off // 4].item())
+                if n:
+                    raise _lib.DtHipError(f'in-step dedupe: {n} lookups found their election table full (batch {B})')
+
     def can_preelect(self, B):
         """the step's ids-only half can run ahead of it (dt_deepfm_preelect): in-step dedupe on, single process"""
         st = self.dm.config.distribute_strategy
@@ -425,7 +440,7 @@ class FusedDeepFM:
         ids = self._slot_buffers(B, slot) if (slot and dedupe) else buf        # this step's rows / segment buffers
         pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
         if preelected and not pre:
-            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process, B <= 8192)')
+            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process)')
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
@@ -617,7 +632,7 @@ class FusedDCN(FusedDeepFM):
         ids = self._slot_buffers(B, slot) if (slot and dedupe) else buf        # this step's rows / segment buffers
         pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
         if preelected and not pre:
-            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process, B <= 8192)')
+            raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process)')
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),

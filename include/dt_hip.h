@@ -440,8 +440,8 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * dW1, dW2, db1, db2, dw3, dw_out, db_out, loss, dgamma, dbeta, dw_lin (zeroed by the call).
  * phases: 1 = forward only (logits + loss), 2 = forward + backward; OR-ed with DT_STEP_LOSS_MSE the loss is
  * MeanSquaredError on the linear output (regression task, deepmodel.py:130-131) instead of BinaryCrossentropy.
- * dedupe_ws (may be NULL; B <= 8192; 16-byte aligned): dt_deepfm_dedupe_bytes(B,F) bytes of scratch (no
- * initialisation needed); dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step
+ * dedupe_ws (may be NULL; 16-byte aligned): dt_deepfm_dedupe_bytes(B,F) bytes of scratch, zero-filled once before
+ * its first use; dedupe_slots = dt_deepfm_dedupe_slots(B,F).  When given (and phases == 2) the step
  * resolves duplicate lookups itself: a table row
  * looked up ONCE keeps its (rows_out, grad_rows) entry; a row looked up several times becomes a SEGMENT — every one of
  * its lookups reports -1 in rows_out (their grad_rows entries still hold the per-lookup gradients) and the segment
@@ -482,6 +482,12 @@ int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset,
 int64_t dt_deepfm_dedupe_slots(int B, int F);
 int64_t dt_deepfm_dedupe_bytes(int B, int F);
 int dt_deepfm_dedupe_segments(int B, int F, int64_t* out7_host);
+/* Byte offset inside dedupe_ws of an int32 that counts the lookups whose election block found its 8192-slot table full
+ * (possible only for B > 8192 and > 8192 distinct rows of one field in one of its B / 1024 hash partitions; such a lookup is
+ * updated as if its row were looked up once).  dedupe_ws must be ZERO-FILLED once before its first use; the counter only
+ * grows: non-zero after a step = that step's duplicate handling was incomplete.  Any batch size with B F < 2^23 is taken:
+ * batches beyond 8192 rows place their segments in per-FIELD regions (dt_deepfm_dedupe_segments reports regions / capacity). */
+int64_t dt_deepfm_dedupe_overflow_offset(int B, int F);
 int dt_deepfm_supported(int B, int F, int D, int Nd, int H1, int H2);
 
 /* ---- fused DCN train step (nets ['dcn_nets']: Cross || DNN on BN(concat(embeddings, dense)), deepnets.py:194-207;

@@ -685,7 +685,11 @@ def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2, monkeypatch)
 
 @pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
 @pytest.mark.parametrize('vocab,B,F,D,drop', [(30, 256, 26, 16, 0.0), (5000, 1000, 26, 16, 0.0), (5000, 513, 26, 16, 0.3),
-                                              (200000, 4096, 26, 16, 0.0), (3000, 300, 7, 32, 0.0), (900, 77, 5, 8, 0.0)])
+                                              (200000, 4096, 26, 16, 0.0), (3000, 300, 7, 32, 0.0), (900, 77, 5, 8, 0.0),
+                                              # beyond 8192 rows (round 5): the election walks a field's lookups in chunks and
+                                              # places its segments in per-field regions — rows looked up ~300 times each, ~4
+                                              # times each, mostly once; a ragged chunk, D = 32
+                                              (30, 9000, 26, 16, 0.0), (5000, 20000, 26, 16, 0.0), (200000, 16500, 7, 32, 0.0)])
 def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab, B, F, D, drop, net):
     """DeepModel.train_step on the pipelined DeepFM step applies Keras Adam to the table rows looked up once inside the
     step (dt_deepfm_train_step_adam, k_wgrad_rows) and leaves only the segments to the optimizer launch: same tables,

@@ -161,3 +161,32 @@ def test_headline_in_step_optimizer_matches_oracle_adam_two_steps(dev, dist, net
     assert res['ok'], str(sorted(res.items()))
     assert res['steps_counted'] == 2 and res['warm_rows'] > 30000, res
     assert res['rows_masked'] < 0.1 * (res['rows_masked'] + res['rows_compared']), res
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'zipf'])
+def test_large_batch_step_matches_oracle_and_updates_in_step(dev, dist):
+    """the fused step beyond B = 8192 (SURVEY §8(d)(ii)'s large-batch diagnostic).  B = 32768 on the 26 x 1 M-row
+    tables: the election walks each field's lookups in chunks (32 hash partitions per field, per-field segment regions placed
+    through cursors), the dedupe and the in-step optimizer stay on — the step against the float64 oracle, then the in-step
+    optimizer path against the oracle-checked separate path on a second batch."""
+    import bench
+    from oracle import headline
+    from deeptables_amd.models import deepnets
+    B = 32768
+    dm = bench.build_model(deepnets.DeepFM, dev)
+    bench.N_BATCHES, keep = 2, bench.N_BATCHES
+    try:
+        batches = bench.make_batches(B, dev, seed=1234, dist_kind=dist)
+    finally:
+        bench.N_BATCHES = keep
+    res = headline.check_train_step(dm, batches[0])
+    assert res['lookups'] == B * 26
+    if dist == 'zipf':
+        assert res['distinct_rows'] < res['lookups'] // 2
+    _check(res)
+    plan = dm.fused_plan()
+    from deeptables_amd import fused
+    assert fused._dedupe_in_step(plan, B, True) and fused._rows_in_step(plan, B, True, True) is not None
+    res2 = headline.check_rows_in_step(dm, batches[1])
+    assert headline.rows_in_step_ok(res2), str(sorted(res2.items()))
+    plan.check_dedupe()
