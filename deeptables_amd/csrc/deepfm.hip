@@ -128,8 +128,15 @@ struct DedupeWs {
     // reserves its share through these cursors (seg_cur doubles as the consumers' nseg array); NULL: per-block regions
     int *seg_cur, *list_cur;
     int* overflow;               // lookups that found their election table full (see elect_block); NULL: not counted
+    // ... and kernel A stores one BYTE per lookup, the row's hash partition (0xff: id out of range / beyond B), field-major
+    // with pid_stride (B rounded up to 8) bytes per field: what the election blocks scan instead of the 8-byte rows
+    unsigned char* pid_fm;
+    int pid_stride;
 };
 constexpr int kSegCap = kElectSlots / 2;     // a block's rows with >= 2 lookups: at most B / 2
+__device__ __forceinline__ unsigned elect_hash(int64_t row) { return ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u; }
+// partition of a row among 2^parts_log2: the top bits of the hash (the low 13 bits pick the slot)
+__device__ __forceinline__ int elect_part(unsigned h, int parts_log2) { return (int)((h >> 13) >> (19 - parts_log2)); }
 
 // phase timestamps (s_memtime, shader cycles) of wave 0 of every block: ws region `stamps` [blocks][16] u64,
 // read back by tools/phase_times.py; costs one scalar load + store per phase
@@ -224,6 +231,9 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             if (c == 0 && in[t]) {
                 const int64_t occ = (int64_t)b * dm.F + fld[t];
                 if (dd.rows_fm) dd.rows_fm[(int64_t)fld[t] * dm.B + b] = row[t];     // for the election blocks (see DedupeWs)
+                if (dd.rows_fm && dd.pid_fm)                  // B > kElectSlots: + the row's partition byte (what the blocks scan)
+                    dd.pid_fm[(int64_t)fld[t] * dd.pid_stride + b] =
+                        ok[t] ? (unsigned char)elect_part(elect_hash(row[t]), dd.parts_log2) : (unsigned char)0xff;
                 if (rows_out) rows_out[occ] = row[t];         // (NULL: a pre-elected step, dt_deepfm_preelect wrote them)
                 if (!ok[t] && oob) atomicAdd(oob, 1);
             }
@@ -317,14 +327,17 @@ struct PrepOut {
 //   NT    threads that run it: 1024 = a whole block of the prep launch (hardware barriers), 256 = the four matrix waves of a
 //         weight-gradient block running the NEXT step's election in their idle time (k_wgrad_rows; they meet at an LDS counter:
 //         the block's memory waves must not be held at a hardware barrier)
-//   any B: the field's B lookups are walked in chunks of NT x kElU (round 4 took B <= 8192 = one chunk of a 1024-thread block,
-//         slots kept in registers); pass 3 finds a lookup's slot again by probing.  B <= kElectSlots keeps round 4's private
-//         regions (no global counter: a returning device-scope atomic in the middle of the chain costs ~2 us); beyond that a
-//         block's segments / list entries are placed in its FIELD's region through two returning atomics (dd.seg_cur /
-//         dd.list_cur, zeroed by the launch that wrote rows_fm) — per-block regions would take eblocks x B entries.
-// Termination: a block holds at most kElectSlots distinct rows.  B <= kElectSlots guarantees it; for larger batches the hash
-// partitions (~1024 lookups each) would have to be 8x over-full — a lookup that finds the table full is counted in
-// dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row (-> updated as if looked up once).
+//   BIG   false: B <= kElectSlots, round 4's layout — private segment / list regions per block (no global counter: a
+//         returning device-scope atomic in the middle of the chain costs ~2 us), the field's lookups in chunks of NT x kElU
+//         (one chunk with 1024 threads: a lookup's slot stays in a register for pass 3).
+//         true: any batch size.  ~4096 lookups per block (half of the table); the block does not read the field's B rows
+//         (8 B each, eblocks x B x 8 bytes of L2 traffic: 184 us at B = 65536) but the partition BYTE kernel A stored per
+//         lookup (pid_fm), and fetches a row only where the byte matches; its segments / list entries go to its FIELD's region
+//         through two returning atomics (dd.seg_cur / dd.list_cur, zeroed by the launch that wrote rows_fm) — per-block
+//         regions would take eblocks x B entries.
+// Termination: a block holds at most kElectSlots distinct rows.  B <= kElectSlots guarantees it; beyond that a partition
+// would have to be 2x over-full of DISTINCT rows (expected 4096, sigma 64) — a lookup that finds the table full is counted
+// in dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row (-> updated as if looked up once).
 constexpr int kElU = 8;               // lookups per thread and chunk, all loads in flight
 struct ElectSync {
     unsigned* cnt;                    // LDS word of the soft barrier (NT = 256), zeroed by the caller
@@ -344,7 +357,7 @@ __device__ __forceinline__ void elect_barrier(ElectSync& sy) {
     }
 }
 
-template <int NT, bool SOFT>
+template <int NT, bool SOFT, bool BIG>
 __device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
                                             int64_t* __restrict__ rows_out, ElectSync sy) {
     unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
@@ -354,23 +367,55 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
     const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
     const int f = 8 * (j >> dd.parts_log2) + (e & 7);
     if (f >= F) {
-        if (tid == 0 && !dd.seg_cur) dd.nseg[e] = 0;
+        if (tid == 0 && !BIG) dd.nseg[e] = 0;
         return;
     }
     const int64_t* rf = dd.rows_fm + (int64_t)f * B;
     constexpr int kChunk = NT * kElU;
     const int nchunks = (B + kChunk - 1) / kChunk;
+    // the lookups of one chunk that are this block's: (batch row, table row) pairs in registers
+    int bq[kElU];
     int64_t rowv[kElU];
-    auto load_chunk = [&](int ch) {                       // all of the thread's row loads of the chunk in flight
+    int myslot[kElU];
+    int nq = 0;
+    auto load_chunk = [&](int ch) {
+        if constexpr (BIG) {
+            // kElU = 8 partition bytes per thread (pid_stride = B rounded up to 8); the (few) rows whose byte matches are fetched
+            // together afterwards
+            const int b0 = (ch * NT + tid) * kElU;
+            uint2 pv = make_uint2(~0u, ~0u);
+            if (b0 < B) pv = *reinterpret_cast<const uint2*>(dd.pid_fm + (int64_t)f * dd.pid_stride + b0);
+            const unsigned w[2] = {pv.x, pv.y};
+            nq = 0;                                           // bit u: byte u is this block's partition
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) rowv[u] = rf[min(ch * kChunk + tid + NT * u, B - 1)];
+            for (int k = 0; k < kElU; ++k) {
+                const int pb = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                nq |= ((pb == part && b0 + k < B) ? 1 : 0) << k;
+                bq[k] = b0 + k;
+            }
+            // unconditional loads (a guarded load closes its region with a full wait): the lanes without a match all read the
+            // field's first row — one line for the whole wave
+#pragma unroll
+            for (int u = 0; u < kElU; ++u) rowv[u] = rf[((nq >> u) & 1) ? bq[u] : 0];
+        } else {
+#pragma unroll
+            for (int u = 0; u < kElU; ++u) {                  // all of the thread's row loads of the chunk in flight
+                bq[u] = ch * kChunk + tid + NT * u;
+                rowv[u] = rf[min(bq[u], B - 1)];
+            }
+        }
     };
-    auto mine = [&](int ch, int u, unsigned& h) {         // is lookup (chunk, u) of this thread one of this block's?
-        const int b = ch * kChunk + tid + NT * u;
-        const int64_t row = rowv[u];
-        if (b >= B || row < 0) return false;
-        h = ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u;
-        return (int)((h >> 13) >> (19 - dd.parts_log2)) == part;               // top bits of h: the partition
+    auto mine = [&](int u, unsigned& h) {                     // is entry u of the chunk one of this block's lookups?
+        if constexpr (BIG) {
+            if (!((nq >> u) & 1)) return false;
+            h = elect_hash(rowv[u]);
+            return true;                                      // (its byte matched: kernel A writes 0xff for row < 0)
+        } else {
+            const int64_t row = rowv[u];
+            if (bq[u] >= B || row < 0) return false;
+            h = elect_hash(row);
+            return elect_part(h, dd.parts_log2) == part;
+        }
     };
     load_chunk(0);
     for (int i = tid; i < kElectSlots; i += NT) eslots[i] = 0ULL;
@@ -383,12 +428,13 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
 #pragma unroll
         for (int u = 0; u < kElU; ++u) {
             unsigned h;
-            if (!mine(ch, u, h)) continue;
+            myslot[u] = -1;
+            if (!mine(u, h)) continue;
             const unsigned long long key = (unsigned long long)(rowv[u] + 1) << 24;
             unsigned slot = h & (kElectSlots - 1);
             int probes = 0;
-            for (;; ++probes) {
-                if (probes == kElectSlots) { ++lost; break; }                  // table full (B > kElectSlots only)
+            for (;;) {
+                if (BIG && ++probes > kElectSlots) { ++lost; slot = ~0u; break; }       // table full
                 const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, key | 1ULL);
                 if (prev == 0ULL) break;
                 if ((prev >> 24) == (unsigned long long)(rowv[u] + 1)) {
@@ -398,47 +444,50 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
                 }
                 slot = (slot + 1) & (kElectSlots - 1);
             }
+            myslot[u] = (int)slot;
         }
     }
-    if (lost && dd.overflow) atomicAdd(dd.overflow, lost);
+    if (BIG && lost && dd.overflow) atomicAdd(dd.overflow, lost);
     elect_barrier<NT, SOFT>(sy);
     // pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one
-    // exclusive scan over those 256 threads of (segments << 16 | list entries)... as 64-bit (segments << 32 | entries): a
-    // large batch's hot rows take more than 64 K entries.  Shuffles inside a wave, the wave totals through LDS.
+    // exclusive scan over those 256 threads of (segments, list entries) — packed in 32 bits for B <= 8192, 64 bits beyond
+    // (a large batch's hot rows take more than 64 K entries): shuffles inside a wave, the wave totals through LDS.
+    // (Walking all 8192 slots instead cost 2.6 us per block; with uniform ids ~2 are flagged.)
+    typedef typename std::conditional<BIG, unsigned long long, unsigned>::type acc_t;
+    constexpr int kSh = BIG ? 32 : 16;
     const int lane = tid & 63, wv = tid >> 6;
     static_assert(kElectSlots / 32 == 256 && NT >= 256, "one bitmap word per thread of the first four waves");
     unsigned word = tid < kElectSlots / 32 ? multi[tid] : 0u;
-    unsigned long long own = 0ULL;
+    acc_t own = 0;
     for (unsigned w = word; w; w &= w - 1) {
         const int slot = 32 * tid + (__ffs((int)w) - 1);
-        own += (1ULL << 32) + (eslots[slot] & 0xffffffULL);
+        own += ((acc_t)1 << kSh) + (acc_t)(eslots[slot] & 0xffffffULL);
     }
-    unsigned long long incl = own;
+    acc_t incl = own;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(incl, o, 64);
+        const acc_t t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    unsigned long long* scan64 = reinterpret_cast<unsigned long long*>(scan);  // [4] wave totals, [4..5] region bases
-    if (lane == 63 && wv < 4) scan64[wv] = incl;
+    acc_t* scanw = reinterpret_cast<acc_t*>(scan);            // [4] wave totals (ints 0..7); ints 8, 9: region bases
+    if (lane == 63 && wv < 4) scanw[wv] = incl;
     elect_barrier<NT, SOFT>(sy);
-    unsigned long long before = 0ULL, total = 0ULL;
+    acc_t before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const unsigned long long t = scan64[w];
+        const acc_t t = scanw[w];
         if (w < wv) before += t;
         total += t;
     }
-    const int nsegs = (int)(total >> 32), nlist = (int)(total & 0xffffffffULL);
-    int base0, base1;                                      // first segment / first list entry of this block (absolute)
-    if (dd.seg_cur) {                                      // B > kElectSlots: the field's region, placed by two returning atomics
+    const int nsegs = (int)(total >> kSh), nlist = (int)(total & (((acc_t)1 << kSh) - 1));
+    int base0, base1;                                         // first segment / first list entry of this block (absolute)
+    if constexpr (BIG) {                                      // the field's region, placed by two returning atomics
         if (tid == 0) {
-            const int cap = B >> 1;                        // a field's rows with >= 2 lookups: at most B / 2
-            const int fp = f;                              // region = field
-            int s0 = nsegs ? atomicAdd(&dd.seg_cur[fp], nsegs) : 0;
-            int l0 = nlist ? atomicAdd(&dd.list_cur[fp], nlist) : 0;
-            scan[8] = fp * cap + s0;
-            scan[9] = fp * B + l0;
+            const int cap = B >> 1;                           // a field's rows with >= 2 lookups: at most B / 2
+            const int s0 = nsegs ? atomicAdd(&dd.seg_cur[f], nsegs) : 0;
+            const int l0 = nlist ? atomicAdd(&dd.list_cur[f], nlist) : 0;
+            scan[8] = f * cap + s0;
+            scan[9] = f * B + l0;
         }
         elect_barrier<NT, SOFT>(sy);
         base0 = scan[8]; base1 = scan[9];
@@ -446,8 +495,8 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
         if (tid == 0) dd.nseg[e] = nsegs;
         base0 = e * kSegCap; base1 = e * B;
     }
-    const unsigned long long excl = before + incl - own;
-    int sidx = base0 + (int)(excl >> 32), lrel = (int)(excl & 0xffffffffULL);
+    const acc_t excl = before + incl - own;
+    int sidx = base0 + (int)(excl >> kSh), lrel = (int)(excl & (((acc_t)1 << kSh) - 1));
     for (unsigned w = word; w; w &= w - 1) {
         const int slot = 32 * tid + (__ffs((int)w) - 1);
         const unsigned long long v = eslots[slot];
@@ -459,37 +508,46 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
         ++sidx; lrel += c;
     }
     elect_barrier<NT, SOFT>(sy);
-    // pass 3: the members of a segment append themselves and leave rows_out (a lookup finds its slot again by probing: the
-    // first probe hits unless the row was displaced in pass 1)
+    // pass 3: the members of a segment append themselves and leave rows_out (one chunk: a lookup's slot is still in its
+    // register; several: it finds the slot again by probing — the first probe hits unless the row was displaced in pass 1)
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (nchunks > 1) load_chunk(ch);                   // (one chunk: the rows are still in registers)
+        if (nchunks > 1) load_chunk(ch);
 #pragma unroll
         for (int u = 0; u < kElU; ++u) {
-            unsigned h;
-            if (!mine(ch, u, h)) continue;
-            const unsigned long long key = (unsigned long long)(rowv[u] + 1);
-            unsigned slot = h & (kElectSlots - 1);
-            unsigned long long v = eslots[slot];
-            int probes = 0;
-            while ((v >> 24) != key && v != 0ULL && probes < kElectSlots) {
-                slot = (slot + 1) & (kElectSlots - 1);
-                v = eslots[slot];
-                ++probes;
+            int slot;
+            if (nchunks == 1) {
+                slot = myslot[u];
+                if (slot < 0) continue;
+            } else {
+                unsigned h;
+                if (!mine(u, h)) continue;
+                const unsigned long long key = (unsigned long long)(rowv[u] + 1);
+                unsigned sl = h & (kElectSlots - 1);
+                unsigned long long v = eslots[sl];
+                int probes = 0;
+                while ((v >> 24) != key && v != 0ULL && probes < kElectSlots) {
+                    sl = (sl + 1) & (kElectSlots - 1);
+                    v = eslots[sl];
+                    ++probes;
+                }
+                if ((v >> 24) != key) continue;                                    // never placed (table full)
+                slot = (int)sl;
             }
-            if ((v >> 24) != key || !(v & 0x800000ULL)) continue;              // looked up once (or never placed)
-            const int b = ch * kChunk + tid + NT * u;
-            const int64_t occ = (int64_t)b * F + f;
+            if (!(eslots[slot] & 0x800000ULL)) continue;                           // looked up once
+            const int64_t occ = (int64_t)bq[u] * F + f;
             const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
             dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
             rows_out[occ] = -1;
         }
     }
 }
-
 // the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
 __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {
     extern __shared__ unsigned long long eslots_dyn[];
-    elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+    if (dd.seg_cur)
+        elect_block<1024, false, true>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+    else
+        elect_block<1024, false, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
 }
 
 // ids -> packed table rows (-1 = id out of range), row-major rows_out [B][F] (what the row-gradient epilogue reads) and
@@ -498,7 +556,8 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_rows_of_ids(const void* __restrict__ idx, const int64_t* __restrict__ row_offset,
                                                      const int32_t* __restrict__ vocab, DeepFmDims dm,
                                                      int64_t* __restrict__ rows_out, int64_t* __restrict__ rows_fm,
-                                                     int* __restrict__ seg_cur, int* __restrict__ list_cur) {
+                                                     int* __restrict__ seg_cur, int* __restrict__ list_cur,
+                                                     unsigned char* __restrict__ pid_fm, int pid_stride, int parts_log2) {
     __shared__ int64_t tile[64][129];             // F <= 128
     if (blockIdx.x == 0 && seg_cur && (int)threadIdx.x < ((dm.F + 7) & ~7)) { seg_cur[threadIdx.x] = 0; list_cur[threadIdx.x] = 0; }
     const int b0 = blockIdx.x * 64;
@@ -513,7 +572,12 @@ __global__ __launch_bounds__(256) void k_rows_of_ids(const void* __restrict__ id
     __syncthreads();
     for (int e = threadIdx.x; e < dm.F * 64; e += blockDim.x) {
         const int f = e >> 6, r = e & 63;
-        if (r < nb) rows_fm[(int64_t)f * dm.B + b0 + r] = tile[r][f];
+        if (r < nb) {
+            rows_fm[(int64_t)f * dm.B + b0 + r] = tile[r][f];
+            if (pid_fm)
+                pid_fm[(int64_t)f * pid_stride + b0 + r] =
+                    tile[r][f] >= 0 ? (unsigned char)elect_part(elect_hash(tile[r][f]), parts_log2) : (unsigned char)0xff;
+        }
     }
 }
 
@@ -526,7 +590,10 @@ __global__ __launch_bounds__(1024) void k_prep(DeepFmDims dm, const float* __res
     const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
     if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots_dyn[];
-        elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        if (dd.seg_cur)
+            elect_block<1024, false, true>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        else
+            elect_block<1024, false, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
         return;
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
@@ -2120,7 +2187,8 @@ extern "C" int64_t dt_deepfm_dedupe_slots(int B, int F) {
 
 // byte offsets inside dedupe_ws: rows_fm | nseg | seg_row | seg_off | seg_cnt | seg_list | total
 struct DedupeLayout {
-    int64_t rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, list_cur, overflow, total;
+    int64_t rows_fm, nseg, seg_row, seg_off, seg_cnt, seg_list, list_cur, overflow, pid, total;
+    int pid_stride;
     int eblocks, parts_log2;
     int regions, cap;            // what a consumer of the segments walks: `regions` regions of up to `cap` segments, nseg[region]
     bool by_field;               // B > kElectSlots: regions = fields (padded to 8), filled through cursors (nseg = the segment cursors)
@@ -2128,11 +2196,13 @@ struct DedupeLayout {
 static DedupeLayout dedupe_layout(int B, int F) {
     const int64_t n = (int64_t)B * F;
     DedupeLayout l;
+    l.by_field = B > kElectSlots;
     l.parts_log2 = 0;
-    while ((1024 << l.parts_log2) < B) ++l.parts_log2;       // ~1024 lookups per election block
+    // ~1024 lookups per election block up to B = 8192 (the launch's chain is the block's); beyond: ~4096 (half of the table's
+    // slots — the scan of the partition bytes is per block)
+    while (((l.by_field ? 4096 : 1024) << l.parts_log2) < B) ++l.parts_log2;
     const int fpad = ((F + 7) >> 3) << 3;                    // fields padded to 8 (XCD-aware ids)
     l.eblocks = fpad << l.parts_log2;
-    l.by_field = B > kElectSlots;
     l.regions = l.by_field ? fpad : l.eblocks;
     l.cap = l.by_field ? (B >> 1) : kSegCap;
     int64_t o = 0;
@@ -2142,6 +2212,8 @@ static DedupeLayout dedupe_layout(int B, int F) {
     l.seg_cnt = take((int64_t)l.regions * l.cap * 4); l.seg_list = take((int64_t)l.regions * B * 4);
     l.list_cur = take((int64_t)fpad * 4);
     l.overflow = take(16);
+    l.pid_stride = (B + 7) & ~7;
+    l.pid = take(l.by_field ? (int64_t)fpad * l.pid_stride : 0);
     l.total = o;
     return l;
 }
@@ -2153,7 +2225,8 @@ static DedupeWs dedupe_view(void* dedupe_ws, const DedupeLayout& dl) {
                 reinterpret_cast<int*>(base + dl.seg_cnt), reinterpret_cast<int*>(base + dl.seg_list),
                 dl.by_field ? reinterpret_cast<int*>(base + dl.nseg) : nullptr,
                 dl.by_field ? reinterpret_cast<int*>(base + dl.list_cur) : nullptr,
-                reinterpret_cast<int*>(base + dl.overflow)};
+                reinterpret_cast<int*>(base + dl.overflow),
+                dl.by_field ? reinterpret_cast<unsigned char*>(base + dl.pid) : nullptr, dl.pid_stride};
     return dd;
 }
 
@@ -2191,10 +2264,10 @@ extern "C" int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* 
     DeepFmDims dm{B, F, 0, 0, 0, 0};
     if (idx_kind == DT_IDX_F32)
         hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_F32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
-                           dd.rows_fm, dd.seg_cur, dd.list_cur);
+                           dd.rows_fm, dd.seg_cur, dd.list_cur, dd.pid_fm, dd.pid_stride, dd.parts_log2);
     else
         hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_I32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
-                           dd.rows_fm, dd.seg_cur, dd.list_cur);
+                           dd.rows_fm, dd.seg_cur, dd.list_cur, dd.pid_fm, dd.pid_stride, dd.parts_log2);
     const size_t ldsB = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
     hipFuncSetAttribute((const void*)k_elect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_elect, dim3(dl.eblocks), dim3(1024), ldsB, st, dd, dm, rows_out);
@@ -2319,7 +2392,7 @@ static int tower_train_step(
     // A (a pre-elected step: rows_out / rows_fm and the segments exist already — kernel A writes neither, the prep launch
     //    has no election blocks)
     DedupeWs ddA = dd;
-    if (preelected) { ddA.rows_fm = nullptr; ddA.seg_cur = nullptr; ddA.list_cur = nullptr; }
+    if (preelected) { ddA.rows_fm = nullptr; ddA.seg_cur = nullptr; ddA.list_cur = nullptr; ddA.pid_fm = nullptr; }
     const int blocksA = ceil_div(B, kRowsPerBlockA);
     double* bnacc = reinterpret_cast<double*>(ws + wl.bnacc);
     double* racc = reinterpret_cast<double*>(ws + wl.racc);

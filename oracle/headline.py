@@ -419,7 +419,9 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
             torch.cuda.synchronize()
             flip = max(_rel_stats(p.grad.reshape(g.shape), g)[0] for p, g in pairs)
             opt.zero_grad()
-            if flip < 2e-4 or attempt == 3:
+            # a flipped unit moves the worst dense gradient by >= 1e-4 of its tensor's largest entry, rounding alone (incl. the
+            # split-bf16 backward's 16-bit products) by 4-8e-6: anything above 3e-5 is treated as a kink and re-drawn
+            if flip < 3e-5 or attempt == 3:
                 break
             res['kink_shifts'] = res.get('kink_shifts', 0) + 1
             with torch.no_grad():

@@ -707,7 +707,12 @@ def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab
         # repeated: the first version of the finishing launch read gamma / beta while other blocks of the SAME launch updated
         # them — a race that showed up in one run out of a few (tools/r3/dbg_ab2.py tells which tensors moved)
         for rep in range(4):
-            res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)), steps=2 + rep % 2)
+            # (beyond 8192 rows ONE step per comparison: after a first step the two paths' tables differ by an ulp here and there
+            # — the update rule runs in two kernels — and among the > 3 M relu units of such a batch one now and then sits within
+            # that ulp of its kink and takes the other derivative in one of the paths: a whole sample's gradient term, 1e-3 of
+            # the slots' largest entry.  Seen once in ~50 comparisons at B = 16500; a single step starts from identical state.)
+            res = headline.check_rows_in_step(dm, (idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)),
+                                              steps=1 if B > 8192 else 2 + rep % 2)
             assert headline.rows_in_step_ok(res), str((rep, sorted(res.items())))
         dm.train_step([idx.to(torch.int32).to(dev), dense.to(dev)], y.to(dev))   # move on (in-step path)
 

@@ -187,6 +187,6 @@ def test_large_batch_step_matches_oracle_and_updates_in_step(dev, dist):
     plan = dm.fused_plan()
     from deeptables_amd import fused
     assert fused._dedupe_in_step(plan, B, True) and fused._rows_in_step(plan, B, True, True) is not None
-    res2 = headline.check_rows_in_step(dm, batches[1])
+    res2 = headline.check_rows_in_step(dm, batches[1], steps=1)       # (one step: see test_fused_gpu's note on relu kinks)
     assert headline.rows_in_step_ok(res2), str(sorted(res2.items()))
     plan.check_dedupe()
