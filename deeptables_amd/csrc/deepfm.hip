@@ -357,102 +357,45 @@ __device__ __forceinline__ void elect_barrier(ElectSync& sy) {
     }
 }
 
+// pass 1 for ONE lookup of this block's partition: claim (CAS) / count (atomicAdd); the SECOND lookup of a row flags its
+// slot in the bitmap.  -> the slot, or -1 (BOUNDED only) when the table is full
+template <bool BOUNDED>
+__device__ __forceinline__ int elect_insert(unsigned long long* eslots, unsigned* multi, int64_t row, unsigned h) {
+    const unsigned long long key = (unsigned long long)(row + 1) << 24;
+    unsigned slot = h & (kElectSlots - 1);
+    for (int probes = 0;; ++probes) {                          // B <= kElectSlots distinct rows always terminate
+        if (BOUNDED && probes >= kElectSlots) return -1;
+        const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, key | 1ULL);
+        if (prev == 0ULL) break;
+        if ((prev >> 24) == (unsigned long long)(row + 1)) {
+            const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
+            if ((old & 0xffffffULL) == 1ULL) atomicOr(&multi[slot >> 5], 1u << (slot & 31));
+            break;
+        }
+        slot = (slot + 1) & (kElectSlots - 1);
+    }
+    return (int)slot;
+}
+// pass 3's lookup of a row's slot (the first probe hits unless the row was displaced in pass 1); -1: never placed
+__device__ __forceinline__ int elect_find(const unsigned long long* eslots, int64_t row, unsigned h) {
+    const unsigned long long key = (unsigned long long)(row + 1);
+    unsigned sl = h & (kElectSlots - 1);
+    unsigned long long v = eslots[sl];
+    for (int probes = 0; (v >> 24) != key && v != 0ULL && probes < kElectSlots; ++probes) {
+        sl = (sl + 1) & (kElectSlots - 1);
+        v = eslots[sl];
+    }
+    return (v >> 24) == key ? (int)sl : -1;
+}
+
+// pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one exclusive scan
+// over those 256 threads of (segments, list entries) — packed in 32 bits for B <= 8192, 64 bits beyond (a large batch's
+// hot rows take more than 64 K entries): shuffles inside a wave, the wave totals through LDS.  (Walking all 8192 slots
+// instead cost 2.6 us per block; with uniform ids ~2 are flagged.)  -> base1, the block's first list entry (absolute);
+// leaves every flagged slot as key | flag | cursor.  Ends with a barrier.
 template <int NT, bool SOFT, bool BIG>
-__device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
-                                            int64_t* __restrict__ rows_out, ElectSync sy) {
-    unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
-    int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases
-    // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
-    // so the field's row list is fetched into ONE L2 instead of eight
-    const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
-    const int f = 8 * (j >> dd.parts_log2) + (e & 7);
-    if (f >= F) {
-        if (tid == 0 && !BIG) dd.nseg[e] = 0;
-        return;
-    }
-    const int64_t* rf = dd.rows_fm + (int64_t)f * B;
-    constexpr int kChunk = NT * kElU;
-    const int nchunks = (B + kChunk - 1) / kChunk;
-    // the lookups of one chunk that are this block's: (batch row, table row) pairs in registers
-    int bq[kElU];
-    int64_t rowv[kElU];
-    int myslot[kElU];
-    int nq = 0;
-    auto load_chunk = [&](int ch) {
-        if constexpr (BIG) {
-            // kElU = 8 partition bytes per thread (pid_stride = B rounded up to 8); the (few) rows whose byte matches are fetched
-            // together afterwards
-            const int b0 = (ch * NT + tid) * kElU;
-            uint2 pv = make_uint2(~0u, ~0u);
-            if (b0 < B) pv = *reinterpret_cast<const uint2*>(dd.pid_fm + (int64_t)f * dd.pid_stride + b0);
-            const unsigned w[2] = {pv.x, pv.y};
-            nq = 0;                                           // bit u: byte u is this block's partition
-#pragma unroll
-            for (int k = 0; k < kElU; ++k) {
-                const int pb = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                nq |= ((pb == part && b0 + k < B) ? 1 : 0) << k;
-                bq[k] = b0 + k;
-            }
-            // unconditional loads (a guarded load closes its region with a full wait): the lanes without a match all read the
-            // field's first row — one line for the whole wave
-#pragma unroll
-            for (int u = 0; u < kElU; ++u) rowv[u] = rf[((nq >> u) & 1) ? bq[u] : 0];
-        } else {
-#pragma unroll
-            for (int u = 0; u < kElU; ++u) {                  // all of the thread's row loads of the chunk in flight
-                bq[u] = ch * kChunk + tid + NT * u;
-                rowv[u] = rf[min(bq[u], B - 1)];
-            }
-        }
-    };
-    auto mine = [&](int u, unsigned& h) {                     // is entry u of the chunk one of this block's lookups?
-        if constexpr (BIG) {
-            if (!((nq >> u) & 1)) return false;
-            h = elect_hash(rowv[u]);
-            return true;                                      // (its byte matched: kernel A writes 0xff for row < 0)
-        } else {
-            const int64_t row = rowv[u];
-            if (bq[u] >= B || row < 0) return false;
-            h = elect_hash(row);
-            return elect_part(h, dd.parts_log2) == part;
-        }
-    };
-    load_chunk(0);
-    for (int i = tid; i < kElectSlots; i += NT) eslots[i] = 0ULL;
-    for (int i = tid; i < kElectSlots / 32; i += NT) multi[i] = 0u;
-    elect_barrier<NT, SOFT>(sy);
-    // pass 1: claim (CAS) / count (atomicAdd); the SECOND lookup of a row flags its slot in the bitmap
-    int lost = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch) load_chunk(ch);
-#pragma unroll
-        for (int u = 0; u < kElU; ++u) {
-            unsigned h;
-            myslot[u] = -1;
-            if (!mine(u, h)) continue;
-            const unsigned long long key = (unsigned long long)(rowv[u] + 1) << 24;
-            unsigned slot = h & (kElectSlots - 1);
-            int probes = 0;
-            for (;;) {
-                if (BIG && ++probes > kElectSlots) { ++lost; slot = ~0u; break; }       // table full
-                const unsigned long long prev = atomicCAS(&eslots[slot], 0ULL, key | 1ULL);
-                if (prev == 0ULL) break;
-                if ((prev >> 24) == (unsigned long long)(rowv[u] + 1)) {
-                    const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
-                    if ((old & 0xffffffULL) == 1ULL) atomicOr(&multi[slot >> 5], 1u << (slot & 31));
-                    break;
-                }
-                slot = (slot + 1) & (kElectSlots - 1);
-            }
-            myslot[u] = (int)slot;
-        }
-    }
-    if (BIG && lost && dd.overflow) atomicAdd(dd.overflow, lost);
-    elect_barrier<NT, SOFT>(sy);
-    // pass 2: the flagged slots become segments.  Thread t < 256 owns bitmap word t (slots [32t, 32t + 32)); one
-    // exclusive scan over those 256 threads of (segments, list entries) — packed in 32 bits for B <= 8192, 64 bits beyond
-    // (a large batch's hot rows take more than 64 K entries): shuffles inside a wave, the wave totals through LDS.
-    // (Walking all 8192 slots instead cost 2.6 us per block; with uniform ids ~2 are flagged.)
+__device__ __forceinline__ int elect_segments(unsigned long long* eslots, unsigned* multi, int* scan, const DedupeWs& dd, int B,
+                                              int f, int e, int tid, ElectSync& sy) {
     typedef typename std::conditional<BIG, unsigned long long, unsigned>::type acc_t;
     constexpr int kSh = BIG ? 32 : 16;
     const int lane = tid & 63, wv = tid >> 6;
@@ -508,46 +451,172 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
         ++sidx; lrel += c;
     }
     elect_barrier<NT, SOFT>(sy);
-    // pass 3: the members of a segment append themselves and leave rows_out (one chunk: a lookup's slot is still in its
-    // register; several: it finds the slot again by probing — the first probe hits unless the row was displaced in pass 1)
+    return base1;
+}
+// pass 3 for one lookup: a member of a segment appends itself and leaves rows_out
+__device__ __forceinline__ void elect_append(unsigned long long* eslots, int slot, const DedupeWs& dd, int base1, int b, int F,
+                                             int f, int64_t* __restrict__ rows_out) {
+    if (!(eslots[slot] & 0x800000ULL)) return;                // looked up once
+    const int64_t occ = (int64_t)b * F + f;
+    const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
+    dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
+    rows_out[occ] = -1;
+}
+
+// B <= kElectSlots
+template <int NT, bool SOFT>
+__device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
+                                            int64_t* __restrict__ rows_out, ElectSync sy) {
+    unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
+    int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases
+    // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
+    // so the field's row list is fetched into ONE L2 instead of eight
+    const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
+    const int f = 8 * (j >> dd.parts_log2) + (e & 7);
+    if (f >= F) {
+        if (tid == 0) dd.nseg[e] = 0;
+        return;
+    }
+    const int64_t* rf = dd.rows_fm + (int64_t)f * B;
+    constexpr int kChunk = NT * kElU;
+    const int nchunks = (B + kChunk - 1) / kChunk;
+    int64_t rowv[kElU];
+    int myslot[kElU];
+    auto load_chunk = [&](int ch) {                           // all of the thread's row loads of the chunk in flight
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) rowv[u] = rf[min(ch * kChunk + tid + NT * u, B - 1)];
+    };
+    auto mine = [&](int ch, int u, unsigned& h) {             // is lookup u of the chunk one of this block's?
+        const int64_t row = rowv[u];
+        if (ch * kChunk + tid + NT * u >= B || row < 0) return false;
+        h = elect_hash(row);
+        return elect_part(h, dd.parts_log2) == part;
+    };
+    load_chunk(0);
+    for (int i = tid; i < kElectSlots; i += NT) eslots[i] = 0ULL;
+    for (int i = tid; i < kElectSlots / 32; i += NT) multi[i] = 0u;
+    elect_barrier<NT, SOFT>(sy);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch) load_chunk(ch);
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) {
+            unsigned h;
+            myslot[u] = mine(ch, u, h) ? elect_insert<false>(eslots, multi, rowv[u], h) : -1;
+        }
+    }
+    elect_barrier<NT, SOFT>(sy);
+    const int base1 = elect_segments<NT, SOFT, false>(eslots, multi, scan, dd, B, f, e, tid, sy);
+    // pass 3 (one chunk: a lookup's slot is still in its register; several: it finds the slot again by probing)
     for (int ch = 0; ch < nchunks; ++ch) {
         if (nchunks > 1) load_chunk(ch);
 #pragma unroll
         for (int u = 0; u < kElU; ++u) {
-            int slot;
-            if (nchunks == 1) {
-                slot = myslot[u];
-                if (slot < 0) continue;
-            } else {
+            int slot = myslot[u];
+            if (nchunks > 1) {
                 unsigned h;
-                if (!mine(u, h)) continue;
-                const unsigned long long key = (unsigned long long)(rowv[u] + 1);
-                unsigned sl = h & (kElectSlots - 1);
-                unsigned long long v = eslots[sl];
-                int probes = 0;
-                while ((v >> 24) != key && v != 0ULL && probes < kElectSlots) {
-                    sl = (sl + 1) & (kElectSlots - 1);
-                    v = eslots[sl];
-                    ++probes;
-                }
-                if ((v >> 24) != key) continue;                                    // never placed (table full)
-                slot = (int)sl;
+                slot = mine(ch, u, h) ? elect_find(eslots, rowv[u], h) : -1;
             }
-            if (!(eslots[slot] & 0x800000ULL)) continue;                           // looked up once
-            const int64_t occ = (int64_t)bq[u] * F + f;
-            const unsigned long long old = atomicAdd(&eslots[slot], 1ULL);
-            dd.seg_list[base1 + (int)(old & 0x7fffffULL)] = (int)occ;
-            rows_out[occ] = -1;
+            if (slot >= 0) elect_append(eslots, slot, dd, base1, ch * kChunk + tid + NT * u, F, f, rows_out);
         }
     }
 }
+
+// Any batch size (the prep launch takes this one beyond kElectSlots rows).  A block reading its field's B rows (8 B each) made
+// the launch 184 us at B = 65536 — eblocks x B x 8 bytes of L2 traffic in chunks of dependent round trips.  Here:
+//   * ~4096 lookups per block (half of the table's slots: a quarter of the blocks), and kernel A stores one BYTE per lookup —
+//     its row's partition (pid_fm) — which is all a block scans: B bytes, every load of the thread in flight at once;
+//   * the lookups whose byte matches are compacted into an LDS list (mlist, 32 KB: a launch with such blocks runs one per CU)
+//     and only THEIR rows are fetched — one round trip in pass 1, one (L2-warm) in pass 3;
+//   * segments / list entries go to the FIELD's region through two returning atomics (dd.seg_cur / dd.list_cur, zeroed by the
+//     launch that wrote rows_fm): per-block regions would take eblocks x B entries.
+// Termination / capacity: the table and the list hold kElectSlots entries.  A partition would have to be 2x over-full
+// (expected 4096 lookups, sigma 64 — or a batch that repeats few rows thousands of times: then the list fills up) — what does
+// not fit is counted in dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row.
+template <int NT, bool SOFT>
+__device__ __forceinline__ void elect_block_big(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
+                                                int64_t* __restrict__ rows_out, ElectSync sy) {
+    unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
+    int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases | [12] list length
+    int* mlist = scan + 16;                                                   // [kElectSlots] batch rows of this block's lookups
+    unsigned* mcount = reinterpret_cast<unsigned*>(scan + 12);
+    const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
+    const int f = 8 * (j >> dd.parts_log2) + (e & 7);
+    if (f >= F) return;
+    const int64_t* rf = dd.rows_fm + (int64_t)f * B;
+    const unsigned char* pf = dd.pid_fm + (int64_t)f * dd.pid_stride;
+    for (int i = tid; i < kElectSlots; i += NT) eslots[i] = 0ULL;
+    for (int i = tid; i < kElectSlots / 32; i += NT) multi[i] = 0u;
+    if (tid == 0) *mcount = 0u;
+    elect_barrier<NT, SOFT>(sy);
+    // scan: 16 partition bytes per load, four loads in flight per thread
+    for (int b0 = tid * 16; b0 < B; b0 += NT * 64) {
+        uint4 pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int bb = b0 + q * NT * 16;
+            pv[q] = bb < B ? *reinterpret_cast<const uint4*>(pf + bb) : make_uint4(~0u, ~0u, ~0u, ~0u);   // (pid_stride: B rounded up to 16)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned w[4] = {pv[q].x, pv[q].y, pv[q].z, pv[q].w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int b = b0 + q * NT * 16 + k;
+                if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
+                    const unsigned pos = atomicAdd(mcount, 1u);
+                    if (pos < (unsigned)kElectSlots) mlist[pos] = b;
+                }
+            }
+        }
+    }
+    elect_barrier<NT, SOFT>(sy);
+    const unsigned found = *mcount;
+    const int n = (int)min(found, (unsigned)kElectSlots);
+    int lost = (tid == 0 && found > (unsigned)kElectSlots) ? (int)(found - kElectSlots) : 0;
+    // pass 1 over the compact list: kElU rows per thread in flight
+    for (int i0 = tid; i0 < n; i0 += NT * kElU) {
+        int bq[kElU];
+        int64_t rowv[kElU];
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) {
+            const int i = i0 + NT * u;
+            bq[u] = i < n ? mlist[i] : -1;
+            rowv[u] = rf[bq[u] >= 0 ? bq[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kElU; ++u)
+            if (bq[u] >= 0 && elect_insert<true>(eslots, multi, rowv[u], elect_hash(rowv[u])) < 0) ++lost;
+    }
+    if (lost && dd.overflow) atomicAdd(dd.overflow, lost);
+    elect_barrier<NT, SOFT>(sy);
+    const int base1 = elect_segments<NT, SOFT, true>(eslots, multi, scan, dd, B, f, e, tid, sy);
+    for (int i0 = tid; i0 < n; i0 += NT * kElU) {
+        int bq[kElU];
+        int64_t rowv[kElU];
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) {
+            const int i = i0 + NT * u;
+            bq[u] = i < n ? mlist[i] : -1;
+            rowv[u] = rf[bq[u] >= 0 ? bq[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kElU; ++u) {
+            if (bq[u] < 0) continue;
+            const int slot = elect_find(eslots, rowv[u], elect_hash(rowv[u]));
+            if (slot >= 0) elect_append(eslots, slot, dd, base1, bq[u], F, f, rows_out);
+        }
+    }
+}
+constexpr size_t kElectLds = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
+constexpr size_t kElectLdsBig = kElectLds + (size_t)kElectSlots * sizeof(int);
+
 // the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
 __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {
     extern __shared__ unsigned long long eslots_dyn[];
     if (dd.seg_cur)
-        elect_block<1024, false, true>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
     else
-        elect_block<1024, false, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
 }
 
 // ids -> packed table rows (-1 = id out of range), row-major rows_out [B][F] (what the row-gradient epilogue reads) and
@@ -591,9 +660,9 @@ __global__ __launch_bounds__(1024) void k_prep(DeepFmDims dm, const float* __res
     if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots_dyn[];
         if (dd.seg_cur)
-            elect_block<1024, false, true>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+            elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
         else
-            elect_block<1024, false, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+            elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
         return;
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
@@ -2212,7 +2281,7 @@ static DedupeLayout dedupe_layout(int B, int F) {
     l.seg_cnt = take((int64_t)l.regions * l.cap * 4); l.seg_list = take((int64_t)l.regions * B * 4);
     l.list_cur = take((int64_t)fpad * 4);
     l.overflow = take(16);
-    l.pid_stride = (B + 7) & ~7;
+    l.pid_stride = (B + 15) & ~15;
     l.pid = take(l.by_field ? (int64_t)fpad * l.pid_stride : 0);
     l.total = o;
     return l;
@@ -2268,7 +2337,7 @@ extern "C" int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* 
     else
         hipLaunchKernelGGL(k_rows_of_ids<DT_IDX_I32>, dim3(ceil_div(B, 64)), dim3(256), 0, st, idx, row_offset, vocab, dm, rows_out,
                            dd.rows_fm, dd.seg_cur, dd.list_cur, dd.pid_fm, dd.pid_stride, dd.parts_log2);
-    const size_t ldsB = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
+    const size_t ldsB = dl.by_field ? kElectLdsBig : kElectLds;
     hipFuncSetAttribute((const void*)k_elect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_elect, dim3(dl.eblocks), dim3(1024), ldsB, st, dd, dm, rows_out);
     return launch_status("dt_deepfm_preelect");
@@ -2422,7 +2491,7 @@ static int tower_train_step(
                ws + wl.W2TL, W2, x3 ? x3_w1b : nullptr, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2,
                x3 && dcn ? x3_cwp : nullptr, cross_w, cross_b, w3, Lc};
     const int elect_blocks = (dd.rows_fm && !preelected) ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
-    const size_t ldsB = elect_blocks ? (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int) : 0;
+    const size_t ldsB = elect_blocks ? (dd.seg_cur ? kElectLdsBig : kElectLds) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     hipLaunchKernelGGL(k_prep, dim3(56 + elect_blocks), dim3(1024), ldsB, st, dm, W1, po, 56, dd, rows_out);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
