@@ -129,7 +129,8 @@ SIGNATURES = {
                                            _ptr, _ptr, _ptr, _ptr, _ptr, _c_f32, _c_f32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int,
                                            _c_f32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
-                                           _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
+                                           _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr, _ptr, _ptr, _ptr]),
+    'dt_deepfm_step_chains': (_c_int, [_c_int] * 5),
     'dt_deepfm_dropout_hash': (ctypes.c_uint32, [ctypes.c_uint32] * 3),
     'dt_feed_gather': (_c_int, [_ptr, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_embedding_gather_owned': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -153,7 +154,7 @@ SIGNATURES = {
                                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _ptr, _c_f32, _ptr,
                                         _ptr, _ptr, _c_int, _ptr, _c_f32, _c_f32, _c_f32, _c_f32,
-                                        _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr]),
+                                        _ptr, _ptr, _ptr, _c_i64, _c_f32, _ptr, _ptr, _ptr, _ptr]),
 }
 
 DT_IDX_F32, DT_IDX_I32 = 0, 1
@@ -163,6 +164,7 @@ DT_STEP_TOWER_X3 = 0x80
 DT_STEP_PREELECTED = 0x100
 DT_STEP_TOWER_BF16 = 0x200
 DT_STEP_STAMPS = 0x400
+DT_STEP_PREPARED = 0x800
 DT_FEED_CURSOR_WORDS = 528          # 16 (1 + 32 ticket groups), csrc/embedding.hip kFeedGroups
 DT_ACT_LINEAR, DT_ACT_RELU = 0, 1
 # keras.activations names the CIN / AFM kernels fuse (include/dt_hip.h DT_ACT_*)

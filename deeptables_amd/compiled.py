@@ -111,6 +111,7 @@ class CompiledTrainLoop:
         self._first_events = None
         self._slots_per_step = False
         self.preelected = False
+        self.chained = False
         self.uploaded = False
         srcs = list(feed.blocks) + ([] if self.slot_y is None else [feed.y])
         dsts = list(self.slots) + ([] if self.slot_y is None else [self.slot_y])
@@ -188,7 +189,7 @@ class CompiledTrainLoop:
         st = self.strategy
         return self.dp and getattr(st, 'sharded_embeddings', False) and st.active and self.dm.fused_plan() is not None
 
-    def _body(self, i, core_only=False, preelected=False):
+    def _body(self, i, core_only=False, preelected=False, chained=False):
         dm = self.dm
         ins, yb, wb = self._step_inputs(i)
         if core_only:
@@ -199,9 +200,16 @@ class CompiledTrainLoop:
             dm.model._dt_flat_grad = plan.accum
             return
         fused_opt = self.with_optimizer and not self.dp
+        chain = {}
+        if chained:
+            # chained steps (fused.can_chain): step i prepares step i + 1 (its ids sit in the slots already: the execution's
+            # gather ran first) and runs prepared by step i - 1; the first step of an execution prepares itself
+            if i + 1 < self.k:
+                chain['next_ids'] = (self.slots[0][(i + 1) * self.B:(i + 2) * self.B], i + 1)
+            chain['prepared'] = i >= 1
         loss, logit = dm._forward_backward(ins, yb, wb, apply_rows=fused_opt and self.strategy is None,
                                            logit_out=None if self.logits is None else self.logits[i],
-                                           slot=i if self._slots_per_step else 0, preelected=preelected)
+                                           slot=i if self._slots_per_step else 0, preelected=preelected, **chain)
         if fused_opt:
             dm.optimizer.step()             # single process: the optimizer step is part of the captured graph
         used_plan = getattr(dm, '_step_used_plan', False)
@@ -238,9 +246,15 @@ class CompiledTrainLoop:
         pre = (self.k > 1 and not self.dp and not core_only and plan is not None and hasattr(plan, 'can_preelect') and
                plan.can_preelect(self.B) and self.feed.kinds[0] == 'cat' and
                self.slots[0].dtype in (torch.int32, torch.float32))
-        self._slots_per_step = bool(pre)
+        # chained steps: the ids-only and weights-only work of step i + 1 inside step i's launches (no prep launch from the
+        # second step of an execution on)
+        chain = (not pre and self.k > 1 and not self.dp and not core_only and self.with_optimizer and plan is not None and
+                 hasattr(plan, 'can_chain') and plan.can_chain(self.B) and self.feed.kinds[0] == 'cat' and
+                 self.slots[0].dtype in (torch.int32, torch.float32) and not self.feed.weighted)
+        self.chained = bool(chain)
+        self._slots_per_step = bool(pre or chain)
         self.preelected = bool(pre)
-        if pre:                              # the steps' own rows / segment buffers exist before the capture starts
+        if pre or chain:                     # the steps' own rows / segment buffers exist before the capture starts
             for i in range(1, self.k):
                 plan._slot_buffers(self.B, i)
         g = torch.cuda.CUDAGraph()
@@ -265,7 +279,7 @@ class CompiledTrainLoop:
                 for i in range(self.k):
                     if pre and i == 1:
                         torch.cuda.current_stream().wait_stream(side)
-                    self._body(i, core_only=core_only, preelected=pre and i >= 1)
+                    self._body(i, core_only=core_only, preelected=pre and i >= 1, chained=chain)
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
         self._owner = (id(dm.model), id(dm.optimizer), id(getattr(dm, '_fused_plan', None)))

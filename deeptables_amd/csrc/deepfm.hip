@@ -134,6 +134,16 @@ struct DedupeWs {
     int pid_stride;
 };
 constexpr int kSegCap = kElectSlots / 2;     // a block's rows with >= 2 lookups: at most B / 2
+// Chained steps (dt_*_train_step_adam's `next_*` arguments): what step n does for step n + 1 while its own launches run —
+// kernel A packs the next ids' rows, the weight-gradient launch's matrix waves run the next election in their idle time, the
+// finishing launch writes the tile kernel's weight layouts from the weights it has just updated.  Step n + 1 then runs with
+// DT_STEP_PREPARED: no prep launch at all (four launches).  idx == NULL: not chained.
+struct StepNext {
+    const void* idx;             // [B][F] ids of the next step (same kind as this step's)
+    int64_t* rows_out;           // the next step's rows_out
+    DedupeWs dd;                 // ... and its dedupe workspace
+    int eblocks;                 // its election blocks
+};
 __device__ __forceinline__ unsigned elect_hash(int64_t row) { return ((unsigned)row ^ (unsigned)(row >> 32)) * 0x9E3779B1u; }
 // partition of a row among 2^parts_log2: the top bits of the hash (the low 13 bits pick the slot)
 __device__ __forceinline__ int elect_part(unsigned h, int parts_log2) { return (int)((h >> 13) >> (19 - parts_log2)); }
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
     DeepFmDims dm, float* __restrict__ X, float* __restrict__ lin_out, float* __restrict__ fm_out,
     int64_t* __restrict__ rows_out, int* __restrict__ oob, double* __restrict__ bnacc, DedupeWs dd,
     float* __restrict__ grad_rows, float* __restrict__ S_out, EmbDrop drop, unsigned long long* stamps,
-    double* __restrict__ racc_zero, int racc_n) {
+    double* __restrict__ racc_zero, int racc_n, StepNext nx) {
     __shared__ __attribute__((aligned(16))) float rowbuf[RPB][kMaxC];
     DT_STAMP(stamps, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
         // the two table rows.  Every load is unconditional from a clamped (valid) address and zeroed afterwards: guarded
         // loads made the compiler close each slot's region with s_waitcnt vmcnt(0) — six round trips in a row (round 2's
         // ISA reading).
-        int id[2], voc[2], fld[2];
+        int id[2], voc[2], fld[2], idn[2];
         int64_t roff[2];
         bool in[2];
 #pragma unroll
@@ -210,6 +220,9 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
             in[t] = j < NV;
             fld[t] = min(j, NV - 1) / LPR;
             id[t] = load_id<KIND>(idx, (int64_t)b * dm.F + fld[t]);
+            // chained steps (StepNext): the NEXT step's ids travel in the same round trip — its packed rows are written below, so
+            // that its election can run inside this step's weight-gradient launch
+            idn[t] = nx.idx ? load_id<KIND>(nx.idx, (int64_t)b * dm.F + fld[t]) : 0;
             voc[t] = vocab[fld[t]];
             roff[t] = row_offset[fld[t]];
         }
@@ -236,6 +249,11 @@ __global__ __launch_bounds__(64 * RPB) void k_sparse_fwd(
                         ok[t] ? (unsigned char)elect_part(elect_hash(row[t]), dd.parts_log2) : (unsigned char)0xff;
                 if (rows_out) rows_out[occ] = row[t];         // (NULL: a pre-elected step, dt_deepfm_preelect wrote them)
                 if (!ok[t] && oob) atomicAdd(oob, 1);
+                if (nx.idx) {
+                    const int64_t rn = (unsigned)idn[t] < (unsigned)voc[t] ? roff[t] + idn[t] : (int64_t)-1;
+                    nx.rows_out[occ] = rn;
+                    nx.dd.rows_fm[(int64_t)fld[t] * dm.B + b] = rn;
+                }
             }
         }
         DT_STAMP(stamps, 1);
@@ -463,10 +481,11 @@ __device__ __forceinline__ void elect_append(unsigned long long* eslots, int slo
     rows_out[occ] = -1;
 }
 
-// B <= kElectSlots
-template <int NT, bool SOFT>
+// B <= kElectSlots.  U = lookups per thread and chunk: NT x U >= 8192 keeps the whole field in one chunk (one round trip, slots in
+// registers) — 8 for a 1024-thread block, 32 for the 256 hosted threads
+template <int NT, bool SOFT, int U = kElU>
 __device__ __forceinline__ void elect_block(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
-                                            int64_t* __restrict__ rows_out, ElectSync sy) {
+                                            int64_t* __restrict__ rows_out, ElectSync& sy) {
     unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
     int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases
     // XCD-aware ids (workgroups go round-robin over the 8 XCDs): every partition block of a field runs on XCD f % 8,
@@ -478,13 +497,13 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
         return;
     }
     const int64_t* rf = dd.rows_fm + (int64_t)f * B;
-    constexpr int kChunk = NT * kElU;
+    constexpr int kChunk = NT * U;
     const int nchunks = (B + kChunk - 1) / kChunk;
-    int64_t rowv[kElU];
-    int myslot[kElU];
+    int64_t rowv[U];
+    int myslot[U];
     auto load_chunk = [&](int ch) {                           // all of the thread's row loads of the chunk in flight
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) rowv[u] = rf[min(ch * kChunk + tid + NT * u, B - 1)];
+        for (int u = 0; u < U; ++u) rowv[u] = rf[min(ch * kChunk + tid + NT * u, B - 1)];
     };
     auto mine = [&](int ch, int u, unsigned& h) {             // is lookup u of the chunk one of this block's?
         const int64_t row = rowv[u];
@@ -499,7 +518,7 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch) load_chunk(ch);
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) {
+        for (int u = 0; u < U; ++u) {
             unsigned h;
             myslot[u] = mine(ch, u, h) ? elect_insert<false>(eslots, multi, rowv[u], h) : -1;
         }
@@ -510,7 +529,7 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
     for (int ch = 0; ch < nchunks; ++ch) {
         if (nchunks > 1) load_chunk(ch);
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) {
+        for (int u = 0; u < U; ++u) {
             int slot = myslot[u];
             if (nchunks > 1) {
                 unsigned h;
@@ -534,7 +553,7 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
 // not fit is counted in dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row.
 template <int NT, bool SOFT>
 __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
-                                                int64_t* __restrict__ rows_out, ElectSync sy) {
+                                                int64_t* __restrict__ rows_out, ElectSync& sy) {
     unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
     int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases | [12] list length
     int* mlist = scan + 16;                                                   // [kElectSlots] batch rows of this block's lookups
@@ -613,10 +632,11 @@ constexpr size_t kElectLdsBig = kElectLds + (size_t)kElectSlots * sizeof(int);
 // the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
 __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {
     extern __shared__ unsigned long long eslots_dyn[];
+    ElectSync sy{nullptr, 0u};
     if (dd.seg_cur)
-        elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, sy);
     else
-        elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+        elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, sy);
 }
 
 // ids -> packed table rows (-1 = id out of range), row-major rows_out [B][F] (what the row-gradient epilogue reads) and
@@ -659,10 +679,11 @@ __global__ __launch_bounds__(1024) void k_prep(DeepFmDims dm, const float* __res
     const int bid = (int)blockIdx.x - elect_blocks;          // < 0: election block
     if (bid < 0) {   // the dedupe's election (see DedupeWs): block = (field, hash partition)
         extern __shared__ unsigned long long eslots_dyn[];
+        ElectSync sy{nullptr, 0u};
         if (dd.seg_cur)
-            elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+            elect_block_big<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, sy);
         else
-            elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, ElectSync{nullptr, 0u});
+            elect_block<1024, false>(eslots_dyn, dd, dm.B, dm.F, (int)blockIdx.x, (int)threadIdx.x, rows_out, sy);
         return;
     }
     if (bid >= bn_blocks && o.x3_W1B) {  // weight layouts of the split-bf16 tower (tower_x3.h): hi | lo halves, 16 bytes per store
@@ -1782,22 +1803,47 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
 // waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
 // d linear_logit kernel: field f = its D columns, dense k = one column.
+// Chained steps: the split-bf16 tile kernel's weight layouts (X3Weights, tower_x3.h) written by the finishing launch from the
+// weights it has just updated — the prep launch's layout blocks of the NEXT step (k_prep writes the same values from the
+// same fp32 weights: every part is the bf16 rounding of what the parts before it left).  W1B == NULL: not written.
+struct X3Lay {
+    __bf16 *W1B, *W1R, *W2B, *W2R;
+    int64_t w1b_lo, w1r_lo, w2b_lo, w2r_lo;
+    float* cwp;                  // DCN: [2 L + 1][CP] fp32 copies of the cross kernels | biases | w3c
+};
+__device__ __forceinline__ void x3_parts(float v, __bf16 (&q)[3]) {
+    float r = v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const __bf16 a = (__bf16)r;
+        q[k] = a;
+        r -= (float)a;
+    }
+}
+
 __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, const DeepFmDims& dm, float* accum,
                                                const DeepFmAccum& al, const float* __restrict__ wpart, int row_blocks,
                                                int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
                                                const float* __restrict__ w3c, const RecSrc& rs, const Part3& pl,
-                                               floatx2 (*sm)[64], const DenseAdam& da, int blk) {
+                                               floatx2 (*sm)[64], float* slin_s, const DenseAdam& da, int blk,
+                                               const X3Lay& lay = X3Lay{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr}) {
     // (what the tile kernel summed over the batch — db1, the d w_lin column sums, DCN's cross record — is read from the
     // record shards here: no launch stands between kernel C and this one for them)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blk == 0 && Lc == 0) {
+        // d linear_logit kernel: field f = the sum of its D columns of sum_b dz X.  Every column sum is fetched by its own
+        // thread (ONE round trip for the block; a thread walking its field's D columns made D dependent ones — the longest
+        // chain of the launch), the fields are added up from LDS.
+        float* sl = reinterpret_cast<float*>(slin_s);
+        for (int c = threadIdx.x; c < dm.C; c += blockDim.x) sl[c] = rec_sum(rs, pl.slin + c);
+        __syncthreads();
         for (int q = threadIdx.x; q < dm.F + dm.Nd; q += blockDim.x) {
             float v = 0.f;
             if (q < dm.F) {
-                for (int d = 0; d < dm.D; ++d) v += rec_sum(rs, pl.slin + q * dm.D + d);
+                for (int d = 0; d < dm.D; ++d) v += sl[q * dm.D + d];
             } else {
-                v = rec_sum(rs, pl.slin + dm.F * dm.D + (q - dm.F));
+                v = sl[dm.F * dm.D + (q - dm.F)];
             }
             accum[al.dwlin + q] = v;
             if (da.p) adam_one(da.p, da.m, da.v, al.dwlin + q, v, da.lr_t, da.b1, da.b2, da.eps);
@@ -1829,6 +1875,7 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     if (da.p && wave == 0) {
         pp[0] = da.p[e0]; pp[1] = da.p[e1]; pm[0] = da.m[e0]; pm[1] = da.m[e1]; pv[0] = da.v[e0]; pv[1] = da.v[e1];
     }
+    float pnew[2] = {0.f, 0.f};                   // the two updated weights (chained steps: their bf16 parts go to the layouts)
     auto adam2 = [&](float g0, float g1) {       // Keras Adam on elements e0, e1 from the prefetched slots
         const float g[2] = {g0, g1};
         const int64_t ei[2] = {e0, e1};
@@ -1838,7 +1885,8 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
             const float vi = da.b2 * pv[k] + (1.f - da.b2) * g[k] * g[k];
             da.m[ei[k]] = mi;
             da.v[ei[k]] = vi;
-            da.p[ei[k]] = pp[k] - da.lr_t * mi / (sqrtf(vi) + da.eps);
+            pnew[k] = pp[k] - da.lr_t * mi / (sqrtf(vi) + da.eps);
+            da.p[ei[k]] = pnew[k];
         }
     };
     floatx2 v[8];
@@ -1864,6 +1912,25 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         accum[e0] = m.x;
         accum[e1] = m.y;
         if (da.p) adam2(m.x, m.y);
+        if (da.p && lay.W1B) {
+            // W2[k][n = row], k = 2 lane + i.  W2R: row-major [128][64]; W2B: element j of lane (n % 16, g), step s, column tile t
+            // = W2[32 s + 8 g + j][16 t + n % 16] — k = 2 lane, 2 lane + 1 are neighbours j, j + 1 of one lane's 8
+            __bf16 q0[3], q1[3];
+            x3_parts(pnew[0], q0);
+            x3_parts(pnew[1], q1);
+            const int k0 = 2 * lane, n = row;
+            const int64_t ib = ((((int64_t)(k0 >> 5) * 4 + (n >> 4)) * 64) + ((k0 >> 3) & 3) * 16 + (n & 15)) * 8 + (k0 & 7);
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) {
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<b2*>(lay.W2B + pt * lay.w2b_lo + ib) = b2{q0[pt], q1[pt]};
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                lay.W2R[pt * lay.w2r_lo + (int64_t)k0 * kH2 + n] = q0[pt];
+                lay.W2R[pt * lay.w2r_lo + (int64_t)(k0 + 1) * kH2 + n] = q1[pt];
+            }
+        }
         return;
     }
     const float dg = wave_sum(w.x * m.x + w.y * m.y);
@@ -1873,6 +1940,26 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         const floatx2 g = floatx2{ga * m.x + be * d.x, ga * m.y + be * d.y};
         *reinterpret_cast<floatx2*>(accum + e0) = g;
         if (da.p) adam2(g.x, g.y);
+        if (da.p && lay.W1B) {
+            // W1[k = col][n], n = 2 lane + i.  W1R: row-major [CP][128]; W1B: element j of lane (n % 16, g), step s, wave w
+            // = W1[32 s + 8 g + j][16 w + n % 16]
+            __bf16 q0[3], q1[3];
+            x3_parts(pnew[0], q0);
+            x3_parts(pnew[1], q1);
+            const int k = col, n0 = 2 * lane;
+            const int64_t kb = ((int64_t)(k >> 5) * 8) * 64 * 8 + (((k >> 3) & 3) * 16) * 8 + (k & 7);
+            const int64_t i0 = kb + ((int64_t)(n0 >> 4) * 64 + (n0 & 15)) * 8, i1 = kb + ((int64_t)((n0 + 1) >> 4) * 64 + ((n0 + 1) & 15)) * 8;
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) {
+                lay.W1B[pt * lay.w1b_lo + i0] = q0[pt];
+                lay.W1B[pt * lay.w1b_lo + i1] = q1[pt];
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<b2*>(lay.W1R + pt * lay.w1r_lo + (int64_t)k * kH1 + n0) = b2{q0[pt], q1[pt]};
+            }
+        }
     }
     if (Lc) {
         // DCN: lane l <= Lc finishes layer l of this column (lane Lc: the w3c entry) — the gradients, and in
@@ -1880,24 +1967,33 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         // dependent round trips: 19 us for the launch).  The BN-backward sums are the tile kernel's (sdx / sdxx).
         // Cross record (see the cross backward of kernel C): vectors G_0 .. G_L [CP] | scalars [32]: Sco_l at l, SA_l at 16 + l, Sdz at 31
         const int scal = pl.cross + (Lc + 1) * dm.CP;
-        if (lane <= Lc) {
-            const int l = lane;
-            const float sdz = rec_sum(rs, scal + 31);
-            float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
-            for (int j = 0; j < Lc; ++j) {
-                const float bj = cb[(int64_t)j * dm.C + col], wj = cw[(int64_t)j * dm.C + col];
-                if (j < l) cl += bj;
-                if (j > l) suf += rec_sum(rs, scal + 16 + j) * wj;
-            }
+        // every shard sum this column needs is requested at once (lane j holds SA_j / Sco_j; a lane walking them one after
+        // the other paid Lc dependent round trips)
+        const int l = lane;
+        const float sa_mine = l < Lc ? rec_sum(rs, scal + 16 + l) : 0.f;
+        const float sco_mine = l <= Lc ? rec_sum(rs, scal + l) : 0.f;
+        const float G = l <= Lc ? rec_sum(rs, pl.cross + l * dm.CP + col) : 0.f;
+        const float sdz = rec_sum(rs, scal + 31);
+        float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
+        for (int j = 0; j < Lc; ++j) {
+            const float saj = __shfl(sa_mine, j, 64);
+            const float bj = cb[(int64_t)j * dm.C + col], wj = cw[(int64_t)j * dm.C + col];
+            if (j < l) cl += bj;
+            if (j > l) suf += saj * wj;
+        }
+        if (l <= Lc) {
             const int64_t ig = l < Lc ? al.dcw + (int64_t)l * dm.C + col : al.dw3 + col;
-            const float G = rec_sum(rs, pl.cross + l * dm.CP + col);
-            const float gw = ga_b * G + be_b * rec_sum(rs, scal + l) + (l < Lc ? rec_sum(rs, scal + 16 + l) : sdz) * cl;
+            const float gw = ga_b * G + be_b * sco_mine + (l < Lc ? sa_mine : sdz) * cl;
             const float gb = sdz * w3c[col] + suf;                // d b_l (l < Lc)
             accum[ig] = gw;
             if (l < Lc) accum[al.dcb + (int64_t)l * dm.C + col] = gb;
             if (da.p) {
                 adam_one(da.p, da.m, da.v, ig, gw, da.lr_t, da.b1, da.b2, da.eps);
                 if (l < Lc) adam_one(da.p, da.m, da.v, al.dcb + (int64_t)l * dm.C + col, gb, da.lr_t, da.b1, da.b2, da.eps);
+                if (lay.cwp) {       // chained steps: the padded fp32 copies [cross kernels | cross biases | w3c] the tile kernel reads
+                    lay.cwp[(int64_t)(l < Lc ? l : 2 * Lc) * dm.CP + col] = da.p[ig];
+                    if (l < Lc) lay.cwp[(int64_t)(Lc + l) * dm.CP + col] = da.p[al.dcb + (int64_t)l * dm.C + col];
+                }
             }
         }
     }
@@ -1910,10 +2006,11 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
                                                    const float* __restrict__ w3c, RecSrc rs, int col_blocks) {
     // blocks [0, col_blocks): one per column (E'); the blocks behind them: the record entries -> the gradient buffer
     __shared__ floatx2 sm[4][64];
+    __shared__ float slin_s[kMaxC];
     const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
     const Part3 pl = part3_layout(dm.CP, Lc, 1);
     if ((int)blockIdx.x < col_blocks)
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, none, (int)blockIdx.x);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, none, (int)blockIdx.x);
     else
         finish_record_entry(((int)blockIdx.x - col_blocks) * (int)blockDim.x + (int)threadIdx.x, rs, pl, al, dm, Lc, accum, none);
 }
@@ -1941,14 +2038,15 @@ struct FinishSeg {
     const float* values;
     int sstride, D;
 };
-__global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W1, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, 4) void k_finish_step(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                      DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
                                                      int small_blocks, int seg_blocks, FinishSeg fs, int Lc,
                                                      const float* __restrict__ cw, const float* __restrict__ cb,
-                                                     const float* __restrict__ w3c, RecSrc rs) {
+                                                     const float* __restrict__ w3c, RecSrc rs, X3Lay lay) {
     __shared__ floatx2 sm[4][64];
+    __shared__ float slin_s[kMaxC];
     const Part3 pl = part3_layout(dm.CP, Lc, 1);
     // every thread reads lr_t itself (a uniform scalar load, consumed at the end of its dependency chain) instead of one
     // thread + an LDS broadcast behind a barrier at the block's start — one dependent round trip less per block; the
@@ -1962,7 +2060,7 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
     if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, da, b);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, da, b, lay);
     } else if (b < col_blocks + small_blocks) {
         // one thread per record entry: db1 | db2 | dw3 (dnn part) | dwo | dbo | loss | dbeta | dgamma — summed over the shards,
         // stored, updated (the d w_lin entries — DCN: the cross kernels / biases — belong to the column blocks above)
@@ -2142,13 +2240,24 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
                                                     RowsEpi ep, RowsAdam ad, EmbDrop drop,
                                                     unsigned long long* stamps_rows, int matrix_waves_join,
-                                                    double* __restrict__ bnacc_zero, int bnacc_n) {
+                                                    double* __restrict__ bnacc_zero, int bnacc_n, StepNext nx) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
-    __shared__ unsigned arrived, work[2];
-    if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; }
+    __shared__ unsigned arrived, work[2], ecnt;
+    if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; ecnt = 0u; }
     __syncthreads();          // the only hardware barrier: the two halves never wait for each other afterwards
     if (threadIdx.x < 256) {
         wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
+        if (nx.idx) {
+            // chained steps: the NEXT step's election (ids only: kernel A of this step packed its rows) on the four matrix
+            // waves, in the 64 KB of LDS their partial tiles just left — a launch of its own costs 9 us of the step's chain
+            // (k_prep), here it takes time the matrix waves would have spent helping with the row epilogue
+            ElectSync sy{&ecnt, 0u};
+            for (int e = (int)blockIdx.x; e < nx.eblocks; e += (int)gridDim.x) {
+                elect_barrier<256, true>(sy);                     // every wave is done with the LDS (partial tiles / the table before)
+                elect_block<256, true, 32>(reinterpret_cast<unsigned long long*>(red), nx.dd, dm.B, dm.F, e, (int)threadIdx.x,
+                                           nx.rows_out, sy);
+            }
+        }
         // the GEMM's partial tile is stored: the matrix waves take their share of what is left of the epilogue
         if (matrix_waves_join) rows_epilogue_wave<DCN>(work, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
         if (stamps_all && threadIdx.x == 0) stamps_all[(int64_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime();
@@ -2352,6 +2461,28 @@ struct StepDense {
     float lr;
 };
 
+// chained steps (see StepNext): the next step's ids and the buffers its election fills
+struct StepChain {
+    const void* next_idx;
+    int64_t* next_rows_out;
+    void* next_dedupe_ws;
+};
+// a step of this shape / these phases can be chained (prepare its successor, run prepared): the in-step optimizer on the
+// split-bf16 tile kernel, a batch the register-resident election takes
+static bool step_chains(const DeepFmDims& dm, int phases, bool with_dense, bool with_dedupe) {
+    const bool x3_flag = (phases & (DT_STEP_TOWER_X3 | DT_STEP_TOWER_BF16)) != 0;
+    return (phases & 0xf) == 2 && !(phases & (DT_STEP_SKIP_FINISH | DT_STEP_FINISH_ONLY)) && x3_flag && dm.CP <= 512 &&
+           x3_fits(dm.CP) && with_dense && with_dedupe && dm.B <= kElectSlots && (int64_t)dm.B * dm.F < (1LL << 23);
+}
+
+// 1 when dt_deepfm_train_step_adam / dt_dcn_train_step_adam with these phases (and dense_n > 0, dedupe_ws) can prepare its
+// successor (next_idx) and run prepared (DT_STEP_PREPARED)
+extern "C" int dt_deepfm_step_chains(int B, int F, int D, int Nd, int phases) {
+    DeepFmDims dm; int lpr;
+    if (!deepfm_dims(B, F, D, Nd, &dm, &lpr)) return 0;
+    return step_chains(dm, phases, true, true) ? 1 : 0;
+}
+
 // the step both entry points run: DeepFM (cross == NULL) or DCN (cross kernels / biases [Lc][C]; w3 = the [C + 64] kernel
 // applied to Concatenate([cross, dnn]), w_lin unused)
 static int tower_train_step(
@@ -2364,7 +2495,7 @@ static int tower_train_step(
     void* dedupe_ws, int64_t dedupe_slots, float grad_rows_scale, int grad_rows_field_major, int phases,
     float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
     const float* sample_weight, void* stream, const float* cross_w, const float* cross_b, int Lc,
-    const RowsAdam* adam = nullptr, const StepDense* sdense = nullptr) {
+    const RowsAdam* adam = nullptr, const StepDense* sdense = nullptr, const StepChain* chain = nullptr) {
     DeepFmDims dm; int lpr;
     DT_UNSUPPORTED(!deepfm_dims(B, F, D, Nd, &dm, &lpr), "dt_deepfm_train_step: unsupported shape B=%d F=%d D=%d Nd=%d",
                    B, F, D, Nd);
@@ -2385,7 +2516,9 @@ static int tower_train_step(
     const bool skip_finish = (phases & DT_STEP_SKIP_FINISH) != 0, finish_only = (phases & DT_STEP_FINISH_ONLY) != 0;
     const bool bf16_flag = (phases & DT_STEP_TOWER_BF16) != 0;       // plain bf16: the split kernel with the leading products only
     const bool x3_flag = (phases & DT_STEP_TOWER_X3) != 0 || bf16_flag;
-    const bool preelected = (phases & DT_STEP_PREELECTED) != 0;
+    const bool prepared = (phases & DT_STEP_PREPARED) != 0;      // election + weight layouts done by the previous step's launches
+    const bool preelected = (phases & DT_STEP_PREELECTED) != 0 || prepared;
+    const int phases_all = phases;
     const bool stamps_flag = (phases & DT_STEP_STAMPS) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
@@ -2458,6 +2591,21 @@ static int tower_train_step(
                "dt_deepfm_train_step_adam: the in-step row update needs a backward step with the in-step dedupe (dedupe_ws) "
                "and row-major row gradients");
 
+    // chained steps: both directions need a step the chain covers (dt_deepfm_step_chains)
+    const bool chains = step_chains(dm, phases_all, adam && sdense, dd.rows_fm != nullptr);
+    DT_REQUIRE(!prepared || chains, "dt_deepfm_train_step: DT_STEP_PREPARED on a step that cannot be chained (dt_deepfm_step_chains)");
+    DT_REQUIRE(!(chain && chain->next_idx) || (chains && chain->next_rows_out && chain->next_dedupe_ws),
+               "dt_deepfm_train_step_adam: next_idx on a step that cannot be chained, or without next_rows_out / next_dedupe_ws");
+    StepNext nx{nullptr, nullptr, dd, 0};
+    if (chain && chain->next_idx) {
+        DT_REQUIRE((uintptr_t)chain->next_dedupe_ws % 16 == 0 && chain->next_dedupe_ws != dedupe_ws && chain->next_rows_out != rows_out,
+                   "dt_deepfm_train_step_adam: the next step needs its own rows_out / dedupe_ws (16-byte aligned)");
+        const DedupeLayout dln = dedupe_layout(B, F);
+        nx.idx = chain->next_idx;
+        nx.rows_out = chain->next_rows_out;
+        nx.dd = dedupe_view(chain->next_dedupe_ws, dln);
+        nx.eblocks = dln.eblocks;
+    }
     // A (a pre-elected step: rows_out / rows_fm and the segments exist already — kernel A writes neither, the prep launch
     //    has no election blocks)
     DedupeWs ddA = dd;
@@ -2469,7 +2617,7 @@ static int tower_train_step(
     hipLaunchKernelGGL((k_sparse_fwd<KIND, L, kRowsPerBlockA>), dim3(blocksA), dim3(64 * kRowsPerBlockA), 0, st, idx, \
                        (const float4*)table, row_offset, vocab, dense, w_lin, dm, ws + wl.X, ws + wl.lin, ws + wl.fm, \
                        preelected ? (int64_t*)nullptr : rows_out, oob_count, bnacc, ddA, grad_rows, ws + wl.S, drop, \
-                       stamps ? stamps + (int64_t)tiles * 48 : nullptr, racc, (int)wl.racc_n)
+                       stamps ? stamps + (int64_t)tiles * 48 : nullptr, racc, (int)wl.racc_n, nx)
 #define DT_A_L(KIND)                                                                  \
     switch (lpr) {                                                                    \
         case 1: DT_A(KIND, 1); break; case 2: DT_A(KIND, 2); break;                   \
@@ -2493,7 +2641,8 @@ static int tower_train_step(
     const int elect_blocks = (dd.rows_fm && !preelected) ? ((((F + 7) >> 3) << 3) << dd.parts_log2) : 0;      // fields padded to 8 (XCD-aware ids)
     const size_t ldsB = elect_blocks ? (dd.seg_cur ? kElectLdsBig : kElectLds) : 0;
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-    hipLaunchKernelGGL(k_prep, dim3(56 + elect_blocks), dim3(1024), ldsB, st, dm, W1, po, 56, dd, rows_out);
+    // (a prepared step has neither an election nor layouts left to do: no prep launch)
+    if (!prepared) hipLaunchKernelGGL(k_prep, dim3(56 + elect_blocks), dim3(1024), ldsB, st, dm, W1, po, 56, dd, rows_out);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
         size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
@@ -2567,13 +2716,13 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx);
         } else {
             hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
             hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx);
         }
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
@@ -2588,10 +2737,13 @@ static int tower_train_step(
             const FinishSeg fs{SegTail{dd.nseg, dd.seg_row, dd.seg_off, dd.seg_cnt, dd.seg_list, dl.regions, dl.cap},
                                adam->table, adam->m, adam->v, grad_rows, adam->sstride, D};
             const DenseAdam da{sdense->p, sdense->m, sdense->v, adam->lr_t_host, adam->b1, adam->b2, adam->eps};
+            // chained steps: the next step's weight layouts, from the weights this launch updates
+            const X3Lay lay = nx.idx ? X3Lay{x3_w1b, x3_w1r, x3_w2b, x3_w2r, n1, n1, n2, n2, dcn ? x3_cwp : nullptr}
+                                     : X3Lay{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
-                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc);
+                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay);
         } else if (!skip_finish) {
             // E': slices added up, dW1 / dW2 / d w_lin finished; the record entries (db1 .. dgamma / dbeta) -> accum
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
@@ -2642,7 +2794,8 @@ extern "C" int dt_deepfm_train_step_adam(
     void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
     const float* sample_weight,
     float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
-    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
+    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr,
+    const void* next_idx, int64_t* next_rows_out, void* next_dedupe_ws, void* stream) {
     DT_REQUIRE(w_lin && table && adam_m && adam_v, "dt_deepfm_train_step_adam: null pointer");
     DT_REQUIRE(dense_n == 0 || (dense_p && dense_m && dense_v && adam_state),
                "dt_deepfm_train_step_adam: the dense half needs the flat buffers and the device step state");
@@ -2653,10 +2806,12 @@ extern "C" int dt_deepfm_train_step_adam(
     const RowsAdam ad{table, adam_m, adam_v, slot_stride, adam_state ? adam_state_lr_t(adam_state) : nullptr, lr_t, beta1,
                       beta2, eps, 0};
     const StepDense sd{dense_p, dense_m, dense_v, dense_n, adam_state, lr};
+    const StepChain ch{next_idx, next_rows_out, next_dedupe_ws};
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, w_lin, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, nullptr, nullptr, 0, &ad, dense_n > 0 ? &sd : nullptr);
+                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, nullptr, nullptr, 0, &ad, dense_n > 0 ? &sd : nullptr,
+                            &ch);
 }
 
 // ---- DCN (nets ['dcn_nets'], deepnets.py:194-207): the same step with the Cross network (layers.py:428-436) in place of
@@ -2712,7 +2867,8 @@ extern "C" int dt_dcn_train_step_adam(
     void* dedupe_ws, int64_t dedupe_slots, int phases, float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
     const float* sample_weight,
     float* adam_m, float* adam_v, int slot_stride, void* adam_state, float lr_t, float beta1, float beta2,
-    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream) {
+    float eps, float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr,
+    const void* next_idx, int64_t* next_rows_out, void* next_dedupe_ws, void* stream) {
     DT_REQUIRE(cross_w && cross_b && table && adam_m && adam_v, "dt_dcn_train_step_adam: null pointer");
     DT_UNSUPPORTED(L < 1 || L > kCrossMax, "dt_dcn_train_step_adam: %d cross layers (1..%d)", L, kCrossMax);
     DT_REQUIRE((phases & 0xf) == 2 && dedupe_ws, "dt_dcn_train_step_adam: a backward step (phases 2) with dedupe_ws");
@@ -2724,10 +2880,12 @@ extern "C" int dt_dcn_train_step_adam(
     const RowsAdam ad{table, adam_m, adam_v, slot_stride, adam_state ? adam_state_lr_t(adam_state) : nullptr, lr_t, beta1,
                       beta2, eps, 0};
     const StepDense sd{dense_p, dense_m, dense_v, dense_n, adam_state, lr};
+    const StepChain ch{next_idx, next_rows_out, next_dedupe_ws};
     return tower_train_step(idx, idx_kind, table, row_offset, vocab, dense, y, B, F, D, Nd, nullptr, bn_gamma, bn_beta,
                             bn_moving_mean, bn_moving_var, bn_eps, bn_momentum, W1, b1, W2, b2, w3, w_out, b_out, logit_out,
                             rows_out, grad_rows, accum, workspace, oob_count, dedupe_ws, dedupe_slots, 1.0f, 0, phases,
-                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, cross_w, cross_b, L, &ad, dense_n > 0 ? &sd : nullptr);
+                            embedding_dropout, dropout_seed, dense_input_dropout, sample_weight, stream, cross_w, cross_b, L, &ad, dense_n > 0 ? &sd : nullptr,
+                            &ch);
 }
 
 extern "C" int dt_dcn_train_step(

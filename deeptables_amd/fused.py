@@ -407,9 +407,32 @@ class FusedDeepFM:
         self.emb.sparse_grads[self.key] = [SparseRowGrad(sb['rows_own'].view(-1), grad_own.view(-1, D), fields=0)]
         return work
 
+    def _whole_in_step(self, opt):
+        """the optimizer's flat dense group is this plan's: the step's last launch runs the whole optimizer step"""
+        table = self.emb.tables[self.key]
+        flat = getattr(opt, '_flat', None)
+        return bool(flat is not None and flat[0] is self.flat_params and flat[1] is self.accum and
+                    os.environ.get('DT_AMD_STEP_IN_STEP', '1') != '0' and
+                    all(id(p) in flat[5] for p in opt.params if p is not table))
+
+    def can_chain(self, B):
+        """consecutive steps of one captured execution can be CHAINED (csrc/deepfm.hip StepNext): step i packs step i + 1's
+        rows, runs its election on the weight-gradient launch's idle matrix waves and writes the tile kernel's weight layouts
+        from the weights it has just updated — step i + 1 then has no prep launch (four launches).  Single process, in-step
+        dedupe and optimizer, split-bf16 tower, B <= 8192; DT_AMD_CHAIN=0 turns it off."""
+        if os.environ.get('DT_AMD_CHAIN', '1') == '0' or self.dm.config.distribute_strategy is not None:
+            return False
+        opt = _rows_in_step(self, B, True, True) if _dedupe_in_step(self, B, True) else None
+        if opt is None or not self._whole_in_step(opt):
+            return False
+        phases = 2 | _step_loss(self.dm) | self.tower_flag
+        return bool(lib().dt_deepfm_step_chains(B, self.F, self.D, self.Nd, phases))
+
     def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None, slot=0,
-            preelected=False):
-        """-> (loss [1] view, logit [B,1]).  slot / preelected: the compiled loop's per-step id buffers (`preelect`).  logit_out: a caller-owned [B,1] fp32 buffer the step writes its logits to (the
+            preelected=False, next_ids=None, prepared=False):
+        """-> (loss [1] view, logit [B,1]).  slot / preelected: the compiled loop's per-step id buffers (`preelect`).
+        next_ids / prepared (chained steps, `can_chain`): next_ids = (ids of the following step, its slot) — this step prepares
+        it; prepared: this step was prepared by the one before it (slot's buffers hold its rows / segments).  logit_out: a caller-owned [B,1] fp32 buffer the step writes its logits to (the
         compiled loop keeps one per captured step) instead of the plan's own.  With backward=True fills `.grad` of every dense parameter
         (views of one static buffer) and registers the embedding table's sparse gradient.  apply_rows=True: the caller
         runs `optimizer.step()` right after this call, so the step may update the table rows looked up once itself
@@ -441,6 +464,18 @@ class FusedDeepFM:
         pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
         if preelected and not pre:
             raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process)')
+        nxt = (None, None, None)
+        if prepared or next_ids is not None:
+            if opt is None or not dedupe:
+                raise _lib.DtHipError('chained steps need the in-step dedupe and optimizer (can_chain)')
+            if prepared:
+                pre |= _lib.DT_STEP_PREPARED
+            if next_ids is not None:
+                nidx, nslot = next_ids
+                if nidx.dtype != idx.dtype or nidx.shape != idx.shape or not nidx.is_contiguous() or not nslot or nslot == slot:
+                    raise ValueError('next_ids: (contiguous ids like this step\'s, a slot of their own)')
+                nb = self._slot_buffers(B, nslot)
+                nxt = (ptr(nidx), ptr(nb['rows']), ptr(nb['dedupe']))
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.lin.kernel), ptr(self.bn.gamma), ptr(self.bn.beta),
@@ -464,7 +499,7 @@ class FusedDeepFM:
             check(lib().dt_deepfm_train_step_adam(
                 *head, 2 | _step_loss(self.dm) | self.tower_flag | self.diag_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
-                opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_deepfm_train_step_adam')
+                opt.b1, opt.b2, opt.eps, *dn, *nxt, stream_ptr()), 'dt_deepfm_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:
@@ -609,7 +644,7 @@ class FusedDCN(FusedDeepFM):
         return b
 
     def run(self, idx, dense, y, backward=True, apply_rows=False, sample_weight=None, logit_out=None, slot=0,
-            preelected=False):
+            preelected=False, next_ids=None, prepared=False):
         self.dm.model._dt_sharded_step = False
         B = idx.shape[0]
         buf = self._buffers(B)
@@ -633,6 +668,18 @@ class FusedDCN(FusedDeepFM):
         pre = _lib.DT_STEP_PREELECTED if (preelected and dedupe and backward) else 0
         if preelected and not pre:
             raise _lib.DtHipError('a pre-elected step needs the in-step dedupe (backward, single process)')
+        nxt = (None, None, None)
+        if prepared or next_ids is not None:
+            if opt is None or not dedupe:
+                raise _lib.DtHipError('chained steps need the in-step dedupe and optimizer (can_chain)')
+            if prepared:
+                pre |= _lib.DT_STEP_PREPARED
+            if next_ids is not None:
+                nidx, nslot = next_ids
+                if nidx.dtype != idx.dtype or nidx.shape != idx.shape or not nidx.is_contiguous() or not nslot or nslot == slot:
+                    raise ValueError('next_ids: (contiguous ids like this step\'s, a slot of their own)')
+                nb = self._slot_buffers(B, nslot)
+                nxt = (ptr(nidx), ptr(nb['rows']), ptr(nb['dedupe']))
         head = (ptr(idx), kind, ptr(table), ptr(getattr(self.emb, f'row_offset_{self.key}')),
                 ptr(getattr(self.emb, f'vocab_{self.key}')), ptr(dense), ptr(y), B, self.F, self.D, self.Nd,
                 ptr(self.cross.kernel_stack), ptr(self.cross.bias_stack), self.nl, ptr(self.bn.gamma), ptr(self.bn.beta),
@@ -652,7 +699,7 @@ class FusedDCN(FusedDeepFM):
             check(lib().dt_dcn_train_step_adam(
                 *head, 2 | _step_loss(self.dm) | self.tower_flag | self.diag_flag | pre, self.emb_dropout if training else 0.0, ptr(self.drop_seed),
                 self.dense_dropout if training else 0.0, ptr(sw), ptr(slots['m']), ptr(slots['v']), int(slots['m'].stride(0)), ptr(opt._state_tensor(table.device)), 0.0,
-                opt.b1, opt.b2, opt.eps, *dn, stream_ptr()), 'dt_dcn_train_step_adam')
+                opt.b1, opt.b2, opt.eps, *dn, *nxt, stream_ptr()), 'dt_dcn_train_step_adam')
             if whole:
                 opt.applied_in_step()
         else:

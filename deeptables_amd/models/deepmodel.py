@@ -269,12 +269,12 @@ class DeepModel:
         return self._forward_backward(inputs, y, sample_weight, logit_out=logit_out)
 
     def _forward_backward(self, inputs, y, sample_weight=None, apply_rows=False, logit_out=None, slot=0, preelected=False,
-                          next_ids=None):
+                          next_ids=None, prepared=False):
         """`forward_backward` with the library-internal switches of `train_step` / compiled.CompiledTrainLoop:
         apply_rows=True is the promise that `self.optimizer.step()` follows immediately: a fused plan may then apply the
         row-sparse update of the table rows looked up once (and the dense update) inside its own kernels — the gradients are
-        consumed by the call, so this is not a public mode.  slot / preelected / next_ids: the compiled loop's per-step id
-        buffers (fused.FusedDeepFM.run)."""
+        consumed by the call, so this is not a public mode.  slot / preelected / next_ids / prepared: the compiled loop's
+        per-step id buffers and its chained steps (fused.FusedDeepFM.run)."""
         plan = self.fused_plan() if self.model.training else None
         if plan is not None and sample_weight is not None and not getattr(plan, 'takes_sample_weight', False):
             plan = None
@@ -289,8 +289,8 @@ class DeepModel:
                 kw['logit_out'] = logit_out
             if slot or preelected:
                 kw['slot'], kw['preelected'] = slot, preelected
-            if next_ids is not None:
-                kw['next_ids'] = next_ids
+            if next_ids is not None or prepared:
+                kw['next_ids'], kw['prepared'], kw['slot'] = next_ids, prepared, slot
             loss, logit = plan.run(cat, dense, y, apply_rows=apply_rows, **kw)
             self.model._dt_flat_grad = plan.accum
             return loss[0], logit

@@ -477,6 +477,17 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * workspace region at dt_deepfm_stamps_offset_floats() (tools/phase_times.py reads them back).  The library reads no
  * environment variables: every switch of a call is in its arguments. */
 #define DT_STEP_STAMPS 0x400
+/* Chained steps (dt_deepfm_train_step_adam / dt_dcn_train_step_adam, dt_deepfm_step_chains() == 1): a step given the NEXT
+ * step's ids (next_idx, the same kind and shape as idx; next_rows_out / next_dedupe_ws: that step's own buffers) does the
+ * next step's ids-only and weight-only work inside its own launches — kernel A packs the next ids' table rows, the
+ * weight-gradient launch's matrix waves run the next election in their idle time, the finishing launch writes the tile
+ * kernel's bf16 weight layouts from the weights it has just updated.  The next call then passes phases | DT_STEP_PREPARED
+ * with idx = that next_idx, rows_out = that next_rows_out, dedupe_ws = that next_dedupe_ws and the same workspace, and runs
+ * FOUR launches (no prep launch).  Nothing may touch the dense weights or the two buffers between the two calls.
+ * deeptables_amd/compiled.py chains the k steps of one captured execution this way; the first step of an execution prepares
+ * itself (five launches).  Keras' steps_per_execution is the reference's counterpart (deepmodel.py:319-346). */
+#define DT_STEP_PREPARED 0x800
+int dt_deepfm_step_chains(int B, int F, int D, int Nd, int phases);
 int dt_deepfm_preelect(const void* idx, int idx_kind, const int64_t* row_offset, const int32_t* vocab, int B, int F,
                        int64_t* rows_out, void* dedupe_ws, int64_t dedupe_slots, void* stream);
 int64_t dt_deepfm_dedupe_slots(int B, int F);
@@ -525,7 +536,8 @@ int dt_dcn_train_step_adam(const void* idx, int idx_kind, float* table, const in
                            float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
                            const float* sample_weight, float* adam_m, float* adam_v, int slot_stride,
                            void* adam_state, float lr_t, float beta1, float beta2, float eps, float* dense_p,
-                           float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
+                           float* dense_m, float* dense_v, int64_t dense_n, float lr, const void* next_idx,
+                           int64_t* next_rows_out, void* next_dedupe_ws, void* stream);
 /* workspace: dt_deepfm_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED ONCE before its first use (hipMemset / torch.zeros):
  * it holds the step's batch-sum accumulators (BatchNormalization's sum x / sum x^2 per column, the tile kernel's record sums),
  * which the launches add into with double-precision atomics and hand back zeroed — a step leaves the invariant as it found it,
@@ -571,7 +583,8 @@ int dt_deepfm_train_step_adam(const void* idx, int idx_kind, float* table, const
                               float embedding_dropout, unsigned* dropout_seed, float dense_input_dropout,
                               const float* sample_weight, float* adam_m, float* adam_v,
                               int slot_stride, void* adam_state, float lr_t, float beta1, float beta2, float eps,
-                              float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr, void* stream);
+                              float* dense_p, float* dense_m, float* dense_v, int64_t dense_n, float lr,
+                              const void* next_idx, int64_t* next_rows_out, void* next_dedupe_ws, void* stream);
 /* embedding_dropout > 0 (ModelConfig.embedding_dropout, config.py:84: SpatialDropout1D on every [B,1,D] embedding =
  * element dropout scaled by 1/(1-p)): element (b, f, d) is kept iff dt_deepfm_dropout_hash(*dropout_seed, b, f*D+d) >=
  * p * 2^32.  *dropout_seed is a DEVICE word, advanced by the step itself (so a captured graph draws a fresh mask at every

@@ -67,6 +67,9 @@ def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
         loop = graphed.compiled_loop
         assert loop is not None and loop.graph is not None and loop.k == 10
         assert not loop.preelected                   # (opt-in, next test)
+        # row-sparse tables: the steps of an execution are chained (step i runs step i + 1's election and weight layouts inside
+        # its own launches: no prep launch from the second step on) — same weights as the eager steps, which prepare themselves
+        assert loop.chained == sparse
         assert type(graphed.fused_plan()).__name__ == ('FusedDCN' if net == 'DCN' else 'FusedDeepFM')
         # small tables keep Keras' dense table gradient: its scatter adds the lookups' rows with float atomics, whose order
         # differs from run to run (ulps of a gradient; Adam's g / (sqrt(v) + eps) turns a few of them into 1e-5 of a weight
