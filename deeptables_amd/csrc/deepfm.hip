@@ -891,6 +891,12 @@ struct DcnArgs {
     int mse;                     // loss: 0 = BinaryCrossentropy on the sigmoid output, 1 = MeanSquaredError on the linear output
     int wt;                      // pipelined step: write-through stores of the tile's outputs (st4_wt)
     const float* sw;             // [B] per-row loss weights (Keras sample_weight x class_weight; loss = sum_b w_b l_b / B), NULL: 1
+    // DCN: the tile's cross vectors G_0 .. G_L [CP each] leave as a per-tile record [tiles][gstride] (plain stores) and are
+    // summed over the tiles where they are finished (the finishing launch's column blocks).  As atomics into the record
+    // shards they made the tile kernel 86 us instead of 35: 3.1 K scattered elements per tile = ~800 line requests per block,
+    // 64 blocks deep on every line.  (The DeepFM record is 1.6 K elements in whole lines: +1.5 us.)
+    float* gpart;
+    int gstride;
 };
 constexpr int kCrossMax = 8;     // cross layers the fused DCN step takes
 constexpr int kCrossScal = 48 * 16;                                  // floats of the P / Gram block (k_mlp_fwd3 crP)
@@ -1458,8 +1464,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd3(const float* __restrict__ X, M
                 for (int st = 0; st < 8; ++st)
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kq) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
                 if (n16 <= L) {                                   // C layout: Xhat column 16 ct + 4 kq + i, coefficient n16
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) radd(rec + n16 * CP + 16 * ct + 4 * kq + i, d[i]);
+                    st4(dc.gpart + (int64_t)blockIdx.x * dc.gstride + n16 * CP + 16 * ct + 4 * kq, d);
                 }
             }
         }
@@ -1803,6 +1808,11 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
 // waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
 // d linear_logit kernel: field f = its D columns, dense k = one column.
+// DCN: the tile kernel's per-tile cross records (DcnArgs.gpart), summed by the column blocks
+struct GPart {
+    const float* part;
+    int stride, tiles;
+};
 // Chained steps: the split-bf16 tile kernel's weight layouts (X3Weights, tower_x3.h) written by the finishing launch from the
 // weights it has just updated — the prep launch's layout blocks of the NEXT step (k_prep writes the same values from the
 // same fp32 weights: every part is the bf16 rounding of what the parts before it left).  W1B == NULL: not written.
@@ -1826,8 +1836,9 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
                                                const DeepFmAccum& al, const float* __restrict__ wpart, int row_blocks,
                                                int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
                                                const float* __restrict__ w3c, const RecSrc& rs, const Part3& pl,
-                                               floatx2 (*sm)[64], float* slin_s, const DenseAdam& da, int blk,
+                                               floatx2 (*sm)[64], float* slin_s, const DenseAdam& da, int blk, const GPart& gp,
                                                const X3Lay& lay = X3Lay{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr}) {
+    float* gsum_s = slin_s;          // [4][16] (DCN; the d w_lin scratch is DeepFM's)
     // (what the tile kernel summed over the batch — db1, the d w_lin column sums, DCN's cross record — is read from the
     // record shards here: no launch stands between kernel C and this one for them)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1899,6 +1910,24 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     floatx2 m = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     for (int sl = wave + 32; sl < row_blocks; sl += 4) m += *reinterpret_cast<const floatx2*>(src + (int64_t)sl * 8192);
     sm[wave][lane] = m;
+    if (Lc && !w2) {
+        // DCN: this column's cross vectors G_0 .. G_L = the tiles' records summed (lane = tile, every load of a round in flight;
+        // the four waves take every fourth group of 64 tiles), met in LDS behind the barrier below
+        float gl[kCrossMax + 1];
+#pragma unroll
+        for (int l = 0; l <= kCrossMax; ++l) gl[l] = 0.f;
+        for (int t = wave * 64 + lane; t < gp.tiles; t += 256) {
+            const float* q = gp.part + (int64_t)t * gp.stride + col;
+#pragma unroll
+            for (int l = 0; l <= kCrossMax; ++l)
+                if (l <= Lc) gl[l] += q[(int64_t)l * dm.CP];
+        }
+#pragma unroll
+        for (int l = 0; l <= kCrossMax; ++l) {
+            const float t = wave_sum(gl[l]);
+            if (lane == 0) gsum_s[wave * 16 + l] = t;
+        }
+    }
     __syncthreads();
     if (wave != 0) return;
     m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
@@ -1972,7 +2001,7 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         const int l = lane;
         const float sa_mine = l < Lc ? rec_sum(rs, scal + 16 + l) : 0.f;
         const float sco_mine = l <= Lc ? rec_sum(rs, scal + l) : 0.f;
-        const float G = l <= Lc ? rec_sum(rs, pl.cross + l * dm.CP + col) : 0.f;
+        const float G = l <= Lc ? (gsum_s[l] + gsum_s[16 + l]) + (gsum_s[32 + l] + gsum_s[48 + l]) : 0.f;
         const float sdz = rec_sum(rs, scal + 31);
         float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
         for (int j = 0; j < Lc; ++j) {
@@ -2003,14 +2032,14 @@ __global__ __launch_bounds__(256) void k_bn_grads2(const float* __restrict__ W1,
                                                    const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                    DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
                                                    int Lc, const float* __restrict__ cw, const float* __restrict__ cb,
-                                                   const float* __restrict__ w3c, RecSrc rs, int col_blocks) {
+                                                   const float* __restrict__ w3c, RecSrc rs, int col_blocks, GPart gp) {
     // blocks [0, col_blocks): one per column (E'); the blocks behind them: the record entries -> the gradient buffer
     __shared__ floatx2 sm[4][64];
     __shared__ float slin_s[kMaxC];
     const DenseAdam none{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
     const Part3 pl = part3_layout(dm.CP, Lc, 1);
     if ((int)blockIdx.x < col_blocks)
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, none, (int)blockIdx.x);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, none, (int)blockIdx.x, gp);
     else
         finish_record_entry(((int)blockIdx.x - col_blocks) * (int)blockDim.x + (int)threadIdx.x, rs, pl, al, dm, Lc, accum, none);
 }
@@ -2044,7 +2073,7 @@ __global__ __launch_bounds__(256, 4) void k_finish_step(const float* __restrict_
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
                                                      int small_blocks, int seg_blocks, FinishSeg fs, int Lc,
                                                      const float* __restrict__ cw, const float* __restrict__ cb,
-                                                     const float* __restrict__ w3c, RecSrc rs, X3Lay lay) {
+                                                     const float* __restrict__ w3c, RecSrc rs, X3Lay lay, GPart gp) {
     __shared__ floatx2 sm[4][64];
     __shared__ float slin_s[kMaxC];
     const Part3 pl = part3_layout(dm.CP, Lc, 1);
@@ -2060,7 +2089,7 @@ __global__ __launch_bounds__(256, 4) void k_finish_step(const float* __restrict_
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
     if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
-        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, da, b, lay);
+        bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, da, b, gp, lay);
     } else if (b < col_blocks + small_blocks) {
         // one thread per record entry: db1 | db2 | dw3 (dnn part) | dwo | dbo | loss | dbeta | dgamma — summed over the shards,
         // stored, updated (the d w_lin entries — DCN: the cross kernels / biases — belong to the column blocks above)
@@ -2297,6 +2326,7 @@ struct DeepFmWs {
     int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnacc, racc, stamps, dXc, dXn,
         gammap, x3, total;
     int64_t bnacc_n, racc_n;          // doubles
+    int64_t gpart;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
@@ -2320,6 +2350,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.bnacc = take(2 * w.bnacc_n);
     w.racc_n = (int64_t)kRecShards * part3_layout(dm.CP, L, 1).stride;
     w.racc = take(2 * w.racc_n);
+    w.gpart = take(L > 0 ? (int64_t)tiles * (L + 1) * dm.CP : 0);      // DCN: per-tile cross vectors G_0 .. G_L (DcnArgs.gpart)
     w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
@@ -2522,7 +2553,8 @@ static int tower_train_step(
     const bool stamps_flag = (phases & DT_STEP_STAMPS) != 0;
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
-    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, 0, sample_weight};
+    const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, 0, sample_weight, ws + wl.gpart, (Lc + 1) * dm.CP};
+    const GPart gpt{ws + wl.gpart, (Lc + 1) * dm.CP, ceil_div(B, kTM)};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  reinterpret_cast<const double*>(ws + wl.bnacc), bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
@@ -2583,7 +2615,7 @@ static int tower_train_step(
         const int rec_blocks_f = ceil_div(part3_layout(dm.CP, Lc, 1).n, 256);
         const RecSrc rsrc_f{reinterpret_cast<const double*>(ws + wl.racc), part3_layout(dm.CP, Lc, 1).stride};
         hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks_f), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                           accum, al, ws + wl.wpart, wgrad_row_blocks(), Lc, cross_w, cross_b, w3, rsrc_f, dm.C + kH2);
+                           accum, al, ws + wl.wpart, wgrad_row_blocks(), Lc, cross_w, cross_b, w3, rsrc_f, dm.C + kH2, gpt);
         if (drop.thr || drop.thr_dense) hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);
         return launch_status(dcn ? "dt_dcn_train_step" : "dt_deepfm_train_step");
     }
@@ -2743,11 +2775,11 @@ static int tower_train_step(
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
-                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay);
+                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay, gpt);
         } else if (!skip_finish) {
             // E': slices added up, dW1 / dW2 / d w_lin finished; the record entries (db1 .. dgamma / dbeta) -> accum
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,
-                               accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, rsrc, dm.C + kH2);
+                               accum, al, ws + wl.wpart, row_blocks, Lc, cross_w, cross_b, w3, rsrc, dm.C + kH2, gpt);
         }
         if ((drop.thr || drop.thr_dense) && !skip_finish)
             hipLaunchKernelGGL(k_emb_drop_advance, dim3(1), dim3(1), 0, st, dropout_seed);

@@ -593,8 +593,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
                 for (int st = 0; st < 8; ++st)
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(4 * st + kg) * XS + 16 * ct + n16], bop[st], d, 0, 0, 0);
                 if (n16 <= L) {                                   // C layout: xhat column 16 ct + 4 kg + i, coefficient n16
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) radd(rec + n16 * CP + 16 * ct + 4 * kg + i, d[i]);
+                    st4(dc.gpart + (int64_t)blockIdx.x * dc.gstride + n16 * CP + 16 * ct + 4 * kg, d);
                 }
             }
         }
