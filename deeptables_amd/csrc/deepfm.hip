@@ -1808,11 +1808,40 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
 // waves after those transpose-sum dW2 (one per dH2 column); block 0 also folds the reduced sum_b dz X into
 // d linear_logit kernel: field f = its D columns, dense k = one column.
-// DCN: the tile kernel's per-tile cross records (DcnArgs.gpart), summed by the column blocks
+// DCN: the tile kernel's per-tile cross records (DcnArgs.gpart [tiles][stride], stride = (L + 1) CP) and their sums over the
+// tiles, gsum [(L + 1) CP]: formed by the matrix waves of the weight-gradient launch (reduce_gpart), read by the finishing launch
 struct GPart {
     const float* part;
     int stride, tiles;
+    float* gsum;
 };
+// matrix waves of weight-gradient block `blk` (256 threads, soft barriers: see k_wgrad_rows): entries [16 blk, 16 blk + 16) of the
+// cross record summed over the tiles — thread = (entry, group of tiles), 16 partials per entry meet in LDS
+__device__ __forceinline__ void reduce_gpart(const GPart& gp, float* lds, int blk, int nblk, int tid, ElectSync& sy) {
+    const int ee = tid & 15, tg = tid >> 4;
+    for (int e0 = 16 * blk; e0 < gp.stride; e0 += 16 * nblk) {
+        float acc = 0.f;
+        for (int t0 = tg; t0 < gp.tiles; t0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 16 * u;
+                const float x = gp.part[(int64_t)min(t, gp.tiles - 1) * gp.stride + e0 + ee];       // unconditional, clamped
+                v[u] = t < gp.tiles ? x : 0.f;
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        elect_barrier<256, true>(sy);                 // the LDS words below are free (the election / the partial tiles are done)
+        lds[tg * 16 + ee] = acc;
+        elect_barrier<256, true>(sy);
+        if (tid < 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += lds[g * 16 + tid];
+            gp.gsum[e0 + tid] = t;
+        }
+    }
+}
 // Chained steps: the split-bf16 tile kernel's weight layouts (X3Weights, tower_x3.h) written by the finishing launch from the
 // weights it has just updated — the prep launch's layout blocks of the NEXT step (k_prep writes the same values from the
 // same fp32 weights: every part is the bf16 rounding of what the parts before it left).  W1B == NULL: not written.
@@ -1838,7 +1867,6 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
                                                const float* __restrict__ w3c, const RecSrc& rs, const Part3& pl,
                                                floatx2 (*sm)[64], float* slin_s, const DenseAdam& da, int blk, const GPart& gp,
                                                const X3Lay& lay = X3Lay{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr}) {
-    float* gsum_s = slin_s;          // [4][16] (DCN; the d w_lin scratch is DeepFM's)
     // (what the tile kernel summed over the batch — db1, the d w_lin column sums, DCN's cross record — is read from the
     // record shards here: no launch stands between kernel C and this one for them)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1910,24 +1938,6 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
     floatx2 m = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     for (int sl = wave + 32; sl < row_blocks; sl += 4) m += *reinterpret_cast<const floatx2*>(src + (int64_t)sl * 8192);
     sm[wave][lane] = m;
-    if (Lc && !w2) {
-        // DCN: this column's cross vectors G_0 .. G_L = the tiles' records summed (lane = tile, every load of a round in flight;
-        // the four waves take every fourth group of 64 tiles), met in LDS behind the barrier below
-        float gl[kCrossMax + 1];
-#pragma unroll
-        for (int l = 0; l <= kCrossMax; ++l) gl[l] = 0.f;
-        for (int t = wave * 64 + lane; t < gp.tiles; t += 256) {
-            const float* q = gp.part + (int64_t)t * gp.stride + col;
-#pragma unroll
-            for (int l = 0; l <= kCrossMax; ++l)
-                if (l <= Lc) gl[l] += q[(int64_t)l * dm.CP];
-        }
-#pragma unroll
-        for (int l = 0; l <= kCrossMax; ++l) {
-            const float t = wave_sum(gl[l]);
-            if (lane == 0) gsum_s[wave * 16 + l] = t;
-        }
-    }
     __syncthreads();
     if (wave != 0) return;
     m = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
@@ -2001,7 +2011,7 @@ __device__ __forceinline__ void bn_grads2_body(const float* __restrict__ W1, con
         const int l = lane;
         const float sa_mine = l < Lc ? rec_sum(rs, scal + 16 + l) : 0.f;
         const float sco_mine = l <= Lc ? rec_sum(rs, scal + l) : 0.f;
-        const float G = l <= Lc ? (gsum_s[l] + gsum_s[16 + l]) + (gsum_s[32 + l] + gsum_s[48 + l]) : 0.f;
+        const float G = l <= Lc ? gp.gsum[(int64_t)l * dm.CP + col] : 0.f;     // (summed over the tiles by the weight-gradient launch)
         const float sdz = rec_sum(rs, scal + 31);
         float cl = 0.f, suf = 0.f;                            // c_l = b_0 + .. + b_{l-1};  sum_{j > l} SA_j w_j
         for (int j = 0; j < Lc; ++j) {
@@ -2269,18 +2279,19 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
                                                     RowsEpi ep, RowsAdam ad, EmbDrop drop,
                                                     unsigned long long* stamps_rows, int matrix_waves_join,
-                                                    double* __restrict__ bnacc_zero, int bnacc_n, StepNext nx) {
+                                                    double* __restrict__ bnacc_zero, int bnacc_n, StepNext nx, GPart gp) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
     __shared__ unsigned arrived, work[2], ecnt;
     if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; ecnt = 0u; }
     __syncthreads();          // the only hardware barrier: the two halves never wait for each other afterwards
     if (threadIdx.x < 256) {
         wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
+        ElectSync sy{&ecnt, 0u};
+        if (DCN && gp.part) reduce_gpart(gp, red, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sy);
         if (nx.idx) {
             // chained steps: the NEXT step's election (ids only: kernel A of this step packed its rows) on the four matrix
             // waves, in the 64 KB of LDS their partial tiles just left — a launch of its own costs 9 us of the step's chain
             // (k_prep), here it takes time the matrix waves would have spent helping with the row epilogue
-            ElectSync sy{&ecnt, 0u};
             for (int e = (int)blockIdx.x; e < nx.eblocks; e += (int)gridDim.x) {
                 elect_barrier<256, true>(sy);                     // every wave is done with the LDS (partial tiles / the table before)
                 elect_block<256, true, 32>(reinterpret_cast<unsigned long long*>(red), nx.dd, dm.B, dm.F, e, (int)threadIdx.x,
@@ -2326,7 +2337,7 @@ struct DeepFmWs {
     int64_t X, H1, dH1, dH2, lin, fm, z, dz, dlogit, mean, rstd, sc, betap, W1L, W2L, W2TL, S, wpart, bnacc, racc, stamps, dXc, dXn,
         gammap, x3, total;
     int64_t bnacc_n, racc_n;          // doubles
-    int64_t gpart;
+    int64_t gpart, gsum;
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
@@ -2351,6 +2362,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.racc_n = (int64_t)kRecShards * part3_layout(dm.CP, L, 1).stride;
     w.racc = take(2 * w.racc_n);
     w.gpart = take(L > 0 ? (int64_t)tiles * (L + 1) * dm.CP : 0);      // DCN: per-tile cross vectors G_0 .. G_L (DcnArgs.gpart)
+    w.gsum = take(L > 0 ? (int64_t)(L + 1) * dm.CP : 0);               // ... and their sums over the tiles
     w.stamps = take((int64_t)5 * tiles * 16 * 2);   // u64 [3 tile kernels][tiles][16] + kernel A [2 * tiles][16]
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
@@ -2554,7 +2566,7 @@ static int tower_train_step(
     phases &= 0xf;
     DT_REQUIRE(!(skip_finish && finish_only), "dt_deepfm_train_step: DT_STEP_SKIP_FINISH and DT_STEP_FINISH_ONLY together");
     const DcnArgs dca{cross_w, cross_b, w3, Lc, ws + wl.dXc, mse, 0, sample_weight, ws + wl.gpart, (Lc + 1) * dm.CP};
-    const GPart gpt{ws + wl.gpart, (Lc + 1) * dm.CP, ceil_div(B, kTM)};
+    const GPart gpt{dcn ? ws + wl.gpart : nullptr, (Lc + 1) * dm.CP, ceil_div(B, kTM), ws + wl.gsum};
     MlpParams mp{b1, W2, b2, dcn ? w3 + dm.C : w3, w_out, b_out, bn_gamma, ws + wl.mean, ws + wl.rstd, ws + wl.sc, ws + wl.betap,
                  W1, ws + wl.W1L, ws + wl.W2L, ws + wl.W2TL,
                  reinterpret_cast<const double*>(ws + wl.bnacc), bn_beta, bn_eps, bn_momentum, bn_moving_mean, bn_moving_var,
@@ -2748,13 +2760,13 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);
         } else {
             hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
             hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
                                ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx);
+                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);
         }
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
