@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, call 9: sub-wave segment walker (four segments per wave) — optimizer / fused / headline suites, zipf vs uniform
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_optim_gpu.py tests/test_fused_gpu.py tests/test_headline_gpu.py tests/test_compiled_gpu.py tests/test_parallel_gpu.py -m gpu -x -q > gpurun_out/c9_tests.txt 2>&1
+echo "tests rc=$?"; tail -3 gpurun_out/c9_tests.txt | cut -c1-300
+line() { grep "^{" $1 | python -c "
+import sys,json
+j=json.loads(sys.stdin.read()); print('$2', round(j['value']/1e6,3), 'M rows/s', round(j['ms_per_step']*1e3,1), 'us', 'median', round(j['step_us']['median'],1), 'parity', (j.get('parity') or {}).get('ok'))" || tail -5 ${1%.json}.err; }
+timeout 300 python bench.py --no-cpu-baseline --no-extras --no-parity > gpurun_out/c9_uniform.json 2> gpurun_out/c9_uniform.err; line gpurun_out/c9_uniform.json uniform
+timeout 300 python bench.py --dist zipf --no-cpu-baseline --no-extras > gpurun_out/c9_zipf.json 2> gpurun_out/c9_zipf.err; line gpurun_out/c9_zipf.json zipf
+bash tools_prof.sh c9_zipf --dist zipf --steps 100 --warmup 10 --no-parity | head -5
+bash tools_prof.sh c9_uniform --steps 100 --warmup 10 --no-parity | head -5
