@@ -536,6 +536,8 @@ def main():
     wall, ev_s, step_stats = time_steps(loop, args.steps, args.warmup, barrier, device)
     if strategy is not None and hasattr(strategy, 'check_sparse_overflow'):
         strategy.check_sparse_overflow()            # a bucket that dropped entries invalidates the run: fail loudly
+    if dm.fused_plan() is not None and hasattr(dm.fused_plan(), 'check_dedupe'):
+        dm.fused_plan().check_dedupe()              # an election table that overflowed (B > 8192 only) invalidates it as well
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -593,6 +595,12 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
                        'rccl_ranks': rccl_ranks,
                        'hipgraph': loop.graph is not None, 'steps_per_graph_replay': spg,
+                       # chained steps (deeptables_amd/compiled.py): step i of a replay runs step i + 1's election and weight layouts
+                       # inside its own launches — four launches per step from the replay's second step on, five for its first
+                       'chained_steps': bool(getattr(loop, 'chained', False)),
+                       'launches_per_step': ({True: '4 (5 for the first step of a replay)', False: '5'}[bool(getattr(loop, 'chained', False))]
+                                             if type(dm.fused_plan()).__name__ in ('FusedDeepFM', 'FusedDCN') and strategy is None and
+                                             not args.no_optimizer else None),
                        'timed_object': 'deeptables_amd.compiled.CompiledTrainLoop (DeepModel.fit steps_per_execution)',
                        'graph_uploaded_before_first_replay': bool(loop.uploaded),
                        'optimizer_in_timed_region': not args.no_optimizer,

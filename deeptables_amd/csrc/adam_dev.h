@@ -109,33 +109,29 @@ __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks,
                                               float eps, int sstride, int blk = -1) {
     const int lane = threadIdx.x & 63;
     const int lpr = D >> 2;                               // lanes per row (a power of two <= 64: checked by the host)
-    // A segment is walked by a SUB-WAVE of GS = max(16, lpr) lanes (round 5; a whole wave before): with Zipf ids a batch of
-    // 8192 has ~15 K segments of ~7 members — 64 lanes took 4 members of 4 lanes per pass and idled on the rest while the
-    // wave's next segments waited behind three dependent round trips each (the finishing launch 24.9 us against 16.5 us with
-    // uniform ids).  Four segments per wave now share those round trips.
-    const int GS = lpr > 16 ? lpr : 16, nsub = 64 / GS;
-    const int sw = lane / GS, ls = lane - sw * GS;
-    const int groups = GS / lpr, grp = ls / lpr, part = ls - grp * lpr;
+    const int groups = 64 / lpr, grp = lane / lpr, part = lane - grp * lpr;
     // blk: the block's index among the `row_blocks` blocks that walk segments (default: the launch's leading blocks)
     const int gw = (blk >= 0 ? blk : (int)blockIdx.x) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     const int nw = row_blocks * (int)(blockDim.x >> 6);
     // region e = gw % regions is shared by wpr waves (local index lw); fewer waves than regions: a wave walks several
     const int wpr = nw >= sg.regions ? nw / sg.regions : 1, lw = nw >= sg.regions ? gw / sg.regions : 0;
     if (lw >= wpr) return;
-    const int upr = wpr * nsub, lu = lw * nsub + sw;      // sub-waves per region, this one's index
     const int e0 = gw % sg.regions;
+    // (Round 5 tried a SUB-wave of 16 lanes per segment — four segments per wave sharing the round trips: with Zipf ids the
+    // launch went from 24.9 to 35.8 us.  A wave runs its sub-waves in lockstep, so one hot row's hundreds of members held
+    // the three other sub-waves' next segments back; with one wave per segment only that wave's own queue waits.)
     // Dependent round trips per segment: (segment record) -> (member list | p, m, v of the row) -> (members' gradient rows)
-    // -> stores.  The record of the sub-wave's NEXT segment is fetched while the current one is summed (and the first one
-    // before its region's count is even known: index e cap + lu is always inside the arrays), and the row's p / m / v
+    // -> stores.  The record of the wave's NEXT segment is fetched while the current one is summed (and the first one
+    // before its region's count is even known: index e cap + lw is always inside the arrays), and the row's p / m / v
     // do not wait for the member sums (round 2 walked list -> values -> p, m, v: five trips).
     for (int e = e0; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw)) {
-        int sl = lu;
+        int sl = lw;
         int s = e * sg.cap + min(sl, sg.cap - 1);
         int64_t row = sg.row[s];
         int off = sg.off[s], cnt = sg.cnt[s];
         const int nseg = (e == e0 ? nseg0 : sg.nseg[e]);
-        while (sl < nseg) {                               // (per sub-wave: the lanes of a sub-wave agree on sl / cnt)
-            const int sn = e * sg.cap + min(sl + upr, sg.cap - 1);
+        while (sl < nseg) {
+            const int sn = e * sg.cap + min(sl + wpr, sg.cap - 1);
             const int64_t row_n = sg.row[sn];
             const int off_n = sg.off[sn], cnt_n = sg.cnt[sn];
             const int64_t i0 = row * D + 4 * part, s0 = row * sstride + 4 * part;
@@ -162,9 +158,7 @@ __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks,
                 const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
                 acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
             }
-            // the member groups of the sub-wave meet (xor offsets stay inside its GS lanes; every lane of a sub-wave is here:
-            // its loop bounds depend on the sub-wave's segment only)
-            for (int o = lpr; o < GS; o <<= 1) {
+            for (int o = lpr; o < 64; o <<= 1) {
                 acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
                 acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
             }
@@ -183,7 +177,7 @@ __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks,
                 *reinterpret_cast<float4*>(v + s0) = vi;
                 *reinterpret_cast<float4*>(table + i0) = p;
             }
-            sl += upr;
+            sl += wpr;
             row = row_n; off = off_n; cnt = cnt_n;
         }
     }

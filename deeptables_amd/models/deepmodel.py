@@ -460,6 +460,8 @@ class DeepModel:
             if strategy is not None and getattr(strategy, 'sparse_bucket_ratio', 1.0) < 1.0 and \
                     hasattr(strategy, 'check_sparse_overflow'):
                 strategy.check_sparse_overflow()       # a bucket that dropped entries in ANY step of the epoch: fail loudly
+            if batch_size > 8192 and getattr(self, '_fused_plan', None) is not None and hasattr(self._fused_plan, 'check_dedupe'):
+                self._fused_plan.check_dedupe()        # batches beyond 8192 rows: an election table that overflowed (fused.py)
             logs = {'loss': float(torch.cat([l.reshape(-1) for l in losses]).mean().item()) if losses else float('nan')}
             if probs:
                 yp, yt = torch.cat(probs).cpu().numpy(), torch.cat(ys).cpu().numpy()
