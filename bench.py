@@ -154,8 +154,8 @@ def spin_gpu(device, ms=60.0):
 
 def time_steps(loop, steps, warmup, barrier, device, spin=True):
     """EXACTLY `steps` train steps are timed after `warmup` untimed ones, all through the product's compiled loop
-    (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides both counts, so the warm-up runs through replays
-    of the same graph — the timed replays are never a graph's first launch)."""
+    (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides `steps`; the warm-up runs through replays of the same
+    graph and, for what k does not divide, eager steps)."""
     import gc
     loop.run(warmup)
     if spin and os.environ.get('DT_BENCH_SPIN'):      # measured (tools/r4/call13.sh): no gain in gpu_us, slower host enqueue
@@ -517,15 +517,19 @@ def main():
     sharded = getattr(strategy, 'sharded_embeddings', False) and strategy.active and dm.fused_plan() is not None
     # The timed object is the PRODUCT's compiled loop (deeptables_amd/compiled.py — what DeepModel.fit(steps_per_execution=k)
     # runs): k consecutive train steps per captured hipGraph over static input slots filled from the device-resident table.
-    # k = the largest value <= --steps-per-graph dividing BOTH the timed steps and the warm-up, so that exactly `steps` steps
-    # are timed, all through replays, and the warm-up has already replayed the same graph (row-owned tables: the step stays
-    # eager unless --graph-segments — a replay's fixed cost exceeds six eager launches there).
+    # k = the largest value <= --steps-per-graph dividing the timed steps, so that exactly `steps` steps are timed, all through
+    # replays (row-owned tables: the step stays eager unless --graph-segments — a replay's fixed cost exceeds six eager
+    # launches there).
     from deeptables_amd.compiled import CompiledTrainLoop
     feed = make_feed(batches)
     spg = 1
     if world == 1 and strategy is None and not args.no_graph:
-        spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1)
-                  if args.steps % d == 0 and (args.warmup % d == 0 or args.warmup == 0))
+        # k divides the TIMED steps (exactly `steps` steps are timed, all through replays); the warm-up runs through the same
+        # loop — whole replays and, when k does not divide it, its last steps eagerly (untimed).  Round 4 also made k divide the
+        # warm-up, which put the driver's `--steps 20 --warmup 5` on 5-step graphs: a replay's fixed cost (~10 us of idle GPU)
+        # was paid twice as often as in `fit`'s default of 10 steps per execution.  (first_replay_us: a graph's first launch
+        # costs what every later one does — it is uploaded at capture time.)
+        spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0)
     warm_capture = 2
     loop = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
                              graph_segments=args.graph_segments,
@@ -595,6 +599,7 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+table-rows-sharded' if sharded else ''),
                        'rccl_ranks': rccl_ranks,
                        'hipgraph': loop.graph is not None, 'steps_per_graph_replay': spg,
+                       'warmup_steps_eager': (args.warmup % spg) if loop.graph is not None else args.warmup,
                        # chained steps (deeptables_amd/compiled.py): step i of a replay runs step i + 1's election and weight layouts
                        # inside its own launches — four launches per step from the replay's second step on, five for its first
                        'chained_steps': bool(getattr(loop, 'chained', False)),
