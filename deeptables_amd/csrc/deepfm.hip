@@ -2077,7 +2077,7 @@ struct FinishSeg {
     const float* values;
     int sstride, D;
 };
-__global__ __launch_bounds__(256, 4) void k_finish_step(const float* __restrict__ W1, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W1, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, DeepFmDims dm, float* accum,
                                                      DeepFmAccum al, const float* __restrict__ wpart, int row_blocks,
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void k_tower_x3(const float* __restrict__ X, M
     floatx4 xv[NCH];                                              // raw X, kept to the end (xhat, d w_lin)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) xv[j] = ld4(X + (int64_t)(m0 + srow) * CP + 64 * j + qcol);   // rows beyond B are zero (host memset)
-    constexpr int kPF = 5;                                        // GEMM1 B operands in flight (steps ahead: ~1 K cycles of MFMAs, an L2 round trip under load)
+    constexpr int kPF = 5;                                        // GEMM1 B operands in flight (steps ahead: ~1 K cycles of MFMAs, an L2 round trip under load; 8: 222 VGPRs, the launch 29.8 us against 28.8)
     const __bf16* w1b = xw.W1B + ((int64_t)wave * 64 + lane) * 8; // + step * 8 * 64 * 8
     x3_b8 bq[kPF][3];
 #pragma unroll
