@@ -739,3 +739,48 @@ def test_in_step_optimizer_matches_oracle_adam_over_three_steps(dev, net):
         assert res['ok'] and res['steps_counted'] == 3 and res['warm_rows'] > 1000, str(sorted(res.items()))
     finally:
         dl.DENSE_GRAD_MAX_ELEMS = old
+
+
+@pytest.mark.parametrize('net', ['DeepFM', 'DCN'])
+@pytest.mark.parametrize('vocab,B', [(40, 512), (3000, 1000), (200000, 4096)])
+def test_chained_steps_equal_plain_steps(dev, monkeypatch, net, vocab, B):
+    """Chained steps (include/dt_hip.h DT_STEP_PREPARED, csrc/deepfm.hip StepNext): step n, given step n + 1's ids, packs their
+    rows (kernel A), runs their election on the weight-gradient launch's matrix waves and writes the tile kernel's bf16 weight
+    layouts from the weights it has just updated; step n + 1 then runs WITHOUT its prep launch.  Four chained steps through
+    `FusedDeepFM.run(next_ids=..., prepared=...)` (eager: no graph) must leave the tables, slots and dense parameters of
+    four plain `train_step`s — with duplicate ids (vocab 40: almost every lookup is a segment member), out-of-range ids and a
+    ragged last tile (B = 1000)."""
+    from deeptables_amd.models import layers as L, deepnets
+    monkeypatch.setattr(L, 'DENSE_GRAD_MAX_ELEMS', 0)
+    extra = dict(nets=deepnets.DCN, cross_params={'num_cross_layer': 5}) if net == 'DCN' else {}
+    F, Nd, D = 26, 13, 16
+    plain, cats = build(F, Nd, D, vocab=vocab, **extra)
+    chained, _ = build(F, Nd, D, vocab=vocab, **extra)
+    plan = chained.fused_plan()
+    assert type(plan).__name__ == 'Fused' + net and plan.can_chain(B)
+    steps = []
+    for s in range(4):
+        idx, dense, y = batch(cats, Nd, B, seed=70 + s)
+        if s == 2:
+            idx[::13, 4] = vocab + 999                       # out-of-range ids: zero row, no update
+        steps.append((idx.to(torch.int32).to(dev), dense.to(dev), y.to(dev)))
+    plain.model.train(); chained.model.train()
+    for idx, dense, y in steps:
+        plain.train_step([idx, dense], y)
+    opt = chained.optimizer
+    for s, (idx, dense, y) in enumerate(steps):
+        nxt = (steps[s + 1][0], s + 1) if s + 1 < len(steps) else None
+        opt.zero_grad(flat=False)
+        plan.run(idx, dense, y, apply_rows=True, slot=s, next_ids=nxt, prepared=s >= 1)
+        opt.step()
+    torch.cuda.synchronize()
+    assert plain.optimizer.t == chained.optimizer.t == 4
+    for (n0, p0), (n1, p1) in zip(plain.model.named_parameters(), chained.model.named_parameters()):
+        assert n0 == n1 and (p0 - p1).abs().max().item() <= 2e-6, (n0, (p0 - p1).abs().max().item())
+    ta, tb = plain.optimizer._st(plain.fused_plan().emb.tables['d16'], rows=True), opt._st(plan.emb.tables['d16'], rows=True)
+    assert (ta['m'] - tb['m']).abs().max().item() <= 1e-6 * max(1.0, ta['m'].abs().max().item())
+    # a step that cannot be chained says so instead of running prepared on nothing
+    from deeptables_amd import _lib
+    assert _lib.lib().dt_deepfm_step_chains(B, F, D, Nd, 2 | _lib.DT_STEP_TOWER_X3) == 1
+    assert _lib.lib().dt_deepfm_step_chains(B, F, D, Nd, 2) == 0                      # exact-fp32 tower: k_prep's layouts
+    assert _lib.lib().dt_deepfm_step_chains(16384, F, D, Nd, 2 | _lib.DT_STEP_TOWER_X3) == 0

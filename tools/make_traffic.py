@@ -33,20 +33,24 @@ def main():
     write, _ = avg_per_kernel(sys.argv[2], 'WRITE_SIZE')
     per = {}
     raw = corr = 0.0
+    # launches per STEP: kernel A runs once per step; the prep launch only in the first step of a chained execution, the feed
+    # gather once per execution, the state's init once per run — each kernel's average is weighted by how often a step meets it
+    steps = float(nf.get('k_sparse_fwd', 0) or max(nf.values()))
     for k in fetch:
         f, w = fetch[k], write.get(k, 0.0)
+        per_step = min(1.0, nf[k] / steps)
         per[k] = {'FETCH_SIZE': round(f, 1), 'WRITE_SIZE': round(w, 1), 'wide_16B_reads': k in WIDE,
-                  'launches_averaged': nf[k]}
-        raw += (f + w) * 1024
-        corr += ((2 * f if k in WIDE else f) + w) * 1024
+                  'launches_averaged': nf[k], 'launches_per_step': round(per_step, 3)}
+        raw += (f + w) * 1024 * per_step
+        corr += ((2 * f if k in WIDE else f) + w) * 1024 * per_step
     B, F, D, ND = 8192, 26, 16, 13
     n_dense = (F * D + ND) * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1 + 2 * (F * D + ND) + (F + ND)
     fwd_bwd = B * (4 * F + 4 * ND + 8 + 12 * F * D) + 12 * n_dense
     opt = B * 6 * 4 * F * D                      # p, m, v of the looked-up rows, read + write
     out = {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py '
-                  '--steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-parity (tools_pmc.sh), averages per launch, KB -> bytes '
-                  'x1024; built by tools/make_traffic.py',
+                  '--steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-parity (tools_pmc.sh), averages per launch weighted by the '
+                  'launches per step, KB -> bytes x1024; built by tools/make_traffic.py',
         'step': 'fwd + bwd + Adam (the timed region of bench.py)',
         'per_kernel_KB': per,
         'correction': 'MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) '
