@@ -548,9 +548,10 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
 //     and only THEIR rows are fetched — one round trip in pass 1, one (L2-warm) in pass 3;
 //   * segments / list entries go to the FIELD's region through two returning atomics (dd.seg_cur / dd.list_cur, zeroed by the
 //     launch that wrote rows_fm): per-block regions would take eblocks x B entries.
-// Termination / capacity: the table and the list hold kElectSlots entries.  A partition would have to be 2x over-full
-// (expected 4096 lookups, sigma 64 — or a batch that repeats few rows thousands of times: then the list fills up) — what does
-// not fit is counted in dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row.
+// Termination / capacity: the table holds kElectSlots DISTINCT rows (a partition's expected 4096 lookups, sigma 64, would have
+// to be 2x over-full of distinct rows: what does not fit is counted in dd.overflow — the host checks it,
+// fused.FusedDeepFM.check_dedupe — and keeps its own row).  The list holds kElectSlots lookups; a hot row's thousands of
+// lookups beyond that take the slow paths noted below, nothing is lost.
 template <int NT, bool SOFT>
 __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
                                                 int64_t* __restrict__ rows_out, ElectSync& sy) {
@@ -567,7 +568,10 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
     for (int i = tid; i < kElectSlots / 32; i += NT) multi[i] = 0u;
     if (tid == 0) *mcount = 0u;
     elect_barrier<NT, SOFT>(sy);
-    // scan: 16 partition bytes per load, four loads in flight per thread
+    // scan: 16 partition bytes per load, four loads in flight per thread.  A block's lookups beyond the list's capacity (a hot
+    // row: with Zipf ids one row takes 8 % of a field's lookups — 5 K of 65,536, all in ONE partition) are inserted right here,
+    // one dependent row load each; pass 3 then walks the partition bytes again instead of the list (`spilled`)
+    int lost = 0;
     for (int b0 = tid * 16; b0 < B; b0 += NT * 64) {
         uint4 pv[4];
 #pragma unroll
@@ -583,7 +587,12 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
                 const int b = b0 + q * NT * 16 + k;
                 if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
                     const unsigned pos = atomicAdd(mcount, 1u);
-                    if (pos < (unsigned)kElectSlots) mlist[pos] = b;
+                    if (pos < (unsigned)kElectSlots) {
+                        mlist[pos] = b;
+                    } else {
+                        const int64_t row = rf[b];
+                        if (elect_insert<true>(eslots, multi, row, elect_hash(row)) < 0) ++lost;
+                    }
                 }
             }
         }
@@ -591,7 +600,7 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
     elect_barrier<NT, SOFT>(sy);
     const unsigned found = *mcount;
     const int n = (int)min(found, (unsigned)kElectSlots);
-    int lost = (tid == 0 && found > (unsigned)kElectSlots) ? (int)(found - kElectSlots) : 0;
+    const bool spilled = found > (unsigned)kElectSlots;
     // pass 1 over the compact list: kElU rows per thread in flight
     for (int i0 = tid; i0 < n; i0 += NT * kElU) {
         int bq[kElU];
@@ -609,20 +618,37 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
     if (lost && dd.overflow) atomicAdd(dd.overflow, lost);
     elect_barrier<NT, SOFT>(sy);
     const int base1 = elect_segments<NT, SOFT, true>(eslots, multi, scan, dd, B, f, e, tid, sy);
-    for (int i0 = tid; i0 < n; i0 += NT * kElU) {
-        int bq[kElU];
-        int64_t rowv[kElU];
+    if (!spilled) {
+        for (int i0 = tid; i0 < n; i0 += NT * kElU) {
+            int bq[kElU];
+            int64_t rowv[kElU];
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) {
-            const int i = i0 + NT * u;
-            bq[u] = i < n ? mlist[i] : -1;
-            rowv[u] = rf[bq[u] >= 0 ? bq[u] : 0];
+            for (int u = 0; u < kElU; ++u) {
+                const int i = i0 + NT * u;
+                bq[u] = i < n ? mlist[i] : -1;
+                rowv[u] = rf[bq[u] >= 0 ? bq[u] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kElU; ++u) {
+                if (bq[u] < 0) continue;
+                const int slot = elect_find(eslots, rowv[u], elect_hash(rowv[u]));
+                if (slot >= 0) elect_append(eslots, slot, dd, base1, bq[u], F, f, rows_out);
+            }
         }
+    } else {
+        // the list did not hold every lookup of the partition: pass 3 from the partition bytes (a row load per match)
+        for (int b0 = tid * 16; b0 < B; b0 += NT * 16) {
+            const uint4 pv = *reinterpret_cast<const uint4*>(pf + b0);
+            const unsigned w[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-        for (int u = 0; u < kElU; ++u) {
-            if (bq[u] < 0) continue;
-            const int slot = elect_find(eslots, rowv[u], elect_hash(rowv[u]));
-            if (slot >= 0) elect_append(eslots, slot, dd, base1, bq[u], F, f, rows_out);
+            for (int k = 0; k < 16; ++k) {
+                const int b = b0 + k;
+                if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
+                    const int64_t row = rf[b];
+                    const int slot = elect_find(eslots, row, elect_hash(row));
+                    if (slot >= 0) elect_append(eslots, slot, dd, base1, b, F, f, rows_out);
+                }
+            }
         }
     }
 }
