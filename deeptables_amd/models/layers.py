@@ -289,7 +289,8 @@ class CIN(Layer):
     def _filter(self, idx, layer_size):
         """[F0*Hk, L] filter of layer idx; reduce_D composes the low-rank factors (layers.py:697-702)."""
         if not self.reduce_D:
-            return self.f_[idx][0]
+            f = self.f_[idx]
+            return f.view(f.shape[1], f.shape[2])       # (a view: `f[0]`'s select_backward zero-fills + copies a full-size gradient)
         f_m = torch.matmul(self.f0_[idx], self.f__[idx])                       # [1,L,F0,Hk]
         f_o = f_m.reshape(1, layer_size, self.field_nums[0] * self.field_nums[idx])
         return f_o.permute(0, 2, 1)[0]
