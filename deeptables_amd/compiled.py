@@ -104,6 +104,7 @@ class CompiledTrainLoop:
         self._opt_graph_sig = None       # addresses / shapes of the exchanged gradients the optimizer graph was captured on
         self._last_exchange_sig = None
         self._opt_graph_refused = False
+        self._sig_objects = None         # (embedding layers, parameters) the signature walks
         self._sparse_refs = None
         self.logits = None          # [k, B, outputs] static: step i's logits
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
@@ -339,7 +340,10 @@ class CompiledTrainLoop:
                 st.assume_uniform_batches = keep_uniform
             if ev:
                 ev[2].record()
-            sig = self._exchange_signature() if self.with_optimizer else None
+            # (only where an optimizer graph exists or may be captured: the eager row-owned step is host-bound, and walking the
+            # model for the signature cost it ~10 us per step)
+            graphed_opt = self.with_optimizer and self.use_graph and (not self._sharded() or self.graph_segments)
+            sig = self._exchange_signature() if graphed_opt else None
             if self.opt_graph is not None and sig != self._opt_graph_sig:
                 # the exchanged gradients moved (a strategy that does not keep them in place): the captured optimizer step
                 # would read the capture step's addresses — drop it and stay eager
@@ -377,15 +381,18 @@ class CompiledTrainLoop:
     def _exchange_signature(self):
         """(address, shape) of every tensor the optimizer step reads after the exchange: the sparse (rows, values) pairs of
         the embedding layers and the dense gradients.  A captured optimizer step is only valid while these stay put."""
-        from .models.layers import MultiColumnEmbedding
+        if self._sig_objects is None:
+            from .models.layers import MultiColumnEmbedding
+            self._sig_objects = ([l for l in self.dm.model.modules() if isinstance(l, MultiColumnEmbedding)],
+                                 list(self.dm.model.parameters()))
+        layers, params = self._sig_objects
         sig = []
-        for layer in self.dm.model.modules():
-            if isinstance(layer, MultiColumnEmbedding):
-                for key in sorted(layer.sparse_grads):
-                    for g in layer.sparse_grads[key]:
-                        sig.append((key, g.rows.data_ptr(), tuple(g.rows.shape), g.values.data_ptr(), tuple(g.values.shape),
-                                    getattr(g, 'fields', None)))
-        for p in self.dm.model.parameters():
+        for layer in layers:
+            for key in sorted(layer.sparse_grads):
+                for g in layer.sparse_grads[key]:
+                    sig.append((key, g.rows.data_ptr(), tuple(g.rows.shape), g.values.data_ptr(), tuple(g.values.shape),
+                                getattr(g, 'fields', None)))
+        for p in params:
             if p.grad is not None:
                 sig.append((p.grad.data_ptr(), tuple(p.grad.shape)))
         return tuple(sig)
