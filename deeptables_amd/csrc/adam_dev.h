@@ -103,6 +103,9 @@ struct SegTail {
     const int *off, *cnt, *list;
     int regions, cap;
 };
+// DEEP: eight members per group in flight for the rows with many members (k_finish_step; +28 VGPRs — the optimizer launch of
+// the layer-by-layer graphs, whose main body is latency-bound on its occupancy, keeps the four-deep loop only)
+template <bool DEEP = false>
 __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks, int nseg0, float* __restrict__ table,
                                               float* __restrict__ m, float* __restrict__ v,
                                               const float* __restrict__ values, int D, float lr_t, float b1, float b2,
@@ -124,61 +127,113 @@ __device__ __forceinline__ void adam_segments(const SegTail& sg, int row_blocks,
     // -> stores.  The record of the wave's NEXT segment is fetched while the current one is summed (and the first one
     // before its region's count is even known: index e cap + lw is always inside the arrays), and the row's p / m / v
     // do not wait for the member sums (round 2 walked list -> values -> p, m, v: five trips).
+    // Round 5: TWO segments of the wave's queue per iteration (sl and sl + wpr) — their records, member lists, p / m / v and
+    // members' rows travel in the same round trips.  With Zipf ids a batch of 8192 has ~15 K segments, 3.7 per wave: walking
+    // them one after the other made the finishing launch 29.8 us against 16.2 us with uniform ids (878 segments: at most one
+    // per wave, for which nothing changes).  Every load is unconditional from a clamped (valid) address.
+    struct SegRec { int64_t row; int off, cnt; };
+    auto rec = [&](int e, int sl, int nseg) {
+        const int s = e * sg.cap + min(sl, sg.cap - 1);
+        SegRec r{sg.row[s], sg.off[s], sg.cnt[s]};
+        if (sl >= nseg) { r.row = 0; r.off = 0; r.cnt = 0; }       // (beyond the region's segments: nothing to walk)
+        return r;
+    };
+    auto adam_row = [&](const SegRec& r, float4 acc, float4 p, float4 mi, float4 vi) {
+        for (int o = lpr; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (grp == 0 && r.cnt > 0) {
+            const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+            float* pp = reinterpret_cast<float*>(&p);
+            float* pm = reinterpret_cast<float*>(&mi);
+            float* pv = reinterpret_cast<float*>(&vi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pm[k] = b1 * pm[k] + (1.f - b1) * g[k];
+                pv[k] = b2 * pv[k] + (1.f - b2) * g[k] * g[k];
+                pp[k] -= lr_t * pm[k] / (sqrtf(pv[k]) + eps);
+            }
+            *reinterpret_cast<float4*>(m + r.row * sstride + 4 * part) = mi;
+            *reinterpret_cast<float4*>(v + r.row * sstride + 4 * part) = vi;
+            *reinterpret_cast<float4*>(table + r.row * D + 4 * part) = p;
+        }
+    };
     for (int e = e0; e < sg.regions; e += (nw >= sg.regions ? sg.regions : nw)) {
         int sl = lw;
-        int s = e * sg.cap + min(sl, sg.cap - 1);
-        int64_t row = sg.row[s];
-        int off = sg.off[s], cnt = sg.cnt[s];
+        // (the first records are requested before the region's count is known: index e cap + sl is always inside the arrays;
+        // what lies beyond the count is dropped once it is)
+        SegRec A, Bq;
+        {
+            const int sa = e * sg.cap + min(sl, sg.cap - 1), sb = e * sg.cap + min(sl + wpr, sg.cap - 1);
+            A = SegRec{sg.row[sa], sg.off[sa], sg.cnt[sa]};
+            Bq = SegRec{sg.row[sb], sg.off[sb], sg.cnt[sb]};
+        }
         const int nseg = (e == e0 ? nseg0 : sg.nseg[e]);
+        if (sl >= nseg) A = SegRec{0, 0, 0};
+        if (sl + wpr >= nseg) Bq = SegRec{0, 0, 0};
         while (sl < nseg) {
-            const int sn = e * sg.cap + min(sl + wpr, sg.cap - 1);
-            const int64_t row_n = sg.row[sn];
-            const int off_n = sg.off[sn], cnt_n = sg.cnt[sn];
-            const int64_t i0 = row * D + 4 * part, s0 = row * sstride + 4 * part;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f), mi = p, vi = p;
-            if (grp == 0) {
-                p = *reinterpret_cast<const float4*>(table + i0);
-                mi = *reinterpret_cast<const float4*>(m + s0);
-                vi = *reinterpret_cast<const float4*>(v + s0);
+            const SegRec An = rec(e, sl + 2 * wpr, nseg), Bn = rec(e, sl + 3 * wpr, nseg);
+            const SegRec R[2] = {A, Bq};
+            float4 p[2], mi[2], vi[2], acc[2];
+            int o[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t i0 = R[q].row * D + 4 * part, s0 = R[q].row * sstride + 4 * part;
+                p[q] = *reinterpret_cast<const float4*>(table + i0);
+                mi[q] = *reinterpret_cast<const float4*>(m + s0);
+                vi[q] = *reinterpret_cast<const float4*>(v + s0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)                    // the first four members of every group (clamped: cnt >= 2 or 0)
+                    o[q][k] = sg.list[R[q].off + min(grp + k * groups, max(R[q].cnt - 1, 0))];
             }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int i = grp;
-            for (; i + 3 * groups < cnt; i += 4 * groups) {      // four members per group in flight
-                const int o0 = sg.list[off + i], o1 = sg.list[off + i + groups], o2 = sg.list[off + i + 2 * groups],
-                          o3 = sg.list[off + i + 3 * groups];
-                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
-                const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
-                const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
-                const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
-                acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
-                acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
-            }
-            for (; i < cnt; i += groups) {
-                const int o0 = sg.list[off + i];
-                const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
-                acc.x += g0.x; acc.y += g0.y; acc.z += g0.z; acc.w += g0.w;
-            }
-            for (int o = lpr; o < 64; o <<= 1) {
-                acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-                acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-            }
-            if (grp == 0) {
-                const float g[4] = {acc.x, acc.y, acc.z, acc.w};
-                float* pp = reinterpret_cast<float*>(&p);
-                float* pm = reinterpret_cast<float*>(&mi);
-                float* pv = reinterpret_cast<float*>(&vi);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float4 g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = *reinterpret_cast<const float4*>(values + (int64_t)o[q][k] * D + 4 * part);
+                acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    pm[k] = b1 * pm[k] + (1.f - b1) * g[k];
-                    pv[k] = b2 * pv[k] + (1.f - b2) * g[k] * g[k];
-                    pp[k] -= lr_t * pm[k] / (sqrtf(pv[k]) + eps);
+                    const float w = grp + k * groups < R[q].cnt ? 1.f : 0.f;
+                    acc[q].x += w * g[k].x; acc[q].y += w * g[k].y; acc[q].z += w * g[k].z; acc[q].w += w * g[k].w;
                 }
-                *reinterpret_cast<float4*>(m + s0) = mi;
-                *reinterpret_cast<float4*>(v + s0) = vi;
-                *reinterpret_cast<float4*>(table + i0) = p;
             }
-            sl += wpr;
-            row = row_n; off = off_n; cnt = cnt_n;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                        // a row with more than 4 x groups members: the rest
+                int i = grp + 4 * groups;
+                // a HOT row (Zipf ids: the top row of a field takes 8 % of its lookups — 650 members at B = 8192) is the launch's
+                // longest chain on its one wave: eight members per group in flight per round trip (sixteen: 202 VGPRs, two waves per SIMD)
+                for (; DEEP && i + 7 * groups < R[q].cnt; i += 8 * groups) {
+                    int oo[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) oo[k] = sg.list[R[q].off + i + k * groups];
+                    float4 gg[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gg[k] = *reinterpret_cast<const float4*>(values + (int64_t)oo[k] * D + 4 * part);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc[q].x += gg[k].x; acc[q].y += gg[k].y; acc[q].z += gg[k].z; acc[q].w += gg[k].w; }
+                }
+                for (; i + 3 * groups < R[q].cnt; i += 4 * groups) {
+                    const int o0 = sg.list[R[q].off + i], o1 = sg.list[R[q].off + i + groups],
+                              o2 = sg.list[R[q].off + i + 2 * groups], o3 = sg.list[R[q].off + i + 3 * groups];
+                    const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                    const float4 g1 = *reinterpret_cast<const float4*>(values + (int64_t)o1 * D + 4 * part);
+                    const float4 g2 = *reinterpret_cast<const float4*>(values + (int64_t)o2 * D + 4 * part);
+                    const float4 g3 = *reinterpret_cast<const float4*>(values + (int64_t)o3 * D + 4 * part);
+                    acc[q].x += (g0.x + g1.x) + (g2.x + g3.x); acc[q].y += (g0.y + g1.y) + (g2.y + g3.y);
+                    acc[q].z += (g0.z + g1.z) + (g2.z + g3.z); acc[q].w += (g0.w + g1.w) + (g2.w + g3.w);
+                }
+                for (; i < R[q].cnt; i += groups) {
+                    const int o0 = sg.list[R[q].off + i];
+                    const float4 g0 = *reinterpret_cast<const float4*>(values + (int64_t)o0 * D + 4 * part);
+                    acc[q].x += g0.x; acc[q].y += g0.y; acc[q].z += g0.z; acc[q].w += g0.w;
+                }
+            }
+            adam_row(R[0], acc[0], p[0], mi[0], vi[0]);
+            adam_row(R[1], acc[1], p[1], mi[1], vi[1]);
+            sl += 2 * wpr;
+            A = An; Bq = Bn;
         }
     }
 }

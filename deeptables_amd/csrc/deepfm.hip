@@ -2131,7 +2131,7 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
         // stored, updated (the d w_lin entries — DCN: the cross kernels / biases — belong to the column blocks above)
         finish_record_entry((b - col_blocks) * (int)blockDim.x + (int)threadIdx.x, rs, pl, al, dm, Lc, accum, da);
     } else if (fs.seg.nseg) {
-        adam_segments(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
+        adam_segments<true>(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
                       fs.sstride, sb);
     }
     __syncthreads();
