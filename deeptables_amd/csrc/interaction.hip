@@ -432,6 +432,9 @@ __global__ __launch_bounds__(256) void k_bilinear_bwd_w(const float* __restrict_
             if (t < D * D) {
                 const int d = t / D, d2 = t - d * D;
                 float sacc = 0.f;
+                // (unrolled four deep only: with all 64 iterations unrolled in each of the 16 k blocks the scheduler hoisted the
+                // LDS reads of several blocks and spilled 572 registers — profiles/r04_kernel_resources.txt)
+#pragma unroll 4
                 for (int r = 0; r < TB; ++r) sacc += xi[r * D + d] * gj[r * D + d2];
                 acc[k] += sacc;
             }

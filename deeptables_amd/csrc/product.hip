@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void k_op_mat_bwd_k(const float* __restrict__ 
             if (t < nout) {
                 const int a = t / D, d = t - a * D;
                 float s = 0.f;
+                // (four deep: fully unrolled in each of the 16 k blocks the LDS reads were hoisted across blocks — 572 spilled
+                // registers, one wave per SIMD; profiles/r04_kernel_resources.txt)
+#pragma unroll 4
                 for (int r = 0; r < TB; ++r) s += gxj[r * D + a] * xi[r * D + d];
                 acc[k] += s;
             }

@@ -485,3 +485,41 @@ def test_ctypes_signatures_follow_the_header_prototypes():
     for name, params in protos:
         decls = [p.strip() for p in params.split(',') if p.strip() and p.strip() != 'void']
         assert [kind(d) for d in decls] == [of_ctype[a] for a in _lib.SIGNATURES[name][1]], name
+
+
+def test_dedupe_layout_and_chain_queries_need_no_gpu():
+    """Host-side answers of the C-ABI (no launch): the in-step dedupe's workspace layout for batches up to and beyond 8192 rows
+    (round 5: any batch size — per-block segment regions up to 8192 rows, per-FIELD regions + cursors + partition bytes beyond)
+    and which steps can be chained (`dt_deepfm_step_chains`)."""
+    import ctypes
+    from deeptables_amd import _lib
+    lib = _lib.lib()
+    F = 26
+
+    def seg(B):
+        out = (ctypes.c_int64 * 7)()
+        assert lib.dt_deepfm_dedupe_segments(B, F, ctypes.cast(out, ctypes.c_void_p)) == 0
+        return [int(v) for v in out]
+    small, big = seg(8192), seg(32768)
+    # B <= 8192: one region per election block (fields padded to 8 x B / 1024 hash partitions), 4096 segments each
+    assert small[5] == 32 * 8 and small[6] == 4096
+    # beyond: one region per field (padded to 8), a field's rows with >= 2 lookups are at most B / 2
+    assert big[5] == 32 and big[6] == 32768 // 2
+    for B, s in ((8192, small), (32768, big)):
+        total = lib.dt_deepfm_dedupe_bytes(B, F)
+        assert 0 < s[0] < s[1] < s[2] < s[3] < s[4] < total                      # nseg | seg_row | seg_off | seg_cnt | seg_list
+        assert s[4] + 4 * s[5] * B <= total                                     # the member list: regions x B entries
+        ov = lib.dt_deepfm_dedupe_overflow_offset(B, F)
+        assert s[4] + 4 * s[5] * B <= ov < total and ov % 4 == 0
+        assert lib.dt_deepfm_dedupe_slots(B, F) == B * F
+    # the partition bytes only exist beyond 8192 rows
+    assert lib.dt_deepfm_dedupe_bytes(32768, F) - lib.dt_deepfm_dedupe_overflow_offset(32768, F) >= 32 * 32768
+    assert lib.dt_deepfm_dedupe_bytes(8192, F) - lib.dt_deepfm_dedupe_overflow_offset(8192, F) <= 64
+    # chained steps: the in-step optimizer on the split-bf16 (or plain-bf16) tile kernel, batches the register-resident election takes
+    x3, bf16 = _lib.DT_STEP_TOWER_X3, _lib.DT_STEP_TOWER_BF16
+    assert lib.dt_deepfm_step_chains(8192, F, 16, 13, 2 | x3) == 1 and lib.dt_deepfm_step_chains(8192, F, 16, 13, 2 | bf16) == 1
+    assert lib.dt_deepfm_step_chains(8192, F, 16, 13, 2) == 0                      # exact-fp32 tower
+    assert lib.dt_deepfm_step_chains(8192, F, 16, 13, 1 | x3) == 0                  # forward only
+    assert lib.dt_deepfm_step_chains(8192, F, 16, 13, 2 | x3 | _lib.DT_STEP_SKIP_FINISH) == 0
+    assert lib.dt_deepfm_step_chains(8193, F, 16, 13, 2 | x3) == 0                  # beyond the register-resident election
+    assert lib.dt_deepfm_step_chains(8192, F, 8, 13, 2 | x3) == 1 and lib.dt_deepfm_step_chains(8192, 200, 16, 13, 2 | x3) == 0
