@@ -582,27 +582,11 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned w[4] = {pv[q].x, pv[q].y, pv[q].z, pv[q].w};
-            // the wave's matches of these 16 byte positions take their list slots with ONE returning LDS atomic (a slot per
-            // match: 4096 same-address atomics per block, each with its own round trip — the launch was 67 us at B = 65536)
-            unsigned long long mk[16];
-            int tot = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int b = b0 + q * NT * 16 + k;
-                mk[k] = __ballot((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B);
-                tot += __popcll(mk[k]);
-            }
-            if (tot == 0) continue;                                            // (wave-uniform)
-            const int lane = tid & 63;
-            unsigned base = 0u;
-            if (lane == 0) base = atomicAdd(mcount, (unsigned)tot);
-            base = __shfl(base, 0, 64);
-            const unsigned long long below = (1ULL << lane) - 1ULL;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if ((mk[k] >> lane) & 1ULL) {
-                    const int b = b0 + q * NT * 16 + k;
-                    const unsigned pos = base + (unsigned)__popcll(mk[k] & below);
+                if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
+                    const unsigned pos = atomicAdd(mcount, 1u);
                     if (pos < (unsigned)kElectSlots) {
                         mlist[pos] = b;
                     } else {
@@ -610,7 +594,6 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
                         if (elect_insert<true>(eslots, multi, row, elect_hash(row)) < 0) ++lost;
                     }
                 }
-                base += (unsigned)__popcll(mk[k]);
             }
         }
     }
