@@ -585,6 +585,8 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int b = b0 + q * NT * 16 + k;
+                // (one returning LDS atomic per match.  Taking a wave's slots with one atomic — 16 ballots + prefix counts per load
+                // — was measured slower: the prep launch 49.8 vs 43.4 us at B = 32768, 87.6 vs 74.5 us at 65536, tools/r5/call16.sh)
                 if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
                     const unsigned pos = atomicAdd(mcount, 1u);
                     if (pos < (unsigned)kElectSlots) {
