@@ -357,6 +357,10 @@ struct PrepOut {
 // would have to be 2x over-full of DISTINCT rows (expected 4096, sigma 64) — a lookup that finds the table full is counted
 // in dd.overflow (the host checks it: fused.FusedDeepFM.check_dedupe) and keeps its own row (-> updated as if looked up once).
 constexpr int kElU = 8;               // lookups per thread and chunk, all loads in flight
+constexpr int kElectList = 16384;     // elect_block_big's LDS list of a block's lookups (64 KB next to the 66 KB table: one block per CU).
+                                      // Twice the table: a hot row's lookups share ONE slot — with Zipf(1.05) ids at B = 65536 the top
+                                      // row's 5 K lookups + the partition's other 4 K overflowed an 8192-entry list into the slow paths
+                                      // (the prep launch 130 us instead of 75)
 struct ElectSync {
     unsigned* cnt;                    // LDS word of the soft barrier (NT = 256), zeroed by the caller
     unsigned target;
@@ -550,14 +554,14 @@ __device__ __forceinline__ void elect_block(unsigned long long* eslots, const De
 //     launch that wrote rows_fm): per-block regions would take eblocks x B entries.
 // Termination / capacity: the table holds kElectSlots DISTINCT rows (a partition's expected 4096 lookups, sigma 64, would have
 // to be 2x over-full of distinct rows: what does not fit is counted in dd.overflow — the host checks it,
-// fused.FusedDeepFM.check_dedupe — and keeps its own row).  The list holds kElectSlots lookups; a hot row's thousands of
+// fused.FusedDeepFM.check_dedupe — and keeps its own row).  The list holds kElectList lookups; a hot row's thousands of
 // lookups beyond that take the slow paths noted below, nothing is lost.
 template <int NT, bool SOFT>
 __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, const DedupeWs& dd, int B, int F, int e, int tid,
                                                 int64_t* __restrict__ rows_out, ElectSync& sy) {
     unsigned* multi = reinterpret_cast<unsigned*>(eslots + kElectSlots);      // [kElectSlots / 32]
     int* scan = reinterpret_cast<int*>(multi + kElectSlots / 32);             // [16]: wave totals | region bases | [12] list length
-    int* mlist = scan + 16;                                                   // [kElectSlots] batch rows of this block's lookups
+    int* mlist = scan + 16;                                                   // [kElectList] batch rows of this block's lookups
     unsigned* mcount = reinterpret_cast<unsigned*>(scan + 12);
     const int j = e >> 3, part = j & ((1 << dd.parts_log2) - 1);
     const int f = 8 * (j >> dd.parts_log2) + (e & 7);
@@ -589,7 +593,7 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
                 // — was measured slower: the prep launch 49.8 vs 43.4 us at B = 32768, 87.6 vs 74.5 us at 65536, tools/r5/call16.sh)
                 if ((int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == part && b < B) {
                     const unsigned pos = atomicAdd(mcount, 1u);
-                    if (pos < (unsigned)kElectSlots) {
+                    if (pos < (unsigned)kElectList) {
                         mlist[pos] = b;
                     } else {
                         const int64_t row = rf[b];
@@ -601,8 +605,8 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
     }
     elect_barrier<NT, SOFT>(sy);
     const unsigned found = *mcount;
-    const int n = (int)min(found, (unsigned)kElectSlots);
-    const bool spilled = found > (unsigned)kElectSlots;
+    const int n = (int)min(found, (unsigned)kElectList);
+    const bool spilled = found > (unsigned)kElectList;
     // pass 1 over the compact list: kElU rows per thread in flight
     for (int i0 = tid; i0 < n; i0 += NT * kElU) {
         int bq[kElU];
@@ -655,7 +659,7 @@ __device__ __forceinline__ void elect_block_big(unsigned long long* eslots, cons
     }
 }
 constexpr size_t kElectLds = (size_t)kElectSlots * 8 + kElectSlots / 32 * sizeof(unsigned) + 16 * sizeof(int);
-constexpr size_t kElectLdsBig = kElectLds + (size_t)kElectSlots * sizeof(int);
+constexpr size_t kElectLdsBig = kElectLds + (size_t)kElectList * sizeof(int);
 
 // the election alone (dt_deepfm_preelect: the ids-only half of a step, run ahead of it)
 __global__ __launch_bounds__(1024) void k_elect(DedupeWs dd, DeepFmDims dm, int64_t* __restrict__ rows_out) {

@@ -690,10 +690,10 @@ def test_weighted_steps_after_a_narrow_tower_plan(dev, net, H1, H2, monkeypatch)
                                               # places its segments in per-field regions — rows looked up ~300 times each, ~4
                                               # times each, mostly once; a ragged chunk, D = 32
                                               (30, 9000, 26, 16, 0.0), (5000, 20000, 26, 16, 0.0), (200000, 16500, 7, 32, 0.0),
-                                              # three rows per field at B = 40000: every row's ~13 K lookups sit in ONE hash
-                                              # partition — more than an election block's 8192-entry lookup list holds (the
+                                              # three rows per field at B = 60000: every row's ~20 K lookups sit in ONE hash
+                                              # partition — more than an election block's 16384-entry lookup list holds (the
                                               # spill paths: BENCH b65536 with Zipf ids met them first and got them wrong)
-                                              (3, 40000, 7, 16, 0.0)])
+                                              (3, 60000, 7, 16, 0.0)])
 def test_rows_in_step_equals_the_separate_optimizer_step(dev, monkeypatch, vocab, B, F, D, drop, net):
     """DeepModel.train_step on the pipelined DeepFM step applies Keras Adam to the table rows looked up once inside the
     step (dt_deepfm_train_step_adam, k_wgrad_rows) and leaves only the segments to the optimizer launch: same tables,

@@ -34,7 +34,8 @@ bash tools_prof.sh r05_xdeepfm --model xDeepFM --steps 20 --warmup 5 --no-parity
 bash tools_prof.sh r05_autoint --model AutoInt --steps 50 --warmup 10 --no-parity > ${O}_stats_autoint.txt 2>&1
 ROWS=1 timeout 200 python tools/phase_times.py > ${O}_deepfm_phase_stamps.txt 2>&1
 bash tools_pmc.sh r05_pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 20 --warmup 5 --no-parity > ${O}_pmc_mfma.txt 2>&1
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6 > ${O}_tests.txt
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -12 > ${O}_tests.txt
+python __graft_entry__.py --smoke > ${O}_smoke.txt 2>&1; tail -1 ${O}_smoke.txt
 for f in driver deepfm zipf deepfm_nochain b32768 b65536 deepfm_f32tower deepfm_bf16tower dcn dcn_dp_w1 dp_w1 sharded_w1 xdeepfm autoint; do grep "^{" ${O}_line_$f.json | python -c "
 import sys,json
 j=json.loads(sys.stdin.read()); print('$f', round(j['value']/1e6,3), 'M rows/s', round(j['ms_per_step']*1e3,1), 'us', 'median', round(j['step_us']['median'],1), 'frac', round(j['roofline']['frac'],4), 'traffic', j['roofline'].get('traffic'), 'parity', (j.get('parity') or {}).get('ok'), j.get('phases'), j.get('fit_rows_per_s'), (j.get('other_layout') or {}).get('rows_per_s'))" || tail -3 ${O}_line_$f.err; done
