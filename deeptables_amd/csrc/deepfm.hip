@@ -1,4 +1,5 @@
-// deepfm.hip — the whole DeepFM train step (forward + BCE + backward) as SIX fused launches.
+// deepfm.hip — the whole DeepFM / DCN train step (forward + loss + backward + Keras Adam) as FOUR fused launches
+// (five for a step that prepares itself; rounds 3-4: six).
 //
 // DeepFM = nets ['linear','fm_nets','dnn_nets'] (deeptables/models/deepnets.py:15) assembled by
 // DeepModel.__build_model (deeptables/models/deepmodel.py:259-317):
@@ -9,16 +10,20 @@
 //   fm    = FM()(Concatenate(emb, axis=1))                              layers.py:53-62
 //   dnn   = Dense(1,no bias)(relu(Dense(64)(relu(Dense(128)(xn)))))     deepnets.py:401-427, deepmodel.py:291-292
 //   logit = Dense(1, bias)(Add([lin, fm, dnn]))  (sigmoid applied by the loss)   deepmodel.py:296-297,455
-// The reference runs this as ~100 small TF ops per step; the generic path of this repo as ~60 launches.  Here:
-//   A  k_sparse_fwd     gather + FM + linear + concat row X + field sums S + per-block BN statistics   (HBM-bound)
-//   B  k_prep           level 1 of the BN reduction (16 slices per column) + MFMA operand layouts of W1 / W2 / W2^T
-//   C  k_mlp_fwd3       BN level 2 (mean/rstd, moving stats) -> X -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit + the top of the backward
-//   E  k_wgrad4         Xhat^T dH1 and H1^T dH2 (split over batch slices) + reduction of C's per-tile partial sums
-//   E' k_bn_grads2      slices added up; dgamma, dbeta, dW1, dW2, d w_lin finished
-//   D  k_dx_sparse_bwd  dXn = dH1 W1^T with BN backward + FM/linear terms + embedding row-gradients as its epilogue
-// (details in front of the kernels).  Matrix work uses v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32) so
-// logits stay within 1e-4 of the oracle.  No float atomics on any dense gradient: per-tile / per-slice partials + one
-// reduction pass each.
+// The reference runs this as ~100 small TF ops per step; the layer-by-layer path of this repo as ~60 launches.  Here
+// (details in front of the kernels):
+//   A   k_sparse_fwd    gather + FM + linear + concat row X + field sums S + the batch sums of BatchNormalization (double
+//                       atomics into sharded accumulators: bnacc); chained steps: + the NEXT step's packed rows
+//   [B  k_prep          the in-step dedupe's election + the tile kernel's weight layouts — only in a step that was not
+//                       prepared by the one before it (DT_STEP_PREPARED)]
+//   C   k_tower_x3      (tower_x3.h; exact fp32: k_mlp_fwd3) mean / rstd from bnacc, BN, Dense128, Dense64, logits, loss, dz,
+//                       dH2, dH1, dXn = dH1 W1^T with the two BN-backward column sums; the tile's record sums -> racc (atomics)
+//   E|D k_wgrad_rows    waves 0-3: Xhat^T dH1 and H1^T dH2 batch slices (fp32 MFMA), then the NEXT step's election (chained);
+//                       waves 4-7: row gradients + in-place Keras Adam of the rows looked up once
+//   F   k_finish_step   segments (rows looked up several times), record entries + slices -> dense gradients + Adam, the NEXT
+//                       step's bf16 weight layouts (chained), the step state
+// Dense gradients are deterministic: per-slice partials + one pass, and the batch sums are double-precision atomics of fp32
+// addends (exact unless their magnitudes span 2^23: the totals do not depend on the order of arrival).
 #include <stdlib.h>
 #include "common.h"
 #include "adam_dev.h"
@@ -846,16 +851,9 @@ struct MlpParams {
 //       16x16x4: lane (n = l%16, q = l/16), step 4G+j  <->  k = 16G + 4q + j
 //     weights come from L2 in lane-major re-layouts written once per step by k_prep (W1L, W2L, W2TL) or, for
 //     dXn = dH1 . W1^T, straight from the ROW-major W1 whose rows are the k-contiguous vectors needed.
-// Launches (after A = k_sparse_fwd and B = k_prep + k_bn_final):
-//   C  k_mlp_fwd3     X tile -> BN -> Dense128 -> relu -> Dense64 -> relu -> logits, BCE, dlogit, and — still on the
-//                     tile — the TOP of the backward: dH2 (registers), dH1 = relu'(dH2 . W2^T); per-tile partial sums
-//                     of db1, db2, dw3, dw_out, db_out, d w_lin (raw X is still in registers) and the loss
-//   E  k_wgrad3       M = Xhat^T dH1 (Xhat = (X - mean) rstd, formed on the operand), dW2 = H1^T dH2, + the reduction
-//                     of C's per-tile partial sums
-//   E' k_bn_grads     dgamma = rowdot(W1, M), dbeta = W1 db1 (= the two batch sums BN's backward needs: they are linear
-//                     in dH1, so no pass over dXn is required), dW1 = gamma M + beta (x) db1 in place, d w_lin
-//   D  k_dx_sparse_bwd  dXn = dH1 . W1^T per 16-column block with the BN backward, the FM / linear terms and the
-//                     embedding row-gradient store (incl. the duplicate merge) as its epilogue: dXn never exists in HBM
+// (The launch list of round 2 that stood here — C k_mlp_fwd3, E k_wgrad3, E' k_bn_grads, D k_dx_sparse_bwd — is history:
+// the file's header has today's.  k_mlp_fwd3 below is the exact-fp32 tile kernel of `dnn_params['mfma_dtype'] = 'f32'` and of
+// forward-only calls; the default tile kernel is tower_x3.h.)
 // =============================================================================================
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));

@@ -4,8 +4,9 @@ kernel sequence for, `DeepModel.train_step` runs that instead of the layer-by-la
 path.  Same weights, same gradients (tests/test_fused_gpu.py checks both against the oracle).
 
 DeepFM (nets ['linear','fm_nets','dnn_nets'], deepnets.py:15) -> `dt_deepfm_train_step`
-(csrc/deepfm.hip): 7 launches instead of ~60, the sparse gradient leaving the step already deduplicated;
-under `parallel.ShardedEmbeddingStrategy` the same kernels run on rows gathered by their owning ranks.
+(csrc/deepfm.hip): four launches (five for a step that prepares itself) instead of ~60, the optimizer inside them, the
+sparse gradient deduplicated in the step; consecutive steps of a captured execution are CHAINED (`can_chain`); under
+`parallel.ShardedEmbeddingStrategy` the same kernels run on rows gathered by their owning ranks.
 """
 import ctypes
 import os
