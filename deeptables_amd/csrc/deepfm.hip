@@ -169,9 +169,12 @@ __device__ __forceinline__ int elect_part(unsigned h, int parts_log2) { return (
 //                              forms mean / variance in double: E[x^2] - mean^2 loses 2 log2(|mean| / sigma) of 53 bits)
 //   racc  [kRecShards][stride] the tile kernel's per-tile record entries (Part3: db1, db2, dw3, d w_out, d b_out, loss, the
 //                              d w_lin column sums, the two BN-backward sums sdx / sdxx, DCN's cross record)
-// Every addend is an fp32 value; a shard entry is the double sum of at most 64 of them, which is EXACT unless their
-// magnitudes span more than 2^23 — so the totals do not depend on the order the blocks arrive in, and the rounded fp32
-// results are the same from run to run (what the per-tile records + reduction launch guaranteed before).
+// racc: every addend is an fp32 value and a shard entry is the double sum of at most 64 of them (B = 8192), which is EXACT
+// unless their magnitudes span more than 2^23 — the totals do not depend on the order the blocks arrive in.  bnacc: the
+// addends are a block's 16-row sums formed in double (x^2 of an fp32 value is exact in double); their order of arrival can
+// move a total by an ulp of a DOUBLE, which survives the rounding to fp32 with probability ~1e-9 per value.  Either way the
+// fp32 results are the same from run to run (what the per-tile records + reduction launch guaranteed before; checked: four
+// runs of a step bit-identical, tools/r5/dbg_elect.py).
 // Life cycle: kernel A zeroes racc (kernel C of the same step adds into it); the launch after kernel C zeroes bnacc for the
 // NEXT step's kernel A — the workspace must be zero-filled once before its first use (dt_deepfm_workspace_bytes).
 constexpr int kBnShards = 8;
