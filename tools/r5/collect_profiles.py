@@ -1,6 +1,6 @@
-"""gpurun_out/r05_* (tools/r4/evidence.sh, then tools/r4/call24.sh on the final source hash) -> profiles/r05_*: the bench lines
+"""gpurun_out/r05_* (tools/r5/evidence.sh, then tools/r5/refresh.sh on the final source hash) -> profiles/r05_*: the bench lines
 (one jsonl, `_run` names the command), the two DeepFM lines as files of their own, the kernel-stats csv per model, the phase
-stamps, the MFMA-busy and PMC summaries.  python tools/r4/collect_profiles.py"""
+stamps, the MFMA-busy and PMC summaries.  python tools/r5/collect_profiles.py"""
 import json
 import os
 import shutil
