@@ -169,23 +169,32 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     if loop.dp:
         loop.phase_events = []
     evs = []
+    # the timing events exist (and have been recorded once) before the region starts: the first record of a fresh HIP event
+    # cost the host 73-80 us (tools/r5/call18.sh: 116 -> 112 us per step on the 20-step command, same box) — the bench's own
+    # overhead, not the step's.  (Polling the last event instead of sleeping in synchronize gained nothing: same call.)
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(steps // max(1, getattr(loop, 'k', 1)) + 2)]
+    for e in pool:
+        e.record()
+    torch.cuda.synchronize()
 
     def mark(k):
-        e = torch.cuda.Event(enable_timing=True)
+        e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
         e.record()                 # HIP event on the launch stream after every launch unit (median / p10 / p90 below)
         evs.append((e, k))
-    e0 = torch.cuda.Event(enable_timing=True)
+    e0 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    t_e0 = time.perf_counter() - t0
     loop.run(steps, on_execution=mark)
     t_enq = time.perf_counter() - t0
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     gc.enable()
-    per, prev = [], e0
+    per, prev, units = [], e0, []
     for e, k in evs:
         per += [prev.elapsed_time(e) * 1e3 / k] * k          # us per step (a replay of k steps: its mean)
+        units.append(round(prev.elapsed_time(e) * 1e3, 1))
         prev = e
     per.sort()
 
@@ -195,7 +204,9 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
              'launch_units': len(evs),
              # host clock of the timed region: all launch units enqueued after `host_enqueue_us`, the GPU's own time for them
              # `gpu_us` (HIP events), the rest of `wall_us` is launch latency before the first kernel + the final synchronize
-             'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': e0.elapsed_time(evs[-1][0]) * 1e3}
+             'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': e0.elapsed_time(evs[-1][0]) * 1e3, 'first_record_us': t_e0 * 1e6}
+    if len(units) <= 10:
+        stats['unit_us'] = units                       # GPU time of each launch unit, in order (the first holds the launch latency)
     return wall, e0.elapsed_time(evs[-1][0]) / 1e3, stats
 
 
@@ -431,7 +442,7 @@ def main():
     ap.add_argument('--cin', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help="cin_params['mfma_dtype'] of xDeepFM: exact-fp32 MFMA, split-bf16 (fp32 bars) or plain bf16 (1e-2 bars)")
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--steps-per-graph', type=int, default=10,
+    ap.add_argument('--steps-per-graph', type=int, default=20,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -527,7 +538,7 @@ def main():
         # k divides the TIMED steps (exactly `steps` steps are timed, all through replays); the warm-up runs through the same
         # loop — whole replays and, when k does not divide it, its last steps eagerly (untimed).  Round 4 also made k divide the
         # warm-up, which put the driver's `--steps 20 --warmup 5` on 5-step graphs: a replay's fixed cost (~10 us of idle GPU)
-        # was paid twice as often as in `fit`'s default of 10 steps per execution.  (first_replay_us: a graph's first launch
+        # was paid twice as often as in `fit`'s default (then 10, now 20 steps per execution: tools/r5/call21.sh).  (first_replay_us: a graph's first launch
         # costs what every later one does — it is uploaded at capture time.)
         spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0)
     warm_capture = 2

@@ -477,7 +477,7 @@ def resolve_steps_per_execution(dm, requested, feed, batch_size, steps_per_epoch
     """`fit(steps_per_execution=...)`: an int k > 1 asks for the compiled loop; 'auto' (the default, also
     `training.DEFAULT_STEPS_PER_EXECUTION`) compiles when the graph has a fused whole-step plan (known to be
     capturable: no host synchronisation inside the step), the feed is device resident and an epoch holds at least ten
-    steps; 1 / 0: eager steps."""
+    steps (5, 10 or 20 steps per execution, by the epoch's length); 1 / 0: eager steps."""
     if requested is None:
         requested = training.DEFAULT_STEPS_PER_EXECUTION
     if requested in (0, 1, False):
@@ -493,6 +493,8 @@ def resolve_steps_per_execution(dm, requested, feed, batch_size, steps_per_epoch
         if dm.fused_plan() is None or (feed.weighted and not getattr(dm.fused_plan(), 'takes_sample_weight', False)):
             return 1
         # an epoch must hold at least two executions, and an execution at least five steps (below that the capture costs
-        # more than it saves)
-        return 10 if steps_per_epoch >= 20 else 5 if steps_per_epoch >= 10 else 1
+        # more than it saves).  Twenty steps per execution where the epoch allows: the first step of an execution is the only
+        # one that launches `k_prep`, and a replay boundary idles the GPU for a moment — 105.1 -> 104.4 us per step at
+        # batch 8192 (tools/r5/call21.sh; 103.7 at forty, which an epoch of the reference's size rarely divides into)
+        return 20 if steps_per_epoch >= 40 else 10 if steps_per_epoch >= 20 else 5 if steps_per_epoch >= 10 else 1
     return max(1, min(int(requested), int(steps_per_epoch)))

@@ -91,7 +91,7 @@ def test_auto_steps_per_execution_compiles_fused_plans_only(dev):
     df, y = _frame(64 * 40)
     dm = _model('DeepFM')
     dm.fit(df, y, batch_size=64, epochs=1, verbose=0, validation_split=0)
-    assert dm.compiled_loop is not None and dm.compiled_loop.graph is not None and dm.compiled_loop.k == 10
+    assert dm.compiled_loop is not None and dm.compiled_loop.graph is not None and dm.compiled_loop.k == 20
     other = _model('AFM')
     other.fit(df, y, batch_size=64, epochs=1, verbose=0, validation_split=0)
     assert other.compiled_loop is None

@@ -418,7 +418,8 @@ def test_steps_per_execution_policy():
     dm = types.SimpleNamespace(config=types.SimpleNamespace(distribute_strategy=None), fused_plan=lambda: plan)
     no_plan = types.SimpleNamespace(config=types.SimpleNamespace(distribute_strategy=None), fused_plan=lambda: None)
     r = compiled.resolve_steps_per_execution
-    assert r(dm, 'auto', feed, 8192, 50) == 10 and r(dm, 'auto', feed, 8192, 12) == 5 and r(dm, 'auto', feed, 8192, 3) == 1
+    assert r(dm, 'auto', feed, 8192, 50) == 20 and r(dm, 'auto', feed, 8192, 25) == 10
+    assert r(dm, 'auto', feed, 8192, 12) == 5 and r(dm, 'auto', feed, 8192, 3) == 1
     assert r(no_plan, 'auto', feed, 8192, 50) == 1          # layer-by-layer graphs: on request only
     assert r(no_plan, 4, feed, 8192, 50) == 4 and r(dm, 100, feed, 8192, 23) == 23
     assert r(dm, 1, feed, 8192, 50) == 1 and r(dm, 0, feed, 8192, 50) == 1
