@@ -314,7 +314,9 @@ def test_roofline_fraction_follows_from_the_committed_evidence():
     steps = max(c for _, c in step_kernels.values())
     per_step = [k for k, (_, c) in step_kernels.items() if c == steps]
     assert len(per_step) == 4 and len(step_kernels) == 5, sorted(stats)
-    assert any('k_prep' in k and c * 8 <= steps for k, (_, c) in step_kernels.items())
+    # (under this command — 100 timed steps after 2 capture + 10 warm-up steps, twenty per replay — the eager warm-up steps
+    # launch `k_prep` each: 12 + 5 replays of 112 steps; in the timed replays alone it is one launch per twenty steps)
+    assert any('k_prep' in k and c * 4 <= steps for k, (_, c) in step_kernels.items())
     total = sum(us * c / steps for us, c in step_kernels.values())
     assert 0.85 * rf['launch_us'] <= total <= 1.05 * rf['launch_us'], (total, rf['launch_us'])
     tj = json.load(open(os.path.join(root, 'profiles', 'deepfm_traffic.json')))
