@@ -158,7 +158,7 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
     graph and, for what k does not divide, eager steps)."""
     import gc
     loop.run(warmup)
-    if spin and os.environ.get('DT_BENCH_SPIN'):      # measured (tools/r4/call13.sh): no gain in gpu_us, slower host enqueue
+    if spin and os.environ.get('DT_BENCH_SPIN'):      # measured (tools/r4/call13.sh, tools/r5/call23.sh): under 1 % on the first replay
         spin_gpu(device)
     barrier()
     torch.cuda.synchronize()
@@ -205,7 +205,7 @@ def time_steps(loop, steps, warmup, barrier, device, spin=True):
              # host clock of the timed region: all launch units enqueued after `host_enqueue_us`, the GPU's own time for them
              # `gpu_us` (HIP events), the rest of `wall_us` is launch latency before the first kernel + the final synchronize
              'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': e0.elapsed_time(evs[-1][0]) * 1e3, 'first_record_us': t_e0 * 1e6}
-    if len(units) <= 10:
+    if len(units) <= 64:
         stats['unit_us'] = units                       # GPU time of each launch unit, in order (the first holds the launch latency)
     return wall, e0.elapsed_time(evs[-1][0]) / 1e3, stats
 
