@@ -4,7 +4,7 @@
 deepmodel.py:114-129) on MI355X — `k` consecutive train steps captured ONCE into one hipGraph over static
 input slots and replayed by `DeepModel.fit`.
 
-Why: a fused DeepFM / DCN step is six launches of ~15-35 us; launched eagerly from Python the host cannot keep
+Why: a fused DeepFM / DCN step is four or five launches of ~15-40 us; launched eagerly from Python the host cannot keep
 up (~3.5 us per launch + the interpreter), and even a one-step graph pays its fixed replay cost (~10 us of idle
 GPU between two replays) every step.  One graph of k steps keeps the launches of consecutive steps back to back.
 

@@ -880,7 +880,8 @@ __device__ __forceinline__ void st4_sel(float* p, floatx4 v, bool wt) {
 // cross layers): no slin; G[0..L] (CP floats each: G_l = Xhat^T coeff_l over the tile's rows, see the cross backward of
 // kernel C) and one CP-float block of scalars follow: [l] = sum_r coeff_l, [16 + l] = sum_r A_{l+1}, [31] = sum_r dz.
 // Pipelined step (G3, see k_mlp_fwd3): two more CP-float vectors per tile, sdx = sum_r dXn[r] and sdxx = sum_r dXn[r] xhat[r]
-// over the tile's rows (the two batch sums of BatchNormalization's backward), reduced by k_wgrad4's reducer blocks.
+// over the tile's rows (the two batch sums of BatchNormalization's backward).  Since round 5 every entry is ADDED into the
+// sharded double-precision sums `racc` (radd) instead of being written per tile and reduced by a launch of its own.
 struct Part3 {
     int slin, db1, db2, dw3, dwo, dbo, loss, cross, sdx, sdxx, n, stride;
 };
@@ -2151,7 +2152,7 @@ __global__ void k_emb_drop_advance(unsigned* seed) { *seed = *seed * 1664525u + 
 // ---------------------------------------------------------------------------------------------
 // Pipelined step, launch E+D: the weight-gradient GEMMs (MFMA-bound) and the row-gradient epilogue + the row-sparse
 // Adam update of the rows looked up once (bound by random 64 / 128-byte records) in ONE launch of 512-thread blocks,
-// one per CU: waves 0-3 run a heavy block of k_wgrad4, waves 4-7 the epilogue of the block's share of the 32-row
+// one per CU: waves 0-3 run a heavy block of the weight-gradient GEMMs (wgrad_heavy), waves 4-7 the epilogue of the block's share of the 32-row
 // tiles — one matrix wave and one memory wave per SIMD, neither waiting for the other.  With dXn and the two BN
 // batch sums already there (kernel C + the record reduction), a lookup's gradient is elementwise:
 //   dX[c]            = gamma rstd (dXn - mean_b(dXn) - xhat mean_b(dXn xhat))
@@ -2388,7 +2389,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.W2L = take((int64_t)kH1 * kH2);
     w.W2TL = take((int64_t)kH1 * kH2);
     w.S = take(rows * dm.D);                        // S[b][d] = sum_f E[b,f,d] (kernel A -> kernel D)
-    w.wpart = take((int64_t)256 * 8192);            // k_wgrad4's per-slice partial macro tiles (<= 256 heavy blocks)
+    w.wpart = take((int64_t)256 * 8192);            // wgrad_heavy's per-slice partial macro tiles (<= 256 heavy blocks)
     // the batch-sum accumulators (doubles; see bnacc / racc in front of kernel A): zero before the first step, kept by the steps
     w.bnacc_n = (int64_t)kBnShards * 2 * dm.CP;
     w.bnacc = take(2 * w.bnacc_n);

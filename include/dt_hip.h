@@ -429,7 +429,7 @@ int dt_field_scale_bwd(const float* x, const float* a, const float* grad_out, in
  * The graph DeepModel.__build_model assembles for DeepFM (deepmodel.py:259-317) — embedding gather,
  * concat + BatchNormalization('bn_concat_emb_dense'), linear, FM, Dense(128)-relu-Dense(64)-relu,
  * the per-net Dense(1) logits, Add, Dense(1) output, BinaryCrossentropy (from logits, mean over B)
- * — forward AND backward in six launches (csrc/deepfm.hip).  Hidden sizes are fixed to the
+ * — forward AND backward in the launches csrc/deepfm.hip's header lists (A, prep, C, E||D, finish).  Hidden sizes are fixed to the
  * ModelConfig default dnn_params ((128,0,False),(64,0,False)), relu; dt_deepfm_supported() says
  * whether a shape is covered (else the host uses the per-layer entry points above).
  *   W1 [C,128] b1 [128] W2 [128,64] b2 [64] w3 [64] (dense_logit_dnn_nets) w_out [1] b_out [1]|NULL
