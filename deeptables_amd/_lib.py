@@ -28,6 +28,8 @@ SIGNATURES = {
     'dt_build_arch': (ctypes.c_char_p, []),
     'dt_source_hash': (ctypes.c_char_p, []),
     'dt_graph_upload': (_c_int, [_ptr, _ptr]),
+    'dt_step_trace': (_c_int, [_c_int]),
+    'dt_step_trace_read': (_c_int, [_ptr, _c_int, _ptr]),
     'dt_embedding_fwd': (_c_int, [_ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr,
                                   _ptr, _ptr]),
     'dt_embedding_bwd_dense': (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),

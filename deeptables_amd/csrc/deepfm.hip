@@ -2560,6 +2560,72 @@ extern "C" int dt_deepfm_step_chains(int B, int F, int D, int Nd, int phases) {
     return step_chains(dm, phases, true, true) ? 1 : 0;
 }
 
+// ---- launch-boundary trace of an EAGER step (bench.py's per-kernel split; never enabled inside a stream capture) ----
+// dt_step_trace(1): every fused train step this thread enqueues afterwards records a HIP event on its stream in front of
+// its first launch and behind each of its launch groups (A [+ the prep launch] | C | E||D | F); dt_step_trace_read waits
+// for the last traced step and returns the four intervals, averaged over the (up to 32) steps traced since the switch was
+// set.  Events belong to the thread (created on first use).
+namespace {
+constexpr int kTraceEvents = 5, kTraceSteps = 32;
+thread_local bool g_trace_on = false;
+thread_local int g_trace_step = -1;                       // steps traced since dt_step_trace(1) - 1
+thread_local int g_trace_have[kTraceSteps];               // boundaries recorded of the step in each ring entry
+thread_local hipEvent_t g_trace_ev[kTraceSteps][kTraceEvents];
+thread_local bool g_trace_init = false;
+inline void trace_mark(int i, hipStream_t st) {
+    if (!g_trace_on) return;
+    if (!g_trace_init) {
+        for (int s = 0; s < kTraceSteps; ++s) {
+            g_trace_have[s] = 0;
+            for (int e = 0; e < kTraceEvents; ++e) g_trace_ev[s][e] = nullptr;
+        }
+        g_trace_init = true;
+    }
+    if (i == 0) { ++g_trace_step; g_trace_have[g_trace_step % kTraceSteps] = 0; }
+    if (g_trace_step < 0) return;
+    const int s = g_trace_step % kTraceSteps;
+    if (g_trace_have[s] != i) return;                     // a step shape without this boundary: the entry stays incomplete
+    if (!g_trace_ev[s][i]) hipEventCreate(&g_trace_ev[s][i]);
+    hipEventRecord(g_trace_ev[s][i], st);
+    g_trace_have[s] = i + 1;
+}
+}  // namespace
+
+extern "C" int dt_step_trace(int enable) {
+    g_trace_on = enable != 0;
+    g_trace_step = -1;
+    if (g_trace_init) for (int s = 0; s < kTraceSteps; ++s) g_trace_have[s] = 0;
+    return DT_OK;
+}
+
+extern "C" int dt_step_trace_read(float* us_host, int n, int* steps_host) {
+    DT_REQUIRE(us_host && n >= kTraceEvents - 1, "dt_step_trace_read: us_host must take %d floats", kTraceEvents - 1);
+    double sum[kTraceEvents - 1] = {0, 0, 0, 0};
+    int steps = 0;
+    if (g_trace_init && g_trace_step >= 0) {
+        const int last = g_trace_step % kTraceSteps;
+        if (g_trace_have[last] == kTraceEvents && hipEventSynchronize(g_trace_ev[last][kTraceEvents - 1]) != hipSuccess) {
+            dt::set_error("dt_step_trace_read: hipEventSynchronize failed");
+            return DT_ERR_LAUNCH;
+        }
+        for (int s = 0; s < kTraceSteps; ++s) {
+            if (g_trace_have[s] != kTraceEvents) continue;
+            bool ok = true;
+            float ms[kTraceEvents - 1];
+            for (int i = 0; i + 1 < kTraceEvents && ok; ++i)
+                ok = hipEventElapsedTime(&ms[i], g_trace_ev[s][i], g_trace_ev[s][i + 1]) == hipSuccess;
+            if (!ok) continue;                            // (an entry whose step has not finished: only older than `last`)
+            for (int i = 0; i + 1 < kTraceEvents; ++i) sum[i] += ms[i] * 1e3;
+            ++steps;
+        }
+    }
+    DT_REQUIRE(steps > 0, "dt_step_trace_read: no traced step with the in-step optimizer on this thread "
+               "(dt_step_trace(1), then dt_deepfm_train_step_adam / dt_dcn_train_step_adam)");
+    for (int i = 0; i + 1 < kTraceEvents; ++i) us_host[i] = (float)(sum[i] / steps);
+    if (steps_host) *steps_host = steps;
+    return DT_OK;
+}
+
 // the step both entry points run: DeepFM (cross == NULL) or DCN (cross kernels / biases [Lc][C]; w3 = the [C + 64] kernel
 // applied to Concatenate([cross, dnn]), w_lin unused)
 static int tower_train_step(
@@ -2684,6 +2750,17 @@ static int tower_train_step(
         nx.dd = dedupe_view(chain->next_dedupe_ws, dln);
         nx.eblocks = dln.eblocks;
     }
+    // every host-side check sits in front of the first launch: kernel A adds into bnacc, and a step abandoned behind it
+    // would hand the next step on this workspace a dirty accumulator (the workspace's zero-on-entry invariant)
+    const size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
+                         (dcn ? kCrossLds + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
+    DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
+    if (adam && sdense) {
+        const int64_t want_flat = dcn ? al.dcb + (int64_t)Lc * dm.C : al.dwlin + F + Nd;
+        DT_REQUIRE(sdense->n_flat == want_flat, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
+                   "%lld floats (the accumulator layout up to its last gradient)", (long long)sdense->n_flat,
+                   (long long)want_flat);
+    }
     // A (a pre-elected step: rows_out / rows_fm and the segments exist already — kernel A writes neither, the prep launch
     //    has no election blocks)
     DedupeWs ddA = dd;
@@ -2702,6 +2779,7 @@ static int tower_train_step(
         case 4: DT_A(KIND, 4); break; case 8: DT_A(KIND, 8); break;                   \
         default: DT_A(KIND, 16); break;                                               \
     }
+    trace_mark(0, st);
     if (idx_kind == DT_IDX_F32) { DT_A_L(DT_IDX_F32) } else { DT_A_L(DT_IDX_I32) }
 #undef DT_A_L
 #undef DT_A
@@ -2721,11 +2799,9 @@ static int tower_train_step(
     if (ldsB) hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     // (a prepared step has neither an election nor layouts left to do: no prep launch)
     if (!prepared) hipLaunchKernelGGL(k_prep, dim3(56 + elect_blocks), dim3(1024), ldsB, st, dm, W1, po, 56, dd, rows_out);
+    trace_mark(1, st);
     // C (always with the top of the backward: its extra outputs are simply unused by a forward-only call)
     {
-        size_t ldsC = ((size_t)kTM * (dm.CP + kPad) + 4 * dm.CP + kTM * (kH1 + kPad) + kTM * kH2S + 5 * kTM +
-                       (dcn ? kCrossLds + (2 * Lc + 1) * dm.CP : 0)) * sizeof(float);
-        DT_UNSUPPORTED(ldsC > 160 * 1024, "dt_dcn_train_step: the tile kernel needs %zu B of LDS", ldsC);
 #define DT_C(N)                                                                                                     \
     case N:                                                                                                         \
         if (dcn && pipe) {                                                                                          \
@@ -2772,6 +2848,7 @@ static int tower_train_step(
 #undef DT_CXL
 #undef DT_C
     }
+    trace_mark(2, st);
     const Part3 pl3 = part3_layout(dm.CP, Lc, pipe ? 1 : 0);
     const RecSrc rsrc{racc, pl3.stride};                  // (the shard stride is the producing tile kernel's: its own layout's)
     const int rec_blocks = ceil_div(pl3.n, 256);          // one thread per record entry (finish_record_entry)
@@ -2802,12 +2879,9 @@ static int tower_train_step(
                                stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
                                stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);
         }
+        trace_mark(3, st);
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)
-            const int64_t want_flat = dcn ? al.dcb + (int64_t)Lc * dm.C : al.dwlin + F + Nd;
-            DT_REQUIRE(sdense->n_flat == want_flat, "dt_deepfm_train_step_adam: dense_n=%lld, the flat buffers hold "
-                       "%lld floats (the accumulator layout up to its last gradient)", (long long)sdense->n_flat,
-                       (long long)want_flat);
             // 512 blocks: 1.5 us faster with uniform ids (878 segments), 1024: 4.6 us faster with Zipf ids (15 K segments)
             const int seg_blocks = 1024;
             const int small_blocks = rec_blocks;
@@ -2822,6 +2896,7 @@ static int tower_train_step(
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
                                dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay, gpt);
+            trace_mark(4, st);
         } else if (!skip_finish) {
             // E': slices added up, dW1 / dW2 / d w_lin finished; the record entries (db1 .. dgamma / dbeta) -> accum
             hipLaunchKernelGGL(k_bn_grads2, dim3(dm.C + kH2 + rec_blocks), dim3(256), 0, st, W1, bn_gamma, bn_beta, dm,

@@ -66,6 +66,15 @@ const char* dt_source_hash(void);     /* sha256[:16] of the sources this binary 
  * Keras steps_per_execution, deepmodel.py:319-346) uploads its captured k-step graph once, so that the first replay costs
  * what every later one costs.  Goes through this library's HIP runtime, i.e. the one the host framework loaded.        */
 int dt_graph_upload(void* graph_exec, void* stream);
+/* Launch-boundary trace of the fused train step (measurement plumbing, bench.py's `kernel_split_us`): after dt_step_trace(1)
+ * every dt_deepfm_train_step_adam / dt_dcn_train_step_adam this thread enqueues EAGERLY (never inside a stream capture)
+ * records a HIP event on its stream in front of its first launch and behind each launch group — A (+ the prep launch of an
+ * unprepared step) | C | E||D | F, the four launches that replace the ~100 TF ops of one keras train step
+ * (deepmodel.py:114-129).  dt_step_trace_read waits for the last traced step and writes the four intervals in
+ * microseconds, averaged over the steps traced since dt_step_trace(1) (the last 32 at most), to us_host[0..3] (HOST
+ * pointer, n >= 4) and their number to *steps_host (HOST, may be NULL).  dt_step_trace(0) switches the recording off.  */
+int dt_step_trace(int enable);
+int dt_step_trace_read(float* us_host, int n, int* steps_host);
 
 /* ---- a2  MultiColumnEmbedding.call  (models/layers.py:889-904) -------------------------- *
  * All F columns live in ONE packed table [sum_f vocab_f, D]; column f starts at row

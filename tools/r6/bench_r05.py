@@ -29,7 +29,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -137,162 +137,51 @@ def ring_order(feed, batch, n_steps, device):
     return torch.arange(n_steps * batch, device=device, dtype=torch.int64) % feed.n
 
 
-def _sysfs_card(device_index=0):
-    """/sys/class/drm/cardN/device of the HIP device: matched by PCI address (a node shows every GPU of the host and their
-    partitions — 64 card nodes on the round-6 boxes — while HIP sees one device)"""
-    import glob
-    try:
-        pr = torch.cuda.get_device_properties(device_index)
-        want = '%04x:%02x:%02x' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-    except Exception:
-        want = None
-    cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
-    for c in cards:
-        base = os.path.dirname(c)
-        if want and os.path.basename(os.path.realpath(base)).lower().startswith(want):
-            return base, want
-    return (os.path.dirname(cards[0]), None) if cards else (None, want)
+def spin_gpu(device, ms=60.0):
+    """~`ms` of light streaming work that touches nothing of the model: the timed region starts with the clocks up (a
+    20-step timed region is 2.5 ms long; an idle GPU spends it ramping)"""
+    buf = torch.empty(16 << 20, dtype=torch.float32, device=device)       # 64 MB
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        buf.add_(1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    per = max(e0.elapsed_time(e1) / 20, 1e-3)
+    for _ in range(int(ms / per) + 1):
+        buf.add_(1.0)
 
 
-def gpu_clocks(base):
-    """current shader / memory clock and package power from the amdgpu sysfs nodes of `base` (_sysfs_card).  One reading
-    costs the driver ~1 ms (measured: tools/r6/call1.sh) — it must not sit between the warm-up and the timed region; the
-    bench samples from a side thread instead (ClockSampler)."""
-    import glob
-    import re
-    if base is None:
-        return None
-    out = {}
-
-    def current(path):
-        try:
-            txt = open(path).read()
-        except OSError:
-            return None
-        m = re.search(r'(\d+)\s*[Mm][Hh]z\s*\*', txt)
-        return int(m.group(1)) if m else None
-    out['sclk_mhz'] = current(os.path.join(base, 'pp_dpm_sclk'))
-    out['mclk_mhz'] = current(os.path.join(base, 'pp_dpm_mclk'))
-    for hw in glob.glob(os.path.join(base, 'hwmon', 'hwmon*')):
-        for name, key, scale in (('power1_input', 'power_w', 1e-6), ('power1_average', 'power_w', 1e-6)):
-            try:
-                out.setdefault(key, round(int(open(os.path.join(hw, name)).read()) * scale, 1))
-            except (OSError, ValueError):
-                pass
-    return out
-
-
-class ClockSampler:
-    """a side thread reading (sclk, mclk, power) of the benchmarked device from sysfs in a loop while the warm-up, the
-    contract region and its repeats run — the launching thread never waits for a reading (file reads release the GIL).
-    `window(t0, t1)` -> the samples whose reading finished inside [t0, t1] (perf_counter seconds)."""
-
-    def __init__(self, device_index=0):
-        import threading
-        self.base, self.pci = _sysfs_card(device_index)
-        self.samples = []
-        self._stop = threading.Event()
-        self._th = threading.Thread(target=self._run, daemon=True) if self.base else None
-
-    def _run(self):
-        while not self._stop.is_set():
-            c = gpu_clocks(self.base)
-            if c:
-                self.samples.append((time.perf_counter(), c.get('sclk_mhz'), c.get('mclk_mhz'), c.get('power_w')))
-            self._stop.wait(0.0005)
-
-    def __enter__(self):
-        if self._th:
-            # (the launching thread must not wait 5 ms for the interpreter lock while this thread parses a reading)
-            self._switch = sys.getswitchinterval()
-            sys.setswitchinterval(2e-5)
-            self._th.start()
-        return self
-
-    def __exit__(self, *exc):
-        self._stop.set()
-        if self._th:
-            self._th.join(timeout=2)
-            sys.setswitchinterval(self._switch)
-        return False
-
-    def window(self, t0, t1):
-        sel = [s for s in self.samples if t0 <= s[0] <= t1]
-
-        def col(i):
-            v = sorted(x[i] for x in sel if x[i] is not None)
-            return None if not v else {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1]}
-        return {'n': len(sel), 'sclk_mhz': col(1), 'mclk_mhz': col(2), 'power_w': col(3)}
-
-
-def smi_clocks():
-    """the same figures from `rocm-smi` (a subprocess: ~0.3-1 s — only used OUTSIDE the timed neighbourhood, as a cross-check
-    of the sysfs reader and where sysfs is not readable)"""
-    import subprocess
-    try:
-        r = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showperflevel', '--json'], capture_output=True,
-                           text=True, timeout=20)
-        j = json.loads(r.stdout)
-        card = j.get('card0') or next(iter(j.values()))
-        keep = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if 'sclk' in kl or 'mclk' in kl or 'fclk' in kl or 'power' in kl or 'performance' in kl:
-                keep[k] = v
-        return keep
-    except Exception as e:          # diagnostic only
-        return {'error': repr(e)[:120]}
-
-
-def time_steps(loop, steps, warmup, barrier, device, repeats=0, warm_through_graph=True, sample_clocks=False):
-    """EXACTLY `steps` train steps are timed after the untimed warm-up, all through the product's compiled loop
-    (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides `steps`).
-
-    Round 6 — what sits between the warm-up and the timed region decides a 2 ms measurement, so that interval is now as short
-    as the contract allows (barrier + synchronize) and is itself reported (`pause_before_region_us`):
-      * the collector pass over the parity leg's millions of objects, the creation and first record of every timing event
-        (73-80 us each on a fresh event, tools/r5/call18.sh) happen BEFORE the warm-up;
-      * the warm-up runs through replays of the graph that is timed: `--warmup W` asks for W untimed steps, whole replays
-        hold k, so ceil(W / k) replays run (>= W steps; `warmup_steps_run` in the line).  Round 5 ran W < k as eager steps:
-        the timed region then WAS the graph's first replay ever, over k - 1 rows / segment buffers no launch had touched;
-      * `repeats` more regions of `steps` steps follow the contract region back to back (sync in between, like the
-        contract's brackets): `repeat_step_us` shows whether the first region is an outlier or the state of the machine;
-      * shader / memory clocks and power are sampled from sysfs by a side thread while the warm-up, the region and the
-        repeats run (one reading costs the driver ~1 ms: in line it would idle the GPU in front of the region).
-    -> (wall seconds of the contract region, its HIP-event seconds, stats)"""
+def time_steps(loop, steps, warmup, barrier, device, spin=True):
+    """EXACTLY `steps` train steps are timed after `warmup` untimed ones, all through the product's compiled loop
+    (deeptables_amd/compiled.py: k steps per hipGraph replay, k divides `steps`; the warm-up runs through replays of the same
+    graph and, for what k does not divide, eager steps)."""
     import gc
-    k = loop.k if loop.graph is not None else 1
-    warm_run = warmup
-    if warm_through_graph and loop.graph is not None and k > 1:
-        warm_run = max(k, -(-warmup // k) * k)
+    loop.run(warmup)
+    if spin and os.environ.get('DT_BENCH_SPIN'):      # measured (tools/r4/call13.sh, tools/r5/call23.sh): under 1 % on the first replay
+        spin_gpu(device)
+    barrier()
+    torch.cuda.synchronize()
+    # host hygiene of a 2.3 ms timed region: the parity leg in front of it leaves millions of Python objects behind — a
+    # generation-2 collection inside the region cost ~300 us of host clock (enqueue 501 us against 180 us without the leg)
     gc.collect()
     gc.disable()
     if loop.dp:
         loop.phase_events = []
-    n_units = (steps // max(1, k) + 2) * (1 + repeats) + 4
-    pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_units)]
+    evs = []
+    # the timing events exist (and have been recorded once) before the region starts: the first record of a fresh HIP event
+    # cost the host 73-80 us (tools/r5/call18.sh: 116 -> 112 us per step on the 20-step command, same box) — the bench's own
+    # overhead, not the step's.  (Polling the last event instead of sleeping in synchronize gained nothing: same call.)
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(steps // max(1, getattr(loop, 'k', 1)) + 2)]
     for e in pool:
         e.record()
     torch.cuda.synchronize()
-    sampler = ClockSampler(device.index or 0) if sample_clocks else None
-    if sampler is not None:
-        sampler.__enter__()
-    t_idle = time.perf_counter()
-    if sampler is not None:
-        time.sleep(0.004)                 # a few readings of the idle device (before anything of this leg is enqueued)
-    t_w0 = time.perf_counter()
-    loop.run(warm_run)
-    t_w = time.perf_counter()
-    barrier()
-    torch.cuda.synchronize()
-    t_sync = time.perf_counter()
-    evs = []
 
-    def mark(kk):
+    def mark(k):
         e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
-        e.record()                 # HIP event on the launch stream after every launch unit
-        evs.append((e, kk))
-    e0 = pool.pop()
+        e.record()                 # HIP event on the launch stream after every launch unit (median / p10 / p90 below)
+        evs.append((e, k))
+    e0 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     t_e0 = time.perf_counter() - t0
@@ -301,92 +190,24 @@ def time_steps(loop, steps, warmup, barrier, device, repeats=0, warm_through_gra
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    t_end = time.perf_counter()
+    gc.enable()
     per, prev, units = [], e0, []
-    for e, kk in evs:
-        per += [prev.elapsed_time(e) * 1e3 / kk] * kk          # us per step (a replay of k steps: its mean)
+    for e, k in evs:
+        per += [prev.elapsed_time(e) * 1e3 / k] * k          # us per step (a replay of k steps: its mean)
         units.append(round(prev.elapsed_time(e) * 1e3, 1))
         prev = e
-    gpu_s = e0.elapsed_time(evs[-1][0]) / 1e3
-    # the same region again, `repeats` times, back to back
-    rep_us, rep_wall_us = [], []
-    for _ in range(repeats):
-        ea, eb = pool.pop(), pool.pop()
-        ta = time.perf_counter()
-        ea.record()
-        loop.run(steps)
-        eb.record()
-        barrier()
-        torch.cuda.synchronize()
-        rep_wall_us.append((time.perf_counter() - ta) * 1e6 / steps)
-        rep_us.append(ea.elapsed_time(eb) * 1e3 / steps)
-    t_rep = time.perf_counter()
-    if sampler is not None:
-        sampler.__exit__()
-    gc.enable()
     per.sort()
 
     def pct(q):
         return per[min(len(per) - 1, int(q * len(per)))]
-    several = len(evs) > 1
-    stats = {'median': pct(0.5), 'p10': pct(0.1) if several else None, 'p90': pct(0.9) if several else None,
-             'mean': sum(per) / len(per), 'n': len(per), 'launch_units': len(evs),
+    stats = {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'mean': sum(per) / len(per), 'n': len(per),
+             'launch_units': len(evs),
              # host clock of the timed region: all launch units enqueued after `host_enqueue_us`, the GPU's own time for them
              # `gpu_us` (HIP events), the rest of `wall_us` is launch latency before the first kernel + the final synchronize
-             'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': gpu_s * 1e6, 'first_record_us': t_e0 * 1e6,
-             'warmup_steps_run': warm_run,
-             # host time between the last warm-up launch being enqueued and the region's first record (the warm-up's GPU
-             # time + barrier + synchronize), and the part of it behind the synchronize (the GPU idles for that long)
-             'pause_before_region_us': (t0 - t_w) * 1e6, 'idle_gap_before_region_us': (t0 - t_sync) * 1e6}
-    if sampler is not None and sampler.base:
-        stats['clocks'] = {'source': 'amdgpu sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon power1_input of the HIP device (PCI ' +
-                                     str(sampler.pci) + '), sampled by a side thread (~1 ms per reading)',
-                           'idle': sampler.window(t_idle, t_w0), 'warmup': sampler.window(t_w0, t_sync),
-                           'contract_region': sampler.window(t0, t_end),
-                           'repeats': sampler.window(t_end, t_rep) if repeats else None}
+             'host_enqueue_us': t_enq * 1e6, 'wall_us': wall * 1e6, 'gpu_us': e0.elapsed_time(evs[-1][0]) * 1e3, 'first_record_us': t_e0 * 1e6}
     if len(units) <= 64:
         stats['unit_us'] = units                       # GPU time of each launch unit, in order (the first holds the launch latency)
-    if repeats:
-        srt = sorted(rep_us)
-        stats['repeat_step_us'] = [round(v, 2) for v in rep_us]          # HIP-event us per step of each repeated region
-        stats['repeat_wall_step_us'] = [round(v, 2) for v in rep_wall_us]
-        stats['repeat_spread'] = (srt[-1] - srt[0]) / srt[len(srt) // 2]
-        stats['steady_step_us'] = srt[len(srt) // 2]
-    return wall, gpu_s, stats
-
-
-def kernel_split(loop, n_steps=None):
-    """HIP events at the launch boundaries of eagerly enqueued CHAINED steps (dt_step_trace: the library records an event in
-    front of the step's first launch and behind each launch group) -> mean us of A | C | E||D | F over the traced steps.  The
-    steps are real train steps on the loop's slots (step j prepares step j + 1, as inside the captured execution), enqueued
-    back to back without a host synchronisation in between; they run after everything that is timed."""
-    import ctypes
-    from deeptables_amd._lib import lib, check
-    k = loop.k
-    if loop.graph is None or not loop.chained or k < 3:
-        return None
-    n = min(k, n_steps or k)
-    loop._select(k)
-    loop._gather()                     # the next k batches into the slots (advances the device cursor like a replay)
-    keep = loop._slots_per_step
-    loop._slots_per_step = True
-    check(lib().dt_step_trace(1), 'dt_step_trace')
-    try:
-        for j in range(k):             # (all k: the last step of a chain prepares nothing, like the execution's)
-            loop._body(j, chained=True)
-        us = (ctypes.c_float * 4)()
-        cnt = ctypes.c_int(0)
-        check(lib().dt_step_trace_read(ctypes.cast(us, ctypes.c_void_p), 4, ctypes.cast(ctypes.pointer(cnt), ctypes.c_void_p)),
-              'dt_step_trace_read')
-    finally:
-        lib().dt_step_trace(0)
-        loop._slots_per_step = keep
-    torch.cuda.synchronize()
-    a, c, ed, f = (float(v) for v in us)
-    return {'A_sparse_fwd': round(a, 2), 'C_tower': round(c, 2), 'ED_wgrad_rows': round(ed, 2), 'F_finish': round(f, 2),
-            'sum': round(a + c + ed + f, 2), 'steps_traced': int(cnt.value),
-            'note': 'eager chained steps, HIP events between the launches (dt_step_trace); the first traced step of the chain '
-                    'carries the prep launch in A; event records between launches cost each boundary ~1-2 us'}
+    return wall, e0.elapsed_time(evs[-1][0]) / 1e3, stats
 
 
 TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'deepfm_traffic.json')
@@ -623,12 +444,6 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--steps-per-graph', type=int, default=20,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
-    ap.add_argument('--repeats', type=int, default=5,
-                    help='regions of --steps steps timed back to back BEHIND the contract region (`value` is the contract '
-                         'region; `step_us.repeat_step_us` / `steady_rows_per_s` are these)')
-    ap.add_argument('--legacy-warmup', action='store_true',
-                    help="round 5's warm-up (A/B): warm-up steps that do not fill a replay run eagerly, so that with "
-                         "--warmup < steps-per-graph the timed region is the captured graph's first replay")
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (no Adam step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the benchmarked configuration')
@@ -727,23 +542,13 @@ def main():
         # costs what every later one does — it is uploaded at capture time.)
         spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0)
     warm_capture = 2
-    # rows the loop will walk: capture warm-up + the warm-up rounded up to whole replays + the contract region + its repeats
-    # + one execution of traced eager steps (kernel_split)
-    total_steps = warm_capture + (args.warmup + 2 * max(spg, 1)) + args.steps * (1 + max(0, args.repeats)) + max(spg, 1)
     loop = CompiledTrainLoop(dm, feed, args.batch, spg, with_optimizer=not args.no_optimizer, use_graph=not args.no_graph,
                              graph_segments=args.graph_segments,
-                             order_capacity=max(feed.n, total_steps * args.batch))
-    loop.set_order(ring_order(feed, args.batch, total_steps, device))
+                             order_capacity=max(feed.n, (warm_capture + args.warmup + args.steps) * args.batch))
+    loop.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
     loop.capture(warm_steps=warm_capture)
     spg = loop.k if loop.graph is not None else 1
-    wall, ev_s, step_stats = time_steps(loop, args.steps, args.warmup, barrier, device, repeats=max(0, args.repeats),
-                                        warm_through_graph=not args.legacy_warmup, sample_clocks=(rank == 0))
-    split = None
-    if rank == 0 and world == 1 and strategy is None and not args.no_optimizer and not args.no_extras:
-        try:
-            split = kernel_split(loop)
-        except Exception as e:          # diagnostic
-            split = {'error': repr(e)[:200]}
+    wall, ev_s, step_stats = time_steps(loop, args.steps, args.warmup, barrier, device)
     if strategy is not None and hasattr(strategy, 'check_sparse_overflow'):
         strategy.check_sparse_overflow()            # a bucket that dropped entries invalidates the run: fail loudly
     if dm.fused_plan() is not None and hasattr(dm.fused_plan(), 'check_dedupe'):
@@ -775,7 +580,7 @@ def main():
                                       order_capacity=max(feed.n, (warm_capture + args.warmup + args.steps) * args.batch))
             loop2.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
             loop2.capture(warm_steps=warm_capture)
-            w2, _, st2_stats = time_steps(loop2, args.steps, args.warmup, barrier, device)
+            w2, _, st2_stats = time_steps(loop2, args.steps, args.warmup, barrier, device, spin=False)
             t2 = torch.tensor([w2], dtype=torch.float64, device=device)
             if world > 1:
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
@@ -829,11 +634,6 @@ def main():
                          'algorithmic_bytes_per_row': bpr, 'launch_us': step_s * 1e6},
             'step_us': step_stats,
         }
-        if step_stats.get('steady_step_us'):
-            # the repeated regions behind the contract region (same steps, same graph): what `fit` sustains
-            result['steady_rows_per_s'] = args.batch * world / (step_stats['steady_step_us'] * 1e-6)
-        if split is not None:
-            result['kernel_split_us'] = split
         # the arithmetic the timed path computes in: "f32" alone would hide the split-bf16 operand formats
         tflag = getattr(dm.fused_plan(), 'tower_flag', 0)
         if tflag == 0x80:
@@ -909,39 +709,8 @@ def main():
                                            order_capacity=max(feed.n, (2 + spg + args.steps) * args.batch))
                     fb.set_order(ring_order(feed, args.batch, 2 + spg + args.steps, device))
                     fb.capture(warm_steps=2)
-                    w2, _, _ = time_steps(fb, args.steps, spg, barrier, device)
+                    w2, _, _ = time_steps(fb, args.steps, spg, barrier, device, spin=False)
                     result['fwd_bwd_only_rows_per_s'] = args.batch * args.steps / w2
-                    del fb
-                if not args.no_optimizer and strategy is None and args.model in ('DeepFM', 'DCN') and args.tower is None:
-                    # the same command on the two variants the headline is compared with (VERDICT r5 #1d): the unchained step
-                    # (five launches: DT_AMD_CHAIN=0) and the exact-fp32 tower (all products 24-bit: `--tower f32`)
-                    var = {}
-
-                    def timed_variant(model_dm):
-                        lp = CompiledTrainLoop(model_dm, feed, args.batch, spg, use_graph=not args.no_graph,
-                                               order_capacity=max(feed.n, (2 + args.warmup + 2 * spg + 3 * args.steps) * args.batch))
-                        lp.set_order(ring_order(feed, args.batch, 2 + args.warmup + 2 * spg + 3 * args.steps, device))
-                        lp.capture(warm_steps=2)
-                        wv, _, sv = time_steps(lp, args.steps, args.warmup, barrier, device, repeats=2)
-                        return {'rows_per_s': args.batch * args.steps / wv, 'ms_per_step': wv / args.steps * 1e3,
-                                'repeat_step_us': sv.get('repeat_step_us'), 'chained': bool(lp.chained)}
-                    keep_env = os.environ.get('DT_AMD_CHAIN')
-                    os.environ['DT_AMD_CHAIN'] = '0'
-                    try:
-                        var['unchained'] = timed_variant(dm)
-                    finally:
-                        if keep_env is None:
-                            os.environ.pop('DT_AMD_CHAIN', None)
-                        else:
-                            os.environ['DT_AMD_CHAIN'] = keep_env
-                    mp32 = dict(MODEL_PARAMS.get(args.model) or {})
-                    mp32['dnn_params'] = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': 'f32'}
-                    dm32 = build_model(nets, device, None, dim, mp32)
-                    var['tower_f32'] = timed_variant(dm32)
-                    var['tower_f32']['dtype'] = 'f32 (exact fp32 MFMA tower: every product 24-bit, forward and backward)'
-                    del dm32
-                    torch.cuda.empty_cache()
-                    result['variants'] = var
             except Exception as e:   # diagnostics must not kill the contract line
                 result['extras_error'] = repr(e)
         if not args.no_cpu_baseline and world == 1:
