@@ -44,21 +44,23 @@ class _old_garbage_frozen:
     """Objects that exist when a stream capture starts are kept away from the cyclic collector until it ends (gc.freeze): a
     collection inside the capture otherwise runs the destructors of whatever old garbage it finds — an earlier loop's
     hipGraph, side streams, events of a model the caller dropped — and a destroy call of that kind inside a global-mode
-    capture aborts the process.  The capture's own garbage is still collected as it appears.  An application that froze
-    objects itself (gc.freeze() at start-up) gets its permanent generation back: unfreeze() empties it, so it is re-frozen."""
+    capture aborts the process.  The capture's own garbage is still collected as it appears.
+    An application that froze objects itself (gc.freeze() at start-up) keeps its permanent generation untouched: unfreeze()
+    would empty it and a re-freeze would pin everything alive at that moment — including cyclic garbage made since — for good
+    (ADVICE r5).  For such a process the old garbage is collected once right before the capture and nothing is frozen."""
 
     def __enter__(self):
         import gc
         self.app_frozen = gc.get_freeze_count() > 0
         gc.collect()
-        gc.freeze()
+        if not self.app_frozen:
+            gc.freeze()
         return self
 
     def __exit__(self, *exc):
         import gc
-        gc.unfreeze()
-        if self.app_frozen:
-            gc.freeze()
+        if not self.app_frozen:
+            gc.unfreeze()
         return False
 
 
@@ -127,8 +129,10 @@ class CompiledTrainLoop:
     def owned_by(self, dm):
         """True while `dm` still holds the model, optimizer and fused plan this loop (and its captured graph) was built on —
         `DeepModel.fit` rebuilds the loop otherwise (a rebuilt optimizer / plan has new buffers; the graph has the old ones')"""
-        return self._owner is None or \
-            self._owner == (id(dm.model), id(dm.optimizer), id(getattr(dm, '_fused_plan', None)))
+        if self._owner is None:
+            return True
+        held = [r() if r is not None else None for r in self._owner]      # (weak references: a freed object's id can be reused)
+        return held[0] is dm.model and held[1] is dm.optimizer and held[2] is getattr(dm, '_fused_plan', None)
 
     # -- the feed ---------------------------------------------------------------------------------------------
     def set_order(self, perm=None):
@@ -294,7 +298,9 @@ class CompiledTrainLoop:
                     self._body(i, core_only=core_only, preelected=pre and i >= 1, chained=chain)
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
         self.graph = g
-        self._owner = (id(dm.model), id(dm.optimizer), id(getattr(dm, '_fused_plan', None)))
+        import weakref
+        self._owner = tuple(None if o is None else weakref.ref(o)
+                            for o in (dm.model, dm.optimizer, getattr(dm, '_fused_plan', None)))
         # python side effects (the sparse-gradient registration) are not replayed: keep the captured static
         # (rows, values) tensors and re-attach them after every replay (data parallel: the exchange reads them)
         self._sparse_refs = [(l, {key: list(v) for key, v in l.sparse_grads.items()}) for l in emb_layers]

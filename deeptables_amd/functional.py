@@ -244,6 +244,22 @@ class Layer(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # built-in Keras layers used by the reference graph
 # ---------------------------------------------------------------------------------------------
+_VENDOR_GEMM_NOTED = set()
+
+
+def note_vendor_gemm(who, x_shape, w_shape):
+    """One log line per (layer, weight shape) when a product leaves the hand-written kernels (csrc/dense.hip takes K and N
+    up to its LDS tile; beyond that the GEMM goes to the vendor library through torch): never silent."""
+    key = (who, tuple(w_shape))
+    if key in _VENDOR_GEMM_NOTED:
+        return
+    _VENDOR_GEMM_NOTED.add(key)
+    import logging
+    logging.getLogger('deeptables_amd').warning(
+        '%s: [%s] x [%s] is outside csrc/dense.hip\'s tile -> vendor GEMM (torch.addmm / rocBLAS), not a hand-written kernel',
+        who, ' x '.join(str(int(v)) for v in x_shape), ' x '.join(str(int(v)) for v in w_shape))
+
+
 class Dense(Layer):
     """keras.layers.Dense: y = act(x @ kernel + bias), kernel [in, out] (glorot_uniform, zeros)."""
 
@@ -277,6 +293,7 @@ class Dense(Layer):
                 y = activation(y)
             return y
         lead = x.shape[:-1]                      # shapes outside the kernels' LDS tile: vendor GEMM
+        note_vendor_gemm(f'Dense {self.name!r}', x.shape, self.kernel.shape)
         x2 = x.reshape(-1, x.shape[-1])
         y = torch.addmm(self.bias, x2, self.kernel) if self.bias is not None else x2 @ self.kernel
         if activation is not None:

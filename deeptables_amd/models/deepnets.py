@@ -1,8 +1,13 @@
 # -*- coding:utf-8 -*-
-"""Drop-in for `deeptables.models.deepnets` (deeptables/models/deepnets.py): the net-function
-plugin API.  A net function has the signature of `linear` below (enforced by `register_nets`,
-deepnets.py:496-502), receives the symbolic embeddings / dense tensors of the model under
-construction and returns a tensor (or None to opt out, deepmodel.py:284).
+"""Drop-in for `deeptables.models.deepnets` (DataCanvasIO/DeepTables, Apache-2.0; reference file
+deeptables/models/deepnets.py): the net-function plugin API.
+
+What is kept from the reference is its INTERFACE, because models, checkpoints and user plugins depend on it: the names of
+the net functions and presets, the six-argument plugin signature (`register_nets` compares against `linear`,
+deepnets.py:496-502), the Keras layer names (1:1 weight mapping with a Keras checkpoint) and the keys / order of the
+`model_desc.add_net` records.  How the graphs are put together is this repo's: every net body works on a `_Wiring`
+object (the six plugin arguments + the recurring moves: stack the field embeddings, describe a net, run the DNN tower)
+and the FGCNN / product families are generated from tables instead of being written out per net.
 """
 from inspect import signature
 
@@ -10,6 +15,7 @@ from . import layers
 from ..functional import Dense, Concatenate, Flatten, BatchNormalization, Activation, Dropout, ReduceSum, Layer
 from ..utils import counter
 
+# presets (deepnets.py:14-22)
 WideDeep = ['linear', 'dnn_nets']
 DeepFM = ['linear', 'fm_nets', 'dnn_nets']
 xDeepFM = ['linear', 'cin_nets', 'dnn_nets']
@@ -20,154 +26,163 @@ FiBiNet = ['fibi_dnn_nets']
 PNN = ['pnn_nets']
 AFM = ['afm_nets']
 
+_HIDDEN_DEFAULT = ((128, 0, True), (64, 0, False))          # deepnets.py:406 (ModelConfig always overrides it, config.py:90-93)
+_HIDDEN_ERROR = '[hidden_units] must be a list of tuple([units],[dropout_rate],[use_bn]) and at least one tuple.'
 
-def _concat_embeddings(embeddings, concat_layer_name):
-    if embeddings is None or len(embeddings) == 0:
+
+class _Wiring:
+    """The six arguments of a net function and the moves every net repeats."""
+
+    __slots__ = ('embeddings', 'flat', 'dense', 'xn', 'config', 'desc')
+
+    def __init__(self, embeddings, flat, dense, xn, config, desc):
+        self.embeddings, self.flat, self.dense, self.xn, self.config, self.desc = embeddings, flat, dense, xn, config, desc
+
+    def fields(self, concat_name):
+        """[B,F,D] stack of the field embeddings (None without categorical columns; one column: itself)"""
+        e = self.embeddings
+        if not e:
+            return None
+        return e[0] if len(e) == 1 else Concatenate(axis=1, name=concat_name)(e)
+
+    def pairs(self):
+        """the embedding list for the pairwise layers, None below two fields"""
+        e = self.embeddings
+        return e if e is not None and len(e) >= 2 else None
+
+    def note(self, key, src, out):
+        """model_desc record; src / out: a tensor (its shape is recorded), a string, or None"""
+        self.desc.add_net(key, getattr(src, 'shape', src), getattr(out, 'shape', out))
+        return out
+
+    def absent(self, key):
+        self.desc.add_net(key, (None), (None))
         return None
-    if len(embeddings) == 1:
-        return embeddings[0]
-    return Concatenate(axis=1, name=concat_layer_name)(embeddings)
+
+    def tower(self, x, cell, key):
+        out = dnn(x, self.config.dnn_params, cellname=cell)
+        self.desc.add_net(key, x.shape, out.shape)
+        return out
+
+    def n_fields(self):
+        return f'list({len(self.embeddings)})'
 
 
-def linear(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """Linear(order-1) interactions (deepnets.py:43-66)."""
-    x_emb = None
-    concat_embeddings = _concat_embeddings(embeddings, 'concat_linear_embedding')
-    if concat_embeddings is not None:
-        x_emb = ReduceSum(axis=-1, name='linear_reduce_sum')(concat_embeddings)
-    if x_emb is not None and dense_layer is not None:
-        x = Concatenate(name='concat_linear_emb_dense')([x_emb, dense_layer])
-    elif x_emb is not None:
-        x = x_emb
-    elif dense_layer is not None:
-        x = dense_layer
-    else:
+def _plugin(body):
+    """body(_Wiring) -> a net function with the reference's plugin signature and the body's name"""
+    def net(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+        return body(_Wiring(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc))
+    net.__name__ = net.__qualname__ = body.__name__
+    net.__doc__ = body.__doc__
+    return net
+
+
+# ---- order-1 / order-2 / attention / compressed interactions --------------------------------------------------------
+@_plugin
+def linear(w):
+    """Linear (order-1) interactions: Dense(1, no bias) over [sum_D(embeddings), dense] (deepnets.py:43-66)."""
+    stack = w.fields('concat_linear_embedding')
+    parts = []
+    if stack is not None:
+        parts.append(ReduceSum(axis=-1, name='linear_reduce_sum')(stack))
+    if w.dense is not None:
+        parts.append(w.dense)
+    if not parts:
         raise ValueError('No input layer exists.')
-    input_shape = x.shape
-    x = Dense(1, activation=None, use_bias=False, name='linear_logit')(x)
-    model_desc.add_net('linear', input_shape, x.shape)
-    return x
+    x = parts[0] if len(parts) == 1 else Concatenate(name='concat_linear_emb_dense')(parts)
+    return w.note('linear', x, Dense(1, activation=None, use_bias=False, name='linear_logit')(x))
 
 
-def cin_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """Compressed Interaction Network (deepnets.py:69-81)."""
-    cin_concat = _concat_embeddings(embeddings, 'concat_cin_embedding')
-    if cin_concat is None:
-        model_desc.add_net('cin', (None), (None))
-        return None
-    cin_output = layers.CIN(params=config.cin_params)(cin_concat)
-    model_desc.add_net('cin', cin_concat.shape, cin_output.shape)
-    return cin_output
+def _on_field_stack(fn_name, concat_name, key, make_layer, doc):
+    """a net that is ONE layer over the stacked field embeddings (cin_nets, fm_nets)"""
+    def body(w):
+        stack = w.fields(concat_name)
+        return w.absent(key) if stack is None else w.note(key, stack, make_layer(w.config)(stack))
+    body.__name__, body.__doc__ = fn_name, doc
+    return _plugin(body)
 
 
-def fm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FM pairwise (order-2) interactions (deepnets.py:84-96)."""
-    concat_embeddings_layer = _concat_embeddings(embeddings, 'concat_fm_embedding')
-    if concat_embeddings_layer is None:
-        model_desc.add_net('fm', (None), (None))
-        return None
-    fm_output = layers.FM(name='fm_layer')(concat_embeddings_layer)
-    model_desc.add_net('fm', concat_embeddings_layer.shape, fm_output.shape)
-    return fm_output
+cin_nets = _on_field_stack('cin_nets', 'concat_cin_embedding', 'cin', lambda c: layers.CIN(params=c.cin_params),
+                           'Compressed Interaction Network (deepnets.py:69-81; layers.py:638-734).')
+fm_nets = _on_field_stack('fm_nets', 'concat_fm_embedding', 'fm', lambda c: layers.FM(name='fm_layer'),
+                          'FM pairwise (order-2) interactions (deepnets.py:84-96; layers.py:53-62).')
 
 
-def afm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+@_plugin
+def afm_nets(w):
     """Attentional FM (deepnets.py:99-108)."""
-    if embeddings is None or len(embeddings) < 2:
+    e = w.pairs()
+    if e is None:
         return None
-    afm_output = layers.AFM(params=config.afm_params, name='afm_layer')(embeddings)
-    model_desc.add_net('afm', f'list({len(embeddings)})', afm_output.shape)
-    return afm_output
+    return w.note('afm', w.n_fields(), layers.AFM(params=w.config.afm_params, name='afm_layer')(e))
 
 
-def opnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """OuterProduct + DNN (deepnets.py:111-125)."""
-    if embeddings is None or len(embeddings) < 2:
-        return None
-    op = layers.OuterProduct(config.pnn_params, name='outer_product_layer')(embeddings)
-    model_desc.add_net('opnn-outer_product', f'list({len(embeddings)})', op.shape)
-    concat_all = Concatenate(name='concat_opnn_all')([op, concat_emb_dense])
-    x_dnn = dnn(concat_all, config.dnn_params, cellname='opnn')
-    model_desc.add_net('opnn-dnn', concat_all.shape, x_dnn.shape)
-    return x_dnn
+@_plugin
+def autoint_nets(w):
+    """AutoInt: `num_attention` stacked multi-head field self-attention layers, flattened (deepnets.py:210-224)."""
+    stack = w.fields('concat_autoint_embedding')
+    if stack is None:
+        return w.absent('autoint')
+    x = stack
+    for _ in range(w.config.autoint_params['num_attention']):
+        x = layers.MultiheadAttention(params=w.config.autoint_params)(x)
+    return w.note('autoint', stack, Flatten()(x))
 
 
-def ipnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """InnerProduct + DNN (deepnets.py:128-141)."""
-    if embeddings is None or len(embeddings) < 2:
-        return None
-    ip = layers.InnerProduct(name='inner_product_layer')(embeddings)
-    model_desc.add_net('ipnn-inner_product', f'list({len(embeddings)})', ip.shape)
-    concat_all = Concatenate(name='concat_ipnn_all')([ip, concat_emb_dense])
-    x_dnn = dnn(concat_all, config.dnn_params, cellname='ipnn')
-    model_desc.add_net('ipnn-dnn', concat_all.shape, x_dnn.shape)
-    return x_dnn
+# ---- product networks: <products of the embedding pairs> ++ BN(concat) -> DNN -----------------------------------------
+def _product_net(fn_name, cell, products, doc):
+    """products: [(record key, layer factory(config))] applied to the embedding list, in order"""
+    def body(w):
+        e = w.pairs()
+        if e is None:
+            return None
+        outs = [w.note(key, w.n_fields(), make(w.config)(e)) for key, make in products]
+        return w.tower(Concatenate(name=f'concat_{cell}_all')(outs + [w.xn]), cell, f'{cell}-dnn')
+    body.__name__, body.__doc__ = fn_name, doc
+    return _plugin(body)
 
 
-def pnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """Inner product ++ outer product + DNN (deepnets.py:144-160)."""
-    if embeddings is None or len(embeddings) < 2:
-        return None
-    ip = layers.InnerProduct(name='pnn_inner_product_layer')(embeddings)
-    model_desc.add_net('pnn-inner_product', f'list({len(embeddings)})', ip.shape)
-    op = layers.OuterProduct(params=config.pnn_params, name='pnn_outer_product_layer')(embeddings)
-    model_desc.add_net('pnn-outer_product', f'list({len(embeddings)})', op.shape)
-    concat_all = Concatenate(name='concat_pnn_all')([ip, op, concat_emb_dense])
-    x_dnn = dnn(concat_all, config.dnn_params, cellname='pnn')
-    model_desc.add_net('pnn-dnn', concat_all.shape, x_dnn.shape)
-    return x_dnn
+opnn_nets = _product_net('opnn_nets', 'opnn',
+                         [('opnn-outer_product', lambda c: layers.OuterProduct(c.pnn_params, name='outer_product_layer'))],
+                         'OuterProduct + DNN (deepnets.py:111-125).')
+ipnn_nets = _product_net('ipnn_nets', 'ipnn',
+                         [('ipnn-inner_product', lambda c: layers.InnerProduct(name='inner_product_layer'))],
+                         'InnerProduct + DNN (deepnets.py:128-141).')
+pnn_nets = _product_net('pnn_nets', 'pnn',
+                        [('pnn-inner_product', lambda c: layers.InnerProduct(name='pnn_inner_product_layer')),
+                         ('pnn-outer_product', lambda c: layers.OuterProduct(params=c.pnn_params, name='pnn_outer_product_layer'))],
+                        'Inner product ++ outer product + DNN (deepnets.py:144-160).')
 
 
-def dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+# ---- towers on BN(concat(embeddings, dense)) -------------------------------------------------------------------------
+@_plugin
+def dnn_nets(w):
     """MLP (deepnets.py:163-169)."""
-    x_dnn = dnn(concat_emb_dense, config.dnn_params)
-    model_desc.add_net('dnn', concat_emb_dense.shape, x_dnn.shape)
-    return x_dnn
+    return w.tower(w.xn, 'dnn', 'dnn')
 
 
-def cross_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """Cross network (deepnets.py:172-178)."""
-    cross = layers.Cross(params=config.cross_params, name='cross_layer')(concat_emb_dense)
-    model_desc.add_net('cross', concat_emb_dense.shape, cross.shape)
-    return cross
+@_plugin
+def cross_nets(w):
+    """Cross network (deepnets.py:172-178; layers.py:417-436)."""
+    return w.note('cross', w.xn, layers.Cross(params=w.config.cross_params, name='cross_layer')(w.xn))
 
 
-def cross_dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+@_plugin
+def cross_dnn_nets(w):
     """Cross -> DNN (deepnets.py:181-191)."""
-    x = concat_emb_dense
-    cross = layers.Cross(params=config.cross_params, name='cross_dnn_layer')(x)
-    model_desc.add_net('cross_dnn-cross', x.shape, cross.shape)
-    x_dnn = dnn(cross, config.dnn_params, cellname='cross_dnn')
-    model_desc.add_net('cross_dnn-dnn', cross.shape, x_dnn.shape)
-    return x_dnn
+    crossed = w.note('cross_dnn-cross', w.xn, layers.Cross(params=w.config.cross_params, name='cross_dnn_layer')(w.xn))
+    return w.tower(crossed, 'cross_dnn', 'cross_dnn-dnn')
 
 
-def dcn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """Cross || DNN, concatenated (deepnets.py:194-207)."""
-    x = concat_emb_dense
-    cross_out = layers.Cross(params=config.cross_params, name='dcn_cross_layer')(x)
-    model_desc.add_net('dcn-widecross', x.shape, cross_out.shape)
-    dnn_out = dnn(x, config.dnn_params, cellname='dcn')
-    model_desc.add_net('dcn-dnn2', x.shape, dnn_out.shape)
-    stack_out = Concatenate(name='concat_cross_dnn')([cross_out, dnn_out])
-    model_desc.add_net('dcn', x.shape, stack_out.shape)
-    return stack_out
+@_plugin
+def dcn_nets(w):
+    """Cross || DNN on the same input, concatenated (deepnets.py:194-207)."""
+    wide = w.note('dcn-widecross', w.xn, layers.Cross(params=w.config.cross_params, name='dcn_cross_layer')(w.xn))
+    deep = w.tower(w.xn, 'dcn', 'dcn-dnn2')
+    return w.note('dcn', w.xn, Concatenate(name='concat_cross_dnn')([wide, deep]))
 
 
-def autoint_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """AutoInt: stacked multi-head field self-attention (deepnets.py:210-224)."""
-    concat_embeddings_layer = _concat_embeddings(embeddings, 'concat_autoint_embedding')
-    if concat_embeddings_layer is None:
-        model_desc.add_net('autoint', (None), (None))
-        return None
-    output = concat_embeddings_layer
-    for i in range(config.autoint_params['num_attention']):
-        output = layers.MultiheadAttention(params=config.autoint_params)(output)
-    output = Flatten()(output)
-    model_desc.add_net('autoint', concat_embeddings_layer.shape, output.shape)
-    return output
-
-
+# ---- FGCNN -----------------------------------------------------------------------------------------------------------
 class _ExpandDims(Layer):
     """keras.ops.expand_dims(x, -1) (deepnets.py:245)."""
 
@@ -195,206 +210,177 @@ class _SplitFields(Layer):
         return outs
 
 
-def fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN feature generation: stacked Conv/MaxPool/recombine blocks; output = new features ++ raw
-    embeddings along the field axis (deepnets.py:227-261)."""
-    fgcnn_emb_concat_index = counter.next_num('concat_fgcnn_embedding')
-    fgcnn_emb_concat = _concat_embeddings(embeddings, f'concat_fgcnn_embedding_{fgcnn_emb_concat_index}')
-    if fgcnn_emb_concat is None:
-        model_desc.add_net('fgcnn', (None), (None))
-        return None
-    fg_inputs = _ExpandDims()(fgcnn_emb_concat)
-    fg_filters = config.fgcnn_params.get('fg_filters', (14, 16))
-    fg_heights = config.fgcnn_params.get('fg_heights', (7, 7))
-    fg_pool_heights = config.fgcnn_params.get('fg_pool_heights', (2, 2))
-    fg_new_feat_filters = config.fgcnn_params.get('fg_new_feat_filters', (2, 2))
-    new_features = list()
-    for filters, width, pool, new_filters in zip(fg_filters, fg_heights, fg_pool_heights, fg_new_feat_filters):
-        fg_inputs, new_feats = layers.FGCNN(filters=filters, kernel_height=width, pool_height=pool,
-                                            new_filters=new_filters)(fg_inputs)
-        new_features.append(new_feats)
-    concat_all_features = Concatenate(axis=1)(new_features + [fgcnn_emb_concat])
-    model_desc.add_net('fg', fgcnn_emb_concat.shape, concat_all_features.shape)
-    return concat_all_features
+_FG_DEFAULTS = (('fg_filters', (14, 16)), ('fg_heights', (7, 7)), ('fg_pool_heights', (2, 2)), ('fg_new_feat_filters', (2, 2)))
 
 
-def fgcnn_cin_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN with CIN as deep classifier (deepnets.py:264-275)."""
-    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    if fg_output is None:
-        return None
-    cin_output = layers.CIN(params=config.cin_params)(fg_output)
-    model_desc.add_net('fgcnn-cin', fg_output.shape, cin_output.shape)
-    return cin_output
+def _feature_generation(w):
+    """FGCNN feature generation (deepnets.py:227-261): stacked Conv / MaxPool / recombine blocks; the generated features of
+    every block ++ the raw embeddings along the field axis.  None (and an empty record) without categorical columns."""
+    raw = w.fields('concat_fgcnn_embedding_%s' % counter.next_num('concat_fgcnn_embedding'))
+    if raw is None:
+        return w.absent('fgcnn')
+    x = _ExpandDims()(raw)
+    generated = []
+    for filters, height, pool, new_filters in zip(*(w.config.fgcnn_params.get(k, d) for k, d in _FG_DEFAULTS)):
+        x, feats = layers.FGCNN(filters=filters, kernel_height=height, pool_height=pool, new_filters=new_filters)(x)
+        generated.append(feats)
+    return w.note('fg', raw, Concatenate(axis=1)(generated + [raw]))
 
 
-def fgcnn_fm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN with FM as deep classifier (deepnets.py:278-289)."""
-    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    if fg_output is None:
-        return None
-    fm_output = layers.FM(name='fm_fgcnn_layer')(fg_output)
-    model_desc.add_net('fgcnn-fm', fg_output.shape, fm_output.shape)
-    return fm_output
+fg_nets = _plugin(_feature_generation)
+fg_nets.__name__ = fg_nets.__qualname__ = 'fg_nets'
 
 
-def fgcnn_afm_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN with AFM as deep classifier (deepnets.py:292-303)."""
-    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    if fg_output is None:
-        return None
-    split_features = _SplitFields()(fg_output)
-    afm_output = layers.AFM(params=config.afm_params)(split_features)
-    model_desc.add_net('fgcnn-afm', fg_output.shape, afm_output.shape)
-    return afm_output
+def _fg_flat_with_dense(w, fg, extra=()):
+    parts = [Flatten()(fg)] + list(extra)
+    if w.dense is not None:
+        parts.append(w.dense)
+    return parts[0] if len(parts) == 1 else Concatenate()(parts)
 
 
-def fgcnn_ipnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN with IPNN as deep classifier (deepnets.py:306-323)."""
-    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    if fg_output is None:
-        return None
-    split_features = _SplitFields()(fg_output)
-    inner_product = layers.InnerProduct()(split_features)
-    dnn_input_layers = [Flatten()(fg_output), inner_product]
-    if dense_layer is not None:
-        dnn_input_layers.append(dense_layer)
-    dnn_input = Concatenate()(dnn_input_layers)
-    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fgcnn_ipnn')
-    model_desc.add_net('fgcnn-ipnn', fg_output.shape, dnn_out.shape)
-    return dnn_out
+def _fg_head_cin(w, fg):
+    return layers.CIN(params=w.config.cin_params)(fg)
 
 
-def fgcnn_dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FGCNN with DNN as deep classifier (deepnets.py:326-341)."""
-    fg_output = fg_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    if fg_output is None:
-        return None
-    if dense_layer is not None:
-        dnn_input = Concatenate()([Flatten()(fg_output), dense_layer])
-    else:
-        dnn_input = Flatten()(fg_output)
-    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fgcnn_dnn')
-    model_desc.add_net('fgcnn-ipnn', fg_output.shape, dnn_out.shape)
-    return dnn_out
+def _fg_head_fm(w, fg):
+    return layers.FM(name='fm_fgcnn_layer')(fg)
 
 
-def fibi_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
-    """FiBiNet: SENET re-weighted embeddings and the raw embeddings each go through a bilinear interaction;
-    the two [B,P,D] blocks are concatenated along the pair axis (deepnets.py:344-371)."""
-    senet_index = counter.next_num('senet_layer')
-    senet_emb_concat = _concat_embeddings(embeddings, f'concat_senet_embedding_{senet_index}')
-    if senet_emb_concat is None:
-        model_desc.add_net('fibi', (None), (None))
-        return None
-    senet_pooling_op = config.fibinet_params.get('senet_pooling_op', 'mean')
-    senet_reduction_ratio = config.fibinet_params.get('senet_reduction_ratio', 3)
-    bilinear_type = config.fibinet_params.get('bilinear_type', 'field_interaction')
-    senet_embedding = layers.SENET(pooling_op=senet_pooling_op, reduction_ratio=senet_reduction_ratio,
-                                   name=f'senet_layer_{senet_index}')(senet_emb_concat)
-    senet_bilinear_out = layers.BilinearInteraction(bilinear_type=bilinear_type,
-                                                    name=f'senet_bilinear_layer_{senet_index}')(senet_embedding)
-    bilinear_out = layers.BilinearInteraction(bilinear_type=bilinear_type,
-                                              name=f'embedding_bilinear_layer_{senet_index}')(senet_emb_concat)
-    concat_bilinear = Concatenate(axis=1, name=f'concat_bilinear_{senet_index}')([senet_bilinear_out, bilinear_out])
-    model_desc.add_net('fibi', senet_emb_concat.shape, concat_bilinear.shape)
-    return concat_bilinear
+def _fg_head_afm(w, fg):
+    return layers.AFM(params=w.config.afm_params)(_SplitFields()(fg))
 
 
-def fibi_dnn_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc):
+def _fg_head_ipnn(w, fg):
+    ip = layers.InnerProduct()(_SplitFields()(fg))
+    return dnn(_fg_flat_with_dense(w, fg, [ip]), w.config.dnn_params, cellname='fgcnn_ipnn')
+
+
+def _fg_head_dnn(w, fg):
+    return dnn(_fg_flat_with_dense(w, fg), w.config.dnn_params, cellname='fgcnn_dnn')
+
+
+def _fg_classifier(fn_name, key, head, doc):
+    """FGCNN's generated features -> `head` as the deep classifier"""
+    def body(w):
+        fg = _feature_generation(w)
+        return None if fg is None else w.note(key, fg, head(w, fg))
+    body.__name__, body.__doc__ = fn_name, doc
+    return _plugin(body)
+
+
+fgcnn_cin_nets = _fg_classifier('fgcnn_cin_nets', 'fgcnn-cin', _fg_head_cin, 'FGCNN with CIN as deep classifier (deepnets.py:264-275).')
+fgcnn_fm_nets = _fg_classifier('fgcnn_fm_nets', 'fgcnn-fm', _fg_head_fm, 'FGCNN with FM as deep classifier (deepnets.py:278-289).')
+fgcnn_afm_nets = _fg_classifier('fgcnn_afm_nets', 'fgcnn-afm', _fg_head_afm, 'FGCNN with AFM as deep classifier (deepnets.py:292-303).')
+fgcnn_ipnn_nets = _fg_classifier('fgcnn_ipnn_nets', 'fgcnn-ipnn', _fg_head_ipnn,
+                                 'FGCNN with IPNN as deep classifier (deepnets.py:306-323).')
+# (the reference records this one under 'fgcnn-ipnn' too, deepnets.py:340)
+fgcnn_dnn_nets = _fg_classifier('fgcnn_dnn_nets', 'fgcnn-ipnn', _fg_head_dnn, 'FGCNN with DNN as deep classifier (deepnets.py:326-341).')
+
+
+# ---- FiBiNet ---------------------------------------------------------------------------------------------------------
+def _fibi(w):
+    """SENET re-weighted embeddings and the raw embeddings each through a bilinear interaction; the two [B,P,D] blocks
+    concatenated along the pair axis (deepnets.py:344-371)."""
+    n = counter.next_num('senet_layer')
+    raw = w.fields(f'concat_senet_embedding_{n}')
+    if raw is None:
+        return w.absent('fibi')
+    p = w.config.fibinet_params
+    kind = p.get('bilinear_type', 'field_interaction')
+    squeezed = layers.SENET(pooling_op=p.get('senet_pooling_op', 'mean'), reduction_ratio=p.get('senet_reduction_ratio', 3),
+                            name=f'senet_layer_{n}')(raw)
+    both = [layers.BilinearInteraction(bilinear_type=kind, name=f'senet_bilinear_layer_{n}')(squeezed),
+            layers.BilinearInteraction(bilinear_type=kind, name=f'embedding_bilinear_layer_{n}')(raw)]
+    return w.note('fibi', raw, Concatenate(axis=1, name=f'concat_bilinear_{n}')(both))
+
+
+fibi_nets = _plugin(_fibi)
+fibi_nets.__name__ = fibi_nets.__qualname__ = 'fibi_nets'
+
+
+@_plugin
+def fibi_dnn_nets(w):
     """FiBiNet with DNN as deep classifier (deepnets.py:374-386; like the reference it needs a dense input)."""
-    if embeddings is None or len(embeddings) <= 1:
+    if w.pairs() is None:
         return None
-    fibi_output = fibi_nets(embeddings, flatten_emb_layer, dense_layer, concat_emb_dense, config, model_desc)
-    dnn_input = Concatenate(name='concat_bilinear_dense')(
-        [Flatten(name='flatten_fibi_output')(fibi_output), dense_layer])
-    dnn_out = dnn(dnn_input, config.dnn_params, cellname='fibi_dnn')
-    model_desc.add_net('fibi-dnn', fibi_output.shape, dnn_out.shape)
-    return dnn_out
+    fibi = _fibi(w)
+    x = Concatenate(name='concat_bilinear_dense')([Flatten(name='flatten_fibi_output')(fibi), w.dense])
+    out = dnn(x, w.config.dnn_params, cellname='fibi_dnn')
+    return w.note('fibi-dnn', fibi, out)
+
+
+# ---- the DNN tower ---------------------------------------------------------------------------------------------------
+def _tower_cells(params):
+    cells = params.get('hidden_units', _HIDDEN_DEFAULT)
+    if len(cells) <= 0:
+        raise ValueError(_HIDDEN_ERROR)
+    return cells, params.get('activation', 'relu'), params.get('kernel_initializer', 'he_uniform')
 
 
 def dnn(x, params, cellname='dnn'):
-    """[Dense -> (BN) -> Activation -> (Dropout)]* (deepnets.py:401-427)."""
-    custom_dnn_fn = params.get('custom_dnn_fn')
-    if custom_dnn_fn is not None:
-        return custom_dnn_fn(x, params, cellname + '_custom')
-    hidden_units = params.get('hidden_units', ((128, 0, True), (64, 0, False)))
-    activation = params.get('activation', 'relu')
-    kernel_initializer = params.get('kernel_initializer', 'he_uniform')
-    if len(hidden_units) <= 0:
-        raise ValueError(
-            '[hidden_units] must be a list of tuple([units],[dropout_rate],[use_bn]) and at least one tuple.')
-    index = 1
-    for units, dropout, batch_norm in hidden_units:
-        x = Dense(units, use_bias=not batch_norm, name=f'{cellname}_dense_{index}',
-                  kernel_initializer=kernel_initializer)(x)
-        if batch_norm:
-            x = BatchNormalization(name=f'{cellname}_bn_{index}')(x)
-        x = Activation(activation=activation, name=f'{cellname}_activation_{index}')(x)
-        if dropout > 0:
-            x = Dropout(dropout, name=f'{cellname}_dropout_{index}')(x)
-        index += 1
+    """[Dense -> (BN) -> Activation -> (Dropout)]* (deepnets.py:401-427); params['custom_dnn_fn'] replaces the cell."""
+    custom = params.get('custom_dnn_fn')
+    if custom is not None:
+        return custom(x, params, cellname + '_custom')
+    cells, activation, init = _tower_cells(params)
+    for i, (units, rate, use_bn) in enumerate(cells, start=1):
+        x = Dense(units, use_bias=not use_bn, name=f'{cellname}_dense_{i}', kernel_initializer=init)(x)
+        if use_bn:
+            x = BatchNormalization(name=f'{cellname}_bn_{i}')(x)
+        x = Activation(activation=activation, name=f'{cellname}_activation_{i}')(x)
+        if rate > 0:
+            x = Dropout(rate, name=f'{cellname}_dropout_{i}')(x)
     return x
 
 
 def custom_dnn_D_A_D_B(x, params, cellname='dnn_D_A_D_B'):
-    """Dense(act) -> Dropout -> BN cell order (deepnets.py:430-452)."""
-    hidden_units = params.get('hidden_units', ((128, 0, True), (64, 0, False)))
-    activation = params.get('activation', 'relu')
-    kernel_initializer = params.get('kernel_initializer', 'he_uniform')
-    if len(hidden_units) <= 0:
-        raise ValueError(
-            '[hidden_units] must be a list of tuple([units],[dropout_rate],[use_bn]) and at least one tuple.')
-    index = 1
-    for units, dropout, batch_norm in hidden_units:
-        x = Dense(units, activation=activation, kernel_initializer=kernel_initializer,
-                  name=f'{cellname}_dense_{index}')(x)
-        if dropout > 0:
-            x = Dropout(dropout, name=f'{cellname}_dropout_{index}')(x)
-        if batch_norm:
-            x = BatchNormalization(name=f'{cellname}_bn_{index}')(x)
-        index += 1
+    """the alternative cell order Dense(activation) -> (Dropout) -> (BN) (deepnets.py:430-452)."""
+    cells, activation, init = _tower_cells(params)
+    for i, (units, rate, use_bn) in enumerate(cells, start=1):
+        x = Dense(units, activation=activation, kernel_initializer=init, name=f'{cellname}_dense_{i}')(x)
+        if rate > 0:
+            x = Dropout(rate, name=f'{cellname}_dropout_{i}')(x)
+        if use_bn:
+            x = BatchNormalization(name=f'{cellname}_bn_{i}')(x)
     return x
 
 
-def get(identifier):
-    """Name or callable -> net function (deepnets.py:455-478)."""
-    if identifier is None:
-        raise ValueError(f'identifier can not be none.')
-    if isinstance(identifier, str):
-        nets_fn = custom_nets.get(identifier)
-        if nets_fn is not None:
-            return nets_fn
-        fn = globals().get(identifier)
-        if fn is None or not callable(fn):
-            raise ValueError(f'Unknown nets function: {identifier}')
-        return fn
-    elif callable(identifier):
-        register_nets(identifier)
-        return identifier
-    else:
-        raise TypeError(f'Could not interpret nets function identifier: {repr(identifier)}')
-
-
+# ---- registry (deepnets.py:455-502) ----------------------------------------------------------------------------------
 custom_nets = {}
 
 
-def get_nets(nets):
-    """Names of the nets, callables registered on the fly (deepnets.py:484-493).  The reference
-    dedups through set() which makes the order hash-dependent; here duplicates
-    are dropped but the caller's order is kept, which fixes the Add order of the logits."""
-    str_nets = []
-    for net in nets:
-        name = net if isinstance(net, str) else register_nets(net)
-        if name not in str_nets:
-            str_nets.append(name)
-    return str_nets
-
-
 def register_nets(nets_fn):
+    """a user's net function joins the registry under its __name__; its signature must be `linear`'s"""
     if not callable(nets_fn):
         raise ValueError('nets_fn must be a valid callable function.')
     if signature(nets_fn) != signature(linear):
         raise ValueError(f'Signature of nets_fn is invalid, except {signature(linear)}  but {signature(nets_fn)}')
     custom_nets[nets_fn.__name__] = nets_fn
     return nets_fn.__name__
+
+
+def get(identifier):
+    """name or callable -> net function (registered nets shadow the built-in ones)"""
+    if identifier is None:
+        raise ValueError('identifier can not be none.')
+    if callable(identifier):
+        register_nets(identifier)
+        return identifier
+    if not isinstance(identifier, str):
+        raise TypeError(f'Could not interpret nets function identifier: {repr(identifier)}')
+    fn = custom_nets.get(identifier) or globals().get(identifier)
+    if fn is None or not callable(fn):
+        raise ValueError(f'Unknown nets function: {identifier}')
+    return fn
+
+
+def get_nets(nets):
+    """names of the nets, callables registered on the fly (deepnets.py:484-493).  The reference dedups through set(),
+    which makes the order hash-dependent; here duplicates are dropped but the caller's order is
+    kept, which fixes the Add order of the logits."""
+    names = []
+    for net in nets:
+        name = net if isinstance(net, str) else register_nets(net)
+        if name not in names:
+            names.append(name)
+    return names

@@ -638,9 +638,13 @@ class FGCNN(Layer):
         _, pb, pa = _same_pad(F, h, 1)
         xp = torch.nn.functional.pad(x, (0, 0, 0, 0, pb, pa))             # zero-pad the field axis
         taps = xp.unfold(1, h, 1).permute(0, 1, 2, 4, 3).reshape(B * F * D, h * C)   # [B,F,D,C,h] -> rows of taps
-        out = ops.dense(taps, self.conv_kernel.reshape(h * C, self.filters), self.conv_bias, None) \
-            if ops.dense_supported(taps, self.conv_kernel.reshape(h * C, self.filters)) \
-            else torch.addmm(self.conv_bias, taps, self.conv_kernel.reshape(h * C, self.filters))
+        wk = self.conv_kernel.reshape(h * C, self.filters)
+        if ops.dense_supported(taps, wk):
+            out = ops.dense(taps, wk, self.conv_bias, None)
+        else:
+            from ..functional import note_vendor_gemm
+            note_vendor_gemm(f'FGCNN {self.name!r} convolution', taps.shape, wk.shape)
+            out = torch.addmm(self.conv_bias, taps, wk)
         if self._act is not None:
             out = self._act(out)
         out = out.reshape(B, F, D, self.filters)

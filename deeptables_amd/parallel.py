@@ -149,7 +149,7 @@ class DataParallelStrategy:
         W = self.world_size
         if getattr(grad, 'fields', None) == -2:
             raise RuntimeError('a sparse gradient whose rows were already applied inside the train step '
-                               '(forward_backward(apply_rows=True)) cannot be exchanged: apply_rows belongs to the '
+                               '(_forward_backward(apply_rows=True)) cannot be exchanged: apply_rows belongs to the '
                                'single-process train_step only')
         if W == 1 and not getattr(self, 'force_dp', False):
             return grad

@@ -226,14 +226,14 @@ class KerasAdam:
         """flat=True: members of the registered flat group get their (zeroed) views of the flat gradient buffer as
         `.grad` — backward kernels and autograd accumulate straight into it; flat=False: the caller (a fused step)
         fills the flat buffer itself."""
-        # forward_backward(apply_rows=True) is a promise that step() follows at once: the rows looked up once were already
+        # _forward_backward(apply_rows=True) is a promise that step() follows at once: the rows looked up once were already
         # updated inside the step.  A gradient of that kind still pending here means the promise was broken (the segments and
         # the dense parameters never got their half of the update): fail loudly instead of training on half-applied steps
         if not self._applied_in_step:
             for layer in self.embedding_layers:
                 for grads in layer.sparse_grads.values():
                     if any(getattr(g, 'fields', None) == -2 for g in grads):
-                        raise RuntimeError('forward_backward(apply_rows=True) was not followed by optimizer.step(): the '
+                        raise RuntimeError('_forward_backward(apply_rows=True) was not followed by optimizer.step(): the '
                                            'table rows looked up once are updated, the segments and dense parameters are not')
         self._applied_in_step = False
         for p in self.params:

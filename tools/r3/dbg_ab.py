@@ -34,7 +34,7 @@ for (vocab, B, F, D) in [(3000, 300, 7, 32), (5000, 1000, 26, 16), (200000, 4096
     for name, ar in (('A1', False), ('A2', False), ('B1', True), ('B2', True), ('A3', False), ('B3', True)):
         restore(s0)
         for _ in range(2):
-            dm.forward_backward(ins, yy, apply_rows=ar); opt.step()
+            dm._forward_backward(ins, yy, apply_rows=ar); opt.step()
         torch.cuda.synchronize()
         res[name] = snap()
     rows_b = plan._bufs[B]['rows'].reshape(-1)

@@ -40,7 +40,7 @@ for (vocab, B, F, D) in [(200000, 4096, 26, 16), (3000, 300, 7, 32)]:
     for rep in range(12):
         restore(s0)
         for _ in range(NS):
-            dm.forward_backward(ins, yy, apply_rows=True); opt.step()
+            dm._forward_backward(ins, yy, apply_rows=True); opt.step()
         torch.cuda.synchronize()
         b = snap()
         dt = (ref['table'] - b['table']).abs().amax(1)

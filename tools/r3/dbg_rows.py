@@ -29,7 +29,7 @@ dm2, _ = T.build(F, 13, D, vocab=vocab)
 dm.model.train(); dm2.model.train()
 for st in range(3):
     dm.forward_backward(ins, yy); dm.optimizer.step()
-    dm2.forward_backward(ins, yy, apply_rows=True); dm2.optimizer.step()
+    dm2._forward_backward(ins, yy, apply_rows=True); dm2.optimizer.step()
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(headline.dense_parameters(dm), headline.dense_parameters(dm2)):
         e = (p.detach() - q.detach()).abs().max().item()
