@@ -432,7 +432,8 @@ def parity_leg(args, device):
             b = make_batches(args.batch, device, seed=1234, dist_kind=kind)[0]
             r = headline.check_train_step(dm, b)
             bf16 = 'tower' if args.tower == 'bf16' else \
-                (args.model == 'xDeepFM' and (os.environ.get('DT_AMD_CIN_DTYPE', '') == 'bf16' or args.cin == 'bf16'))
+                ((args.model == 'xDeepFM' and (os.environ.get('DT_AMD_CIN_DTYPE', '') == 'bf16' or args.cin == 'bf16')) or
+                 (args.model == 'AutoInt' and args.attn == 'bf16'))
             good, rule = headline.verdict(r, bf16=bf16)
             ok = ok and good
             rules.add(rule)
@@ -463,7 +464,8 @@ def parity_leg(args, device):
     out['max_abs_logit_err_all'] = max(abs_errs) if abs_errs else None
     # north_star's bar is ABSOLUTE (logits within 1e-4 of the reference, 1e-2 in the bf16 modes); the verdict's rule scales it
     # by max(1, max |logit|) — the builder's reading for graphs whose logits sit far above 1 (DCN: +-160).  Both are stated:
-    out['logits_within_absolute_bar'] = bool(abs_errs) and max(abs_errs) <= (1e-2 if args.tower == 'bf16' or args.cin == 'bf16' else 1e-4)
+    out['logits_within_absolute_bar'] = bool(abs_errs) and \
+        max(abs_errs) <= (1e-2 if 'bf16' in (args.tower, args.cin, getattr(args, 'attn', None)) else 1e-4)
     out['tolerance'] = ('gather bit-exact; logits 1e-4 (north_star; 1e-2 in bf16 mode) of max(1, max |logit|): a 6-layer Cross '
                         'network puts logits far above 1 — `logits_within_absolute_bar` says whether the absolute 1e-4 (1e-2) holds '
                         'as well; gradients: ' + ' / '.join(sorted(rules)) + ' (oracle/headline.verdict); Adam 1e-3 of the step')
@@ -629,6 +631,9 @@ def main():
                          "1e-2 then); default: the library's")
     ap.add_argument('--cin', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help="cin_params['mfma_dtype'] of xDeepFM: exact-fp32 MFMA, split-bf16 (fp32 bars) or plain bf16 (1e-2 bars)")
+    ap.add_argument('--attn', default=None, choices=['f32', 'bf16'],
+                    help="autoint_params['mfma_dtype'] of AutoInt: exact fp32 MFMA or the layer's bf16 mode (projection-shaped "
+                         "products on bf16 MFMA; the line's parity bars are 1e-2 then)")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--steps-per-graph', type=int, default=20,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
@@ -704,6 +709,10 @@ def main():
         mp = dict(MODEL_PARAMS.get(args.model) or {})
         mp['dnn_params'] = {'hidden_units': ((128, 0, False), (64, 0, False)), 'activation': 'relu', 'mfma_dtype': args.tower}
         MODEL_PARAMS[args.model] = mp
+    if args.attn is not None and args.model == 'AutoInt':
+        mp = dict(MODEL_PARAMS['AutoInt'])
+        mp['autoint_params'] = dict(mp['autoint_params'], mfma_dtype={'f32': 'float32'}.get(args.attn, args.attn))
+        MODEL_PARAMS['AutoInt'] = mp
     if args.cin is not None and args.model == 'xDeepFM':
         mp = dict(MODEL_PARAMS['xDeepFM'])
         mp['cin_params'] = dict(mp['cin_params'], mfma_dtype={'f32': 'float32'}.get(args.cin, args.cin))
@@ -728,13 +737,14 @@ def main():
     from deeptables_amd.compiled import CompiledTrainLoop
     feed = make_feed(batches)
     spg = 1
-    if world == 1 and strategy is None and not args.no_graph:
+    if not args.no_graph:        # (data parallel: the loop keeps k only if the whole step — exchange included — captures)
         # k divides the TIMED steps (exactly `steps` steps are timed, all through replays); the warm-up runs through the same
         # loop — whole replays and, when k does not divide it, its last steps eagerly (untimed).  Round 4 also made k divide the
         # warm-up, which put the driver's `--steps 20 --warmup 5` on 5-step graphs: a replay's fixed cost (~10 us of idle GPU)
         # was paid twice as often as in `fit`'s default (then 10, now 20 steps per execution: tools/r5/call21.sh).  (first_replay_us: a graph's first launch
         # costs what every later one does — it is uploaded at capture time.)
         spg = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0)
+    spg_req = spg
     warm_capture = 2
     # rows the loop will walk: capture warm-up + the warm-up rounded up to whole replays + the contract region + its repeats
     # + one execution of traced eager steps (kernel_split)
@@ -780,9 +790,9 @@ def main():
                 st2.force_dp = True
             dm2 = build_model(nets, device, st2, dim, MODEL_PARAMS.get(args.model))
             st2.broadcast_parameters(dm2.model)
-            loop2 = CompiledTrainLoop(dm2, feed, args.batch, 1, use_graph=not args.no_graph,
-                                      order_capacity=max(feed.n, (warm_capture + args.warmup + args.steps) * args.batch))
-            loop2.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + args.steps, device))
+            loop2 = CompiledTrainLoop(dm2, feed, args.batch, spg_req, use_graph=not args.no_graph,
+                                      order_capacity=max(feed.n, (warm_capture + args.warmup + 2 * spg_req + args.steps) * args.batch))
+            loop2.set_order(ring_order(feed, args.batch, warm_capture + args.warmup + 2 * spg_req + args.steps, device))
             loop2.capture(warm_steps=warm_capture)
             w2, _, st2_stats = time_steps(loop2, args.steps, args.warmup, barrier, device)
             t2 = torch.tensor([w2], dtype=torch.float64, device=device)
@@ -790,7 +800,8 @@ def main():
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             other = {'parallelism': f'dp{world}' + ('' if sharded else '+table-rows-sharded'),
                      'rows_per_s': args.batch * args.steps * world / float(t2.item()),
-                     'ms_per_step': float(t2.item()) / args.steps * 1e3, 'step_us': st2_stats, 'phases': loop2.phase_times()}
+                     'ms_per_step': float(t2.item()) / args.steps * 1e3, 'step_us': st2_stats, 'phases': loop2.phase_times(),
+                     'dp_whole_step_graph': bool(getattr(loop2, 'dp_graph', False))}
             del loop2, dm2
             torch.cuda.empty_cache()
         except Exception as e:          # the second layout is a diagnostic: it must not kill the contract line
@@ -818,6 +829,9 @@ def main():
                        # chained steps (deeptables_amd/compiled.py): step i of a replay runs step i + 1's election and weight layouts
                        # inside its own launches — four launches per step from the replay's second step on, five for its first
                        'chained_steps': bool(getattr(loop, 'chained', False)),
+                       # N > 1 structures: k whole steps (fwd + bwd, RCCL exchange, optimizer) in one hipGraph, or round 5's
+                       # [graph: fwd + bwd] -> eager exchange -> [graph: optimizer]
+                       'dp_whole_step_graph': bool(getattr(loop, 'dp_graph', False)) if strategy is not None else None,
                        'merged_launches': bool(getattr(loop, 'merged', False)),
                        'launches_per_step': (('3 (5 for the first step of a replay)' if getattr(loop, 'merged', False) else
                                               {True: '4 (5 for the first step of a replay)', False: '5'}[bool(getattr(loop, 'chained', False))])
@@ -871,6 +885,9 @@ def main():
                                   'flops_per_row': fpr, 'launch_us': step_s * 1e6,
                                   'launch': f'one train step = one hipGraph replay / {spg}; flops = the CIN / attention '
                                             'contractions, fwd + dgrad + wgrad'}
+            if args.model == 'AutoInt' and args.attn == 'bf16':
+                result['dtype'] = 'bf16 (attention layer projections / dX / weight gradient, fp32 accumulate); f32 elsewhere'
+                result['roofline']['mfma_dtype'] = 'bf16 for the projection-shaped products (70 % of the flops), f32 for scores / P V'
             if bf16:
                 result['dtype'] = 'bf16 (CIN contractions, fp32 accumulate); f32 elsewhere'
             elif x3:

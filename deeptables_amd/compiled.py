@@ -86,7 +86,15 @@ class CompiledTrainLoop:
         self.strategy = dm.config.distribute_strategy
         st = self.strategy
         self.dp = st is not None and (st.world_size > 1 or getattr(st, 'force_dp', False) or getattr(st, 'force', False))
-        self.k = 1 if self.dp else max(1, int(steps_per_execution))
+        # Data parallel, round 6: the WHOLE step — forward + backward, the RCCL gradient exchange and the optimizer — of k
+        # consecutive steps in one hipGraph (RCCL's collectives are stream-capturable; every rank captures the same sequence), so
+        # that no Python runs between a step's launches.  Needs the "nccl" backend and fixed per-rank batches (persistent exchange
+        # buffers); DT_AMD_DP_GRAPH=0 or a capture that fails falls back to the round-5 structure ([graph: fwd + bwd] -> eager
+        # exchange -> [graph: optimizer], one step per unit).
+        self.dp_graph = False
+        self._dp_graph_wanted = bool(self.dp and use_graph and os.environ.get('DT_AMD_DP_GRAPH', '1') != '0' and
+                                     self._nccl_backend(st))
+        self.k = max(1, int(steps_per_execution)) if (not self.dp or self._dp_graph_wanted) else 1
         self.device = feed.device
         n = self.k * self.B
         # the epoch's row order lives in a persistent device vector and a device cursor walks it (dt_feed_gather advances it
@@ -125,6 +133,47 @@ class CompiledTrainLoop:
             arr = ctypes.c_void_p * nb
             self._gather_args = (arr(*[t.data_ptr() for t in srcs]), arr(*[t.data_ptr() for t in dsts]),
                                  (ctypes.c_int * nb)(*[t.element_size() * (t.numel() // t.shape[0]) for t in srcs]), nb)
+
+    @staticmethod
+    def _nccl_backend(st):
+        try:
+            import torch.distributed as dist
+            return dist.is_initialized() and dist.get_backend(st.group) == 'nccl'
+        except Exception:
+            return False
+
+    def _dp_step(self, i):
+        """one whole data-parallel train step on slot i: forward + backward, the gradient exchange, the optimizer step"""
+        st, opt = self.strategy, self.dm.optimizer
+        self._body(i)
+        keep_uniform, st.assume_uniform_batches = getattr(st, 'assume_uniform_batches', False), True
+        try:
+            st.exchange_gradients(self.dm.model, opt if self.with_optimizer else None)
+        finally:
+            st.assume_uniform_batches = keep_uniform
+        if self.with_optimizer:
+            opt.step()          # (a pending asynchronous dense all-reduce is joined by the optimizer's pre_dense_hook)
+
+    def _capture_dp_whole(self):
+        """-> a graph of k whole data-parallel steps, or None (the caller falls back to the split structure)"""
+        g = torch.cuda.CUDAGraph()
+        try:
+            with _old_garbage_frozen():
+                with torch.cuda.graph(g):
+                    self._gather()
+                    for i in range(self.k):
+                        self._dp_step(i)
+            torch.cuda.synchronize()
+            return g
+        except Exception as e:          # a stack whose collectives cannot be captured: say so once, keep training
+            import logging
+            logging.getLogger('deeptables_amd').warning('data-parallel step: whole-step capture failed (%r); falling back to '
+                                                        'graph | eager exchange | graph', e)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            return None
 
     def owned_by(self, dm):
         """True while `dm` still holds the model, optimizer and fused plan this loop (and its captured graph) was built on —
@@ -250,6 +299,17 @@ class CompiledTrainLoop:
                 self._eager_steps(1, collect)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self._dp_graph_wanted:
+            g = self._capture_dp_whole()
+            if g is not None:
+                self.graph, self.dp_graph = g, True
+                import weakref
+                self._owner = tuple(None if o is None else weakref.ref(o)
+                                    for o in (dm.model, dm.optimizer, getattr(dm, '_fused_plan', None)))
+                self.uploaded = _hip_graph_upload(g)
+                torch.cuda.synchronize()
+                return warm_steps
+            self.k = 1              # the split structure runs one step per unit
         if not self.use_graph or (self._sharded() and not self.graph_segments):
             return warm_steps
         from .models.layers import MultiColumnEmbedding
@@ -330,6 +390,17 @@ class CompiledTrainLoop:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         g = None if eager else self.graph
+        if g is not None and self.dp_graph:
+            g.replay()              # k whole steps: exchange and optimizer are inside
+            return
+        if self.dp_graph:           # an eager step of a loop whose graph holds whole steps (warm-up remainders)
+            if ev:
+                ev[1].record(); ev[2].record()
+            self._dp_step(0)
+            if ev:
+                ev[3].record()
+                self.phase_events.append(tuple(ev))
+            return
         if g is not None and self._sharded():
             plan = self.dm.fused_plan()
             self._gather()

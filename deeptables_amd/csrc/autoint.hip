@@ -95,19 +95,50 @@ __device__ __forceinline__ void ai_load_x(const float* __restrict__ x, int64_t b
     }
 }
 
+// ---- north_star's "1e-2 bf16" mode of the layer (mfma_mode = DT_AI_BF16; D = 32 only) ------------------------------------
+// The three projection-shaped products of the layer — Y = x Wcat (forward, and its recomputation in the backward), dX = dY
+// Wcat^T and the weight gradient x^T dY — run on v_mfma_f32_16x16x32_bf16 with plain bf16 operands and fp32 accumulation:
+// 70 % of the layer's matrix work at 1/16 of the fp32-MFMA time.  With D = 32 the operand registers the fp32 kernels
+// already hold ARE the 16x16x32 layout: a lane (n, q) owns the 8 contraction indices k = 8 q + t of row / column n — eight
+// floats become one bf16x8 operand, one MFMA replaces eight.  The score / probability products (d_h = 8: two steps of the
+// fp32 MFMA) stay exact fp32, and so do softmax, relu masks and BatchNormalization: results within 1e-2 of the float64
+// oracle (of each tensor's largest entry), tests/test_autoint_gpu.py.
+typedef __bf16 ai_b8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ ai_b8 ai_pack8(const float (&v)[8]) {
+    ai_b8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    return o;
+}
+__device__ __forceinline__ ai_b8 ai_pack8(const ai_f4& a, const ai_f4& b) {
+    ai_b8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
+    return o;
+}
+#define AI_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+
 // Y = relu(x Wcat + b) -> the wave's LDS slab ys[32][YS]   (NP = 3 or 4 projections: q | k | v [| residual])
-template <int D>
+template <int D, bool BF = false>
 __device__ __forceinline__ void ai_project(const float (&xa)[2][D / 4], const float (&wr)[D / 4][D / 4],
                                            const float (&br)[D / 4], int NP, float* ys, int n, int q) {
     constexpr int TK = D / 4, YS = 4 * D + kAiPad;
+    ai_b8 xb0, xb1;
+    if constexpr (BF) { static_assert(D == 32, "bf16 mode: D = 32"); xb0 = ai_pack8(xa[0]); xb1 = ai_pack8(xa[1]); }
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) {                  // 4D / 16 column tiles
         if (ct * 16 >= NP * D) break;
         ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        if constexpr (BF) {
+            const ai_b8 wb = ai_pack8(wr[ct]);
+            AI_MFMA_BF16(c0, xb0, wb);
+            AI_MFMA_BF16(c1, xb1, wb);
+        } else {
 #pragma unroll
         for (int t = 0; t < TK; ++t) {
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][t], wr[ct][t], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][t], wr[ct][t], c1, 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -118,10 +149,12 @@ __device__ __forceinline__ void ai_project(const float (&xa)[2][D / 4], const fl
 }
 
 // the same with the weights read from the block's LDS copy wl[D][WS] (B operand of step t: W[TK q + t][16 ct + n])
-template <int D>
+template <int D, bool BF = false>
 __device__ __forceinline__ void ai_project_lds(const float (&xa)[2][D / 4], const float* wl, int WS,
                                                const float (&br)[D / 4], int NP, float* ys, int n, int q) {
     constexpr int TK = D / 4, YS = 4 * D + kAiPad;
+    ai_b8 xb0, xb1;
+    if constexpr (BF) { static_assert(D == 32, "bf16 mode: D = 32"); xb0 = ai_pack8(xa[0]); xb1 = ai_pack8(xa[1]); }
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) {
         if (ct * 16 >= NP * D) break;
@@ -129,10 +162,16 @@ __device__ __forceinline__ void ai_project_lds(const float (&xa)[2][D / 4], cons
 #pragma unroll
         for (int t = 0; t < TK; ++t) wv[t] = wl[(TK * q + t) * WS + 16 * ct + n];
         ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        if constexpr (BF) {
+            const ai_b8 wb = ai_pack8(wv);
+            AI_MFMA_BF16(c0, xb0, wb);
+            AI_MFMA_BF16(c1, xb1, wb);
+        } else {
 #pragma unroll
         for (int t = 0; t < TK; ++t) {
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][t], wv[t], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][t], wv[t], c1, 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -186,7 +225,7 @@ __device__ __forceinline__ void ai_apply(const ai_f4 (&p)[2][2], const float* ys
     }
 }
 
-template <int D, int DH, bool DROP>
+template <int D, int DH, bool DROP, bool BF = false>
 __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, AiW w4, int B, int F, int NP,
                                                      float* __restrict__ out_a, float* __restrict__ lse_out,
                                                      unsigned drop_thr, float inv_keep, unsigned seed,
@@ -222,7 +261,7 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
     int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
     for (; b < B; b += nwaves) {
-        ai_project<D>(xa, wr, br, NP, ys, n, q);
+        ai_project<D, BF>(xa, wr, br, NP, ys, n, q);
         if (b + nwaves < B) ai_load_x<D>(x, b + nwaves, F, n, q, xa);      // next row's operand while this one is attended
         ai_fence();
 #pragma unroll
@@ -394,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_autoint_bn_apply(const float* __restri
 // field steps per batch row.  The block's eight waves sum their accumulators through the (dead) slabs at the end and leave
 // ONE partial [D*M + M] per block in wpart; dt_autoint_bwd_w's second launch adds the <= 256 partials and writes the four
 // Keras variables' gradients.  dY itself never reaches HBM (pass dY = NULL).
-template <int D, int DH, bool WG, bool DROP>
+template <int D, int DH, bool WG, bool DROP, bool BF = false>
 __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                             const float* __restrict__ g, int B, int F, int NP,
                                             float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
@@ -456,7 +495,7 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
                               av.w > 0.f ? gv.w : 0.f};
             }
         }
-        ai_project_lds<D>(xa, wl, WS, br, NP, ys, n, q);
+        ai_project_lds<D, BF>(xa, wl, WS, br, NP, ys, n, q);
         ai_fence();
         // residual branch: d(pre-activation of R) = dZ * (R > 0), straight to HBM
         unsigned rmask = 0;                                  // relu mask of this lane's R elements, 4 bits per float4
@@ -675,7 +714,30 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
             }
             ai_fence();
         }
-        if (WG) {
+        if (WG && BF) {
+            // bf16 mode: the field index is the contraction index — field(g = q, j) = 4 j + q, j < 7 (the eighth is zero):
+            // the seven fp32 steps' operands of a lane are ONE bf16x8 operand
+            if constexpr (BF) {
+                ai_b8 xa8[D / 16];
+#pragma unroll
+                for (int T = 0; T < D / 16; ++T) {
+                    float v[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) v[s] = s < WSTEPS ? xw[T][s < WSTEPS ? s : 0] : 0.f;
+                    xa8[T] = ai_pack8(v);
+                }
+#pragma unroll
+                for (int ct = 0; ct < WT; ++ct) {
+                    if (16 * ct >= M) break;
+                    float v[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) v[s] = s < WSTEPS ? ys[(4 * (s < WSTEPS ? s : 0) + q) * C::YS + n + 16 * ct] : 0.f;
+                    const ai_b8 dy8 = ai_pack8(v);
+#pragma unroll
+                    for (int T = 0; T < D / 16; ++T) AI_MFMA_BF16(wacc[T][ct], xa8[T], dy8);
+                }
+            }
+        } else if (WG) {
 #pragma unroll
             for (int s = 0; s < WSTEPS; ++s) {
                 const float* yr = ys + (4 * s + q) * C::YS + n;
@@ -704,6 +766,22 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
 #pragma unroll
                 for (int ct = 0; ct < D / 16; ++ct) dx[T][ct] = ai_f4{0.f, 0.f, 0.f, 0.f};
             const int MQ = M / 4;                            // 24 or 32 (D = 32), 12 or 16 (D = 16): multiples of 4
+            if constexpr (BF) {
+                // bf16 mode: eight consecutive m of a lane per step (MQ = 24 or 32: three or four steps)
+                for (int t = 0; t < MQ; t += 8) {
+                    const float* ap = ys + n * C::YS + MQ * q + t;
+                    const ai_b8 a0 = ai_pack8(*reinterpret_cast<const ai_f4*>(ap), *reinterpret_cast<const ai_f4*>(ap + 4));
+                    const ai_b8 a1 = ai_pack8(*reinterpret_cast<const ai_f4*>(ap + 16 * C::YS),
+                                              *reinterpret_cast<const ai_f4*>(ap + 16 * C::YS + 4));
+#pragma unroll
+                    for (int ct = 0; ct < D / 16; ++ct) {
+                        const float* wp = wl + (16 * ct + n) * WS + MQ * q + t;
+                        const ai_b8 w8 = ai_pack8(*reinterpret_cast<const ai_f4*>(wp), *reinterpret_cast<const ai_f4*>(wp + 4));
+                        AI_MFMA_BF16(dx[0][ct], a0, w8);
+                        AI_MFMA_BF16(dx[1][ct], a1, w8);
+                    }
+                }
+            } else
             for (int t = 0; t < MQ; t += 4) {
                 const ai_f4 a0 = *reinterpret_cast<const ai_f4*>(ys + n * C::YS + MQ * q + t);
                 const ai_f4 a1 = *reinterpret_cast<const ai_f4*>(ys + (16 + n) * C::YS + MQ * q + t);
@@ -773,19 +851,19 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
     }
 }
 
-template <int D, int DH, bool DROP>
+template <int D, int DH, bool DROP, bool BF = false>
 __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                      const float* __restrict__ g, int B, int F, int NP,
                                                      float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
                                                      unsigned drop_thr, float inv_keep, unsigned seed) {
-    ai_bwd_body<D, DH, false, DROP>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr);
+    ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr);
 }
-template <int D, int DH, bool DROP>
+template <int D, int DH, bool DROP, bool BF = false>
 __global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                        const float* __restrict__ g, int B, int F, int NP,
                                                        float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
                                                        unsigned seed, float* __restrict__ wpart) {
-    ai_bwd_body<D, DH, true, DROP>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart);
+    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart);
 }
 
 // sum of the per-block partials -> the gradients of the NP Keras kernels [NP][D][D] (gW[p][k][j] = dWc[k][p D + j]) and
@@ -848,13 +926,25 @@ extern "C" unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned 
             hipLaunchKernelGGL((KERNEL<DV, HV, false>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);            \
         }                                                                                                                  \
     } while (0)
+#define DT_AI_LAUNCH_BF(KERNEL, DV, HV, WAVES, ...)                                                                        \
+    do {                                                                                                                   \
+        if (thr) {                                                                                                         \
+            hipFuncSetAttribute((const void*)KERNEL<DV, HV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+            hipLaunchKernelGGL((KERNEL<DV, HV, true, true>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);       \
+        } else {                                                                                                           \
+            hipFuncSetAttribute((const void*)KERNEL<DV, HV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((KERNEL<DV, HV, false, true>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);      \
+        }                                                                                                                  \
+    } while (0)
 #define DT_AI_DISPATCH(KERNEL, WAVES, LDS_FLOATS, ...)                                                             \
     do {                                                                                                           \
         const int dh = D / H;                                                                                      \
         int blocks = (int)((B + (WAVES) - 1) / (WAVES));                                                           \
         if (blocks > 2048 / (WAVES)) blocks = 2048 / (WAVES);                                                      \
         const size_t lds = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
-        if (D == 32 && dh == 8) DT_AI_LAUNCH(KERNEL, 32, 8, WAVES, __VA_ARGS__);                                   \
+        if (mfma_mode == DT_AI_BF16 && D == 32 && dh == 8) DT_AI_LAUNCH_BF(KERNEL, 32, 8, WAVES, __VA_ARGS__);     \
+        else if (mfma_mode == DT_AI_BF16 && D == 32 && dh == 16) DT_AI_LAUNCH_BF(KERNEL, 32, 16, WAVES, __VA_ARGS__); \
+        else if (D == 32 && dh == 8) DT_AI_LAUNCH(KERNEL, 32, 8, WAVES, __VA_ARGS__);                              \
         else if (D == 32 && dh == 16) DT_AI_LAUNCH(KERNEL, 32, 16, WAVES, __VA_ARGS__);                            \
         else if (D == 16 && dh == 4) DT_AI_LAUNCH(KERNEL, 16, 4, WAVES, __VA_ARGS__);                              \
         else if (D == 16 && dh == 8) DT_AI_LAUNCH(KERNEL, 16, 8, WAVES, __VA_ARGS__);                              \
@@ -883,7 +973,8 @@ static bool ai_weights(const float* const* W, const float* const* b, int NP, AiW
 
 extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
                               const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
-                              int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream) {
+                              int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, int mfma_mode, void* stream) {
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_fwd: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && out_a && B > 0 && B < (1LL << 31), "dt_autoint_fwd: null pointer / bad batch");
@@ -904,7 +995,8 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
                               const float* bq, const float* bk, const float* bv, const float* br, const float* a,
                               const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                               const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
-                              float* dY, float* dX, void* stream) {
+                              float* dY, float* dX, int mfma_mode, void* stream) {
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_bwd: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && a && g && B > 0 && B < (1LL << 31), "dt_autoint_bwd: null pointer / bad batch");
@@ -937,7 +1029,8 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
                                 const float* bq, const float* bk, const float* bv, const float* br, const float* a,
                                 const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                                 const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
-                                float* dX, float* gW, float* gb, void* workspace, void* stream) {
+                                float* dX, float* gW, float* gb, void* workspace, int mfma_mode, void* stream) {
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
     DT_REQUIRE(gW && gb && workspace, "dt_autoint_bwd_w: null gradient / workspace pointer");
@@ -984,7 +1077,8 @@ extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* W
                                  const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
                                  int D, int H, float dropout_rate, unsigned seed, const float* gamma, const float* beta,
                                  float eps, float momentum, float* moving_mean, float* moving_var, float* out_a,
-                                 float* out_y, float* save_mean, float* save_rstd, void* workspace, void* stream) {
+                                 float* out_y, float* save_mean, float* save_rstd, void* workspace, int mfma_mode, void* stream) {
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_fwd_bn: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd_bn: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_REQUIRE(x && out_a && out_y && save_mean && save_rstd && workspace && B > 0 && B < (1LL << 31),
                "dt_autoint_fwd_bn: null pointer / bad batch");

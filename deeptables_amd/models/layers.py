@@ -86,11 +86,13 @@ class MultiheadAttention(Layer):
             # four Dense layers' variables are passed as they are (no concatenated copy, no gradient split)
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rate > 0 else 0
             bnl = self.batch_normalize
+            md = self.params.get('mfma_dtype')      # 'bf16': the layer's 1e-2 mode (ops.autoint_layer)
             if self.training:        # BN with batch statistics rides along: its backward is folded into the layer's
                 return ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
                                          batch_norm=(bnl.gamma, bnl.beta, bnl.moving_mean, bnl.moving_variance,
-                                                     bnl.epsilon, bnl.momentum))
-            outputs = ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed)
+                                                     bnl.epsilon, bnl.momentum), mfma_dtype=md)
+            outputs = ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
+                                        mfma_dtype=md)
             return bnl(outputs)
         # generic shapes: one [D, 4D] GEMM (relu and bias fused) for the four projections + the attention core kernel
         W_cat = torch.cat([p.kernel for p in projs], dim=1)

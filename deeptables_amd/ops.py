@@ -633,8 +633,9 @@ class _AutoIntLayer(torch.autograd.Function):
     backward is applied inside the layer's backward kernel while it reads the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, *wb):
+    def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, mode, *wb):
         require_cuda(x, *wb)
+        mode = int(mode)
         x = _f32c(x)
         wb = [_f32c(t) for t in wb]
         NP = len(wb) // 2
@@ -652,15 +653,15 @@ class _AutoIntLayer(torch.autograd.Function):
             check(lib().dt_autoint_fwd_bn(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
                                           float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(gamma), ptr(beta), float(eps),
                                           float(momentum), ptr(moving_mean), ptr(moving_var), ptr(a), ptr(y), ptr(mean),
-                                          ptr(rstd), ptr(ws), stream_ptr()), 'dt_autoint_fwd_bn')
-            ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, True)
+                                          ptr(rstd), ptr(ws), mode, stream_ptr()), 'dt_autoint_fwd_bn')
+            ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, True, mode)
             ctx.save_for_backward(x, a, *wb, mean, rstd, *([gamma] if gamma is not None else []))
             ctx.has_affine = (gamma is not None, beta is not None)
             return y
         check(lib().dt_autoint_fwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
-                                   float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, stream_ptr()),
+                                   float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, mode, stream_ptr()),
               'dt_autoint_fwd')
-        ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, bn is not None)
+        ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, bn is not None, mode)
         if bn is None:
             ctx.save_for_backward(x, a, *wb)
             return a
@@ -679,7 +680,7 @@ class _AutoIntLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        H, NP, rate, seed, has_bn = ctx.cfg
+        H, NP, rate, seed, has_bn, mode = ctx.cfg
         saved = list(ctx.saved_tensors)
         x, a = saved[0], saved[1]
         wb = saved[2:2 + 2 * NP]
@@ -707,14 +708,14 @@ class _AutoIntLayer(torch.autograd.Function):
             wsw = _autoint_ws(B, D, x.device)
             check(lib().dt_autoint_bwd_w(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                          rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(gx), ptr(gWs),
-                                         ptr(gbs), ptr(wsw), stream_ptr()), 'dt_autoint_bwd_w')
+                                         ptr(gbs), ptr(wsw), mode, stream_ptr()), 'dt_autoint_bwd_w')
             return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
-                    gbeta if has_bn and ctx.has_affine[1] else None, *[gWs[i] for i in range(NP)],
+                    gbeta if has_bn and ctx.has_affine[1] else None, None, *[gWs[i] for i in range(NP)],
                     *[gbs[i] for i in range(NP)])
         dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
         check(lib().dt_autoint_bwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                    rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dY), ptr(gx),
-                                   stream_ptr()), 'dt_autoint_bwd')
+                                   mode, stream_ptr()), 'dt_autoint_bwd')
         # kernel / bias gradients = x^T dY, colsum(dY): batch reductions on the Dense weight-gradient kernel (its W / y
         # arguments are unused for a linear layer without grad_x)
         buf = torch.zeros(D * M + M, dtype=torch.float32, device=x.device)
@@ -725,7 +726,7 @@ class _AutoIntLayer(torch.autograd.Function):
         gW = [gWs[i] for i in range(NP)]
         gb = [gbc[i * D:(i + 1) * D] for i in range(NP)]
         return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
-                gbeta if has_bn and ctx.has_affine[1] else None, *gW, *gb)
+                gbeta if has_bn and ctx.has_affine[1] else None, None, *gW, *gb)
 
 
 def autoint_supported(x, num_heads):
@@ -733,18 +734,32 @@ def autoint_supported(x, num_heads):
         bool(lib().dt_autoint_supported(int(x.shape[1]), int(x.shape[2]), int(num_heads)))
 
 
-def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None):
+def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None, mfma_dtype=None):
     """a = relu(multi-head field attention(relu-projections of x) [+ relu residual projection]) — layers.py:123-150.
     kernels / biases: those of dense_Q, dense_K, dense_V[, dense_residual] (3 or 4 of each; [D,D] and [D]).
     batch_norm = (gamma, beta, moving_mean, moving_var, eps, momentum): also applies the layer's training-mode
-    BatchNormalization (layers.py:151) and returns BN(a)."""
+    BatchNormalization (layers.py:151) and returns BN(a).
+    mfma_dtype (autoint_params['mfma_dtype']): None / 'float32' — exact fp32 MFMA; 'bf16' — north_star's 1e-2 mode: the layer's
+    projection-shaped products on the bf16 matrix cores (include/dt_hip.h DT_AI_BF16; embedding size 32 only)."""
     assert len(kernels) == len(biases) and len(kernels) in (3, 4)
+    mode = autoint_mfma_mode(mfma_dtype, int(x.shape[-1]))
     if batch_norm is None:
-        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None,
+        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None, mode,
                                    *kernels, *biases)
     gamma, beta, mm, mv, eps, momentum = batch_norm
     return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), (mm, mv, float(eps), float(momentum)),
-                               gamma, beta, *kernels, *biases)
+                               gamma, beta, mode, *kernels, *biases)
+
+
+def autoint_mfma_mode(mfma_dtype, D):
+    """autoint_params['mfma_dtype'] -> the C-ABI's mfma_mode; an unsupported request raises (no silent fp32)"""
+    if mfma_dtype in (None, 'float32', 'f32', 'fp32'):
+        return _lib.DT_AI_F32
+    if mfma_dtype in ('bf16', 'bfloat16'):
+        if D != 32:
+            raise _lib.DtHipError(f"autoint_params['mfma_dtype'] = 'bf16' needs an embedding size of 32 (got {D})")
+        return _lib.DT_AI_BF16
+    raise ValueError(f"autoint_params['mfma_dtype'] = {mfma_dtype!r}: 'float32' or 'bf16'")
 
 
 class _SplitCols(torch.autograd.Function):

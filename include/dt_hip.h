@@ -349,16 +349,22 @@ int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, co
  * [2D] = sum_g | sum_gx from dt_bn_train_bwd_stats.
  * dropout_rate: Dropout on the attention weights (layers.py:141), keep-mask = dt_autoint_dropout_hash(seed, b, h,
  * query, key) >= rate * 2^32, kept weights scaled by 1/(1-rate); pass 0 at inference.  fp32 MFMA (16x16x4); F <= 32,
- * D in {16, 32}, d_h in {4, 8, 16} (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.            */
+ * D in {16, 32}, d_h in {4, 8, 16} (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.
+ * mfma_mode (every entry point of the layer; autoint_params['mfma_dtype']): DT_AI_F32 — exact fp32 MFMA throughout;
+ * DT_AI_BF16 (D = 32) — north_star's "1e-2 bf16" mode: the projection-shaped products (x Wcat and its recomputation, dX = dY
+ * Wcat^T, the weight gradient x^T dY) on v_mfma_f32_16x16x32_bf16 with plain bf16 operands and fp32 accumulation; scores,
+ * softmax, relu masks and BatchNormalization stay fp32.  Results within 1e-2 of the oracle (of each tensor's largest entry). */
+#define DT_AI_F32 0
+#define DT_AI_BF16 1
 int dt_autoint_supported(int F, int D, int H);
 unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j);
 int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                    const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
-                   float dropout_rate, unsigned seed, float* out_a, float* lse, void* stream);
+                   float dropout_rate, unsigned seed, float* out_a, float* lse, int mfma_mode, void* stream);
 int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                    const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                    int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
-                   const float* bn_rstd, const float* bn_sums, float* dY, float* dX, void* stream);
+                   const float* bn_rstd, const float* bn_sums, float* dY, float* dX, int mfma_mode, void* stream);
 /* dt_autoint_fwd_bn — dt_autoint_fwd followed by the layer's training-mode BatchNormalization (layers.py:151) in two
  * launches instead of four: the attention kernel's epilogue leaves per-block sums of (a - moving_mean) and its square, the
  * second launch adds them up in its prologue, normalises (out_y = BN(out_a)), writes save_mean / save_rstd [D] for the
@@ -369,7 +375,7 @@ int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* Wk, const fl
                       const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
                       float dropout_rate, unsigned seed, const float* gamma, const float* beta, float eps, float momentum,
                       float* moving_mean, float* moving_var, float* out_a, float* out_y, float* save_mean,
-                      float* save_rstd, void* workspace, void* stream);
+                      float* save_rstd, void* workspace, int mfma_mode, void* stream);
 /* dt_autoint_bwd_w — the same backward with the kernel / bias gradients of dense_Q | dense_K | dense_V [| dense_residual]
  * (layers.py:104-108; in the reference: four MatMul + BiasAddGrad ops over [B*F, D]) accumulated inside the launch from the
  * pre-activation gradients while they are in LDS, plus one small reduction launch: dY never reaches HBM and no
@@ -380,7 +386,7 @@ int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const flo
                      const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                      int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
                      const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
-                     void* stream);
+                     int mfma_mode, void* stream);
 
 /* ---- input feed: batch assembly on the device (replaces `tf.data.Dataset.from_tensor_slices(...).shuffle().batch()` of
  *      utils/dataset_generator.py:36-72 for a table resident in HBM; deeptables_amd/compiled.py) -------------------- *

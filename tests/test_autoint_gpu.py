@@ -64,6 +64,59 @@ def test_autoint_layer_matches_float64_reference(dev, B, F, D, H, res, rate):
     assert rel(bd_grad, br.grad) < 1e-4, rel(bd_grad, br.grad)
 
 
+@pytest.mark.parametrize('B,F,H,res,rate,bn', [(64, 26, 4, True, 0.0, False), (2100, 26, 4, True, 0.0, True),
+                                               (300, 28, 2, False, 0.0, True), (129, 13, 4, True, 0.3, False),
+                                               (2500, 32, 2, True, 0.0, False)])
+def test_autoint_layer_bf16_mode_meets_the_1e2_bar(dev, B, F, H, res, rate, bn):
+    """north_star's "1e-2 bf16" mode of the attention layer (include/dt_hip.h DT_AI_BF16, autoint_params['mfma_dtype'] = 'bf16';
+    layers.py:104-153): the projections, dX = dY Wcat^T and the weight gradient x^T dY on v_mfma_f32_16x16x32_bf16 (plain bf16
+    operands, fp32 accumulation), everything else exact.  Against the float64 restatement: output and every gradient within 1e-2
+    of the tensor's largest entry (F = 32 takes dt_autoint_bwd + the Dense weight-gradient kernel, F <= 28 the in-kernel weight
+    gradient; with and without the fused BatchNormalization)."""
+    from deeptables_amd import ops
+    D = 32
+    g = torch.Generator().manual_seed(B * 17 + F)
+    NP = 4 if res else 3
+    x = torch.randn(B, F, D, generator=g) * 0.7
+    W = torch.randn(D, NP * D, generator=g) * (1.5 / D ** 0.5)
+    b = torch.randn(NP * D, generator=g) * 0.2
+    go = torch.randn(B, F, D, generator=g)
+    seed = 777 + B
+    xd = x.to(dev).requires_grad_(True)
+    Ws = [W[:, i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+    bs = [b[i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+    gamma = (torch.rand(D, generator=g) + 0.5)
+    beta = torch.randn(D, generator=g) * 0.1
+    batch_norm = None
+    if bn:
+        gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+        batch_norm = (gd, bd, torch.zeros(D, device=dev), torch.ones(D, device=dev), 1e-3, 0.99)
+    out = ops.autoint_layer(xd, Ws, bs, H, rate, seed, batch_norm=batch_norm, mfma_dtype='bf16')
+    out.backward(go.to(dev))
+    keep = ops.autoint_dropout_keep(seed, B, H, F, rate).double() if rate > 0 else None
+    xr, Wr, br = (t.double().requires_grad_(True) for t in (x, W, b))
+    ar = reference(xr, Wr, br, H, res, keep)
+    if bn:
+        gr, btr = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        flat = ar.reshape(-1, D)
+        mu, var = flat.mean(0), flat.var(0, unbiased=False)
+        ar = ((ar - mu) / torch.sqrt(var + 1e-3)) * gr + btr
+    ar.backward(go.double())
+
+    def rel(u, v):
+        return (u.detach().double().cpu() - v.detach()).abs().max().item() / max(v.detach().abs().max().item(), 1e-30)
+    errs = {'out': rel(out, ar), 'dx': rel(xd.grad, xr.grad), 'dW': rel(torch.cat([w.grad for w in Ws], 1), Wr.grad),
+            'db': rel(torch.cat([v.grad for v in bs], 0), br.grad)}
+    if bn:
+        errs['dgamma'], errs['dbeta'] = rel(gd.grad, gr.grad), rel(bd.grad, btr.grad)
+    assert all(v < 1e-2 for v in errs.values()), errs
+    assert errs['out'] > 1e-6, ('the bf16 kernels did not run', errs)        # (fp32 results sit at ~1e-7)
+    # an unsupported request is refused, not served in fp32
+    with pytest.raises(Exception):
+        ops.autoint_layer(torch.zeros(4, 5, 16, device=dev), [torch.zeros(16, 16, device=dev)] * 3,
+                          [torch.zeros(16, device=dev)] * 3, 2, mfma_dtype='bf16')
+
+
 def test_dropout_hash_is_the_kernels(dev):
     from deeptables_amd import ops
     from deeptables_amd._lib import lib

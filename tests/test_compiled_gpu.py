@@ -180,14 +180,19 @@ def test_preelected_steps_train_like_eager_steps(dev, monkeypatch):
         dl.DENSE_GRAD_MAX_ELEMS = old
 
 
+@pytest.mark.parametrize('whole', [True, False])
 @pytest.mark.parametrize('uniform', [False, True])
-def test_compiled_data_parallel_fit_trains_like_the_eager_one(dev, uniform):
+def test_compiled_data_parallel_fit_trains_like_the_eager_one(dev, monkeypatch, uniform, whole):
     """under data parallel the loop captures `optimizer.step()` into its own graph on the third step.  That is
     only valid while the exchanged sparse gradients keep their addresses — with a DEFAULT strategy (assume_uniform_batches
     False) `allgather_sparse` used to hand back freshly allocated tensors every step, so the replays updated the tables from
     whatever the capture step's (since recycled) buffers held.  World size 1 through RCCL (force_dp + force_collectives: the
     flat all-reduce and the sparse all-gathers are really issued), row-sparse tables; the compiled fit must leave the weights
-    of the step-by-step fit under the same strategy."""
+    of the step-by-step fit under the same strategy.
+    Round 6 (`whole`): the default structure captures k WHOLE steps — forward + backward, the RCCL exchange and the optimizer —
+    into one hipGraph (compiled.CompiledTrainLoop._capture_dp_whole); DT_AMD_DP_GRAPH=0 keeps round 5's
+    [graph] -> eager exchange -> [optimizer graph].  Both must train like the eager fit."""
+    monkeypatch.setenv('DT_AMD_DP_GRAPH', '1' if whole else '0')
     import os
     import socket
     import torch.distributed as dist
@@ -217,8 +222,12 @@ def test_compiled_data_parallel_fit_trains_like_the_eager_one(dev, uniform):
         _fit(graphed, df, y, 10)
         assert eager.compiled_loop is None
         loop = graphed.compiled_loop
-        assert loop is not None and loop.dp and loop.k == 1 and loop.graph is not None
-        assert loop.opt_graph is not None and not loop._opt_graph_refused      # the persistent exchange path was taken
+        assert loop is not None and loop.dp and loop.graph is not None
+        if whole:
+            assert loop.dp_graph and loop.k == 10 and loop.opt_graph is None   # exchange + optimizer are inside the graph
+        else:
+            assert not loop.dp_graph and loop.k == 1
+            assert loop.opt_graph is not None and not loop._opt_graph_refused  # the persistent exchange path was taken
         assert graphed.config.distribute_strategy.assume_uniform_batches is uniform   # (restored after every exchange)
         _same(eager, graphed, tol=2e-6)
         assert eager.optimizer.t == graphed.optimizer.t == 3 * 12
