@@ -631,9 +631,9 @@ def main():
                          "1e-2 then); default: the library's")
     ap.add_argument('--cin', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help="cin_params['mfma_dtype'] of xDeepFM: exact-fp32 MFMA, split-bf16 (fp32 bars) or plain bf16 (1e-2 bars)")
-    ap.add_argument('--attn', default=None, choices=['f32', 'bf16'],
-                    help="autoint_params['mfma_dtype'] of AutoInt: exact fp32 MFMA or the layer's bf16 mode (projection-shaped "
-                         "products on bf16 MFMA; the line's parity bars are 1e-2 then)")
+    ap.add_argument('--attn', default=None, choices=['f32', 'bf16x2', 'bf16'],
+                    help="autoint_params['mfma_dtype'] of AutoInt: exact fp32 MFMA, split-bf16 (two-part operands, fp32 bars) or the "
+                         "layer's bf16 mode (the line's parity bars are 1e-2 then)")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--steps-per-graph', type=int, default=20,
                     help='train steps (consecutive batches) captured into one hipGraph replay (single process)')
@@ -885,6 +885,10 @@ def main():
                                   'flops_per_row': fpr, 'launch_us': step_s * 1e6,
                                   'launch': f'one train step = one hipGraph replay / {spg}; flops = the CIN / attention '
                                             'contractions, fwd + dgrad + wgrad'}
+            attn_mode = args.attn or os.environ.get('DT_AMD_AUTOINT_DTYPE') or 'bf16x2'      # (the library's default at embedding size 32)
+            if args.model == 'AutoInt' and attn_mode == 'bf16x2':
+                result['dtype'] = 'f32 (split-bf16 attention projections / dX / weight gradient: 16-bit operands, fp32 accumulate)'
+                result['roofline']['mfma_dtype'] = 'split-bf16 (three bf16 MFMAs per product) for the projection-shaped products, f32 for scores / P V'
             if args.model == 'AutoInt' and args.attn == 'bf16':
                 result['dtype'] = 'bf16 (attention layer projections / dX / weight gradient, fp32 accumulate); f32 elsewhere'
                 result['roofline']['mfma_dtype'] = 'bf16 for the projection-shaped products (70 % of the flops), f32 for scores / P V'

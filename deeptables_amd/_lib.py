@@ -160,7 +160,7 @@ SIGNATURES = {
 }
 
 DT_IDX_F32, DT_IDX_I32 = 0, 1
-DT_AI_F32, DT_AI_BF16 = 0, 1
+DT_AI_F32, DT_AI_BF16, DT_AI_BF16X2 = 0, 1, 2
 DT_STEP_LOSS_MSE = 0x10
 DT_STEP_SKIP_FINISH, DT_STEP_FINISH_ONLY = 0x20, 0x40
 DT_STEP_TOWER_X3 = 0x80

@@ -97,18 +97,72 @@ __device__ __forceinline__ void ai_load_x(const float* __restrict__ x, int64_t b
 
 // ---- north_star's "1e-2 bf16" mode of the layer (mfma_mode = DT_AI_BF16; D = 32 only) ------------------------------------
 // The three projection-shaped products of the layer — Y = x Wcat (forward, and its recomputation in the backward), dX = dY
-// Wcat^T and the weight gradient x^T dY — run on v_mfma_f32_16x16x32_bf16 with plain bf16 operands and fp32 accumulation:
-// 70 % of the layer's matrix work at 1/16 of the fp32-MFMA time.  With D = 32 the operand registers the fp32 kernels
+// Wcat^T and the weight gradient x^T dY — run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 70 % of the layer's matrix
+// work at 1/16 of the fp32-MFMA time per product.  The two backward products take plain bf16 operands (2^-9 per operand).
+// The FORWARD product takes two-part operands (a = hi + lo, three products hi hi + hi lo + lo hi: 2^-17) — measured first
+// with plain operands: outputs 3e-3, but ~0.3 % of the relu units of the four projections sat within that noise of zero and
+// took the other derivative: gradients 4-36 % off in the largest entry, 8 % in L2, logits 1.6e-2 after three layers.  With
+// fp32-class pre-activations the relu decisions are the oracle's and only the backward's own rounding is left.
+// mfma_mode = DT_AI_BF16X2 (split-bf16, the construction of tower_x3.h / cin_bf16.hip for this layer): the forward product with
+// THREE-part operands (all 24 mantissa bits, six products: fp32-class pre-activations — with two parts the logits of the
+// three-layer AutoInt graph were 8e-5 off and relu units flipped: dense gradients 7e-3), the two backward products with two
+// parts (2^-17, gradients ~1e-5 of the tensor max): the exact kernels' parity bars on the bf16 matrix cores.  With D = 32 the operand registers the fp32 kernels
 // already hold ARE the 16x16x32 layout: a lane (n, q) owns the 8 contraction indices k = 8 q + t of row / column n — eight
 // floats become one bf16x8 operand, one MFMA replaces eight.  The score / probability products (d_h = 8: two steps of the
 // fp32 MFMA) stay exact fp32, and so do softmax, relu masks and BatchNormalization: results within 1e-2 of the float64
 // oracle (of each tensor's largest entry), tests/test_autoint_gpu.py.
 typedef __bf16 ai_b8 __attribute__((ext_vector_type(8)));
+#define AI_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
 __device__ __forceinline__ ai_b8 ai_pack8(const float (&v)[8]) {
     ai_b8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
     return o;
+}
+// v = hi + lo with 16 mantissa bits kept (lo = the bf16 rounding of what hi left)
+__device__ __forceinline__ void ai_split8(const float (&v)[8], ai_b8& hi, ai_b8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(v[e] - (float)h);
+    }
+}
+// v = hi + mid + lo EXACTLY (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ void ai_split8_3(const float (&v)[8], ai_b8& hi, ai_b8& mid, ai_b8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[e] = h; mid[e] = m;
+        lo[e] = (__bf16)(r1 - (float)m);
+    }
+}
+// Y tile += x W with split operands: PARTS = 2 (16 bits: hi hi + hi lo + lo hi, 2^-17) or 3 (all 24 bits: six products, the
+// dropped terms 2^-24 of the product — fp32-class pre-activations, the oracle's relu decisions)
+template <int PARTS>
+__device__ __forceinline__ void ai_split_mma(const float (&x0)[8], const float (&x1)[8], const float (&w)[8], ai_f4& c0, ai_f4& c1) {
+    ai_f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;               // the small products, added last
+    if constexpr (PARTS == 2) {
+        ai_b8 xh0, xl0, xh1, xl1, wh, wlo;
+        ai_split8(x0, xh0, xl0); ai_split8(x1, xh1, xl1); ai_split8(w, wh, wlo);
+        AI_MFMA_BF16(s0, xh0, wlo); AI_MFMA_BF16(s1, xh1, wlo);
+        AI_MFMA_BF16(s0, xl0, wh); AI_MFMA_BF16(s1, xl1, wh);
+        AI_MFMA_BF16(c0, xh0, wh); AI_MFMA_BF16(c1, xh1, wh);
+        c0 += s0; c1 += s1;
+    } else {
+        ai_b8 xh0, xm0, xl0, xh1, xm1, xl1, wh, wm, wlo;
+        ai_split8_3(x0, xh0, xm0, xl0); ai_split8_3(x1, xh1, xm1, xl1); ai_split8_3(w, wh, wm, wlo);
+        ai_f4 t0 = s0, t1 = s0;
+        AI_MFMA_BF16(t0, xh0, wlo); AI_MFMA_BF16(t1, xh1, wlo);
+        AI_MFMA_BF16(t0, xm0, wm); AI_MFMA_BF16(t1, xm1, wm);
+        AI_MFMA_BF16(t0, xl0, wh); AI_MFMA_BF16(t1, xl1, wh);
+        AI_MFMA_BF16(s0, xh0, wm); AI_MFMA_BF16(s1, xh1, wm);
+        AI_MFMA_BF16(s0, xm0, wh); AI_MFMA_BF16(s1, xm1, wh);
+        AI_MFMA_BF16(c0, xh0, wh); AI_MFMA_BF16(c1, xh1, wh);
+        c0 += s0 + t0; c1 += s1 + t1;
+    }
 }
 __device__ __forceinline__ ai_b8 ai_pack8(const ai_f4& a, const ai_f4& b) {
     ai_b8 o;
@@ -116,23 +170,20 @@ __device__ __forceinline__ ai_b8 ai_pack8(const ai_f4& a, const ai_f4& b) {
     for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
     return o;
 }
-#define AI_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
 
 // Y = relu(x Wcat + b) -> the wave's LDS slab ys[32][YS]   (NP = 3 or 4 projections: q | k | v [| residual])
-template <int D, bool BF = false>
+template <int D, int BF = 0>
 __device__ __forceinline__ void ai_project(const float (&xa)[2][D / 4], const float (&wr)[D / 4][D / 4],
                                            const float (&br)[D / 4], int NP, float* ys, int n, int q) {
     constexpr int TK = D / 4, YS = 4 * D + kAiPad;
-    ai_b8 xb0, xb1;
-    if constexpr (BF) { static_assert(D == 32, "bf16 mode: D = 32"); xb0 = ai_pack8(xa[0]); xb1 = ai_pack8(xa[1]); }
+    if constexpr (BF != 0) static_assert(D == 32, "bf16 modes: D = 32");
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) {                  // 4D / 16 column tiles
         if (ct * 16 >= NP * D) break;
         ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        if constexpr (BF) {
-            const ai_b8 wb = ai_pack8(wr[ct]);
-            AI_MFMA_BF16(c0, xb0, wb);
-            AI_MFMA_BF16(c1, xb1, wb);
+        if constexpr (BF != 0) {
+            // (the splits of x repeat per column tile: the compiler keeps them in registers across the unrolled loop)
+            ai_split_mma<BF == 2 ? 3 : 2>(xa[0], xa[1], wr[ct], c0, c1);
         } else {
 #pragma unroll
         for (int t = 0; t < TK; ++t) {
@@ -149,12 +200,11 @@ __device__ __forceinline__ void ai_project(const float (&xa)[2][D / 4], const fl
 }
 
 // the same with the weights read from the block's LDS copy wl[D][WS] (B operand of step t: W[TK q + t][16 ct + n])
-template <int D, bool BF = false>
+template <int D, int BF = 0>
 __device__ __forceinline__ void ai_project_lds(const float (&xa)[2][D / 4], const float* wl, int WS,
                                                const float (&br)[D / 4], int NP, float* ys, int n, int q) {
     constexpr int TK = D / 4, YS = 4 * D + kAiPad;
-    ai_b8 xb0, xb1;
-    if constexpr (BF) { static_assert(D == 32, "bf16 mode: D = 32"); xb0 = ai_pack8(xa[0]); xb1 = ai_pack8(xa[1]); }
+    if constexpr (BF != 0) static_assert(D == 32, "bf16 modes: D = 32");
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) {
         if (ct * 16 >= NP * D) break;
@@ -162,10 +212,8 @@ __device__ __forceinline__ void ai_project_lds(const float (&xa)[2][D / 4], cons
 #pragma unroll
         for (int t = 0; t < TK; ++t) wv[t] = wl[(TK * q + t) * WS + 16 * ct + n];
         ai_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        if constexpr (BF) {
-            const ai_b8 wb = ai_pack8(wv);
-            AI_MFMA_BF16(c0, xb0, wb);
-            AI_MFMA_BF16(c1, xb1, wb);
+        if constexpr (BF != 0) {                             // the forward's products, operation for operation (same relu masks)
+            ai_split_mma<BF == 2 ? 3 : 2>(xa[0], xa[1], wv, c0, c1);
         } else {
 #pragma unroll
         for (int t = 0; t < TK; ++t) {
@@ -225,7 +273,7 @@ __device__ __forceinline__ void ai_apply(const ai_f4 (&p)[2][2], const float* ys
     }
 }
 
-template <int D, int DH, bool DROP, bool BF = false>
+template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, AiW w4, int B, int F, int NP,
                                                      float* __restrict__ out_a, float* __restrict__ lse_out,
                                                      unsigned drop_thr, float inv_keep, unsigned seed,
@@ -433,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_autoint_bn_apply(const float* __restri
 // field steps per batch row.  The block's eight waves sum their accumulators through the (dead) slabs at the end and leave
 // ONE partial [D*M + M] per block in wpart; dt_autoint_bwd_w's second launch adds the <= 256 partials and writes the four
 // Keras variables' gradients.  dY itself never reaches HBM (pass dY = NULL).
-template <int D, int DH, bool WG, bool DROP, bool BF = false>
+template <int D, int DH, bool WG, bool DROP, int BF = 0>
 __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                             const float* __restrict__ g, int B, int F, int NP,
                                             float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
@@ -718,13 +766,13 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
             // bf16 mode: the field index is the contraction index — field(g = q, j) = 4 j + q, j < 7 (the eighth is zero):
             // the seven fp32 steps' operands of a lane are ONE bf16x8 operand
             if constexpr (BF) {
-                ai_b8 xa8[D / 16];
+                ai_b8 xa8[D / 16], xa8l[D / 16];
 #pragma unroll
                 for (int T = 0; T < D / 16; ++T) {
                     float v[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) v[s] = s < WSTEPS ? xw[T][s < WSTEPS ? s : 0] : 0.f;
-                    xa8[T] = ai_pack8(v);
+                    if constexpr (BF == 2) ai_split8(v, xa8[T], xa8l[T]); else xa8[T] = ai_pack8(v);
                 }
 #pragma unroll
                 for (int ct = 0; ct < WT; ++ct) {
@@ -732,9 +780,20 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
                     float v[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) v[s] = s < WSTEPS ? ys[(4 * (s < WSTEPS ? s : 0) + q) * C::YS + n + 16 * ct] : 0.f;
-                    const ai_b8 dy8 = ai_pack8(v);
+                    if constexpr (BF == 2) {
+                        ai_b8 dyh, dyl;
+                        ai_split8(v, dyh, dyl);
 #pragma unroll
-                    for (int T = 0; T < D / 16; ++T) AI_MFMA_BF16(wacc[T][ct], xa8[T], dy8);
+                        for (int T = 0; T < D / 16; ++T) {
+                            AI_MFMA_BF16(wacc[T][ct], xa8[T], dyl);
+                            AI_MFMA_BF16(wacc[T][ct], xa8l[T], dyh);
+                            AI_MFMA_BF16(wacc[T][ct], xa8[T], dyh);
+                        }
+                    } else {
+                        const ai_b8 dy8 = ai_pack8(v);
+#pragma unroll
+                        for (int T = 0; T < D / 16; ++T) AI_MFMA_BF16(wacc[T][ct], xa8[T], dy8);
+                    }
                 }
             }
         } else if (WG) {
@@ -768,17 +827,40 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
             const int MQ = M / 4;                            // 24 or 32 (D = 32), 12 or 16 (D = 16): multiples of 4
             if constexpr (BF) {
                 // bf16 mode: eight consecutive m of a lane per step (MQ = 24 or 32: three or four steps)
+                auto ld8 = [](const float* p, float (&v)[8]) {
+                    const ai_f4 u = *reinterpret_cast<const ai_f4*>(p), w = *reinterpret_cast<const ai_f4*>(p + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = u[e]; v[4 + e] = w[e]; }
+                };
                 for (int t = 0; t < MQ; t += 8) {
                     const float* ap = ys + n * C::YS + MQ * q + t;
-                    const ai_b8 a0 = ai_pack8(*reinterpret_cast<const ai_f4*>(ap), *reinterpret_cast<const ai_f4*>(ap + 4));
-                    const ai_b8 a1 = ai_pack8(*reinterpret_cast<const ai_f4*>(ap + 16 * C::YS),
-                                              *reinterpret_cast<const ai_f4*>(ap + 16 * C::YS + 4));
+                    float av0[8], av1[8];
+                    ld8(ap, av0);
+                    ld8(ap + 16 * C::YS, av1);
+                    if constexpr (BF == 2) {
+                        ai_b8 a0h, a0l, a1h, a1l;
+                        ai_split8(av0, a0h, a0l);
+                        ai_split8(av1, a1h, a1l);
 #pragma unroll
-                    for (int ct = 0; ct < D / 16; ++ct) {
-                        const float* wp = wl + (16 * ct + n) * WS + MQ * q + t;
-                        const ai_b8 w8 = ai_pack8(*reinterpret_cast<const ai_f4*>(wp), *reinterpret_cast<const ai_f4*>(wp + 4));
-                        AI_MFMA_BF16(dx[0][ct], a0, w8);
-                        AI_MFMA_BF16(dx[1][ct], a1, w8);
+                        for (int ct = 0; ct < D / 16; ++ct) {
+                            float wv8[8];
+                            ld8(wl + (16 * ct + n) * WS + MQ * q + t, wv8);
+                            ai_b8 wh, wlo;
+                            ai_split8(wv8, wh, wlo);
+                            AI_MFMA_BF16(dx[0][ct], a0h, wlo); AI_MFMA_BF16(dx[1][ct], a1h, wlo);
+                            AI_MFMA_BF16(dx[0][ct], a0l, wh); AI_MFMA_BF16(dx[1][ct], a1l, wh);
+                            AI_MFMA_BF16(dx[0][ct], a0h, wh); AI_MFMA_BF16(dx[1][ct], a1h, wh);
+                        }
+                    } else {
+                        const ai_b8 a0 = ai_pack8(av0), a1 = ai_pack8(av1);
+#pragma unroll
+                        for (int ct = 0; ct < D / 16; ++ct) {
+                            float wv8[8];
+                            ld8(wl + (16 * ct + n) * WS + MQ * q + t, wv8);
+                            const ai_b8 w8 = ai_pack8(wv8);
+                            AI_MFMA_BF16(dx[0][ct], a0, w8);
+                            AI_MFMA_BF16(dx[1][ct], a1, w8);
+                        }
                     }
                 }
             } else
@@ -851,14 +933,14 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
     }
 }
 
-template <int D, int DH, bool DROP, bool BF = false>
+template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                      const float* __restrict__ g, int B, int F, int NP,
                                                      float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
                                                      unsigned drop_thr, float inv_keep, unsigned seed) {
     ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr);
 }
-template <int D, int DH, bool DROP, bool BF = false>
+template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                        const float* __restrict__ g, int B, int F, int NP,
                                                        float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
@@ -929,11 +1011,21 @@ extern "C" unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned 
 #define DT_AI_LAUNCH_BF(KERNEL, DV, HV, WAVES, ...)                                                                        \
     do {                                                                                                                   \
         if (thr) {                                                                                                         \
-            hipFuncSetAttribute((const void*)KERNEL<DV, HV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-            hipLaunchKernelGGL((KERNEL<DV, HV, true, true>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);       \
+            if (mfma_mode == DT_AI_BF16X2) {                                                                              \
+                hipFuncSetAttribute((const void*)KERNEL<DV, HV, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((KERNEL<DV, HV, true, 2>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);     \
+            } else {                                                                                                       \
+                hipFuncSetAttribute((const void*)KERNEL<DV, HV, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((KERNEL<DV, HV, true, 1>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);     \
+            }                                                                                                              \
         } else {                                                                                                           \
-            hipFuncSetAttribute((const void*)KERNEL<DV, HV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL((KERNEL<DV, HV, false, true>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);      \
+            if (mfma_mode == DT_AI_BF16X2) {                                                                              \
+                hipFuncSetAttribute((const void*)KERNEL<DV, HV, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((KERNEL<DV, HV, false, 2>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);    \
+            } else {                                                                                                       \
+                hipFuncSetAttribute((const void*)KERNEL<DV, HV, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((KERNEL<DV, HV, false, 1>), dim3(blocks), dim3(64 * (WAVES)), lds, st, __VA_ARGS__);    \
+            }                                                                                                              \
         }                                                                                                                  \
     } while (0)
 #define DT_AI_DISPATCH(KERNEL, WAVES, LDS_FLOATS, ...)                                                             \
@@ -942,8 +1034,8 @@ extern "C" unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned 
         int blocks = (int)((B + (WAVES) - 1) / (WAVES));                                                           \
         if (blocks > 2048 / (WAVES)) blocks = 2048 / (WAVES);                                                      \
         const size_t lds = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
-        if (mfma_mode == DT_AI_BF16 && D == 32 && dh == 8) DT_AI_LAUNCH_BF(KERNEL, 32, 8, WAVES, __VA_ARGS__);     \
-        else if (mfma_mode == DT_AI_BF16 && D == 32 && dh == 16) DT_AI_LAUNCH_BF(KERNEL, 32, 16, WAVES, __VA_ARGS__); \
+        if (mfma_mode != DT_AI_F32 && D == 32 && dh == 8) DT_AI_LAUNCH_BF(KERNEL, 32, 8, WAVES, __VA_ARGS__);      \
+        else if (mfma_mode != DT_AI_F32 && D == 32 && dh == 16) DT_AI_LAUNCH_BF(KERNEL, 32, 16, WAVES, __VA_ARGS__); \
         else if (D == 32 && dh == 8) DT_AI_LAUNCH(KERNEL, 32, 8, WAVES, __VA_ARGS__);                              \
         else if (D == 32 && dh == 16) DT_AI_LAUNCH(KERNEL, 32, 16, WAVES, __VA_ARGS__);                            \
         else if (D == 16 && dh == 4) DT_AI_LAUNCH(KERNEL, 16, 4, WAVES, __VA_ARGS__);                              \
@@ -974,7 +1066,7 @@ static bool ai_weights(const float* const* W, const float* const* b, int NP, AiW
 extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
                               const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
                               int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, int mfma_mode, void* stream) {
-    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_fwd: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_fwd: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && out_a && B > 0 && B < (1LL << 31), "dt_autoint_fwd: null pointer / bad batch");
@@ -996,7 +1088,7 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
                               const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                               const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
                               float* dY, float* dX, int mfma_mode, void* stream) {
-    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_bwd: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
     DT_REQUIRE(x && a && g && B > 0 && B < (1LL << 31), "dt_autoint_bwd: null pointer / bad batch");
@@ -1030,7 +1122,7 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
                                 const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                                 const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
                                 float* dX, float* gW, float* gb, void* workspace, int mfma_mode, void* stream) {
-    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
     DT_REQUIRE(gW && gb && workspace, "dt_autoint_bwd_w: null gradient / workspace pointer");
@@ -1078,7 +1170,7 @@ extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* W
                                  int D, int H, float dropout_rate, unsigned seed, const float* gamma, const float* beta,
                                  float eps, float momentum, float* moving_mean, float* moving_var, float* out_a,
                                  float* out_y, float* save_mean, float* save_rstd, void* workspace, int mfma_mode, void* stream) {
-    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !(mfma_mode == DT_AI_BF16 && D == 32), "dt_autoint_fwd_bn: mfma_mode %d (DT_AI_BF16 needs D = 32; D = %d)", mfma_mode, D);
+    DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_fwd_bn: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd_bn: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_REQUIRE(x && out_a && out_y && save_mean && save_rstd && workspace && B > 0 && B < (1LL << 31),
                "dt_autoint_fwd_bn: null pointer / bad batch");

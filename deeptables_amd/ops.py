@@ -753,13 +753,18 @@ def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch
 
 def autoint_mfma_mode(mfma_dtype, D):
     """autoint_params['mfma_dtype'] -> the C-ABI's mfma_mode; an unsupported request raises (no silent fp32)"""
-    if mfma_dtype in (None, 'float32', 'f32', 'fp32'):
+    if mfma_dtype is None:
+        # the library's default, like the Dense tower's (fused.py) and CIN's: split-bf16 where the kernels have it (embedding
+        # size 32) — the exact kernels' parity bars at 0.92 x their step time on the AutoInt graph (tools/r6/call6.sh);
+        # DT_AMD_AUTOINT_DTYPE overrides the default (a caller's explicit autoint_params['mfma_dtype'] always wins)
+        mfma_dtype = os.environ.get('DT_AMD_AUTOINT_DTYPE') or ('bf16x2' if D == 32 else 'float32')
+    if mfma_dtype in ('float32', 'f32', 'fp32'):
         return _lib.DT_AI_F32
-    if mfma_dtype in ('bf16', 'bfloat16'):
+    if mfma_dtype in ('bf16', 'bfloat16', 'bf16x2'):
         if D != 32:
-            raise _lib.DtHipError(f"autoint_params['mfma_dtype'] = 'bf16' needs an embedding size of 32 (got {D})")
-        return _lib.DT_AI_BF16
-    raise ValueError(f"autoint_params['mfma_dtype'] = {mfma_dtype!r}: 'float32' or 'bf16'")
+            raise _lib.DtHipError(f"autoint_params['mfma_dtype'] = {mfma_dtype!r} needs an embedding size of 32 (got {D})")
+        return _lib.DT_AI_BF16X2 if mfma_dtype == 'bf16x2' else _lib.DT_AI_BF16
+    raise ValueError(f"autoint_params['mfma_dtype'] = {mfma_dtype!r}: 'float32', 'bf16x2' (split-bf16, fp32 bars) or 'bf16'")
 
 
 class _SplitCols(torch.autograd.Function):

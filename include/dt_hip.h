@@ -351,11 +351,16 @@ int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, co
  * query, key) >= rate * 2^32, kept weights scaled by 1/(1-rate); pass 0 at inference.  fp32 MFMA (16x16x4); F <= 32,
  * D in {16, 32}, d_h in {4, 8, 16} (dt_autoint_supported); other shapes: dt_dense_fwd + dt_mha_core_fwd.
  * mfma_mode (every entry point of the layer; autoint_params['mfma_dtype']): DT_AI_F32 — exact fp32 MFMA throughout;
- * DT_AI_BF16 (D = 32) — north_star's "1e-2 bf16" mode: the projection-shaped products (x Wcat and its recomputation, dX = dY
- * Wcat^T, the weight gradient x^T dY) on v_mfma_f32_16x16x32_bf16 with plain bf16 operands and fp32 accumulation; scores,
- * softmax, relu masks and BatchNormalization stay fp32.  Results within 1e-2 of the oracle (of each tensor's largest entry). */
+ * DT_AI_BF16 (D = 32) — north_star's "1e-2 bf16" mode: the projection-shaped products on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation — x Wcat (and its recomputation in the backward) with two-part operands (three products, 2^-17: the relu
+ * decisions stay the oracle's), dX = dY Wcat^T and the weight gradient x^T dY with plain bf16 operands; scores, softmax and
+ * BatchNormalization stay fp32.  Results within 1e-2 of the oracle (of each tensor's largest entry). */
 #define DT_AI_F32 0
 #define DT_AI_BF16 1
+/* DT_AI_BF16X2 (D = 32): split-bf16 — three-part operands (all 24 mantissa bits, six products) in x Wcat and its
+ * recomputation, two-part operands (16 bits, three products) in dX and the weight gradient: held to the exact kernels' bars
+ * (2e-5 forward, 1e-4 gradients against the float64 oracle) at 6/16 resp. 3/16 of the fp32-MFMA time of those products. */
+#define DT_AI_BF16X2 2
 int dt_autoint_supported(int F, int D, int H);
 unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j);
 int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
