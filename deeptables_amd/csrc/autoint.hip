@@ -52,6 +52,14 @@ struct AiBn {
     const float *gamma, *mean, *rstd, *sum_g, *sum_gx;   // gamma may be NULL (scale = False); mean == NULL: no BN
     float inv_n;
 };
+// optional: the BatchNormalization-backward batch sums of the layer BELOW (whose output y = BN(a_prev) is this layer's input x)
+// formed here, while this layer's dX — the gradient w.r.t. y — leaves: sum_b dX and sum_b dX xhat_prev per channel, added as
+// doubles into sums [2 D] (zeroed by the caller).  Replaces that layer's dt_bn_train_bwd_stats pass over a_prev and dX (two
+// launches, 54 MB read at the Criteo shape) by one more read of a_prev rows in this kernel's epilogue.
+struct AiPrev {
+    const float *a, *mean, *rstd;       // a == NULL: off
+    double* sums;                        // [D] sum_g | [D] sum_gx
+};
 template <int D>
 __device__ __forceinline__ float ai_w(const AiW& w, int k, int m) { return w.W[m / D][k * D + (m % D)]; }
 template <int D>
@@ -485,7 +493,8 @@ template <int D, int DH, bool WG, bool DROP, int BF = 0>
 __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                             const float* __restrict__ g, int B, int F, int NP,
                                             float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
-                                            unsigned drop_thr, float inv_keep, unsigned seed, float* __restrict__ wpart) {
+                                            unsigned drop_thr, float inv_keep, unsigned seed, float* __restrict__ wpart,
+                                            AiPrev pv) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -519,6 +528,9 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
     constexpr int WSTEPS = 7;                               // field steps of the weight-gradient product (fields 4s + q < 28)
     ai_f4 wacc[D / 16][WT];                                 // wacc[T][ct][r] = dWc[16T + 4q + r][16ct + n]
     float bacc[2] = {0.f, 0.f};                             // column sums of dY: columns lane and 64 + lane
+    // AiPrev: the wave's running sums live in LDS (pacc [2 D] behind the eight slabs), not in eight registers all kernel long
+    float* pacc = lds + D * WS + 8 * (32 * C::YS + 96) + wave * 2 * D;
+    if (pv.a && lane < 2 * D / 4) *reinterpret_cast<ai_f4*>(pacc + 4 * lane) = ai_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < WT; ++ct) {
 #pragma unroll
@@ -889,13 +901,50 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ys[(16 * T + 4 * q + r) * C::YS + 16 * ct + n] = dx[T][ct][r];
             ai_fence();
+            // (mean / rstd of the lane's channels are re-read per row — L1 hits — instead of living in eight registers all kernel long)
+            ai_f4 pmu = {0.f, 0.f, 0.f, 0.f}, prs = pmu, psg = pmu, psgx = pmu;
+            if (pv.a) {
+                pmu = *reinterpret_cast<const ai_f4*>(pv.mean + 4 * (lane % (D / 4)));
+                prs = *reinterpret_cast<const ai_f4*>(pv.rstd + 4 * (lane % (D / 4)));
+            }
             for (int e = lane; e < F * (D / 4); e += 64) {
                 const int i = e / (D / 4), c4 = e - i * (D / 4);
-                *reinterpret_cast<ai_f4*>(dX + ((int64_t)b * F + i) * D + 4 * c4) =
-                    *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+                const ai_f4 dxv = *reinterpret_cast<const ai_f4*>(ys + i * C::YS + 4 * c4);
+                *reinterpret_cast<ai_f4*>(dX + ((int64_t)b * F + i) * D + 4 * c4) = dxv;
+                if (pv.a) {
+                    const ai_f4 av = *reinterpret_cast<const ai_f4*>(pv.a + ((int64_t)b * F + i) * D + 4 * c4);
+                    psg += dxv;
+                    psgx += dxv * ((av - pmu) * prs);
+                }
+            }
+            if (pv.a) {          // the row's sums: lanes with the same float4 column meet by shuffles, lanes < D/4 add them up
+#pragma unroll
+                for (int o = D / 4; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        psg[c] += __shfl_xor(psg[c], o, 64);
+                        psgx[c] += __shfl_xor(psgx[c], o, 64);
+                    }
+                }
+                if (lane < D / 4) {
+                    *reinterpret_cast<ai_f4*>(pacc + 4 * lane) += psg;
+                    *reinterpret_cast<ai_f4*>(pacc + D + 4 * lane) += psgx;
+                }
             }
         }
         ai_fence();
+    }
+    if (pv.a) {
+        // the block's eight waves meet; ONE double atomic per channel and sum per block (<= 256 blocks: ~1.5 us of arrivals
+        // on 2 D addresses)
+        __syncthreads();
+        if (threadIdx.x < 2 * D) {
+            const float* p0 = lds + D * WS + 8 * (32 * C::YS + 96);
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += (double)p0[w * 2 * D + threadIdx.x];
+            unsafeAtomicAdd(pv.sums + threadIdx.x, v);
+        }
     }
     if (WG) {
         // the eight waves' accumulators -> their slabs ([D][YS]: row d, column m), summed by the whole block
@@ -937,15 +986,15 @@ template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                      const float* __restrict__ g, int B, int F, int NP,
                                                      float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
-                                                     unsigned drop_thr, float inv_keep, unsigned seed) {
-    ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr);
+                                                     unsigned drop_thr, float inv_keep, unsigned seed, AiPrev pv) {
+    ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr, pv);
 }
 template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                        const float* __restrict__ g, int B, int F, int NP,
                                                        float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
-                                                       unsigned seed, float* __restrict__ wpart) {
-    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart);
+                                                       unsigned seed, float* __restrict__ wpart, AiPrev pv) {
+    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart, pv);
 }
 
 // sum of the per-block partials -> the gradients of the NP Keras kernels [NP][D][D] (gW[p][k][j] = dWc[k][p D + j]) and
@@ -1087,7 +1136,8 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
                               const float* bq, const float* bk, const float* bv, const float* br, const float* a,
                               const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                               const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
-                              float* dY, float* dX, int mfma_mode, void* stream) {
+                              float* dY, float* dX, const float* prev_a, const float* prev_mean, const float* prev_rstd,
+                              double* prev_sums, int mfma_mode, void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
@@ -1102,8 +1152,10 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
     hipStream_t st = as_stream(stream);
     DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd: incomplete BatchNormalization arguments");
     const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
-    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, w4, a, g, (int)B, F, NP, dY,
-                   dX, bn, thr, inv_keep, seed);
+    DT_REQUIRE(!prev_a || (prev_mean && prev_rstd && prev_sums && dX), "dt_autoint_bwd: prev_a needs prev_mean / prev_rstd / prev_sums and dX");
+    const AiPrev pv{prev_a, prev_mean, prev_rstd, prev_sums};
+    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D, x, w4, a, g, (int)B, F, NP, dY,
+                   dX, bn, thr, inv_keep, seed, pv);
     return launch_status("dt_autoint_bwd");
 }
 
@@ -1121,7 +1173,9 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
                                 const float* bq, const float* bk, const float* bv, const float* br, const float* a,
                                 const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                                 const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
-                                float* dX, float* gW, float* gb, void* workspace, int mfma_mode, void* stream) {
+                                float* dX, float* gW, float* gb, void* workspace, const float* prev_a,
+                                const float* prev_mean, const float* prev_rstd, double* prev_sums, int mfma_mode,
+                                void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
@@ -1144,8 +1198,10 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
     DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd_w: incomplete BatchNormalization arguments");
     const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
     float* wpart = static_cast<float*>(workspace);
-    DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96), x, w4, a, g, (int)B, F, NP,
-                   dX, bn, thr, inv_keep, seed, wpart);
+    DT_REQUIRE(!prev_a || (prev_mean && prev_rstd && prev_sums && dX), "dt_autoint_bwd_w: prev_a needs prev_mean / prev_rstd / prev_sums and dX");
+    const AiPrev pv{prev_a, prev_mean, prev_rstd, prev_sums};
+    DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D, x, w4, a, g, (int)B, F, NP,
+                   dX, bn, thr, inv_keep, seed, wpart, pv);
     int nparts = (int)((B + 7) / 8);
     if (nparts > 256) nparts = 256;
     const int total = D * M + M;

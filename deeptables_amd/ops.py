@@ -626,6 +626,22 @@ def _autoint_ws(B, D, device, nbytes=None, tag='w'):
     return buf
 
 
+class AutoIntBnLink:
+    """What two stacked interacting layers share (deepnets.py:219-221: `output = MultiheadAttention(...)(output)`): the layer
+    below leaves its pre-normalisation output, the batch statistics and a zeroed [2 D] double buffer here; the layer above, whose
+    backward produces dX = the gradient w.r.t. the lower layer's BatchNormalization output, adds that normalisation's two
+    backward sums into the buffer while dX leaves (csrc/autoint.hip AiPrev) and records dX's address.  The lower layer's
+    backward then skips its own statistics pass — if the gradient it receives IS that dX (a second consumer of its output
+    would make autograd hand it a sum — in another tensor, or added IN PLACE into dX, which moves dX's version counter: either
+    way the pass runs as before)."""
+
+    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver')
+
+    def __init__(self):
+        self.a = self.mean = self.rstd = self.sums = None
+        self.dx_ptr = self.dx_ver = None
+
+
 class _AutoIntLayer(torch.autograd.Function):
     """forward(x, num_heads, dropout_rate, seed, bn, *wb): wb = Wq, Wk, Wv[, Wr], bq, bk, bv[, br] (the Keras variables,
     never concatenated).  bn = None -> returns a = relu(attention + residual); bn = (gamma, beta, moving_mean,
@@ -633,9 +649,10 @@ class _AutoIntLayer(torch.autograd.Function):
     backward is applied inside the layer's backward kernel while it reads the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, mode, *wb):
+    def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, mode, links, *wb):
         require_cuda(x, *wb)
         mode = int(mode)
+        ctx.link_in, ctx.link_out = links if links is not None else (None, None)
         x = _f32c(x)
         wb = [_f32c(t) for t in wb]
         NP = len(wb) // 2
@@ -657,6 +674,11 @@ class _AutoIntLayer(torch.autograd.Function):
             ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, True, mode)
             ctx.save_for_backward(x, a, *wb, mean, rstd, *([gamma] if gamma is not None else []))
             ctx.has_affine = (gamma is not None, beta is not None)
+            if ctx.link_out is not None:
+                lk = ctx.link_out
+                lk.a, lk.mean, lk.rstd = a, mean, rstd
+                lk.sums = torch.zeros(2 * D, dtype=torch.float64, device=x.device)
+                lk.dx_ptr = None
             return y
         check(lib().dt_autoint_fwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
                                    float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, mode, stream_ptr()),
@@ -691,15 +713,29 @@ class _AutoIntLayer(torch.autograd.Function):
         if has_bn:
             mean, rstd = saved[2 + 2 * NP], saved[3 + 2 * NP]
             gamma = saved[4 + 2 * NP] if ctx.has_affine[0] else None
-            sums = torch.empty((2 * D,), dtype=torch.float32, device=x.device)
-            ggamma = torch.empty((D,), dtype=torch.float32, device=x.device)
-            gbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
-            ws = _bn_ws(B * F, D, x.device)
-            check(lib().dt_bn_train_bwd_stats(ptr(a), ptr(g), B * F, D, ptr(mean), ptr(rstd), ptr(sums), ptr(ggamma),
-                                              ptr(gbeta), ptr(ws), stream_ptr()), 'dt_bn_train_bwd_stats')
+            lk = ctx.link_out
+            if lk is not None and lk.dx_ptr is not None and lk.dx_ptr == g.data_ptr() and lk.dx_ver == g._version and \
+                    lk.sums is not None:
+                # the layer above formed this normalisation's backward sums while it wrote g (AutoIntBnLink): no pass over a, g
+                sums = lk.sums.to(torch.float32)
+                gbeta, ggamma = sums[:D], sums[D:]
+                lk.dx_ptr = None
+            else:
+                sums = torch.empty((2 * D,), dtype=torch.float32, device=x.device)
+                ggamma = torch.empty((D,), dtype=torch.float32, device=x.device)
+                gbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+                ws = _bn_ws(B * F, D, x.device)
+                check(lib().dt_bn_train_bwd_stats(ptr(a), ptr(g), B * F, D, ptr(mean), ptr(rstd), ptr(sums), ptr(ggamma),
+                                                  ptr(gbeta), ptr(ws), stream_ptr()), 'dt_bn_train_bwd_stats')
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty_like(x) if need_x else None
         M = NP * D
+        # the layer below: its BatchNormalization-backward sums ride in this backward's epilogue (AutoIntBnLink)
+        li = ctx.link_in
+        prev = (None, None, None, None)
+        if li is not None and need_x and li.a is not None and li.sums is not None and tuple(li.a.shape) == tuple(x.shape):
+            prev = (ptr(li.a), ptr(li.mean), ptr(li.rstd), ptr(li.sums))
+            li.dx_ptr, li.dx_ver = gx.data_ptr(), gx._version
         if F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense':
             # the kernel / bias gradients are accumulated inside the layer's backward launch (csrc/autoint.hip WG): the
             # pre-activation gradients dY [B*F, NP*D] never reach HBM and no Dense weight-gradient launch follows
@@ -708,14 +744,14 @@ class _AutoIntLayer(torch.autograd.Function):
             wsw = _autoint_ws(B, D, x.device)
             check(lib().dt_autoint_bwd_w(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                          rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(gx), ptr(gWs),
-                                         ptr(gbs), ptr(wsw), mode, stream_ptr()), 'dt_autoint_bwd_w')
+                                         ptr(gbs), ptr(wsw), *prev, mode, stream_ptr()), 'dt_autoint_bwd_w')
             return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
-                    gbeta if has_bn and ctx.has_affine[1] else None, None, *[gWs[i] for i in range(NP)],
+                    gbeta if has_bn and ctx.has_affine[1] else None, None, None, *[gWs[i] for i in range(NP)],
                     *[gbs[i] for i in range(NP)])
         dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
         check(lib().dt_autoint_bwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                    rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dY), ptr(gx),
-                                   mode, stream_ptr()), 'dt_autoint_bwd')
+                                   *prev, mode, stream_ptr()), 'dt_autoint_bwd')
         # kernel / bias gradients = x^T dY, colsum(dY): batch reductions on the Dense weight-gradient kernel (its W / y
         # arguments are unused for a linear layer without grad_x)
         buf = torch.zeros(D * M + M, dtype=torch.float32, device=x.device)
@@ -726,7 +762,7 @@ class _AutoIntLayer(torch.autograd.Function):
         gW = [gWs[i] for i in range(NP)]
         gb = [gbc[i * D:(i + 1) * D] for i in range(NP)]
         return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
-                gbeta if has_bn and ctx.has_affine[1] else None, None, *gW, *gb)
+                gbeta if has_bn and ctx.has_affine[1] else None, None, None, *gW, *gb)
 
 
 def autoint_supported(x, num_heads):
@@ -734,7 +770,7 @@ def autoint_supported(x, num_heads):
         bool(lib().dt_autoint_supported(int(x.shape[1]), int(x.shape[2]), int(num_heads)))
 
 
-def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None, mfma_dtype=None):
+def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None, mfma_dtype=None, link=True):
     """a = relu(multi-head field attention(relu-projections of x) [+ relu residual projection]) — layers.py:123-150.
     kernels / biases: those of dense_Q, dense_K, dense_V[, dense_residual] (3 or 4 of each; [D,D] and [D]).
     batch_norm = (gamma, beta, moving_mean, moving_var, eps, momentum): also applies the layer's training-mode
@@ -744,11 +780,17 @@ def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch
     assert len(kernels) == len(biases) and len(kernels) in (3, 4)
     mode = autoint_mfma_mode(mfma_dtype, int(x.shape[-1]))
     if batch_norm is None:
-        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None, mode,
+        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None, mode, None,
                                    *kernels, *biases)
     gamma, beta, mm, mv, eps, momentum = batch_norm
-    return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), (mm, mv, float(eps), float(momentum)),
-                               gamma, beta, mode, *kernels, *biases)
+    # stacked layers: the input's link (left by the layer below, when x IS its normalised output) and this layer's own
+    link_in = getattr(x, '_dt_bn_link', None) if link and os.environ.get('DT_AMD_AUTOINT_LINK', '1') != '0' else None
+    link_out = AutoIntBnLink() if link else None
+    y = _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), (mm, mv, float(eps), float(momentum)),
+                            gamma, beta, mode, (link_in, link_out), *kernels, *biases)
+    if link_out is not None and link_out.a is not None:
+        y._dt_bn_link = link_out
+    return y
 
 
 def autoint_mfma_mode(mfma_dtype, D):

@@ -355,6 +355,10 @@ int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, co
  * accumulation — x Wcat (and its recomputation in the backward) with two-part operands (three products, 2^-17: the relu
  * decisions stay the oracle's), dX = dY Wcat^T and the weight gradient x^T dY with plain bf16 operands; scores, softmax and
  * BatchNormalization stay fp32.  Results within 1e-2 of the oracle (of each tensor's largest entry). */
+/* prev_a / prev_mean / prev_rstd / prev_sums (dt_autoint_bwd, dt_autoint_bwd_w; all NULL = off): when this layer's input x is
+ * y_prev = BatchNormalization(a_prev) of the interacting layer below it (deepnets.py:219-221 stacks them), the two batch sums
+ * of THAT BatchNormalization's backward — sum_b dX and sum_b dX xhat_prev per channel, what dt_bn_train_bwd_stats(a_prev, dX)
+ * computes — are added (doubles) into prev_sums [2 D] = sum_g | sum_gx while dX leaves; the caller zeroes prev_sums first. */
 #define DT_AI_F32 0
 #define DT_AI_BF16 1
 /* DT_AI_BF16X2 (D = 32): split-bf16 — three-part operands (all 24 mantissa bits, six products) in x Wcat and its
@@ -369,7 +373,8 @@ int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float
 int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                    const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                    int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
-                   const float* bn_rstd, const float* bn_sums, float* dY, float* dX, int mfma_mode, void* stream);
+                   const float* bn_rstd, const float* bn_sums, float* dY, float* dX, const float* prev_a, const float* prev_mean,
+                   const float* prev_rstd, double* prev_sums, int mfma_mode, void* stream);
 /* dt_autoint_fwd_bn — dt_autoint_fwd followed by the layer's training-mode BatchNormalization (layers.py:151) in two
  * launches instead of four: the attention kernel's epilogue leaves per-block sums of (a - moving_mean) and its square, the
  * second launch adds them up in its prologue, normalises (out_y = BN(out_a)), writes save_mean / save_rstd [D] for the
@@ -391,7 +396,8 @@ int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const flo
                      const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                      int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
                      const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
-                     int mfma_mode, void* stream);
+                     const float* prev_a, const float* prev_mean,
+                   const float* prev_rstd, double* prev_sums, int mfma_mode, void* stream);
 
 /* ---- input feed: batch assembly on the device (replaces `tf.data.Dataset.from_tensor_slices(...).shuffle().batch()` of
  *      utils/dataset_generator.py:36-72 for a table resident in HBM; deeptables_amd/compiled.py) -------------------- *
