@@ -504,10 +504,11 @@ def check_in_step_vs_oracle(dm, batches, lr=1e-3, upd_tol=2e-3, g_band=2e-6):
 def rows_in_step_ok(res):
     """both paths form the same gradient with the same kernels; the update rule runs in two different kernels (fused
     multiply-add contraction may differ by an ulp or two, and the members of a segment are summed in the order the
-    election's cursor handed out — not the same from run to run): table rows within 5e-7 absolute (values ~5e-2, steps
-    ~1e-3: 0.05 % of a step; seen: 1.2e-7 after three steps with dropout), dense parameters (values up to ~1 in the
-    tests) within 1e-6, slots within 1e-5 of their largest entry"""
-    return bool(res['rows_in_step_taken'] and res['rows_moved'] > 0 and res['table_abs_err'] <= 5e-7 and
+    election's cursor handed out — not the same from run to run): table rows within 1e-6 absolute (values ~5e-2, steps
+    ~1e-3: 0.1 % of a step; seen: 1.2e-7 after three steps with dropout, 5.6e-7 once in round 6 for rows with ~300 members
+    each — vocab 30 at B = 9000, where the order of a segment's sum moves its last bits; a stale row or a race costs a
+    whole step, 1e-3), dense parameters (values up to ~1 in the tests) within 1e-6, slots within 1e-5 of their largest entry"""
+    return bool(res['rows_in_step_taken'] and res['rows_moved'] > 0 and res['table_abs_err'] <= 1e-6 and
                 res['m_rel_err'] <= 1e-5 and res['v_rel_err'] <= 1e-5 and res['dense_abs_err'] <= 1e-6 and
                 res['steps_counted'][0] == res['steps_counted'][1])
 
