@@ -842,7 +842,8 @@ def main():
                        'optimizer_in_timed_region': not args.no_optimizer,
                        'fused_plan': type(dm.fused_plan()).__name__ if dm.fused_plan() is not None else None,
                        'tower_mfma': {0: 'f32 (exact)', 0x80: 'bf16x3 (split-bf16 operands: six bf16 MFMAs per product forward, '
-                                      'three backward, fp32 accumulate)', 0x200: 'bf16 (plain bf16 operands, fp32 accumulate: '
+                                      'three backward — dH1, dXn and, since round 6, the weight-gradient GEMMs X^T dH1 / H1^T dH2 —, '
+                                      'fp32 accumulate)', 0x200: 'bf16 (plain bf16 operands, fp32 accumulate: '
                                       "north_star's 1e-2 mode)"}.get(getattr(dm.fused_plan(), 'tower_flag', 0))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,

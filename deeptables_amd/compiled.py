@@ -301,6 +301,14 @@ class CompiledTrainLoop:
         torch.cuda.synchronize()
         if self._dp_graph_wanted:
             g = self._capture_dp_whole()
+            if self.strategy.world_size > 1:
+                # every rank replays the same structure or none does: a rank whose capture failed takes the others with it to
+                # the split structure (their k-step graphs would wait for collectives it never issues)
+                import torch.distributed as dist
+                ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.strategy.group)
+                if int(ok.item()) == 0:
+                    g = None
             if g is not None:
                 self.graph, self.dp_graph = g, True
                 import weakref

@@ -1837,6 +1837,131 @@ __device__ __forceinline__ void wgrad_heavy(float* red, int hid, const float* __
     DT_STAMP(stamps, 5);
 }
 
+// Round 6: the same heavy block on the bf16 matrix cores.  Measured first (tools/r6/call8.sh, the K loop compiled out): the
+// fp32-MFMA GEMM keeps the matrix waves away from the row epilogue for ~28 K of its ~69 K cycles — without it the launch takes
+// 33.0 us instead of 41.6, the step 92.9 us instead of 101.9.  v_mfma_f32_32x32x16_bf16 contracts 16 batch rows per
+// instruction at 16x the fp32 rate; a lane (c = l % 32, s = l / 32) holds the 8 rows 16 ch + 8 s + j of its columns, i.e. the
+// same row loads as above with another row-to-lane assignment.  PARTS = 2 (the default tower mode, DT_STEP_TOWER_X3): both
+// operands as hi + lo (16 mantissa bits), products hi hi + hi lo + lo hi, fp32 accumulation — 2^-17 per product, the
+// precision of the tile kernel's backward products (dW within ~1e-5 of its largest entry); PARTS = 1 (DT_STEP_TOWER_BF16):
+// plain bf16.  The exact-fp32 tower keeps wgrad_heavy.
+typedef __bf16 wg_b8 __attribute__((ext_vector_type(8)));
+template <int PARTS>
+__device__ __forceinline__ void wgrad_heavy_bf16(float* red, int hid, const float* __restrict__ X, const MlpParams& p,
+                                                 const DeepFmDims& dm, const float* __restrict__ H1,
+                                                 const float* __restrict__ dH1, const float* __restrict__ dH2, int row_blocks,
+                                                 int rows_per_block, float* __restrict__ wpart, unsigned* soft_cnt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane >> 5, c = lane & 31;
+    const int nmac1 = dm.CP >> 6, nmac = nmac1 + 1;
+    int mac, rb;
+    if ((row_blocks & 7) == 0) {
+        const int xcd = hid & 7, j = hid >> 3, per = row_blocks >> 3;
+        mac = j % nmac;
+        rb = xcd * per + j / nmac;
+    } else {
+        mac = hid % nmac;
+        rb = hid / nmac;
+    }
+    const int rq = rows_per_block >> 2;                 // rows per wave (a multiple of 2; 64 at B = 8192)
+    const int r_begin = rb * rows_per_block + wave * rq;
+    const int r_end = min(dm.B, r_begin + rq);
+    const bool first = mac < nmac1;
+    const float* pa; const float* pb; int sa, sb;
+    floatx2 mu = {0.f, 0.f}, rs = {1.f, 1.f};
+    if (first) {
+        const int ca = 64 * mac + 2 * c;
+        pa = X + ca; sa = dm.CP; pb = dH1; sb = kH1;
+        mu = *reinterpret_cast<const floatx2*>(p.mean + ca);
+        rs = *reinterpret_cast<const floatx2*>(p.rstd + ca);
+    } else {
+        pa = dH2 + 2 * c; sa = kH2; pb = H1; sb = kH1;
+    }
+    pb += 4 * c;
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    // a chunk = 16 batch rows: this lane's 8 rows are r0 + 8 s + j.  Every load is unconditional from a clamped (valid) row;
+    // rows beyond the wave's share contribute zeros
+    floatx2 av[8];
+    floatx4 bv[8];
+    auto load_chunk = [&](int r0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = min(r0 + 8 * s + j, dm.B - 1);
+            av[j] = *reinterpret_cast<const floatx2*>(pa + (int64_t)row * sa);
+            bv[j] = ld4(pb + (int64_t)row * sb);
+        }
+    };
+    auto split8 = [](const float (&v)[8], wg_b8& hi, wg_b8& lo) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            hi[e] = h;
+            if constexpr (PARTS == 2) lo[e] = (__bf16)(v[e] - (float)h);
+        }
+    };
+    if (r_begin < r_end) load_chunk(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+        wg_b8 ah[2], al[2], bh[4], bl[4];
+        {
+            float va[2][8], vb[4][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = r0 + 8 * s + j < r_end;
+                const floatx2 a = ok ? (av[j] - mu) * rs : floatx2{0.f, 0.f};
+                const floatx4 b = ok ? bv[j] : floatx4{0.f, 0.f, 0.f, 0.f};
+                va[0][j] = a.x; va[1][j] = a.y;
+                vb[0][j] = b.x; vb[1][j] = b.y; vb[2][j] = b.z; vb[3][j] = b.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) split8(va[t], ah[t], al[t]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split8(vb[u], bh[u], bl[u]);
+        }
+        if (r0 + 16 < r_end) load_chunk(r0 + 16);           // the next chunk's rows fly under this chunk's products
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (PARTS == 2) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
+                }
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+            }
+    }
+    // the four waves' partial macro tiles meet in LDS exactly as in wgrad_heavy (same accumulator layout)
+    auto put = [&](float* slot) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * s;
+                st4(slot + (2 * i + t) * 128 + 4 * c, floatx4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]});
+            }
+    };
+    put(red + wave * 8192);
+    if (soft_cnt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(soft_cnt, 1u);
+        while (*reinterpret_cast<volatile unsigned*>(soft_cnt) < 4u) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+    float* dst = wpart + ((int64_t)mac * row_blocks + rb) * 8192;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = 4 * (tid + 256 * u);
+        st4(dst + e, (ld4(red + e) + ld4(red + 8192 + e)) + (ld4(red + 16384 + e) + ld4(red + 24576 + e)));
+    }
+}
+
 // E': adds up the batch slices of E and finishes the BN / W1 gradients.  With M = Xhat^T dH1 and db1 = colsum(dH1):
 //   dgamma = sum_b dXn xhat = rowdot(W1, M)      dbeta = sum_b dXn = W1 . db1      dW1 = gamma M + beta (x) db1
 // (dXn = dH1 W1^T is linear in dH1, so its two batch sums need no pass over it).  One wave per column of X; the
@@ -2306,7 +2431,7 @@ __device__ __forceinline__ void rows_epilogue_wave(unsigned* work, int first_til
     }
 }
 
-template <bool DCN>
+template <bool DCN, int WM = 0>      // WM: the weight-gradient GEMMs on fp32 MFMA (0), plain bf16 (1) or split-bf16 (2: wgrad_heavy_bf16)
 __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X, MlpParams p, DeepFmDims dm,
                                                     const float* __restrict__ H1, const float* __restrict__ dH1,
                                                     const float* __restrict__ dH2, int row_blocks, int rows_per_block,
@@ -2319,7 +2444,10 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
     if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; ecnt = 0u; }
     __syncthreads();          // the only hardware barrier: the two halves never wait for each other afterwards
     if (threadIdx.x < 256) {
-        wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
+        if constexpr (WM == 0)
+            wgrad_heavy(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, stamps_all, &arrived);
+        else
+            wgrad_heavy_bf16<WM>(red, (int)blockIdx.x, X, p, dm, H1, dH1, dH2, row_blocks, rows_per_block, wpart, &arrived);
         ElectSync sy{&ecnt, 0u};
         if (DCN && gp.part) reduce_gpart(gp, red, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sy);
         if (nx.idx) {
@@ -2866,19 +2994,20 @@ static int tower_train_step(
         // change — the kernel boundaries do not wait for this data: plain stores)
         RowsAdam ad = adam ? *adam : RowsAdam{nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f, 0.f, 0};
         const int join_env = 1;            // the matrix waves join the row epilogue once their tile is stored
-        if (dcn) {
-            hipFuncSetAttribute((const void*)k_wgrad_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
-            hipLaunchKernelGGL(k_wgrad_rows<true>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
-                               ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
-                               stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);
-        } else {
-            hipFuncSetAttribute((const void*)k_wgrad_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);
-            hipLaunchKernelGGL(k_wgrad_rows<false>, dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm, ws + wl.H1,
-                               ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,
-                               stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,
-                               stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);
-        }
+        // the weight-gradient GEMMs follow the tower's mode: exact fp32 MFMA with the exact tower, split-bf16 (two parts, like
+        // the tile kernel's backward products) with the split tower, plain bf16 in the 1e-2 mode; stamped diagnostics keep fp32
+        const int wm = (!x3 || stamps) ? 0 : bf16_flag ? 1 : 2;
+#define DT_ED(DCNV, WMV)                                                                                                  \
+    do {                                                                                                                  \
+        hipFuncSetAttribute((const void*)k_wgrad_rows<DCNV, WMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsE);   \
+        hipLaunchKernelGGL((k_wgrad_rows<DCNV, WMV>), dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm,       \
+                           ws + wl.H1, ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,                \
+                           stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,                                 \
+                           stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);    \
+    } while (0)
+        if (dcn) { if (wm == 0) DT_ED(true, 0); else if (wm == 1) DT_ED(true, 1); else DT_ED(true, 2); }
+        else { if (wm == 0) DT_ED(false, 0); else if (wm == 1) DT_ED(false, 1); else DT_ED(false, 2); }
+#undef DT_ED
         trace_mark(3, st);
         if (adam && sdense) {
             // F: E' + the dense Adam + the segments + the state's advance in one launch (k_finish_step)

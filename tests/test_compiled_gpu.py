@@ -36,10 +36,10 @@ def _model(net, task='binary', seed=4, **extra):
     return dm
 
 
-def _fit(dm, df, y, spe, **kw):
+def _fit(dm, df, y, spe, epochs=3, **kw):
     torch.manual_seed(123)                      # the epoch permutations come from the device generator
     torch.cuda.manual_seed_all(123)
-    return dm.fit(df, y, batch_size=64, epochs=3, verbose=0, validation_split=0, shuffle=True,
+    return dm.fit(df, y, batch_size=64, epochs=epochs, verbose=0, validation_split=0, shuffle=True,
                   steps_per_execution=spe, **kw)
 
 
@@ -61,8 +61,15 @@ def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
         df, y = _frame(64 * 23 + 17, task=task)     # 23 steps per epoch: two replays of 10 + three eager steps
         extra = dict(cross_params={'num_cross_layer': 3}) if net == 'DCN' else {}
         eager, graphed = _model(net, task, **extra), _model(net, task, **extra)
-        h0 = _fit(eager, df, y, 1)
-        h1 = _fit(graphed, df, y, 10)
+        # The dense-gradient path (sparse False) is compared after ONE epoch: its table gradient is a float-atomics scatter whose
+        # order differs from run to run, Adam's normalisation amplifies those ulps to ~1e-6 of a weight within ~50 steps, and
+        # from then on every few runs some relu unit sits inside that noise and the two fits take different derivatives for one
+        # sample — a bimodal 1e-3 in the tables at a fixed step (tools/r6/dbg_lockstep2.py: two EAGER fits fork the same way,
+        # 0-10 times in 16 runs depending on the seed, with the fp32 and with the split-bf16 weight-gradient kernels alike).
+        # Twenty-three steps (two replays of ten + three eager steps) exercise the same loop logic below that horizon.
+        epochs = 3 if sparse else 1
+        h0 = _fit(eager, df, y, 1, epochs=epochs)
+        h1 = _fit(graphed, df, y, 10, epochs=epochs)
         assert eager.compiled_loop is None
         loop = graphed.compiled_loop
         assert loop is not None and loop.graph is not None and loop.k == 10
@@ -76,7 +83,7 @@ def test_graphed_fit_trains_like_eager_fit(dev, net, task, sparse):
         # now and then) — the row-sparse path (segments, no atomics) is held to 2e-6
         tol = 2e-6 if sparse else 5e-5
         _same(eager, graphed, tol=tol)
-        assert eager.optimizer.t == graphed.optimizer.t == 3 * 23
+        assert eager.optimizer.t == graphed.optimizer.t == epochs * 23
         assert np.allclose(h0.history['loss'], h1.history['loss'], atol=tol), (h0.history, h1.history)
         key = 'auc' if task == 'binary' else 'mse'
         assert np.allclose(h0.history[key], h1.history[key], atol=1e-5), (h0.history, h1.history)
