@@ -2242,7 +2242,8 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
                                                      DenseAdam da, AdamState* __restrict__ st, float lr, int col_blocks,
                                                      int small_blocks, int seg_blocks, FinishSeg fs, int Lc,
                                                      const float* __restrict__ cw, const float* __restrict__ cb,
-                                                     const float* __restrict__ w3c, RecSrc rs, X3Lay lay, GPart gp) {
+                                                     const float* __restrict__ w3c, RecSrc rs, X3Lay lay, GPart gp,
+                                                     const float* __restrict__ lr_snap) {
     __shared__ floatx2 sm[4][64];
     __shared__ float slin_s[kMaxC];
     const Part3 pl = part3_layout(dm.CP, Lc, 1);
@@ -2256,7 +2257,8 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
                       ? col_blocks + ((int)blockIdx.x - seg_blocks) : (int)blockIdx.x - seg_blocks - small_blocks;
     int nseg0 = 0;
     if (sb >= 0 && fs.seg.nseg) nseg0 = fs.seg.nseg[(sb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) % fs.seg.regions];
-    if (st) da.lr_t = st->lr_t;
+    // the step's rate: the copy the weight-gradient launch left (lr_snap), never the state itself — see the end of this kernel
+    if (lr_snap) da.lr_t = *lr_snap; else if (st) da.lr_t = st->lr_t;
     if (b < col_blocks) {
         bn_grads2_body(W1, gamma, beta, dm, accum, al, wpart, row_blocks, Lc, cw, cb, w3c, rs, pl, sm, slin_s, da, b, gp, lay);
     } else if (b < col_blocks + small_blocks) {
@@ -2267,8 +2269,21 @@ __global__ __launch_bounds__(256) void k_finish_step(const float* __restrict__ W
         adam_segments<true>(fs.seg, seg_blocks, nseg0, fs.table, fs.m, fs.v, fs.values, fs.D, da.lr_t, da.b1, da.b2, da.eps,
                       fs.sstride, sb);
     }
-    __syncthreads();
-    adam_finish(st, threadIdx.x == 0 ? 0u : kNoTicket, lr, da.b1, da.b2);
+    // The device step state advances HERE.  Rounds 2-5 let the last block to arrive do it (an arrival ticket per block, so
+    // that every block had read lr_t from the state before it moved): measured in round 6 (tools/r6/call14.sh, call15.sh) the
+    // 2550 tickets of this launch cost 7 us in an otherwise empty launch and 2.2-2.7 us of the step (40 arrivals queue on each
+    // of the 64 counters, and a queued returning atomic takes ~350 ns).  With the rate read from lr_snap nobody in this launch
+    // reads the state, so one thread may advance it at any time.
+    if (lr_snap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && st) {
+            const int t = st->t + 1;
+            st->t = t;
+            st->lr_t = adam_lr_t(lr, da.b1, da.b2, t);
+        }
+    } else {
+        __syncthreads();
+        adam_finish(st, threadIdx.x == 0 ? 0u : kNoTicket, lr, da.b1, da.b2);
+    }
 }
 
 // advances the dropout seed once per step (after kernel D: every reader of this step's value has finished)
@@ -2438,7 +2453,8 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
                                                     float* __restrict__ wpart, unsigned long long* stamps_all,
                                                     RowsEpi ep, RowsAdam ad, EmbDrop drop,
                                                     unsigned long long* stamps_rows, int matrix_waves_join,
-                                                    double* __restrict__ bnacc_zero, int bnacc_n, StepNext nx, GPart gp) {
+                                                    double* __restrict__ bnacc_zero, int bnacc_n, StepNext nx, GPart gp,
+                                                    float* __restrict__ lr_snap) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [4][64*128]: the matrix waves' partial macro tiles
     __shared__ unsigned arrived, work[2], ecnt;
     if (threadIdx.x == 0) { arrived = 0u; work[0] = 0u; work[1] = 0u; ecnt = 0u; }
@@ -2467,6 +2483,9 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(const float* __restrict__ X,
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
         // kernel C (the only reader of this step's BN batch sums) is done: the accumulators go back to zero for the next kernel A
         for (int j = (int)blockIdx.x * 256 + ((int)threadIdx.x - 256); j < bnacc_n; j += (int)gridDim.x * 256) bnacc_zero[j] = 0.0;
+        // the finishing launch reads the step's rate from this copy, so that ONE of its threads may advance the device state
+        // at any time (see k_finish_step: no arrival tickets)
+        if (lr_snap && blockIdx.x == 0 && threadIdx.x == 256) *lr_snap = ad.lr_t_dev ? *ad.lr_t_dev : ad.lr_t_host;
         rows_epilogue_wave<DCN>(work, (int)blockIdx.x, (int)gridDim.x, dm, ep, ad, drop);
         if (stamps_rows && threadIdx.x == 256) stamps_rows[(int64_t)blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memtime();
     }
@@ -2500,6 +2519,7 @@ struct DeepFmWs {
         gammap, x3, total;
     int64_t bnacc_n, racc_n;          // doubles
     int64_t gpart, gsum;
+    int64_t lrsnap;                   // the step's bias-corrected rate, copied by the weight-gradient launch for the finishing one
 };
 static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0: DCN with L cross layers
     DeepFmWs w;
@@ -2529,6 +2549,7 @@ static DeepFmWs deepfm_ws_layout(const DeepFmDims& dm, int L = 0) {     // L > 0
     w.dXc = take(L > 0 ? rows * dm.CP : 0);         // DCN: d loss / d Xn through the cross network (kernel C -> kernel D)
     w.dXn = take(rows * dm.CP);                     // pipelined step: dXn = dH1 . W1^T [+ the cross term] (kernel C -> the row-gradient epilogue)
     w.gammap = take(dm.CP);
+    w.lrsnap = take(4);
     // split-bf16 tower: W1B (3 bf16 parts of CP x 128) | W1R (2 parts) | W2B (3 parts of 128 x 64) | W2R (2 parts)
     w.x3 = take((5 * (int64_t)dm.CP * kH1 + 5 * (int64_t)kH1 * kH2 + 1) / 2 + (2 * kCrossMax + 1) * (int64_t)dm.CP);
     w.total = o;
@@ -3003,7 +3024,8 @@ static int tower_train_step(
         hipLaunchKernelGGL((k_wgrad_rows<DCNV, WMV>), dim3(nmac * row_blocks), dim3(512), ldsE, st, ws + wl.X, mp, dm,       \
                            ws + wl.H1, ws + wl.dH1, ws + wl.dH2, row_blocks, rows_per_block, ws + wl.wpart,                \
                            stamps ? stamps + (int64_t)tiles * 32 : nullptr, ep, ad, drop,                                 \
-                           stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt);    \
+                           stamps ? stamps + (int64_t)tiles * 16 : nullptr, join_env, bnacc, (int)wl.bnacc_n, nx, gpt,    \
+                           (adam && sdense) ? ws + wl.lrsnap : nullptr);                                               \
     } while (0)
         if (dcn) { if (wm == 0) DT_ED(true, 0); else if (wm == 1) DT_ED(true, 1); else DT_ED(true, 2); }
         else { if (wm == 0) DT_ED(false, 0); else if (wm == 1) DT_ED(false, 1); else DT_ED(false, 2); }
@@ -3024,7 +3046,7 @@ static int tower_train_step(
             // gamma / beta: this step's values as kernel C published them (other blocks of the launch update the parameters)
             hipLaunchKernelGGL(k_finish_step, dim3(dm.C + kH2 + small_blocks + seg_blocks), dim3(256), 0, st, W1, ws + wl.gammap,
                                ws + wl.betap, dm, accum, al, ws + wl.wpart, row_blocks, da, (AdamState*)sdense->state, sdense->lr,
-                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay, gpt);
+                               dm.C + kH2, small_blocks, seg_blocks, fs, Lc, cross_w, cross_b, w3, rsrc, lay, gpt, ws + wl.lrsnap);
             trace_mark(4, st);
         } else if (!skip_finish) {
             // E': slices added up, dW1 / dW2 / d w_lin finished; the record entries (db1 .. dgamma / dbeta) -> accum
