@@ -293,7 +293,7 @@ def test_roofline_fraction_follows_from_the_committed_evidence():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, 'profiles', 'r05_bench_line.json')).read())
+    line = json.loads(open(os.path.join(root, 'profiles', 'r06_bench_line.json')).read())
     rf = line['roofline']
     F, ND, D, B = 26, 13, 16, 8192
     n_dense = (F * D + ND) * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1 + 2 * (F * D + ND) + (F + ND)
@@ -305,7 +305,7 @@ def test_roofline_fraction_follows_from_the_committed_evidence():
     # the step time against the kernel-trace summary of the same command: the kernels of one step sum to the step within
     # -15 % (kernel boundaries + the replay's fixed cost are in the step, not in the sum) / +5 % (under the tracer every
     # dispatch is timed on its own: with ten steps per replay the untraced step has almost no idle time left to absorb that)
-    rows = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r05_deepfm_kernel_stats.csv'))))
+    rows = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r06_deepfm_kernel_stats.csv'))))
     stats = {r['Name'].split('(')[0].replace('void ', ''): (float(r['AverageNs']) / 1e3, int(r['Calls'])) for r in rows}
     # (per replay, not per step: the compiled loop's feed gather + its cursor advance)
     step_kernels = {k: v for k, v in stats.items() if k.startswith('dt::k_') and 'state_init' not in k and 'feed' not in k}
@@ -314,8 +314,8 @@ def test_roofline_fraction_follows_from_the_committed_evidence():
     steps = max(c for _, c in step_kernels.values())
     per_step = [k for k, (_, c) in step_kernels.items() if c == steps]
     assert len(per_step) == 4 and len(step_kernels) == 5, sorted(stats)
-    # (under this command — 100 timed steps after 2 capture + 10 warm-up steps, twenty per replay — the eager warm-up steps
-    # launch `k_prep` each: 12 + 5 replays of 112 steps; in the timed replays alone it is one launch per twenty steps)
+    # (round 6's command — 200 timed steps x 3 regions after the capture's eager steps and the warm-up replay, twenty per
+    # replay: 622 step launches, `k_prep` once per replay + once per eager step = 33)
     assert any('k_prep' in k and c * 4 <= steps for k, (_, c) in step_kernels.items())
     total = sum(us * c / steps for us, c in step_kernels.values())
     assert 0.85 * rf['launch_us'] <= total <= 1.05 * rf['launch_us'], (total, rf['launch_us'])
