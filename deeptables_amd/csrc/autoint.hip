@@ -51,6 +51,7 @@ struct AiW {
 struct AiBn {
     const float *gamma, *mean, *rstd, *sum_g, *sum_gx;   // gamma may be NULL (scale = False); mean == NULL: no BN
     float inv_n;
+    const double* sums64;                                // != NULL: sum_g | sum_gx as the doubles an AiPrev pass left ([2 D])
 };
 // optional: the BatchNormalization-backward batch sums of the layer BELOW (whose output y = BN(a_prev) is this layer's input x)
 // formed here, while this layer's dX — the gradient w.r.t. y — leaves: sum_b dX and sum_b dX xhat_prev per channel, added as
@@ -60,6 +61,36 @@ struct AiPrev {
     const float *a, *mean, *rstd;       // a == NULL: off
     double* sums;                        // [D] sum_g | [D] sum_gx
 };
+// optional: the layer's input is handed over UN-normalised — x = a_prev, the output of the interacting layer below BEFORE its
+// BatchNormalization — and normalised while it is loaded: x_used = s x + t per channel, s = rstd gamma, t = beta - mean s
+// (one fma per element; within two roundings of bn.hip k_bn_apply's (x - mean) rstd gamma + beta, and the SAME values in the
+// forward and in the backward's recomputation, which is what the relu masks need).  The normalised tensor y_prev is then never
+// written or read (27 MB each way per layer at the Criteo shape) and the layer below runs without its apply pass.  The
+// constants sit in the block's LDS (xc = [D] s | [D] t), not in registers.
+struct AiXn {
+    const float *mean, *rstd, *gamma, *beta;     // mean == NULL: off; gamma / beta may be NULL (1 / 0)
+};
+template <int D>
+__device__ __forceinline__ void ai_xn_fill(const AiXn& xn, float* xc) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float sc = xn.rstd[c] * (xn.gamma ? xn.gamma[c] : 1.f);
+        xc[c] = sc;
+        xc[D + c] = (xn.beta ? xn.beta[c] : 0.f) - xn.mean[c] * sc;
+    }
+}
+// the A operand of the projections (ai_load_x's layout: xa[T][t] = channel (D/4) q + t), normalised in place
+template <int D>
+__device__ __forceinline__ void ai_xn_rows(const float* xc, int q, float (&xa)[2][D / 4]) {
+#pragma unroll
+    for (int t = 0; t < D / 4; t += 4) {
+        const int c = (D / 4) * q + t;
+        const ai_f4 sc = *reinterpret_cast<const ai_f4*>(xc + c), sh = *reinterpret_cast<const ai_f4*>(xc + D + c);
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[T][t + e] = fmaf(xa[T][t + e], sc[e], sh[e]);
+    }
+}
 template <int D>
 __device__ __forceinline__ float ai_w(const AiW& w, int k, int m) { return w.W[m / D][k * D + (m % D)]; }
 template <int D>
@@ -285,12 +316,18 @@ template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x, AiW w4, int B, int F, int NP,
                                                      float* __restrict__ out_a, float* __restrict__ lse_out,
                                                      unsigned drop_thr, float inv_keep, unsigned seed,
-                                                     const float* __restrict__ bn_shift, float* __restrict__ bn_part) {
+                                                     const float* __restrict__ bn_shift, float* __restrict__ bn_part,
+                                                     AiXn xn) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float* ys = lds + wave * 32 * C::YS;
+    const float* xc = lds + 4 * 32 * C::YS;                 // [2 D] input-normalisation constants (AiXn)
+    if (xn.mean) {
+        ai_xn_fill<D>(xn, lds + 4 * 32 * C::YS);
+        __syncthreads();
+    }
     // BatchNormalization statistics of the layer's output (layers.py:151) ride along (bn_part != NULL): every lane owns the
     // float4 column lane % (D/4) of all the rows it stores and keeps sum / sum of squares of (a - K), K = bn_shift (the
     // moving mean: near the batch mean after a few steps, and the same for every block, so partials add up without a
@@ -317,6 +354,7 @@ __global__ __launch_bounds__(256) void k_autoint_fwd(const float* __restrict__ x
     int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
     for (; b < B; b += nwaves) {
+        if (xn.mean) ai_xn_rows<D>(xc, q, xa);              // (here, not behind the load: the prefetch must stay in flight)
         ai_project<D, BF>(xa, wr, br, NP, ys, n, q);
         if (b + nwaves < B) ai_load_x<D>(x, b + nwaves, F, n, q, xa);      // next row's operand while this one is attended
         ai_fence();
@@ -416,7 +454,11 @@ __global__ __launch_bounds__(1024) void k_autoint_bn_apply(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float momentum, float* __restrict__ moving_mean,
                                                            float* __restrict__ moving_var, float* __restrict__ save_mean,
-                                                           float* __restrict__ save_rstd, float* __restrict__ y) {
+                                                           float* __restrict__ save_rstd, float* __restrict__ y,
+                                                           double* __restrict__ zero_sums) {
+    // zero_sums [2 D] (may be NULL): the double accumulators the layer ABOVE adds this normalisation's backward sums into
+    // (AiPrev) start every step at zero — here, not in a fill launch of their own
+    if (zero_sums && blockIdx.x == 0 && threadIdx.x < 2 * D) zero_sums[threadIdx.x] = 0.0;
     __shared__ __attribute__((aligned(16))) float red[1024];
     __shared__ __attribute__((aligned(16))) float cmean[32], crstd[32], cg[32], cb[32];
     const int t = threadIdx.x, W2 = 2 * D;                  // W2 = 32 or 64 values per record
@@ -458,6 +500,7 @@ __global__ __launch_bounds__(1024) void k_autoint_bn_apply(const float* __restri
         }
     }
     __syncthreads();
+    if (!y) return;                                          // statistics only: the layer above normalises on load (AiXn)
     // the float4 column of a thread is the same in every iteration (the stride is a multiple of D/4)
     const int c4 = t & (D / 4 - 1);
     const ai_f4 m = *reinterpret_cast<const ai_f4*>(cmean + 4 * c4), r = *reinterpret_cast<const ai_f4*>(crstd + 4 * c4);
@@ -494,7 +537,7 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
                                             const float* __restrict__ g, int B, int F, int NP,
                                             float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
                                             unsigned drop_thr, float inv_keep, unsigned seed, float* __restrict__ wpart,
-                                            AiPrev pv) {
+                                            AiPrev pv, AiXn xn) {
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -510,6 +553,9 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
     float br[D / 4];
 #pragma unroll
     for (int ct = 0; ct < D / 4; ++ct) br[ct] = ai_b<D>(w4, min(16 * ct + n, M - 1));
+    const float* xc = lds + D * WS + 8 * (32 * C::YS + 96) + 8 * 2 * D;     // [2 D] input-normalisation constants (AiXn)
+    const bool xnorm = xn.mean != nullptr;
+    if (xnorm) ai_xn_fill<D>(xn, lds + D * WS + 8 * (32 * C::YS + 96) + 8 * 2 * D);
     __syncthreads();
     // BN-backward constants of this lane's 4 channels (the float4 column of the g / a loads below is lane % (D/4))
     ai_f4 bc1 = {1.f, 1.f, 1.f, 1.f}, bc2 = {0.f, 0.f, 0.f, 0.f}, bc3 = bc2, bmu = bc2;
@@ -519,8 +565,16 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
         const ai_f4 ga = bn.gamma ? *reinterpret_cast<const ai_f4*>(bn.gamma + 4 * c4) : bc1;
         bmu = *reinterpret_cast<const ai_f4*>(bn.mean + 4 * c4);
         bc1 = ga * rs;
-        bc2 = *reinterpret_cast<const ai_f4*>(bn.sum_g + 4 * c4) * bn.inv_n;
-        bc3 = rs * *reinterpret_cast<const ai_f4*>(bn.sum_gx + 4 * c4) * bn.inv_n;
+        ai_f4 sg, sgx;
+        if (bn.sums64) {                                     // (the float values a conversion launch would have left)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sg[e] = (float)bn.sums64[4 * c4 + e]; sgx[e] = (float)bn.sums64[D + 4 * c4 + e]; }
+        } else {
+            sg = *reinterpret_cast<const ai_f4*>(bn.sum_g + 4 * c4);
+            sgx = *reinterpret_cast<const ai_f4*>(bn.sum_gx + 4 * c4);
+        }
+        bc2 = sg * bn.inv_n;
+        bc3 = rs * sgx * bn.inv_n;
     }
     const float scale = 1.0f / sqrtf((float)DH);
     const int nwaves = gridDim.x * 8;
@@ -540,6 +594,7 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
     int64_t b = (int64_t)blockIdx.x * 8 + wave;
     if (b < B) ai_load_x<D>(x, b, F, n, q, xa);
     for (; b < B; b += nwaves) {
+        if (xnorm) ai_xn_rows<D>(xc, q, xa);                // (here, not behind the prefetch; its constants die before gz lives)
         // dZ rows -> LDS (rows >= F: zero), issued before the projections so the loads fly under them
         ai_f4 gz[(32 * (D / 4) + 63) / 64];
 #pragma unroll
@@ -947,8 +1002,24 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
         }
     }
     if (WG) {
-        // the eight waves' accumulators -> their slabs ([D][YS]: row d, column m), summed by the whole block
         __syncthreads();
+        float* out = wpart + (int64_t)blockIdx.x * (D * M + M);
+        constexpr int SLAB = 32 * C::YS + 96;
+        const float* s0 = lds + D * WS;
+        // bias partials first: every wave leaves its column sums in row 0 of its slab; the block's sums also stay in LDS
+        // (over the weights, dead now) for the AiXn correction below
+        ys[lane] = bacc[0];
+        ys[64 + lane] = bacc[1];
+        __syncthreads();
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s0[w * SLAB + m];
+            out[D * M + m] = v;
+            wl[m] = v;
+        }
+        __syncthreads();
+        // the eight waves' accumulators -> their slabs ([D][YS]: row d, column m), summed by the whole block
 #pragma unroll
         for (int ct = 0; ct < WT; ++ct) {
             if (16 * ct >= M) break;
@@ -958,26 +1029,16 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
                 for (int r = 0; r < 4; ++r) ys[(16 * T + 4 * q + r) * C::YS + 16 * ct + n] = wacc[T][ct][r];
         }
         __syncthreads();
-        float* out = wpart + (int64_t)blockIdx.x * (D * M + M);
-        constexpr int SLAB = 32 * C::YS + 96;
-        const float* s0 = lds + D * WS;
+        // AiXn: the accumulators hold a_prev^T dY (the x^T operand was loaded un-normalised); with x = s a_prev + t per
+        // channel (s = rstd gamma, t = beta - mean s):  x^T dY = s (a_prev^T dY) + t colsum(dY) — one correction per block
+        // partial instead of a normalisation of every operand element in the row loop
         for (int e = threadIdx.x; e < D * M; e += blockDim.x) {
             const int d = e / M, m = e - d * M;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += s0[w * SLAB + d * C::YS + m];
+            if (xnorm) v = xc[d] * v + xc[D + d] * wl[m];
             out[e] = v;
-        }
-        __syncthreads();
-        // bias partials: every wave leaves its column sums in row 0 of its slab
-        ys[lane] = bacc[0];
-        ys[64 + lane] = bacc[1];
-        __syncthreads();
-        for (int m = threadIdx.x; m < M; m += blockDim.x) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += s0[w * SLAB + m];
-            out[D * M + m] = v;
         }
     }
 }
@@ -986,21 +1047,25 @@ template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                      const float* __restrict__ g, int B, int F, int NP,
                                                      float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
-                                                     unsigned drop_thr, float inv_keep, unsigned seed, AiPrev pv) {
-    ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr, pv);
+                                                     unsigned drop_thr, float inv_keep, unsigned seed, AiPrev pv, AiXn xn) {
+    ai_bwd_body<D, DH, false, DROP, BF>(x, w4, a, g, B, F, NP, dY, dX, bn, drop_thr, inv_keep, seed, nullptr, pv, xn);
 }
 template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                        const float* __restrict__ g, int B, int F, int NP,
                                                        float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
-                                                       unsigned seed, float* __restrict__ wpart, AiPrev pv) {
-    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart, pv);
+                                                       unsigned seed, float* __restrict__ wpart, AiPrev pv, AiXn xn) {
+    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart, pv, xn);
 }
 
 // sum of the per-block partials -> the gradients of the NP Keras kernels [NP][D][D] (gW[p][k][j] = dWc[k][p D + j]) and
 // biases [NP][D]; nparts <= 256
 __global__ __launch_bounds__(1024) void k_autoint_wgrad_reduce(const float* __restrict__ wpart, int nparts, int D, int M,
-                                                               float* __restrict__ gW, float* __restrict__ gb) {
+                                                               float* __restrict__ gW, float* __restrict__ gb,
+                                                               const double* __restrict__ bn_sums64,
+                                                               float* __restrict__ bn_grads) {
+    // bn_grads [2 D] (may be NULL) = gradient of beta | gamma of the layer's BatchNormalization = the two sums as floats
+    if (bn_grads && bn_sums64 && blockIdx.x == 0 && threadIdx.x < 2 * D) bn_grads[threadIdx.x] = (float)bn_sums64[threadIdx.x];
     // a block owns 64 consecutive elements (coalesced 256-byte reads of every partial); its 16 waves split the partials
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1114,7 +1179,8 @@ static bool ai_weights(const float* const* W, const float* const* b, int NP, AiW
 
 extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr,
                               const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
-                              int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, int mfma_mode, void* stream) {
+                              int D, int H, float dropout_rate, unsigned seed, float* out_a, float* lse, const float* xn_mean,
+                              const float* xn_rstd, const float* xn_gamma, const float* xn_beta, int mfma_mode, void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_fwd: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
@@ -1127,8 +1193,10 @@ extern "C" int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, 
     unsigned thr; float inv_keep;
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_fwd: dropout_rate %f", dropout_rate);
     hipStream_t st = as_stream(stream);
-    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
-                   (const float*)nullptr, (float*)nullptr);
+    DT_REQUIRE(!xn_mean || xn_rstd, "dt_autoint_fwd: xn_mean needs xn_rstd");
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad) + 2 * D, x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
+                   (const float*)nullptr, (float*)nullptr, xn);
     return launch_status("dt_autoint_fwd");
 }
 
@@ -1137,7 +1205,8 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
                               const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                               const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
                               float* dY, float* dX, const float* prev_a, const float* prev_mean, const float* prev_rstd,
-                              double* prev_sums, int mfma_mode, void* stream) {
+                              double* prev_sums, const float* xn_mean, const float* xn_rstd, const float* xn_gamma,
+                              const float* xn_beta, int mfma_mode, void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd: unsupported shape F=%d D=%d H=%d", F, D, H);
     if (B == 0) return DT_OK;
@@ -1151,11 +1220,13 @@ extern "C" int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, 
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_bwd: dropout_rate %f", dropout_rate);
     hipStream_t st = as_stream(stream);
     DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd: incomplete BatchNormalization arguments");
-    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
+    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F), nullptr};
     DT_REQUIRE(!prev_a || (prev_mean && prev_rstd && prev_sums && dX), "dt_autoint_bwd: prev_a needs prev_mean / prev_rstd / prev_sums and dX");
     const AiPrev pv{prev_a, prev_mean, prev_rstd, prev_sums};
-    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D, x, w4, a, g, (int)B, F, NP, dY,
-                   dX, bn, thr, inv_keep, seed, pv);
+    DT_REQUIRE(!xn_mean || xn_rstd, "dt_autoint_bwd: xn_mean needs xn_rstd");
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
+    DT_AI_DISPATCH(k_autoint_bwd, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D + 2 * D, x, w4, a, g, (int)B, F, NP, dY,
+                   dX, bn, thr, inv_keep, seed, pv, xn);
     return launch_status("dt_autoint_bwd");
 }
 
@@ -1174,8 +1245,9 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
                                 const float* g, int64_t B, int F, int D, int H, float dropout_rate, unsigned seed,
                                 const float* bn_gamma, const float* bn_mean, const float* bn_rstd, const float* bn_sums,
                                 float* dX, float* gW, float* gb, void* workspace, const float* prev_a,
-                                const float* prev_mean, const float* prev_rstd, double* prev_sums, int mfma_mode,
-                                void* stream) {
+                                const float* prev_mean, const float* prev_rstd, double* prev_sums, const float* xn_mean,
+                                const float* xn_rstd, const float* xn_gamma, const float* xn_beta,
+                                const double* bn_sums_f64, float* bn_grads, int mfma_mode, void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
@@ -1186,6 +1258,7 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
     if (B == 0) {
         hipMemsetAsync(gW, 0, sizeof(float) * D * M, st);
         hipMemsetAsync(gb, 0, sizeof(float) * M, st);
+        if (bn_grads) hipMemsetAsync(bn_grads, 0, sizeof(float) * 2 * D, st);
         return launch_status("dt_autoint_bwd_w");
     }
     DT_REQUIRE(x && a && g && B > 0 && B < (1LL << 31), "dt_autoint_bwd_w: null pointer / bad batch");
@@ -1195,17 +1268,21 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
     DT_REQUIRE(ai_weights(Ws, bs, NP, &w4), "dt_autoint_bwd_w: null weight pointer");
     unsigned thr; float inv_keep;
     DT_REQUIRE(ai_drop(dropout_rate, &thr, &inv_keep), "dt_autoint_bwd_w: dropout_rate %f", dropout_rate);
-    DT_REQUIRE(!bn_mean || (bn_rstd && bn_sums), "dt_autoint_bwd_w: incomplete BatchNormalization arguments");
-    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F)};
+    DT_REQUIRE(!bn_mean || (bn_rstd && (bn_sums || bn_sums_f64)), "dt_autoint_bwd_w: incomplete BatchNormalization arguments");
+    const AiBn bn{bn_gamma, bn_mean, bn_rstd, bn_sums, bn_sums ? bn_sums + D : nullptr, 1.0f / ((float)B * (float)F),
+                  bn_mean ? bn_sums_f64 : nullptr};
+    DT_REQUIRE(!xn_mean || xn_rstd, "dt_autoint_bwd_w: xn_mean needs xn_rstd");
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
     float* wpart = static_cast<float*>(workspace);
     DT_REQUIRE(!prev_a || (prev_mean && prev_rstd && prev_sums && dX), "dt_autoint_bwd_w: prev_a needs prev_mean / prev_rstd / prev_sums and dX");
     const AiPrev pv{prev_a, prev_mean, prev_rstd, prev_sums};
-    DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D, x, w4, a, g, (int)B, F, NP,
-                   dX, bn, thr, inv_keep, seed, wpart, pv);
+    DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D + 2 * D, x, w4, a, g, (int)B, F, NP,
+                   dX, bn, thr, inv_keep, seed, wpart, pv, xn);
     int nparts = (int)((B + 7) / 8);
     if (nparts > 256) nparts = 256;
     const int total = D * M + M;
-    hipLaunchKernelGGL(k_autoint_wgrad_reduce, dim3((total + 63) / 64), dim3(1024), 0, st, wpart, nparts, D, M, gW, gb);
+    hipLaunchKernelGGL(k_autoint_wgrad_reduce, dim3((total + 63) / 64), dim3(1024), 0, st, wpart, nparts, D, M, gW, gb,
+                       bn_sums_f64, bn_grads);
     return launch_status("dt_autoint_bwd_w");
 }
 
@@ -1225,10 +1302,12 @@ extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* W
                                  const float* bq, const float* bk, const float* bv, const float* br, int64_t B, int F,
                                  int D, int H, float dropout_rate, unsigned seed, const float* gamma, const float* beta,
                                  float eps, float momentum, float* moving_mean, float* moving_var, float* out_a,
-                                 float* out_y, float* save_mean, float* save_rstd, void* workspace, int mfma_mode, void* stream) {
+                                 float* out_y, float* save_mean, float* save_rstd, void* workspace, const float* xn_mean,
+                                 const float* xn_rstd, const float* xn_gamma, const float* xn_beta, double* zero_sums,
+                                 int mfma_mode, void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_fwd_bn: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_fwd_bn: unsupported shape F=%d D=%d H=%d", F, D, H);
-    DT_REQUIRE(x && out_a && out_y && save_mean && save_rstd && workspace && B > 0 && B < (1LL << 31),
+    DT_REQUIRE(x && out_a && save_mean && save_rstd && workspace && B > 0 && B < (1LL << 31),
                "dt_autoint_fwd_bn: null pointer / bad batch");
     const int NP = Wr ? 4 : 3;
     const float* Ws[4] = {Wq, Wk, Wv, Wr};
@@ -1240,16 +1319,19 @@ extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* W
     hipStream_t st = as_stream(stream);
     float* part = static_cast<float*>(workspace);
     float* lse = nullptr;
-    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad), x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
-                   (const float*)moving_mean, part);
+    DT_REQUIRE(!xn_mean || xn_rstd, "dt_autoint_fwd_bn: xn_mean needs xn_rstd");
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
+    DT_AI_DISPATCH(k_autoint_fwd, 4, 4 * 32 * (4 * D + kAiPad) + 2 * D, x, w4, (int)B, F, NP, out_a, lse, thr, inv_keep, seed,
+                   (const float*)moving_mean, part, xn);
     int nparts = (int)((B + 3) / 4);
     if (nparts > 512) nparts = 512;
     const int64_t total4 = B * F * (D / 4);
     DT_REQUIRE(total4 < (1LL << 31), "dt_autoint_fwd_bn: tensor too large");
     int blocks = (int)((total4 + 1023) / 1024);
     if (blocks > 256) blocks = 256;
+    if (!out_y) blocks = 1;                                  // statistics only: the layer above normalises on load (xn_*)
     hipLaunchKernelGGL(k_autoint_bn_apply, dim3(blocks), dim3(1024), 0, st, out_a, (int)total4, D, part, nparts,
                        1.0f / ((float)B * (float)F), gamma, beta, eps, momentum, moving_mean, moving_var, save_mean,
-                       save_rstd, out_y);
+                       save_rstd, out_y, zero_sums);
     return launch_status("dt_autoint_fwd_bn");
 }

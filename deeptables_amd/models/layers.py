@@ -81,6 +81,8 @@ class MultiheadAttention(Layer):
         _ndim_check(x, 3)
         rate = float(self.dropout_rate) if self.training else 0.0
         projs = [self.dense_Q, self.dense_K, self.dense_V] + ([self.dense_residual] if self.use_residual else [])
+        if not (self.training and ops.autoint_supported(x, self.num_heads)):
+            x = ops.autoint_materialize(x)          # (a pending normalisation of the layer below: only the fused path takes it)
         if ops.autoint_supported(x, self.num_heads):
             # projections + attention + dropout + residual + relu in one launch per direction (csrc/autoint.hip); the
             # four Dense layers' variables are passed as they are (no concatenated copy, no gradient split)
@@ -90,7 +92,10 @@ class MultiheadAttention(Layer):
             if self.training:        # BN with batch statistics rides along: its backward is folded into the layer's
                 return ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
                                          batch_norm=(bnl.gamma, bnl.beta, bnl.moving_mean, bnl.moving_variance,
-                                                     bnl.epsilon, bnl.momentum), mfma_dtype=md)
+                                                     bnl.epsilon, bnl.momentum), mfma_dtype=md,
+                                         # set by deepnets.autoint_nets on every layer of the stack but the last: the next
+                                         # interacting layer is this output's only consumer and normalises it while loading
+                                         defer_bn=bool(getattr(self, 'feeds_interacting_layer', False)))
             outputs = ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
                                         mfma_dtype=md)
             return bnl(outputs)

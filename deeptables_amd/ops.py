@@ -635,11 +635,18 @@ class AutoIntBnLink:
     would make autograd hand it a sum — in another tensor, or added IN PLACE into dX, which moves dX's version counter: either
     way the pass runs as before)."""
 
-    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver')
+    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver', 'lazy', 'gamma', 'beta')
 
     def __init__(self):
         self.a = self.mean = self.rstd = self.sums = None
         self.dx_ptr = self.dx_ver = None
+        # lazy (autoint_layer(defer_bn=True)): the tensor handed to the layer above IS `a` — the normalisation is pending and
+        # the consumer applies it while it loads its input (csrc/autoint.hip AiXn) with gamma / beta [D] (None = 1 / 0)
+        self.lazy = False
+        self.gamma = self.beta = None
+
+    def xn_ptrs(self):
+        return (ptr(self.mean), ptr(self.rstd), ptr(self.gamma), ptr(self.beta)) if self.lazy else (None,) * 4
 
 
 class _AutoIntLayer(torch.autograd.Function):
@@ -652,8 +659,10 @@ class _AutoIntLayer(torch.autograd.Function):
     def forward(ctx, x, num_heads, dropout_rate, seed, bn, gamma, beta, mode, links, *wb):
         require_cuda(x, *wb)
         mode = int(mode)
-        ctx.link_in, ctx.link_out = links if links is not None else (None, None)
+        ctx.link_in, ctx.link_out, defer = links if links is not None else (None, None, False)
         x = _f32c(x)
+        # the layer below handed over its UN-normalised output (AutoIntBnLink.lazy): normalised while this layer loads it
+        xn = ctx.link_in.xn_ptrs() if ctx.link_in is not None else (None,) * 4
         wb = [_f32c(t) for t in wb]
         NP = len(wb) // 2
         Ws, bs = wb[:NP] + [None] * (4 - NP), wb[NP:] + [None] * (4 - NP)
@@ -662,26 +671,34 @@ class _AutoIntLayer(torch.autograd.Function):
         if bn is not None and B > 0 and os.environ.get('DT_AMD_AUTOINT_BN', 'fused') != 'separate':
             # attention + BatchNormalization in two launches: the statistics ride in the attention kernel's epilogue
             moving_mean, moving_var, eps, momentum = bn
-            y = torch.empty_like(a)
+            lk = ctx.link_out
+            defer = bool(defer) and lk is not None and F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense'
+            y = None if defer else torch.empty_like(a)
             mean = torch.empty((D,), dtype=torch.float32, device=x.device)
             rstd = torch.empty((D,), dtype=torch.float32, device=x.device)
             n = int(lib().dt_autoint_fwd_bn_workspace_bytes(B, D))
             ws = _autoint_ws(0, D, x.device, nbytes=n, tag='bn')
+            # (the link's double accumulators are zeroed by the call's second launch, not by a fill of their own)
+            sums = torch.empty(2 * D, dtype=torch.float64, device=x.device) if lk is not None else None
             check(lib().dt_autoint_fwd_bn(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
                                           float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(gamma), ptr(beta), float(eps),
                                           float(momentum), ptr(moving_mean), ptr(moving_var), ptr(a), ptr(y), ptr(mean),
-                                          ptr(rstd), ptr(ws), mode, stream_ptr()), 'dt_autoint_fwd_bn')
+                                          ptr(rstd), ptr(ws), *xn, ptr(sums), mode, stream_ptr()), 'dt_autoint_fwd_bn')
             ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, True, mode)
             ctx.save_for_backward(x, a, *wb, mean, rstd, *([gamma] if gamma is not None else []))
             ctx.has_affine = (gamma is not None, beta is not None)
-            if ctx.link_out is not None:
-                lk = ctx.link_out
+            if lk is not None:
                 lk.a, lk.mean, lk.rstd = a, mean, rstd
-                lk.sums = torch.zeros(2 * D, dtype=torch.float64, device=x.device)
+                lk.sums = sums
                 lk.dx_ptr = None
+                lk.lazy, lk.gamma, lk.beta = defer, gamma, beta
+            if defer:
+                # the output IS a: its only consumer (the interacting layer above, by the caller's promise) normalises on load;
+                # the gradient that comes back is the one w.r.t. the NORMALISED tensor, as before
+                return a
             return y
         check(lib().dt_autoint_fwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], B, F, D, num_heads,
-                                   float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, mode, stream_ptr()),
+                                   float(dropout_rate), int(seed) & 0xFFFFFFFF, ptr(a), None, *xn, mode, stream_ptr()),
               'dt_autoint_fwd')
         ctx.cfg = (num_heads, NP, float(dropout_rate), int(seed) & 0xFFFFFFFF, bn is not None, mode)
         if bn is None:
@@ -709,7 +726,8 @@ class _AutoIntLayer(torch.autograd.Function):
         Ws, bs = list(wb[:NP]) + [None] * (4 - NP), list(wb[NP:]) + [None] * (4 - NP)
         B, F, D = x.shape
         g = _f32c(g)
-        gamma = mean = rstd = sums = ggamma = gbeta = None
+        gamma = mean = rstd = sums = ggamma = gbeta = sums64 = None
+        fused_w = F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense'
         if has_bn:
             mean, rstd = saved[2 + 2 * NP], saved[3 + 2 * NP]
             gamma = saved[4 + 2 * NP] if ctx.has_affine[0] else None
@@ -717,8 +735,15 @@ class _AutoIntLayer(torch.autograd.Function):
             if lk is not None and lk.dx_ptr is not None and lk.dx_ptr == g.data_ptr() and lk.dx_ver == g._version and \
                     lk.sums is not None:
                 # the layer above formed this normalisation's backward sums while it wrote g (AutoIntBnLink): no pass over a, g
-                sums = lk.sums.to(torch.float32)
-                gbeta, ggamma = sums[:D], sums[D:]
+                if fused_w:
+                    # ... and the kernel reads the doubles as they are; the gradients of beta | gamma (the same two sums as
+                    # floats) come out of the call's reduction launch
+                    sums64 = lk.sums
+                    bn_grads = torch.empty((2 * D,), dtype=torch.float32, device=x.device)
+                    gbeta, ggamma = bn_grads[:D], bn_grads[D:]
+                else:
+                    sums = lk.sums.to(torch.float32)
+                    gbeta, ggamma = sums[:D], sums[D:]
                 lk.dx_ptr = None
             else:
                 sums = torch.empty((2 * D,), dtype=torch.float32, device=x.device)
@@ -736,7 +761,10 @@ class _AutoIntLayer(torch.autograd.Function):
         if li is not None and need_x and li.a is not None and li.sums is not None and tuple(li.a.shape) == tuple(x.shape):
             prev = (ptr(li.a), ptr(li.mean), ptr(li.rstd), ptr(li.sums))
             li.dx_ptr, li.dx_ver = gx.data_ptr(), gx._version
-        if F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense':
+        xn = li.xn_ptrs() if li is not None else (None,) * 4      # x IS a_prev, normalised on load (forward did the same)
+        if xn[0] is not None and not fused_w:
+            raise _lib.DtHipError('autoint_layer: a deferred BatchNormalization input needs the fused weight-gradient backward (F <= 28)')
+        if fused_w:
             # the kernel / bias gradients are accumulated inside the layer's backward launch (csrc/autoint.hip WG): the
             # pre-activation gradients dY [B*F, NP*D] never reach HBM and no Dense weight-gradient launch follows
             gWs = torch.empty((NP, D, D), dtype=torch.float32, device=x.device)
@@ -744,14 +772,15 @@ class _AutoIntLayer(torch.autograd.Function):
             wsw = _autoint_ws(B, D, x.device)
             check(lib().dt_autoint_bwd_w(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                          rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(gx), ptr(gWs),
-                                         ptr(gbs), ptr(wsw), *prev, mode, stream_ptr()), 'dt_autoint_bwd_w')
+                                         ptr(gbs), ptr(wsw), *prev, *xn, ptr(sums64),
+                                         ptr(bn_grads) if sums64 is not None else None, mode, stream_ptr()), 'dt_autoint_bwd_w')
             return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
                     gbeta if has_bn and ctx.has_affine[1] else None, None, None, *[gWs[i] for i in range(NP)],
                     *[gbs[i] for i in range(NP)])
         dY = torch.empty((B * F, M), dtype=torch.float32, device=x.device)
         check(lib().dt_autoint_bwd(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                    rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dY), ptr(gx),
-                                   *prev, mode, stream_ptr()), 'dt_autoint_bwd')
+                                   *prev, *xn, mode, stream_ptr()), 'dt_autoint_bwd')
         # kernel / bias gradients = x^T dY, colsum(dY): batch reductions on the Dense weight-gradient kernel (its W / y
         # arguments are unused for a linear layer without grad_x)
         buf = torch.zeros(D * M + M, dtype=torch.float32, device=x.device)
@@ -770,27 +799,62 @@ def autoint_supported(x, num_heads):
         bool(lib().dt_autoint_supported(int(x.shape[1]), int(x.shape[2]), int(num_heads)))
 
 
-def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None, mfma_dtype=None, link=True):
+def autoint_layer(x, kernels, biases, num_heads, dropout_rate=0.0, seed=0, batch_norm=None, mfma_dtype=None, link=True,
+                  defer_bn=False):
     """a = relu(multi-head field attention(relu-projections of x) [+ relu residual projection]) — layers.py:123-150.
     kernels / biases: those of dense_Q, dense_K, dense_V[, dense_residual] (3 or 4 of each; [D,D] and [D]).
     batch_norm = (gamma, beta, moving_mean, moving_var, eps, momentum): also applies the layer's training-mode
     BatchNormalization (layers.py:151) and returns BN(a).
     mfma_dtype (autoint_params['mfma_dtype']): None / 'float32' — exact fp32 MFMA; 'bf16' — north_star's 1e-2 mode: the layer's
-    projection-shaped products on the bf16 matrix cores (include/dt_hip.h DT_AI_BF16; embedding size 32 only)."""
+    projection-shaped products on the bf16 matrix cores (include/dt_hip.h DT_AI_BF16; embedding size 32 only).
+    defer_bn=True (with batch_norm): the caller's promise that the ONLY consumer of the result is another autoint_layer call —
+    the returned tensor then holds the un-normalised output, marked (`_dt_bn_link.lazy`), and that call normalises it while
+    it loads its input: the normalised tensor never exists (models/deepnets.py autoint_nets sets it for all but the last
+    layer of the stack).  autoint_materialize(y) turns such a tensor into the normalised one for any other consumer."""
     assert len(kernels) == len(biases) and len(kernels) in (3, 4)
     mode = autoint_mfma_mode(mfma_dtype, int(x.shape[-1]))
+    lazy_in = getattr(x, '_dt_bn_link', None)
+    if lazy_in is not None and lazy_in.lazy and (not link or os.environ.get('DT_AMD_AUTOINT_LINK', '1') == '0'):
+        x = autoint_materialize(x)
     if batch_norm is None:
-        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None, mode, None,
-                                   *kernels, *biases)
+        li = getattr(x, '_dt_bn_link', None)
+        return _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), None, None, None, mode,
+                                   (li, None, False) if li is not None and li.lazy else None, *kernels, *biases)
     gamma, beta, mm, mv, eps, momentum = batch_norm
     # stacked layers: the input's link (left by the layer below, when x IS its normalised output) and this layer's own
     link_in = getattr(x, '_dt_bn_link', None) if link and os.environ.get('DT_AMD_AUTOINT_LINK', '1') != '0' else None
     link_out = AutoIntBnLink() if link else None
     y = _AutoIntLayer.apply(x, int(num_heads), float(dropout_rate), int(seed), (mm, mv, float(eps), float(momentum)),
-                            gamma, beta, mode, (link_in, link_out), *kernels, *biases)
+                            gamma, beta, mode, (link_in, link_out, bool(defer_bn) and link_out is not None),
+                            *kernels, *biases)
     if link_out is not None and link_out.a is not None:
         y._dt_bn_link = link_out
     return y
+
+
+class _AutoIntMaterialize(torch.autograd.Function):
+    """a tensor whose BatchNormalization is pending (autoint_layer(defer_bn=True)) -> the normalised tensor.  The gradient
+    passes through unchanged: what flows back into the deferring layer is the gradient w.r.t. the NORMALISED tensor."""
+
+    @staticmethod
+    def forward(ctx, a, mean, rstd, gamma, beta):
+        y = (a - mean) * rstd
+        if gamma is not None:
+            y = y * gamma
+        if beta is not None:
+            y = y + beta
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None, None
+
+
+def autoint_materialize(y):
+    lk = getattr(y, '_dt_bn_link', None)
+    if lk is None or not lk.lazy:
+        return y
+    return _AutoIntMaterialize.apply(y, lk.mean, lk.rstd, lk.gamma, lk.beta)
 
 
 def autoint_mfma_mode(mfma_dtype, D):

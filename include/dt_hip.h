@@ -359,6 +359,12 @@ int dt_cin_layer_bwd_bf16x3(const float* x0, const float* xk, const float* W, co
  * y_prev = BatchNormalization(a_prev) of the interacting layer below it (deepnets.py:219-221 stacks them), the two batch sums
  * of THAT BatchNormalization's backward — sum_b dX and sum_b dX xhat_prev per channel, what dt_bn_train_bwd_stats(a_prev, dX)
  * computes — are added (doubles) into prev_sums [2 D] = sum_g | sum_gx while dX leaves; the caller zeroes prev_sums first. */
+/* xn_mean / xn_rstd / xn_gamma / xn_beta [D] (every entry point of the layer that reads x; xn_mean = NULL: off; xn_gamma /
+ * xn_beta may be NULL = 1 / 0): x is handed over UN-normalised — x = a_prev, the output of the interacting layer below BEFORE
+ * its BatchNormalization — and normalised while it is loaded, x_used = (x - mean) rstd gamma + beta.  The layer below is then
+ * called with dt_autoint_fwd_bn(out_y = NULL): its statistics are finished, its normalised output is never written.  dX stays
+ * the gradient w.r.t. the NORMALISED input (what the layer below's backward expects as g with bn_mean set); with prev_a, pass
+ * prev_a = x, prev_mean = xn_mean, prev_rstd = xn_rstd. */
 #define DT_AI_F32 0
 #define DT_AI_BF16 1
 /* DT_AI_BF16X2 (D = 32): split-bf16 — three-part operands (all 24 mantissa bits, six products) in x Wcat and its
@@ -369,35 +375,44 @@ int dt_autoint_supported(int F, int D, int H);
 unsigned dt_autoint_dropout_hash(unsigned seed, unsigned b, unsigned h, unsigned i, unsigned j);
 int dt_autoint_fwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                    const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
-                   float dropout_rate, unsigned seed, float* out_a, float* lse, int mfma_mode, void* stream);
+                   float dropout_rate, unsigned seed, float* out_a, float* lse, const float* xn_mean, const float* xn_rstd,
+                   const float* xn_gamma, const float* xn_beta, int mfma_mode, void* stream);
 int dt_autoint_bwd(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                    const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                    int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
                    const float* bn_rstd, const float* bn_sums, float* dY, float* dX, const float* prev_a, const float* prev_mean,
-                   const float* prev_rstd, double* prev_sums, int mfma_mode, void* stream);
+                   const float* prev_rstd, double* prev_sums, const float* xn_mean, const float* xn_rstd,
+                   const float* xn_gamma, const float* xn_beta, int mfma_mode, void* stream);
 /* dt_autoint_fwd_bn — dt_autoint_fwd followed by the layer's training-mode BatchNormalization (layers.py:151) in two
  * launches instead of four: the attention kernel's epilogue leaves per-block sums of (a - moving_mean) and its square, the
  * second launch adds them up in its prologue, normalises (out_y = BN(out_a)), writes save_mean / save_rstd [D] for the
  * backward and moves moving_mean / moving_var (Keras: moving = moving * momentum + batch * (1 - momentum), biased batch
- * variance).  workspace: dt_autoint_fwd_bn_workspace_bytes(B, D) bytes. */
+ * variance).  workspace: dt_autoint_fwd_bn_workspace_bytes(B, D) bytes.
+ * out_y = NULL: statistics only (one block finishes them) — for a layer whose consumer normalises on load (xn_* above).
+ * zero_sums [2 D] doubles (may be NULL): zeroed by the second launch — the accumulators the layer above will pass as prev_sums. */
 int64_t dt_autoint_fwd_bn_workspace_bytes(int64_t B, int D);
 int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                       const float* bk, const float* bv, const float* br, int64_t B, int F, int D, int H,
                       float dropout_rate, unsigned seed, const float* gamma, const float* beta, float eps, float momentum,
                       float* moving_mean, float* moving_var, float* out_a, float* out_y, float* save_mean,
-                      float* save_rstd, void* workspace, int mfma_mode, void* stream);
+                      float* save_rstd, void* workspace, const float* xn_mean, const float* xn_rstd, const float* xn_gamma,
+                      const float* xn_beta, double* zero_sums, int mfma_mode, void* stream);
 /* dt_autoint_bwd_w — the same backward with the kernel / bias gradients of dense_Q | dense_K | dense_V [| dense_residual]
  * (layers.py:104-108; in the reference: four MatMul + BiasAddGrad ops over [B*F, D]) accumulated inside the launch from the
  * pre-activation gradients while they are in LDS, plus one small reduction launch: dY never reaches HBM and no
  * dt_dense_bwd follows.  gW [NP][D][D] (the Keras kernels' layout, one after the other), gb [NP][D]: OVERWRITTEN.
- * F <= 28.  workspace: dt_autoint_bwd_workspace_bytes(B, D) bytes (per-block partials). */
+ * F <= 28.  workspace: dt_autoint_bwd_workspace_bytes(B, D) bytes (per-block partials).
+ * bn_sums_f64 [2 D] (may be NULL; then bn_sums is used): the BatchNormalization-backward sums as the DOUBLES the layer above
+ * left in its prev_sums — read as they are, no conversion launch; bn_grads [2 D] (may be NULL): the same two sums as floats =
+ * the gradients of beta | gamma, written by the reduction launch. */
 int64_t dt_autoint_bwd_workspace_bytes(int64_t B, int D);
 int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                      const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
                      int D, int H, float dropout_rate, unsigned seed, const float* bn_gamma, const float* bn_mean,
                      const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
-                     const float* prev_a, const float* prev_mean,
-                   const float* prev_rstd, double* prev_sums, int mfma_mode, void* stream);
+                     const float* prev_a, const float* prev_mean, const float* prev_rstd, double* prev_sums,
+                     const float* xn_mean, const float* xn_rstd, const float* xn_gamma, const float* xn_beta,
+                     const double* bn_sums_f64, float* bn_grads, int mfma_mode, void* stream);
 
 /* ---- input feed: batch assembly on the device (replaces `tf.data.Dataset.from_tensor_slices(...).shuffle().batch()` of
  *      utils/dataset_generator.py:36-72 for a table resident in HBM; deeptables_amd/compiled.py) -------------------- *

@@ -223,6 +223,64 @@ def test_stacked_layers_share_the_batchnorm_backward_sums(dev, B, F, H, mode):
         assert (a - b).abs().max().item() <= 1e-4 * scale, ((a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('B,F,H,mode', [(37, 26, 4, None), (64, 26, 4, 'float32'), (19, 7, 2, 'bf16'), (33, 28, 4, None)])
+def test_deferred_batchnorm_of_stacked_layers(dev, B, F, H, mode):
+    """autoint_layer(defer_bn=True): a layer whose only consumer is the next interacting layer hands over its UN-normalised
+    output and that layer normalises it while it loads its input (csrc/autoint.hip AiXn, include/dt_hip.h xn_*): the
+    normalised tensor is never written.  Three stacked layers, the lower two deferring, against the same three layers with
+    materialised normalisations: the stack's output and every gradient (input, the 24 Dense variables, gamma / beta of the
+    three normalisations) agree to 2e-5 of the tensor's largest entry (one fma instead of three roundings per loaded element;
+    the weight gradient as s a^T dY + t colsum(dY)); the moving statistics are the same; a deferred tensor that meets another
+    consumer is normalised by autoint_materialize with the same gradients."""
+    from deeptables_amd import ops
+    D, NP, L = 32, 4, 3
+    g = torch.Generator().manual_seed(B + 11 * F)
+    x = torch.randn(B, F, D, generator=g) * 0.7
+    go = torch.randn(B, F, D, generator=g)
+
+    def params():
+        gg = torch.Generator().manual_seed(5)
+        out = []
+        for _ in range(L):
+            W = torch.randn(D, NP * D, generator=gg) * (1.5 / D ** 0.5)
+            b = torch.randn(NP * D, generator=gg) * 0.2
+            Ws = [W[:, i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+            bs = [b[i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+            gamma = (torch.rand(D, generator=gg) + 0.5).to(dev).requires_grad_(True)
+            beta = (torch.randn(D, generator=gg) * 0.3).to(dev).requires_grad_(True)
+            out.append((Ws, bs, gamma, beta))
+        return out
+
+    def run(defer, foreign_consumer=False):
+        ps = params()
+        xd = x.to(dev).requires_grad_(True)
+        h, moving = xd, []
+        for l, (Ws, bs, gamma, beta) in enumerate(ps):
+            mm, mv = torch.zeros(D, device=dev), torch.ones(D, device=dev)
+            moving += [mm, mv]
+            h = ops.autoint_layer(h, Ws, bs, H, 0.0, 0, batch_norm=(gamma, beta, mm, mv, 1e-3, 0.99), mfma_dtype=mode,
+                                  defer_bn=defer and (l < L - 1 or foreign_consumer))
+            lk = getattr(h, '_dt_bn_link', None)
+            assert (lk is not None and lk.lazy) == bool(defer and (l < L - 1 or foreign_consumer))
+        if foreign_consumer:
+            h = ops.autoint_materialize(h)                   # the top layer deferred, the consumer is not an interacting layer
+        out = h.detach().clone()
+        (h * go.to(dev)).sum().backward()
+        grads = [xd.grad] + [t.grad for Ws, bs, gamma, beta in ps for t in (*Ws, *bs, gamma, beta)]
+        return out, grads, moving
+
+    ref_out, ref, ref_mov = run(False)
+    for fc in (False, True):
+        out, got, mov = run(True, foreign_consumer=fc)
+        bar = 1e-2 if mode == 'bf16' else 2e-5
+        assert (out - ref_out).abs().max().item() <= bar * ref_out.abs().max().item()
+        for a, b in zip(got, ref):
+            scale = max(b.abs().max().item(), 1e-30)
+            assert (a - b).abs().max().item() <= (2.5e-1 if mode == 'bf16' else 1e-4) * scale, ((a - b).abs().max().item(), scale)
+        for a, b in zip(mov, ref_mov):
+            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
 def test_dropout_hash_is_the_kernels(dev):
     from deeptables_amd import ops
     from deeptables_amd._lib import lib
