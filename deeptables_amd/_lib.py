@@ -84,7 +84,10 @@ SIGNATURES = {
     'dt_autoint_fwd_bn': (_c_int, [_ptr] * 9 + [_c_i64, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32, _ptr, _ptr, _c_f32, _c_f32]
                           + [_ptr] * 12 + [_c_int, _ptr]),
     'dt_autoint_fwd_bn_workspace_bytes': (_c_i64, [_c_i64, _c_int]),
-    'dt_autoint_bwd_w': (_c_int, [_ptr] * 11 + [_c_i64, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32] + [_ptr] * 18 + [_c_int, _ptr]),
+    'dt_autoint_bwd_w': (_c_int, [_ptr] * 11 + [_c_i64, _c_int, _c_int, _c_int, _c_f32, ctypes.c_uint32] + [_ptr] * 19 + [_c_int, _ptr]),
+    'dt_autoint_head_workspace_bytes': (_c_i64, [_c_i64, _c_int]),
+    'dt_autoint_head_fwd': (_c_int, [_ptr] * 7 + [_c_i64, _c_int, _c_int, _ptr, _ptr]),
+    'dt_autoint_head_bwd': (_c_int, [_ptr] * 7 + [_c_i64, _c_int, _c_int] + [_ptr] * 5),
     'dt_autoint_bwd_workspace_bytes': (_c_i64, [_c_i64, _c_int]),
     'dt_bn_train_bwd_stats': (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'dt_adam_state_init': (_c_int, [_ptr, _c_f32, _c_f32, _c_f32, _c_int, _ptr]),

@@ -118,6 +118,9 @@ class CompiledTrainLoop:
         self._sparse_refs = None
         self.logits = None          # [k, B, outputs] static: step i's logits
         self.losses = None          # [k] static (layer-by-layer path); fused plans: evaluated from the logits on demand
+        # layer-by-layer path, single process: step i's (loss, logits) are kept BY REFERENCE — the tensors the step allocated
+        # (inside a capture: in the graph's private pool, rewritten by every replay) — instead of two copy launches per step
+        self._out_refs, self._graph_out_refs, self._outputs_by_ref = {}, None, False
         self.phase_events = None    # data parallel: [(e0, e1, e2, e3)] around fwd+bwd | exchange | optimizer (bench.py)
         self._first_events = None
         self._slots_per_step = False
@@ -281,10 +284,14 @@ class CompiledTrainLoop:
         if self.logits is None:             # first (eager) step: the static outputs of the k steps
             self.logits = torch.empty((self.k,) + tuple(logit.shape), dtype=logit.dtype, device=logit.device)
             self.losses = torch.zeros(self.k, dtype=torch.float32, device=logit.device)
-        if logit.data_ptr() != self.logits[i].data_ptr():
-            self.logits[i].copy_(logit)     # layer-by-layer path / row-owned tables: the step wrote its own buffer
-        if not used_plan:
-            self.losses[i].copy_(loss.reshape(()))
+        self._outputs_by_ref = not used_plan and not self.dp
+        if self._outputs_by_ref:
+            self._out_refs[i] = (loss.detach().reshape(()), logit.detach())
+        else:
+            if logit.data_ptr() != self.logits[i].data_ptr():
+                self.logits[i].copy_(logit)     # row-owned tables / data parallel: the step wrote its own buffer
+            if not used_plan:
+                self.losses[i].copy_(loss.reshape(()))
         self._losses_from_logits = bool(used_plan)
 
     def capture(self, warm_steps=2, collect=None):
@@ -365,6 +372,7 @@ class CompiledTrainLoop:
                         torch.cuda.current_stream().wait_stream(side)
                     self._body(i, core_only=core_only, preelected=pre and i >= 1, chained=chain)
         self._slots_per_step = False        # eager steps (slot 0 buffers, their own election)
+        self._graph_out_refs = dict(self._out_refs) if self._outputs_by_ref else None
         self.graph = g
         import weakref
         self._owner = tuple(None if o is None else weakref.ref(o)
@@ -417,6 +425,8 @@ class CompiledTrainLoop:
             plan.sharded_post(self.B, self.strategy)
         elif g is not None:
             g.replay()
+            if self._graph_out_refs is not None:
+                self._out_refs = dict(self._graph_out_refs)     # (an eager remainder step may have replaced entry 0)
             if self.dp or not self.with_optimizer:
                 for layer, refs in self._sparse_refs:
                     layer.sparse_grads = {key: list(v) for key, v in refs.items()}
@@ -530,7 +540,10 @@ class CompiledTrainLoop:
 
     def _collect(self, out, k):
         n = k * self.B
-        logits = self.logits[:k]
+        by_ref = self._outputs_by_ref and all(j in self._out_refs for j in range(k))
+        need_logits = getattr(self, '_losses_from_logits', False) or out.get('want_outputs', True)
+        logits = None if not need_logits else \
+            (torch.stack([self._out_refs[j][1] for j in range(k)]) if by_ref else self.logits[:k])
         yk = wk = None
         if self.slot_y is not None:
             yk = self.slot_y[:n]
@@ -551,7 +564,7 @@ class CompiledTrainLoop:
                 per = per * wk.reshape(k, self.B).to(z.dtype)
             out['loss'].append(per.mean(-1))
         else:
-            out['loss'].append(self.losses[:k].clone())
+            out['loss'].append(torch.stack([self._out_refs[j][0] for j in range(k)]) if by_ref else self.losses[:k].clone())
         if out.get('want_outputs', True):
             out['logit'].append(logits.reshape((n,) + tuple(logits.shape[2:])).clone())
             out['y'].append(yk.clone())

@@ -537,7 +537,10 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
                                             const float* __restrict__ g, int B, int F, int NP,
                                             float* __restrict__ dY, float* __restrict__ dX, AiBn bn,
                                             unsigned drop_thr, float inv_keep, unsigned seed, float* __restrict__ wpart,
-                                            AiPrev pv, AiXn xn) {
+                                            AiPrev pv, AiXn xn, const float* __restrict__ g1w = nullptr) {
+    // g1w != NULL: the incoming gradient is RANK ONE — the layer's (normalised, flattened) output feeds a Dense(1) and nothing
+    // else, so dL/dy[b][i][c] = g[b] g1w[i D + c] with g [B] the gradient of that unit's output and g1w [F D] its kernel: formed
+    // here from one scalar and the kernel's L1-resident rows instead of a [B,F,D] tensor written and read back (54 MB)
     using C = AiCfg<D, DH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -603,7 +606,9 @@ __device__ __forceinline__ void ai_bwd_body(const float* __restrict__ x, AiW w4,
             const int i = e / (D / 4), c4 = e - i * (D / 4);
             gz[u] = ai_f4{0.f, 0.f, 0.f, 0.f};
             if (i < F) {
-                ai_f4 gv = *reinterpret_cast<const ai_f4*>(g + ((int64_t)b * F + i) * D + 4 * c4);
+                ai_f4 gv;
+                if (g1w) gv = *reinterpret_cast<const ai_f4*>(g1w + i * D + 4 * c4) * g[b];
+                else gv = *reinterpret_cast<const ai_f4*>(g + ((int64_t)b * F + i) * D + 4 * c4);
                 const ai_f4 av = *reinterpret_cast<const ai_f4*>(a + ((int64_t)b * F + i) * D + 4 * c4);
                 if (bn.mean) gv = bc1 * (gv - bc2 - (av - bmu) * bc3);
                 gz[u] = ai_f4{av.x > 0.f ? gv.x : 0.f, av.y > 0.f ? gv.y : 0.f, av.z > 0.f ? gv.z : 0.f,
@@ -1054,8 +1059,9 @@ template <int D, int DH, bool DROP, int BF = 0>
 __global__ __launch_bounds__(512) void k_autoint_bwd_w(const float* __restrict__ x, AiW w4, const float* __restrict__ a,
                                                        const float* __restrict__ g, int B, int F, int NP,
                                                        float* __restrict__ dX, AiBn bn, unsigned drop_thr, float inv_keep,
-                                                       unsigned seed, float* __restrict__ wpart, AiPrev pv, AiXn xn) {
-    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart, pv, xn);
+                                                       unsigned seed, float* __restrict__ wpart, AiPrev pv, AiXn xn,
+                                                       const float* __restrict__ g1w) {
+    ai_bwd_body<D, DH, true, DROP, BF>(x, w4, a, g, B, F, NP, nullptr, dX, bn, drop_thr, inv_keep, seed, wpart, pv, xn, g1w);
 }
 
 // sum of the per-block partials -> the gradients of the NP Keras kernels [NP][D][D] (gW[p][k][j] = dWc[k][p D + j]) and
@@ -1093,6 +1099,151 @@ __global__ __launch_bounds__(1024) void k_autoint_wgrad_reduce(const float* __re
         } else {
             gb[e - D * M] = t;
         }
+    }
+}
+
+// ---- the head of the AutoInt graph: BatchNormalization (pending: AiXn) -> Flatten -> Dense(1) (deepnets.py:222-224 +
+// deepmodel.py:131-143 `task_output` / `dense_logit_*`) without the normalised tensor -------------------------------------------
+// forward: z[b] = sum_k (s a[b][k] + t) w[k] + bias, one wave per row (four rows per wave at the Criteo shape); s, t are formed
+// once per block in LDS, a wave's share of w, s, t stays in registers
+constexpr int kAiHeadK4 = 4;            // float4 chunks per lane: K <= 1024
+__global__ __launch_bounds__(256) void k_autoint_head_fwd(const float* __restrict__ a, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, AiXn xn, int B, int K, int D,
+                                                          float* __restrict__ z) {
+    __shared__ __attribute__((aligned(16))) float cs[64], ct[64];
+    if ((int)threadIdx.x < D) {
+        const int c = threadIdx.x;
+        const float s1 = xn.rstd[c] * (xn.gamma ? xn.gamma[c] : 1.f);
+        cs[c] = s1;
+        ct[c] = (xn.beta ? xn.beta[c] : 0.f) - xn.mean[c] * s1;                          // ai_xn_fill's arithmetic
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, K4 = K >> 2, D4 = D >> 2;
+    ai_f4 wv[kAiHeadK4], sc[kAiHeadK4], sh[kAiHeadK4];
+#pragma unroll
+    for (int u = 0; u < kAiHeadK4; ++u) {
+        const int k4 = lane + 64 * u;
+        wv[u] = sc[u] = sh[u] = ai_f4{0.f, 0.f, 0.f, 0.f};
+        if (k4 < K4) {
+            wv[u] = reinterpret_cast<const ai_f4*>(w)[k4];
+            sc[u] = *reinterpret_cast<const ai_f4*>(cs + 4 * (k4 % D4));
+            sh[u] = *reinterpret_cast<const ai_f4*>(ct + 4 * (k4 % D4));
+        }
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+    const int wpb = blockDim.x >> 6;
+    for (int64_t n = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); n < B; n += (int64_t)gridDim.x * wpb) {
+        const ai_f4* ap = reinterpret_cast<const ai_f4*>(a) + n * K4;
+        ai_f4 av[kAiHeadK4];
+#pragma unroll
+        for (int u = 0; u < kAiHeadK4; ++u) av[u] = lane + 64 * u < K4 ? ap[lane + 64 * u] : ai_f4{0.f, 0.f, 0.f, 0.f};
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < kAiHeadK4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += fmaf(av[u][e], sc[u][e], sh[u][e]) * wv[u][e];
+        acc = wave_sum(acc);
+        if (lane == 0) z[n] = acc + b0;
+    }
+}
+
+// backward, launch 1: a block owns 32 rows; thread k4 accumulates R[k] = sum_rows gz[row] a[row][k] over its float4 column
+// -> part[block][K + 4] (element K: the block's sum of gz)
+constexpr int kAiHeadRows = 32;
+__global__ __launch_bounds__(256) void k_autoint_head_bwd(const float* __restrict__ a, const float* __restrict__ gz, int B,
+                                                          int K, float* __restrict__ part) {
+    __shared__ float gs[kAiHeadRows];
+    const int64_t r0 = (int64_t)blockIdx.x * kAiHeadRows;
+    const int nr = (int)(min((int64_t)B, r0 + kAiHeadRows) - r0);
+    if ((int)threadIdx.x < kAiHeadRows) gs[threadIdx.x] = (int)threadIdx.x < nr ? gz[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    float* prow = part + (int64_t)blockIdx.x * (K + 4);
+    const int K4 = K >> 2;
+    for (int k4 = threadIdx.x; k4 < K4; k4 += blockDim.x) {
+        const ai_f4* xp = reinterpret_cast<const ai_f4*>(a) + r0 * K4 + k4;
+        ai_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        int n = 0;
+        for (; n + 7 < nr; n += 8) {                         // eight 16-byte loads in flight per thread
+            ai_f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)(n + u) * K4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u] * gs[n + u];
+        }
+        for (; n < nr; ++n) acc += xp[(int64_t)n * K4] * gs[n];
+        reinterpret_cast<ai_f4*>(prow)[k4] = acc;
+    }
+    if (threadIdx.x < 64) {
+        float bsum = (int)threadIdx.x < kAiHeadRows ? gs[threadIdx.x] : 0.f;
+        bsum = wave_sum(bsum);
+        if (threadIdx.x == 0) prow[K] = bsum;
+    }
+}
+
+// backward, launch 2 (a block per 64 columns): R[k], S = sum gz from the partials (doubles); the Dense kernel's gradient
+// gW[k] = s R + t S (x = s a + t), its bias gradient S, and the two batch sums of the pending BatchNormalization's backward
+// for the rank-one gradient dL/dy = gz w:  sum_g[c] = S sum_f w[f][c],  sum_gx[c] = sum_f w[f][c] rstd_c (R[f][c] - mean_c S)
+// — ADDED into bn_sums (doubles, zero when the step starts: dt_autoint_fwd_bn's zero_sums), one atomic per block and channel
+__global__ __launch_bounds__(1024) void k_autoint_head_finish(const float* __restrict__ part, int nparts, int K, int D,
+                                                              const float* __restrict__ w, AiXn xn, float* __restrict__ gW,
+                                                              float* __restrict__ gb, double* __restrict__ bn_sums) {
+    __shared__ double red[16][64];
+    __shared__ double hS;
+    const int t = threadIdx.x, lane = t & 63, grp = t >> 6;
+    const int64_t stride = K + 4;
+    double s = 0.0;
+    for (int p = t; p < nparts; p += 1024) s += (double)part[(int64_t)p * stride + K];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (t < 64) {
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += red[g2][t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (t == 0) { hS = v; if (gb && blockIdx.x == 0) gb[0] = (float)v; }
+    }
+    __syncthreads();
+    const double S = hS;
+    const int k = blockIdx.x * 64 + lane;
+    double R = 0.0;
+    if (k < K) {
+        const float* pp = part + k;
+        int p = grp;
+        for (; p + 16 * 7 < nparts; p += 16 * 8) {           // eight loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(p + 16 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) R += (double)v[u];
+        }
+        for (; p < nparts; p += 16) R += (double)pp[(int64_t)p * stride];
+    }
+    __syncthreads();
+    red[grp][lane] = R;
+    __syncthreads();
+    double hx = 0.0, hw = 0.0;
+    if (grp == 0 && k < K) {
+        R = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) R += red[g2][lane];
+        const int c = k % D;
+        const float rs = xn.rstd[c], mu = xn.mean[c];
+        const float s1 = rs * (xn.gamma ? xn.gamma[c] : 1.f);
+        const float t1 = (xn.beta ? xn.beta[c] : 0.f) - mu * s1;
+        gW[k] = (float)((double)s1 * R + (double)t1 * S);
+        hw = (double)w[k];
+        hx = hw * (double)rs * (R - (double)mu * S);
+    }
+    __syncthreads();
+    if (grp == 0) { red[0][lane] = hw; red[1][lane] = hx; }
+    __syncthreads();
+    // the block's 64 columns are 64 / D whole fields (the block's first column is a multiple of 64, D divides 64)
+    if (t < D) {
+        double sw = 0.0, sx = 0.0;
+        for (int j = t; j < 64; j += D) { sw += red[0][j]; sx += red[1][j]; }
+        unsafeAtomicAdd(bn_sums + t, S * sw);
+        unsafeAtomicAdd(bn_sums + D + t, sx);
     }
 }
 
@@ -1247,7 +1398,8 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
                                 float* dX, float* gW, float* gb, void* workspace, const float* prev_a,
                                 const float* prev_mean, const float* prev_rstd, double* prev_sums, const float* xn_mean,
                                 const float* xn_rstd, const float* xn_gamma, const float* xn_beta,
-                                const double* bn_sums_f64, float* bn_grads, int mfma_mode, void* stream) {
+                                const double* bn_sums_f64, float* bn_grads, const float* g_rank1_w, int mfma_mode,
+                                void* stream) {
     DT_UNSUPPORTED(mfma_mode != DT_AI_F32 && !((mfma_mode == DT_AI_BF16 || mfma_mode == DT_AI_BF16X2) && D == 32), "dt_autoint_bwd_w: mfma_mode %d (DT_AI_BF16 / DT_AI_BF16X2 need D = 32; D = %d)", mfma_mode, D);
     DT_UNSUPPORTED(!dt_autoint_supported(F, D, H), "dt_autoint_bwd_w: unsupported shape F=%d D=%d H=%d", F, D, H);
     DT_UNSUPPORTED(F > 28, "dt_autoint_bwd_w: F=%d > 28 fields (use dt_autoint_bwd + dt_dense_bwd)", F);
@@ -1277,7 +1429,7 @@ extern "C" int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk
     DT_REQUIRE(!prev_a || (prev_mean && prev_rstd && prev_sums && dX), "dt_autoint_bwd_w: prev_a needs prev_mean / prev_rstd / prev_sums and dX");
     const AiPrev pv{prev_a, prev_mean, prev_rstd, prev_sums};
     DT_AI_DISPATCH(k_autoint_bwd_w, 8, D * (4 * D + kAiPad) + 8 * (32 * (4 * D + kAiPad) + 96) + 8 * 2 * D + 2 * D, x, w4, a, g, (int)B, F, NP,
-                   dX, bn, thr, inv_keep, seed, wpart, pv, xn);
+                   dX, bn, thr, inv_keep, seed, wpart, pv, xn, g_rank1_w);
     int nparts = (int)((B + 7) / 8);
     if (nparts > 256) nparts = 256;
     const int total = D * M + M;
@@ -1334,4 +1486,48 @@ extern "C" int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* W
                        1.0f / ((float)B * (float)F), gamma, beta, eps, momentum, moving_mean, moving_var, save_mean,
                        save_rstd, out_y, zero_sums);
     return launch_status("dt_autoint_fwd_bn");
+}
+
+// ---- the head of the AutoInt graph (see k_autoint_head_*): a [B, K = F D] un-normalised output of the top interacting layer,
+// xn_* its pending BatchNormalization, w [K] / bias [1] (may be NULL) the Dense(1) that consumes the flattened result
+extern "C" int64_t dt_autoint_head_workspace_bytes(int64_t B, int K) {
+    const int64_t blocks = (B + kAiHeadRows - 1) / kAiHeadRows;
+    return (blocks < 1 ? 1 : blocks) * (int64_t)(K + 4) * (int64_t)sizeof(float);
+}
+
+extern "C" int dt_autoint_head_fwd(const float* a, const float* w, const float* bias, const float* xn_mean,
+                                   const float* xn_rstd, const float* xn_gamma, const float* xn_beta, int64_t B, int K, int D,
+                                   float* z, void* stream) {
+    DT_UNSUPPORTED(K < 4 || K > 256 * kAiHeadK4 || (K & 3) || D < 4 || D > 64 || 64 % D || K % D, "dt_autoint_head_fwd: K=%d D=%d (K <= 1024, D in {4..64} dividing 64 and K)", K, D);
+    if (B == 0) return DT_OK;
+    DT_REQUIRE(a && w && z && xn_mean && xn_rstd && B > 0 && B < (1LL << 31), "dt_autoint_head_fwd: null pointer / bad batch");
+    hipStream_t st = as_stream(stream);
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
+    int blocks = (int)((B + 3) / 4);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_autoint_head_fwd, dim3(blocks), dim3(256), 0, st, a, w, bias, xn, (int)B, K, D, z);
+    return launch_status("dt_autoint_head_fwd");
+}
+
+// gz [B] = gradient of the unit's output.  gW [K], gb [1] (may be NULL): OVERWRITTEN.  bn_sums [2 D] doubles: the pending
+// normalisation's backward sums for dL/dy = gz w are ADDED (zero them first: dt_autoint_fwd_bn's zero_sums does) — pass them
+// as dt_autoint_bwd_w(bn_sums_f64 = bn_sums, g = gz, g_rank1_w = w).
+extern "C" int dt_autoint_head_bwd(const float* a, const float* w, const float* gz, const float* xn_mean,
+                                   const float* xn_rstd, const float* xn_gamma, const float* xn_beta, int64_t B, int K, int D,
+                                   float* gW, float* gb, double* bn_sums, void* workspace, void* stream) {
+    DT_UNSUPPORTED(K < 4 || K > 1024 || (K & 3) || D < 4 || D > 64 || 64 % D || K % D, "dt_autoint_head_bwd: K=%d D=%d (K <= 1024, D in {4..64} dividing 64 and K)", K, D);
+    DT_REQUIRE(gW && bn_sums && workspace && w && xn_mean && xn_rstd, "dt_autoint_head_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (B == 0) {
+        hipMemsetAsync(gW, 0, sizeof(float) * K, st);
+        if (gb) hipMemsetAsync(gb, 0, sizeof(float), st);
+        return launch_status("dt_autoint_head_bwd");
+    }
+    DT_REQUIRE(a && gz && B > 0 && B < (1LL << 31), "dt_autoint_head_bwd: null pointer / bad batch");
+    float* part = static_cast<float*>(workspace);
+    const int blocks = (int)((B + kAiHeadRows - 1) / kAiHeadRows);
+    hipLaunchKernelGGL(k_autoint_head_bwd, dim3(blocks), dim3(256), 0, st, a, gz, (int)B, K, part);
+    const AiXn xn{xn_mean, xn_rstd, xn_gamma, xn_beta};
+    hipLaunchKernelGGL(k_autoint_head_finish, dim3((K + 63) / 64), dim3(1024), 0, st, part, blocks, K, D, w, xn, gW, gb, bn_sums);
+    return launch_status("dt_autoint_head_bwd");
 }

@@ -263,6 +263,10 @@ def note_vendor_gemm(who, x_shape, w_shape):
 class Dense(Layer):
     """keras.layers.Dense: y = act(x @ kernel + bias), kernel [in, out] (glorot_uniform, zeros)."""
 
+    @property
+    def accepts_pending_norm(self):
+        return self.units == 1 and self.activation_name in (None, 'linear')
+
     def __init__(self, units, activation=None, use_bias=True, kernel_initializer='glorot_uniform',
                  bias_initializer='zeros', kernel_regularizer=None, activity_regularizer=None, **kwargs):
         super().__init__(**kwargs)
@@ -285,6 +289,14 @@ class Dense(Layer):
         """fused_activation: an activation the model's execution plan folds into this layer (Model.__init__)."""
         act_name = self.activation_name if self.activation_name not in (None, 'linear') else fused_activation
         activation = self.activation if self.activation is not None else get_activation(fused_activation)
+        lk = getattr(x, '_dt_bn_link', None)
+        if lk is not None and lk.lazy:
+            # the flattened output of an interacting layer whose BatchNormalization is pending (Model.__init__'s peephole):
+            # a linear Dense(1) takes it as it is (ops.autoint_head), anything else gets the normalised tensor
+            if self.units == 1 and act_name in (None, 'linear') and self.training and \
+                    ops.autoint_head_supported(x, self.kernel, lk):
+                return ops.autoint_head(x, self.kernel, self.bias)
+            x = ops.autoint_materialize(x)
         fused_act = act_name if act_name in (None, 'linear', 'relu') else None
         if x.is_cuda and ops.dense_supported(x, self.kernel):
             # hand-written fp32 MFMA / GEMV kernels (csrc/dense.hip); relu and bias fused
@@ -338,11 +350,17 @@ class SpatialDropout1D(Dropout):
 
 
 class Flatten(Layer):
+    passes_pending_norm = True           # (Model.__init__'s peephole: a pending BatchNormalization travels through a reshape)
+
     def compute_output_shape(self, input_shape):
         return (input_shape[0], int(np.prod(input_shape[1:])))
 
     def call(self, x, **kwargs):
-        return x.reshape(x.shape[0], -1)
+        y = x.reshape(x.shape[0], -1)
+        lk = getattr(x, '_dt_bn_link', None)
+        if lk is not None and lk.lazy:
+            y._dt_bn_link = lk
+        return y
 
 
 def _packed_view(tensors, axis):
@@ -511,6 +529,24 @@ class Model(nn.Module):
                 if len(cons) == 1 and isinstance(cons[0].layer, Activation) and cons[0].layer.activation_name == 'relu':
                     self._fused_relu.add(id(node))
                     self._passthrough.add(id(cons[0]))
+        # second peephole: a layer that can hand over its output with the trailing BatchNormalization PENDING (the AutoInt
+        # interacting layer) does so when that output has exactly one consumer and the consumer applies the normalisation while
+        # it loads its input — the next interacting layer, or (through a Flatten that feeds nothing else) a linear Dense(1): the
+        # normalised tensor is then never written (csrc/autoint.hip AiXn, k_autoint_head_*).  A consumer that cannot take the
+        # pending form at run time (inference, unsupported shape) materialises it itself.
+        self._defer_norm = set()
+        for node in order:
+            if not getattr(node.layer, 'can_defer_output_norm', False) or isinstance(node.outputs, list) or \
+                    id(node.outputs) in outs:
+                continue
+            cons = consumers.get(id(node.outputs), [])
+            if len(cons) == 1 and getattr(cons[0].layer, 'passes_pending_norm', False) and \
+                    not isinstance(cons[0].outputs, list) and id(cons[0].outputs) not in outs and \
+                    not isinstance(cons[0].inputs, (list, tuple)):
+                cons = consumers.get(id(cons[0].outputs), [])
+            if len(cons) == 1 and getattr(cons[0].layer, 'accepts_pending_norm', False) and \
+                    not isinstance(cons[0].inputs, (list, tuple)) and id(cons[0]) not in self._fused_relu:
+                self._defer_norm.add(id(node))
 
     @property
     def input(self):
@@ -547,6 +583,8 @@ class Model(nn.Module):
                 out = fetch(node.inputs)                      # its relu already ran inside the producing Dense
             elif id(node) in self._fused_relu:
                 out = node.layer(fetch(node.inputs), fused_activation='relu')
+            elif id(node) in self._defer_norm:
+                out = node.layer(fetch(node.inputs), defer_bn=True)
             else:
                 out = node.layer(fetch(node.inputs))
             if isinstance(node.outputs, list):

@@ -123,14 +123,9 @@ def autoint_nets(w):
     stack = w.fields('concat_autoint_embedding')
     if stack is None:
         return w.absent('autoint')
-    x, made = stack, []
+    x = stack
     for _ in range(w.config.autoint_params['num_attention']):
-        made.append(layers.MultiheadAttention(params=w.config.autoint_params))
-        x = made[-1](x)
-    for below in made[:-1]:
-        # its output has ONE consumer, the interacting layer above: that layer applies the BatchNormalization while it loads
-        # its input and the normalised tensor is never written (ops.autoint_layer defer_bn)
-        below.feeds_interacting_layer = True
+        x = layers.MultiheadAttention(params=w.config.autoint_params)(x)
     return w.note('autoint', stack, Flatten()(x))
 
 

@@ -77,7 +77,11 @@ class MultiheadAttention(Layer):
             raise ValueError(f'Wrong dimensions of inputs, expected 3 but input {len(input_shape)}.')
         return tuple(input_shape)
 
-    def call(self, x, **kwargs):
+    # functional.Model's peephole: the trailing BatchNormalization may stay pending for a consumer that applies it on load
+    can_defer_output_norm = True
+    accepts_pending_norm = True
+
+    def call(self, x, defer_bn=False, **kwargs):
         _ndim_check(x, 3)
         rate = float(self.dropout_rate) if self.training else 0.0
         projs = [self.dense_Q, self.dense_K, self.dense_V] + ([self.dense_residual] if self.use_residual else [])
@@ -93,9 +97,9 @@ class MultiheadAttention(Layer):
                 return ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
                                          batch_norm=(bnl.gamma, bnl.beta, bnl.moving_mean, bnl.moving_variance,
                                                      bnl.epsilon, bnl.momentum), mfma_dtype=md,
-                                         # set by deepnets.autoint_nets on every layer of the stack but the last: the next
-                                         # interacting layer is this output's only consumer and normalises it while loading
-                                         defer_bn=bool(getattr(self, 'feeds_interacting_layer', False)))
+                                         # (functional.Model's peephole: the output's only consumer — the next interacting
+                                         # layer, or Flatten -> Dense(1) — normalises it while loading)
+                                         defer_bn=bool(defer_bn))
             outputs = ops.autoint_layer(x, [p.kernel for p in projs], [p.bias for p in projs], self.num_heads, rate, seed,
                                         mfma_dtype=md)
             return bnl(outputs)

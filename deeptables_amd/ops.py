@@ -635,7 +635,7 @@ class AutoIntBnLink:
     would make autograd hand it a sum — in another tensor, or added IN PLACE into dX, which moves dX's version counter: either
     way the pass runs as before)."""
 
-    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver', 'lazy', 'gamma', 'beta')
+    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver', 'lazy', 'gamma', 'beta', 'rank1')
 
     def __init__(self):
         self.a = self.mean = self.rstd = self.sums = None
@@ -644,6 +644,9 @@ class AutoIntBnLink:
         # the consumer applies it while it loads its input (csrc/autoint.hip AiXn) with gamma / beta [D] (None = 1 / 0)
         self.lazy = False
         self.gamma = self.beta = None
+        # rank1 = (gz [B], w [F D]) left by autoint_head's backward: the gradient w.r.t. the normalised output is gz w — the
+        # tensor autograd hands over (address dx_ptr) is then an unwritten placeholder and must never be read
+        self.rank1 = None
 
     def xn_ptrs(self):
         return (ptr(self.mean), ptr(self.rstd), ptr(self.gamma), ptr(self.beta)) if self.lazy else (None,) * 4
@@ -690,7 +693,7 @@ class _AutoIntLayer(torch.autograd.Function):
             if lk is not None:
                 lk.a, lk.mean, lk.rstd = a, mean, rstd
                 lk.sums = sums
-                lk.dx_ptr = None
+                lk.dx_ptr = lk.rank1 = None
                 lk.lazy, lk.gamma, lk.beta = defer, gamma, beta
             if defer:
                 # the output IS a: its only consumer (the interacting layer above, by the caller's promise) normalises on load;
@@ -726,14 +729,21 @@ class _AutoIntLayer(torch.autograd.Function):
         Ws, bs = list(wb[:NP]) + [None] * (4 - NP), list(wb[NP:]) + [None] * (4 - NP)
         B, F, D = x.shape
         g = _f32c(g)
-        gamma = mean = rstd = sums = ggamma = gbeta = sums64 = None
+        gamma = mean = rstd = sums = ggamma = gbeta = sums64 = g1w = None
         fused_w = F <= 28 and os.environ.get('DT_AMD_AUTOINT_WGRAD', 'fused') != 'dense'
         if has_bn:
             mean, rstd = saved[2 + 2 * NP], saved[3 + 2 * NP]
             gamma = saved[4 + 2 * NP] if ctx.has_affine[0] else None
             lk = ctx.link_out
-            if lk is not None and lk.dx_ptr is not None and lk.dx_ptr == g.data_ptr() and lk.dx_ver == g._version and \
-                    lk.sums is not None:
+            linked = lk is not None and lk.dx_ptr is not None and lk.dx_ptr == g.data_ptr() and lk.dx_ver == g._version and \
+                lk.sums is not None
+            if lk is not None and lk.rank1 is not None:
+                # autoint_head's backward: g is an unwritten placeholder, the gradient is gz[b] w[i D + c] (formed in the kernel)
+                if not (linked and fused_w):
+                    raise _lib.DtHipError('autoint_layer: the rank-one gradient of autoint_head did not reach its layer unchanged')
+                g, g1w = lk.rank1
+                lk.rank1 = None
+            if linked:
                 # the layer above formed this normalisation's backward sums while it wrote g (AutoIntBnLink): no pass over a, g
                 if fused_w:
                     # ... and the kernel reads the doubles as they are; the gradients of beta | gamma (the same two sums as
@@ -773,7 +783,8 @@ class _AutoIntLayer(torch.autograd.Function):
             check(lib().dt_autoint_bwd_w(ptr(x), *[ptr(t) for t in Ws], *[ptr(t) for t in bs], ptr(a), ptr(g), B, F, D, H,
                                          rate, seed, ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(gx), ptr(gWs),
                                          ptr(gbs), ptr(wsw), *prev, *xn, ptr(sums64),
-                                         ptr(bn_grads) if sums64 is not None else None, mode, stream_ptr()), 'dt_autoint_bwd_w')
+                                         ptr(bn_grads) if sums64 is not None else None, ptr(g1w), mode, stream_ptr()),
+                  'dt_autoint_bwd_w')
             return (gx, None, None, None, None, ggamma if has_bn and ctx.has_affine[0] else None,
                     gbeta if has_bn and ctx.has_affine[1] else None, None, None, *[gWs[i] for i in range(NP)],
                     *[gbs[i] for i in range(NP)])
@@ -854,7 +865,60 @@ def autoint_materialize(y):
     lk = getattr(y, '_dt_bn_link', None)
     if lk is None or not lk.lazy:
         return y
+    D = int(lk.mean.numel())
+    if y.shape[-1] != D:                                          # flattened [B, F D]: the channel is the fastest index
+        return _AutoIntMaterialize.apply(y.reshape(-1, D), lk.mean, lk.rstd, lk.gamma, lk.beta).reshape(y.shape)
     return _AutoIntMaterialize.apply(y, lk.mean, lk.rstd, lk.gamma, lk.beta)
+
+
+class _AutoIntHead(torch.autograd.Function):
+    """BatchNormalization (pending) -> Flatten -> Dense(1): the head of the AutoInt graph (deepnets.py:222-224, deepmodel.py:
+    131-143) on the top interacting layer's UN-normalised output (csrc/autoint.hip k_autoint_head_*).  Backward: the Dense
+    kernel / bias gradients and the normalisation's two backward sums (into the link's double buffer); the gradient w.r.t. the
+    normalised tensor is rank one — gz[b] w[k] — and is NOT written: the link carries (gz, w) to the layer's backward kernel,
+    autograd carries an unwritten placeholder whose address the layer checks."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, lk):
+        require_cuda(x, kernel)
+        B, K = x.shape
+        D = int(lk.mean.numel())
+        z = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+        check(lib().dt_autoint_head_fwd(ptr(x), ptr(kernel), ptr(bias), *lk.xn_ptrs(), B, K, D, ptr(z), stream_ptr()),
+              'dt_autoint_head_fwd')
+        ctx.save_for_backward(x, kernel)
+        ctx.lk, ctx.has_bias = lk, bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, kernel = ctx.saved_tensors
+        lk = ctx.lk
+        B, K = x.shape
+        D = int(lk.mean.numel())
+        gz = _f32c(gz).reshape(-1)
+        gW = torch.empty_like(kernel)
+        gb = torch.empty((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws = _autoint_ws(0, D, x.device, nbytes=int(lib().dt_autoint_head_workspace_bytes(B, K)), tag='head')
+        check(lib().dt_autoint_head_bwd(ptr(x), ptr(kernel), ptr(gz), *lk.xn_ptrs(), B, K, D, ptr(gW), ptr(gb), ptr(lk.sums),
+                                        ptr(ws), stream_ptr()), 'dt_autoint_head_bwd')
+        gx = torch.empty_like(x)                                  # placeholder: never written, never read (lk.rank1)
+        lk.dx_ptr, lk.dx_ver, lk.rank1 = gx.data_ptr(), gx._version, (gz, kernel)
+        return gx, gW, gb, None
+
+
+def autoint_head_supported(x, kernel, lk):
+    K = int(x.shape[-1]) if x.dim() == 2 else 0
+    return bool(x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and lk is not None and lk.lazy and
+                lk.sums is not None and lk.a is not None and x.data_ptr() == lk.a.data_ptr() and
+                tuple(kernel.shape) == (K, 1) and 4 <= K <= 1024 and K % 4 == 0 and K % int(lk.mean.numel()) == 0 and
+                int(lk.a.shape[1]) <= 28)
+
+
+def autoint_head(x, kernel, bias):
+    """x: the FLATTENED output of autoint_layer(defer_bn=True) (its `_dt_bn_link` carried along); kernel [K, 1], bias [1] / None
+    of the Dense(1) that consumes it -> z [B, 1]."""
+    return _AutoIntHead.apply(x, kernel, bias, x._dt_bn_link)
 
 
 def autoint_mfma_mode(mfma_dtype, D):

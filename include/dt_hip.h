@@ -404,7 +404,9 @@ int dt_autoint_fwd_bn(const float* x, const float* Wq, const float* Wk, const fl
  * F <= 28.  workspace: dt_autoint_bwd_workspace_bytes(B, D) bytes (per-block partials).
  * bn_sums_f64 [2 D] (may be NULL; then bn_sums is used): the BatchNormalization-backward sums as the DOUBLES the layer above
  * left in its prev_sums — read as they are, no conversion launch; bn_grads [2 D] (may be NULL): the same two sums as floats =
- * the gradients of beta | gamma, written by the reduction launch. */
+ * the gradients of beta | gamma, written by the reduction launch.
+ * g_rank1_w [F D] (may be NULL): the incoming gradient is rank one — g is then [B] (one value per batch row) and
+ * dL/dy[b][i][c] = g[b] g_rank1_w[i D + c]: the layer's flattened output feeds a single Dense(1) (dt_autoint_head_*). */
 int64_t dt_autoint_bwd_workspace_bytes(int64_t B, int D);
 int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wr, const float* bq,
                      const float* bk, const float* bv, const float* br, const float* a, const float* g, int64_t B, int F,
@@ -412,7 +414,20 @@ int dt_autoint_bwd_w(const float* x, const float* Wq, const float* Wk, const flo
                      const float* bn_rstd, const float* bn_sums, float* dX, float* gW, float* gb, void* workspace,
                      const float* prev_a, const float* prev_mean, const float* prev_rstd, double* prev_sums,
                      const float* xn_mean, const float* xn_rstd, const float* xn_gamma, const float* xn_beta,
-                     const double* bn_sums_f64, float* bn_grads, int mfma_mode, void* stream);
+                     const double* bn_sums_f64, float* bn_grads, const float* g_rank1_w, int mfma_mode, void* stream);
+/* dt_autoint_head_* — the head of the AutoInt graph, BatchNormalization(top interacting layer) -> Flatten -> Dense(1)
+ * (deepnets.py:222-224, deepmodel.py:131-143 `task_output` / `dense_logit_*`), without the normalised tensor: a [B, K = F D]
+ * is the top layer's UN-normalised output (dt_autoint_fwd_bn with out_y = NULL), xn_* its pending normalisation (as above),
+ * w [K] / bias [1] (may be NULL) the Dense(1).  fwd: z [B] = (s a + t) . w + bias.  bwd: gz [B] = gradient w.r.t. z; gW [K],
+ * gb [1] (may be NULL): OVERWRITTEN; bn_sums [2 D] doubles: the two batch sums of the pending normalisation's backward for
+ * dL/dy = gz w are ADDED (zero before the step: dt_autoint_fwd_bn's zero_sums) — the top layer's backward is then dt_autoint_bwd_w(g = gz, g_rank1_w = w, bn_sums_f64 = bn_sums) and no
+ * [B,F,D] gradient tensor exists.  K <= 1024, D divides 64 and K; workspace: dt_autoint_head_workspace_bytes(B, K) bytes. */
+int64_t dt_autoint_head_workspace_bytes(int64_t B, int K);
+int dt_autoint_head_fwd(const float* a, const float* w, const float* bias, const float* xn_mean, const float* xn_rstd,
+                        const float* xn_gamma, const float* xn_beta, int64_t B, int K, int D, float* z, void* stream);
+int dt_autoint_head_bwd(const float* a, const float* w, const float* gz, const float* xn_mean, const float* xn_rstd,
+                        const float* xn_gamma, const float* xn_beta, int64_t B, int K, int D, float* gW, float* gb,
+                        double* bn_sums, void* workspace, void* stream);
 
 /* ---- input feed: batch assembly on the device (replaces `tf.data.Dataset.from_tensor_slices(...).shuffle().batch()` of
  *      utils/dataset_generator.py:36-72 for a table resident in HBM; deeptables_amd/compiled.py) -------------------- *

@@ -281,6 +281,65 @@ def test_deferred_batchnorm_of_stacked_layers(dev, B, F, H, mode):
             assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize('B,F,H,mode,bias', [(41, 26, 4, None, True), (100, 26, 4, 'float32', False), (23, 9, 2, 'bf16', True)])
+def test_autoint_head_takes_the_pending_normalisation_and_hands_back_a_rank_one_gradient(dev, B, F, H, mode, bias):
+    """BatchNormalization -> Flatten -> Dense(1) on top of the interacting stack (deepnets.py:222-224, deepmodel.py:131-143):
+    ops.autoint_head reads the top layer's UN-normalised output, and its backward leaves the Dense gradients, the
+    normalisation's two backward sums and a RANK-ONE gradient (gz, w) for the layer's backward kernel — no [B,F,D] gradient
+    tensor is written.  Against the materialised path (normalised tensor, matmul): logits to 2e-5, every gradient to 1e-4 of
+    its largest entry."""
+    from deeptables_amd import ops
+    D, NP, L = 32, 4, 2
+    g = torch.Generator().manual_seed(3 * B + F)
+    x = torch.randn(B, F, D, generator=g) * 0.7
+    gz = torch.randn(B, 1, generator=g)
+    kern = (torch.randn(F * D, 1, generator=g) * 0.1)
+    b0 = torch.randn(1, generator=g) if bias else None
+
+    def params():
+        gg = torch.Generator().manual_seed(17)
+        out = []
+        for _ in range(L):
+            W = torch.randn(D, NP * D, generator=gg) * (1.5 / D ** 0.5)
+            b = torch.randn(NP * D, generator=gg) * 0.2
+            Ws = [W[:, i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+            bs = [b[i * D:(i + 1) * D].contiguous().to(dev).requires_grad_(True) for i in range(NP)]
+            gamma = (torch.rand(D, generator=gg) + 0.5).to(dev).requires_grad_(True)
+            beta = (torch.randn(D, generator=gg) * 0.3).to(dev).requires_grad_(True)
+            out.append((Ws, bs, gamma, beta))
+        return out
+
+    def run(head):
+        ps = params()
+        xd = x.to(dev).requires_grad_(True)
+        kd = kern.to(dev).requires_grad_(True)
+        bd = b0.to(dev).requires_grad_(True) if bias else None
+        h = xd
+        for Ws, bs, gamma, beta in ps:
+            bn = (gamma, beta, torch.zeros(D, device=dev), torch.ones(D, device=dev), 1e-3, 0.99)
+            h = ops.autoint_layer(h, Ws, bs, H, 0.0, 0, batch_norm=bn, mfma_dtype=mode, defer_bn=head)
+        if head:
+            flat = h.reshape(B, -1)
+            flat._dt_bn_link = h._dt_bn_link
+            assert ops.autoint_head_supported(flat, kd, flat._dt_bn_link)
+            z = ops.autoint_head(flat, kd, bd)
+        else:
+            z = h.reshape(B, -1) @ kd
+            if bias:
+                z = z + bd
+        (z * gz.to(dev)).sum().backward()
+        grads = [xd.grad, kd.grad] + ([bd.grad] if bias else []) + \
+            [t.grad for Ws, bs, gamma, beta in ps for t in (*Ws, *bs, gamma, beta)]
+        return z.detach(), grads
+
+    zr, ref = run(False)
+    zh, got = run(True)
+    assert (zh - zr).abs().max().item() <= (1e-2 if mode == 'bf16' else 2e-5) * max(1.0, zr.abs().max().item())
+    for a, b in zip(got, ref):
+        scale = max(b.abs().max().item(), 1e-30)
+        assert (a - b).abs().max().item() <= (2.5e-1 if mode == 'bf16' else 1e-4) * scale, ((a - b).abs().max().item(), scale)
+
+
 def test_dropout_hash_is_the_kernels(dev):
     from deeptables_amd import ops
     from deeptables_amd._lib import lib

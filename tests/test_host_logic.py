@@ -228,3 +228,33 @@ def test_bench_gpus_flag_must_match_the_launcher():
     r = _run_bench(['--gpus', '4'], {'DT_BENCH_SPAWN_PROBE': '1', 'WORLD_SIZE': '2', 'RANK': '0'}, timeout=120)
     assert r.returncode != 0
     assert 'WORLD_SIZE=2' in (r.stderr + r.stdout)
+
+
+def test_model_peephole_defers_the_interacting_layers_normalisation_only_for_consumers_that_take_it():
+    """functional.Model.__init__: an AutoInt interacting layer hands over its output with the BatchNormalization pending when
+    that output has ONE consumer which applies it on load — the next interacting layer, or Flatten -> linear Dense(1)
+    (deepnets.py:219-224, deepmodel.py:131-143) — and never otherwise (a second consumer, a model output, a wider Dense)."""
+    import torch
+    from deeptables_amd import functional as K
+    from deeptables_amd.models import layers
+
+    def stack(tail):
+        inp = K.Input(shape=(6, 32), name='x')
+        a = layers.MultiheadAttention(params={'num_heads': 4}, name='att_a')(inp)
+        b = layers.MultiheadAttention(params={'num_heads': 4}, name='att_b')(a)
+        return inp, a, b, tail(a, b)
+
+    def deferred(model):
+        return sorted(n.layer.name for n in model.nodes if id(n) in model._defer_norm)
+
+    inp, a, b, out = stack(lambda a, b: K.Dense(1, name='out')(K.Flatten(name='fl')(b)))
+    assert deferred(K.Model(inputs=[inp], outputs=out)) == ['att_a', 'att_b']
+    inp, a, b, out = stack(lambda a, b: K.Dense(1, activation='relu', name='out')(K.Flatten(name='fl')(b)))
+    assert deferred(K.Model(inputs=[inp], outputs=out)) == ['att_a']                       # a relu unit is not the linear head
+    inp, a, b, out = stack(lambda a, b: K.Dense(3, name='out')(K.Flatten(name='fl')(b)))
+    assert deferred(K.Model(inputs=[inp], outputs=out)) == ['att_a']                       # neither is a wider Dense
+    inp, a, b, out = stack(lambda a, b: K.Add(name='add')([K.Dense(1, name='o1')(K.Flatten(name='f1')(b)),
+                                                          K.Dense(1, name='o2')(K.Flatten(name='f2')(a))]))
+    assert deferred(K.Model(inputs=[inp], outputs=out)) == ['att_b']                       # att_a's output has two consumers
+    inp, a, b, out = stack(lambda a, b: b)
+    assert deferred(K.Model(inputs=[inp], outputs=out)) == ['att_a']                       # a model output stays normalised
