@@ -142,6 +142,21 @@ def test_layer_by_layer_graph_is_capturable_on_request(dev):
     assert np.allclose(h0.history['loss'], h1.history['loss'], atol=5e-6)
 
 
+def test_autoint_graph_with_pending_normalisations_is_capturable(dev):
+    """the AutoInt graph — interacting layers whose BatchNormalization stays pending for the consumer (functional.Model's
+    peephole: layer -> layer, layer -> Flatten -> Dense(1) with the rank-one gradient) — through the captured loop: same
+    weights and loss curve as the eager fit, remainder steps included (12 steps per epoch, five per replay)"""
+    att = dict(autoint_params={'num_attention': 2, 'num_heads': 2, 'dropout_rate': 0, 'use_residual': True})
+    df, y = _frame(64 * 12)
+    eager, graphed = _model('AutoInt', **att), _model('AutoInt', **att)
+    assert len(graphed.model._defer_norm) == 2
+    h0 = _fit(eager, df, y, 1, epochs=2)
+    h1 = _fit(graphed, df, y, 5, epochs=2)
+    assert graphed.compiled_loop is not None and graphed.compiled_loop.graph is not None
+    _same(eager, graphed, tol=5e-6)
+    assert np.allclose(h0.history['loss'], h1.history['loss'], atol=5e-6)
+
+
 def test_compiled_loop_on_a_device_feed_reuses_its_graph(dev):
     """bench.py's use: `fit(feed)` on a ready device-resident TableBatches; the second call replays the first call's graph"""
     from deeptables_amd.training import TableBatches
