@@ -340,6 +340,28 @@ def test_autoint_head_takes_the_pending_normalisation_and_hands_back_a_rank_one_
         assert (a - b).abs().max().item() <= (2.5e-1 if mode == 'bf16' else 1e-4) * scale, ((a - b).abs().max().item(), scale)
 
 
+def test_rank_one_gradient_that_meets_a_second_consumer_raises(dev):
+    """ops.autoint_head hands autograd an UNWRITTEN placeholder as the gradient of the pending-normalisation tensor; the layer
+    accepts the rank-one form only if that placeholder arrives unchanged.  A second consumer of the tensor makes autograd sum
+    the placeholder with another gradient: the layer must refuse (DtHipError), not train on uninitialised memory."""
+    from deeptables_amd import ops
+    from deeptables_amd._lib import DtHipError
+    B, F, D, H = 16, 6, 32, 4
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(B, F, D, generator=g) * 0.5).to(dev).requires_grad_(True)
+    Ws = [(torch.randn(D, D, generator=g) * 0.2).to(dev).requires_grad_(True) for _ in range(4)]
+    bs = [torch.zeros(D, device=dev, requires_grad=True) for _ in range(4)]
+    gamma, beta = torch.ones(D, device=dev, requires_grad=True), torch.zeros(D, device=dev, requires_grad=True)
+    bn = (gamma, beta, torch.zeros(D, device=dev), torch.ones(D, device=dev), 1e-3, 0.99)
+    h = ops.autoint_layer(x, Ws, bs, H, 0.0, 0, batch_norm=bn, defer_bn=True)
+    flat = h.reshape(B, -1)
+    flat._dt_bn_link = h._dt_bn_link
+    kern = (torch.randn(F * D, 1, generator=g) * 0.1).to(dev).requires_grad_(True)
+    loss = ops.autoint_head(flat, kern, None).sum() + (ops.autoint_materialize(h) * 0.1).sum()
+    with pytest.raises(DtHipError):
+        loss.backward()
+
+
 def test_dropout_hash_is_the_kernels(dev):
     from deeptables_amd import ops
     from deeptables_amd._lib import lib
