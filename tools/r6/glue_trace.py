@@ -43,7 +43,7 @@ def main():
             if name.startswith('dt::') or 'dt::k_' in name:
                 continue
             frames = [f for f in (e.stack or []) if 'deeptables_amd' in f or 'bench.py' in f][:4]
-            key = (name[:70], e.name, tuple(shape_str(s) for s in (e.input_shapes or [])[:3]), tuple(frames))
+            key = (name[:70], e.name, tuple(str(s) for s in (e.input_shapes or [])[:3]), tuple(frames))
             agg[key] += 1
             dur[key] += k.duration
     print(f'== {model}: non-library device kernels of {steps} eager steps, by launching op and deeptables_amd frames')
@@ -53,9 +53,6 @@ def main():
         for f in frames:
             print('          ', f)
 
-
-def shape_str(s):
-    return str(s)
 
 
 def bench_step(dm, b):
