@@ -635,7 +635,7 @@ class AutoIntBnLink:
     would make autograd hand it a sum — in another tensor, or added IN PLACE into dX, which moves dX's version counter: either
     way the pass runs as before)."""
 
-    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver', 'lazy', 'gamma', 'beta', 'rank1')
+    __slots__ = ('a', 'mean', 'rstd', 'sums', 'dx_ptr', 'dx_ver', 'lazy', 'gamma', 'beta', 'rank1', 'dirty')
 
     def __init__(self):
         self.a = self.mean = self.rstd = self.sums = None
@@ -647,6 +647,15 @@ class AutoIntBnLink:
         # rank1 = (gz [B], w [F D]) left by autoint_head's backward: the gradient w.r.t. the normalised output is gz w — the
         # tensor autograd hands over (address dx_ptr) is then an unwritten placeholder and must never be read
         self.rank1 = None
+        # the sums are ADDED into by the consumer's backward and start at zero with every forward (the forward's second launch
+        # zeroes them): a second backward over the same forward (retain_graph) finds them dirty and zeroes them itself
+        self.dirty = False
+
+    def sums_for_adding(self):
+        if self.dirty:
+            self.sums.zero_()
+        self.dirty = True
+        return ptr(self.sums)
 
     def xn_ptrs(self):
         return (ptr(self.mean), ptr(self.rstd), ptr(self.gamma), ptr(self.beta)) if self.lazy else (None,) * 4
@@ -694,6 +703,7 @@ class _AutoIntLayer(torch.autograd.Function):
                 lk.a, lk.mean, lk.rstd = a, mean, rstd
                 lk.sums = sums
                 lk.dx_ptr = lk.rank1 = None
+                lk.dirty = False
                 lk.lazy, lk.gamma, lk.beta = defer, gamma, beta
             if defer:
                 # the output IS a: its only consumer (the interacting layer above, by the caller's promise) normalises on load;
@@ -769,7 +779,7 @@ class _AutoIntLayer(torch.autograd.Function):
         li = ctx.link_in
         prev = (None, None, None, None)
         if li is not None and need_x and li.a is not None and li.sums is not None and tuple(li.a.shape) == tuple(x.shape):
-            prev = (ptr(li.a), ptr(li.mean), ptr(li.rstd), ptr(li.sums))
+            prev = (ptr(li.a), ptr(li.mean), ptr(li.rstd), li.sums_for_adding())
             li.dx_ptr, li.dx_ver = gx.data_ptr(), gx._version
         xn = li.xn_ptrs() if li is not None else (None,) * 4      # x IS a_prev, normalised on load (forward did the same)
         if xn[0] is not None and not fused_w:
@@ -900,8 +910,8 @@ class _AutoIntHead(torch.autograd.Function):
         gW = torch.empty_like(kernel)
         gb = torch.empty((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
         ws = _autoint_ws(0, D, x.device, nbytes=int(lib().dt_autoint_head_workspace_bytes(B, K)), tag='head')
-        check(lib().dt_autoint_head_bwd(ptr(x), ptr(kernel), ptr(gz), *lk.xn_ptrs(), B, K, D, ptr(gW), ptr(gb), ptr(lk.sums),
-                                        ptr(ws), stream_ptr()), 'dt_autoint_head_bwd')
+        check(lib().dt_autoint_head_bwd(ptr(x), ptr(kernel), ptr(gz), *lk.xn_ptrs(), B, K, D, ptr(gW), ptr(gb),
+                                        lk.sums_for_adding(), ptr(ws), stream_ptr()), 'dt_autoint_head_bwd')
         gx = torch.empty_like(x)                                  # placeholder: never written, never read (lk.rank1)
         lk.dx_ptr, lk.dx_ver, lk.rank1 = gx.data_ptr(), gx._version, (gz, kernel)
         return gx, gW, gb, None

@@ -340,6 +340,35 @@ def test_autoint_head_takes_the_pending_normalisation_and_hands_back_a_rank_one_
         assert (a - b).abs().max().item() <= (2.5e-1 if mode == 'bf16' else 1e-4) * scale, ((a - b).abs().max().item(), scale)
 
 
+def test_second_backward_over_the_same_forward_does_not_double_the_shared_sums(dev):
+    """the BatchNormalization-backward sums two layers share are ADDED into by the consumer's backward and zeroed by the
+    producer's forward: a second backward over the same forward (retain_graph=True) must start them from zero again —
+    both passes leave the same gradients (accumulated: exactly twice the first)"""
+    from deeptables_amd import ops
+    B, F, D, H = 24, 9, 32, 4
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, F, D, generator=g) * 0.5).to(dev).requires_grad_(True)
+    ps = []
+    h = x
+    for _ in range(2):
+        Ws = [(torch.randn(D, D, generator=g) * 0.25).to(dev).requires_grad_(True) for _ in range(4)]
+        bs = [torch.zeros(D, device=dev, requires_grad=True) for _ in range(4)]
+        gamma, beta = (torch.rand(D, generator=g) + 0.5).to(dev).requires_grad_(True), torch.zeros(D, device=dev, requires_grad=True)
+        h = ops.autoint_layer(h, Ws, bs, H, 0.0, 0, batch_norm=(gamma, beta, torch.zeros(D, device=dev), torch.ones(D, device=dev), 1e-3, 0.99),
+                              defer_bn=True)
+        ps += [*Ws, *bs, gamma, beta]
+    flat = h.reshape(B, -1)
+    flat._dt_bn_link = h._dt_bn_link
+    kern = (torch.randn(F * D, 1, generator=g) * 0.1).to(dev).requires_grad_(True)
+    loss = (ops.autoint_head(flat, kern, None) * torch.randn(B, 1, generator=g).to(dev)).sum()
+    loss.backward(retain_graph=True)
+    first = [t.grad.clone() for t in (x, kern, *ps)]
+    loss.backward()
+    for a, t in zip(first, (x, kern, *ps)):
+        scale = max(a.abs().max().item(), 1e-30)
+        assert (t.grad - 2 * a).abs().max().item() <= 2e-5 * scale, ((t.grad - 2 * a).abs().max().item(), scale)
+
+
 def test_rank_one_gradient_that_meets_a_second_consumer_raises(dev):
     """ops.autoint_head hands autograd an UNWRITTEN placeholder as the gradient of the pending-normalisation tensor; the layer
     accepts the rank-one form only if that placeholder arrives unchanged.  A second consumer of the tensor makes autograd sum
